@@ -449,8 +449,9 @@ class HiTADVOracle:
         st['opt'].step()
         st['last_adv'] = adv_np
         st['last_dist'] = dist_val.detach().numpy()
-        return dict(adv_loss=adv_loss.item(), dist_loss=float(dist_loss), pred=pred_np.copy(),
-                    dist_val=st['last_dist'].copy(), loss=loss.mean().item())
+        return dict(adv_loss=adv_loss.item(), dist_loss=float(dist_loss.detach()),
+                    pred=pred_np.copy(), adv=adv_np.copy(), dist_val=st['last_dist'].copy(),
+                    loss=loss.mean().item())
 
     def prepare(self, data, target):
         """HiT_ADV.py:51-123: split, score, select centres, allocate bookkeeping."""

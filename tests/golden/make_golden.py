@@ -1,0 +1,368 @@
+"""Generate the golden fixtures in this directory from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference, CPU torch).  Imports the
+reference unmodified through ``ref_harness`` (stand-ins for absent third-party
+packages only), feeds it seeded synthetic inputs and stores inputs + outputs as
+small .npz files.  The fixtures are data; no reference source text is stored.
+
+    python tests/golden/make_golden.py
+
+Fixture index:
+  g1_set_distance.npz  chamfer / hausdorff / ChamferDist / HausdorffDist (+Q1 call)
+  g2_knn_dist.npz      KNNDist values, CurvStdDist, kappa / kappa-std
+  g3_deform.npz        kernel_density, 192-step deformation, grads wrt (P, sigma)
+  g4_fps.npz           farthest_point_sample with recorded start indices
+  g5_attack.npz        full HiT_ADV.attack trajectory with a toy victim
+  g5b_attack_wide.npz  short trajectory at eval.py sizes (N=1024, C=192, T=256)
+  g6_adv_clip.npz      adversarial losses and clip/projection operators
+  g7_cwknn.npz         CWKNN.attack trajectory with the toy victim
+  g8_state_dicts.json  state_dict key/shape lists of the victims
+"""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+
+ref_harness.install()
+
+from ShapeAttack.HiT_ADV import HiT_ADV  # noqa: E402
+from util import dist_utils, set_distance, adv_utils, clip_utils  # noqa: E402
+from CW.kNN import CWKNN  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def synth_cloud(cloud_id, n):
+    """BASELINE.md section 3 synthetic input: unit-ball gaussian cloud + unit normals."""
+    g = torch.Generator('cpu').manual_seed(1234 + cloud_id)
+    xyz = torch.randn(n, 3, generator=g)
+    xyz = xyz - xyz.mean(0, keepdim=True)
+    xyz = xyz / xyz.norm(dim=1).max()
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    label = torch.randint(0, 40, (1,), generator=g)
+    return torch.cat([xyz, nrm], 1), label
+
+
+def synth_batch(b, n, first=0):
+    cl = [synth_cloud(first + i, n) for i in range(b)]
+    return torch.stack([c[0] for c in cl]), torch.cat([c[1] for c in cl])
+
+
+class ToyVictim(torch.nn.Module):
+    """< 1K parameters; weights are stored in the fixture."""
+
+    def __init__(self, classes=40, width=16):
+        super().__init__()
+        self.conv = torch.nn.Conv1d(3, width, 1)
+        self.fc = torch.nn.Linear(width, classes)
+
+    def forward(self, x):
+        h = torch.relu(self.conv(x))
+        return self.fc(torch.max(h, 2)[0])
+
+
+def toy_victim(seed):
+    torch.manual_seed(seed)
+    m = ToyVictim()
+    with torch.no_grad():
+        m.conv.weight.mul_(3.0)
+        m.fc.weight.mul_(4.0)
+    return m.eval()
+
+
+def npify(d):
+    out = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    return out
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **npify(d))
+    print("wrote %-24s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------ G1
+def g1():
+    data, _ = synth_batch(2, 1024)
+    ori = data[:, :, :3].contiguous()
+    g = torch.Generator('cpu').manual_seed(7)
+    adv = ori + 0.02 * torch.randn(ori.shape, generator=g)
+    other, _ = synth_batch(2, 256, first=10)
+    small = other[:, :, :3].contiguous()
+    w = torch.tensor([0.3, 1.7])
+    out = dict(adv=adv, ori=ori, small=small, weights=w)
+    out['chamfer_l1'], out['chamfer_l2'] = set_distance.chamfer(adv, ori)
+    out['hausdorff_l1'], out['hausdorff_l2'] = set_distance.hausdorff(adv, ori)
+    out['chamfer_small_l1'], out['chamfer_small_l2'] = set_distance.chamfer(small, ori)
+    out['hausdorff_small_l1'], out['hausdorff_small_l2'] = set_distance.hausdorff(small, ori)
+    for m in ('adv2ori', 'ori2adv', 'both'):
+        out['ChamferDist_%s' % m] = dist_utils.ChamferDist(m)(adv, ori, w, batch_avg=False)
+        out['HausdorffDist_%s' % m] = dist_utils.HausdorffDist(m)(adv, ori, w, batch_avg=False)
+    out['ChamferDist_avg'] = dist_utils.ChamferDist()(adv, ori)
+    out['HausdorffDist_avg'] = dist_utils.HausdorffDist()(adv, ori)
+    # quirk Q1: the HiT-ADV call site passes [B,3,N] tensors (HiT_ADV.py:230)
+    out['ChamferDist_q1'] = dist_utils.ChamferDist()(adv.transpose(1, 2).contiguous(),
+                                                     ori.transpose(1, 2).contiguous(),
+                                                     torch.from_numpy(np.ones(2) * 1e-4),
+                                                     batch_avg=False)
+    # autograd through the Chamfer operator (what CW/kNN.py:104-111 back-propagates)
+    a = adv.clone().requires_grad_()
+    dist_utils.ChamferDist('both')(a, ori, w).backward()
+    out['ChamferDist_both_grad'] = a.grad
+    a = adv.clone().requires_grad_()
+    dist_utils.HausdorffDist('both')(a, ori, w).backward()
+    out['HausdorffDist_both_grad'] = a.grad
+    save('g1_set_distance.npz', out)
+
+
+# ------------------------------------------------------------------ G2
+def g2():
+    data, _ = synth_batch(2, 1024, first=2)
+    ori = data[:, :, :3].contiguous()
+    nrm = data[:, :, 3:].contiguous()
+    g = torch.Generator('cpu').manual_seed(8)
+    adv = ori + 0.01 * torch.randn(ori.shape, generator=g)
+    out = dict(ori=ori, normal=nrm, adv=adv)
+    for k in (4, 5):
+        out['KNNDist_k%d' % k] = dist_utils.KNNDist(k=k)(adv, batch_avg=False)
+        out['KNNDist_k%d_chfirst' % k] = dist_utils.KNNDist(k=k)(adv.transpose(1, 2).contiguous(),
+                                                                 batch_avg=False)
+    a = adv.clone().requires_grad_()
+    dist_utils.KNNDist(k=5)(a, torch.tensor([0.5, 2.0])).backward()
+    out['KNNDist_k5_grad'] = a.grad
+    a = adv.clone().requires_grad_()
+    dist_utils.ChamferkNNDist()(a, ori).backward()
+    out['ChamferkNNDist'] = dist_utils.ChamferkNNDist()(adv, ori, batch_avg=False)
+    out['ChamferkNNDist_grad'] = a.grad
+    ori_t, adv_t, nrm_t = (t.transpose(1, 2).contiguous() for t in (ori, adv, nrm))
+    out['CurvStdDist_k4'] = dist_utils.CurvStdDist(k=4)(ori_t, adv_t, nrm_t)
+    att = HiT_ADV.__new__(HiT_ADV)
+    out['kappa_k16'] = att._get_kappa_ori(ori_t, nrm_t, k=16)
+    out['kappa_std_k16'] = att._get_kappa_std_ori(ori_t, nrm_t, k=16)
+    save('g2_knn_dist.npz', out)
+
+
+# ------------------------------------------------------------------ G3
+def g3():
+    out = {}
+    data, _ = synth_batch(2, 1024, first=4)
+    ori = data[:, :, :3].transpose(1, 2).contiguous()  # [B,3,N]
+    out['ori'] = ori
+    for C in (16, 192):
+        g = torch.Generator('cpu').manual_seed(100 + C)
+        pick = torch.stack([torch.randperm(1024, generator=g)[:C] for _ in range(2)])
+        central = torch.gather(ori, 2, pick[:, None, :].expand(2, 3, C)).contiguous()
+        P = ((torch.rand(2, C, 3, generator=g) * 2 - 1) * 0.55).requires_grad_()
+        sig = (0.1 + torch.rand(2, C, generator=g) * 1.1).requires_grad_()
+        up = torch.randn(2, 3, 1024, generator=g)
+        att = HiT_ADV.__new__(HiT_ADV)
+        att.central_num = C
+        ker = att.kernel_density(central, ori, sig)
+        num = torch.zeros_like(ori)
+        den = torch.zeros(2, 1, 1024)
+        for j in range(C):  # the reference's loop body (HiT_ADV.py:170-175) driven from here
+            num = num + (ori + P[:, j, :].unsqueeze(dim=2)) * ker[:, j, :].unsqueeze(dim=1)
+            den = den + ker[:, j, :].unsqueeze(1)
+        adv = num / den
+        (adv * up).sum().backward()
+        pre = 'c%d_' % C
+        out.update({pre + 'central': central, pre + 'P': P, pre + 'sigma': sig, pre + 'upstream': up,
+                    pre + 'adv': adv, pre + 'grad_P': P.grad, pre + 'grad_sigma': sig.grad})
+        if C == 16:
+            out[pre + 'ker'] = ker
+        out[pre + 'tl_batch'] = att.transformation_loss(adv, P, sig, batch_avg=True)
+        out[pre + 'tl_each'] = att.transformation_loss(adv, P, sig, batch_avg=False)
+        kstd = torch.rand(2, C, 1, generator=g)
+        out[pre + 'central_kappa'] = kstd
+        out[pre + 'hide'] = att.curv_std_loss(sig, kstd, 1.2, 0.1)
+    save('g3_deform.npz', out)
+
+
+# ------------------------------------------------------------------ G4
+def g4():
+    data, _ = synth_batch(3, 1024, first=6)
+    xyz = data[:, :, :3].contiguous()
+    att = HiT_ADV.__new__(HiT_ADV)
+    torch.manual_seed(42)
+    start = torch.randint(0, 1024, (3,), dtype=torch.long)
+    torch.manual_seed(42)
+    idx = att.farthest_point_sample(xyz, 256)
+    assert (idx[:, 0] == start).all()
+    save('g4_fps.npz', dict(xyz=xyz, start=start, idx=idx))
+
+
+# ------------------------------------------------------------------ G5
+def run_reference_attack(model, data, target, seed, **hp):
+    """Run HiT_ADV.attack while recording the arguments of its own helper calls."""
+    att = HiT_ADV(model, adv_func=adv_utils.UntargetedLogitsAdvLoss(kappa=30.), **hp)
+    trace = dict(P=[], sigma=[], adv=[], logits=[], adv_loss=[])
+    cap = {}
+    orig_tl, orig_kd, orig_hide = att.transformation_loss, att.kernel_density, att.curv_std_loss
+
+    def tl(adv_data, perturb_mat, gauss_delta, batch_avg=True):
+        if not batch_avg:  # called exactly once per iteration with batch_avg=False (:195)
+            trace['P'].append(perturb_mat.detach().clone())
+            trace['sigma'].append(gauss_delta.detach().clone())
+            trace['adv'].append(adv_data.detach().clone())
+        return orig_tl(adv_data, perturb_mat, gauss_delta, batch_avg)
+
+    def kd(central_points, pc, delta):
+        cap['central'] = central_points.detach().clone()
+        return orig_kd(central_points, pc, delta)
+
+    def hide(gauss_delta, central_kappa_std, max_delta, min_delta):
+        cap['central_kappa'] = central_kappa_std.detach().clone()
+        return orig_hide(gauss_delta, central_kappa_std, max_delta, min_delta)
+
+    class Adv(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, logits, targets):
+            v = self.inner(logits, targets)
+            trace['logits'].append(logits.detach().clone())
+            trace['adv_loss'].append(v.detach().clone())
+            return v
+
+    att.transformation_loss, att.kernel_density, att.curv_std_loss = tl, kd, hide
+    att.adv_func = Adv(att.adv_func)
+    torch.manual_seed(seed)
+    with redirect_stdout(io.StringIO()) as log:
+        best, succ = att.attack(data, target)
+    out = {k: torch.stack(v) for k, v in trace.items()}
+    out.update(cap)
+    out['best'] = best
+    out['success_num'] = int(succ)
+    lb = [l for l in log.getvalue().splitlines() if l.startswith('lower_bound is')]
+    out['lower_bound_text'] = np.array(lb[-1] if lb else '')
+    return out
+
+
+def g5():
+    model = toy_victim(3)
+    data, _ = synth_batch(4, 256, first=20)
+    with torch.no_grad():
+        target = model(data[:, :, :3].transpose(1, 2).contiguous()).argmax(1)  # clean-correct labels
+    hp = dict(attack_lr=1e-2, central_num=16, total_central_num=32, init_weight=10., max_weight=80.,
+              binary_step=2, num_iter=10, cd_weight=1e-4, ker_weight=1., hide_weight=1.,
+              curv_loss_knn=8, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+    out = run_reference_attack(model, data, target, seed=11, **hp)
+    out.update(data=data, target=target, seed=11,
+               **{'w_' + k: v for k, v in model.state_dict().items()})
+    out.update({'hp_' + k: v for k, v in hp.items()})
+    save('g5_attack.npz', out)
+
+
+def g5b():
+    model = toy_victim(5)
+    data, _ = synth_batch(2, 1024, first=30)
+    with torch.no_grad():
+        target = model(data[:, :, :3].transpose(1, 2).contiguous()).argmax(1)
+    hp = dict(attack_lr=1e-2, central_num=192, total_central_num=256, init_weight=10.,
+              max_weight=80., binary_step=1, num_iter=5, cd_weight=1e-4, ker_weight=1.,
+              hide_weight=1., curv_loss_knn=16, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+    out = run_reference_attack(model, data, target, seed=13, **hp)
+    out['adv'] = out['adv'][-1]  # keep only the last iterate of the wide run
+    out.update(data=data, target=target, seed=13,
+               **{'w_' + k: v for k, v in model.state_dict().items()})
+    out.update({'hp_' + k: v for k, v in hp.items()})
+    save('g5b_attack_wide.npz', out)
+
+
+# ------------------------------------------------------------------ G6
+def g6():
+    g = torch.Generator('cpu').manual_seed(21)
+    logits = torch.randn(6, 40, generator=g) * 5
+    tgt = torch.randint(0, 40, (6,), generator=g)
+    out = dict(logits=logits, target=tgt)
+    for kappa in (0., 30.):
+        out['untargeted_k%d' % kappa] = adv_utils.UntargetedLogitsAdvLoss(kappa)(logits, tgt)
+        out['targeted_k%d' % kappa] = adv_utils.LogitsAdvLoss(kappa)(logits, tgt)
+    out['cross_entropy'] = adv_utils.CrossEntropyAdvLoss()(logits, tgt)
+    ori = torch.randn(2, 3, 128, generator=g)
+    pc = ori + 0.2 * torch.randn(2, 3, 128, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(2, 3, 128, generator=g), dim=1)
+    out.update(pc=pc, ori=ori, normal=nrm)
+    out['clip_l2'] = clip_utils.ClipPointsL2(budget=1.5)(pc, ori)
+    out['clip_linf'] = clip_utils.ClipPointsLinf(budget=0.18)(pc, ori)
+    out['project_inner'] = clip_utils.ProjectInnerPoints()(pc.clone(), ori, nrm)
+    out['project_clip'] = clip_utils.ProjectInnerClipLinf(budget=0.18)(pc.clone(), ori, nrm)
+    save('g6_adv_clip.npz', out)
+
+
+# ------------------------------------------------------------------ G7
+def g7():
+    model = toy_victim(9)
+    data, _ = synth_batch(2, 256, first=40)
+    xyz = data[:, :, :3].contiguous()
+    with torch.no_grad():
+        clean = model(xyz.transpose(1, 2).contiguous()).argmax(1)
+    target = (clean + 1) % 40  # targeted attack towards another class
+    advs = []
+    clip = clip_utils.ClipPointsLinf(budget=0.18)
+
+    def recording_clip(pc, ori_pc):
+        r = clip(pc, ori_pc)
+        advs.append(r.detach().clone())
+        return r
+
+    att = CWKNN(model, adv_utils.LogitsAdvLoss(kappa=15.), dist_utils.ChamferkNNDist(),
+                recording_clip, attack_lr=1e-2, num_iter=10)
+    torch.manual_seed(17)
+    with redirect_stdout(io.StringIO()):
+        final, succ = att.attack(xyz, target)
+    out = dict(data=xyz, target=target, seed=17, adv_trace=torch.stack(advs), final=final,
+               success_num=int(succ), **{'w_' + k: v for k, v in model.state_dict().items()})
+    save('g7_cwknn.npz', out)
+
+
+# ------------------------------------------------------------------ G8
+def g8():
+    shapes = {}
+    from model import feature_models
+    m = feature_models.PointNetFeatureModel(40, normal_channel=False)
+    shapes['pointnet'] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    shapes['pointnet_param_count'] = sum(p.numel() for p in m.parameters())
+    try:
+        from model.pointnet2_cls_ssg import get_model
+        m = get_model(40, normal_channel=False)
+        shapes['pointnet++'] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    except Exception as e:  # noqa: BLE001
+        shapes['pointnet++_error'] = repr(e)
+    try:
+        import argparse
+        from model.dgcnn_cls import DGCNN_cls
+        m = DGCNN_cls(argparse.Namespace(k=5, emb_dims=1024, dropout=0.2), output_channels=40)
+        shapes['dgcnn'] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    except Exception as e:  # noqa: BLE001
+        shapes['dgcnn_error'] = repr(e)
+    try:
+        import argparse
+        from model.pct_cls import Pct
+        m = Pct(argparse.Namespace(dropout=0.2), output_channels=40)
+        shapes['pct'] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    except Exception as e:  # noqa: BLE001
+        shapes['pct_error'] = repr(e)
+    with open(os.path.join(HERE, 'g8_state_dicts.json'), 'w') as f:
+        json.dump(shapes, f, indent=0, sort_keys=True)
+    print('wrote g8_state_dicts.json', {k: (len(v) if isinstance(v, dict) else v)
+                                        for k, v in shapes.items()})
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8']
+    for name in which:
+        globals()[name]()

@@ -1,0 +1,172 @@
+"""Pin the CPU oracle against vectors captured from the reference itself.
+
+The fixtures were produced by tests/golden/make_golden.py, which imports the
+unmodified reference in the build container.  These tests need no GPU and no
+reference tree.
+"""
+import numpy as np
+import torch
+
+from helpers import T, golden, golden_json, hp_from_fixture, toy_from_fixture
+from oracle import hitadv_oracle as O
+
+RT = dict(rtol=1e-5, atol=1e-6)
+
+
+def close(a, b, **kw):
+    kw = {**RT, **kw}
+    np.testing.assert_allclose(np.asarray(a.detach() if torch.is_tensor(a) else a),
+                               np.asarray(b), **kw)
+
+
+def test_g1_set_distances():
+    fx = golden('g1_set_distance.npz')
+    adv, ori, small, w = (T(fx[k]) for k in ('adv', 'ori', 'small', 'weights'))
+    l1, l2 = O.chamfer(adv, ori)
+    close(l1, fx['chamfer_l1']); close(l2, fx['chamfer_l2'])
+    l1, l2 = O.hausdorff(adv, ori)
+    close(l1, fx['hausdorff_l1']); close(l2, fx['hausdorff_l2'])
+    l1, l2 = O.chamfer(small, ori)
+    close(l1, fx['chamfer_small_l1']); close(l2, fx['chamfer_small_l2'])
+    l1, l2 = O.hausdorff(small, ori)
+    close(l1, fx['hausdorff_small_l1']); close(l2, fx['hausdorff_small_l2'])
+    for m in ('adv2ori', 'ori2adv', 'both'):
+        close(O.chamfer_dist(adv, ori, w, False, m), fx['ChamferDist_%s' % m])
+        close(O.hausdorff_dist(adv, ori, w, False, m), fx['HausdorffDist_%s' % m])
+    close(O.chamfer_dist(adv, ori), fx['ChamferDist_avg'])
+    close(O.hausdorff_dist(adv, ori), fx['HausdorffDist_avg'])
+    q1 = O.chamfer_dist(adv.transpose(1, 2).contiguous(), ori.transpose(1, 2).contiguous(),
+                        torch.from_numpy(np.ones(2) * 1e-4), batch_avg=False)
+    close(q1, fx['ChamferDist_q1'], rtol=1e-4)  # 1024-term fp32 dot products
+    a = adv.clone().requires_grad_()
+    O.chamfer_dist(a, ori, w, True, 'both').backward()
+    close(a.grad, fx['ChamferDist_both_grad'])
+    a = adv.clone().requires_grad_()
+    O.hausdorff_dist(a, ori, w, True, 'both').backward()
+    close(a.grad, fx['HausdorffDist_both_grad'])
+
+
+def test_g2_knn_dist_and_curvature():
+    fx = golden('g2_knn_dist.npz')
+    ori, nrm, adv = (T(fx[k]) for k in ('ori', 'normal', 'adv'))
+    for k in (4, 5):
+        close(O.knn_dist(adv, None, False, k), fx['KNNDist_k%d' % k])
+        close(O.knn_dist(adv.transpose(1, 2).contiguous(), None, False, k),
+              fx['KNNDist_k%d_chfirst' % k])
+    a = adv.clone().requires_grad_()
+    O.knn_dist(a, torch.tensor([0.5, 2.0]), True, 5).backward()
+    close(a.grad, fx['KNNDist_k5_grad'])
+    close(O.chamfer_knn_dist(adv, ori, batch_avg=False), fx['ChamferkNNDist'])
+    a = adv.clone().requires_grad_()
+    O.chamfer_knn_dist(a, ori).backward()
+    close(a.grad, fx['ChamferkNNDist_grad'])
+    ori_t, adv_t, nrm_t = (t.transpose(1, 2).contiguous() for t in (ori, adv, nrm))
+    close(O.curv_std_dist(ori_t, adv_t, nrm_t, k=4), fx['CurvStdDist_k4'])
+    close(O.kappa_ori(ori_t, nrm_t, 16)[0], fx['kappa_k16'])
+    close(O.kappa_std_ori(ori_t, nrm_t, 16), fx['kappa_std_k16'])
+
+
+def test_g3_deformation_and_small_losses():
+    fx = golden('g3_deform.npz')
+    ori = T(fx['ori'])
+    for C in (16, 192):
+        p = 'c%d_' % C
+        central, up = T(fx[p + 'central']), T(fx[p + 'upstream'])
+        P = T(fx[p + 'P']).clone().requires_grad_()
+        sig = T(fx[p + 'sigma']).clone().requires_grad_()
+        ker = O.kernel_density(central, ori, sig)
+        if C == 16:
+            close(ker, fx[p + 'ker'])
+        adv = O.deform_loop(ori, P, ker)
+        close(adv, fx[p + 'adv'])
+        (adv * up).sum().backward()
+        close(P.grad, fx[p + 'grad_P'], rtol=1e-4)
+        close(sig.grad, fx[p + 'grad_sigma'], rtol=1e-4)
+        close(O.transformation_loss(P, sig, C, True), fx[p + 'tl_batch'])
+        close(O.transformation_loss(P, sig, C, False), fx[p + 'tl_each'])
+        close(O.curv_std_loss(sig, T(fx[p + 'central_kappa']), 1.2, 0.1), fx[p + 'hide'])
+
+
+def test_g4_fps_from_start_bit_exact():
+    fx = golden('g4_fps.npz')
+    idx = O.fps_from_start(T(fx['xyz']), 256, T(fx['start']))
+    assert (idx.numpy() == fx['idx']).all()
+
+
+def test_g6_adv_losses_and_clips():
+    fx = golden('g6_adv_clip.npz')
+    logits, tgt = T(fx['logits']), T(fx['target'])
+    for kappa in (0., 30.):
+        close(O.untargeted_logits_adv_loss(logits, tgt, kappa), fx['untargeted_k%d' % kappa])
+        close(O.logits_adv_loss(logits, tgt, kappa), fx['targeted_k%d' % kappa])
+    close(O.cross_entropy_adv_loss(logits, tgt), fx['cross_entropy'])
+    pc, ori, nrm = T(fx['pc']), T(fx['ori']), T(fx['normal'])
+    close(O.clip_points_l2(pc, ori, 1.5), fx['clip_l2'])
+    close(O.clip_points_linf(pc, ori, 0.18), fx['clip_linf'])
+    close(O.project_inner_points(pc, ori, nrm), fx['project_inner'])
+    close(O.project_inner_clip_linf(pc, ori, nrm, 0.18), fx['project_clip'])
+
+
+def _run_oracle_attack(fx):
+    hp = hp_from_fixture(fx)
+    model = toy_from_fixture(fx)
+    att = O.HiTADVOracle(model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), **hp)
+    torch.manual_seed(int(fx['seed']))
+    trace = []
+    best, succ = att.attack(T(fx['data']), T(fx['target']), trace=trace)
+    return att, trace, best, succ
+
+
+def test_g5_full_attack_trajectory():
+    """HiT_ADV.attack end to end: same RNG draws, trajectory, discrete decisions."""
+    fx = golden('g5_attack.npz')
+    att, trace, best, succ = _run_oracle_attack(fx)
+    close(att.state['central'], fx['central'], rtol=0, atol=0)
+    close(att.state['central_kappa'], fx['central_kappa'])
+    n = len(trace)
+    assert n == fx['P'].shape[0] == 20
+    for i, rec in enumerate(trace):
+        # fixture rows hold the clamped, pre-update parameters of iteration i;
+        # the oracle trace holds the post-update ones -> compare i against i+1's input
+        close(rec['adv_loss'], fx['adv_loss'][i], rtol=1e-4)
+        assert (rec['pred'] == fx['logits'][i].argmax(1)).all()
+        close(rec['adv'], fx['adv'][i], rtol=1e-4, atol=1e-6)
+        if i + 1 < n and trace[i + 1]['step'] == rec['step']:
+            close(np.clip(rec['P'], -0.55, 0.55), fx['P'][i + 1], rtol=1e-4, atol=1e-6)
+            close(np.clip(rec['sigma'], 0.1, 1.2), fx['sigma'][i + 1], rtol=1e-4, atol=1e-6)
+    close(best, fx['best'], rtol=1e-4, atol=1e-6)
+    assert int(succ) == int(fx['success_num'])
+    assert best.dtype == np.float64 and best.shape == fx['best'].shape
+
+
+def test_g5b_wide_attack_short_trajectory():
+    fx = golden('g5b_attack_wide.npz')
+    att, trace, best, succ = _run_oracle_attack(fx)
+    close(att.state['central'], fx['central'], rtol=0, atol=0)
+    for i, rec in enumerate(trace):
+        close(rec['adv_loss'], fx['adv_loss'][i], rtol=1e-4)
+    close(att.state['last_adv'], fx['adv'], rtol=1e-4, atol=1e-6)
+    close(best, fx['best'], rtol=1e-4, atol=1e-6)
+    assert int(succ) == int(fx['success_num'])
+
+
+def test_g7_cwknn_trajectory():
+    fx = golden('g7_cwknn.npz')
+    model = toy_from_fixture(fx)
+    torch.manual_seed(int(fx['seed']))
+    trace = []
+    final, succ = O.cw_knn_attack(
+        model, lambda l, t: O.logits_adv_loss(l, t, 15.), O.chamfer_knn_dist,
+        lambda pc, ori: O.clip_points_linf(pc, ori, 0.18), T(fx['data']), T(fx['target']),
+        attack_lr=1e-2, num_iter=10, trace=trace)
+    for i, rec in enumerate(trace):
+        close(rec['adv'], fx['adv_trace'][i], rtol=1e-4, atol=1e-6)
+    close(final, fx['final'], rtol=1e-4, atol=1e-6)
+    assert succ == int(fx['success_num'])
+    assert final.dtype == np.float32
+
+
+def test_g8_pointnet_state_dict_layout_recorded():
+    shapes = golden_json('g8_state_dicts.json')
+    assert len(shapes['pointnet']) == 111
+    assert shapes['pointnet_param_count'] == 3471473
