@@ -1,0 +1,73 @@
+"""ctypes binding of libhitadv_hip.so (C ABI declared in include/hitadv.h).
+
+This is the only place the shared library is touched.  There is NO fallback: if the
+library is missing or a launch fails, the caller gets a RuntimeError.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhitadv_hip.so")
+
+_c = ctypes
+_P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/hitadv.h
+PROTOTYPES = {
+    "hitadv_version": [],
+    "hitadv_pairwise_sqdist": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hitadv_nn_min": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "hitadv_nn_min_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "hitadv_knn_points": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
+    "hitadv_knn_points_bwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P],
+    "hitadv_deform_fwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "hitadv_deform_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "hitadv_deform_bwd_scratch_floats": [_I, _I, _I],
+    "hitadv_best_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "hitadv_adam_step": [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _L, _F, _P, _P],
+    "hitadv_fps_from_start": [_P, _P, _I, _I, _I, _P, _P],
+    "hitadv_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
+    "hitadv_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "hitadv_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "hitadv_query_ball_point": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "hitadv_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "hitadv_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "hitadv_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "hitadv_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hitadv_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+}
+_RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64}
+
+_lib = None
+
+
+class HitAdvLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once.  torch must already be imported so that the HIP runtime the
+    library binds to (SONAME libamdhip64.so.7) is the one torch itself uses."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (load order matters, see docstring)
+    if not os.path.exists(LIB_PATH):
+        raise HitAdvLibraryError(
+            "libhitadv_hip.so is not built (%s). Build it with `make -C hit_adv_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library out of sync
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, _c.c_int)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        what = "invalid argument" if rc == -1 else "hipError %d" % rc
+        raise HitAdvLibraryError("%s failed: %s" % (name, what))

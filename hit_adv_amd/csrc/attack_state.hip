@@ -1,0 +1,147 @@
+// On-device attack bookkeeping: best-result tracking and the Adam step for (perturb, sigma).
+// These replace the per-iteration device->host copies and Python loops of
+// ShapeAttack/HiT_ADV.py:186-217 and the torch.optim.Adam instance of :142-145, so that a whole
+// inner iteration can be captured into one hipGraph.
+#include "common.hpp"
+#include "hitadv.h"
+
+namespace hitadv {
+
+__device__ __forceinline__ uint32_t ordered_bits(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void best_update_k(
+    const float *__restrict__ logits, const int64_t *__restrict__ label, const float *__restrict__ perturb,
+    const float *__restrict__ sigma, const float *__restrict__ adv, int num_class, int N, int C,
+    float *__restrict__ bestdist, int64_t *__restrict__ bestscore, float *__restrict__ o_bestdist,
+    int64_t *__restrict__ o_bestscore, float *__restrict__ o_bestattack, int64_t *__restrict__ pred_out,
+    float *__restrict__ dist_val_out, int32_t *__restrict__ iter_counter) {
+  __shared__ float s1[4], s2[4];
+  __shared__ int s_copy;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // transformation_loss(batch_avg=False): (|P_b|_F + |1 - sigma_b|_2) / C
+  float a1 = 0.f, a2 = 0.f;
+  const float *pp = perturb + (size_t)b * C * 3;
+  for (int e = threadIdx.x; e < C * 3; e += 256) a1 = fmaf(pp[e], pp[e], a1);
+  const float *sp = sigma + (size_t)b * C;
+  for (int e = threadIdx.x; e < C; e += 256) {
+    const float t = 1.0f - sp[e];
+    a2 = fmaf(t, t, a2);
+  }
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if (lane == 0) {
+    s1[wave] = a1;
+    s2[wave] = a2;
+  }
+  // argmax over the logits, lowest index on ties (wave 0)
+  unsigned long long key = 0ull;
+  if (wave == 0) {
+    for (int c = lane; c < num_class; c += 64) {
+      const unsigned long long k =
+          ((unsigned long long)ordered_bits(logits[(size_t)b * num_class + c]) << 32) | (0xFFFFFFFFu - (uint32_t)c);
+      key = k > key ? k : key;
+    }
+    key = wave_max_u64(key);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float d = (__builtin_sqrtf((s1[0] + s1[1]) + (s1[2] + s1[3])) +
+                     __builtin_sqrtf((s2[0] + s2[1]) + (s2[2] + s2[3]))) / (float)C;
+    const int64_t pred = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xffffffffu));
+    pred_out[b] = pred;
+    dist_val_out[b] = d;
+    int copy = 0;
+    if (pred != label[b]) {
+      if (d < bestdist[b]) {
+        bestdist[b] = d;
+        bestscore[b] = pred;
+      }
+      if (d < o_bestdist[b]) {
+        o_bestdist[b] = d;
+        o_bestscore[b] = pred;
+        copy = 1;
+      }
+    }
+    s_copy = copy;
+    if (b == 0 && iter_counter != nullptr) *iter_counter += 1;
+  }
+  __syncthreads();
+  if (s_copy) {
+    const float *src = adv + (size_t)b * 3 * N;
+    float *dst = o_bestattack + (size_t)b * 3 * N;
+    for (int e = threadIdx.x; e < 3 * N; e += 256) dst[e] = src[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_k(float *__restrict__ p0, const float *__restrict__ g0,
+                                              float *__restrict__ m0, float *__restrict__ v0, long long n0,
+                                              float lr0, float *__restrict__ p1, const float *__restrict__ g1,
+                                              float *__restrict__ m1, float *__restrict__ v1, long long n1,
+                                              float lr1, const int32_t *__restrict__ step) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n0 + n1) return;
+  const bool second = e >= n0;
+  const long long i = second ? e - n0 : e;
+  float *p = second ? p1 : p0;
+  const float *g = second ? g1 : g0;
+  float *m = second ? m1 : m0;
+  float *v = second ? v1 : v0;
+  const double lr = second ? (double)lr1 : (double)lr0;
+  const int t = *step + 1;
+  const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
+  const double bc1 = 1.0 - pow(beta1, (double)t);
+  const double bc2 = 1.0 - pow(beta2, (double)t);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float gi = g[i];
+  const float mi = m[i] + (gi - m[i]) * (float)(1.0 - beta1);
+  const float vi = v[i] * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = __builtin_sqrtf(vi) / bc2_sqrt + (float)eps;
+  p[i] = p[i] - (step_size * mi) / denom;
+}
+
+__global__ void bump_k(int32_t *c) { *c += 1; }
+
+}  // namespace hitadv
+
+using namespace hitadv;
+
+extern "C" const char *hitadv_version(void) { return "hitadv-hip 0.1 (gfx950)"; }
+
+extern "C" int hitadv_best_update(const float *logits, const int64_t *label, const float *perturb,
+                                  const float *sigma, const float *adv, int B, int num_class, int N, int C,
+                                  float *bestdist, int64_t *bestscore, float *o_bestdist, int64_t *o_bestscore,
+                                  float *o_bestattack, int64_t *pred_out, float *dist_val_out,
+                                  int32_t *iter_counter, void *stream) {
+  if (!logits || !label || !perturb || !sigma || !adv || !bestdist || !bestscore || !o_bestdist || !o_bestscore ||
+      !o_bestattack || !pred_out || !dist_val_out || B <= 0 || num_class <= 0 || N <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  best_update_k<<<B, 256, 0, (hipStream_t)stream>>>(logits, label, perturb, sigma, adv, num_class, N, C, bestdist,
+                                                    bestscore, o_bestdist, o_bestscore, o_bestattack, pred_out,
+                                                    dist_val_out, iter_counter);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_adam_step(float *perturb, const float *g_perturb, float *m_perturb, float *v_perturb,
+                                int64_t n_perturb, float lr_perturb, float *sigma, const float *g_sigma,
+                                float *m_sigma, float *v_sigma, int64_t n_sigma, float lr_sigma, int32_t *step,
+                                void *stream) {
+  if (!perturb || !g_perturb || !m_perturb || !v_perturb || !step || n_perturb <= 0 || n_sigma < 0)
+    return HITADV_E_ARG;
+  if (n_sigma > 0 && (!sigma || !g_sigma || !m_sigma || !v_sigma)) return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = n_perturb + n_sigma;
+  adam_k<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(perturb, g_perturb, m_perturb, v_perturb, n_perturb,
+                                                         lr_perturb, sigma, g_sigma, m_sigma, v_sigma, n_sigma,
+                                                         lr_sigma, step);
+  bump_k<<<1, 1, 0, s>>>(step);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}

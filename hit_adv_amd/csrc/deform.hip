@@ -1,0 +1,205 @@
+// HiT-ADV kernel-weighted deformation, forward and backward.
+//
+//   k[n,j]  = exp(-|x_n - c_j| / (2 sigma_j^2))          (un-squared norm, HiT_ADV.py:298-304)
+//   adv_n   = x_n + (sum_j k[n,j] p_j) / (sum_j k[n,j])  (== the 192-step loop of :160-175)
+//
+//   K3f deform_fwd   lanes own points; the cloud's centre table (c, p, -log2e/(2 sigma^2)) sits in
+//                    LDS and is read as broadcasts; the 4 waves of a block split the centre range
+//                    and merge partial sums through LDS in fixed order.  Transcendental/VALU-bound.
+//   K3b deform_bwd   lanes own CENTRES (the reduction axis N then runs inside a lane, no cross-lane
+//                    traffic); each block covers a 64-point slab whose per-point terms are
+//                    precomputed into LDS; per-slab partials are summed in fixed order by
+//                    deform_bwd_reduce -> bitwise reproducible gradients, no atomics.
+#include "common.hpp"
+#include "hitadv.h"
+
+namespace hitadv {
+
+constexpr int DF_PTS = 64;    // points per block (forward)
+constexpr int DF_CMAX = 1024; // centres staged per LDS pass
+constexpr float LOG2E = 1.4426950408889634f;
+
+__global__ __launch_bounds__(256) void deform_fwd(const float *__restrict__ ori,
+                                                  const float *__restrict__ central,
+                                                  const float *__restrict__ perturb,
+                                                  const float *__restrict__ sigma, int N, int C,
+                                                  float *__restrict__ adv, float *__restrict__ inv_den) {
+  __shared__ float4 sc[DF_CMAX];  // cx cy cz a
+  __shared__ float4 sp[DF_CMAX];  // px py pz -
+  __shared__ float4 part[4][DF_PTS];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * DF_PTS + lane;
+  const int nn = n < N ? n : N - 1;
+  const float *op = ori + (size_t)b * 3 * N;
+  const float x = op[nn], y = op[N + nn], z = op[2 * N + nn];
+  float sx = 0.f, sy = 0.f, sz = 0.f, den = 0.f;
+  for (int c0 = 0; c0 < C; c0 += DF_CMAX) {
+    const int cnt = min(DF_CMAX, C - c0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+      const float *cp = central + (size_t)b * 3 * C + c0 + j;
+      const float *pp = perturb + ((size_t)b * C + c0 + j) * 3;
+      const float s = sigma[(size_t)b * C + c0 + j];
+      sc[j] = make_float4(cp[0], cp[C], cp[2 * C], -LOG2E / (2.0f * s * s));
+      sp[j] = make_float4(pp[0], pp[1], pp[2], 0.f);
+    }
+    __syncthreads();
+    const int per = (cnt + 3) >> 2;
+    const int lo = wave * per, hi = min(lo + per, cnt);
+#pragma unroll 4
+    for (int j = lo; j < hi; ++j) {
+      const float4 c = sc[j];
+      const float4 p = sp[j];
+      const float r = __builtin_sqrtf(sqdist3(x, y, z, c.x, c.y, c.z));
+      const float k = exp2f(r * c.w);
+      sx = fmaf(k, p.x, sx);
+      sy = fmaf(k, p.y, sy);
+      sz = fmaf(k, p.z, sz);
+      den = den + k;
+    }
+  }
+  part[wave][lane] = make_float4(sx, sy, sz, den);
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    float4 a = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 o = part[w][lane];
+      a.x += o.x;
+      a.y += o.y;
+      a.z += o.z;
+      a.w += o.w;
+    }
+    const float inv = 1.0f / a.w;
+    float *ap = adv + (size_t)b * 3 * N;
+    ap[n] = x + a.x * inv;
+    ap[N + n] = y + a.y * inv;
+    ap[2 * N + n] = z + a.z * inv;
+    inv_den[(size_t)b * N + n] = inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------- backward
+// With S = sum_j k p_j, Dn = sum_j k:  adv = x + S/Dn
+//   dL/dp_j[d]  = sum_n g[n,d]/Dn * k[n,j]
+//   dL/dk[n,j]  = sum_d g[n,d]/Dn * p_j[d] - sum_d g[n,d]/Dn * (adv[n,d]-x[n,d])
+//   dL/dsig_j   = sum_n dL/dk[n,j] * k[n,j] * r[n,j] / sig_j^3
+constexpr int DB_PTS = 64;  // points per slab
+
+__global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
+                                                  const float *__restrict__ central,
+                                                  const float *__restrict__ perturb,
+                                                  const float *__restrict__ sigma,
+                                                  const float *__restrict__ adv,
+                                                  const float *__restrict__ inv_den,
+                                                  const float *__restrict__ g_adv, int N, int C,
+                                                  int nslab, float *__restrict__ partials) {
+  __shared__ float4 sxyz[DB_PTS];  // x y z cn
+  __shared__ float4 sg[DB_PTS];    // gDx gDy gDz -
+  const int b = blockIdx.z, slab = blockIdx.y;
+  const int n0 = slab * DB_PTS;
+  const int cnt = min(DB_PTS, N - n0);
+  if (threadIdx.x < DB_PTS) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), g = a;
+    if (threadIdx.x < cnt) {
+      const int n = n0 + threadIdx.x;
+      const float *op = ori + (size_t)b * 3 * N;
+      const float *ap = adv + (size_t)b * 3 * N;
+      const float *gp = g_adv + (size_t)b * 3 * N;
+      const float inv = inv_den[(size_t)b * N + n];
+      const float x = op[n], y = op[N + n], z = op[2 * N + n];
+      const float gx = gp[n] * inv, gy = gp[N + n] * inv, gz = gp[2 * N + n] * inv;
+      const float cn = gx * (ap[n] - x) + gy * (ap[N + n] - y) + gz * (ap[2 * N + n] - z);
+      a = make_float4(x, y, z, cn);
+      g = make_float4(gx, gy, gz, 0.f);
+    }
+    sxyz[threadIdx.x] = a;
+    sg[threadIdx.x] = g;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= C) return;
+  const float *cp = central + (size_t)b * 3 * C + j;
+  const float cx = cp[0], cy = cp[C], cz = cp[2 * C];
+  const float *pp = perturb + ((size_t)b * C + j) * 3;
+  const float px = pp[0], py = pp[1], pz = pp[2];
+  const float s = sigma[(size_t)b * C + j];
+  const float a2 = -LOG2E / (2.0f * s * s);
+  float apx = 0.f, apy = 0.f, apz = 0.f, asg = 0.f;
+#pragma unroll 4
+  for (int t = 0; t < cnt; ++t) {
+    const float4 pt = sxyz[t];
+    const float4 g = sg[t];
+    const float r = __builtin_sqrtf(sqdist3(pt.x, pt.y, pt.z, cx, cy, cz));
+    const float k = exp2f(r * a2);
+    apx = fmaf(g.x, k, apx);
+    apy = fmaf(g.y, k, apy);
+    apz = fmaf(g.z, k, apz);
+    const float dk = fmaf(g.x, px, fmaf(g.y, py, g.z * pz)) - pt.w;
+    asg = fmaf(dk * k, r, asg);
+  }
+  float *out = partials + (((size_t)b * nslab + slab) * 4) * C + j;
+  out[0] = apx;
+  out[C] = apy;
+  out[2 * C] = apz;
+  out[3 * C] = asg / (s * s * s);
+}
+
+__global__ __launch_bounds__(256) void deform_bwd_reduce(const float *__restrict__ partials, int C,
+                                                         int nslab, float *__restrict__ grad_perturb,
+                                                         float *__restrict__ grad_sigma) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= C) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int s = 0; s < nslab; ++s) {
+    const float *p = partials + (((size_t)b * nslab + s) * 4) * C + j;
+    a0 += p[0];
+    a1 += p[C];
+    a2 += p[2 * C];
+    a3 += p[3 * C];
+  }
+  float *gp = grad_perturb + ((size_t)b * C + j) * 3;
+  gp[0] = a0;
+  gp[1] = a1;
+  gp[2] = a2;
+  grad_sigma[(size_t)b * C + j] = a3;
+}
+
+}  // namespace hitadv
+
+using namespace hitadv;
+
+extern "C" int hitadv_deform_fwd(const float *ori, const float *central, const float *perturb,
+                                 const float *sigma, int B, int N, int C, float *adv, float *inv_den,
+                                 void *stream) {
+  if (!ori || !central || !perturb || !sigma || !adv || !inv_den || B <= 0 || N <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  dim3 grid((N + DF_PTS - 1) / DF_PTS, B);
+  deform_fwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, N, C, adv, inv_den);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t hitadv_deform_bwd_scratch_floats(int B, int N, int C) {
+  const int64_t nslab = (N + DB_PTS - 1) / DB_PTS;
+  return (int64_t)B * nslab * 4 * C;
+}
+
+extern "C" int hitadv_deform_bwd(const float *ori, const float *central, const float *perturb,
+                                 const float *sigma, const float *adv, const float *inv_den,
+                                 const float *g_adv, int B, int N, int C, float *partials,
+                                 float *grad_perturb, float *grad_sigma, void *stream) {
+  if (!ori || !central || !perturb || !sigma || !adv || !inv_den || !g_adv || !partials || !grad_perturb ||
+      !grad_sigma || B <= 0 || N <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int nslab = (N + DB_PTS - 1) / DB_PTS;
+  dim3 grid((C + 255) / 256, nslab, B);
+  deform_bwd<<<grid, 256, 0, s>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials);
+  dim3 grid2((C + 255) / 256, B);
+  deform_bwd_reduce<<<grid2, 256, 0, s>>>(partials, C, nslab, grad_perturb, grad_sigma);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,203 @@
+// K nearest neighbours (canonical rule: direct-difference fp32 squared distance, ascending,
+// ties -> lower index) and its backward.
+//
+//   K4  knn_topk<KB>   one lane per query, references broadcast from LDS (float4), a sorted
+//                      KB-entry insertion list per lane held entirely in VGPRs (compile-time
+//                      indices only, so nothing spills to scratch).  fp32-VALU-bound.
+#include "common.hpp"
+#include "hitadv.h"
+
+namespace hitadv {
+
+constexpr int KNN_RCH = 1024;
+
+template <int KB, typename IdxT>
+__global__ __launch_bounds__(64) void knn_topk(const float *__restrict__ q, const float *__restrict__ p,
+                                               int N, int M, int K, float *__restrict__ dists,
+                                               IdxT *__restrict__ idx) {
+  __shared__ float4 sref[KNN_RCH];
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const bool live = i < N;
+  const float *qp = q + ((size_t)b * N + (live ? i : N - 1)) * 3;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  p += (size_t)b * M * 3;
+  float d[KB];
+  int ix[KB];
+#pragma unroll
+  for (int t = 0; t < KB; ++t) {
+    d[t] = __builtin_inff();
+    ix[t] = 0;
+  }
+  for (int c0 = 0; c0 < M; c0 += KNN_RCH) {
+    const int cnt = min(KNN_RCH, M - c0);
+    __syncthreads();
+    for (int r = threadIdx.x; r < cnt; r += 64) {
+      const float *s = p + (size_t)(c0 + r) * 3;
+      sref[r] = make_float4(s[0], s[1], s[2], 0.f);
+    }
+    __syncthreads();
+    for (int r = 0; r < cnt; ++r) {
+      const float4 v = sref[r];
+      const float c = sqdist3(qx, qy, qz, v.x, v.y, v.z);
+      if (c < d[KB - 1]) {
+        const int j = c0 + r;
+#pragma unroll
+        for (int t = KB - 1; t > 0; --t) {
+          const bool sh = c < d[t - 1];
+          const bool wr = c < d[t];
+          const float nd = sh ? d[t - 1] : c;
+          const int ni = sh ? ix[t - 1] : j;
+          d[t] = wr ? nd : d[t];
+          ix[t] = wr ? ni : ix[t];
+        }
+        const bool w0 = c < d[0];
+        d[0] = w0 ? c : d[0];
+        ix[0] = w0 ? j : ix[0];
+      }
+    }
+  }
+  if (live) {
+    float *od = dists + ((size_t)b * N + i) * K;
+    IdxT *oi = idx + ((size_t)b * N + i) * K;
+#pragma unroll
+    for (int t = 0; t < KB; ++t)
+      if (t < K) {
+        od[t] = d[t];
+        oi[t] = (IdxT)ix[t];
+      }
+  }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void knn_bwd_q(const float *__restrict__ q, const float *__restrict__ p,
+                                                 const IdxT *__restrict__ idx, const float *__restrict__ g,
+                                                 int N, int M, int K, float *__restrict__ grad_q) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float *qp = q + ((size_t)b * N + i) * 3;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  p += (size_t)b * M * 3;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int t = 0; t < K; ++t) {
+    const int j = (int)idx[((size_t)b * N + i) * K + t];
+    const float g2 = 2.0f * g[((size_t)b * N + i) * K + t];
+    ax = ax + g2 * (qx - p[j * 3]);
+    ay = ay + g2 * (qy - p[j * 3 + 1]);
+    az = az + g2 * (qz - p[j * 3 + 2]);
+  }
+  float *o = grad_q + ((size_t)b * N + i) * 3;
+  o[0] = ax;
+  o[1] = ay;
+  o[2] = az;
+}
+
+// grad_p[j] = -sum_{(i,t): idx[i,t]==j} 2 g[i,t] (q_i - p_j); one lane per reference point, the
+// (idx, g, q_i) triples stream through LDS in query order -> fixed summation order, no atomics.
+constexpr int KB_ENT = 4096;
+template <typename IdxT>
+__global__ __launch_bounds__(256) void knn_bwd_p(const float *__restrict__ q, const float *__restrict__ p,
+                                                 const IdxT *__restrict__ idx, const float *__restrict__ g,
+                                                 int N, int M, int K, float *__restrict__ grad_p) {
+  __shared__ int sidx[KB_ENT];
+  __shared__ float sg[KB_ENT];
+  __shared__ float sq[(KB_ENT / 1) / 1 > 0 ? 3 * KB_ENT / 1 : 3];  // sized for K == 1 worst case
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool live = j < M;
+  const float *pp = p + ((size_t)b * M + (live ? j : M - 1)) * 3;
+  const float px = pp[0], py = pp[1], pz = pp[2];
+  const int qch = KB_ENT / K;  // queries per chunk
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int i0 = 0; i0 < N; i0 += qch) {
+    const int nq = min(qch, N - i0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nq * K; e += 256) {
+      sidx[e] = (int)idx[((size_t)b * N + i0) * K + e];
+      sg[e] = 2.0f * g[((size_t)b * N + i0) * K + e];
+    }
+    for (int e = threadIdx.x; e < nq * 3; e += 256) sq[e] = q[((size_t)b * N + i0) * 3 + e];
+    __syncthreads();
+    for (int i = 0; i < nq; ++i) {
+      const float qx = sq[i * 3], qy = sq[i * 3 + 1], qz = sq[i * 3 + 2];
+      for (int t = 0; t < K; ++t) {
+        if (sidx[i * K + t] == j) {
+          const float g2 = sg[i * K + t];
+          ax = ax - g2 * (qx - px);
+          ay = ay - g2 * (qy - py);
+          az = az - g2 * (qz - pz);
+        }
+      }
+    }
+  }
+  if (live) {
+    float *o = grad_p + ((size_t)b * M + j) * 3;
+    o[0] = ax;
+    o[1] = ay;
+    o[2] = az;
+  }
+}
+
+template <typename IdxT>
+static int launch_knn(const float *q, const float *p, int B, int N, int M, int K, float *dists, IdxT *idx,
+                      hipStream_t s) {
+  dim3 grid((N + 63) / 64, B);
+#define HITADV_KNN_CASE(KB)                                                       \
+  if (K <= KB) {                                                                  \
+    knn_topk<KB, IdxT><<<grid, 64, 0, s>>>(q, p, N, M, K, dists, idx);            \
+    return 0;                                                                     \
+  }
+  HITADV_KNN_CASE(1)
+  HITADV_KNN_CASE(4)
+  HITADV_KNN_CASE(8)
+  HITADV_KNN_CASE(12)
+  HITADV_KNN_CASE(16)
+  HITADV_KNN_CASE(20)
+  HITADV_KNN_CASE(24)
+  HITADV_KNN_CASE(32)
+  HITADV_KNN_CASE(48)
+  HITADV_KNN_CASE(64)
+#undef HITADV_KNN_CASE
+  return HITADV_E_ARG;
+}
+
+}  // namespace hitadv
+
+using namespace hitadv;
+
+extern "C" int hitadv_knn_points(const float *q, const float *p, int B, int N, int M, int K, float *dists,
+                                 void *idx, int idx_is_i64, void *stream) {
+  if (!q || !p || !dists || !idx || B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > 64 || K > M)
+    return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = idx_is_i64 ? launch_knn<int64_t>(q, p, B, N, M, K, dists, (int64_t *)idx, s)
+                      : launch_knn<int32_t>(q, p, B, N, M, K, dists, (int32_t *)idx, s);
+  if (rc) return rc;
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_knn_points_bwd(const float *q, const float *p, const void *idx, int idx_is_i64,
+                                     const float *g_dists, int B, int N, int M, int K, float *grad_q,
+                                     float *grad_p, void *stream) {
+  if (!q || !p || !idx || !g_dists || B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > 64) return HITADV_E_ARG;
+  if (!grad_q && !grad_p) return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (grad_q) {
+    dim3 grid((N + 255) / 256, B);
+    if (idx_is_i64)
+      knn_bwd_q<int64_t><<<grid, 256, 0, s>>>(q, p, (const int64_t *)idx, g_dists, N, M, K, grad_q);
+    else
+      knn_bwd_q<int32_t><<<grid, 256, 0, s>>>(q, p, (const int32_t *)idx, g_dists, N, M, K, grad_q);
+  }
+  if (grad_p) {
+    dim3 grid((M + 255) / 256, B);
+    if (idx_is_i64)
+      knn_bwd_p<int64_t><<<grid, 256, 0, s>>>(q, p, (const int64_t *)idx, g_dists, N, M, K, grad_p);
+    else
+      knn_bwd_p<int32_t><<<grid, 256, 0, s>>>(q, p, (const int32_t *)idx, g_dists, N, M, K, grad_p);
+  }
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,186 @@
+"""Tensor-level front end of the HIP kernels (torch tensors in HBM -> C ABI calls).
+
+torch is plumbing here: it owns device memory, the current HIP stream and the autograd
+tape; every computation below happens in libhitadv_hip.so.  All functions require CUDA
+(ROCm) tensors and raise otherwise -- there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+FORM_DIRECT, FORM_GRAM = 0, 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: hit_adv_amd has no CPU path" % name)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------- pairwise / set minima
+def pairwise_sqdist(x, y, form=FORM_GRAM):
+    """x[B,N,D], y[B,M,D] -> P[B,N,M] (no autograd; see NNMin for the differentiable reductions)."""
+    x, y = _dev(x.detach(), "x"), _dev(y.detach(), "y")
+    B, N, D = x.shape
+    M = y.shape[1]
+    P = torch.empty(B, N, M, device=x.device, dtype=torch.float32)
+    _lib.call("hitadv_pairwise_sqdist", _p(x), _p(y), _p(P), B, N, M, D, form, _stream())
+    return P
+
+
+class NNMin(torch.autograd.Function):
+    """(x[B,N,D], y[B,M,D]) -> (min_x[B,N], arg_x[B,N], min_y[B,M], arg_y[B,M])."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _dev(x, "x"), _dev(y, "y")
+        B, N, D = x.shape
+        M = y.shape[1]
+        dev = x.device
+        min_x = torch.empty(B, N, device=dev)
+        min_y = torch.empty(B, M, device=dev)
+        arg_x = torch.empty(B, N, device=dev, dtype=torch.int32)
+        arg_y = torch.empty(B, M, device=dev, dtype=torch.int32)
+        scratch = torch.empty(B, N, M, device=dev) if D != 3 else None
+        _lib.call("hitadv_nn_min", _p(x), _p(y), B, N, M, D, _p(min_x), _p(arg_x), _p(min_y), _p(arg_y),
+                  _p(scratch), _stream())
+        ctx.save_for_backward(x, y, arg_x, arg_y)
+        ctx.mark_non_differentiable(arg_x, arg_y)
+        return min_x, arg_x, min_y, arg_y
+
+    @staticmethod
+    def backward(ctx, g_min_x, _gax, g_min_y, _gay):
+        x, y, arg_x, arg_y = ctx.saved_tensors
+        B, N, D = x.shape
+        M = y.shape[1]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if gx is None and gy is None:
+            return None, None
+        gmx = g_min_x.contiguous().float() if g_min_x is not None else None
+        gmy = g_min_y.contiguous().float() if g_min_y is not None else None
+        _lib.call("hitadv_nn_min_bwd", _p(x), _p(y), _p(arg_x), _p(arg_y), _p(gmx), _p(gmy), B, N, M, D,
+                  _p(gx), _p(gy), _stream())
+        return gx, gy
+
+
+def nn_min(x, y):
+    return NNMin.apply(x, y)
+
+
+# --------------------------------------------------------------------------- kNN
+class KnnPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p1, p2, K):
+        p1, p2 = _dev(p1, "p1"), _dev(p2, "p2")
+        B, N, D = p1.shape
+        M = p2.shape[1]
+        if D != 3 or p2.shape[2] != 3:
+            raise RuntimeError("knn_points: only 3-D points are supported by the HIP kernel")
+        if not 1 <= K <= min(M, 64):
+            raise RuntimeError("knn_points: need 1 <= K <= min(M, 64), got K=%d, M=%d" % (K, M))
+        dists = torch.empty(B, N, K, device=p1.device)
+        idx = torch.empty(B, N, K, device=p1.device, dtype=torch.int64)
+        _lib.call("hitadv_knn_points", _p(p1), _p(p2), B, N, M, K, _p(dists), _p(idx), 1, _stream())
+        ctx.save_for_backward(p1, p2, idx)
+        ctx.mark_non_differentiable(idx)
+        return dists, idx
+
+    @staticmethod
+    def backward(ctx, g_dists, _gi):
+        p1, p2, idx = ctx.saved_tensors
+        B, N, _ = p1.shape
+        M = p2.shape[1]
+        K = idx.shape[2]
+        g1 = torch.empty_like(p1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(p2) if ctx.needs_input_grad[1] else None
+        if g1 is None and g2 is None:
+            return None, None, None
+        g = g_dists.contiguous().float()
+        _lib.call("hitadv_knn_points_bwd", _p(p1), _p(p2), _p(idx), 1, _p(g), B, N, M, K, _p(g1), _p(g2),
+                  _stream())
+        return g1, g2, None
+
+
+# --------------------------------------------------------------------------- deformation
+class Deform(torch.autograd.Function):
+    """adv = ori + (sum_j k_j p_j) / (sum_j k_j),  k_j = exp(-|x - c_j| / (2 sigma_j^2)).
+
+    Differentiable w.r.t. perturb[B,C,3] and sigma[B,C] only (ori / central are constants of the
+    attack, ShapeAttack/HiT_ADV.py:57,63-93)."""
+
+    @staticmethod
+    def forward(ctx, ori, central, perturb, sigma):
+        ori, central = _dev(ori, "ori"), _dev(central, "central")
+        perturb, sigma = _dev(perturb, "perturb"), _dev(sigma, "sigma")
+        B, _, N = ori.shape
+        C = central.shape[2]
+        adv = torch.empty_like(ori)
+        inv_den = torch.empty(B, N, device=ori.device)
+        _lib.call("hitadv_deform_fwd", _p(ori), _p(central), _p(perturb), _p(sigma), B, N, C, _p(adv),
+                  _p(inv_den), _stream())
+        ctx.save_for_backward(ori, central, perturb, sigma, adv, inv_den)
+        return adv
+
+    @staticmethod
+    def backward(ctx, g_adv):
+        ori, central, perturb, sigma, adv, inv_den = ctx.saved_tensors
+        B, _, N = ori.shape
+        C = central.shape[2]
+        g_adv = g_adv.contiguous().float()
+        n = _lib.load().hitadv_deform_bwd_scratch_floats(B, N, C)
+        partials = torch.empty(n, device=ori.device)
+        gp = torch.empty_like(perturb)
+        gs = torch.empty_like(sigma)
+        _lib.call("hitadv_deform_bwd", _p(ori), _p(central), _p(perturb), _p(sigma), _p(adv), _p(inv_den),
+                  _p(g_adv), B, N, C, _p(partials), _p(gp), _p(gs), _stream())
+        return None, None, gp, gs
+
+
+def deform(ori, central, perturb, sigma):
+    return Deform.apply(ori, central, perturb, sigma)
+
+
+# --------------------------------------------------------------------------- attack state
+def best_update(logits, label, perturb, sigma, adv, state):
+    """In-place update of the best-so-far buffers in ``state`` (see hitadv_best_update)."""
+    B, K = logits.shape
+    N = adv.shape[2]
+    C = sigma.shape[1]
+    _lib.call("hitadv_best_update", _p(logits), _p(label), _p(perturb), _p(sigma), _p(adv), B, K, N, C,
+              _p(state["bestdist"]), _p(state["bestscore"]), _p(state["o_bestdist"]), _p(state["o_bestscore"]),
+              _p(state["o_bestattack"]), _p(state["pred"]), _p(state["dist_val"]), _p(state.get("iter")),
+              _stream())
+
+
+def adam_step(perturb, sigma, g_perturb, g_sigma, m_p, v_p, m_s, v_s, step, lr_p, lr_s):
+    """One torch.optim.Adam-equivalent step on both parameter groups; ``step`` is a device int32[1]."""
+    g_perturb, g_sigma = g_perturb.contiguous(), g_sigma.contiguous()
+    _lib.call("hitadv_adam_step", _p(perturb), _p(g_perturb), _p(m_p), _p(v_p), perturb.numel(),
+              ctypes.c_float(lr_p), _p(sigma), _p(g_sigma), _p(m_s), _p(v_s), sigma.numel(),
+              ctypes.c_float(lr_s), _p(step), _stream())
+
+
+# --------------------------------------------------------------------------- FPS
+def fps_from_start(xyz, npoint, start):
+    """xyz[B,N,3], start[B] int64 -> idx[B,npoint] int64 (ShapeAttack/HiT_ADV.py:489-510 semantics)."""
+    xyz = _dev(xyz.detach(), "xyz")
+    start = _dev(start, "start", torch.int64)
+    B, N, _ = xyz.shape
+    idx = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
+    _lib.call("hitadv_fps_from_start", _p(xyz), _p(start), B, N, npoint, _p(idx), _stream())
+    return idx

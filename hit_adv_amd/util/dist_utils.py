@@ -1,0 +1,128 @@
+"""Distance operators with the reference's nn.Module protocol
+``dist(adv_pc, ori_pc, weights=None, batch_avg=True)`` (util/dist_utils.py:15-175, 258-294, 464-495).
+The set reductions and the kNN search run in HIP kernels; what is left in torch is O(B*N) glue.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..pytorch3d_ops import knn_gather, knn_points
+from .set_distance import chamfer, hausdorff
+
+
+def _apply_weights(loss, weights, batch_avg):
+    if weights is None:
+        weights = torch.ones(loss.shape[0])
+    loss = loss * weights.float().to(loss.device)
+    return loss.mean() if batch_avg else loss
+
+
+def _select(method, forward_term, backward_term):
+    if method == 'adv2ori':
+        return forward_term
+    if method == 'ori2adv':
+        return backward_term
+    return (forward_term + backward_term) / 2.
+
+
+class L2Dist(nn.Module):
+    """util/dist_utils.py:15-41."""
+
+    def forward(self, adv_pc, ori_pc, weights=None, batch_avg=True):
+        dist = torch.sqrt(torch.sum((adv_pc - ori_pc) ** 2, dim=[1, 2]) + 1e-7)
+        return _apply_weights(dist, weights, batch_avg)
+
+
+class ChamferDist(nn.Module):
+    """util/dist_utils.py:44-80."""
+
+    def __init__(self, method='adv2ori'):
+        super().__init__()
+        self.method = method
+
+    def forward(self, adv_pc, ori_pc, weights=None, batch_avg=True):
+        fwd, bwd = chamfer(adv_pc, ori_pc)
+        return _apply_weights(_select(self.method, fwd, bwd), weights, batch_avg)
+
+
+class HausdorffDist(nn.Module):
+    """util/dist_utils.py:83-119."""
+
+    def __init__(self, method='adv2ori'):
+        super().__init__()
+        self.method = method
+
+    def forward(self, adv_pc, ori_pc, weights=None, batch_avg=True):
+        fwd, bwd = hausdorff(adv_pc, ori_pc)
+        return _apply_weights(_select(self.method, fwd, bwd), weights, batch_avg)
+
+
+class KNNDist(nn.Module):
+    """kNN-distance penalty of the AAAI'20 attack, util/dist_utils.py:122-175.
+
+    The reference builds the full Gram matrix and takes topk(k+1); here one HIP kernel returns the
+    k+1 smallest squared distances per point directly (rank 0 is the point itself and is dropped,
+    as in :157-158)."""
+
+    def __init__(self, k=5, alpha=1.05):
+        super().__init__()
+        self.k = k
+        self.alpha = alpha
+
+    def forward(self, pc, weights=None, batch_avg=True):
+        if pc.shape[1] == 3:  # [B,3,K] -> [B,K,3]; a [B,K,3] input passes through (:146-147)
+            pc = pc.transpose(2, 1)
+        pc = pc.contiguous()
+        dists = knn_points(pc, pc, K=self.k + 1).dists
+        value = dists[..., 1:].mean(dim=-1)  # [B,K]
+        with torch.no_grad():
+            threshold = value.mean(dim=-1) + self.alpha * value.std(dim=-1)
+            mask = (value > threshold[:, None]).float()
+        return _apply_weights((value * mask).mean(dim=1), weights, batch_avg)
+
+
+class ChamferkNNDist(nn.Module):
+    """util/dist_utils.py:258-294."""
+
+    def __init__(self, chamfer_method='adv2ori', knn_k=5, knn_alpha=1.05, chamfer_weight=5., knn_weight=3.):
+        super().__init__()
+        self.chamfer_dist = ChamferDist(method=chamfer_method)
+        self.knn_dist = KNNDist(k=knn_k, alpha=knn_alpha)
+        self.w1 = chamfer_weight
+        self.w2 = knn_weight
+
+    def forward(self, adv_pc, ori_pc, weights=None, batch_avg=True):
+        return (self.chamfer_dist(adv_pc, ori_pc, weights=weights, batch_avg=batch_avg) * self.w1 +
+                self.knn_dist(adv_pc, weights=weights, batch_avg=batch_avg) * self.w2)
+
+
+def curvature_proxy(pc, normal, k):
+    """kappa[b,n] = mean_k |unit(x_nbr - x_n) . normal_n| over the k nearest neighbours and the kNN
+    index table it used.  pc, normal: [B,3,N].  (ShapeAttack/HiT_ADV.py:318-325, dist_utils.py:476-486)"""
+    pts = pc.permute(0, 2, 1).contiguous()
+    idx = knn_points(pts, pts, K=k + 1).idx
+    nbr = knn_gather(pts, idx)[:, :, 1:, :]  # [B,N,k,3]
+    vec = nbr - pts.unsqueeze(2)
+    vec = vec / vec.norm(2, dim=3, keepdim=True).clamp(min=1e-12)
+    kappa = (vec * normal.permute(0, 2, 1).unsqueeze(2)).sum(3).abs().mean(2)
+    return kappa, idx
+
+
+def curvature_std(pc, normal, k):
+    """Unbiased std of the neighbours' curvature proxy, [B,N] (HiT_ADV.py:327-339)."""
+    kappa, idx = curvature_proxy(pc, normal, k)
+    nbr_kappa = knn_gather(kappa.unsqueeze(2), idx)[:, :, 1:, 0]  # [B,N,k]
+    return nbr_kappa.std(dim=2), kappa, idx
+
+
+class CurvStdDist(nn.Module):
+    """util/dist_utils.py:464-495 (an eval_ASR metric, util/other_utils.py:39,75)."""
+
+    def __init__(self, k=5):
+        super().__init__()
+        self.k = k
+
+    def forward(self, ori_data, adv_data, ori_normal):
+        a = curvature_std(ori_data, ori_normal, self.k)[0]
+        b = curvature_std(adv_data, ori_normal, self.k)[0]
+        return torch.nn.PairwiseDistance(p=2)(a, b).mean()

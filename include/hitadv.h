@@ -1,0 +1,172 @@
+/*
+ * hitadv.h -- C ABI of libhitadv_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the HiT-ADV data-parallel hot path.  The reference
+ * (TRLou/HiT-ADV) has no FFI of its own for most of this path -- it is Python
+ * calling torch ops -- so each entry point below names the reference code it
+ * replaces (file:line relative to the reference root).  The nine pointnet2_ops
+ * entry points mirror the reference's own `*_kernel_wrapper` prototypes
+ * (pointnet2_ops_lib/pointnet2_ops/_ext-src/src/{sampling,ball_query,
+ * group_points,interpolate}.cpp) one for one.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM), fp32 / int32 / int64 as typed,
+ *     dense row-major ("contiguous") in the shapes given;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     every call only enqueues work -- no allocation, no synchronisation, so
+ *     calls may be captured into a hipGraph;
+ *   - return value: 0 on success, a hipError_t code if the launch failed,
+ *     HITADV_E_ARG (-1) for an invalid argument.  Nothing calls exit() (the
+ *     reference's CUDA_CHECK_ERRORS does, include/cuda_utils.h:30-39);
+ *   - inputs are never written; outputs are fully overwritten unless stated.
+ *
+ * Squared distances in the "direct" form are evaluated in fp32 as
+ * ((dx*dx + dy*dy) + dz*dz), one rounding per operation, no FMA contraction,
+ * which is what makes index outputs bit-reproducible against the CPU oracle.
+ */
+#ifndef HITADV_H
+#define HITADV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HITADV_E_ARG (-1)
+
+#define HITADV_FORM_DIRECT 0 /* ((dx*dx+dy*dy)+dz*dz)                           */
+#define HITADV_FORM_GRAM 1   /* (|x|^2+|y|^2) - 2 x.y  (util/set_distance.py:31) */
+
+/* Library / build identification (static string). */
+const char *hitadv_version(void);
+
+/* ------------------------------------------------------------------ set distances */
+
+/* P[b,i,j] = |x_i - y_j|^2.  x[B,N,D], y[B,M,D] -> P[B,N,M].
+ * Replaces _Distance.batch_pairwise_dist (util/set_distance.py:15-32) and its inline
+ * variants (util/dist_utils.py:148-150, model/dgcnn_cls.py:8-10).
+ * D == 3 is the tuned path (HBM-store-bound); other D use a generic kernel that always
+ * evaluates the direct form. */
+int hitadv_pairwise_sqdist(const float *x, const float *y, float *P, int B, int N, int M, int D,
+                           int form, void *stream);
+
+/* Fused nearest-neighbour reduction in both directions, no matrix materialised (D == 3):
+ *   min_x[b,i] = min_j |x_i - y_j|^2, arg_x[b,i] = lowest such j   (and symmetrically for y).
+ * Replaces the two torch.min passes of ChamferDistance/HausdorffDistance.forward
+ * (util/set_distance.py:40-50, 58-70).  For D != 3, `scratch` must hold B*N*M floats.
+ * Any of the four outputs may be NULL only in pairs (min_y/arg_y together). */
+int hitadv_nn_min(const float *x, const float *y, int B, int N, int M, int D, float *min_x,
+                  int32_t *arg_x, float *min_y, int32_t *arg_y, float *scratch, void *stream);
+
+/* Backward of hitadv_nn_min through the saved arg-mins (what autograd does through
+ * torch.min at util/set_distance.py:46-49):
+ *   grad_x[b,i,:] = 2 g_min_x[b,i] (x_i - y_arg_x[i]) + sum_{j: arg_y[j]==i} 2 g_min_y[b,j] (x_i - y_j)
+ * and symmetrically grad_y (skipped when grad_y == NULL).  Deterministic (no atomics). */
+int hitadv_nn_min_bwd(const float *x, const float *y, const int32_t *arg_x, const int32_t *arg_y,
+                      const float *g_min_x, const float *g_min_y, int B, int N, int M, int D,
+                      float *grad_x, float *grad_y, void *stream);
+
+/* K nearest neighbours, direct form, ascending, ties -> lower index.  q[B,N,3], p[B,M,3] ->
+ * dists[B,N,K], idx[B,N,K] (int64 when idx_is_i64 != 0, else int32).  1 <= K <= min(M, 64).
+ * Replaces pytorch3d.ops.knn_points as called at ShapeAttack/HiT_ADV.py:78,320,329 and
+ * util/dist_utils.py:482, and the Gram+topk of KNNDist (util/dist_utils.py:148-158). */
+int hitadv_knn_points(const float *q, const float *p, int B, int N, int M, int K, float *dists,
+                      void *idx, int idx_is_i64, void *stream);
+
+/* Backward of hitadv_knn_points w.r.t. both point sets, given g_dists[B,N,K]:
+ *   grad_q[b,i,:]  =  sum_t 2 g[b,i,t] (q_i - p_idx[b,i,t])
+ *   grad_p[b,j,:]  = -sum_{(i,t): idx[b,i,t]==j} 2 g[b,i,t] (q_i - p_j)      (deterministic)
+ * grad_q or grad_p may be NULL. */
+int hitadv_knn_points_bwd(const float *q, const float *p, const void *idx, int idx_is_i64,
+                          const float *g_dists, int B, int N, int M, int K, float *grad_q,
+                          float *grad_p, void *stream);
+
+/* ------------------------------------------------------------------ HiT-ADV deformation */
+
+/* Kernel-weighted deformation, replaces HiT_ADV.kernel_density + the C-step accumulation loop
+ * (ShapeAttack/HiT_ADV.py:160-175, 298-304):
+ *   k[n,j] = exp(-|x_n - c_j|_2 / (2 sigma_j^2)),   adv_n = x_n + (sum_j k p_j) / (sum_j k)
+ * ori[B,3,N], central[B,3,C], perturb[B,C,3], sigma[B,C] -> adv[B,3,N], inv_den[B,N] (=1/sum_j k,
+ * saved for the backward).  */
+int hitadv_deform_fwd(const float *ori, const float *central, const float *perturb,
+                      const float *sigma, int B, int N, int C, float *adv, float *inv_den,
+                      void *stream);
+
+/* Gradient of the above w.r.t. perturb and sigma for upstream g_adv[B,3,N].
+ * `partials` is caller scratch of hitadv_deform_bwd_scratch_floats(B,N,C) floats.
+ * Accumulation order is fixed -> bitwise reproducible. */
+int hitadv_deform_bwd(const float *ori, const float *central, const float *perturb,
+                      const float *sigma, const float *adv, const float *inv_den,
+                      const float *g_adv, int B, int N, int C, float *partials,
+                      float *grad_perturb, float *grad_sigma, void *stream);
+int64_t hitadv_deform_bwd_scratch_floats(int B, int N, int C);
+
+/* ------------------------------------------------------------------ attack-state kernels */
+
+/* On-device replacement of the per-iteration host bookkeeping (ShapeAttack/HiT_ADV.py:186-217):
+ * pred = argmax(logits[b,:]) (lowest index on ties), dist_val[b] = (|P_b|_F + |1-sigma_b|_2)/C
+ * (transformation_loss batch_avg=False, :313-316), then, only when pred != label,
+ * strict-'<' updates of (bestdist,bestscore) and (o_bestdist,o_bestscore,o_bestattack[b,:,:]=adv[b]).
+ * Also writes pred_out[B] (int64) and dist_val_out[B], and adds 1 to *iter_counter if non-NULL. */
+int hitadv_best_update(const float *logits, const int64_t *label, const float *perturb,
+                       const float *sigma, const float *adv, int B, int num_class, int N, int C,
+                       float *bestdist, int64_t *bestscore, float *o_bestdist, int64_t *o_bestscore,
+                       float *o_bestattack, int64_t *pred_out, float *dist_val_out,
+                       int32_t *iter_counter, void *stream);
+
+/* Adam step for the two parameter groups of ShapeAttack/HiT_ADV.py:142-145 in one launch
+ * (torch.optim.Adam defaults: betas (0.9,0.999), eps 1e-8, no weight decay, no amsgrad).
+ * *step is incremented by the kernel (device-side counter -> graph-capturable). */
+int hitadv_adam_step(float *perturb, const float *g_perturb, float *m_perturb, float *v_perturb,
+                     int64_t n_perturb, float lr_perturb, float *sigma, const float *g_sigma,
+                     float *m_sigma, float *v_sigma, int64_t n_sigma, float lr_sigma,
+                     int32_t *step, void *stream);
+
+/* ------------------------------------------------------------------ farthest point sampling */
+
+/* FPS with a given first index per cloud; running distance 1e10, strict-'<' update, arg-max with
+ * lowest index on ties.  xyz[B,N,3], start[B] -> idx[B,m] (int64).
+ * Replaces HiT_ADV.farthest_point_sample (ShapeAttack/HiT_ADV.py:489-510; the random start of
+ * :501 is drawn by the caller) and model/pointnet2_utils.py:63-84. */
+int hitadv_fps_from_start(const float *xyz, const int64_t *start, int B, int N, int m,
+                          int64_t *idx, void *stream);
+
+/* ------------------------------------------------------------------ pointnet2_ops natives
+ * One for one with the reference's kernel wrappers; same argument order.               */
+
+/* src/sampling.cpp:11-13 furthest_point_sampling_kernel_wrapper.  temp[B,N] is scratch that this
+ * call initialises itself (the reference's host code fills it with 1e10, sampling.cpp:70-76).
+ * Starts at index 0, skips points with |p|^2 <= 1e-3, reference tie rule (thread-slot order). */
+int hitadv_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                   int32_t *idxs, void *stream);
+/* src/sampling.cpp:4-6 */
+int hitadv_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,
+                         float *out, void *stream);
+/* src/sampling.cpp:7-9; grad_points[b,c,n] is fully overwritten (deterministic, no atomics). */
+int hitadv_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                              const int32_t *idx, float *grad_points, void *stream);
+/* src/ball_query.cpp:4-6; idx[b,m,nsample] is fully written (zeros for an empty ball). */
+int hitadv_query_ball_point(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                            const float *xyz, int32_t *idx, void *stream);
+/* src/group_points.cpp:4-6 */
+int hitadv_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                        const int32_t *idx, float *out, void *stream);
+/* src/group_points.cpp:8-10; grad_points fully overwritten (deterministic). */
+int hitadv_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                             const int32_t *idx, float *grad_points, void *stream);
+/* src/interpolate.cpp:4-5 */
+int hitadv_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                    int32_t *idx, void *stream);
+/* src/interpolate.cpp:6-8 */
+int hitadv_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                             const float *weight, float *out, void *stream);
+/* src/interpolate.cpp:9-12; grad_points fully overwritten (deterministic). */
+int hitadv_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                  const int32_t *idx, const float *weight, float *grad_points,
+                                  void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HITADV_H */

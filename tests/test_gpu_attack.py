@@ -1,0 +1,172 @@
+"""GPU parity of the attack classes (HiT_ADV, CWKNN) against trajectories captured from the
+reference (g5/g5b/g7) and against the CPU oracle on fresh inputs."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, golden, hp_from_fixture, synth_batch, toy_from_fixture
+from oracle import hitadv_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-4, atol=1e-6):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def _attacker(fx, **kw):
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    return HiT_ADV(toy_from_fixture(fx), adv_func=UntargetedLogitsAdvLoss(kappa=30.), verbose=False,
+                   **hp_from_fixture(fx), **kw)
+
+
+class _Recorder:
+    """Wraps an attacker's iteration to record (P, sigma) before and adv/pred after each pass."""
+
+    def __init__(self, att):
+        self.att, self.rows = att, []
+        self.inner = att._iteration
+        att._iteration = self
+
+    def __call__(self, ws):
+        self.inner(ws)
+        torch.cuda.synchronize()
+        self.rows.append(dict(P=ws.P.detach().cpu().numpy().copy(), sigma=ws.sigma.detach().cpu().numpy().copy(),
+                              adv=ws.adv.cpu().numpy().copy(), pred=ws.state['pred'].cpu().numpy().copy(),
+                              adv_loss=ws.adv_loss.item()))
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_hit_adv_follows_reference_trajectory(use_graph):
+    fx = golden('g5_attack.npz')
+    att = _attacker(fx, use_graph=use_graph)
+    rec = _Recorder(att) if not use_graph else None
+    torch.manual_seed(int(fx['seed']))
+    best, succ = att.attack(T(fx['data']), T(fx['target']))
+    assert att.last_graph_used == bool(use_graph)
+    ws = next(iter(att._ws.values()))
+    assert torch.equal(ws.central.cpu(), T(fx['central']))  # same centres selected, bit for bit
+    assert best.dtype == np.float64 and best.shape == fx['best'].shape
+    assert isinstance(succ, torch.Tensor) and succ.dtype == torch.int64 and succ.dim() == 0
+    assert int(succ) == int(fx['success_num'])
+    close(best, fx['best'], rtol=1e-4, atol=2e-5)
+    if rec is not None:
+        n = len(rec.rows)
+        assert n == 20
+        for i, row in enumerate(rec.rows):
+            close(row['adv'], fx['adv'][i], rtol=1e-4, atol=2e-5)
+            assert (row['pred'] == fx['logits'][i].argmax(1)).all()
+            close(row['adv_loss'], fx['adv_loss'][i], rtol=1e-4, atol=1e-5)
+            if (i + 1) % 10:  # next fixture row = this iteration's updated parameters, clamped
+                close(np.clip(row['P'], -0.55, 0.55), fx['P'][i + 1], rtol=1e-4, atol=2e-5)
+                close(np.clip(row['sigma'], 0.1, 1.2), fx['sigma'][i + 1], rtol=1e-4, atol=2e-5)
+
+
+def test_hit_adv_wide_configuration_vs_reference():
+    fx = golden('g5b_attack_wide.npz')  # N=1024, C=192, T=256: eval.py sizes
+    att = _attacker(fx)
+    torch.manual_seed(int(fx['seed']))
+    best, succ = att.attack(T(fx['data']), T(fx['target']))
+    ws = next(iter(att._ws.values()))
+    assert torch.equal(ws.central.cpu(), T(fx['central']))
+    close(ws.adv, fx['adv'], rtol=1e-4, atol=2e-5)
+    close(best, fx['best'], rtol=1e-4, atol=2e-5)
+    assert int(succ) == int(fx['success_num'])
+
+
+def test_hit_adv_graph_and_eager_agree_and_prints_progress():
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    fx = golden('g5_attack.npz')
+    model = toy_from_fixture(fx)
+    data, _ = synth_batch(6, 512, first=500)
+    with torch.no_grad():
+        target = model(data[:, :, :3].transpose(1, 2).contiguous()).argmax(1)
+    outs = []
+    for graph in (False, True):
+        att = HiT_ADV(model, UntargetedLogitsAdvLoss(30.), binary_step=3, num_iter=15, cd_weight=1e-4,
+                      ker_weight=1., hide_weight=1., curv_loss_knn=16, central_num=48, total_central_num=64,
+                      max_sigm=1.2, min_sigm=0.1, budget=0.55, use_graph=graph)
+        torch.manual_seed(99)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            outs.append(att.attack(data, target))
+        text = buf.getvalue()
+        assert text.count('Step ') == 15 and 'Successfully attack' in text and 'lower_bound is' in text
+    assert np.array_equal(outs[0][0], outs[1][0])  # same kernels, same order: bitwise equal
+    assert int(outs[0][1]) == int(outs[1][1])
+    # oracle on the same inputs / draws
+    oracle = O.HiTADVOracle(model.cpu(), lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), binary_step=3,
+                            num_iter=15, cd_weight=1e-4, ker_weight=1., hide_weight=1., curv_loss_knn=16,
+                            central_num=48, total_central_num=64, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+    torch.manual_seed(99)
+    ref_best, ref_succ = oracle.attack(data, target)
+    assert int(ref_succ) == int(outs[0][1])
+    close(outs[0][0], ref_best, rtol=1e-3, atol=1e-4)  # 45 chaotic Adam steps apart in fp32
+
+
+def test_cwknn_follows_reference_trajectory():
+    from hit_adv_amd.CW.kNN import CWKNN
+    from hit_adv_amd.util.adv_utils import LogitsAdvLoss
+    from hit_adv_amd.util.clip_utils import ClipPointsLinf
+    from hit_adv_amd.util.dist_utils import ChamferkNNDist
+    fx = golden('g7_cwknn.npz')
+    trace = []
+    clip = ClipPointsLinf(budget=0.18)
+
+    def recording_clip(pc, ori):
+        out = clip(pc, ori)
+        trace.append(out.detach().cpu().numpy().copy())
+        return out
+
+    att = CWKNN(toy_from_fixture(fx), LogitsAdvLoss(kappa=15.), ChamferkNNDist(), recording_clip,
+                attack_lr=1e-2, num_iter=10, verbose=False)
+    torch.manual_seed(int(fx['seed']))
+    final, succ = att.attack(T(fx['data']), T(fx['target']))
+    assert final.dtype == np.float32 and final.shape == fx['final'].shape
+    # The reference's own trajectory cannot be a tight target here: at iteration 0 every point sits
+    # 1e-7 from its original, where the Gram-form distances (and their gradients 2x_i - 2y_j) of the
+    # reference are pure fp32 rounding noise, and Adam's first step (+-lr * sign(g)) amplifies that
+    # noise to +-1e-2 per coordinate.  So: (a) tight parity against the oracle evaluated with the
+    # SAME direct-form distances, (b) the clip invariant and a loose envelope against the fixture.
+    def direct_chamfer_knn(adv, ori):
+        P = O.pairwise_sqdist_direct(ori, adv)  # [B,N2,N1]
+        cham = P.min(dim=1).values.mean(dim=1)
+        S = torch.sort(O.pairwise_sqdist_direct(adv, adv), dim=-1, stable=True).values[..., 1:6].mean(-1)
+        with torch.no_grad():
+            mask = (S > (S.mean(-1) + 1.05 * S.std(-1))[:, None]).float()
+        return cham * 5. + (S * mask).mean(1) * 3.
+
+    torch.manual_seed(int(fx['seed']))
+    otrace = []
+    ofinal, osucc = O.cw_knn_attack(toy_from_fixture(fx), lambda l, t: O.logits_adv_loss(l, t, 15.),
+                                    direct_chamfer_knn, lambda pc, ori: O.clip_points_linf(pc, ori, 0.18),
+                                    T(fx['data']), T(fx['target']), attack_lr=1e-2, num_iter=10, trace=otrace)
+    for i, row in enumerate(trace):
+        np.testing.assert_allclose(row, otrace[i]['adv'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(final, ofinal, rtol=1e-4, atol=1e-5)
+    assert succ == osucc
+    ori = np.transpose(fx['data'], (0, 2, 1))
+    for i, row in enumerate(trace):
+        assert np.abs(row - ori).max() <= 0.18 + 1e-6
+        assert np.abs(row - fx['adv_trace'][i]).max() <= 2 * 1e-2 * (i + 1) + 1e-6
+
+
+def test_pointnet_victim_loads_reference_layout_and_runs():
+    from helpers import golden_json
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    shapes = golden_json('g8_state_dicts.json')
+    torch.manual_seed(0)
+    m = PointNetFeatureModel(40, normal_channel=False)
+    sd = m.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == shapes['pointnet']
+    assert sum(p.numel() for p in m.parameters()) == shapes['pointnet_param_count']
+    m = m.cuda()
+    logits, trans_feat = m(torch.randn(4, 3, 1024, device='cuda'))
+    assert logits.shape == (4, 40) and trans_feat.shape == (4, 64, 64)

@@ -1,0 +1,444 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (hit_adv_amd.ops / _ext -> ctypes ->
+libhitadv_hip.so), against the CPU oracle and the golden vectors captured from the reference.
+
+Bar: bit-exact for every index output and for direct-form squared distances; for floating point
+results the tolerance is written next to each assertion.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, golden, synth_batch
+from oracle import c_oracle as N
+from oracle import hitadv_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+EPS = float(np.finfo(np.float32).eps)
+
+
+@pytest.fixture(scope="module")
+def A():
+    import hit_adv_amd.ops as ops
+    from hit_adv_amd import _lib
+    _lib.load()
+    return ops
+
+
+def cu(t):
+    return t.cuda()
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def clouds(b, n, first=0):
+    data, _ = synth_batch(b, n, first=first)
+    return data[:, :, :3].contiguous(), data[:, :, 3:].contiguous()
+
+
+# ------------------------------------------------------------------ K1 pairwise
+@pytest.mark.parametrize("n,m", [(1024, 1024), (256, 1024), (100, 1001), (7, 3), (1, 1)])
+def test_pairwise_direct_bit_exact(A, n, m):
+    x, _ = clouds(2, n, 100)
+    y, _ = clouds(2, m, 110)
+    P = A.pairwise_sqdist(cu(x), cu(y), A.FORM_DIRECT).cpu()
+    assert torch.equal(P, O.pairwise_sqdist_direct(x, y))
+
+
+@pytest.mark.parametrize("n,m", [(1024, 1024), (100, 1001)])
+def test_pairwise_gram_within_gram_noise(A, n, m):
+    x, _ = clouds(2, n, 100)
+    y, _ = clouds(2, m, 110)
+    P = A.pairwise_sqdist(cu(x), cu(y), A.FORM_GRAM).cpu()
+    ref = O.pairwise_sqdist_gram(x, y)
+    # both sides evaluate |x|^2+|y|^2-2x.y in fp32; they differ by the rounding of 3-term dot products
+    scale = float((x ** 2).sum(-1).max() + (y ** 2).sum(-1).max())
+    assert (P - ref).abs().max().item() <= 8 * EPS * scale
+    truth = ((x.double()[:, :, None] - y.double()[:, None]) ** 2).sum(-1)
+    assert (P - truth).abs().max().item() <= 8 * EPS * scale
+
+
+def test_pairwise_generic_dim(A):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 70, generator=g)
+    y = torch.randn(2, 4, 70, generator=g)
+    P = A.pairwise_sqdist(cu(x), cu(y)).cpu()
+    truth = ((x.double()[:, :, None] - y.double()[:, None]) ** 2).sum(-1)
+    close(P, truth.float(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ K2 fused NN-min
+@pytest.mark.parametrize("n,m", [(1024, 1024), (256, 1024), (1000, 37), (1, 5), (130, 2049)])
+def test_nn_min_bit_exact_both_directions(A, n, m):
+    x, _ = clouds(3, n, 120)
+    y, _ = clouds(3, m, 130)
+    mx, ax, my, ay = (t.cpu() for t in A.nn_min(cu(x), cu(y)))
+    rx, rax = N.nn_min(x, y)
+    ry, ray = N.nn_min(y, x)
+    assert torch.equal(mx, rx) and torch.equal(ax, rax)
+    assert torch.equal(my, ry) and torch.equal(ay, ray)
+
+
+def test_nn_min_ties_take_lowest_index(A):
+    x, _ = clouds(1, 64, 140)
+    y = torch.cat([x, x, x], 1)  # every query has three exact nearest neighbours at distance 0
+    mx, ax, my, ay = (t.cpu() for t in A.nn_min(cu(x), cu(y)))
+    assert (mx == 0).all() and torch.equal(ax[0], torch.arange(64, dtype=torch.int32))
+    assert (my == 0).all() and torch.equal(ay[0], torch.arange(64, dtype=torch.int32).repeat(3))
+
+
+def test_nn_min_generic_dim_q1_shape(A):
+    # quirk Q1: [B,3,N] tensors, i.e. 3 "points" of dimension N
+    x, _ = clouds(2, 1024, 150)
+    y = x + 0.01 * torch.randn(x.shape, generator=torch.Generator().manual_seed(3))
+    xt, yt = x.transpose(1, 2).contiguous(), y.transpose(1, 2).contiguous()
+    mx, ax, my, ay = (t.cpu() for t in A.nn_min(cu(xt), cu(yt)))
+    P = ((xt.double()[:, :, None] - yt.double()[:, None]) ** 2).sum(-1)
+    close(mx, P.min(2).values.float(), rtol=1e-5)
+    close(my, P.min(1).values.float(), rtol=1e-5)
+    assert torch.equal(ax.long(), P.argmin(2)) and torch.equal(ay.long(), P.argmin(1))
+
+
+def test_set_distance_modules_vs_reference_vectors(A):
+    from hit_adv_amd.util import dist_utils, set_distance
+    fx = golden('g1_set_distance.npz')
+    adv, ori, small, w = (cu(T(fx[k])) for k in ('adv', 'ori', 'small', 'weights'))
+    # the reference evaluates the Gram form whose own fp32 noise is ~4*eps*(|x|^2+|y|^2) per entry;
+    # min-values here are ~1e-3, so means agree to ~1e-5 relative and maxima to the noise floor.
+    noise = 8 * EPS * 2.0
+    for name, mod, a, b in (('chamfer', set_distance.chamfer, adv, ori),
+                            ('hausdorff', set_distance.hausdorff, adv, ori),
+                            ('chamfer_small', set_distance.chamfer, small, ori),
+                            ('hausdorff_small', set_distance.hausdorff, small, ori)):
+        l1, l2 = mod(a, b)
+        close(l1, fx[name + '_l1'], rtol=1e-5, atol=noise)
+        close(l2, fx[name + '_l2'], rtol=1e-5, atol=noise)
+    for m in ('adv2ori', 'ori2adv', 'both'):
+        close(dist_utils.ChamferDist(m)(adv, ori, w, batch_avg=False), fx['ChamferDist_%s' % m], atol=noise)
+        close(dist_utils.HausdorffDist(m)(adv, ori, w, batch_avg=False), fx['HausdorffDist_%s' % m], atol=noise)
+    close(dist_utils.ChamferDist()(adv, ori), fx['ChamferDist_avg'], atol=noise)
+    close(dist_utils.HausdorffDist()(adv, ori), fx['HausdorffDist_avg'], atol=noise)
+    q1 = dist_utils.ChamferDist()(adv.transpose(1, 2).contiguous(), ori.transpose(1, 2).contiguous(),
+                                  torch.from_numpy(np.ones(2) * 1e-4), batch_avg=False)
+    close(q1, fx['ChamferDist_q1'], rtol=1e-4)
+    a = adv.clone().requires_grad_()
+    dist_utils.ChamferDist('both')(a, ori, w).backward()
+    close(a.grad, fx['ChamferDist_both_grad'], rtol=1e-5, atol=1e-7)
+    a = adv.clone().requires_grad_()
+    dist_utils.HausdorffDist('both')(a, ori, w).backward()
+    close(a.grad, fx['HausdorffDist_both_grad'], rtol=1e-5, atol=1e-7)
+
+
+def test_nn_min_backward_matches_autograd_of_direct_matrix(A):
+    x, _ = clouds(2, 300, 160)
+    y, _ = clouds(2, 257, 170)
+    g = torch.Generator().manual_seed(5)
+    wx, wy = torch.randn(2, 300, generator=g), torch.randn(2, 257, generator=g)
+    xr, yr = x.clone().requires_grad_(), y.clone().requires_grad_()
+    P = O.pairwise_sqdist_direct(xr, yr)
+    ((P.min(2).values * wx).sum() + (P.min(1).values * wy).sum()).backward()
+    xg, yg = cu(x).requires_grad_(), cu(y).requires_grad_()
+    mx, _, my, _ = A.nn_min(xg, yg)
+    ((mx * cu(wx)).sum() + (my * cu(wy)).sum()).backward()
+    close(xg.grad, xr.grad, rtol=1e-5, atol=1e-6)
+    close(yg.grad, yr.grad, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ K4 kNN
+@pytest.mark.parametrize("K", [1, 5, 6, 17, 33, 64])
+def test_knn_points_bit_exact(A, K):
+    from hit_adv_amd.pytorch3d_ops import knn_points
+    x, _ = clouds(2, 1024, 180)
+    q = x[:, :300].contiguous()
+    r = knn_points(cu(q), cu(x), K=K)
+    d, ix = N.knn_points(q, x, K)
+    assert r.idx.dtype == torch.int64
+    assert torch.equal(r.idx.cpu(), ix) and torch.equal(r.dists.cpu(), d)
+
+
+def test_knn_points_duplicates_ragged_and_gather(A):
+    from hit_adv_amd.pytorch3d_ops import knn_gather, knn_points
+    x, _ = clouds(2, 77, 190)
+    dup = torch.cat([x[:, :9], x[:, :9], x], 1)  # M = 95, exact ties
+    r = knn_points(cu(dup), cu(dup), K=4, return_nn=True)
+    d, ix = N.knn_points(dup, dup, 4)
+    assert torch.equal(r.idx.cpu(), ix) and torch.equal(r.dists.cpu(), d)
+    assert torch.equal(r.knn.cpu(), O.knn_gather(dup, ix))
+    assert torch.equal(knn_gather(cu(dup), r.idx).cpu(), O.knn_gather(dup, ix))
+    with pytest.raises(RuntimeError):
+        knn_points(cu(x), cu(x), K=78)
+
+
+def test_knn_points_backward(A):
+    from hit_adv_amd.pytorch3d_ops import knn_points
+    x, _ = clouds(2, 200, 200)
+    y, _ = clouds(2, 150, 210)
+    w = torch.randn(2, 200, 5, generator=torch.Generator().manual_seed(6))
+    xr, yr = x.clone().requires_grad_(), y.clone().requires_grad_()
+    P = O.pairwise_sqdist_direct(xr, yr)
+    (torch.sort(P, dim=-1, stable=True).values[..., :5] * w).sum().backward()
+    xg, yg = cu(x).requires_grad_(), cu(y).requires_grad_()
+    (knn_points(xg, yg, K=5).dists * cu(w)).sum().backward()
+    close(xg.grad, xr.grad, rtol=1e-5, atol=1e-6)
+    close(yg.grad, yr.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_knn_dist_operators_vs_reference_vectors(A):
+    from hit_adv_amd.util import dist_utils
+    fx = golden('g2_knn_dist.npz')
+    ori, nrm, adv = (cu(T(fx[k])) for k in ('ori', 'normal', 'adv'))
+    # reference values carry the Gram form's fp32 noise (~4*eps*2 per distance, distances ~1e-3)
+    for k in (4, 5):
+        close(dist_utils.KNNDist(k=k)(adv, batch_avg=False), fx['KNNDist_k%d' % k], rtol=2e-4)
+        close(dist_utils.KNNDist(k=k)(adv.transpose(1, 2).contiguous(), batch_avg=False),
+              fx['KNNDist_k%d_chfirst' % k], rtol=2e-4)
+    close(dist_utils.ChamferkNNDist()(adv, ori, batch_avg=False), fx['ChamferkNNDist'], rtol=2e-4)
+    ori_t, adv_t, nrm_t = (t.transpose(1, 2).contiguous() for t in (ori, adv, nrm))
+    close(dist_utils.CurvStdDist(k=4)(ori_t, adv_t, nrm_t), fx['CurvStdDist_k4'], rtol=1e-5)
+    kstd, kappa, _ = dist_utils.curvature_std(ori_t, nrm_t, 16)
+    close(kappa, fx['kappa_k16'], rtol=1e-5)
+    close(kstd, fx['kappa_std_k16'], rtol=1e-5, atol=1e-7)
+
+
+def test_knn_dist_grad_vs_direct_form_oracle(A):
+    """Gradient parity against autograd through the same (direct-form) distances; the reference's
+    Gram-form gradient differs only through which near-tied point is selected/thresholded."""
+    from hit_adv_amd.util import dist_utils
+    x, _ = clouds(2, 400, 220)
+    w = torch.tensor([0.5, 2.0])
+
+    def oracle_direct(pc):
+        d = torch.sort(O.pairwise_sqdist_direct(pc, pc), dim=-1, stable=True).values[..., 1:6].mean(-1)
+        with torch.no_grad():
+            mask = (d > (d.mean(-1) + 1.05 * d.std(-1))[:, None]).float()
+        return ((d * mask).mean(1) * w).mean()
+
+    xr = x.clone().requires_grad_()
+    oracle_direct(xr).backward()
+    xg = cu(x).requires_grad_()
+    v = dist_utils.KNNDist(k=5)(xg, cu(w))
+    v.backward()
+    close(v, oracle_direct(x), rtol=1e-5)
+    close(xg.grad, xr.grad, rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------ K3 deformation
+@pytest.mark.parametrize("C", [16, 192])
+def test_deform_forward_backward_vs_reference_vectors(A, C):
+    fx = golden('g3_deform.npz')
+    p = 'c%d_' % C
+    ori, central, up = cu(T(fx['ori'])), cu(T(fx[p + 'central'])), cu(T(fx[p + 'upstream']))
+    P = cu(T(fx[p + 'P'])).requires_grad_()
+    sig = cu(T(fx[p + 'sigma'])).requires_grad_()
+    adv = A.deform(ori, central, P, sig)
+    close(adv, fx[p + 'adv'], rtol=1e-5, atol=2e-6)  # fused sum vs 192-step fp32 accumulation
+    (adv * up).sum().backward()
+    scale_p = float(np.abs(fx[p + 'grad_P']).max())
+    scale_s = float(np.abs(fx[p + 'grad_sigma']).max())
+    close(P.grad, fx[p + 'grad_P'], rtol=1e-4, atol=1e-5 * scale_p)
+    close(sig.grad, fx[p + 'grad_sigma'], rtol=1e-4, atol=1e-5 * scale_s)
+
+
+def test_deform_identity_and_ragged_sizes(A):
+    x, _ = clouds(3, 1000, 230)
+    ori = cu(x.transpose(1, 2).contiguous())
+    central = ori[:, :, :37].contiguous()
+    sig = torch.full((3, 37), 0.4, device='cuda')
+    adv = A.deform(ori, central, torch.zeros(3, 37, 3, device='cuda'), sig)
+    assert torch.equal(adv, ori)  # zero translations leave every point where it was, exactly
+    P = torch.rand(3, 37, 3, generator=torch.Generator().manual_seed(2)) - 0.5
+    adv = A.deform(ori, central, cu(P), sig).cpu()
+    ref = O.deform_loop(x.transpose(1, 2).contiguous(), P,
+                        O.kernel_density(central.cpu(), x.transpose(1, 2).contiguous(), sig.cpu()))
+    close(adv, ref, rtol=1e-5, atol=2e-6)
+
+
+# ------------------------------------------------------------------ K5 FPS + natives
+def test_fps_from_start_vs_reference_vector(A):
+    fx = golden('g4_fps.npz')
+    idx = A.fps_from_start(cu(T(fx['xyz'])), 256, cu(T(fx['start'])))
+    assert idx.dtype == torch.int64 and (idx.cpu().numpy() == fx['idx']).all()
+
+
+@pytest.mark.parametrize("n,m", [(1024, 256), (2048, 512), (300, 300), (64, 5), (5000, 64)])
+def test_fps_from_start_bit_exact_sizes(A, n, m):
+    x, _ = clouds(3, n, 240)
+    start = torch.tensor([0, n - 1, n // 2])
+    assert torch.equal(A.fps_from_start(cu(x), m, cu(start)).cpu(), N.fps_from_start(x, m, start))
+
+
+@pytest.mark.parametrize("n,m", [(1024, 51), (2048, 102), (300, 64), (700, 700), (5000, 33)])
+def test_fps_ext_bit_exact(A, n, m):
+    from hit_adv_amd.pointnet2_ops import _ext
+    x, _ = clouds(3, n, 250)
+    x[1, : n // 3] *= 0.01  # a block of near-origin points that the kernel must skip
+    x[2, 5] = x[2, 9]
+    out = _ext.furthest_point_sampling(cu(x), m)
+    assert out.dtype == torch.int32 and torch.equal(out.cpu(), N.furthest_point_sampling(x, m))
+
+
+def test_fps_ext_known_answers(A):
+    from hit_adv_amd.pointnet2_ops import _ext
+    line = torch.zeros(1, 8, 3)
+    line[0, :, 0] = torch.arange(1, 9).float()
+    assert _ext.furthest_point_sampling(cu(line), 4)[0].tolist() == [0, 7, 4, 2]
+    skip = torch.tensor([[[1., 0, 0], [0.01, 0, 0], [0, 0.02, 0], [-1., 0, 0], [0, 1., 0]]])
+    assert _ext.furthest_point_sampling(cu(skip), 3)[0].tolist() == [0, 3, 4]
+    assert _ext.furthest_point_sampling(cu(torch.zeros(1, 4, 3)), 3)[0].tolist() == [0, 0, 0]
+    tie = torch.zeros(1, 1024, 3)
+    tie[0, :, 0] = 0.1
+    tie[0, 1] = torch.tensor([0.1, 0.5, 0.0])
+    tie[0, 514] = torch.tensor([0.1, -0.5, 0.0])
+    assert _ext.furthest_point_sampling(cu(tie), 2)[0].tolist() == [0, 514]
+
+
+def test_ball_query_group_gather_bit_exact(A):
+    from hit_adv_amd.pointnet2_ops import _ext
+    x, _ = clouds(3, 1024, 260)
+    fidx = N.furthest_point_sampling(x, 51)
+    flipped = x.transpose(1, 2).contiguous()
+    new_xyz = N.gather_points(flipped, fidx).transpose(1, 2).contiguous()
+    g_new = _ext.gather_points(cu(flipped), cu(fidx))
+    assert torch.equal(g_new.cpu(), N.gather_points(flipped, fidx))
+    for r, ns in ((0.126, 16), (0.2, 49), (0.01, 8), (5.0, 70)):
+        ref = N.ball_query(new_xyz, x, r, ns)
+        out = _ext.ball_query(cu(new_xyz), cu(x), r, ns)
+        assert out.dtype == torch.int32 and torch.equal(out.cpu(), ref)
+        assert torch.equal(_ext.group_points(cu(flipped), out).cpu(), N.group_points(flipped, ref))
+    kx = torch.tensor([[[0., 0, 0], [0.5, 0, 0], [1.0, 0, 0], [0.2, 0, 0], [5, 5, 5]]])
+    kq = torch.tensor([[[0., 0, 0], [9., 9, 9], [1.0, 0, 0]]])
+    assert _ext.ball_query(cu(kq), cu(kx), 0.5, 3)[0].tolist() == [[0, 3, 0], [0, 0, 0], [2, 2, 2]]
+    assert _ext.ball_query(cu(kq), cu(kx), 0.6, 2)[0].tolist() == [[0, 1], [0, 0], [1, 2]]
+
+
+def test_native_gradients_and_interpolation(A):
+    from hit_adv_amd.pointnet2_ops import _ext
+    g = torch.Generator().manual_seed(0)
+    pts = torch.randn(2, 6, 300, generator=g)
+    idx = torch.randint(0, 300, (2, 20, 9), generator=g).int()
+    go = torch.randn(2, 6, 20, 9, generator=g)
+    close(_ext.group_points_grad(cu(go), cu(idx), 300), N.group_points_grad(go, idx, 300), rtol=1e-5, atol=1e-6)
+    gi = torch.randint(0, 300, (2, 40), generator=g).int()
+    gg = torch.randn(2, 6, 40, generator=g)
+    close(_ext.gather_points_grad(cu(gg), cu(gi), 300), N.gather_points_grad(gg, gi, 300), rtol=1e-5, atol=1e-6)
+    unknown, known = torch.randn(2, 500, 3, generator=g), torch.randn(2, 90, 3, generator=g)
+    d2, ti = _ext.three_nn(cu(unknown), cu(known))
+    rd2, rti = N.three_nn(unknown, known)
+    assert torch.equal(ti.cpu(), rti) and torch.equal(d2.cpu(), rd2)
+    tie = _ext.three_nn(cu(torch.zeros(1, 1, 3)),
+                        cu(torch.tensor([[[1., 0, 0], [-1., 0, 0], [0, 1., 0], [0, 0, 2.]]])))
+    assert tie[1][0, 0].tolist() == [0, 1, 2]
+    feats = torch.randn(2, 6, 90, generator=g)
+    w = torch.rand(2, 500, 3, generator=g)
+    assert torch.equal(_ext.three_interpolate(cu(feats), ti, cu(w)).cpu(), N.three_interpolate(feats, rti, w))
+    g3 = torch.randn(2, 6, 500, generator=g)
+    close(_ext.three_interpolate_grad(cu(g3), ti, cu(w), 90), N.three_interpolate_grad(g3, rti, w, 90),
+          rtol=1e-5, atol=1e-5)
+
+
+def test_native_argument_checks(A):
+    from hit_adv_amd.pointnet2_ops import _ext, pointnet2_utils as pu
+    x, _ = clouds(1, 64, 270)
+    with pytest.raises(RuntimeError):
+        _ext.furthest_point_sampling(x, 4)  # CPU tensor
+    with pytest.raises(RuntimeError):
+        _ext.furthest_point_sampling(cu(x).transpose(1, 2), 4)  # non-contiguous
+    with pytest.raises(RuntimeError):
+        _ext.gather_points(cu(x), cu(torch.zeros(1, 4, dtype=torch.int64)))  # int64 idx
+    idx = pu.furthest_point_sample(cu(x), 8)
+    feats = cu(x.transpose(1, 2).contiguous()).requires_grad_()
+    out = pu.gather_operation(feats, idx)
+    out.sum().backward()
+    assert feats.grad.sum().item() == pytest.approx(8 * 3)
+    bq = pu.ball_query(0.5, 4, cu(x), out.transpose(1, 2).contiguous())
+    grouped = pu.grouping_operation(feats, bq)
+    assert grouped.shape == (1, 3, 8, 4)
+
+
+# ------------------------------------------------------------------ attack-state kernels
+def test_best_update_and_adam_match_host_logic(A):
+    g = torch.Generator().manual_seed(4)
+    B, K, Nn, C = 5, 40, 128, 12
+    st = dict(bestdist=torch.full((B,), 1e10), bestscore=torch.full((B,), -1, dtype=torch.int64),
+              o_bestdist=torch.full((B,), 1e10), o_bestscore=torch.full((B,), -1, dtype=torch.int64),
+              o_bestattack=torch.zeros(B, 3, Nn), pred=torch.zeros(B, dtype=torch.int64),
+              dist_val=torch.zeros(B))
+    dst = {k: v.cuda() for k, v in st.items()}
+    label = torch.randint(0, K, (B,), generator=g)
+    for it in range(6):
+        logits = torch.randn(B, K, generator=g)
+        logits[0, 3] = logits[0, 7] = 50.0  # tie -> lowest index
+        if it % 2:
+            logits[1, label[1]] = 100.0  # still classified correctly -> no update for sample 1
+        P = torch.randn(B, C, 3, generator=g) * (1.0 / (it + 1))
+        sig = torch.rand(B, C, generator=g)
+        adv = torch.randn(B, 3, Nn, generator=g)
+        A.best_update(cu(logits), cu(label), cu(P), cu(sig), cu(adv), dst)
+        pred = logits.argmax(1)
+        dist = O.transformation_loss(P, sig, C, batch_avg=False)
+        for e in range(B):
+            if pred[e] != label[e]:
+                if dist[e] < st['bestdist'][e]:
+                    st['bestdist'][e], st['bestscore'][e] = dist[e], pred[e]
+                if dist[e] < st['o_bestdist'][e]:
+                    st['o_bestdist'][e], st['o_bestscore'][e] = dist[e], pred[e]
+                    st['o_bestattack'][e] = adv[e]
+        assert torch.equal(dst['pred'].cpu(), pred)
+        close(dst['dist_val'], dist, rtol=1e-6)
+        assert torch.equal(dst['bestscore'].cpu(), st['bestscore'])
+        assert torch.equal(dst['o_bestscore'].cpu(), st['o_bestscore'])
+        assert torch.equal(dst['o_bestattack'].cpu(), st['o_bestattack'])
+        close(dst['o_bestdist'], st['o_bestdist'], rtol=1e-6)
+
+    p = torch.randn(3, 7, 3, generator=g).requires_grad_()
+    s = torch.rand(3, 7, generator=g).requires_grad_()
+    opt = torch.optim.Adam([{'params': p, 'lr': 0.05}, {'params': s, 'lr': 0.03}], weight_decay=0.)
+    dp, ds = p.detach().clone().cuda(), s.detach().clone().cuda()
+    m_p, v_p, m_s, v_s = (torch.zeros_like(t) for t in (dp, dp, ds, ds))
+    step = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for it in range(25):
+        gp, gs = torch.randn(3, 7, 3, generator=g), torch.randn(3, 7, generator=g) * 1e-3
+        p.grad, s.grad = gp.clone(), gs.clone()
+        opt.step()
+        A.adam_step(dp, ds, cu(gp), cu(gs), m_p, v_p, m_s, v_s, step, 0.05, 0.03)
+    assert step.item() == 25
+    close(dp, p, rtol=1e-5, atol=1e-6)
+    close(ds, s, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ full-size properties (cfg2 sizes)
+def test_full_size_properties_b32_n1024(A):
+    from hit_adv_amd.pytorch3d_ops import knn_points
+    from hit_adv_amd.util.set_distance import chamfer, hausdorff
+    x, _ = clouds(32, 1024, 300)
+    y, _ = clouds(32, 1024, 400)
+    xc, yc = cu(x), cu(y)
+    # symmetry: swapping the arguments swaps the two outputs, bit for bit
+    a1, a2 = chamfer(xc, yc)
+    b1, b2 = chamfer(yc, xc)
+    assert torch.equal(a1, b2) and torch.equal(a2, b1)
+    h1, h2 = hausdorff(xc, yc)
+    assert (h1 >= a1).all() and (h2 >= a2).all()  # max of the minima dominates their mean
+    # a cloud against itself: zero distance, identity arg-min (no duplicate points in these clouds)
+    mx, ax, _, _ = A.nn_min(xc, xc)
+    assert (mx == 0).all() and torch.equal(ax, torch.arange(1024, device='cuda', dtype=torch.int32).expand(32, -1))
+    # materialised matrix reductions == fused reductions, bit for bit (direct form)
+    P = A.pairwise_sqdist(xc, yc, A.FORM_DIRECT)
+    m1, _, m2, _ = A.nn_min(xc, yc)
+    assert torch.equal(P.min(2).values, m1) and torch.equal(P.min(1).values, m2)
+    # kNN: ascending, rank 0 is the point itself, and rank-1 distance equals the masked NN-min
+    r = knn_points(xc, xc, K=17)
+    assert (r.dists[..., 1:] >= r.dists[..., :-1]).all() and (r.dists[..., 0] == 0).all()
+    assert torch.equal(r.idx[..., 0], torch.arange(1024, device='cuda').expand(32, -1))
+    Pxx = A.pairwise_sqdist(xc, xc, A.FORM_DIRECT)
+    Pxx.diagonal(dim1=1, dim2=2).fill_(float('inf'))
+    assert torch.equal(Pxx.min(2).values, r.dists[..., 1])
+    # FPS: no repeated index on clouds without duplicates; first index is the given start
+    start = torch.arange(32, device='cuda') * 7
+    f = A.fps_from_start(xc, 256, start)
+    assert torch.equal(f[:, 0], start)
+    assert all(len(set(row.tolist())) == 256 for row in f.cpu())
