@@ -114,7 +114,11 @@ def cpu_baseline():
     """The CPU oracle (op-for-op restatement of the reference) on this box's host cores, bounded:
     setup once + 1 warm-up + 2 timed inner iterations at B=32, extrapolated to 10 x 500."""
     from oracle import hitadv_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))  # more intra-op threads than this only adds contention for these op sizes
     torch.set_num_threads(cores)
     data, label = synth(0, B_PER_GPU)
     model = victim()
@@ -132,7 +136,7 @@ def cpu_baseline():
         att.inner_iteration(st)
     t_iter = (time.perf_counter() - t0) / n_timed
     total = t_setup + t_iter * NUM_ITER * BINARY_STEP
-    return dict(value=B_PER_GPU / total, unit="clouds/s", cores=cores, kind="port",
+    return dict(value=B_PER_GPU / total, unit="clouds/s", cores=cores, host_cpus=avail, kind="port",
                 sample="setup (%.1f s) + 1 warm-up + %d timed inner iterations at B=32 (%.2f s/iter), "
                        "extrapolated to %d x %d iterations" % (t_setup, n_timed, t_iter, BINARY_STEP, NUM_ITER),
                 s_per_iteration=round(t_iter, 3))

@@ -143,9 +143,10 @@ def test_cwknn_follows_reference_trajectory():
             mask = (S > (S.mean(-1) + 1.05 * S.std(-1))[:, None]).float()
         return cham * 5. + (S * mask).mean(1) * 3.
 
+    cpu_victim = toy_from_fixture(fx)  # built BEFORE seeding: constructing a module draws from the RNG
     torch.manual_seed(int(fx['seed']))
     otrace = []
-    ofinal, osucc = O.cw_knn_attack(toy_from_fixture(fx), lambda l, t: O.logits_adv_loss(l, t, 15.),
+    ofinal, osucc = O.cw_knn_attack(cpu_victim, lambda l, t: O.logits_adv_loss(l, t, 15.),
                                     direct_chamfer_knn, lambda pc, ori: O.clip_points_linf(pc, ori, 0.18),
                                     T(fx['data']), T(fx['target']), attack_lr=1e-2, num_iter=10, trace=otrace)
     for i, row in enumerate(trace):

@@ -41,7 +41,7 @@ def clouds(b, n, first=0):
 
 
 # ------------------------------------------------------------------ K1 pairwise
-@pytest.mark.parametrize("n,m", [(1024, 1024), (256, 1024), (100, 1001), (7, 3), (1, 1)])
+@pytest.mark.parametrize("n,m", [(1024, 1024), (256, 1024), (100, 1001), (7, 3), (2, 2)])
 def test_pairwise_direct_bit_exact(A, n, m):
     x, _ = clouds(2, n, 100)
     y, _ = clouds(2, m, 110)
