@@ -1,0 +1,119 @@
+"""Evaluation harness: ``eval_ASR(model, test_loader, args, val_attack)`` with the reference's call
+signature and metric definitions (util/other_utils.py:15-101), plus the one thing the reference lacks:
+data-parallel execution.  With ``torch.distributed`` initialised, rank r attacks batches r, r+R, ...
+(each ``attack()`` call keeps the reference's per-batch semantics) and the six
+running sums are combined by ONE all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests).
+"""
+import logging
+import os
+from datetime import datetime
+
+import torch
+import torch.distributed as dist
+
+
+def create_logger(save_path='', file_type='', level='debug'):
+    """Root logger with a stream handler and ./<save_path>/<file_type>_log.txt (other_utils.py:150-170).
+    Unlike the reference it creates the directory and does not stack duplicate handlers."""
+    level = {'debug': logging.DEBUG, 'info': logging.INFO}.get(level, logging.INFO)
+    logger = logging.getLogger()
+    logger.setLevel(level)
+    for h in list(logger.handlers):
+        if getattr(h, '_hitadv', False):
+            logger.removeHandler(h)
+    cs = logging.StreamHandler()
+    cs.setLevel(level)
+    cs._hitadv = True
+    logger.addHandler(cs)
+    if file_type != '':
+        os.makedirs(save_path or '.', exist_ok=True)
+        fh = logging.FileHandler(os.path.join(save_path, file_type + '_log.txt'), mode='w')
+        fh.setLevel(level)
+        fh._hitadv = True
+        logger.addHandler(fh)
+    return logger
+
+
+def shard_indices(n_batches, rank, world):
+    """Batches owned by ``rank``: r, r+world, ... (round-robin keeps shuffle=False order per rank)."""
+    return list(range(rank, n_batches, world))
+
+
+def all_reduce_sums(values, device):
+    """SUM-all-reduce a short list of python floats; identity when not distributed."""
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
+
+
+def _default_metrics():
+    from . import dist_utils
+    from ..FGM.GeoA3_args import uniform_loss
+    knn = dist_utils.KNNDist(k=4)
+    curv = dist_utils.CurvStdDist(k=4)
+    return dict(knn=lambda adv: knn.forward(pc=adv, weights=None, batch_avg=True),
+                uniform=lambda adv, k: uniform_loss(adv_pc=adv, k=k),
+                curv_std=lambda ori, adv, normal: curv.forward(ori_data=ori, adv_data=adv, ori_normal=normal))
+
+
+def _logits(model, x):
+    out = model(x)
+    return out[0] if isinstance(out, tuple) else out  # every victim, not only 'pointnet' (other_utils.py:77-82)
+
+
+def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, logger=None):
+    """Evaluate Attack Success Rate: ASR = (clean-correct - clean-correct-and-still-correct) /
+    clean-correct, and the batch means of KNN / Uniform / CurvStd distances of the adversarial clouds.
+    Returns the (global) ASR as a float; every rank returns the same value."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    metrics = metrics or _default_metrics()
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    if logger is None:
+        logger = create_logger('./log', datetime.now().strftime("%Y%m%d%H%M%S") + '_r%d' % rank, 'info')
+    for name in ('ker_weight', 'hide_weight', 'budget', 'max_sigm', 'min_sigm', 'central_num', 'attack_type'):
+        if hasattr(args, name):
+            logger.info('%s: %s', name, getattr(args, name))
+
+    model.eval()
+    at_num = at_denom = knn_sum = uni_sum = curv_sum = 0.0
+    n_batches = 0
+    for i, (ori_data, label) in enumerate(test_loader):
+        if i % world != rank:
+            continue
+        n_batches += 1
+        ori_data, label = ori_data.float().to(device), label.long().to(device)
+        adv_data = val_attack.attack(ori_data, label)[0]
+        if isinstance(adv_data, tuple):
+            adv_data = adv_data[0]
+        if not torch.is_tensor(adv_data):
+            adv_data = torch.Tensor(adv_data)
+        adv_data = adv_data.float().to(device).transpose(1, 2).contiguous()  # [B,3,N]
+        ori = ori_data.transpose(1, 2).contiguous()
+        normal = ori[:, 3:, :].contiguous() if ori.shape[1] == 6 else None
+        ori = ori[:, :3, :].contiguous()
+        with torch.no_grad():
+            knn_sum += float(metrics['knn'](adv_data))
+            uni_sum += float(metrics['uniform'](adv_data, args.k))
+            if normal is not None:
+                curv_sum += float(metrics['curv_std'](ori, adv_data, normal))
+            ok_ori = _logits(model, ori).argmax(dim=-1) == label
+            ok_adv = _logits(model, adv_data).argmax(dim=-1) == label
+            at_denom += ok_ori.sum().float().item()
+            at_num += ok_ori.sum().float().item() - (ok_ori & ok_adv).sum().float().item()
+
+    at_num, at_denom, knn_sum, uni_sum, curv_sum, total_batches = all_reduce_sums(
+        [at_num, at_denom, knn_sum, uni_sum, curv_sum, float(n_batches)], device)
+    ASR = at_num / (at_denom + 1e-9)
+    total_batches = max(total_batches, 1.0)
+    eval_ASR.last = dict(ASR=ASR, knn=knn_sum / total_batches, uniform=uni_sum / total_batches,
+                         curv_std=curv_sum / total_batches, at_num=at_num, at_denom=at_denom,
+                         batches=total_batches, world=world)
+    if rank == 0:
+        logger.info('Overall attack success rate: %s', ASR)
+        logger.info('Overall KNN dist: %s', knn_sum / total_batches)
+        logger.info('Overall Uniform dist: %s', uni_sum / total_batches)
+        logger.info('Overall CurvStd dist: %s', curv_sum / total_batches)
+    return ASR

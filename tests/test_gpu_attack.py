@@ -171,3 +171,45 @@ def test_pointnet_victim_loads_reference_layout_and_runs():
     m = m.cuda()
     logits, trans_feat = m(torch.randn(4, 3, 1024, device='cuda'))
     assert logits.shape == (4, 40) and trans_feat.shape == (4, 64, 64)
+
+
+def test_uniform_loss_and_eval_asr_on_gpu():
+    """The metric phase (util/other_utils.py:73-98) end to end on the HIP ops, against the oracle."""
+    import argparse
+    import logging
+    from oracle import c_oracle as N
+    from hit_adv_amd.FGM.GeoA3_args import uniform_loss
+    from hit_adv_amd.util.other_utils import eval_ASR
+    data, _ = synth_batch(3, 1024, first=700)
+    xyz = data[:, :, :3].contiguous()
+    for k in (2, 5):
+        close(uniform_loss(xyz.cuda(), k=k), O.uniform_loss(xyz, N, k=k), rtol=1e-5)
+        close(uniform_loss(xyz.transpose(1, 2).contiguous().cuda(), k=k), O.uniform_loss(xyz, N, k=k), rtol=1e-5)
+
+    class Shift:
+        def attack(self, d, t):
+            return (d[:, :, :3] + 0.1 * torch.sin(t.float())[:, None, None]).double().cpu().numpy(), 0
+
+    fx = golden('g5_attack.npz')
+    model = toy_from_fixture(fx)
+    batches = []
+    for i in range(3):
+        d, _ = synth_batch(4, 512, first=800 + 4 * i)
+        with torch.no_grad():
+            lab = model(d[:, :, :3].transpose(1, 2).contiguous()).argmax(1)
+        batches.append((d, lab))
+    log = logging.getLogger('quiet-gpu')
+    log.addHandler(logging.NullHandler())
+    log.propagate = False
+    args = argparse.Namespace(k=5, model='pointnet')
+    asr = eval_ASR(model.cuda(), batches, args, Shift(), logger=log)
+    got = dict(eval_ASR.last)
+    metrics = dict(knn=lambda adv: O.knn_dist(adv, None, True, 4),
+                   uniform=lambda adv, k: O.uniform_loss(adv, N, k=k),
+                   curv_std=lambda ori, adv, normal: O.curv_std_dist(ori, adv, normal, k=4))
+    ref = eval_ASR(toy_from_fixture(fx), batches, args, Shift(), device='cpu', metrics=metrics, logger=log)
+    want = dict(eval_ASR.last)
+    assert asr == ref and got['at_denom'] == want['at_denom'] == 12
+    close(got['knn'], want['knn'], rtol=2e-4)  # oracle KNNDist is Gram-form (its own fp32 noise)
+    close(got['uniform'], want['uniform'], rtol=1e-5)
+    close(got['curv_std'], want['curv_std'], rtol=1e-5)
