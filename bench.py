@@ -68,9 +68,16 @@ def pairwise_roofline(dev):
     us = t0.elapsed_time(t1) * 1e3 / reps
     alg_bytes = (4 * NPOINT * NPOINT + 12 * (NPOINT + NPOINT)) * B_PER_GPU  # 4,218,880 B / cloud pair
     achieved = alg_bytes / (us * 1e-6) / 1e9
+    # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of tools/kbench.py at
+    # the same B/N, corrected per MI355X_MICROARCH.md: WRITE_SIZE exact, FETCH_SIZE x2); null if absent.
+    traffic = None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*kbench_traffic.json"))):
+        with open(path) as f:
+            traffic = json.load(f).get("hitadv::pairwise3_vec4<1>", {}).get("hbm_bytes_per_launch", traffic)
     return dict(kernel="pairwise3_vec4<gram> (hitadv_pairwise_sqdist, B=32, 1024x1024)", bound="hbm",
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=None, us_per_launch=round(us, 2), algorithmic_bytes=alg_bytes)
+                traffic=traffic, us_per_launch=round(us, 2), algorithmic_bytes=alg_bytes)
 
 
 def hot_loop_kernels(dev):
