@@ -79,7 +79,7 @@ class HiT_ADV:
     def __init__(self, model, adv_func, attack_lr=1e-2, init_weight=10., max_weight=80., binary_step=10,
                  num_iter=500, clip_func=None, cd_weight=0, curv_weight=0, ker_weight=0, hide_weight=0,
                  curv_loss_knn=32, central_num=32, total_central_num=128, max_sigm=0.7, min_sigm=0.1,
-                 budget=0.1, alpha=1, use_graph='auto', verbose=True):
+                 budget=0.1, alpha=1, use_graph='auto', verbose=True, fast_victim=True):
         self.model = model.cuda()
         self.model.eval()
         self.adv_func = adv_func
@@ -102,13 +102,25 @@ class HiT_ADV:
         self.total_central_num = total_central_num
         self.use_graph = use_graph
         self.verbose = verbose
+        self.fast_victim = fast_victim
+        self._view = None
         self._chamfer = ChamferDist()
         self._ws = {}
         self.last_graph_used = False
 
     # ------------------------------------------------------------------ small pieces
+    def _victim(self):
+        """The callable used for forward/backward.  Victims that offer ``attack_view()`` (our PointNet:
+        eval-mode BatchNorm folded, points-major GEMMs) are run through that view; its buffers are
+        re-folded in place at every attack() so weight updates are seen and the captured graph stays valid."""
+        if not (self.fast_victim and hasattr(self.model, 'attack_view')):
+            return self.model
+        if self._view is None:
+            self._view = self.model.attack_view()
+        return self._view
+
     def _logits(self, x):
-        out = self.model(x)
+        out = self._victim()(x)
         return out[0] if isinstance(out, tuple) else out
 
     def get_gradient(self, data, target):
@@ -249,6 +261,8 @@ class HiT_ADV:
         normal = data[:, :, 3:].float().to(dev).clone().detach().transpose(1, 2).contiguous()
         target = target.long().to(dev).detach()
         C = self.central_num
+        if self._view is not None:
+            self._view.refresh(self.model)
 
         grad, _ = self.get_gradient(ori, target)
         central, central_kappa, _ = self._select_centres(ori, normal, grad)

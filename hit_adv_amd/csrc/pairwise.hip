@@ -24,7 +24,7 @@ __device__ __forceinline__ float pair_value(float x0, float x1, float x2, float 
   }
 }
 
-constexpr int K1_ROWS = 16;
+constexpr int K1_ROWS = 32;  // 6.31 TB/s vs 6.02 at 16 rows (tools/tune/k1_tune.hip on MI355X)
 
 template <int FORM>
 __global__ __launch_bounds__(256) void pairwise3_vec4(const float *__restrict__ x,

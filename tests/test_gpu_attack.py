@@ -213,3 +213,32 @@ def test_uniform_loss_and_eval_asr_on_gpu():
     close(got['knn'], want['knn'], rtol=2e-4)  # oracle KNNDist is Gram-form (its own fp32 noise)
     close(got['uniform'], want['uniform'], rtol=1e-5)
     close(got['curv_std'], want['curv_std'], rtol=1e-5)
+
+
+def test_pointnet_attack_view_on_gpu_and_in_the_attack():
+    """The folded PointNet view agrees with the module on the GPU, and HiT_ADV with/without it tells the
+    same story on a short run (same centres, same first-iterate logits to fp32 rounding)."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(0)
+    m = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    data, _ = synth_batch(4, 1024, first=600)
+    x = data[:, :, :3].transpose(1, 2).contiguous().cuda()
+    with torch.no_grad():
+        la, ta = m(x)
+        lb, tb = m.attack_view()(x)
+    close(lb, la, rtol=1e-4, atol=1e-5)
+    close(tb, ta, rtol=1e-4, atol=1e-5)
+    label = la.argmax(1)
+    outs = []
+    for fast in (False, True):
+        att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), binary_step=1, num_iter=5, cd_weight=1e-4, ker_weight=1.,
+                      hide_weight=1., curv_loss_knn=16, central_num=192, total_central_num=256, max_sigm=1.2,
+                      min_sigm=0.1, budget=0.55, verbose=False, fast_victim=fast)
+        torch.manual_seed(3)
+        best, succ = att.attack(data, label)
+        ws = next(iter(att._ws.values()))
+        outs.append((best, ws.central.clone(), ws.adv.clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    close(outs[0][2], outs[1][2], rtol=1e-3, atol=1e-4)

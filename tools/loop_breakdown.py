@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Wall-time breakdown of one HiT-ADV inner iteration at cfg2 (graph replay, 300 iterations each):
+full iteration, without the regularisers, and the victim's forward+input-gradient alone."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from helpers import synth_batch  # noqa: E402
+from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV  # noqa: E402
+from hit_adv_amd.model.pointnet import PointNetFeatureModel  # noqa: E402
+from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss  # noqa: E402
+
+HP = dict(attack_lr=1e-2, central_num=192, total_central_num=256, curv_loss_knn=16, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+
+
+def per_iter(att, data, label, iters=300):
+    att.binary_step, att.num_iter = 1, iters
+    att.attack(data, label)  # warm-up + capture
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    att.attack(data, label)
+    torch.cuda.synchronize()
+    t_attack = time.perf_counter() - t0
+    ws = next(iter(att._ws.values()))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ws.graph.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3, t_attack
+
+
+def main():
+    torch.manual_seed(0)
+    model = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    data, _ = synth_batch(32, 1024)
+    data = data.cuda()
+    with torch.no_grad():
+        label = model(data[:, :, :3].transpose(1, 2).contiguous())[0].argmax(1)
+    out = {}
+    for name, w in (('full', dict(cd_weight=1e-4, ker_weight=1., hide_weight=1.)),
+                    ('no_chamfer_q1', dict(cd_weight=0, ker_weight=1., hide_weight=1.)),
+                    ('no_regularisers', dict(cd_weight=0, ker_weight=0, hide_weight=0))):
+        att = HiT_ADV(model, UntargetedLogitsAdvLoss(30.), verbose=False, **HP, **w)
+        ms, t_attack = per_iter(att, data, label)
+        out[name + '_ms_per_iter'] = round(ms, 4)
+        out[name + '_attack300_s'] = round(t_attack, 3)
+    x = torch.randn(32, 3, 1024, device='cuda', requires_grad=True)
+    tgt = label
+    adv_func = UntargetedLogitsAdvLoss(30.)
+
+    def victim_only():
+        logits = model(x)[0]
+        g, = torch.autograd.grad(adv_func(logits, tgt), x)
+        return g
+    for _ in range(3):
+        victim_only()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        victim_only()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        g.replay()
+    torch.cuda.synchronize()
+    out['victim_fwd_bwd_graph_ms'] = round((time.perf_counter() - t0) / 300 * 1e3, 4)
+    t0 = time.perf_counter()
+    for _ in range(100):
+        victim_only()
+    torch.cuda.synchronize()
+    out['victim_fwd_bwd_eager_ms'] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
+    with torch.no_grad():
+        for _ in range(3):
+            model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            model(x)
+        torch.cuda.synchronize()
+        out['victim_fwd_only_eager_ms'] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
