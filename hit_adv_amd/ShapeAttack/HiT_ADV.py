@@ -221,9 +221,16 @@ class HiT_ADV:
         ws.dist_loss.copy_(dist_loss.detach())
 
     def _prepare_graph(self, ws):
-        """Warm up on a side stream, then capture ``_iteration`` once.  State touched by the warm-up
-        is re-initialised by the caller afterwards."""
-        if ws.graph is not None or self.use_graph in (False, 'never'):
+        """Warm up on a side stream, then capture ``_iteration`` once per attack() call.  State touched
+        by the warm-up is re-initialised by the caller afterwards.
+
+        The graph is NOT kept across attack() calls: on ROCm 7.0/PyTorch 2.10 a replay that follows
+        eager victim work issued after the capture (the next call's get_gradient) faults with
+        HSA_STATUS_ERROR_EXCEPTION 0x1016 for some graphs (measured).  Capturing
+        costs ~0.1 s against ~10 s of replays, and within one call nothing eager touches the victim
+        between capture and the last replay."""
+        ws.graph = None
+        if self.use_graph in (False, 'never'):
             return
         try:
             side = torch.cuda.Stream()

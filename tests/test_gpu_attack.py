@@ -242,3 +242,30 @@ def test_pointnet_attack_view_on_gpu_and_in_the_attack():
         outs.append((best, ws.central.clone(), ws.adv.clone()))
     assert torch.equal(outs[0][1], outs[1][1])
     close(outs[0][2], outs[1][2], rtol=1e-3, atol=1e-4)
+
+
+def test_consecutive_attacks_graph_equals_eager_pointnet():
+    """Several attack() calls on one attacker (the eval_ASR pattern): the per-call hipGraph capture must
+    give bitwise the eager results, for the plain PointNet module and for its folded attack view."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(0)
+    m = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    batches = []
+    for i in range(3):
+        d, _ = synth_batch(8, 1024, first=1000 + 8 * i)
+        with torch.no_grad():
+            lab = m(d[:, :, :3].transpose(1, 2).contiguous().cuda())[0].argmax(1)
+        batches.append((d, lab))
+    for fast in (False, True):
+        res = {}
+        for graph in (False, True):
+            att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), binary_step=2, num_iter=6, cd_weight=1e-4, ker_weight=1.,
+                          hide_weight=1., curv_loss_knn=16, central_num=192, total_central_num=256, max_sigm=1.2,
+                          min_sigm=0.1, budget=0.55, verbose=False, fast_victim=fast, use_graph=graph)
+            torch.manual_seed(5)
+            res[graph] = [att.attack(d, l)[0] for d, l in batches]
+            assert att.last_graph_used == graph
+        for a, b in zip(res[False], res[True]):
+            assert np.array_equal(a, b)

@@ -44,7 +44,8 @@ def main():
     with torch.no_grad():
         label = model(data[:, :, :3].transpose(1, 2).contiguous())[0].argmax(1)
     out = {}
-    for name, w in (('full', dict(cd_weight=1e-4, ker_weight=1., hide_weight=1.)),
+    for name, w in (('full_plain_victim', dict(cd_weight=1e-4, ker_weight=1., hide_weight=1., fast_victim=False)),
+                    ('full', dict(cd_weight=1e-4, ker_weight=1., hide_weight=1.)),
                     ('no_chamfer_q1', dict(cd_weight=0, ker_weight=1., hide_weight=1.)),
                     ('no_regularisers', dict(cd_weight=0, ker_weight=0, hide_weight=0))):
         att = HiT_ADV(model, UntargetedLogitsAdvLoss(30.), verbose=False, **HP, **w)
@@ -55,8 +56,10 @@ def main():
     tgt = label
     adv_func = UntargetedLogitsAdvLoss(30.)
 
+    view = model.attack_view()
+
     def victim_only():
-        logits = model(x)[0]
+        logits = view(x)[0]
         g, = torch.autograd.grad(adv_func(logits, tgt), x)
         return g
     for _ in range(3):
