@@ -35,6 +35,7 @@ PROTOTYPES = {
     "hitadv_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
     "hitadv_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "hitadv_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hitadv_linear_max_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64}
 

@@ -127,6 +127,41 @@ def _fold(lin_w, lin_b, bn):
     return (w * s[:, None]).t().contiguous(), (lin_b - bn.running_mean) * s + bn.bias
 
 
+class _LinearMaxOverPoints(torch.autograd.Function):
+    """g[b,c] = max_n act(x[b,n,:] @ Wt[:,c] + bias[c])  with act = identity or ReLU, for x [B*N,Cin].
+
+    Same value and same gradient as ``addmm -> (relu) -> view(B,N,C).max(1)`` under autograd, but
+      * ReLU is applied to the [B,C] maxima (max and ReLU commute), not to the [B*N,C] activations;
+      * the 134 MB activation is not kept for the backward: only the arg-max table [B,C] is;
+      * the backward uses the fact that d/dy is non-zero at ONE point per (cloud, channel): instead of
+        zero-filling and scattering a [B*N,C] gradient and running a dense [B*N,C]x[C,Cin] GEMM, it
+        sums the B*C rows  dg[b,c] * W[c,:]  into their points with ``hitadv_linear_max_bwd`` (one wave
+        per destination point, ascending c, no atomics -> bitwise reproducible).
+    CUDA only; ``FoldedPointNet`` uses the plain formulation for CPU tensors."""
+
+    @staticmethod
+    def forward(ctx, x, Wt, W, bias, B, N, relu):
+        y = torch.addmm(bias, x, Wt)
+        g, idx = y.view(B, N, -1).max(dim=1)
+        del y
+        mask = None
+        if relu:
+            mask = g > 0
+            g = g.clamp_min(0.)
+        ctx.save_for_backward(W, idx, mask)
+        ctx.dims = (B, N)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        from .. import ops
+        W, idx, mask = ctx.saved_tensors
+        B, N = ctx.dims
+        if mask is not None:
+            dg = dg * mask
+        return ops.linear_max_bwd(dg, W, idx, N), None, None, None, None, None, None
+
+
 class FoldedPointNet(nn.Module):
     """Inference-mode restatement of ``PointNetFeatureModel`` for the attack loop (still plain
     PyTorch-ROCm ops: rocBLAS/hipBLASLt GEMMs + elementwise).  Algebraically identical to the module
@@ -136,9 +171,11 @@ class FoldedPointNet(nn.Module):
     * activations are kept points-major ``[B*N, C]`` so each shared layer is ONE ``addmm`` with the
       bias in the GEMM epilogue, the two learned transforms are natural ``bmm``s and no transposes
       or ``contiguous()`` copies of the 134 MB activations are needed;
-    * ReLU is applied in place.
+    * ReLU is applied in place;
+    * the 128->1024 layer + max over points of each stack is one autograd node whose backward exploits
+      that the max routes gradient to one point per (cloud, channel) (``_LinearMaxOverPoints``).
 
-    This cuts the victim's forward+backward from ~250 to ~100 kernels per attack iteration.  Build it
+    This cuts the victim's forward+backward from ~250 to ~90 kernels per attack iteration.  Build it
     with ``PointNetFeatureModel.attack_view()``; it snapshots the weights at that moment.
     """
 
@@ -147,6 +184,10 @@ class FoldedPointNet(nn.Module):
         for k, (w, b) in self._folded(m).items():
             self.register_buffer(k + '_w', w.detach().clone())
             self.register_buffer(k + '_b', b.detach().clone())
+            if k in self._MAXED:  # row-major [Cout,Cin] copy for the sparse backward
+                self.register_buffer(k + '_wr', w.detach().t().contiguous())
+
+    _MAXED = ('s3', 't3', 'e3')
 
     @staticmethod
     def _folded(m):
@@ -183,15 +224,23 @@ class FoldedPointNet(nn.Module):
         for k, (w, b) in self._folded(m).items():
             getattr(self, k + '_w').copy_(w)
             getattr(self, k + '_b').copy_(b)
+            if k in self._MAXED:
+                getattr(self, k + '_wr').copy_(w.t())
         return self
 
     def _lin(self, x, name, relu=True):
         y = torch.addmm(getattr(self, name + '_b'), x, getattr(self, name + '_w'))
         return y.relu_() if relu else y
 
+    def _lin_max(self, x, name, B, N, relu):
+        """Last shared layer of a stack fused with the max over points (see _LinearMaxOverPoints)."""
+        w, b = getattr(self, name + '_w'), getattr(self, name + '_b')
+        if x.is_cuda:
+            return _LinearMaxOverPoints.apply(x, w, getattr(self, name + '_wr'), b, B, N, relu)
+        return self._lin(x, name, relu).view(B, N, -1).max(dim=1)[0]
+
     def _tnet(self, x, B, N, p):
-        h = self._lin(self._lin(self._lin(x, p + '1'), p + '2'), p + '3')
-        g = h.view(B, N, -1).max(dim=1)[0]
+        g = self._lin_max(self._lin(self._lin(x, p + '1'), p + '2'), p + '3', B, N, True)
         return self._lin(self._lin(self._lin(g, p + '4'), p + '5'), p + '6', relu=False)
 
     def forward(self, x):
@@ -202,8 +251,7 @@ class FoldedPointNet(nn.Module):
         h = self._lin(torch.bmm(pts, trans).reshape(B * N, 3), 'e1')  # [B*N,64]
         trans_feat = self._tnet(h, B, N, 't').view(B, 64, 64)
         h = torch.bmm(h.view(B, N, 64), trans_feat).reshape(B * N, 64)
-        h = self._lin(self._lin(h, 'e2'), 'e3', relu=False)
-        g = h.view(B, N, -1).max(dim=1)[0]
+        g = self._lin_max(self._lin(h, 'e2'), 'e3', B, N, False)
         return self._lin(self._lin(self._lin(g, 'h1'), 'h2'), 'h3', relu=False), trans_feat
 
 

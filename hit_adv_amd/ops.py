@@ -184,3 +184,15 @@ def fps_from_start(xyz, npoint, start):
     idx = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
     _lib.call("hitadv_fps_from_start", _p(xyz), _p(start), B, N, npoint, _p(idx), _stream())
     return idx
+
+
+# --------------------------------------------------------------------------- victim-side helper
+def linear_max_bwd(dg, W, idx, N):
+    """dX[b*N+n,:] = sum_{j: idx[b,j]==n} dg[b,j] * W[j,:]   (dg[B,Cout], W[Cout,Cin], idx[B,Cout] int64)."""
+    dg, W = _dev(dg, "dg"), _dev(W, "W")
+    idx = _dev(idx, "idx", torch.int64)
+    B, Cout = dg.shape
+    Cin = W.shape[1]
+    dX = torch.empty(B * N, Cin, device=dg.device)
+    _lib.call("hitadv_linear_max_bwd", _p(dg), _p(W), _p(idx), B, N, Cout, Cin, _p(dX), _stream())
+    return dX

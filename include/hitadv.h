@@ -166,6 +166,15 @@ int hitadv_three_interpolate_grad(int b, int c, int n, int m, const float *grad_
                                   const int32_t *idx, const float *weight, float *grad_points,
                                   void *stream);
 
+/* ------------------------------------------------------------------ victim-side helper
+ * Backward of "shared linear layer -> max over points" (model/feature_models.py:126-127 conv3+bn3 then
+ * torch.max(x, 2), and the same pattern in STN3d/STNkd :164-165, :209-210):
+ *   dX[b,n,:] = sum_{j : idx[b,j]==n} dg[b,j] * W[j,:]
+ * dg[B,Cout], W[Cout,Cin] (BatchNorm already folded), idx[B,Cout] int64 arg-max over points,
+ * dX[B*N,Cin] fully overwritten.  Cin <= 512.  Deterministic (ascending j, no atomics). */
+int hitadv_linear_max_bwd(const float *dg, const float *W, const int64_t *idx, int B, int N, int Cout,
+                          int Cin, float *dX, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -231,6 +231,15 @@ def test_pointnet_attack_view_on_gpu_and_in_the_attack():
     close(lb, la, rtol=1e-4, atol=1e-5)
     close(tb, ta, rtol=1e-4, atol=1e-5)
     label = la.argmax(1)
+    # input gradient through the fused linear+max nodes (sparse, deterministic backward) vs plain autograd
+    w = torch.randn(4, 40, device='cuda', generator=torch.Generator('cuda').manual_seed(2))
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ga, = torch.autograd.grad((m(xa)[0] * w).sum(), xa)
+    view = m.attack_view()
+    gb, = torch.autograd.grad((view(xb)[0] * w).sum(), xb)
+    gb2, = torch.autograd.grad((view(xb)[0] * w).sum(), xb)
+    close(gb, ga, rtol=1e-3, atol=1e-5 * float(ga.abs().max()))
+    assert torch.equal(gb, gb2)  # no atomics anywhere in the backward
     outs = []
     for fast in (False, True):
         att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), binary_step=1, num_iter=5, cd_weight=1e-4, ker_weight=1.,
