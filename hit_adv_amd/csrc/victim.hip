@@ -34,17 +34,30 @@ __global__ __launch_bounds__(256) void linear_max_bwd_k(const float *__restrict_
     for (int j0 = 0; j0 < Cout; j0 += 64) {
       const int j = j0 + lane;
       unsigned long long m = __ballot(j < Cout && sidx[j] == n);
+      // consume the matches four at a time so that four rows of W are in flight (a hot point can own
+      // dozens of channels; one dependent L2 round trip per match made this loop latency-bound)
       while (m) {
-        const int jj = j0 + __builtin_ctzll(m);
-        m &= m - 1;
-        const float g = dgb[jj];
-        const float *wr = W + (size_t)jj * Cin;
+        int jj[4];
+        float g[4];
 #pragma unroll
-        for (int c = 0; c < LM_MAXC; ++c)
-          if (c < nc) {
+        for (int u = 0; u < 4; ++u) {
+          const bool on = m != 0ull;
+          jj[u] = on ? j0 + __builtin_ctzll(m) : 0;
+          m = on ? (m & (m - 1)) : 0ull;
+          g[u] = on ? dgb[jj[u]] : 0.f;
+        }
+        float w[4][LM_MAXC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < LM_MAXC; ++c) {
             const int k = lane + 64 * c;
-            if (k < Cin) acc[c] = fmaf(g, wr[k], acc[c]);
+            w[u][c] = (c < nc && k < Cin) ? W[(size_t)jj[u] * Cin + k] : 0.f;
           }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < LM_MAXC; ++c) acc[c] = fmaf(g[u], w[u][c], acc[c]);
       }
     }
     float *o = dX + ((size_t)b * N + n) * Cin;
@@ -57,9 +70,72 @@ __global__ __launch_bounds__(256) void linear_max_bwd_k(const float *__restrict_
   }
 }
 
+// Max over the point axis of y[B,N,C] (points-major activations), with the arg-max and the lowest
+// point index on ties.  HBM-read-bound: float4 per lane along C (4 KiB per block-row), the point range
+// split over blockIdx.y so that a B x C = 32k-output reduction still fills 256 CUs; partials are merged
+// in split order by max_over_points_merge.
+constexpr int MP_SPLIT = 16;
+__global__ __launch_bounds__(256) void max_over_points_k(const float *__restrict__ y, int N, int C,
+                                                         float *__restrict__ pval, int32_t *__restrict__ pidx) {
+  const int b = blockIdx.z, s = blockIdx.y;
+  const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c0 >= C) return;
+  const int per = (N + MP_SPLIT - 1) / MP_SPLIT;
+  const int n0 = s * per, n1 = min(N, n0 + per);
+  float4 best = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+  int i0 = n0, i1 = n0, i2 = n0, i3 = n0;
+  const float *p = y + ((size_t)b * N + n0) * C + c0;
+#pragma unroll 4
+  for (int n = n0; n < n1; ++n, p += C) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    if (v.x > best.x) { best.x = v.x; i0 = n; }
+    if (v.y > best.y) { best.y = v.y; i1 = n; }
+    if (v.z > best.z) { best.z = v.z; i2 = n; }
+    if (v.w > best.w) { best.w = v.w; i3 = n; }
+  }
+  const size_t o = ((size_t)b * MP_SPLIT + s) * C + c0;
+  *reinterpret_cast<float4 *>(pval + o) = best;
+  *reinterpret_cast<int4 *>(pidx + o) = make_int4(i0, i1, i2, i3);
+}
+
+__global__ __launch_bounds__(256) void max_over_points_merge(const float *__restrict__ pval,
+                                                             const int32_t *__restrict__ pidx, int C,
+                                                             float *__restrict__ out, int64_t *__restrict__ idx,
+                                                             long long total) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const long long b = e / C;
+  float best = -__builtin_inff();
+  int bi = 0;
+  for (int s = 0; s < MP_SPLIT; ++s) {
+    const size_t o = ((size_t)b * MP_SPLIT + s) * C + c;
+    const float v = pval[o];
+    if (v > best || s == 0) { best = v; bi = pidx[o]; }
+  }
+  out[e] = best;
+  idx[e] = bi;
+}
+
 }  // namespace hitadv
 
 using namespace hitadv;
+
+extern "C" int64_t hitadv_max_over_points_scratch(int B, int C) { return (int64_t)B * MP_SPLIT * C; }
+
+extern "C" int hitadv_max_over_points(const float *y, int B, int N, int C, float *part_val, int32_t *part_idx,
+                                      float *out, int64_t *idx, void *stream) {
+  if (!y || !part_val || !part_idx || !out || !idx || B <= 0 || N <= 0 || C <= 0 || (C & 3) ||
+      ((uintptr_t)y & 15))
+    return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((C / 4 + 255) / 256, MP_SPLIT, B);
+  max_over_points_k<<<grid, 256, 0, s>>>(y, N, C, part_val, part_idx);
+  const long long total = (long long)B * C;
+  max_over_points_merge<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part_val, part_idx, C, out, idx, total);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int hitadv_linear_max_bwd(const float *dg, const float *W, const int64_t *idx, int B, int N, int Cout,
                                      int Cin, float *dX, void *stream) {

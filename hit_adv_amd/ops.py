@@ -196,3 +196,16 @@ def linear_max_bwd(dg, W, idx, N):
     dX = torch.empty(B * N, Cin, device=dg.device)
     _lib.call("hitadv_linear_max_bwd", _p(dg), _p(W), _p(idx), B, N, Cout, Cin, _p(dX), _stream())
     return dX
+
+
+def max_over_points(y, B, N):
+    """y[B*N,C] (points-major) -> (max over the N points [B,C], arg-max [B,C] int64, lowest n on ties)."""
+    y = _dev(y, "y")
+    C = y.shape[-1]
+    n = _lib.load().hitadv_max_over_points_scratch(B, C)
+    pv = torch.empty(n, device=y.device)
+    pi = torch.empty(n, device=y.device, dtype=torch.int32)
+    out = torch.empty(B, C, device=y.device)
+    idx = torch.empty(B, C, device=y.device, dtype=torch.int64)
+    _lib.call("hitadv_max_over_points", _p(y), B, N, C, _p(pv), _p(pi), _p(out), _p(idx), _stream())
+    return out, idx

@@ -175,6 +175,13 @@ int hitadv_three_interpolate_grad(int b, int c, int n, int m, const float *grad_
 int hitadv_linear_max_bwd(const float *dg, const float *W, const int64_t *idx, int B, int N, int Cout,
                           int Cin, float *dX, void *stream);
 
+/* g[b,c] = max_n y[b,n,c] and its arg-max (lowest n on ties) for points-major activations y[B,N,C],
+ * C % 4 == 0, y 16-byte aligned.  Replaces torch.max(x, 2) of model/feature_models.py:127,165,210 in the
+ * attack-time victim view.  part_val / part_idx: scratch of hitadv_max_over_points_scratch(B,C) elements. */
+int hitadv_max_over_points(const float *y, int B, int N, int C, float *part_val, int32_t *part_idx,
+                           float *out, int64_t *idx, void *stream);
+int64_t hitadv_max_over_points_scratch(int B, int C);
+
 #ifdef __cplusplus
 }
 #endif

@@ -442,3 +442,33 @@ def test_full_size_properties_b32_n1024(A):
     f = A.fps_from_start(xc, 256, start)
     assert torch.equal(f[:, 0], start)
     assert all(len(set(row.tolist())) == 256 for row in f.cpu())
+
+
+# ------------------------------------------------------------------ victim-side helpers
+def test_max_over_points_and_linear_max_bwd(A):
+    g = torch.Generator().manual_seed(7)
+    B, Np, Cin, Cout = 3, 500, 128, 1024
+    x = torch.randn(B * Np, Cin, generator=g)
+    W = torch.randn(Cout, Cin, generator=g) * 0.1
+    y = x @ W.t()
+    y[5, 17] = y[300, 17] = 99.0  # tie inside cloud 0 -> lowest point index wins
+    val, idx = A.max_over_points(cu(y), B, Np)
+    ref_val, ref_idx = y.view(B, Np, Cout).max(dim=1)
+    assert torch.equal(val.cpu(), ref_val)
+    assert idx.dtype == torch.int64 and idx[0, 17].item() == 5
+    same = torch.ones(B, Cout, dtype=torch.bool)
+    same[0, 17] = False
+    assert torch.equal(idx.cpu()[same], ref_idx[same])
+    # backward: dX[b,n,:] = sum_{j: idx[b,j]==n} dg[b,j] W[j,:]  vs dense autograd through max
+    dg = torch.randn(B, Cout, generator=g)
+    xr = x.clone().requires_grad_()
+    (xr @ W.t()).view(B, Np, Cout).gather(1, idx.cpu().unsqueeze(1)).squeeze(1).mul(dg).sum().backward()
+    dx = A.linear_max_bwd(cu(dg), cu(W), idx, Np)
+    close(dx, xr.grad, rtol=1e-5, atol=1e-5)
+    assert torch.equal(dx, A.linear_max_bwd(cu(dg), cu(W), idx, Np))
+    # a single hot point owning every channel (long serial chain) and a small odd Cin
+    hot = torch.zeros(B, Cout, dtype=torch.int64)
+    W2 = torch.randn(Cout, 70, generator=g)
+    dx = A.linear_max_bwd(cu(dg), cu(W2), cu(hot), Np).cpu().view(B, Np, 70)
+    close(dx[:, 0], dg @ W2, rtol=1e-4, atol=1e-4)
+    assert (dx[:, 1:] == 0).all()
