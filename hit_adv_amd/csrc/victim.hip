@@ -4,69 +4,88 @@
 //     dX[b,n,:] = sum_{j : argmax[b,j] == n} dg[b,j] * W[j,:]
 // i.e. only B*Cout rows of W are ever added, to at most Cout distinct points per cloud.  torch's
 // autograd materialises the [B*N,Cout] gradient (zero fill + scatter), and runs a dense GEMM over it;
-// this kernel does the sparse sum directly: one WAVE per destination point, the arg-max table of the
-// cloud in LDS, matches found with ballot and consumed in ascending j (fixed order, no atomics).
+// this kernel does the sparse sum directly: the arg-max table of the cloud sits in LDS, matches are
+// found with ballot and summed in a fixed order (no atomics); see linear_max_bwd_k for the work split.
 #include "common.hpp"
 #include "hitadv.h"
 
 namespace hitadv {
 
-constexpr int LM_MAXC = 8;    // Cin <= 64 * LM_MAXC
-constexpr int LM_RPW = 8;     // destination rows per wave
-constexpr int LM_ROWS = 4 * LM_RPW;
+constexpr int LM_MAXC = 8;   // Cin <= 64 * LM_MAXC
+constexpr int LM_ROWS = 32;  // destination points per block
+constexpr int LM_UN = 8;     // rows of W kept in flight per wave
 
+// One block per 32 destination points of a cloud.  Most points own no channel (a few hundred of the
+// 1024 win the max-pool), and a few own dozens, so per point: skip if no match (LDS bitmap), otherwise
+// the 4 waves split the channel range, each keeps LM_UN rows of W in flight, and the 4 partial sums are
+// added in wave order -> deterministic, and a hot point costs matches/32 dependent L2 round trips.
 __global__ __launch_bounds__(256) void linear_max_bwd_k(const float *__restrict__ dg, const float *__restrict__ W,
                                                         const int64_t *__restrict__ idx, int N, int Cout, int Cin,
                                                         float *__restrict__ dX) {
-  extern __shared__ int sidx[];  // Cout entries
-  const int b = blockIdx.y;
+  extern __shared__ int sidx[];  // Cout entries, then 4*Cin floats of partial sums
+  __shared__ int has[LM_ROWS];
+  float *part = reinterpret_cast<float *>(sidx + Cout);
+  const int b = blockIdx.y, n0 = blockIdx.x * LM_ROWS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = threadIdx.x; j < Cout; j += 256) sidx[j] = (int)idx[(size_t)b * Cout + j];
+  if (threadIdx.x < LM_ROWS) has[threadIdx.x] = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < Cout; j += 256) {
+    const int n = (int)idx[(size_t)b * Cout + j];
+    sidx[j] = n;
+    if (n >= n0 && n < n0 + LM_ROWS) has[n - n0] = 1;
+  }
   __syncthreads();
   const float *dgb = dg + (size_t)b * Cout;
   const int nc = (Cin + 63) >> 6;
-  for (int r = 0; r < LM_RPW; ++r) {
-    const int n = blockIdx.x * LM_ROWS + wave * LM_RPW + r;
-    if (n >= N) break;  // wave-uniform
+  const int jper = (((Cout + 3) >> 2) + 63) & ~63;  // channels per wave, multiple of 64
+  const int jlo = wave * jper, jhi = min(Cout, jlo + jper);
+  for (int r = 0; r < LM_ROWS; ++r) {
+    const int n = n0 + r;
+    if (n >= N) break;
+    float *o = dX + ((size_t)b * N + n) * Cin;
+    if (!has[r]) {  // block-uniform
+      for (int k = threadIdx.x; k < Cin; k += 256) o[k] = 0.f;
+      continue;
+    }
     float acc[LM_MAXC];
 #pragma unroll
     for (int c = 0; c < LM_MAXC; ++c) acc[c] = 0.f;
-    for (int j0 = 0; j0 < Cout; j0 += 64) {
+    for (int j0 = jlo; j0 < jhi; j0 += 64) {
       const int j = j0 + lane;
-      unsigned long long m = __ballot(j < Cout && sidx[j] == n);
-      // consume the matches four at a time so that four rows of W are in flight (a hot point can own
-      // dozens of channels; one dependent L2 round trip per match made this loop latency-bound)
+      unsigned long long m = __ballot(j < jhi && sidx[j] == n);
       while (m) {
-        int jj[4];
-        float g[4];
+        int jj[LM_UN];
+        float g[LM_UN];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < LM_UN; ++u) {
           const bool on = m != 0ull;
           jj[u] = on ? j0 + __builtin_ctzll(m) : 0;
           m = on ? (m & (m - 1)) : 0ull;
           g[u] = on ? dgb[jj[u]] : 0.f;
         }
-        float w[4][LM_MAXC];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int c = 0; c < LM_MAXC; ++c) {
+        for (int c = 0; c < LM_MAXC; ++c) {
+          if (c < nc) {
             const int k = lane + 64 * c;
-            w[u][c] = (c < nc && k < Cin) ? W[(size_t)jj[u] * Cin + k] : 0.f;
+            float w[LM_UN];
+#pragma unroll
+            for (int u = 0; u < LM_UN; ++u) w[u] = k < Cin ? W[(size_t)jj[u] * Cin + k] : 0.f;
+#pragma unroll
+            for (int u = 0; u < LM_UN; ++u) acc[c] = fmaf(g[u], w[u], acc[c]);
           }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int c = 0; c < LM_MAXC; ++c) acc[c] = fmaf(g[u], w[u][c], acc[c]);
+        }
       }
     }
-    float *o = dX + ((size_t)b * N + n) * Cin;
 #pragma unroll
     for (int c = 0; c < LM_MAXC; ++c)
       if (c < nc) {
         const int k = lane + 64 * c;
-        if (k < Cin) o[k] = acc[c];
+        if (k < Cin) part[wave * Cin + k] = acc[c];
       }
+    __syncthreads();
+    for (int k = threadIdx.x; k < Cin; k += 256)
+      o[k] = ((part[k] + part[Cin + k]) + part[2 * Cin + k]) + part[3 * Cin + k];
+    __syncthreads();
   }
 }
 
@@ -142,7 +161,7 @@ extern "C" int hitadv_linear_max_bwd(const float *dg, const float *W, const int6
   if (!dg || !W || !idx || !dX || B <= 0 || N <= 0 || Cout <= 0 || Cin <= 0 || Cin > 64 * LM_MAXC || Cout > 16384)
     return HITADV_E_ARG;
   dim3 grid((N + LM_ROWS - 1) / LM_ROWS, B);
-  linear_max_bwd_k<<<grid, 256, (size_t)Cout * sizeof(int), (hipStream_t)stream>>>(dg, W, idx, N, Cout, Cin, dX);
+  linear_max_bwd_k<<<grid, 256, (size_t)Cout * sizeof(int) + (size_t)4 * Cin * sizeof(float), (hipStream_t)stream>>>(dg, W, idx, N, Cout, Cin, dX);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

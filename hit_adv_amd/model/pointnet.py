@@ -164,6 +164,22 @@ class _LinearMaxOverPoints(torch.autograd.Function):
         return ops.linear_max_bwd(dg, W, idx, N), None, None, None, None, None, None
 
 
+class _LinearReLU(torch.autograd.Function):
+    """relu(x @ Wt + bias) with bias and ReLU in the GEMM epilogue (hipBLASLt, ``torch._addmm_activation``);
+    backward = threshold on the saved output + one GEMM for dX (weights are constants of the attack)."""
+
+    @staticmethod
+    def forward(ctx, x, Wt, W, bias):
+        y = torch._addmm_activation(bias, x, Wt, use_gelu=False)
+        ctx.save_for_backward(y, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, W = ctx.saved_tensors
+        return torch.mm(torch.ops.aten.threshold_backward(g, y, 0), W), None, None, None
+
+
 class FoldedPointNet(nn.Module):
     """Inference-mode restatement of ``PointNetFeatureModel`` for the attack loop (still plain
     PyTorch-ROCm ops: rocBLAS/hipBLASLt GEMMs + elementwise).  Algebraically identical to the module
@@ -186,10 +202,7 @@ class FoldedPointNet(nn.Module):
         for k, (w, b) in self._folded(m).items():
             self.register_buffer(k + '_w', w.detach().clone())
             self.register_buffer(k + '_b', b.detach().clone())
-            if k in self._MAXED:  # row-major [Cout,Cin] copy for the sparse backward
-                self.register_buffer(k + '_wr', w.detach().t().contiguous())
-
-    _MAXED = ('s3', 't3', 'e3')
+            self.register_buffer(k + '_wr', w.detach().t().contiguous())  # row-major [Cout,Cin] for dX
 
     @staticmethod
     def _folded(m):
@@ -226,12 +239,14 @@ class FoldedPointNet(nn.Module):
         for k, (w, b) in self._folded(m).items():
             getattr(self, k + '_w').copy_(w)
             getattr(self, k + '_b').copy_(b)
-            if k in self._MAXED:
-                getattr(self, k + '_wr').copy_(w.t())
+            getattr(self, k + '_wr').copy_(w.t())
         return self
 
     def _lin(self, x, name, relu=True):
-        y = torch.addmm(getattr(self, name + '_b'), x, getattr(self, name + '_w'))
+        w, b = getattr(self, name + '_w'), getattr(self, name + '_b')
+        if relu and x.is_cuda and x.shape[1] % 4 == 0:
+            return _LinearReLU.apply(x, w, getattr(self, name + '_wr'), b)
+        y = torch.addmm(b, x, w)
         return y.relu_() if relu else y
 
     def _lin_max(self, x, name, B, N, relu):
