@@ -79,7 +79,7 @@ class HiT_ADV:
     def __init__(self, model, adv_func, attack_lr=1e-2, init_weight=10., max_weight=80., binary_step=10,
                  num_iter=500, clip_func=None, cd_weight=0, curv_weight=0, ker_weight=0, hide_weight=0,
                  curv_loss_knn=32, central_num=32, total_central_num=128, max_sigm=0.7, min_sigm=0.1,
-                 budget=0.1, alpha=1, use_graph='auto', verbose=True, fast_victim=True):
+                 budget=0.1, alpha=1, use_graph='auto', verbose=True, fast_victim=True, fused_regulariser=True):
         self.model = model.cuda()
         self.model.eval()
         self.adv_func = adv_func
@@ -103,6 +103,7 @@ class HiT_ADV:
         self.use_graph = use_graph
         self.verbose = verbose
         self.fast_victim = fast_victim
+        self.fused_regulariser = fused_regulariser
         self._view = None
         self._chamfer = ChamferDist()
         self._ws = {}
@@ -202,23 +203,32 @@ class HiT_ADV:
         ops.best_update(logits.detach(), ws.target, ws.P.detach(), ws.sigma.detach(), adv.detach(), ws.state)
 
         adv_loss = self.adv_func(logits, ws.target)
-        dist_loss = torch.zeros((), device=adv.device)
-        if self.cd_weight != 0:
-            # quirk Q1 kept: the operator receives [B,3,N] tensors (:230)
-            w = torch.full((ws.B,), float(self.cd_weight), device=adv.device)
-            dist_loss = dist_loss + self._chamfer(adv, ws.ori, w)
-        if self.ker_weight != 0:
-            dist_loss = dist_loss + self.transformation_loss(adv, ws.P, ws.sigma) * self.ker_weight
-        if self.hide_weight != 0:
-            hide = self._hide(ws.sigma, ws.hide_ref, self.max_sigm, self.min_sigm) * self.hide_weight
-            dist_loss = dist_loss + hide.mean()
-        loss = (adv_loss + ws.scale_const * dist_loss).mean()
+        regs = (self.cd_weight, self.ker_weight, self.hide_weight)
+        if self.fused_regulariser and any(w != 0 for w in regs):
+            # one autograd node: the three regularisers, their gradients and the mean(scale_const) weighting
+            scaled = ops.regulariser(ws.P, ws.sigma, adv, ws.ori, ws.hide_ref, ws.scale_const, regs,
+                                     (self.min_sigm, self.max_sigm), ws.dist_loss)
+            loss = adv_loss + scaled
+            dist_loss = None
+        else:
+            dist_loss = torch.zeros((), device=adv.device)
+            if self.cd_weight != 0:
+                # quirk Q1 kept: the operator receives [B,3,N] tensors (:230)
+                w = torch.full((ws.B,), float(self.cd_weight), device=adv.device)
+                dist_loss = dist_loss + self._chamfer(adv, ws.ori, w)
+            if self.ker_weight != 0:
+                dist_loss = dist_loss + self.transformation_loss(adv, ws.P, ws.sigma) * self.ker_weight
+            if self.hide_weight != 0:
+                hide = self._hide(ws.sigma, ws.hide_ref, self.max_sigm, self.min_sigm) * self.hide_weight
+                dist_loss = dist_loss + hide.mean()
+            loss = (adv_loss + ws.scale_const * dist_loss).mean()
         g_p, g_s = torch.autograd.grad(loss, [ws.P, ws.sigma])
         ops.adam_step(ws.P, ws.sigma, g_p, g_s, ws.m_p, ws.v_p, ws.m_s, ws.v_s, ws.step,
                       self.attack_lr * 5, self.attack_lr * 3)
         ws.adv.copy_(adv.detach())
         ws.adv_loss.copy_(adv_loss.detach())
-        ws.dist_loss.copy_(dist_loss.detach())
+        if dist_loss is not None:
+            ws.dist_loss.copy_(dist_loss.detach())
 
     def _prepare_graph(self, ws):
         """Warm up on a side stream, then capture ``_iteration`` once per attack() call.  State touched

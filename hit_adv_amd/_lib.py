@@ -35,12 +35,15 @@ PROTOTYPES = {
     "hitadv_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
     "hitadv_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "hitadv_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hitadv_regulariser_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "hitadv_regulariser_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "hitadv_regulariser_scratch_floats": [_I],
     "hitadv_linear_max_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "hitadv_max_over_points": [_P, _I, _I, _I, _P, _P, _P, _P, _P],
     "hitadv_max_over_points_scratch": [_I, _I],
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,
-            "hitadv_max_over_points_scratch": _c.c_int64}
+            "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64}
 
 _lib = None
 

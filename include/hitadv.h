@@ -123,6 +123,24 @@ int hitadv_adam_step(float *perturb, const float *g_perturb, float *m_perturb, f
                      float *m_sigma, float *v_sigma, int64_t n_sigma, float lr_sigma,
                      int32_t *step, void *stream);
 
+/* The three distance regularisers of the HiT-ADV loss, fused with the per-sample weighting
+ * (ShapeAttack/HiT_ADV.py:229-245):  dist = cd_w*mean_b Q1_b + ker_w*(|P|_F+|1-sigma|_F)/C + hide_w*mean_b cos_b,
+ * where Q1_b is ChamferDist('adv2ori') evaluated on the [3,N] tensors exactly as the reference calls it
+ * (:230, quirk Q1) and cos_b the cosine similarity of :341-346 against hide_ref[B,C] (the min-max normalised
+ * centre curvature-std, constant over an attack).  Writes *dist_loss = dist and
+ * *scaled_loss = mean(scale_const) * dist  (== mean_b(scale_const_b * dist), :243-245).
+ * scratch: hitadv_regulariser_scratch_floats(B) floats, kept for the backward. */
+int hitadv_regulariser_fwd(const float *perturb, const float *sigma, const float *adv, const float *ori,
+                           const float *hide_ref, const float *scale_const, int B, int N, int C,
+                           float cd_w, float ker_w, float hide_w, float min_sigm, float max_sigm,
+                           float *scratch, float *dist_loss, float *scaled_loss, void *stream);
+/* Gradients of scaled_loss (times *grad_out) w.r.t. perturb[B,C,3], sigma[B,C] and adv[B,3,N]. */
+int hitadv_regulariser_bwd(const float *perturb, const float *sigma, const float *adv, const float *ori,
+                           const float *hide_ref, const float *scratch, const float *grad_out, int B, int N,
+                           int C, float cd_w, float ker_w, float hide_w, float min_sigm, float max_sigm,
+                           float *grad_perturb, float *grad_sigma, float *grad_adv, void *stream);
+int64_t hitadv_regulariser_scratch_floats(int B);
+
 /* ------------------------------------------------------------------ farthest point sampling */
 
 /* FPS with a given first index per cloud; running distance 1e10, strict-'<' update, arg-max with

@@ -42,10 +42,10 @@ class _Recorder:
                               adv_loss=ws.adv_loss.item()))
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_hit_adv_follows_reference_trajectory(use_graph):
+@pytest.mark.parametrize("use_graph,fused", [(False, True), (True, True), (False, False), (True, False)])
+def test_hit_adv_follows_reference_trajectory(use_graph, fused):
     fx = golden('g5_attack.npz')
-    att = _attacker(fx, use_graph=use_graph)
+    att = _attacker(fx, use_graph=use_graph, fused_regulariser=fused)
     rec = _Recorder(att) if not use_graph else None
     torch.manual_seed(int(fx['seed']))
     best, succ = att.attack(T(fx['data']), T(fx['target']))

@@ -472,3 +472,39 @@ def test_max_over_points_and_linear_max_bwd(A):
     dx = A.linear_max_bwd(cu(dg), cu(W2), cu(hot), Np).cpu().view(B, Np, 70)
     close(dx[:, 0], dg @ W2, rtol=1e-4, atol=1e-4)
     assert (dx[:, 1:] == 0).all()
+
+
+def test_fused_regulariser_matches_torch_composition(A):
+    """hitadv_regulariser_{fwd,bwd} vs the reference's composition of ChamferDist (on [B,3,N], quirk Q1),
+    transformation_loss, curv_std_loss and the scale_const weighting, evaluated by the CPU oracle + autograd."""
+    g = torch.Generator().manual_seed(11)
+    B, Np, C = 5, 700, 48
+    ori = torch.randn(B, 3, Np, generator=g) * 0.4
+    adv = (ori + 0.05 * torch.randn(B, 3, Np, generator=g)).requires_grad_()
+    adv.data[1, 0] = ori[1, 1] + 0.01  # make a cross-row match the nearest one for one cloud
+    P = (torch.rand(B, C, 3, generator=g) - 0.5).requires_grad_()
+    sig = (0.1 + 1.1 * torch.rand(B, C, generator=g)).requires_grad_()
+    kap = torch.rand(B, C, 1, generator=g)
+    scale = torch.tensor([10., 45., 80., 5., 27.5])
+    cd, ker, hide, lo, hi = 1e-4, 1.0, 1.0, 0.1, 1.2
+    dist = (O.chamfer_dist(adv, ori, torch.full((B,), cd, dtype=torch.float64)) + O.transformation_loss(P, sig, C) * ker
+            + (O.curv_std_loss(sig, kap, hi, lo) * hide).mean())
+    ref = (scale * dist).mean()
+    ref.backward()
+    ref_hide = ((kap - kap.min()) / (kap.max() - kap.min() + 1e-7)).squeeze(-1)
+    Pg, sg, ag = (cu(t.detach()).requires_grad_() for t in (P, sig, adv))
+    dist_out = torch.zeros((), device='cuda')
+    out = A.regulariser(Pg, sg, ag, cu(ori), cu(ref_hide), cu(scale), (cd, ker, hide), (lo, hi), dist_out)
+    close(out, ref, rtol=1e-5)
+    close(dist_out, dist, rtol=1e-5)
+    out.backward()
+    close(Pg.grad, P.grad, rtol=1e-4, atol=1e-7)
+    close(sg.grad, sig.grad, rtol=1e-4, atol=1e-7)
+    close(ag.grad, adv.grad, rtol=1e-4, atol=1e-9)
+    # single terms
+    for w in ((cd, 0., 0.), (0., ker, 0.), (0., 0., hide)):
+        d2 = torch.zeros((), device='cuda')
+        A.regulariser(Pg, sg, ag, cu(ori), cu(ref_hide), cu(scale), w, (lo, hi), d2)
+        parts = (O.chamfer_dist(adv, ori, torch.full((B,), 1.0, dtype=torch.float64)), O.transformation_loss(P, sig, C),
+                 O.curv_std_loss(sig, kap, hi, lo).mean())
+        close(d2, sum(wi * pi for wi, pi in zip(w, parts)), rtol=1e-5, atol=1e-9)
