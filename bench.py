@@ -81,40 +81,40 @@ def pairwise_roofline(dev):
 
 
 def hot_loop_kernels(dev):
-    """Informational: the attack loop's own kernels (deformation fwd/bwd) at cfg2 sizes."""
-    from hit_adv_amd import ops
+    """Informational: the attack loop's own kernels (deformation fwd/bwd) at cfg2 sizes, C-ABI calls
+    timed with events on the launch stream."""
+    import ctypes
+    from hit_adv_amd import _lib
+    lib = _lib.load()
     g = torch.Generator().manual_seed(1)
-    ori = torch.randn(B_PER_GPU, 3, NPOINT, generator=g).to(dev)
-    C = HP['central_num']
+    B, N, C = B_PER_GPU, NPOINT, HP['central_num']
+    ori = torch.randn(B, 3, N, generator=g).to(dev)
     central = ori[:, :, :C].contiguous()
-    P = (torch.rand(B_PER_GPU, C, 3, generator=g) * 0.55).to(dev).requires_grad_()
-    sig = (0.1 + torch.rand(B_PER_GPU, C, generator=g) * 1.1).to(dev).requires_grad_()
-    up = torch.randn(B_PER_GPU, 3, NPOINT, generator=g).to(dev)
-    out = {}
-    for name, fn in (("deform_fwd", lambda: ops.deform(ori, central, P, sig)),):
+    P = (torch.rand(B, C, 3, generator=g) * 0.55).to(dev)
+    sig = (0.1 + torch.rand(B, C, generator=g) * 1.1).to(dev)
+    up = torch.randn(B, 3, N, generator=g).to(dev)
+    adv, inv = torch.empty_like(ori), torch.empty(B, N, device=dev)
+    part = torch.empty(lib.hitadv_deform_bwd_scratch_floats(B, N, C), device=dev)
+    gp, gs = torch.empty_like(P), torch.empty_like(sig)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+
+    def timed(fn, reps=200):
         for _ in range(10):
             fn()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0.record()
-        for _ in range(100):
+        for _ in range(reps):
             fn()
         t1.record()
         torch.cuda.synchronize()
-        out[name + "_us"] = round(t0.elapsed_time(t1) * 10, 2)
-    adv = ops.deform(ori, central, P, sig)
-    for _ in range(10):
-        torch.autograd.grad(adv, [P, sig], up, retain_graph=True)
-    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0.record()
-    for _ in range(100):
-        torch.autograd.grad(adv, [P, sig], up, retain_graph=True)
-    t1.record()
-    torch.cuda.synchronize()
-    out["deform_bwd_us"] = round(t0.elapsed_time(t1) * 10, 2)
-    out["pairs_per_launch"] = B_PER_GPU * NPOINT * C
-    return out
+        return round(t0.elapsed_time(t1) * 1e3 / reps, 2)
+
+    return {"deform_fwd_us": timed(lambda: lib.hitadv_deform_fwd(p(ori), p(central), p(P), p(sig), B, N, C, p(adv), p(inv), s)),
+            "deform_bwd_us": timed(lambda: lib.hitadv_deform_bwd(p(ori), p(central), p(P), p(sig), p(adv), p(inv), p(up),
+                                                                 B, N, C, p(part), p(gp), p(gs), s)),
+            "pairs_per_launch": B * N * C}
 
 
 def cpu_baseline():
