@@ -50,22 +50,29 @@ def pairwise_roofline(dev):
     y = torch.randn(B_PER_GPU, NPOINT, 3, device=dev)
     for _ in range(20):
         P = ops.pairwise_sqdist(x, y, ops.FORM_GRAM)
-    reps = 200
     P = torch.empty(B_PER_GPU, NPOINT, NPOINT, device=dev)
     import ctypes
     from hit_adv_amd import _lib
     lib = _lib.load()
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    args = (ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(P.data_ptr()),
-            B_PER_GPU, NPOINT, NPOINT, 3, ops.FORM_GRAM, stream)
+    ptrs = (ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(P.data_ptr()))
+    # 20 back-to-back launches captured into a hipGraph (the host's ctypes call rate must not open gaps
+    # between launches), replayed between two events recorded on the stream the replays run on
+    per_graph, reps = 20, 10
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(per_graph):
+            lib.hitadv_pairwise_sqdist(*ptrs, B_PER_GPU, NPOINT, NPOINT, 3, ops.FORM_GRAM, stream)
+    g.replay()
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
     for _ in range(reps):
-        lib.hitadv_pairwise_sqdist(*args)
+        g.replay()
     t1.record()
     torch.cuda.synchronize()
-    us = t0.elapsed_time(t1) * 1e3 / reps
+    us = t0.elapsed_time(t1) * 1e3 / (reps * per_graph)
     alg_bytes = (4 * NPOINT * NPOINT + 12 * (NPOINT + NPOINT)) * B_PER_GPU  # 4,218,880 B / cloud pair
     achieved = alg_bytes / (us * 1e-6) / 1e9
     # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of tools/kbench.py at

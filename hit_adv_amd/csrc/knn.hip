@@ -1,7 +1,8 @@
 // K nearest neighbours (canonical rule: direct-difference fp32 squared distance, ascending,
 // ties -> lower index) and its backward.
 //
-//   K4  knn_topk<KB>   one lane per query, references broadcast from LDS (float4), a sorted
+//   K4  knn_topk<KB>   one lane per query and per quarter of the references (4 waves share 64 queries),
+//                      references broadcast from LDS (float4), a sorted
 //                      KB-entry insertion list per lane held entirely in VGPRs (compile-time
 //                      indices only, so nothing spills to scratch).  fp32-VALU-bound.
 #include "common.hpp"
@@ -11,13 +12,21 @@ namespace hitadv {
 
 constexpr int KNN_RCH = 1024;
 
+// One block = 64 queries x 4 waves.  Every wave scans a quarter of each staged reference chunk for the
+// SAME 64 queries (one query per lane) and keeps its own sorted KB-list in VGPRs; the four lists then
+// meet in LDS and wave 0 runs a 4-way merge (K steps) per query.  Splitting the reference range, not
+// the queries, is what quadruples the number of waves (2048 at B=32, N=1024) without shrinking a
+// query's work below one lane.  Ties: equal distances are ordered by reference index, in the lists
+// (ascending scan + stable insertion) and in the merge (explicit index compare).
 template <int KB, typename IdxT>
-__global__ __launch_bounds__(64) void knn_topk(const float *__restrict__ q, const float *__restrict__ p,
-                                               int N, int M, int K, float *__restrict__ dists,
-                                               IdxT *__restrict__ idx) {
+__global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, const float *__restrict__ p,
+                                                int N, int M, int K, float *__restrict__ dists,
+                                                IdxT *__restrict__ idx) {
   __shared__ float4 sref[KNN_RCH];
+  extern __shared__ float smerge[];  // [4][KB][64] distances, then [4][KB][64] indices
   const int b = blockIdx.y;
-  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   const bool live = i < N;
   const float *qp = q + ((size_t)b * N + (live ? i : N - 1)) * 3;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
@@ -27,17 +36,19 @@ __global__ __launch_bounds__(64) void knn_topk(const float *__restrict__ q, cons
 #pragma unroll
   for (int t = 0; t < KB; ++t) {
     d[t] = __builtin_inff();
-    ix[t] = 0;
+    ix[t] = 0x7fffffff;
   }
   for (int c0 = 0; c0 < M; c0 += KNN_RCH) {
     const int cnt = min(KNN_RCH, M - c0);
     __syncthreads();
-    for (int r = threadIdx.x; r < cnt; r += 64) {
+    for (int r = threadIdx.x; r < cnt; r += 256) {
       const float *s = p + (size_t)(c0 + r) * 3;
       sref[r] = make_float4(s[0], s[1], s[2], 0.f);
     }
     __syncthreads();
-    for (int r = 0; r < cnt; ++r) {
+    const int per = KNN_RCH / 4;
+    const int lo = wave * per, hi = min(lo + per, cnt);
+    for (int r = lo; r < hi; ++r) {
       const float4 v = sref[r];
       const float c = sqdist3(qx, qy, qz, v.x, v.y, v.z);
       if (c < d[KB - 1]) {
@@ -57,15 +68,52 @@ __global__ __launch_bounds__(64) void knn_topk(const float *__restrict__ q, cons
       }
     }
   }
-  if (live) {
-    float *od = dists + ((size_t)b * N + i) * K;
-    IdxT *oi = idx + ((size_t)b * N + i) * K;
+  float *md = smerge;
+  int *mi = reinterpret_cast<int *>(smerge + 4 * KB * 64);
 #pragma unroll
-    for (int t = 0; t < KB; ++t)
-      if (t < K) {
-        od[t] = d[t];
-        oi[t] = (IdxT)ix[t];
+  for (int t = 0; t < KB; ++t) {
+    md[(wave * KB + t) * 64 + lane] = d[t];
+    mi[(wave * KB + t) * 64 + lane] = ix[t];
+  }
+  __syncthreads();
+  if (wave != 0 || !live) return;
+  int pos[4] = {0, 0, 0, 0};
+  float hd[4];
+  int hi4[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    hd[w] = md[(w * KB) * 64 + lane];
+    hi4[w] = mi[(w * KB) * 64 + lane];
+  }
+  float *od = dists + ((size_t)b * N + i) * K;
+  IdxT *oi = idx + ((size_t)b * N + i) * K;
+  for (int t = 0; t < K; ++t) {
+    int bw = 0;
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const bool take = hd[w] < hd[bw] || (hd[w] == hd[bw] && hi4[w] < hi4[bw]);
+      bw = take ? w : bw;
+    }
+    float bd = hd[0];
+    int bi = hi4[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      bd = bw == w ? hd[w] : bd;
+      bi = bw == w ? hi4[w] : bi;
+    }
+    od[t] = bd;
+    oi[t] = (IdxT)bi;
+    // advance the winning list
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (bw == w) {
+        pos[w] += 1;
+        const bool more = pos[w] < KB;
+        const int a = (w * KB + (more ? pos[w] : KB - 1)) * 64 + lane;
+        hd[w] = more ? md[a] : __builtin_inff();
+        hi4[w] = more ? mi[a] : 0x7fffffff;
       }
+    }
   }
 }
 
@@ -102,13 +150,13 @@ __global__ __launch_bounds__(256) void knn_bwd_p(const float *__restrict__ q, co
                                                  int N, int M, int K, float *__restrict__ grad_p) {
   __shared__ int sidx[KB_ENT];
   __shared__ float sg[KB_ENT];
-  __shared__ float sq[(KB_ENT / 1) / 1 > 0 ? 3 * KB_ENT / 1 : 3];  // sized for K == 1 worst case
+  __shared__ float sq[3 * 1024];
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   const bool live = j < M;
   const float *pp = p + ((size_t)b * M + (live ? j : M - 1)) * 3;
   const float px = pp[0], py = pp[1], pz = pp[2];
-  const int qch = KB_ENT / K;  // queries per chunk
+  const int qch = min(KB_ENT / K, 1024);  // queries per chunk
   float ax = 0.f, ay = 0.f, az = 0.f;
   for (int i0 = 0; i0 < N; i0 += qch) {
     const int nq = min(qch, N - i0);
@@ -143,10 +191,14 @@ template <typename IdxT>
 static int launch_knn(const float *q, const float *p, int B, int N, int M, int K, float *dists, IdxT *idx,
                       hipStream_t s) {
   dim3 grid((N + 63) / 64, B);
-#define HITADV_KNN_CASE(KB)                                                       \
-  if (K <= KB) {                                                                  \
-    knn_topk<KB, IdxT><<<grid, 64, 0, s>>>(q, p, N, M, K, dists, idx);            \
-    return 0;                                                                     \
+#define HITADV_KNN_CASE(KB)                                                                          \
+  if (K <= KB) {                                                                                     \
+    const size_t shm = (size_t)8 * KB * 64 * sizeof(float);                                          \
+    if (shm > 48 * 1024)                                                                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_topk<KB, IdxT>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);               \
+    knn_topk<KB, IdxT><<<grid, 256, shm, s>>>(q, p, N, M, K, dists, idx);                            \
+    return 0;                                                                                        \
   }
   HITADV_KNN_CASE(1)
   HITADV_KNN_CASE(4)

@@ -4,7 +4,7 @@
 //                           float4 per row, a wave writes 1 KiB contiguous; the 4 y points of a lane
 //                           live in registers for the whole row tile, x rows come from LDS (broadcast).
 //   K2  nn_min3             fused row/column minima, D = 3, no matrix.  fp32-VALU-bound: references
-//                           staged in LDS as float4, each lane owns Q queries, the 4 waves of a block
+//                           staged in LDS as float4, each lane owns Q queries, the 8 waves of a block
 //                           split the reference range and merge (value, index) pairs through LDS.
 //   generic-D variants      correctness-first kernels for D != 3 (the [B,3,N] call of quirk Q1).
 #include "common.hpp"
@@ -118,17 +118,21 @@ __global__ __launch_bounds__(256) void pairwise_generic(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------ K2
-constexpr int K2_Q = 2;         // queries per lane
-constexpr int K2_RCH = 1024;    // references staged per LDS chunk
-constexpr int K2_QB = 64 * K2_Q;  // queries per block
+constexpr int K2_Q = 4;            // queries per lane
+constexpr int K2_NW = 8;           // waves per block; they split each staged reference chunk
+constexpr int K2_RCH = 1024;       // references staged per LDS chunk
+constexpr int K2_QB = 64 * K2_Q;   // queries per block
+// (Q, NW) = (4, 8) and -fno-slp-vectorize: 15.7 us at B=32, 1024x1024 on MI355X against 24.4 us for
+// (2, 4) with hipcc's default SLP packing (tools/tune/k2_tune.hip): 4.3 Tpair/s = 47 T lane-op/s, which
+// is the plain-VALU issue ceiling measured by tools/tune/valu_rate.hip (40-48 T lane-op/s).
 
-__global__ __launch_bounds__(256) void nn_min3(const float *__restrict__ x, const float *__restrict__ y,
-                                               int N, int M, float *__restrict__ min_x,
-                                               int32_t *__restrict__ arg_x, float *__restrict__ min_y,
-                                               int32_t *__restrict__ arg_y) {
+__global__ __launch_bounds__(K2_NW * 64) void nn_min3(const float *__restrict__ x, const float *__restrict__ y,
+                                                      int N, int M, float *__restrict__ min_x,
+                                                      int32_t *__restrict__ arg_x, float *__restrict__ min_y,
+                                                      int32_t *__restrict__ arg_y) {
   __shared__ float4 sref[K2_RCH];
-  __shared__ float sval[4][K2_QB];
-  __shared__ int sidx[4][K2_QB];
+  __shared__ float sval[K2_NW][K2_QB];
+  __shared__ int sidx[K2_NW][K2_QB];
   const int b = blockIdx.z;
   const int dir = blockIdx.y;
   const float *qp = dir == 0 ? x : y;
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(256) void nn_min3(const float *__restrict__ x, cons
   if (q0 >= nq || omin == nullptr) return;  // block-uniform
   qp += (size_t)b * nq * 3;
   rp += (size_t)b * nr * 3;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // keeps the scan bounds in SGPRs
 
   float qx[K2_Q], qy[K2_Q], qz[K2_Q], best[K2_Q];
   int bi[K2_Q];
@@ -159,12 +164,12 @@ __global__ __launch_bounds__(256) void nn_min3(const float *__restrict__ x, cons
   for (int c0 = 0; c0 < nr; c0 += K2_RCH) {
     const int cnt = min(K2_RCH, nr - c0);
     __syncthreads();
-    for (int p = threadIdx.x; p < cnt; p += 256) {
+    for (int p = threadIdx.x; p < cnt; p += K2_NW * 64) {
       const float *s = rp + (size_t)(c0 + p) * 3;
       sref[p] = make_float4(s[0], s[1], s[2], 0.f);
     }
     __syncthreads();
-    const int per = K2_RCH / 4;
+    const int per = K2_RCH / K2_NW;
     const int lo = wave * per, hi = min(lo + per, cnt);
 #pragma unroll 4
     for (int p = lo; p < hi; ++p) {
@@ -184,15 +189,15 @@ __global__ __launch_bounds__(256) void nn_min3(const float *__restrict__ x, cons
     sidx[wave][lane + 64 * t] = bi[t];
   }
   __syncthreads();
-  if (threadIdx.x < K2_QB) {
-    const int q = q0 + threadIdx.x;
+  for (int e = threadIdx.x; e < K2_QB; e += K2_NW * 64) {
+    const int q = q0 + e;
     if (q < nq) {
-      float v = sval[0][threadIdx.x];
-      int ix = sidx[0][threadIdx.x];
+      float v = sval[0][e];
+      int ix = sidx[0][e];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const float ov = sval[w][threadIdx.x];
-        const int oi = sidx[w][threadIdx.x];
+      for (int w = 1; w < K2_NW; ++w) {
+        const float ov = sval[w][e];
+        const int oi = sidx[w][e];
         const bool take = (ov < v) || (ov == v && oi < ix);
         v = take ? ov : v;
         ix = take ? oi : ix;
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256) void nn_min_bwd3(const float *__restrict__ x, 
                                                    const float *__restrict__ g_min_y, int N, int M,
                                                    float *__restrict__ grad_x, float *__restrict__ grad_y) {
   __shared__ float4 sref[BW_CH];
-  __shared__ int sarg[BW_CH];
+  __shared__ __attribute__((aligned(16))) int sarg[BW_CH];
   const int b = blockIdx.z, dir = blockIdx.y;
   const float *qp = dir == 0 ? x : y;
   const float *rp = dir == 0 ? y : x;
@@ -286,13 +291,21 @@ __global__ __launch_bounds__(256) void nn_min_bwd3(const float *__restrict__ x, 
         sref[p] = make_float4(s[0], s[1], s[2], 2.0f * g_oth[(size_t)b * nr + c0 + p]);
         sarg[p] = a_oth[(size_t)b * nr + c0 + p];
       }
+      for (int p = cnt + threadIdx.x; p < ((cnt + 3) & ~3); p += 256) sarg[p] = -1;  // pad the last int4
       __syncthreads();
-      for (int p = 0; p < cnt; ++p) {
-        if (sarg[p] == q) {
-          const float4 r = sref[p];
-          ax = ax + r.w * (qx - r.x);
-          ay = ay + r.w * (qy - r.y);
-          az = az + r.w * (qz - r.z);
+      // four arg entries per broadcast LDS read; matches are rare (each source point hits one query)
+      for (int p = 0; p < cnt; p += 4) {
+        const int4 a = *reinterpret_cast<const int4 *>(&sarg[p]);
+        if ((a.x == q) | (a.y == q) | (a.z == q) | (a.w == q)) {
+          const int av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (av[u] == q && p + u < cnt) {
+              const float4 r = sref[p + u];
+              ax = ax + r.w * (qx - r.x);
+              ay = ay + r.w * (qy - r.y);
+              az = az + r.w * (qz - r.z);
+            }
         }
       }
     }
@@ -380,7 +393,7 @@ extern "C" int hitadv_nn_min(const float *x, const float *y, int B, int N, int M
   if (D == 3) {
     const int nmax = N > M ? N : M;
     dim3 grid((nmax + K2_QB - 1) / K2_QB, 2, B);
-    nn_min3<<<grid, 256, 0, s>>>(x, y, N, M, min_x, arg_x, min_y, arg_y);
+    nn_min3<<<grid, K2_NW * 64, 0, s>>>(x, y, N, M, min_x, arg_x, min_y, arg_y);
   } else {
     if (!scratch) return HITADV_E_ARG;
     const long long total = (long long)B * N * M;

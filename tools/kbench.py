@@ -19,16 +19,27 @@ from hit_adv_amd.pytorch3d_ops import knn_points  # noqa: E402
 
 
 def timed(fn, reps):
+    """Average launch duration: 20 back-to-back launches captured into a hipGraph (so the host's ctypes call
+    rate cannot open gaps between them), replayed reps/20 times between two events."""
     for _ in range(5):
         fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(20):
+            fn(s)
+    n = max(1, reps // 20)
+    g.replay()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0.record()
-    for _ in range(reps):
-        fn()
+    for _ in range(n):
+        g.replay()
     t1.record()
     torch.cuda.synchronize()
-    return t0.elapsed_time(t1) * 1e3 / reps  # us
+    return t0.elapsed_time(t1) * 1e3 / (n * 20)  # us
 
 
 def main():
@@ -44,53 +55,53 @@ def main():
     x = torch.randn(B, N, 3, generator=g).cuda()
     y = torch.randn(B, N, 3, generator=g).cuda()
     P = torch.empty(B, N, N, device='cuda')
-    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s0 = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     out = {'B': B, 'N': N, 'C': C}
 
     for form, name in ((0, 'direct'), (1, 'gram')):
-        us = timed(lambda: lib.hitadv_pairwise_sqdist(p(x), p(y), p(P), B, N, N, 3, form, s), a.reps)
+        us = timed(lambda s=s0: lib.hitadv_pairwise_sqdist(p(x), p(y), p(P), B, N, N, 3, form, s), a.reps)
         by = (4 * N * N + 24 * N) * B
         out['pairwise_' + name] = dict(us=round(us, 2), GBps=round(by / us / 1e3, 1), frac_of_8TBps=round(by / us / 1e3 / 8000, 4))
     mx, my = torch.empty(B, N, device='cuda'), torch.empty(B, N, device='cuda')
     ax, ay = torch.empty(B, N, device='cuda', dtype=torch.int32), torch.empty(B, N, device='cuda', dtype=torch.int32)
-    us = timed(lambda: lib.hitadv_nn_min(p(x), p(y), B, N, N, 3, p(mx), p(ax), p(my), p(ay), None, s), a.reps)
+    us = timed(lambda s=s0: lib.hitadv_nn_min(p(x), p(y), B, N, N, 3, p(mx), p(ax), p(my), p(ay), None, s), a.reps)
     pairs = 2 * B * N * N  # both directions evaluated independently
     out['nn_min'] = dict(us=round(us, 2), Gpairs_per_s=round(pairs / us / 1e3, 1),
                          valu_TFLOPs_at_11_ops=round(pairs * 11 / us / 1e6, 2))
     gx = torch.empty_like(x)
     gy = torch.empty_like(y)
     gm = torch.randn(B, N, device='cuda')
-    us = timed(lambda: lib.hitadv_nn_min_bwd(p(x), p(y), p(ax), p(ay), p(gm), p(gm), B, N, N, 3, p(gx), p(gy), s), a.reps)
+    us = timed(lambda s=s0: lib.hitadv_nn_min_bwd(p(x), p(y), p(ax), p(ay), p(gm), p(gm), B, N, N, 3, p(gx), p(gy), s), a.reps)
     out['nn_min_bwd'] = dict(us=round(us, 2))
     for K in (1, 6, 17):
         d = torch.empty(B, N, K, device='cuda')
         ix = torch.empty(B, N, K, device='cuda', dtype=torch.int64)
-        us = timed(lambda: lib.hitadv_knn_points(p(x), p(x), B, N, N, K, p(d), p(ix), 1, s), max(20, a.reps // 4))
+        us = timed(lambda s=s0: lib.hitadv_knn_points(p(x), p(x), B, N, N, K, p(d), p(ix), 1, s), max(20, a.reps // 4))
         out['knn_K%d' % K] = dict(us=round(us, 2), Gpairs_per_s=round(B * N * N / us / 1e3, 1))
     ori = x.transpose(1, 2).contiguous()
     central = ori[:, :, :C].contiguous()
     Pm = (torch.rand(B, C, 3, generator=g) * 0.55).cuda()
     sig = (0.1 + torch.rand(B, C, generator=g) * 1.1).cuda()
     adv, inv = torch.empty_like(ori), torch.empty(B, N, device='cuda')
-    us = timed(lambda: lib.hitadv_deform_fwd(p(ori), p(central), p(Pm), p(sig), B, N, C, p(adv), p(inv), s), a.reps)
+    us = timed(lambda s=s0: lib.hitadv_deform_fwd(p(ori), p(central), p(Pm), p(sig), B, N, C, p(adv), p(inv), s), a.reps)
     out['deform_fwd'] = dict(us=round(us, 2), Gpairs_per_s=round(B * N * C / us / 1e3, 2))
     part = torch.empty(lib.hitadv_deform_bwd_scratch_floats(B, N, C), device='cuda')
     gp, gs = torch.empty_like(Pm), torch.empty_like(sig)
     up = torch.randn(B, 3, N, device='cuda')
-    us = timed(lambda: lib.hitadv_deform_bwd(p(ori), p(central), p(Pm), p(sig), p(adv), p(inv), p(up), B, N, C,
+    us = timed(lambda s=s0: lib.hitadv_deform_bwd(p(ori), p(central), p(Pm), p(sig), p(adv), p(inv), p(up), B, N, C,
                                              p(part), p(gp), p(gs), s), a.reps)
     out['deform_bwd(+reduce)'] = dict(us=round(us, 2), Gpairs_per_s=round(B * N * C / us / 1e3, 2))
     start = torch.zeros(B, dtype=torch.int64, device='cuda')
     fi = torch.empty(B, 256, dtype=torch.int64, device='cuda')
-    us = timed(lambda: lib.hitadv_fps_from_start(p(x), p(start), B, N, 256, p(fi), s), 20)
+    us = timed(lambda s=s0: lib.hitadv_fps_from_start(p(x), p(start), B, N, 256, p(fi), s), 20)
     out['fps_from_start_m256'] = dict(us=round(us, 1), us_per_step=round(us / 256, 3))
     f32 = torch.empty(B, 51, dtype=torch.int32, device='cuda')
-    us = timed(lambda: lib.hitadv_furthest_point_sampling(B, N, 51, p(x), None, p(f32), s), 20)
+    us = timed(lambda s=s0: lib.hitadv_furthest_point_sampling(B, N, 51, p(x), None, p(f32), s), 20)
     out['fps_ext_m51'] = dict(us=round(us, 1), us_per_step=round(us / 50, 3))
     new_xyz = x[:, :51].contiguous()
     bq = torch.empty(B, 51, 49, dtype=torch.int32, device='cuda')
-    us = timed(lambda: lib.hitadv_query_ball_point(B, N, 51, ctypes.c_float(0.22), 49, p(new_xyz), p(x), p(bq), s), a.reps)
+    us = timed(lambda s=s0: lib.hitadv_query_ball_point(B, N, 51, ctypes.c_float(0.22), 49, p(new_xyz), p(x), p(bq), s), a.reps)
     out['ball_query_m51_ns49'] = dict(us=round(us, 2))
     print(json.dumps(out))
 
