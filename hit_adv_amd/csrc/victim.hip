@@ -12,7 +12,7 @@
 namespace hitadv {
 
 constexpr int LM_MAXC = 8;   // Cin <= 64 * LM_MAXC
-constexpr int LM_ROWS = 32;  // destination points per block
+constexpr int LM_ROWS = 8;   // destination points per block (small: hot points spread over more CUs)
 constexpr int LM_UN = 8;     // rows of W kept in flight per wave
 
 // One block per 32 destination points of a cloud.  Most points own no channel (a few hundred of the
