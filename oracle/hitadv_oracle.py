@@ -559,6 +559,63 @@ def cw_knn_attack(model, adv_func, dist_func, clip_func, data, target, attack_lr
     return adv.transpose(1, 2).contiguous().detach().numpy(), success
 
 
+def cw_perturb_attack(model, adv_func, dist_func, data, target, attack_lr=1e-2, init_weight=10.,
+                      max_weight=80., binary_step=10, num_iter=500, clip_func=None, trace=None):
+    """CPU restatement of CW/Perturb.py::CWPerturb.attack (:46-202), host-side bookkeeping as in the
+    reference (numpy float64 bounds, strict '<' best tracking, success = pred == target)."""
+    B, N = data.shape[:2]
+    pc = data.float().detach()
+    if pc.shape[1] > 6:
+        pc = pc.transpose(1, 2).contiguous()
+    if pc.shape[1] == 6:
+        pc = pc[:, :3, :]
+    ori = pc.clone().detach()
+    target = target.long().detach()
+    label = target.numpy()
+    lower, upper = np.zeros((B,)), np.ones((B,)) * max_weight
+    weight = np.ones((B,)) * init_weight
+    o_bestdist, o_bestscore = np.array([1e10] * B), np.array([-1] * B)
+    o_bestattack = np.zeros((B, 3, N))
+    last_input = None
+    for step in range(binary_step):
+        adv = (ori.clone().detach() + torch.randn((B, 3, N)) * 1e-7).requires_grad_()
+        bestdist, bestscore = np.array([1e10] * B), np.array([-1] * B)
+        opt = torch.optim.Adam([adv], lr=attack_lr, weight_decay=0.)
+        for it in range(num_iter):
+            out = model(adv)
+            logits = out[0] if isinstance(out, tuple) else out
+            pred = torch.argmax(logits, dim=1).numpy()
+            dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2])).detach().numpy()
+            last_input = adv.detach().numpy().copy()
+            for e in range(B):
+                if pred[e] == label[e]:
+                    if dist_val[e] < bestdist[e]:
+                        bestdist[e], bestscore[e] = dist_val[e], pred[e]
+                    if dist_val[e] < o_bestdist[e]:
+                        o_bestdist[e], o_bestscore[e] = dist_val[e], pred[e]
+                        o_bestattack[e] = last_input[e]
+            adv_loss = adv_func(logits, target).mean()
+            dist_loss = dist_func(adv, ori, torch.from_numpy(weight)).mean()
+            opt.zero_grad()
+            (adv_loss + dist_loss).backward()
+            opt.step()
+            if clip_func is not None:
+                adv.data = clip_func(adv.clone().detach(), ori)
+            if trace is not None:
+                trace.append(dict(step=step, it=it, adv_loss=adv_loss.item(), dist_loss=dist_loss.item(),
+                                  adv=adv.detach().clone().numpy()))
+        for e in range(B):
+            if bestscore[e] == label[e] and bestscore[e] != -1 and bestdist[e] <= o_bestdist[e]:
+                lower[e] = max(lower[e], weight[e])
+            else:
+                upper[e] = min(upper[e], weight[e])
+            weight[e] = (lower[e] + upper[e]) / 2.
+    for e in range(B):
+        if lower[e] == 0.:
+            o_bestattack[e] = last_input[e]
+    return o_bestattack.transpose((0, 2, 1)), int((lower > 0.).sum()), dict(lower=lower, upper=upper)
+
+
 # --------------------------------------------------------------------------
 # eval_ASR metric phase                      util/other_utils.py:15-101
 # --------------------------------------------------------------------------

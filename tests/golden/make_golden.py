@@ -17,6 +17,7 @@ Fixture index:
   g6_adv_clip.npz      adversarial losses and clip/projection operators
   g7_cwknn.npz         CWKNN.attack trajectory with the toy victim
   g8_state_dicts.json  state_dict key/shape lists of the victims
+  g9_cwperturb.npz     CWPerturb.attack (L2Dist + ClipPointsLinf) trajectory with the toy victim
 """
 import io
 import json
@@ -36,6 +37,7 @@ ref_harness.install()
 from ShapeAttack.HiT_ADV import HiT_ADV  # noqa: E402
 from util import dist_utils, set_distance, adv_utils, clip_utils  # noqa: E402
 from CW.kNN import CWKNN  # noqa: E402
+from CW.Perturb import CWPerturb  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -329,6 +331,31 @@ def g7():
     save('g7_cwknn.npz', out)
 
 
+# ------------------------------------------------------------------ G9
+def g9():
+    model = toy_victim(12)
+    data, _ = synth_batch(3, 256, first=50)
+    xyz = data[:, :, :3].contiguous()
+    with torch.no_grad():
+        clean = model(xyz.transpose(1, 2).contiguous()).argmax(1)
+    target = (clean + 3) % 40
+    advs = []
+    clip = clip_utils.ClipPointsLinf(budget=0.18)
+
+    def recording_clip(pc, ori_pc):
+        r = clip(pc, ori_pc)
+        advs.append(r.detach().clone())
+        return r
+
+    att = CWPerturb(model, adv_utils.LogitsAdvLoss(kappa=5.), dist_utils.L2Dist(), attack_lr=1e-2, init_weight=10.,
+                    max_weight=80., binary_step=3, num_iter=10, clip_func=recording_clip)
+    torch.manual_seed(23)
+    with redirect_stdout(io.StringIO()):
+        best, succ = att.attack(xyz, target)
+    save('g9_cwperturb.npz', dict(data=xyz, target=target, seed=23, adv_trace=torch.stack(advs), best=best,
+                                  success_num=int(succ), **{'w_' + k: v for k, v in model.state_dict().items()}))
+
+
 # ------------------------------------------------------------------ G8
 def g8():
     shapes = {}
@@ -363,6 +390,6 @@ def g8():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9']
     for name in which:
         globals()[name]()

@@ -17,7 +17,9 @@ replaced by stand-ins in ``sys.modules``:
 * ``pointnet2_ops_lib...pointnet2_utils``: the CUDA extension (cannot be built
   without nvcc / run without a GPU) -- placeholder only so ``util.other_utils``
   imports; nothing captured here calls it.
-* ``Tensor.cuda`` / ``Module.cuda`` become identities (no GPU here).
+* ``Tensor.cuda`` / ``Module.cuda`` become identities (no GPU here); ``Tensor.cpu`` returns a COPY, as a
+  device->host transfer does -- on a CPU-only box ``t.cpu().numpy()`` would otherwise alias ``t`` and the
+  reference's ``input_val`` snapshots (CW/Perturb.py:125) would silently follow later in-place Adam steps.
 """
 import collections
 import os
@@ -92,6 +94,7 @@ def install():
         sys.modules["pointnet2_ops_lib.pointnet2_ops.pointnet2_utils"]
 
     torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.cpu = lambda self, *a, **k: self.detach().clone() if not self.requires_grad else self.clone()
     torch.nn.Module.cuda = lambda self, *a, **k: self
     torch.cuda.empty_cache = lambda: None
 

@@ -278,3 +278,28 @@ def test_consecutive_attacks_graph_equals_eager_pointnet():
             assert att.last_graph_used == graph
         for a, b in zip(res[False], res[True]):
             assert np.array_equal(a, b)
+
+
+def test_cwperturb_follows_reference_trajectory():
+    from hit_adv_amd.CW.Perturb import CWPerturb
+    from hit_adv_amd.util.adv_utils import LogitsAdvLoss
+    from hit_adv_amd.util.clip_utils import ClipPointsLinf
+    from hit_adv_amd.util.dist_utils import L2Dist
+    fx = golden('g9_cwperturb.npz')
+    trace = []
+    clip = ClipPointsLinf(budget=0.18)
+
+    def recording_clip(pc, ori):
+        out = clip(pc, ori)
+        trace.append(out.detach().cpu().numpy().copy())
+        return out
+
+    att = CWPerturb(toy_from_fixture(fx), LogitsAdvLoss(kappa=5.), L2Dist(), attack_lr=1e-2, init_weight=10.,
+                    max_weight=80., binary_step=3, num_iter=10, clip_func=recording_clip, verbose=False)
+    torch.manual_seed(int(fx['seed']))
+    best, succ = att.attack(T(fx['data']), T(fx['target']))
+    assert len(trace) == 30 and best.dtype == np.float64 and best.shape == fx['best'].shape
+    for i, row in enumerate(trace):
+        np.testing.assert_allclose(row, fx['adv_trace'][i], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(best, fx['best'], rtol=1e-4, atol=2e-6)
+    assert succ == int(fx['success_num'])

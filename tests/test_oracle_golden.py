@@ -170,3 +170,19 @@ def test_g8_pointnet_state_dict_layout_recorded():
     shapes = golden_json('g8_state_dicts.json')
     assert len(shapes['pointnet']) == 111
     assert shapes['pointnet_param_count'] == 3471473
+
+
+def test_g9_cwperturb_trajectory():
+    fx = golden('g9_cwperturb.npz')
+    model = toy_from_fixture(fx)
+    torch.manual_seed(int(fx['seed']))
+    trace = []
+    best, succ, _ = O.cw_perturb_attack(
+        model, lambda l, t: O.logits_adv_loss(l, t, 5.), O.l2_dist, T(fx['data']), T(fx['target']),
+        attack_lr=1e-2, init_weight=10., max_weight=80., binary_step=3, num_iter=10,
+        clip_func=lambda pc, ori: O.clip_points_linf(pc, ori, 0.18), trace=trace)
+    assert len(trace) == 30
+    for i, rec in enumerate(trace):
+        close(rec['adv'], fx['adv_trace'][i], rtol=1e-4, atol=1e-6)
+    close(best, fx['best'], rtol=1e-4, atol=1e-6)
+    assert succ == int(fx['success_num']) and best.dtype == np.float64
