@@ -20,6 +20,7 @@ PROTOTYPES = {
     "hitadv_nn_min_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "hitadv_knn_points": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
     "hitadv_knn_points_bwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P],
+    "hitadv_topk_rows": [_P, _L, _I, _I, _I, _P, _P, _P],
     "hitadv_deform_fwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "hitadv_deform_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_deform_bwd_scratch_floats": [_I, _I, _I],

@@ -117,6 +117,64 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
   }
 }
 
+// K smallest (or largest) entries of every row of a materialised matrix P[B*N, M], ascending
+// (descending) with ties -> lower column index: the selection half of DGCNN's feature-space kNN
+// (model/dgcnn_cls.py:7-13: Gram matrix by GEMM, then topk).  One lane per row; a 64-row x 64-column tile is
+// staged through LDS so that the global reads are coalesced along the row (each wave reads 64 x 256 B
+// segments) and the per-lane reads are conflict-free (row pitch 65 words).
+template <int KB, bool LARGEST>
+__global__ __launch_bounds__(64) void topk_rows(const float *__restrict__ P, long long rows, int M, int K,
+                                                float *__restrict__ vals, int64_t *__restrict__ idx) {
+  __shared__ float tile[64 * 65];
+  const int lane = threadIdx.x;
+  const long long r0 = (long long)blockIdx.x * 64;
+  const long long row = r0 + lane;
+  const bool live = row < rows;
+  float d[KB];
+  int ix[KB];
+#pragma unroll
+  for (int t = 0; t < KB; ++t) {
+    d[t] = __builtin_inff();
+    ix[t] = 0x7fffffff;
+  }
+  for (int c0 = 0; c0 < M; c0 += 64) {
+    const int cnt = min(64, M - c0);
+    __syncthreads();
+    for (int rr = 0; rr < 64; ++rr) {
+      const long long gr = r0 + rr;
+      if (gr < rows && lane < cnt) tile[rr * 65 + lane] = P[gr * M + c0 + lane];
+    }
+    __syncthreads();
+    for (int cc = 0; cc < cnt; ++cc) {
+      float c = tile[lane * 65 + cc];
+      if (LARGEST) c = -c;
+      if (c < d[KB - 1]) {
+        const int j = c0 + cc;
+#pragma unroll
+        for (int t = KB - 1; t > 0; --t) {
+          const bool sh = c < d[t - 1];
+          const bool wr = c < d[t];
+          const float nd = sh ? d[t - 1] : c;
+          const int ni = sh ? ix[t - 1] : j;
+          d[t] = wr ? nd : d[t];
+          ix[t] = wr ? ni : ix[t];
+        }
+        const bool w0 = c < d[0];
+        d[0] = w0 ? c : d[0];
+        ix[0] = w0 ? j : ix[0];
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int t = 0; t < KB; ++t)
+      if (t < K) {
+        vals[row * K + t] = LARGEST ? -d[t] : d[t];
+        idx[row * K + t] = ix[t];
+      }
+  }
+}
+
 template <typename IdxT>
 __global__ __launch_bounds__(256) void knn_bwd_q(const float *__restrict__ q, const float *__restrict__ p,
                                                  const IdxT *__restrict__ idx, const float *__restrict__ g,
@@ -228,6 +286,31 @@ extern "C" int hitadv_knn_points(const float *q, const float *p, int B, int N, i
   if (rc) return rc;
   HITADV_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int hitadv_topk_rows(const float *P, int64_t rows, int M, int K, int largest, float *vals, int64_t *idx,
+                                void *stream) {
+  if (!P || !vals || !idx || rows <= 0 || M <= 0 || K <= 0 || K > 64 || K > M) return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((rows + 63) / 64);
+#define HITADV_TOPK_CASE(KB)                                                           \
+  if (K <= KB) {                                                                       \
+    if (largest)                                                                       \
+      topk_rows<KB, true><<<grid, 64, 0, s>>>(P, rows, M, K, vals, idx);               \
+    else                                                                               \
+      topk_rows<KB, false><<<grid, 64, 0, s>>>(P, rows, M, K, vals, idx);              \
+    HITADV_LAUNCH_CHECK();                                                             \
+    return 0;                                                                          \
+  }
+  HITADV_TOPK_CASE(4)
+  HITADV_TOPK_CASE(8)
+  HITADV_TOPK_CASE(16)
+  HITADV_TOPK_CASE(24)
+  HITADV_TOPK_CASE(32)
+  HITADV_TOPK_CASE(48)
+  HITADV_TOPK_CASE(64)
+#undef HITADV_TOPK_CASE
+  return HITADV_E_ARG;
 }
 
 extern "C" int hitadv_knn_points_bwd(const float *q, const float *p, const void *idx, int idx_is_i64,

@@ -247,3 +247,14 @@ def max_over_points(y, B, N):
     idx = torch.empty(B, C, device=y.device, dtype=torch.int64)
     _lib.call("hitadv_max_over_points", _p(y), B, N, C, _p(pv), _p(pi), _p(out), _p(idx), _stream())
     return out, idx
+
+
+def topk_rows(P, K, largest=True):
+    """Row-wise top-K of a matrix [..., M] -> (vals[..., K], idx[..., K] int64), sorted, ties -> lower column."""
+    P = _dev(P.detach(), "P")
+    M = P.shape[-1]
+    rows = P.numel() // M
+    vals = torch.empty(*P.shape[:-1], K, device=P.device)
+    idx = torch.empty(*P.shape[:-1], K, device=P.device, dtype=torch.int64)
+    _lib.call("hitadv_topk_rows", _p(P), rows, M, K, 1 if largest else 0, _p(vals), _p(idx), _stream())
+    return vals, idx

@@ -82,6 +82,12 @@ int hitadv_knn_points_bwd(const float *q, const float *p, const void *idx, int i
                           const float *g_dists, int B, int N, int M, int K, float *grad_q,
                           float *grad_p, void *stream);
 
+/* K largest (largest != 0) or smallest entries of every row of P[rows, M], sorted, ties -> lower column.
+ * vals[rows,K], idx[rows,K] int64.  The selection step of DGCNN's feature-space kNN
+ * (model/dgcnn_cls.py:12 `pairwise_distance.topk(k)`) and of model/pct_utils.py:98-109. */
+int hitadv_topk_rows(const float *P, int64_t rows, int M, int K, int largest, float *vals, int64_t *idx,
+                     void *stream);
+
 /* ------------------------------------------------------------------ HiT-ADV deformation */
 
 /* Kernel-weighted deformation, replaces HiT_ADV.kernel_density + the C-step accumulation loop

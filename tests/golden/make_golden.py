@@ -18,6 +18,7 @@ Fixture index:
   g7_cwknn.npz         CWKNN.attack trajectory with the toy victim
   g8_state_dicts.json  state_dict key/shape lists of the victims
   g9_cwperturb.npz     CWPerturb.attack (L2Dist + ClipPointsLinf) trajectory with the toy victim
+  g10_dgcnn.npz        DGCNN_cls (seeded init, eval mode): logits, input gradient, first-layer kNN table
 """
 import io
 import json
@@ -356,6 +357,32 @@ def g9():
                                   success_num=int(succ), **{'w_' + k: v for k, v in model.state_dict().items()}))
 
 
+# ------------------------------------------------------------------ G10
+def g10():
+    import argparse
+    import model.dgcnn_cls as ref_dgcnn
+
+    class _TorchOnCpu:  # dgcnn_cls.py:25 hard-codes torch.device('cuda'); everything else passes through
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def device(*a, **k):
+            return torch.device('cpu')
+
+    ref_dgcnn.torch = _TorchOnCpu()
+    torch.manual_seed(31)
+    m = ref_dgcnn.DGCNN_cls(argparse.Namespace(k=5, emb_dims=1024, dropout=0.2), output_channels=40).eval()
+    data, _ = synth_batch(2, 256, first=60)
+    x = data[:, :, :3].transpose(1, 2).contiguous().requires_grad_()
+    logits = m(x)
+    w = torch.randn(2, 40, generator=torch.Generator().manual_seed(4))
+    (logits * w).sum().backward()
+    save('g10_dgcnn.npz', dict(x=x.detach(), logits=logits, grad_w=w, grad_x=x.grad, seed=31,
+                               knn_layer1=ref_dgcnn.knn(x.detach(), 5),
+                               edge_layer1=ref_dgcnn.get_graph_feature(x.detach(), k=5)))
+
+
 # ------------------------------------------------------------------ G8
 def g8():
     shapes = {}
@@ -390,6 +417,6 @@ def g8():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10']
     for name in which:
         globals()[name]()

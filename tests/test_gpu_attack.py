@@ -303,3 +303,36 @@ def test_cwperturb_follows_reference_trajectory():
         np.testing.assert_allclose(row, fx['adv_trace'][i], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(best, fx['best'], rtol=1e-4, atol=2e-6)
     assert succ == int(fx['success_num'])
+
+
+def test_dgcnn_victim_on_gpu_and_under_attack():
+    """DGCNN with the HIP kNN graph: logits / input gradient against the reference's (fixture g10, CPU) and a
+    short HiT-ADV run on it (graph == eager)."""
+    import argparse
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.dgcnn import DGCNN_cls, knn
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    fx = golden('g10_dgcnn.npz')
+    torch.manual_seed(int(fx['seed']))
+    m = DGCNN_cls(argparse.Namespace(k=5, emb_dims=1024, dropout=0.2), output_channels=40).eval().cuda()
+    x = T(fx['x']).cuda().requires_grad_()
+    assert torch.equal(knn(x.detach(), 5).cpu(), T(fx['knn_layer1']))  # 3-D layer: fused HIP kNN, same table
+    logits = m(x)
+    # feature-space neighbour tables come from GPU GEMMs; a near-tie can pick another neighbour, so the
+    # tolerance is looser than for a fixed graph
+    close(logits, fx['logits'], rtol=2e-3, atol=2e-4)
+    (logits * T(fx['grad_w']).cuda()).sum().backward()
+    g = x.grad.cpu().numpy()
+    assert np.abs(g - fx['grad_x']).max() <= 0.05 * np.abs(fx['grad_x']).max()
+    data, _ = synth_batch(4, 512, first=1200)
+    with torch.no_grad():
+        label = m(data[:, :, :3].transpose(1, 2).contiguous().cuda()).argmax(1)
+    outs = []
+    for graph in (False, True):
+        att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), binary_step=2, num_iter=5, cd_weight=1e-4, ker_weight=1.,
+                      hide_weight=1., curv_loss_knn=16, central_num=64, total_central_num=96, max_sigm=1.2,
+                      min_sigm=0.1, budget=0.55, verbose=False, use_graph=graph)
+        torch.manual_seed(8)
+        outs.append(att.attack(data, label)[0])
+        assert att.last_graph_used == graph
+    assert np.array_equal(outs[0], outs[1])

@@ -508,3 +508,15 @@ def test_fused_regulariser_matches_torch_composition(A):
         parts = (O.chamfer_dist(adv, ori, torch.full((B,), 1.0, dtype=torch.float64)), O.transformation_loss(P, sig, C),
                  O.curv_std_loss(sig, kap, hi, lo).mean())
         close(d2, sum(wi * pi for wi, pi in zip(w, parts)), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("K,largest", [(1, True), (5, True), (20, True), (20, False), (64, False)])
+def test_topk_rows_bit_exact(A, K, largest):
+    g = torch.Generator().manual_seed(9)
+    P = torch.randn(3, 130, 257, generator=g)
+    P[0, 0, 5] = P[0, 0, 9] = 7.0  # ties -> lower column first
+    P[0, 0, 100] = P[0, 0, 3] = -7.0
+    vals, idx = A.topk_rows(cu(P), K, largest=largest)
+    order = torch.sort(-P if largest else P, dim=-1, stable=True)
+    assert torch.equal(idx.cpu(), order.indices[..., :K])
+    assert torch.equal(vals.cpu(), P.gather(-1, order.indices[..., :K]))
