@@ -335,4 +335,6 @@ def test_dgcnn_victim_on_gpu_and_under_attack():
         torch.manual_seed(8)
         outs.append(att.attack(data, label)[0])
         assert att.last_graph_used == graph
-    assert np.array_equal(outs[0], outs[1])
+    # torch's gather backward (edge features) accumulates with atomics, so DGCNN gradients are not bitwise
+    # reproducible run to run; graph and eager agree to rounding instead of bit for bit
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-3, atol=1e-4)
