@@ -31,6 +31,7 @@ PROTOTYPES = {
     "hitadv_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_query_ball_point": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "hitadv_query_ball_point_inclusive": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
     "hitadv_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],

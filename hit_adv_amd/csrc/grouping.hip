@@ -9,10 +9,11 @@ namespace hitadv {
 // ballot + prefix popcount, so the "first nsample hits in index order" rule of
 // ball_query_gpu.cu:9-44 is kept without a serial scan.  Empty ball -> zeros, short ball -> padded
 // with the first hit.
+template <bool INCLUSIVE, typename IdxT>
 __global__ __launch_bounds__(256) void ball_query_k(int n, int m, float radius2, int nsample,
                                                     const float *__restrict__ new_xyz,
-                                                    const float *__restrict__ xyz, int32_t *__restrict__ idx,
-                                                    long long nquery) {
+                                                    const float *__restrict__ xyz, IdxT *__restrict__ idx,
+                                                    long long nquery, int empty_value) {
   const long long qid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qid >= nquery) return;
   const int lane = threadIdx.x & 63;
@@ -20,25 +21,25 @@ __global__ __launch_bounds__(256) void ball_query_k(int n, int m, float radius2,
   const float *q = new_xyz + qid * 3;
   const float qx = q[0], qy = q[1], qz = q[2];
   const float *P = xyz + (size_t)b * n * 3;
-  int32_t *out = idx + qid * nsample;
-  int cnt = 0, first = 0;
+  IdxT *out = idx + qid * nsample;
+  int cnt = 0, first = empty_value;
   for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64) {
     const int k = k0 + lane;
     bool hit = false;
     if (k < n) {
       const float d2 = sqdist3(qx, qy, qz, P[k * 3], P[k * 3 + 1], P[k * 3 + 2]);
-      hit = d2 < radius2;
+      hit = INCLUSIVE ? (d2 <= radius2) : (d2 < radius2);
     }
     const unsigned long long mask = __ballot(hit);
     if (mask) {
       if (cnt == 0) first = k0 + __builtin_ctzll(mask);
       const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-      if (hit && pos < nsample) out[pos] = k;
+      if (hit && pos < nsample) out[pos] = (IdxT)k;
       cnt += __popcll(mask);
     }
   }
   cnt = cnt < nsample ? cnt : nsample;
-  for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;
+  for (int l = cnt + lane; l < nsample; l += 64) out[l] = (IdxT)first;
 }
 
 __global__ __launch_bounds__(256) void group_points_k(int c, int n, int npoints, int nsample,
@@ -159,8 +160,18 @@ extern "C" int hitadv_query_ball_point(int b, int n, int m, float radius, int ns
                                        const float *xyz, int32_t *idx, void *stream) {
   if (!new_xyz || !xyz || !idx || b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return HITADV_E_ARG;
   const long long nq = (long long)b * m;
-  ball_query_k<<<(unsigned)((nq + 3) / 4), 256, 0, (hipStream_t)stream>>>(n, m, radius * radius, nsample,
-                                                                          new_xyz, xyz, idx, nq);
+  ball_query_k<false, int32_t><<<(unsigned)((nq + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      n, m, radius * radius, nsample, new_xyz, xyz, idx, nq, 0);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_query_ball_point_inclusive(int b, int n, int m, float radius, int nsample,
+                                                 const float *new_xyz, const float *xyz, int64_t *idx, void *stream) {
+  if (!new_xyz || !xyz || !idx || b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return HITADV_E_ARG;
+  const long long nq = (long long)b * m;
+  ball_query_k<true, int64_t><<<(unsigned)((nq + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      n, m, radius * radius, nsample, new_xyz, xyz, idx, nq, n);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

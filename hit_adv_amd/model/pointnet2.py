@@ -1,0 +1,108 @@
+"""PointNet++ SSG victim (cfg4 of BASELINE.json).  Parameter names follow the reference's
+model/pointnet2_cls_ssg.py::get_model (:6-42) and model/pointnet2_utils.py::PointNetSetAbstraction (:161-205),
+79 state_dict entries (tests/golden/g8_state_dicts.json).  The MLPs stay PyTorch-ROCm; the geometry runs in HIP:
+
+* ``farthest_point_sample`` (pointnet2_utils.py:63-84): the random first index is drawn from the CPU generator
+  exactly as the reference does (:75), the 512/128 sequential arg-max steps run in ``hitadv_fps_from_start``;
+* ``query_ball_point`` (:87-107): ``hitadv_query_ball_point_inclusive`` (d^2 <= r^2, first nsample in index order,
+  padded with the first hit) instead of a [B,S,N] distance matrix + full sort.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def index_points(points, idx):
+    """points [B,N,C], idx [B,S] or [B,S,K] -> [B,S,C] / [B,S,K,C]."""
+    B, _, C = points.shape
+    flat = idx.reshape(B, -1, 1).expand(-1, -1, C)
+    return points.gather(1, flat).reshape(*idx.shape, C)
+
+
+def farthest_point_sample(xyz, npoint):
+    B, N, _ = xyz.shape
+    start = torch.randint(0, N, (B,), dtype=torch.long)
+    return ops.fps_from_start(xyz, npoint, start.to(xyz.device))
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    return ops.query_ball_point(radius, nsample, xyz, new_xyz)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points):
+    B, N, C = xyz.shape
+    new_xyz = index_points(xyz, farthest_point_sample(xyz, npoint))
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped = index_points(xyz, idx) - new_xyz.view(B, npoint, 1, C)
+    if points is not None:
+        grouped = torch.cat([grouped, index_points(points, idx)], dim=-1)
+    return new_xyz, grouped
+
+
+def sample_and_group_all(xyz, points):
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    grouped = xyz.view(B, 1, N, C)
+    if points is not None:
+        grouped = torch.cat([grouped, points.view(B, 1, N, -1)], dim=-1)
+    return new_xyz, grouped
+
+
+class PointNetSetAbstraction(nn.Module):
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.group_all = npoint, radius, nsample, group_all
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for out in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, out, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out))
+            last = out
+
+    def forward(self, xyz, points):
+        """xyz [B,3,N], points [B,D,N] or None -> (new_xyz [B,3,S], features [B,D',S])."""
+        xyz = xyz.permute(0, 2, 1).contiguous()
+        if points is not None:
+            points = points.permute(0, 2, 1)
+        if self.group_all:
+            new_xyz, grouped = sample_and_group_all(xyz, points)
+        else:
+            new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points)
+        h = grouped.permute(0, 3, 2, 1)  # [B,C+D,nsample,npoint]
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            h = F.relu(bn(conv(h)))
+        return new_xyz.permute(0, 2, 1), torch.max(h, 2)[0]
+
+
+class get_model(nn.Module):
+    """``forward(xyz[B,3|6,N]) -> (logits, l3_points)`` -- a tuple, like the reference (pointnet2_cls_ssg.py:42)."""
+
+    def __init__(self, num_class, normal_channel=True):
+        super().__init__()
+        in_channel = 6 if normal_channel else 3
+        self.normal_channel = normal_channel
+        self.sa1 = PointNetSetAbstraction(512, 0.2, 32, in_channel, [64, 64, 128], False)
+        self.sa2 = PointNetSetAbstraction(128, 0.4, 64, 128 + 3, [128, 128, 256], False)
+        self.sa3 = PointNetSetAbstraction(None, None, None, 256 + 3, [256, 512, 1024], True)
+        self.fc1 = nn.Linear(1024, 512)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.drop1 = nn.Dropout(0.4)
+        self.fc2 = nn.Linear(512, 256)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.drop2 = nn.Dropout(0.4)
+        self.fc3 = nn.Linear(256, num_class)
+
+    def forward(self, xyz):
+        B = xyz.shape[0]
+        norm = xyz[:, 3:, :] if self.normal_channel else None
+        xyz = xyz[:, :3, :]
+        l1_xyz, l1 = self.sa1(xyz, norm)
+        l2_xyz, l2 = self.sa2(l1_xyz, l1)
+        _, l3 = self.sa3(l2_xyz, l2)
+        h = l3.view(B, 1024)
+        h = self.drop1(F.relu(self.bn1(self.fc1(h))))
+        h = self.drop2(F.relu(self.bn2(self.fc2(h))))
+        return self.fc3(h), l3

@@ -258,3 +258,14 @@ def topk_rows(P, K, largest=True):
     idx = torch.empty(*P.shape[:-1], K, device=P.device, dtype=torch.int64)
     _lib.call("hitadv_topk_rows", _p(P), rows, M, K, 1 if largest else 0, _p(vals), _p(idx), _stream())
     return vals, idx
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """torch-semantics ball query (model/pointnet2_utils.py:87-107): xyz[B,N,3], new_xyz[B,S,3] -> idx[B,S,nsample] int64."""
+    xyz, new_xyz = _dev(xyz.detach(), "xyz"), _dev(new_xyz.detach(), "new_xyz")
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = torch.empty(B, S, nsample, device=xyz.device, dtype=torch.int64)
+    _lib.call("hitadv_query_ball_point_inclusive", B, N, S, ctypes.c_float(radius), nsample, _p(new_xyz), _p(xyz),
+              _p(idx), _stream())
+    return idx

@@ -173,6 +173,13 @@ int hitadv_gather_points_grad(int b, int c, int n, int npoints, const float *gra
 /* src/ball_query.cpp:4-6; idx[b,m,nsample] is fully written (zeros for an empty ball). */
 int hitadv_query_ball_point(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                             const float *xyz, int32_t *idx, void *stream);
+/* The pure-torch ball query of the PointNet++ victim and of HiT_ADV.query_ball_point
+ * (model/pointnet2_utils.py:87-107, ShapeAttack/HiT_ADV.py:512-532): first nsample indices (ascending) with
+ * d^2 <= r^2 (INCLUSIVE), short rows padded with the first hit, an empty ball filled with n (the reference's
+ * out-of-range marker), int64 indices.  Direct-form distances (the reference uses the Gram form: only points
+ * within fp32 noise of the sphere can differ). */
+int hitadv_query_ball_point_inclusive(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                      const float *xyz, int64_t *idx, void *stream);
 /* src/group_points.cpp:4-6 */
 int hitadv_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
                         const int32_t *idx, float *out, void *stream);

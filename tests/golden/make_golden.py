@@ -18,6 +18,7 @@ Fixture index:
   g7_cwknn.npz         CWKNN.attack trajectory with the toy victim
   g8_state_dicts.json  state_dict key/shape lists of the victims
   g9_cwperturb.npz     CWPerturb.attack (L2Dist + ClipPointsLinf) trajectory with the toy victim
+  g11_pointnet2.npz    PointNet++ SSG (seeded init + seeded FPS starts): FPS / ball-query tables, logits, input grad
   g10_dgcnn.npz        DGCNN_cls (seeded init, eval mode): logits, input gradient, first-layer kNN table
 """
 import io
@@ -383,6 +384,27 @@ def g10():
                                edge_layer1=ref_dgcnn.get_graph_feature(x.detach(), k=5)))
 
 
+# ------------------------------------------------------------------ G11
+def g11():
+    from model import pointnet2_utils as pu
+    from model.pointnet2_cls_ssg import get_model
+    torch.manual_seed(37)
+    m = get_model(40, normal_channel=False).eval()
+    data, _ = synth_batch(2, 1024, first=70)
+    x = data[:, :, :3].transpose(1, 2).contiguous().requires_grad_()
+    torch.manual_seed(41)  # pins the two randint draws of the forward (sa1, sa2 FPS starts)
+    logits, _ = m(x)
+    w = torch.randn(2, 40, generator=torch.Generator().manual_seed(4))
+    (logits * w).sum().backward()
+    pts = x.detach().transpose(1, 2).contiguous()
+    torch.manual_seed(41)
+    fps1 = pu.farthest_point_sample(pts, 512)
+    new_xyz = pu.index_points(pts, fps1)
+    ball1 = pu.query_ball_point(0.2, 32, pts, new_xyz)
+    save('g11_pointnet2.npz', dict(x=x.detach(), logits=logits, grad_w=w, grad_x=x.grad, init_seed=37, fwd_seed=41,
+                                   fps1=fps1, ball1=ball1))
+
+
 # ------------------------------------------------------------------ G8
 def g8():
     shapes = {}
@@ -417,6 +439,6 @@ def g8():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
     for name in which:
         globals()[name]()

@@ -32,3 +32,10 @@ def test_cpu_forward_backward_equals_reference():
     np.testing.assert_allclose(x.grad, fx['grad_x'], rtol=1e-3, atol=1e-6)
     assert (knn(T(fx['x']), 5).numpy() == fx['knn_layer1']).all()
     np.testing.assert_array_equal(get_graph_feature(T(fx['x']), k=5).numpy(), fx['edge_layer1'])
+
+
+def test_pointnet2_state_dict_layout_matches_reference():
+    from hit_adv_amd.model.pointnet2 import get_model
+    shapes = golden_json('g8_state_dicts.json')
+    m = get_model(40, normal_channel=False)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == shapes['pointnet++']

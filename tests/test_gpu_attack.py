@@ -338,3 +338,40 @@ def test_dgcnn_victim_on_gpu_and_under_attack():
     # torch's gather backward (edge features) accumulates with atomics, so DGCNN gradients are not bitwise
     # reproducible run to run; graph and eager agree to rounding instead of bit for bit
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-3, atol=1e-4)
+
+
+def test_pointnet2_victim_on_gpu():
+    """PointNet++ SSG with HIP FPS / ball query against the reference (fixture g11): same FPS table bit for bit,
+    same ball-query table (up to points within fp32 noise of the sphere: the reference thresholds Gram-form
+    distances), logits and input gradient to tolerance; and HiT-ADV runs on it (eager: the per-forward CPU
+    randint of the victim cannot be captured, the attack falls back by itself)."""
+    import warnings
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model import pointnet2 as P2
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    fx = golden('g11_pointnet2.npz')
+    torch.manual_seed(int(fx['init_seed']))
+    m = P2.get_model(40, normal_channel=False).eval().cuda()
+    x = T(fx['x']).cuda().requires_grad_()
+    pts = x.detach().transpose(1, 2).contiguous()
+    torch.manual_seed(int(fx['fwd_seed']))
+    fps1 = P2.farthest_point_sample(pts, 512)
+    assert torch.equal(fps1.cpu(), T(fx['fps1']))
+    ball1 = P2.query_ball_point(0.2, 32, pts, P2.index_points(pts, fps1)).cpu()
+    assert (ball1 != T(fx['ball1'])).float().mean().item() < 1e-3
+    torch.manual_seed(int(fx['fwd_seed']))
+    logits, l3 = m(x)
+    assert l3.shape == (2, 1024, 1)
+    close(logits, fx['logits'], rtol=2e-3, atol=2e-4)
+    (logits * T(fx['grad_w']).cuda()).sum().backward()
+    assert np.abs(x.grad.cpu().numpy() - fx['grad_x']).max() <= 0.05 * np.abs(fx['grad_x']).max()
+    data, _ = synth_batch(2, 1024, first=1300)
+    with torch.no_grad():
+        label = m(data[:, :, :3].transpose(1, 2).contiguous().cuda())[0].argmax(1)
+    att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), binary_step=1, num_iter=3, cd_weight=1e-4, ker_weight=1.,
+                  hide_weight=1., curv_loss_knn=16, central_num=64, total_central_num=96, max_sigm=1.2,
+                  min_sigm=0.1, budget=0.55, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        best, succ = att.attack(data, label)
+    assert best.shape == (2, 1024, 3) and np.isfinite(best).all() and not att.last_graph_used
