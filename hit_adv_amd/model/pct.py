@@ -1,0 +1,132 @@
+"""PCT victim (cfg5 of BASELINE.json).  Parameter names follow the reference's model/pct_cls.py (Pct :27-75,
+Local_op :6-24, Point_Transformer_Last :77-109, SA_Layer :111-139): 113 state_dict entries
+(tests/golden/g8_state_dicts.json).  Attention / MLPs stay PyTorch-ROCm; the neighbourhood construction of
+``sample_and_group`` (model/pct_utils.py:111-140) runs in HIP:
+
+* ``fps`` (util/other_utils.py:254-272): random first index from the CPU generator (:264), then
+  ``hitadv_fps_from_start``.  The reference maximises sqrt of a clamped Gram-form distance; sqrt is monotone, so
+  the selected indices are those of the squared direct-form distance except for fp32 near-ties;
+* ``knn_point`` (pct_utils.py:98-109, ``topk(..., sorted=False)``): ``hitadv_knn_points`` (sorted; the consumer
+  max-pools over the neighbours, so order is irrelevant).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..pytorch3d_ops import knn_points
+from .pointnet2 import index_points
+
+
+def fps(xyz, M):
+    B, N, _ = xyz.shape
+    inds = torch.randint(0, N, size=(B,), dtype=torch.long)
+    return ops.fps_from_start(xyz, M, inds.to(xyz.device))
+
+
+def knn_point(nsample, xyz, new_xyz):
+    return knn_points(new_xyz.detach(), xyz.detach(), K=nsample).idx
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points):
+    """xyz [B,N,3], points [B,N,D] -> (new_xyz [B,S,3], features [B,S,nsample,2D])."""
+    B, N, C = xyz.shape
+    xyz = xyz.contiguous()
+    fps_idx = fps(xyz, npoint)
+    new_xyz = index_points(xyz, fps_idx)
+    centre = index_points(points, fps_idx)
+    idx = knn_point(nsample, xyz, new_xyz)
+    rel = index_points(points, idx) - centre.view(B, npoint, 1, -1)
+    return new_xyz, torch.cat([rel, centre.view(B, npoint, 1, -1).expand(-1, -1, nsample, -1)], dim=-1)
+
+
+class Local_op(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv1d(in_channels, out_channels, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv1d(out_channels, out_channels, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm1d(out_channels)
+        self.bn2 = nn.BatchNorm1d(out_channels)
+
+    def forward(self, x):
+        b, n, s, d = x.shape
+        h = x.permute(0, 1, 3, 2).reshape(-1, d, s)
+        h = F.relu(self.bn1(self.conv1(h)))
+        h = F.relu(self.bn2(self.conv2(h)))
+        return F.adaptive_max_pool1d(h, 1).view(b, n, -1).permute(0, 2, 1)
+
+
+class SA_Layer(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.q_conv = nn.Conv1d(channels, channels // 4, 1, bias=False)
+        self.k_conv = nn.Conv1d(channels, channels // 4, 1, bias=False)
+        self.q_conv.weight = self.k_conv.weight  # shared, as in the reference (:116)
+        self.q_conv.bias = self.k_conv.bias
+        self.v_conv = nn.Conv1d(channels, channels, 1)
+        self.trans_conv = nn.Conv1d(channels, channels, 1)
+        self.after_norm = nn.BatchNorm1d(channels)
+        self.act = nn.ReLU()
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, x):
+        attention = self.softmax(torch.bmm(self.q_conv(x).permute(0, 2, 1), self.k_conv(x)))
+        attention = attention / (1e-9 + attention.sum(dim=1, keepdim=True))
+        x_r = torch.bmm(self.v_conv(x), attention)
+        return x + self.act(self.after_norm(self.trans_conv(x - x_r)))
+
+
+class Point_Transformer_Last(nn.Module):
+    def __init__(self, args, channels=256):
+        super().__init__()
+        self.args = args
+        self.conv1 = nn.Conv1d(channels, channels, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv1d(channels, channels, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm1d(channels)
+        self.bn2 = nn.BatchNorm1d(channels)
+        self.sa1, self.sa2 = SA_Layer(channels), SA_Layer(channels)
+        self.sa3, self.sa4 = SA_Layer(channels), SA_Layer(channels)
+
+    def forward(self, x):
+        h = F.relu(self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x))))))
+        outs = []
+        for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
+            h = sa(h)
+            outs.append(h)
+        return torch.cat(outs, dim=1)
+
+
+class Pct(nn.Module):
+    def __init__(self, args, output_channels=40):
+        super().__init__()
+        self.args = args
+        self.conv1 = nn.Conv1d(3, 64, kernel_size=1, bias=False)
+        self.conv2 = nn.Conv1d(64, 64, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm1d(64)
+        self.bn2 = nn.BatchNorm1d(64)
+        self.gather_local_0 = Local_op(in_channels=128, out_channels=128)
+        self.gather_local_1 = Local_op(in_channels=256, out_channels=256)
+        self.pt_last = Point_Transformer_Last(args)
+        self.conv_fuse = nn.Sequential(nn.Conv1d(1280, 1024, kernel_size=1, bias=False), nn.BatchNorm1d(1024),
+                                       nn.LeakyReLU(negative_slope=0.2))
+        self.linear1 = nn.Linear(1024, 512, bias=False)
+        self.bn6 = nn.BatchNorm1d(512)
+        self.dp1 = nn.Dropout(p=args.dropout)
+        self.linear2 = nn.Linear(512, 256)
+        self.bn7 = nn.BatchNorm1d(256)
+        self.dp2 = nn.Dropout(p=args.dropout)
+        self.linear3 = nn.Linear(256, output_channels)
+
+    def forward(self, x):
+        B = x.shape[0]
+        xyz = x.permute(0, 2, 1)
+        h = F.relu(self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))).permute(0, 2, 1)
+        new_xyz, grouped = sample_and_group(npoint=512, radius=0.15, nsample=32, xyz=xyz, points=h)
+        f0 = self.gather_local_0(grouped)
+        new_xyz, grouped = sample_and_group(npoint=256, radius=0.2, nsample=32, xyz=new_xyz, points=f0.permute(0, 2, 1))
+        f1 = self.gather_local_1(grouped)
+        h = self.conv_fuse(torch.cat([self.pt_last(f1), f1], dim=1))
+        g = F.adaptive_max_pool1d(h, 1).view(B, -1)
+        g = self.dp1(F.leaky_relu(self.bn6(self.linear1(g)), negative_slope=0.2))
+        g = self.dp2(F.leaky_relu(self.bn7(self.linear2(g)), negative_slope=0.2))
+        return self.linear3(g)

@@ -19,6 +19,7 @@ Fixture index:
   g8_state_dicts.json  state_dict key/shape lists of the victims
   g9_cwperturb.npz     CWPerturb.attack (L2Dist + ClipPointsLinf) trajectory with the toy victim
   g11_pointnet2.npz    PointNet++ SSG (seeded init + seeded FPS starts): FPS / ball-query tables, logits, input grad
+  g12_pct.npz          PCT (seeded init + seeded FPS starts): logits, input gradient, first FPS table
   g10_dgcnn.npz        DGCNN_cls (seeded init, eval mode): logits, input gradient, first-layer kNN table
 """
 import io
@@ -405,6 +406,24 @@ def g11():
                                    fps1=fps1, ball1=ball1))
 
 
+# ------------------------------------------------------------------ G12
+def g12():
+    import argparse
+    from model.pct_cls import Pct
+    from util.other_utils import fps
+    torch.manual_seed(43)
+    m = Pct(argparse.Namespace(dropout=0.2), output_channels=40).eval()
+    data, _ = synth_batch(2, 1024, first=80)
+    x = data[:, :, :3].transpose(1, 2).contiguous().requires_grad_()
+    torch.manual_seed(47)
+    logits = m(x)
+    w = torch.randn(2, 40, generator=torch.Generator().manual_seed(4))
+    (logits * w).sum().backward()
+    torch.manual_seed(47)
+    fps1 = fps(x.detach().transpose(1, 2).contiguous(), 512)
+    save('g12_pct.npz', dict(x=x.detach(), logits=logits, grad_w=w, grad_x=x.grad, init_seed=43, fwd_seed=47, fps1=fps1))
+
+
 # ------------------------------------------------------------------ G8
 def g8():
     shapes = {}
@@ -439,6 +458,6 @@ def g8():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
     for name in which:
         globals()[name]()

@@ -375,3 +375,22 @@ def test_pointnet2_victim_on_gpu():
         warnings.simplefilter('ignore')
         best, succ = att.attack(data, label)
     assert best.shape == (2, 1024, 3) and np.isfinite(best).all() and not att.last_graph_used
+
+
+def test_pct_victim_on_gpu():
+    """PCT with HIP FPS / kNN grouping against the reference (fixture g12)."""
+    import argparse
+    from hit_adv_amd.model import pct as PCT
+    fx = golden('g12_pct.npz')
+    torch.manual_seed(int(fx['init_seed']))
+    m = PCT.Pct(argparse.Namespace(dropout=0.2), output_channels=40).eval().cuda()
+    x = T(fx['x']).cuda().requires_grad_()
+    torch.manual_seed(int(fx['fwd_seed']))
+    fps1 = PCT.fps(x.detach().transpose(1, 2).contiguous(), 512)
+    # the reference maximises sqrt(clamped Gram distance): same arg-max except for fp32 near-ties
+    assert (fps1.cpu() != T(fx['fps1'])).float().mean().item() < 0.02
+    torch.manual_seed(int(fx['fwd_seed']))
+    logits = m(x)
+    close(logits, fx['logits'], rtol=5e-3, atol=5e-4)
+    (logits * T(fx['grad_w']).cuda()).sum().backward()
+    assert np.isfinite(x.grad.cpu().numpy()).all()
