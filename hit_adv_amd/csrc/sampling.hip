@@ -3,7 +3,7 @@
 //   K5  fps<PT, EXT>   one workgroup per cloud, points and running distances in VGPRs
 //                      (PT points per lane), cloud mirrored in LDS as float4 for the winner's
 //                      coordinates.  Per step: PT distance updates, a 64-bit (distance-bits,
-//                      tie-key) max via wave shuffles, one barrier, 4-slot merge.  Latency-bound
+//                      tie-key) max via two DPP reductions, one barrier, 4-slot merge.  Latency-bound
 //                      serial chain of m steps.
 //        EXT = false : ShapeAttack/HiT_ADV.py:489-510 semantics (given start, lowest index on ties)
 //        EXT = true  : sampling_gpu.cu:69-173 semantics (start 0, |p|^2 <= 1e-3 skipped, the
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
       const unsigned long long key = tb[u] ? (((unsigned long long)fbits(run[u]) << 32) | tb[u]) : 0ull;
       best = key > best ? key : best;
     }
-    best = wave_max_u64(best);
+    best = wave_max_u64_dpp(best);
     if (lane == 0) slot[j & 1][wave] = best;
     __syncthreads();
     unsigned long long w = slot[j & 1][0];
