@@ -57,14 +57,15 @@ def pairwise_roofline(dev):
     ptrs = (ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(P.data_ptr()))
     # 20 back-to-back launches captured into a hipGraph (the host's ctypes call rate must not open gaps
     # between launches), replayed between two events recorded on the stream the replays run on
-    per_graph, reps = 20, 10
+    per_graph, reps = 20, 50
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for _ in range(per_graph):
             lib.hitadv_pairwise_sqdist(*ptrs, B_PER_GPU, NPOINT, NPOINT, 3, ops.FORM_GRAM, stream)
-    g.replay()
+    for _ in range(reps):  # untimed: lets the clocks settle under this kernel's load
+        g.replay()
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()

@@ -55,8 +55,7 @@ __global__ __launch_bounds__(256) void pairwise3_vec4(const float *__restrict__ 
     r3 = (yc.y * yc.y + yc.z * yc.z) + yc.w * yc.w;
   }
   float *out = P + ((size_t)b * N + i0) * M + j0;
-#pragma unroll 4
-  for (int r = 0; r < rows; ++r) {
+  auto row = [&](int r) {
     const float4 xv = *reinterpret_cast<const float4 *>(&xs[r * 4]);
     float4 v;
     v.x = pair_value<FORM>(xv.x, xv.y, xv.z, xv.w, ya.x, ya.y, ya.z, r0);
@@ -64,6 +63,12 @@ __global__ __launch_bounds__(256) void pairwise3_vec4(const float *__restrict__ 
     v.z = pair_value<FORM>(xv.x, xv.y, xv.z, xv.w, yb.z, yb.w, yc.x, r2);
     v.w = pair_value<FORM>(xv.x, xv.y, xv.z, xv.w, yc.y, yc.z, yc.w, r3);
     *reinterpret_cast<float4 *>(out + (size_t)r * M) = v;
+  };
+  if (rows == K1_ROWS) {  // full tile: compile-time trip count, the scheduler can keep stores back to back
+#pragma unroll 4
+    for (int r = 0; r < K1_ROWS; ++r) row(r);
+  } else {
+    for (int r = 0; r < rows; ++r) row(r);
   }
 }
 
