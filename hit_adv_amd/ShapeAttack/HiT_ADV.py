@@ -242,25 +242,45 @@ class HiT_ADV:
         ws.graph = None
         if self.use_graph in (False, 'never'):
             return
+        # Warm up on a side stream with PyTorch's sync-debug mode set to "error": anything in the iteration
+        # that would synchronise with the host (an adv_func calling .item(), a victim drawing a CPU randint and
+        # copying it over, ...) raises HERE, in eager mode, and we fall back to the eager loop.  Attempting the
+        # capture with such an op inside would invalidate it and can leave PyTorch's capture bookkeeping
+        # (RNG registration, current stream) in a broken state.
+        capturable = True
+        prev_mode = torch.cuda.get_sync_debug_mode()
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(2):
-                    self._iteration(ws)
+                self._iteration(ws)  # unguarded: lets library handles / lazy initialisation happen
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")  # "prototype feature" notice
+                    torch.cuda.set_sync_debug_mode("error")
+                self._iteration(ws)
+        except Exception as e:  # noqa: BLE001
+            capturable = False
+            reason = e
+        finally:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.cuda.set_sync_debug_mode(prev_mode)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._iteration(ws)
-            ws.graph = g
-        except Exception as e:  # noqa: BLE001 - e.g. an adv_func that allocates on the host
-            if self.use_graph is True or self.use_graph == 'always':
-                raise
-            torch.cuda.synchronize()
-            warnings.warn("hipGraph capture of the HiT-ADV iteration failed (%r); running eagerly" % (e,))
-            ws.graph = None
-            self.use_graph = 'never'
+        if capturable:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._iteration(ws)
+                ws.graph = g
+                return
+            except Exception as e:  # noqa: BLE001
+                reason = e
+                torch.cuda.synchronize()
+        if self.use_graph is True or self.use_graph == 'always':
+            raise RuntimeError("the HiT-ADV iteration cannot be captured into a hipGraph: %r" % (reason,))
+        warnings.warn("the HiT-ADV iteration is not hipGraph-capturable (%r); running the eager loop" % (reason,))
+        ws.graph = None
 
     # ------------------------------------------------------------------ attack
     def attack(self, data, target):

@@ -394,3 +394,104 @@ def test_pct_victim_on_gpu():
     close(logits, fx['logits'], rtol=5e-3, atol=5e-4)
     (logits * T(fx['grad_w']).cuda()).sum().backward()
     assert np.isfinite(x.grad.cpu().numpy()).all()
+
+
+def test_hit_adv_pointnet_gpu_vs_cpu_oracle_short_run():
+    """The production configuration (folded PointNet view, fused regulariser, hipGraph, eval.py sizes) against
+    the CPU oracle driving the plain PointNet module: same centres, same predictions, iterates to fp32 tolerance
+    over a short run (the trajectories are chaotic over hundreds of Adam steps, not over five)."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(0)
+    cpu_model = PointNetFeatureModel(40, normal_channel=False).eval()
+    torch.manual_seed(0)
+    gpu_model = PointNetFeatureModel(40, normal_channel=False).eval().cuda()
+    data, _ = synth_batch(4, 1024, first=1400)
+    with torch.no_grad():
+        label = cpu_model(data[:, :, :3].transpose(1, 2).contiguous())[0].argmax(1)
+    hp = dict(binary_step=1, num_iter=5, cd_weight=1e-4, ker_weight=1., hide_weight=1., curv_loss_knn=16,
+              central_num=192, total_central_num=256, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+    oracle = O.HiTADVOracle(cpu_model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), **hp)
+    torch.manual_seed(21)
+    trace = []
+    ref_best, ref_succ = oracle.attack(data, label, trace=trace)
+    att = HiT_ADV(gpu_model, UntargetedLogitsAdvLoss(30.), verbose=False, use_graph=False, **hp)
+    rec = _Recorder(att)  # the recorder synchronises, so this run is eager; the graph run follows
+    torch.manual_seed(21)
+    best, succ = att.attack(data, label)
+    ws = next(iter(att._ws.values()))
+    assert torch.equal(ws.central.cpu(), oracle.state['central'])
+    assert len(rec.rows) == 5
+    for row, ref in zip(rec.rows, trace):
+        assert (row['pred'] == ref['pred']).all()
+        close(row['adv'], ref['adv'], rtol=2e-3, atol=2e-4)
+        close(row['adv_loss'], ref['adv_loss'], rtol=2e-3, atol=1e-4)
+    close(best, ref_best, rtol=2e-3, atol=2e-4)
+    assert int(succ) == int(ref_succ)
+    att2 = HiT_ADV(gpu_model, UntargetedLogitsAdvLoss(30.), verbose=False, **hp)
+    torch.manual_seed(21)
+    best2, succ2 = att2.attack(data, label)
+    assert att2.last_graph_used and np.array_equal(best, best2) and int(succ2) == int(succ)
+
+
+def test_cfg4_sizes_pointnet2_2048_points_smoke():
+    """cfg4 of BASELINE.json at reduced batch: 2048-point clouds, PointNet++ SSG victim (FPS PT=8 path, ball query)."""
+    import warnings
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet2 import get_model
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    from oracle import c_oracle as N
+    torch.manual_seed(0)
+    m = get_model(40, normal_channel=False).eval().cuda()
+    data, _ = synth_batch(3, 2048, first=1500)
+    xyz = data[:, :, :3].contiguous()
+    from hit_adv_amd import ops
+    start = torch.tensor([5, 2047, 100])
+    assert torch.equal(ops.fps_from_start(xyz.cuda(), 512, start.cuda()).cpu(), N.fps_from_start(xyz, 512, start))
+    with torch.no_grad():
+        label = m(xyz.transpose(1, 2).contiguous().cuda())[0].argmax(1)
+    att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), binary_step=1, num_iter=2, cd_weight=1e-4, ker_weight=1.,
+                  hide_weight=1., curv_loss_knn=16, central_num=192, total_central_num=256, max_sigm=1.2,
+                  min_sigm=0.1, budget=0.55, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        best, succ = att.attack(data, label)
+    assert best.shape == (3, 2048, 3) and np.isfinite(best).all()
+
+
+def test_uncapturable_iteration_falls_back_cleanly():
+    """An adv_func that synchronises with the host (here: .item()) cannot live in a hipGraph.  use_graph='auto'
+    must notice during the guarded warm-up, run the eager loop with identical results, and leave PyTorch's
+    capture / RNG bookkeeping intact; use_graph=True must refuse loudly."""
+    import warnings
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    fx = golden('g5_attack.npz')
+    inner = UntargetedLogitsAdvLoss(kappa=30.)
+
+    class Syncing(torch.nn.Module):
+        def forward(self, logits, targets):
+            v = inner(logits, targets)
+            _ = v.item()
+            return v
+
+    outs = []
+    for adv_func, mode in ((inner, False), (Syncing(), 'auto')):
+        att = HiT_ADV(toy_from_fixture(fx), adv_func=adv_func, verbose=False, use_graph=mode, **hp_from_fixture(fx))
+        torch.manual_seed(int(fx['seed']))
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            outs.append(att.attack(T(fx['data']), T(fx['target']))[0])
+        if mode == 'auto':
+            assert not att.last_graph_used and any('not hipGraph-capturable' in str(x.message) for x in w)
+    assert np.array_equal(outs[0], outs[1])
+    torch.manual_seed(1)  # would raise if a capture had been left half-open
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):  # and capturing still works afterwards
+        y = torch.ones(4, device='cuda') * 2
+    g.replay()
+    assert y.sum().item() == 8
+    att = HiT_ADV(toy_from_fixture(fx), adv_func=Syncing(), verbose=False, use_graph=True, **hp_from_fixture(fx))
+    with pytest.raises(RuntimeError):
+        att.attack(T(fx['data']), T(fx['target']))
