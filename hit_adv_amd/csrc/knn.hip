@@ -38,6 +38,35 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
     d[t] = __builtin_inff();
     ix[t] = 0x7fffffff;
   }
+  constexpr int BUF = KB <= 4 ? 1 : (KB <= 12 ? 4 : 8);  // pending-candidate depth (1 = insert directly)
+  float pd[BUF];
+  int pj[BUF];
+  int np = 0;
+#pragma unroll
+  for (int t = 0; t < BUF; ++t) {
+    pd[t] = __builtin_inff();
+    pj[t] = 0x7fffffff;
+  }
+  auto insert = [&](float c, int j) {
+#pragma unroll
+    for (int t = KB - 1; t > 0; --t) {
+      const bool sh = c < d[t - 1];
+      const bool wr = c < d[t];
+      const float nd = sh ? d[t - 1] : c;
+      const int ni = sh ? ix[t - 1] : j;
+      d[t] = wr ? nd : d[t];
+      ix[t] = wr ? ni : ix[t];
+    }
+    const bool w0 = c < d[0];
+    d[0] = w0 ? c : d[0];
+    ix[0] = w0 ? j : ix[0];
+  };
+  auto flush = [&]() {  // oldest first: equal distances keep ascending reference index
+#pragma unroll
+    for (int t = BUF - 1; t >= 0; --t)
+      if (np > t) insert(pd[t], pj[t]);
+    np = 0;
+  };
   for (int c0 = 0; c0 < M; c0 += KNN_RCH) {
     const int cnt = min(KNN_RCH, M - c0);
     __syncthreads();
@@ -51,23 +80,27 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
     for (int r = lo; r < hi; ++r) {
       const float4 v = sref[r];
       const float c = sqdist3(qx, qy, qz, v.x, v.y, v.z);
-      if (c < d[KB - 1]) {
-        const int j = c0 + r;
+      // Accepted candidates (closer than the current KB-th best) are parked in a BUF-deep per-lane shift
+      // register; the expensive sorted insert runs only when some lane's register is full.  The insert body is
+      // executed by the whole wave whenever ANY lane needs it, so batching it per BUF accepted candidates of the
+      // fastest-filling lane (instead of per reference) is what removes most of its cost.
+      const bool acc = c < d[KB - 1];
+      if (BUF == 1) {
+        if (acc) insert(c, c0 + r);
+      } else {
 #pragma unroll
-        for (int t = KB - 1; t > 0; --t) {
-          const bool sh = c < d[t - 1];
-          const bool wr = c < d[t];
-          const float nd = sh ? d[t - 1] : c;
-          const int ni = sh ? ix[t - 1] : j;
-          d[t] = wr ? nd : d[t];
-          ix[t] = wr ? ni : ix[t];
+        for (int t = BUF - 1; t > 0; --t) {
+          pd[t] = acc ? pd[t - 1] : pd[t];
+          pj[t] = acc ? pj[t - 1] : pj[t];
         }
-        const bool w0 = c < d[0];
-        d[0] = w0 ? c : d[0];
-        ix[0] = w0 ? j : ix[0];
+        pd[0] = acc ? c : pd[0];
+        pj[0] = acc ? c0 + r : pj[0];
+        np += acc ? 1 : 0;
+        if (__ballot(np == BUF)) flush();
       }
     }
   }
+  flush();
   float *md = smerge;
   int *mi = reinterpret_cast<int *>(smerge + 4 * KB * 64);
 #pragma unroll
