@@ -1,0 +1,133 @@
+"""Edge cases of the HIP kernels: ragged / tiny / multi-chunk sizes, misaligned views, maximum supported sizes,
+argument errors.  Same parity bar as test_gpu_kernels.py (bit-exact indices and direct-form distances)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import synth_batch
+from oracle import c_oracle as N
+from oracle import hitadv_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import hit_adv_amd.ops as ops
+    return ops
+
+
+def pts(b, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(b, n, 3, generator=g) * 2 - 1
+
+
+def test_pairwise_misaligned_views_and_tiny_sizes(A):
+    big = pts(2, 1030, 1)
+    x = big[:, 1:1025].cuda()  # storage offset 3 floats -> not 16-byte aligned after .contiguous()? contiguous() realigns,
+    y = big[:, 5:1029]         # so also exercise the raw scalar path through odd M below
+    for xs, ys in ((x, y.cuda()), (pts(1, 1, 2).cuda(), pts(1, 1, 3).cuda()), (pts(3, 5, 4).cuda(), pts(3, 1026, 5).cuda()),
+                   (pts(2, 33, 6).cuda(), pts(2, 1021, 7).cuda())):
+        for form in (A.FORM_DIRECT, A.FORM_GRAM):
+            P = A.pairwise_sqdist(xs, ys, form).cpu()
+            ref = O.pairwise_sqdist_direct(xs.cpu(), ys.cpu())
+            if form == A.FORM_DIRECT:
+                assert torch.equal(P, ref)
+            else:
+                assert (P - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 3000), (5000, 3), (2500, 2300)])
+def test_nn_min_multi_chunk_and_degenerate(A, n, m):
+    x, y = pts(2, n, 10), pts(2, m, 11)
+    mx, ax, my, ay = (t.cpu() for t in A.nn_min(x.cuda(), y.cuda()))
+    rx, rax = N.nn_min(x, y)
+    ry, ray = N.nn_min(y, x)
+    assert torch.equal(mx, rx) and torch.equal(ax, rax) and torch.equal(my, ry) and torch.equal(ay, ray)
+
+
+def test_nn_min_backward_one_direction_only_and_scatter_collisions(A):
+    # many y points share one nearest x -> the owner-computes scatter sums several contributions in j order
+    x = torch.tensor([[[0., 0, 0], [10., 0, 0]]])
+    y = torch.cat([torch.randn(1, 300, 3, generator=torch.Generator().manual_seed(1)) * 0.1,
+                   torch.tensor([[[10.1, 0, 0]]])], 1)
+    xg = x.cuda().requires_grad_()
+    _, _, my, _ = A.nn_min(xg, y.cuda())
+    my.sum().backward()  # only the y->x direction carries gradient
+    xr = x.clone().requires_grad_()
+    O.pairwise_sqdist_direct(xr, y).min(1).values.sum().backward()
+    np.testing.assert_allclose(xg.grad.cpu(), xr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,K", [(5000, 17), (3, 3), (70, 64), (2050, 6)])
+def test_knn_multi_chunk_and_k_equals_m(A, m, K):
+    from hit_adv_amd.pytorch3d_ops import knn_points
+    p = pts(2, m, 20)
+    p[0, m - 1] = p[0, 0]  # exact tie between the first and the last reference (different chunks / waves)
+    q = torch.cat([p[:, :7], pts(2, 30, 21)], 1)
+    r = knn_points(q.cuda(), p.cuda(), K=K)
+    d, ix = N.knn_points(q, p, K)
+    assert torch.equal(r.idx.cpu(), ix) and torch.equal(r.dists.cpu(), d)
+
+
+def test_deform_many_centres_and_odd_point_counts(A):
+    g = torch.Generator().manual_seed(30)
+    B, Np, C = 2, 77, 1500  # C > 1024: two LDS passes over the centre table
+    ori = torch.randn(B, 3, Np, generator=g) * 0.5
+    central = torch.randn(B, 3, C, generator=g) * 0.5
+    P = ((torch.rand(B, C, 3, generator=g) - 0.5) * 0.2).requires_grad_()
+    sig = (0.2 + torch.rand(B, C, generator=g)).requires_grad_()
+    up = torch.randn(B, 3, Np, generator=g)
+    att = O.HiTADVOracle.__new__(O.HiTADVOracle)
+    ref = O.deform_loop(ori, P, O.kernel_density(central, ori, sig))
+    (ref * up).sum().backward()
+    Pg, sg = P.detach().cuda().requires_grad_(), sig.detach().cuda().requires_grad_()
+    adv = A.deform(ori.cuda(), central.cuda(), Pg, sg)
+    np.testing.assert_allclose(adv.detach().cpu(), ref.detach(), rtol=1e-5, atol=2e-6)
+    (adv * up.cuda()).sum().backward()
+    np.testing.assert_allclose(Pg.grad.cpu(), P.grad, rtol=2e-4, atol=1e-5 * float(P.grad.abs().max()))
+    np.testing.assert_allclose(sg.grad.cpu(), sig.grad, rtol=2e-4, atol=1e-5 * float(sig.grad.abs().max()))
+
+
+def test_fps_maximum_and_unsupported_sizes(A):
+    from hit_adv_amd import _lib
+    x = pts(1, 16384, 40)
+    start = torch.tensor([123])
+    assert torch.equal(A.fps_from_start(x.cuda(), 40, start.cuda()).cpu(), N.fps_from_start(x, 40, start))
+    with pytest.raises(_lib.HitAdvLibraryError):
+        A.fps_from_start(pts(1, 16385, 41).cuda(), 4, start.cuda())
+    one = pts(2, 1, 42)
+    assert A.fps_from_start(one.cuda(), 3, torch.zeros(2, dtype=torch.int64).cuda()).tolist() == [[0, 0, 0], [0, 0, 0]]
+
+
+def test_natives_ragged_sizes(A):
+    from hit_adv_amd.pointnet2_ops import _ext
+    x = pts(2, 333, 50)
+    q = x[:, :45].contiguous() + 0.01
+    for r, ns in ((0.3, 7), (0.05, 70), (3.0, 400)):
+        assert torch.equal(_ext.ball_query(q.cuda(), x.cuda(), r, ns).cpu(), N.ball_query(q, x, r, ns))
+    d2, ix = _ext.three_nn(q.cuda(), x[:, :2].contiguous().cuda())  # fewer than three known points
+    rd2, rix = N.three_nn(q, x[:, :2].contiguous())
+    assert torch.equal(ix.cpu(), rix) and torch.equal(d2.cpu()[..., :2], rd2[..., :2]) and torch.isinf(d2[..., 2]).all()
+    f = _ext.furthest_point_sampling(x.cuda(), 333)
+    assert torch.equal(f.cpu(), N.furthest_point_sampling(x, 333))
+    assert _ext.furthest_point_sampling(x.cuda(), 0).shape == (2, 0)
+
+
+def test_attack_state_kernels_small_shapes(A):
+    g = torch.Generator().manual_seed(60)
+    B, K, Np, C = 1, 10, 50, 3
+    st = {k: v.cuda() for k, v in dict(
+        bestdist=torch.full((B,), 1e10), bestscore=torch.full((B,), -1, dtype=torch.int64),
+        o_bestdist=torch.full((B,), 1e10), o_bestscore=torch.full((B,), -1, dtype=torch.int64),
+        o_bestattack=torch.zeros(B, 3, Np), pred=torch.zeros(B, dtype=torch.int64), dist_val=torch.zeros(B)).items()}
+    logits = torch.randn(B, K, generator=g)
+    label = (logits.argmax(1) + 1) % K
+    P, sig, adv = torch.randn(B, C, 3, generator=g), torch.rand(B, C, generator=g), torch.randn(B, 3, Np, generator=g)
+    A.best_update(logits.cuda(), label.cuda(), P.cuda(), sig.cuda(), adv.cuda(), st)
+    assert st['pred'].cpu().tolist() == logits.argmax(1).tolist()
+    assert torch.equal(st['o_bestattack'].cpu(), adv)
+    d = torch.zeros((), device='cuda')
+    out = A.regulariser(P.cuda(), sig.cuda(), adv.cuda(), (adv * 0.9).cuda(), torch.rand(B, C, generator=g).cuda(),
+                        torch.tensor([7.0]).cuda(), (1e-4, 1.0, 1.0), (0.1, 1.2), d)
+    assert torch.isfinite(out) and abs(out.item() - 7.0 * d.item()) < 1e-5 * abs(out.item()) + 1e-9
