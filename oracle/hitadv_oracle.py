@@ -616,6 +616,77 @@ def cw_perturb_attack(model, adv_func, dist_func, data, target, attack_lr=1e-2, 
     return o_bestattack.transpose((0, 2, 1)), int((lower > 0.).sum()), dict(lower=lower, upper=upper)
 
 
+def laplace_eig(pc, k=30):
+    """CW/AOF.py:12-51 on CPU: Gram-form kNN (topk of the negated distances), A = exp(-d^2) (direct form) on the
+    symmetrised graph, L = D - A, eigendecomposition (torch.symeig there, torch.linalg.eigh here)."""
+    with torch.no_grad():
+        inner = -2 * torch.matmul(pc.transpose(2, 1), pc)
+        xx = torch.sum(pc ** 2, dim=1, keepdim=True)
+        idx = (-xx - inner - xx.transpose(2, 1)).topk(k=k, dim=-1)[1]
+        p = pc.transpose(2, 1).contiguous()
+        A = torch.exp(-torch.sum((p.unsqueeze(2) - p.unsqueeze(1)).square(), dim=3))
+        mask = torch.zeros_like(A).scatter_(2, idx, 1)
+        mask = mask + mask.transpose(2, 1)
+        mask[mask > 1] = 1
+        A = A * mask
+        L = torch.diag_embed(torch.sum(A, dim=2)) - A
+        return torch.linalg.eigh(L)
+
+
+def cw_aof_attack(model, adv_func, clip_func, data, target, attack_lr=1e-2, binary_step=2, num_iter=200,
+                  GAMMA=0.5, low_pass=100, trace=None):
+    """CPU restatement of CW/AOF.py::CWAOF.attack (:83-241)."""
+    B, N = data.shape[:2]
+    pc = data.float().detach().transpose(1, 2).contiguous()
+    if pc.shape[1] == 6:
+        pc = pc[:, :3, :]
+    ori = pc.clone().detach()
+    target = target.long().detach()
+    label = target.numpy()
+    o_bestdist, o_bestscore = np.array([1e10] * B), np.array([-1] * B)
+    o_bestattack = np.zeros((B, 3, N))
+    input_val = None
+
+    def logits_of(x):
+        out = model(x)
+        return out[0] if isinstance(out, tuple) else out
+
+    for step in range(binary_step):
+        adv = ori.clone().detach() + torch.randn((B, 3, N)) * 1e-7
+        _, V = laplace_eig(adv)
+        projs = torch.bmm(adv, V)
+        hfc = torch.bmm(projs[..., low_pass:], V[..., low_pass:].transpose(2, 1)).detach().clone()
+        lfc = torch.bmm(projs[..., :low_pass], V[..., :low_pass].transpose(2, 1)).detach().clone().requires_grad_()
+        opt = torch.optim.Adam([lfc], lr=attack_lr, weight_decay=0.)
+        for it in range(num_iter):
+            adv_loss = (1 - GAMMA) * adv_func(logits_of(lfc + hfc), target).mean()
+            opt.zero_grad()
+            adv_loss.backward()
+            (GAMMA * adv_func(logits_of(lfc), target).mean()).backward()
+            opt.step()
+            with torch.no_grad():
+                adv = clip_func((lfc + hfc).detach().clone(), ori)
+                coeff = torch.bmm(adv, V)
+                hfc.data = torch.bmm(coeff[..., low_pass:], V[..., low_pass:].transpose(2, 1))
+                lfc.data = torch.bmm(coeff[..., :low_pass], V[..., :low_pass].transpose(2, 1))
+                pred = torch.argmax(logits_of(adv), dim=1).numpy()
+                lfc_pred = torch.argmax(logits_of(lfc), dim=1).numpy()
+            dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2])).numpy()
+            input_val = adv.detach().numpy().copy()
+            for e in range(B):
+                if dist_val[e] < o_bestdist[e] and pred[e] != label[e] and (lfc_pred[e] != label[e] or GAMMA < 0.001):
+                    o_bestdist[e], o_bestscore[e] = dist_val[e], pred[e]
+                    o_bestattack[e] = input_val[e]
+            if trace is not None:
+                trace.append(dict(step=step, it=it, adv=input_val.copy()))
+    for e in range(B):
+        if o_bestscore[e] < 0:
+            o_bestattack[e] = input_val[e]
+    adv_pc = clip_func(torch.tensor(o_bestattack).to(ori), ori)
+    success = (torch.argmax(logits_of(adv_pc), dim=-1) != target).sum().item()
+    return adv_pc.detach().numpy().transpose((0, 2, 1)), success
+
+
 # --------------------------------------------------------------------------
 # eval_ASR metric phase                      util/other_utils.py:15-101
 # --------------------------------------------------------------------------

@@ -20,6 +20,7 @@ Fixture index:
   g9_cwperturb.npz     CWPerturb.attack (L2Dist + ClipPointsLinf) trajectory with the toy victim
   g11_pointnet2.npz    PointNet++ SSG (seeded init + seeded FPS starts): FPS / ball-query tables, logits, input grad
   g12_pct.npz          PCT (seeded init + seeded FPS starts): logits, input gradient, first FPS table
+  g13_aof.npz          CWAOF.attack trajectory (torch.symeig served by torch.linalg.eigh) with the toy victim
   g10_dgcnn.npz        DGCNN_cls (seeded init, eval mode): logits, input gradient, first-layer kNN table
 """
 import io
@@ -424,6 +425,33 @@ def g12():
     save('g12_pct.npz', dict(x=x.detach(), logits=logits, grad_w=w, grad_x=x.grad, init_seed=43, fwd_seed=47, fps1=fps1))
 
 
+# ------------------------------------------------------------------ G13
+def g13():
+    from CW.AOF import CWAOF
+    # torch.symeig only raises in torch 2.x; torch.linalg.eigh is the same decomposition (ascending eigenvalues)
+    torch.symeig = lambda L, eigenvectors=True: torch.linalg.eigh(L)
+    model = toy_victim(14)
+    data, _ = synth_batch(2, 256, first=90)
+    xyz = data[:, :, :3].contiguous()
+    with torch.no_grad():
+        label = model(xyz.transpose(1, 2).contiguous()).argmax(1)
+    advs = []
+    clip = clip_utils.ClipPointsLinf(budget=0.18)
+
+    def recording_clip(pc, ori_pc):
+        r = clip(pc, ori_pc)
+        advs.append(r.detach().clone())
+        return r
+
+    att = CWAOF(model, adv_utils.UntargetedLogitsAdvLoss(kappa=30.), dist_utils.L2Dist(), attack_lr=1e-2,
+                binary_step=2, num_iter=5, GAMMA=0.25, low_pass=40, clip_func=recording_clip)
+    torch.manual_seed(29)
+    with redirect_stdout(io.StringIO()):
+        final, succ = att.attack(xyz, label)
+    save('g13_aof.npz', dict(data=xyz, target=label, seed=29, adv_trace=torch.stack(advs[:10]), final=final,
+                             success_num=int(succ), **{'w_' + k: v for k, v in model.state_dict().items()}))
+
+
 # ------------------------------------------------------------------ G8
 def g8():
     shapes = {}
@@ -458,6 +486,6 @@ def g8():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13']
     for name in which:
         globals()[name]()

@@ -495,3 +495,34 @@ def test_uncapturable_iteration_falls_back_cleanly():
     att = HiT_ADV(toy_from_fixture(fx), adv_func=Syncing(), verbose=False, use_graph=True, **hp_from_fixture(fx))
     with pytest.raises(RuntimeError):
         att.attack(T(fx['data']), T(fx['target']))
+
+
+def test_cwaof_follows_reference_trajectory():
+    """AOF on the GPU (HIP 30-NN graph, rocSOLVER eigh) against the reference trajectory (fixture g13).  The
+    low-frequency projector is invariant to the sign / basis choice inside the retained eigenspace, so the
+    iterates are comparable even though the eigenvectors themselves are not."""
+    from hit_adv_amd.CW.AOF import CWAOF, get_Laplace_from_pc
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    from hit_adv_amd.util.clip_utils import ClipPointsLinf
+    from hit_adv_amd.util.dist_utils import L2Dist
+    fx = golden('g13_aof.npz')
+    pc = T(fx['data']).transpose(1, 2).contiguous()
+    e_gpu, _ = get_Laplace_from_pc(pc.cuda())
+    e_cpu, _ = O.laplace_eig(pc)
+    close(e_gpu, e_cpu, rtol=1e-3, atol=1e-4)
+    trace = []
+    clip = ClipPointsLinf(budget=0.18)
+
+    def recording_clip(p, ori):
+        out = clip(p, ori)
+        trace.append(out.detach().cpu().numpy().copy())
+        return out
+
+    att = CWAOF(toy_from_fixture(fx), UntargetedLogitsAdvLoss(kappa=30.), L2Dist(), attack_lr=1e-2, binary_step=2,
+                num_iter=5, GAMMA=0.25, low_pass=40, clip_func=recording_clip, verbose=False)
+    torch.manual_seed(int(fx['seed']))
+    final, succ = att.attack(T(fx['data']), T(fx['target']))
+    for i in range(10):
+        np.testing.assert_allclose(trace[i], fx['adv_trace'][i], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(final, fx['final'], rtol=1e-3, atol=2e-4)
+    assert succ == int(fx['success_num']) and final.dtype == np.float32

@@ -186,3 +186,17 @@ def test_g9_cwperturb_trajectory():
         close(rec['adv'], fx['adv_trace'][i], rtol=1e-4, atol=1e-6)
     close(best, fx['best'], rtol=1e-4, atol=1e-6)
     assert succ == int(fx['success_num']) and best.dtype == np.float64
+
+
+def test_g13_aof_trajectory():
+    fx = golden('g13_aof.npz')
+    model = toy_from_fixture(fx)
+    torch.manual_seed(int(fx['seed']))
+    trace = []
+    final, succ = O.cw_aof_attack(model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.),
+                                  lambda pc, ori: O.clip_points_linf(pc, ori, 0.18), T(fx['data']), T(fx['target']),
+                                  attack_lr=1e-2, binary_step=2, num_iter=5, GAMMA=0.25, low_pass=40, trace=trace)
+    for i, rec in enumerate(trace):
+        close(rec['adv'], fx['adv_trace'][i], rtol=1e-4, atol=1e-5)
+    close(final, fx['final'], rtol=1e-4, atol=1e-5)
+    assert succ == int(fx['success_num'])
