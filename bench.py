@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--concurrent", type=int, default=2,
+                    help="independent attack() batches in flight per GPU (separate HIP streams; 1 = strictly serial)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,15 +199,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run(todo):
+        """Attack the given steps, `--concurrent` at a time (each step keeps single-call semantics)."""
+        ok = 0
+        for i in range(0, len(todo), max(1, args.concurrent)):
+            group = todo[i:i + max(1, args.concurrent)]
+            res = att.attack_many(group) if len(group) > 1 else [att.attack(*group[0])]
+            ok += sum(int(n) for _, n in res)
+        return ok
+
     torch.manual_seed(1234 + rank)
-    for s in range(args.warmup):
-        att.attack(*batches[s])
+    run(batches[:args.warmup])
     sync()
     t0 = time.perf_counter()
-    succ = 0
-    for s in range(args.warmup, nbatch):
-        _, n_ok = att.attack(*batches[s])
-        succ += int(n_ok)
+    succ = run(batches[args.warmup:])
     sync()
     elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     counters = torch.tensor([float(succ), float(args.steps * B_PER_GPU)], device=dev, dtype=torch.float64)
@@ -226,7 +233,8 @@ def main():
                                    "num_iter=500 x binary_step=10 = 5000 inner iterations per attack()",
                        "batch_per_gpu": B_PER_GPU, "num_point": NPOINT, "num_iter": NUM_ITER,
                        "binary_step": BINARY_STEP, "central_num": HP["central_num"],
-                       "parallelism": "independent batch shards, 1 process per GPU", "hip_graph": att.last_graph_used},
+                       "parallelism": "independent batch shards, 1 process per GPU", "hip_graph": att.last_graph_used,
+                       "attacks_in_flight_per_gpu": min(max(1, args.concurrent), args.steps)},
             "cloud_iterations_per_s": clouds * NUM_ITER * BINARY_STEP / elapsed,
             "attack_success": {"succeeded": counters[0].item(), "attacked": counters[1].item()},
             "roofline": pairwise_roofline(dev),

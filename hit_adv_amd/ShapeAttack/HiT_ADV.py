@@ -230,92 +230,97 @@ class HiT_ADV:
         if dist_loss is not None:
             ws.dist_loss.copy_(dist_loss.detach())
 
-    def _prepare_graph(self, ws):
-        """Warm up on a side stream, then capture ``_iteration`` once per attack() call.  State touched
-        by the warm-up is re-initialised by the caller afterwards.
-
-        The graph is NOT kept across attack() calls: on ROCm 7.0/PyTorch 2.10 a replay that follows
-        eager victim work issued after the capture (the next call's get_gradient) faults with
-        HSA_STATUS_ERROR_EXCEPTION 0x1016 for some graphs (measured).  Capturing
-        costs ~0.1 s against ~10 s of replays, and within one call nothing eager touches the victim
-        between capture and the last replay."""
-        ws.graph = None
-        if self.use_graph in (False, 'never'):
-            return
-        # Warm up on a side stream with PyTorch's sync-debug mode set to "error": anything in the iteration
-        # that would synchronise with the host (an adv_func calling .item(), a victim drawing a CPU randint and
-        # copying it over, ...) raises HERE, in eager mode, and we fall back to the eager loop.  Attempting the
-        # capture with such an op inside would invalidate it and can leave PyTorch's capture bookkeeping
-        # (RNG registration, current stream) in a broken state.
-        capturable = True
+    def _warm_up(self, ws):
+        """Two eager passes of the iteration on ``ws.stream``; the second under PyTorch's sync-debug mode set
+        to "error": anything that would synchronise with the host (an adv_func calling .item(), a victim
+        drawing a CPU randint and copying it over, ...) raises HERE, in eager mode.  Attempting a capture with
+        such an op inside would invalidate it and can leave PyTorch's capture bookkeeping (RNG registration,
+        current stream) in a broken state.  Returns None when capturable, else the reason."""
+        reason = None
         prev_mode = torch.cuda.get_sync_debug_mode()
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            ws.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ws.stream):
                 self._iteration(ws)  # unguarded: lets library handles / lazy initialisation happen
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")  # "prototype feature" notice
                     torch.cuda.set_sync_debug_mode("error")
                 self._iteration(ws)
         except Exception as e:  # noqa: BLE001
-            capturable = False
             reason = e
         finally:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 torch.cuda.set_sync_debug_mode(prev_mode)
-            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream().wait_stream(ws.stream)
             torch.cuda.synchronize()
-        if capturable:
+        return reason
+
+    def _prepare_graphs(self, wss):
+        """Warm up every workspace, THEN capture one hipGraph per workspace (``_iteration`` on its stream).
+
+        Order matters on this stack (ROCm 7.0 runtime bundled with PyTorch 2.10): a replay that follows eager
+        victim work issued after the capture faults with HSA_STATUS_ERROR_EXCEPTION 0x1016 for some graphs
+        (measured).  So all eager work of all workspaces comes first, graphs are captured
+        last, and they are not kept across attack() calls (capturing costs ~0.1 s against seconds of replays)."""
+        for ws in wss:
+            ws.graph = None
+        if self.use_graph in (False, 'never'):
+            return
+        reason = None
+        for ws in wss:
+            reason = reason or self._warm_up(ws)
+        if reason is None:
             try:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._iteration(ws)
-                ws.graph = g
+                for ws in wss:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=ws.stream):
+                        self._iteration(ws)
+                    ws.graph = g
                 return
             except Exception as e:  # noqa: BLE001
                 reason = e
                 torch.cuda.synchronize()
+                for ws in wss:
+                    ws.graph = None
         if self.use_graph is True or self.use_graph == 'always':
             raise RuntimeError("the HiT-ADV iteration cannot be captured into a hipGraph: %r" % (reason,))
         warnings.warn("the HiT-ADV iteration is not hipGraph-capturable (%r); running the eager loop" % (reason,))
-        ws.graph = None
 
-    # ------------------------------------------------------------------ attack
-    def attack(self, data, target):
-        """Attack on given data to target.
-
-        Args:
-            data (torch.FloatTensor): victim data with normals, [B, num_points, 6]
-            target (torch.LongTensor): true labels (the attack is untargeted), [B]
-        Returns:
-            (numpy.float64 [B, num_points, 3], 0-d torch.int64 tensor with the success count)
-        """
+    # ------------------------------------------------------------------ attack phases
+    def _setup(self, data, target, slot=0):
+        """Everything before the binary search (:51-123): scoring, centre selection, state initialisation, and
+        ALL random draws of this attack, taken from the global CPU generator in the reference's order (randint for
+        the FPS start :501, then per binary step rand(B,C,3) :130 and rand(B,C) :133) and uploaded once."""
         B, K = data.shape[:2]
         dev = torch.device('cuda', torch.cuda.current_device())
         ori = data[:, :, :3].float().to(dev).clone().detach().transpose(1, 2).contiguous()
         normal = data[:, :, 3:].float().to(dev).clone().detach().transpose(1, 2).contiguous()
         target = target.long().to(dev).detach()
         C = self.central_num
-        if self._view is not None:
-            self._view.refresh(self.model)
-
         grad, _ = self.get_gradient(ori, target)
         central, central_kappa, _ = self._select_centres(ori, normal, grad)
 
-        ws = self._ws.get((B, K, C))
+        key = (B, K, C, slot)
+        ws = self._ws.get(key)
         if ws is None:
-            ws = self._ws[(B, K, C)] = _Workspace(B, K, C, dev)
+            ws = self._ws[key] = _Workspace(B, K, C, dev)
+            ws.stream = torch.cuda.Stream()
         ws.ori.copy_(ori)
         ws.central.copy_(central)
         ws.target.copy_(target)
         lo, hi = central_kappa.min(), central_kappa.max()
         ws.hide_ref.copy_(((central_kappa - lo) / (hi - lo + 1e-7)).squeeze(-1))
         ws.scale_const.fill_(self.init_weight)
-        self._prepare_graph(ws)
-        self.last_graph_used = ws.graph is not None
+        draws_p, draws_s = [], []
+        for _ in range(self.binary_step):
+            draws_p.append(torch.rand(B, C, 3) * torch.tensor(self.budget))
+            draws_s.append(torch.rand((B, C)))
+        ws.rand_P = torch.stack(draws_p).to(dev) if draws_p else None
+        ws.rand_S = torch.stack(draws_s).to(dev) if draws_s else None
+        return ws
 
+    def _reset_search(self, ws):
         ws.lower.zero_()
         ws.upper.fill_(self.max_weight)
         ws.scale_const.fill_(self.init_weight)
@@ -325,41 +330,43 @@ class HiT_ADV:
         st["o_bestattack"].zero_()
         ws.adv_loss.zero_()
         ws.dist_loss.zero_()
+
+    def _run_step(self, ws, binary_step, verbose):
+        """One binary-search step (:125-273) enqueued on the current stream: fresh parameters, num_iter replays
+        (or eager iterations), per-sample bisection of the distance weight -- no host synchronisation unless
+        ``verbose`` asks for the reference's progress lines."""
+        B, C, st = ws.B, ws.C, ws.state
+        with torch.no_grad():
+            ws.P.copy_(ws.rand_P[binary_step])
+            ws.sigma.copy_(torch.ones((B, C), device=ws.P.device) * self.min_sigm
+                           + ws.rand_S[binary_step] * (self.max_sigm - self.min_sigm))
+        ws.reset_step()
+        ws.adv_loss.zero_()
+        ws.dist_loss.zero_()
         report_every = max(1, self.num_iter // 5)
+        for iteration in range(self.num_iter):
+            report = verbose and iteration % report_every == 0
+            if report:
+                prev = (ws.adv_loss.item(), ws.dist_loss.item())
+            if ws.graph is not None:
+                ws.graph.replay()
+            else:
+                self._iteration(ws)
+            if report:
+                success_num = (st["pred"] != ws.target).sum().item()
+                print('Step {}, iteration {}, success {}/{}\n'
+                      'adv_loss: {:.4f}, dist_loss: {:.4f}'.format(binary_step, iteration, success_num, B,
+                                                                   prev[0], prev[1]))
+        with torch.no_grad():  # (:264-273), on device
+            ok = ((st["bestscore"] != ws.target) & (st["bestscore"] != -1)
+                  & (st["bestdist"] <= st["o_bestdist"]))
+            ws.lower.copy_(torch.where(ok, torch.maximum(ws.lower, ws.scale_const), ws.lower))
+            ws.upper.copy_(torch.where(ok, ws.upper, torch.minimum(ws.upper, ws.scale_const)))
+            ws.scale_const.copy_((ws.lower + ws.upper) / 2.)
 
-        for binary_step in range(self.binary_step):
-            # CPU-generator draws in the reference's order and shapes (:130,133)
-            p0 = torch.rand(B, C, 3) * torch.tensor(self.budget)
-            s0 = torch.rand((B, C))
-            with torch.no_grad():
-                ws.P.copy_(p0.to(dev))
-                ws.sigma.copy_(torch.ones((B, C), device=dev) * self.min_sigm
-                               + s0.to(dev) * (self.max_sigm - self.min_sigm))
-            ws.reset_step()
-            ws.adv_loss.zero_()
-            ws.dist_loss.zero_()
-            for iteration in range(self.num_iter):
-                report = self.verbose and iteration % report_every == 0
-                if report:
-                    prev = (ws.adv_loss.item(), ws.dist_loss.item())
-                if ws.graph is not None:
-                    ws.graph.replay()
-                else:
-                    self._iteration(ws)
-                if report:
-                    success_num = (st["pred"] != ws.target).sum().item()
-                    print('Step {}, iteration {}, success {}/{}\n'
-                          'adv_loss: {:.4f}, dist_loss: {:.4f}'.format(binary_step, iteration, success_num, B,
-                                                                       prev[0], prev[1]))
-            # per-sample bisection of the distance weight (:264-273), on device
-            with torch.no_grad():
-                ok = ((st["bestscore"] != ws.target) & (st["bestscore"] != -1)
-                      & (st["bestdist"] <= st["o_bestdist"]))
-                ws.lower.copy_(torch.where(ok, torch.maximum(ws.lower, ws.scale_const), ws.lower))
-                ws.upper.copy_(torch.where(ok, ws.upper, torch.minimum(ws.upper, ws.scale_const)))
-                ws.scale_const.copy_((ws.lower + ws.upper) / 2.)
-
-        # failed samples keep the last iterate (:277-282)
+    def _finish(self, ws, verbose):
+        """Failure fill and return value (:277-287)."""
+        st = ws.state
         with torch.no_grad():
             fail = ws.lower == 0.
             best = torch.where(fail[:, None, None], ws.adv, st["o_bestattack"])
@@ -368,7 +375,53 @@ class HiT_ADV:
         self.last_lower_bound = lower_cpu
         self.last_bestdist = st["o_bestdist"].cpu()
         success_num = (lower_cpu > 0.).sum()
-        if self.verbose:
+        if verbose:
             print('lower_bound is', lower_cpu)
-            print('Successfully attack {}/{}'.format(success_num, B))
+            print('Successfully attack {}/{}'.format(success_num, ws.B))
         return best.double().cpu().numpy().transpose((0, 2, 1)), success_num
+
+    def attack(self, data, target):
+        """Attack on given data to target.
+
+        Args:
+            data (torch.FloatTensor): victim data with normals, [B, num_points, 6]
+            target (torch.LongTensor): true labels (the attack is untargeted), [B]
+        Returns:
+            (numpy.float64 [B, num_points, 3], 0-d torch.int64 tensor with the success count)
+        """
+        if self._view is not None:
+            self._view.refresh(self.model)
+        ws = self._setup(data, target)
+        self._prepare_graphs([ws])
+        self.last_graph_used = ws.graph is not None
+        self._reset_search(ws)
+        ws.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ws.stream):
+            for binary_step in range(self.binary_step):
+                self._run_step(ws, binary_step, self.verbose)
+        torch.cuda.current_stream().wait_stream(ws.stream)
+        return self._finish(ws, self.verbose)
+
+    def attack_many(self, batches):
+        """Attack several independent batches CONCURRENTLY on one GPU: ``[(data, target), ...] -> [(adv, n), ...]``.
+
+        Results are those of calling ``attack`` on the batches one after the other (same RNG draws in the same
+        order, same kernels per batch) -- every batch keeps the reference's per-call semantics -- but the
+        binary-search steps of the batches are enqueued on separate HIP streams, each replaying its own captured
+        graph.  One B=32 PointNet iteration is ~115 short kernels that leave most of the 256 CUs idle between
+        launches; a second, independent stream fills those gaps.  No progress lines are printed."""
+        if self._view is not None:
+            self._view.refresh(self.model)
+        wss = [self._setup(d, t, slot=i) for i, (d, t) in enumerate(batches)]
+        self._prepare_graphs(wss)
+        self.last_graph_used = all(ws.graph is not None for ws in wss)
+        for ws in wss:
+            self._reset_search(ws)
+            ws.stream.wait_stream(torch.cuda.current_stream())
+        for binary_step in range(self.binary_step):
+            for ws in wss:
+                with torch.cuda.stream(ws.stream):
+                    self._run_step(ws, binary_step, False)
+        for ws in wss:
+            torch.cuda.current_stream().wait_stream(ws.stream)
+        return [self._finish(ws, False) for ws in wss]

@@ -526,3 +526,36 @@ def test_cwaof_follows_reference_trajectory():
         np.testing.assert_allclose(trace[i], fx['adv_trace'][i], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(final, fx['final'], rtol=1e-3, atol=2e-4)
     assert succ == int(fx['success_num']) and final.dtype == np.float32
+
+
+def test_attack_many_equals_sequential_attacks():
+    """Concurrent multi-stream attacks return exactly what back-to-back attack() calls return (PointNet view: every
+    kernel in the loop is deterministic), including the RNG draw order."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(0)
+    m = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    batches = []
+    for i in range(3):
+        d, _ = synth_batch(8, 1024, first=1600 + 8 * i)
+        with torch.no_grad():
+            lab = m(d[:, :, :3].transpose(1, 2).contiguous().cuda())[0].argmax(1)
+        batches.append((d, lab))
+    hp = dict(binary_step=3, num_iter=8, cd_weight=1e-4, ker_weight=1., hide_weight=1., curv_loss_knn=16,
+              central_num=192, total_central_num=256, max_sigm=1.2, min_sigm=0.1, budget=0.55, verbose=False)
+    att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), **hp)
+    torch.manual_seed(77)
+    seq = [att.attack(d, l) for d, l in batches]
+    att2 = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), **hp)
+    torch.manual_seed(77)
+    par = att2.attack_many(batches)
+    assert att2.last_graph_used
+    for (a, na), (b, nb) in zip(seq, par):
+        assert np.array_equal(a, b) and int(na) == int(nb)
+    # and the same attacker can go on with single attacks afterwards
+    torch.manual_seed(78)
+    again = att2.attack(*batches[0])
+    torch.manual_seed(78)
+    ref = att.attack(*batches[0])
+    assert np.array_equal(again[0], ref[0])

@@ -28,6 +28,7 @@ def per_iter(att, data, label, iters=300):
     torch.cuda.synchronize()
     t_attack = time.perf_counter() - t0
     ws = next(iter(att._ws.values()))
+    att._prepare_graphs([ws])  # graphs are per attack() call; capture one for the replay timing
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
