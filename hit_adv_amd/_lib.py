@@ -40,8 +40,8 @@ PROTOTYPES = {
     "hitadv_regulariser_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hitadv_regulariser_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hitadv_regulariser_scratch_floats": [_I],
-    "hitadv_linear_max_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "hitadv_max_over_points": [_P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hitadv_linear_max_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "hitadv_max_over_points": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hitadv_max_over_points_scratch": [_I, _I],
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,

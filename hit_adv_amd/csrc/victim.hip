@@ -20,7 +20,8 @@ constexpr int LM_UN = 8;     // rows of W kept in flight per wave
 // the 4 waves split the channel range, each keeps LM_UN rows of W in flight, and the 4 partial sums are
 // added in wave order -> deterministic, and a hot point costs matches/32 dependent L2 round trips.
 __global__ __launch_bounds__(256) void linear_max_bwd_k(const float *__restrict__ dg, const float *__restrict__ W,
-                                                        const int64_t *__restrict__ idx, int N, int Cout, int Cin,
+                                                        const int64_t *__restrict__ idx,
+                                                        const float *__restrict__ act_out, int N, int Cout, int Cin,
                                                         float *__restrict__ dX) {
   extern __shared__ int sidx[];  // Cout entries, then 4*Cin floats of partial sums
   __shared__ int has[LM_ROWS];
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256) void linear_max_bwd_k(const float *__restrict_
   }
   __syncthreads();
   const float *dgb = dg + (size_t)b * Cout;
+  const float *aob = act_out ? act_out + (size_t)b * Cout : nullptr;  // ReLU'd maxima: gradient passes where > 0
   const int nc = (Cin + 63) >> 6;
   const int jper = (((Cout + 3) >> 2) + 63) & ~63;  // channels per wave, multiple of 64
   const int jlo = wave * jper, jhi = min(Cout, jlo + jper);
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void linear_max_bwd_k(const float *__restrict_
           const bool on = m != 0ull;
           jj[u] = on ? j0 + __builtin_ctzll(m) : 0;
           m = on ? (m & (m - 1)) : 0ull;
-          g[u] = on ? dgb[jj[u]] : 0.f;
+          g[u] = on ? ((aob == nullptr || aob[jj[u]] > 0.f) ? dgb[jj[u]] : 0.f) : 0.f;
         }
 #pragma unroll
         for (int c = 0; c < LM_MAXC; ++c) {
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void max_over_points_k(const float *__restrict
 
 __global__ __launch_bounds__(256) void max_over_points_merge(const float *__restrict__ pval,
                                                              const int32_t *__restrict__ pidx, int C,
+                                                             const float *__restrict__ bias, int relu,
                                                              float *__restrict__ out, int64_t *__restrict__ idx,
                                                              long long total) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -132,6 +135,8 @@ __global__ __launch_bounds__(256) void max_over_points_merge(const float *__rest
     const float v = pval[o];
     if (v > best || s == 0) { best = v; bi = pidx[o]; }
   }
+  if (bias != nullptr) best = best + bias[c];  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
+  if (relu) best = best > 0.f ? best : 0.f;    // max and ReLU commute
   out[e] = best;
   idx[e] = bi;
 }
@@ -142,8 +147,8 @@ using namespace hitadv;
 
 extern "C" int64_t hitadv_max_over_points_scratch(int B, int C) { return (int64_t)B * MP_SPLIT * C; }
 
-extern "C" int hitadv_max_over_points(const float *y, int B, int N, int C, float *part_val, int32_t *part_idx,
-                                      float *out, int64_t *idx, void *stream) {
+extern "C" int hitadv_max_over_points(const float *y, int B, int N, int C, const float *bias, int relu,
+                                      float *part_val, int32_t *part_idx, float *out, int64_t *idx, void *stream) {
   if (!y || !part_val || !part_idx || !out || !idx || B <= 0 || N <= 0 || C <= 0 || (C & 3) ||
       ((uintptr_t)y & 15))
     return HITADV_E_ARG;
@@ -151,17 +156,18 @@ extern "C" int hitadv_max_over_points(const float *y, int B, int N, int C, float
   dim3 grid((C / 4 + 255) / 256, MP_SPLIT, B);
   max_over_points_k<<<grid, 256, 0, s>>>(y, N, C, part_val, part_idx);
   const long long total = (long long)B * C;
-  max_over_points_merge<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part_val, part_idx, C, out, idx, total);
+  max_over_points_merge<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part_val, part_idx, C, bias, relu, out, idx,
+                                                                         total);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int hitadv_linear_max_bwd(const float *dg, const float *W, const int64_t *idx, int B, int N, int Cout,
-                                     int Cin, float *dX, void *stream) {
+extern "C" int hitadv_linear_max_bwd(const float *dg, const float *W, const int64_t *idx, const float *act_out, int B,
+                                     int N, int Cout, int Cin, float *dX, void *stream) {
   if (!dg || !W || !idx || !dX || B <= 0 || N <= 0 || Cout <= 0 || Cin <= 0 || Cin > 64 * LM_MAXC || Cout > 16384)
     return HITADV_E_ARG;
   dim3 grid((N + LM_ROWS - 1) / LM_ROWS, B);
-  linear_max_bwd_k<<<grid, 256, (size_t)Cout * sizeof(int) + (size_t)4 * Cin * sizeof(float), (hipStream_t)stream>>>(dg, W, idx, N, Cout, Cin, dX);
+  linear_max_bwd_k<<<grid, 256, (size_t)Cout * sizeof(int) + (size_t)4 * Cin * sizeof(float), (hipStream_t)stream>>>(dg, W, idx, act_out, N, Cout, Cin, dX);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

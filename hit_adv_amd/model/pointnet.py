@@ -143,25 +143,19 @@ class _LinearMaxOverPoints(torch.autograd.Function):
     def forward(ctx, x, Wt, W, bias, B, N, relu):
         from .. import ops
         y = torch.mm(x, Wt)
-        g, idx = ops.max_over_points(y, B, N)  # one 134 MB read at HBM rate (torch's dim-1 max is ~2.5x slower)
+        # one 134 MB read at HBM rate (torch's dim-1 max is ~2.5x slower); bias add and ReLU ride in the merge pass
+        g, idx = ops.max_over_points(y, B, N, bias=bias, relu=relu)
         del y
-        g = g + bias  # rounding is monotonic, so max_n(y_n + b) == max_n(y_n) + b
-        mask = None
-        if relu:
-            mask = g > 0
-            g = g.clamp_min(0.)
-        ctx.save_for_backward(W, idx, mask)
+        ctx.save_for_backward(W, idx, g if relu else None)
         ctx.dims = (B, N)
         return g
 
     @staticmethod
     def backward(ctx, dg):
         from .. import ops
-        W, idx, mask = ctx.saved_tensors
+        W, idx, act_out = ctx.saved_tensors
         B, N = ctx.dims
-        if mask is not None:
-            dg = dg * mask
-        return ops.linear_max_bwd(dg, W, idx, N), None, None, None, None, None, None
+        return ops.linear_max_bwd(dg, W, idx, N, act_out), None, None, None, None, None, None
 
 
 class _LinearReLU(torch.autograd.Function):

@@ -225,19 +225,20 @@ def fps_from_start(xyz, npoint, start):
 
 
 # --------------------------------------------------------------------------- victim-side helper
-def linear_max_bwd(dg, W, idx, N):
-    """dX[b*N+n,:] = sum_{j: idx[b,j]==n} dg[b,j] * W[j,:]   (dg[B,Cout], W[Cout,Cin], idx[B,Cout] int64)."""
+def linear_max_bwd(dg, W, idx, N, act_out=None):
+    """dX[b*N+n,:] = sum_{j: idx[b,j]==n} dg[b,j] * W[j,:]   (dg[B,Cout], W[Cout,Cin], idx[B,Cout] int64);
+    with ``act_out`` (the ReLU'd forward maxima) only channels whose output is > 0 pass gradient."""
     dg, W = _dev(dg, "dg"), _dev(W, "W")
     idx = _dev(idx, "idx", torch.int64)
     B, Cout = dg.shape
     Cin = W.shape[1]
     dX = torch.empty(B * N, Cin, device=dg.device)
-    _lib.call("hitadv_linear_max_bwd", _p(dg), _p(W), _p(idx), B, N, Cout, Cin, _p(dX), _stream())
+    _lib.call("hitadv_linear_max_bwd", _p(dg), _p(W), _p(idx), _p(act_out), B, N, Cout, Cin, _p(dX), _stream())
     return dX
 
 
-def max_over_points(y, B, N):
-    """y[B*N,C] (points-major) -> (max over the N points [B,C], arg-max [B,C] int64, lowest n on ties)."""
+def max_over_points(y, B, N, bias=None, relu=False):
+    """y[B*N,C] (points-major) -> (act(max over the N points + bias) [B,C], arg-max [B,C] int64, lowest n on ties)."""
     y = _dev(y, "y")
     C = y.shape[-1]
     n = _lib.load().hitadv_max_over_points_scratch(B, C)
@@ -245,7 +246,8 @@ def max_over_points(y, B, N):
     pi = torch.empty(n, device=y.device, dtype=torch.int32)
     out = torch.empty(B, C, device=y.device)
     idx = torch.empty(B, C, device=y.device, dtype=torch.int64)
-    _lib.call("hitadv_max_over_points", _p(y), B, N, C, _p(pv), _p(pi), _p(out), _p(idx), _stream())
+    _lib.call("hitadv_max_over_points", _p(y), B, N, C, _p(bias), 1 if relu else 0, _p(pv), _p(pi), _p(out), _p(idx),
+              _stream())
     return out, idx
 
 

@@ -202,15 +202,17 @@ int hitadv_three_interpolate_grad(int b, int c, int n, int m, const float *grad_
  * torch.max(x, 2), and the same pattern in STN3d/STNkd :164-165, :209-210):
  *   dX[b,n,:] = sum_{j : idx[b,j]==n} dg[b,j] * W[j,:]
  * dg[B,Cout], W[Cout,Cin] (BatchNorm already folded), idx[B,Cout] int64 arg-max over points,
- * dX[B*N,Cin] fully overwritten.  Cin <= 512.  Deterministic (ascending j, no atomics). */
-int hitadv_linear_max_bwd(const float *dg, const float *W, const int64_t *idx, int B, int N, int Cout,
-                          int Cin, float *dX, void *stream);
+ * act_out[B,Cout] (optional, NULL = none): the ReLU'd forward output; gradient passes only where it is > 0.
+ * dX[B*N,Cin] fully overwritten.  Cin <= 512.  Deterministic (fixed order, no atomics). */
+int hitadv_linear_max_bwd(const float *dg, const float *W, const int64_t *idx, const float *act_out, int B, int N,
+                          int Cout, int Cin, float *dX, void *stream);
 
-/* g[b,c] = max_n y[b,n,c] and its arg-max (lowest n on ties) for points-major activations y[B,N,C],
- * C % 4 == 0, y 16-byte aligned.  Replaces torch.max(x, 2) of model/feature_models.py:127,165,210 in the
- * attack-time victim view.  part_val / part_idx: scratch of hitadv_max_over_points_scratch(B,C) elements. */
-int hitadv_max_over_points(const float *y, int B, int N, int C, float *part_val, int32_t *part_idx,
-                           float *out, int64_t *idx, void *stream);
+/* g[b,c] = act(max_n y[b,n,c] + bias[c]) and the arg-max (lowest n on ties) for points-major activations
+ * y[B,N,C], C % 4 == 0, y 16-byte aligned; bias may be NULL, act = ReLU when relu != 0 (max, the bias add and
+ * ReLU commute).  Replaces conv bias + bn + (relu) + torch.max(x, 2) of model/feature_models.py:126-127,164-165,
+ * 209-210 in the attack-time victim view.  part_val / part_idx: scratch of hitadv_max_over_points_scratch(B,C). */
+int hitadv_max_over_points(const float *y, int B, int N, int C, const float *bias, int relu, float *part_val,
+                           int32_t *part_idx, float *out, int64_t *idx, void *stream);
 int64_t hitadv_max_over_points_scratch(int B, int C);
 
 #ifdef __cplusplus

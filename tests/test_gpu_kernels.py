@@ -466,6 +466,15 @@ def test_max_over_points_and_linear_max_bwd(A):
     dx = A.linear_max_bwd(cu(dg), cu(W), idx, Np)
     close(dx, xr.grad, rtol=1e-5, atol=1e-5)
     assert torch.equal(dx, A.linear_max_bwd(cu(dg), cu(W), idx, Np))
+    # bias + ReLU in the merge pass, activation mask in the backward
+    bias = torch.randn(Cout, generator=g)
+    val2, idx2 = A.max_over_points(cu(y), B, Np, bias=cu(bias), relu=True)
+    assert torch.equal(idx2, idx) and torch.equal(val2.cpu(), (ref_val + bias).clamp_min(0.))
+    dxm = A.linear_max_bwd(cu(dg), cu(W), idx, Np, act_out=val2)
+    xr2 = x.clone().requires_grad_()
+    # (channel (0,17) carries the planted tie value in y only, so take the ReLU mask from the kernel's own output)
+    ((xr2 @ W.t()).view(B, Np, Cout).gather(1, idx.cpu().unsqueeze(1)).squeeze(1) * (dg * (val2.cpu() > 0))).sum().backward()
+    close(dxm, xr2.grad, rtol=1e-5, atol=1e-5)
     # a single hot point owning every channel (long serial chain) and a small odd Cin
     hot = torch.zeros(B, Cout, dtype=torch.int64)
     W2 = torch.randn(Cout, 70, generator=g)
