@@ -43,9 +43,11 @@ PROTOTYPES = {
     "hitadv_linear_max_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "hitadv_max_over_points": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hitadv_max_over_points_scratch": [_I, _I],
+    "hitadv_linear_max_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hitadv_linear_max_fwd_scratch": [_I, _I, _I],
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,
-            "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64}
+            "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_linear_max_fwd_scratch": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64}
 
 _lib = None
 

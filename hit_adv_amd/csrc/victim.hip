@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void max_over_points_k(const float *__restrict
 }
 
 __global__ __launch_bounds__(256) void max_over_points_merge(const float *__restrict__ pval,
-                                                             const int32_t *__restrict__ pidx, int C,
+                                                             const int32_t *__restrict__ pidx, int C, int S,
                                                              const float *__restrict__ bias, int relu,
                                                              float *__restrict__ out, int64_t *__restrict__ idx,
                                                              long long total) {
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void max_over_points_merge(const float *__rest
   const long long b = e / C;
   float best = -__builtin_inff();
   int bi = 0;
-  for (int s = 0; s < MP_SPLIT; ++s) {
-    const size_t o = ((size_t)b * MP_SPLIT + s) * C + c;
+  for (int s = 0; s < S; ++s) {
+    const size_t o = ((size_t)b * S + s) * C + c;
     const float v = pval[o];
     if (v > best || s == 0) { best = v; bi = pidx[o]; }
   }
@@ -139,6 +139,146 @@ __global__ __launch_bounds__(256) void max_over_points_merge(const float *__rest
   if (relu) best = best > 0.f ? best : 0.f;    // max and ReLU commute
   out[e] = best;
   idx[e] = bi;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Fused  y = x[B*N,CIN] @ Wt[CIN,Cout]  ->  max / arg-max over the N points of each cloud, on the f32
+// matrix cores (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fmaf chain).  The [B*N,Cout] activation
+// (134 MB for PointNet's 128->1024 layer at B=32) never exists: not written, not re-read.
+//
+//   block   = 4 waves; one cloud, one split of its points, 256 output channels (64 per wave)
+//   W       : the wave's 64 columns x CIN rows live in VGPRs for the whole kernel (2*CIN/2 registers)
+//   x       : 64-point tiles, global -> registers -> LDS (row stride CIN+4 floats: conflict-free
+//             ds_read_b128), double buffered, one barrier per tile; every wave reads the same tile
+//   compute : per tile and wave 2x2 accumulators of 32x32, CIN/2 MFMA steps each
+//   epilogue: accumulator layout = column on the lane, 16 rows in registers -> running (max, first
+//             arg-max) per lane; the two lane halves are merged once at the end.
+// Partials [B,S,Cout] go through max_over_points_merge (bias, ReLU, split order = ascending points).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int LF_TM = 64;
+
+template <int CIN>
+__global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict__ X, const float *__restrict__ Wt,
+                                                        int N, int Cout, int rows_per_split,
+                                                        float *__restrict__ pval, int32_t *__restrict__ pidx) {
+  constexpr int LDA = CIN + 4;
+  constexpr int KS = CIN / 2;            // MFMA steps per output tile
+  constexpr int F4_ROW = CIN / 4;        // float4 per row of x
+  constexpr int ST = LF_TM * F4_ROW / 256;  // float4 staged per thread per tile
+  extern __shared__ float4 sA4[];        // 2 x LF_TM x LDA floats
+  float *sA = reinterpret_cast<float *>(sA4);
+  const int cg = blockIdx.x, s = blockIdx.y, b = blockIdx.z, S = gridDim.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int col0 = cg * 256 + wave * 64;
+  const bool active = col0 < Cout;  // wave-uniform
+  const int n0 = s * rows_per_split, n1 = min(N, n0 + rows_per_split);
+  const int ntiles = (n1 - n0 + LF_TM - 1) / LF_TM;
+  X += (size_t)b * N * CIN;
+
+  // step t of the K loop consumes k = 8*(t/4) + 4*h + t%4: a lane's four consecutive steps are one float4 of x
+  float w[2][KS];
+  const float *wp = Wt + (active ? col0 : 0) + r;  // idle waves (Cout not a multiple of 256) load in range, use nothing
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int t = 0; t < KS; ++t) w[cb][t] = wp[(size_t)(8 * (t >> 2) + 4 * h + (t & 3)) * Cout + 32 * cb];
+
+  float4 st[ST];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < ST; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      const int n = n0 + tile * LF_TM + e / F4_ROW;
+      st[u] = n < n1 ? *reinterpret_cast<const float4 *>(X + (size_t)n * CIN + 4 * (e % F4_ROW))
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < ST; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      *reinterpret_cast<float4 *>(sA + (size_t)buf * LF_TM * LDA + (e / F4_ROW) * LDA + 4 * (e % F4_ROW)) = st[u];
+    }
+  };
+
+  float bv[2] = {-__builtin_inff(), -__builtin_inff()};
+  int bi[2] = {n0, n0};
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const bool more = tile + 1 < ntiles;
+    if (more) fetch(tile + 1);
+    if (active) {
+      const float *a = sA + (size_t)(tile & 1) * LF_TM * LDA + r * LDA + 4 * h;
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < CIN / 8; ++j) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(a + 8 * j);
+        const float4 a1 = *reinterpret_cast<const float4 *>(a + 32 * LDA + 8 * j);
+        const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+        const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = 4 * j + i;
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], w[0][t], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], w[1][t], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], w[0][t], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], w[1][t], acc[1][1], 0, 0, 0);
+        }
+      }
+      // accumulator element e of tile (rb, cb): row 32*rb + (e&3) + 8*(e>>2) + 4*h, column 32*cb + r
+      const int nb = n0 + tile * LF_TM + 4 * h;
+      const bool ragged = n0 + (tile + 1) * LF_TM > n1;  // rows past the split's end are zero-filled: keep them out
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int n = nb + 32 * rb + (e & 3) + 8 * (e >> 2);
+          const bool live = !ragged || n < n1;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const float v = live ? acc[rb][cb][e] : -__builtin_inff();
+            const bool g = v > bv[cb];
+            bv[cb] = g ? v : bv[cb];
+            bi[cb] = g ? n : bi[cb];
+          }
+        }
+    }
+    if (more) stash((tile + 1) & 1);
+    __syncthreads();
+  }
+  if (!active) return;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {  // the other half of the wave holds the same column, other rows
+    const float ov = __shfl_xor(bv[cb], 32, HITADV_WAVE);
+    const int oi = __shfl_xor(bi[cb], 32, HITADV_WAVE);
+    if (ov > bv[cb] || (ov == bv[cb] && oi < bi[cb])) { bv[cb] = ov; bi[cb] = oi; }
+    if (h == 0) {
+      const size_t o = ((size_t)b * S + s) * Cout + col0 + 32 * cb + r;
+      pval[o] = bv[cb];
+      pidx[o] = bi[cb];
+    }
+  }
+}
+
+static void linear_max_split(int B, int N, int Cout, int *S, int *rows) {
+  const int colgroups = (Cout + 255) / 256;
+  int want = (512 + B * colgroups - 1) / (B * colgroups);  // aim at >= 2 blocks per CU
+  const int maxs = (N + LF_TM - 1) / LF_TM;
+  want = want < 1 ? 1 : (want > maxs ? maxs : want);
+  int per = (N + want - 1) / want;
+  per = (per + LF_TM - 1) / LF_TM * LF_TM;
+  *rows = per;
+  *S = (N + per - 1) / per;
 }
 
 }  // namespace hitadv
@@ -156,7 +296,7 @@ extern "C" int hitadv_max_over_points(const float *y, int B, int N, int C, const
   dim3 grid((C / 4 + 255) / 256, MP_SPLIT, B);
   max_over_points_k<<<grid, 256, 0, s>>>(y, N, C, part_val, part_idx);
   const long long total = (long long)B * C;
-  max_over_points_merge<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part_val, part_idx, C, bias, relu, out, idx,
+  max_over_points_merge<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part_val, part_idx, C, MP_SPLIT, bias, relu, out, idx,
                                                                          total);
   HITADV_LAUNCH_CHECK();
   return 0;
@@ -168,6 +308,39 @@ extern "C" int hitadv_linear_max_bwd(const float *dg, const float *W, const int6
     return HITADV_E_ARG;
   dim3 grid((N + LM_ROWS - 1) / LM_ROWS, B);
   linear_max_bwd_k<<<grid, 256, (size_t)Cout * sizeof(int) + (size_t)4 * Cin * sizeof(float), (hipStream_t)stream>>>(dg, W, idx, act_out, N, Cout, Cin, dX);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t hitadv_linear_max_fwd_scratch(int B, int N, int Cout) {
+  if (B <= 0 || N <= 0 || Cout <= 0) return 0;
+  int S, rows;
+  linear_max_split(B, N, Cout, &S, &rows);
+  return (int64_t)B * S * Cout;
+}
+
+extern "C" int hitadv_linear_max_fwd(const float *X, const float *Wt, const float *bias, int B, int N, int Cin, int Cout,
+                                     int relu, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
+                                     void *stream) {
+  if (!X || !Wt || !part_val || !part_idx || !out || !idx || B <= 0 || N <= 0 || Cout <= 0 || (Cout & 63) ||
+      (Cin != 64 && Cin != 128) || ((uintptr_t)X & 15))
+    return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int S, rows;
+  linear_max_split(B, N, Cout, &S, &rows);
+  dim3 grid((Cout + 255) / 256, S, B);
+  const size_t shm = (size_t)2 * LF_TM * (Cin + 4) * sizeof(float);
+  if (Cin == 128) {
+    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_TM * 132 * 4);
+    (void)once;
+    linear_max_fwd_k<128><<<grid, 256, shm, s>>>(X, Wt, N, Cout, rows, part_val, part_idx);
+  } else {
+    linear_max_fwd_k<64><<<grid, 256, shm, s>>>(X, Wt, N, Cout, rows, part_val, part_idx);
+  }
+  const long long total = (long long)B * Cout;
+  max_over_points_merge<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part_val, part_idx, Cout, S, bias, relu, out,
+                                                                         idx, total);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

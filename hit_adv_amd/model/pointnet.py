@@ -142,10 +142,14 @@ class _LinearMaxOverPoints(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Wt, W, bias, B, N, relu):
         from .. import ops
-        y = torch.mm(x, Wt)
-        # one 134 MB read at HBM rate (torch's dim-1 max is ~2.5x slower); bias add and ReLU ride in the merge pass
-        g, idx = ops.max_over_points(y, B, N, bias=bias, relu=relu)
-        del y
+        if ops.linear_max_fwd_supported(*Wt.shape):
+            # GEMM on the f32 matrix cores with the max/arg-max in its epilogue: the 134 MB activation never exists
+            g, idx = ops.linear_max_fwd(x, Wt, B, N, bias=bias, relu=relu)
+        else:
+            y = torch.mm(x, Wt)
+            # one read at HBM rate (torch's dim-1 max is ~2.5x slower); bias add and ReLU ride in the merge pass
+            g, idx = ops.max_over_points(y, B, N, bias=bias, relu=relu)
+            del y
         ctx.save_for_backward(W, idx, g if relu else None)
         ctx.dims = (B, N)
         return g

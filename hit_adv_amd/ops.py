@@ -251,6 +251,25 @@ def max_over_points(y, B, N, bias=None, relu=False):
     return out, idx
 
 
+def linear_max_fwd(x, Wt, B, N, bias=None, relu=False):
+    """Fused x[B*N,Cin] @ Wt[Cin,Cout] -> act(max over the N points + bias) [B,Cout] and its arg-max [B,Cout] int64
+    (f32 MFMA; the [B*N,Cout] activation is never written).  Cin in {64,128}, Cout % 64 == 0."""
+    x, Wt = _dev(x, "x"), _dev(Wt, "Wt")
+    Cin, Cout = Wt.shape
+    n = _lib.load().hitadv_linear_max_fwd_scratch(B, N, Cout)
+    pv = torch.empty(n, device=x.device)
+    pi = torch.empty(n, device=x.device, dtype=torch.int32)
+    out = torch.empty(B, Cout, device=x.device)
+    idx = torch.empty(B, Cout, device=x.device, dtype=torch.int64)
+    _lib.call("hitadv_linear_max_fwd", _p(x), _p(Wt), _p(bias), B, N, Cin, Cout, 1 if relu else 0, _p(pv), _p(pi),
+              _p(out), _p(idx), _stream())
+    return out, idx
+
+
+def linear_max_fwd_supported(Cin, Cout):
+    return Cin in (64, 128) and Cout % 64 == 0
+
+
 def topk_rows(P, K, largest=True):
     """Row-wise top-K of a matrix [..., M] -> (vals[..., K], idx[..., K] int64), sorted, ties -> lower column."""
     P = _dev(P.detach(), "P")

@@ -215,6 +215,16 @@ int hitadv_max_over_points(const float *y, int B, int N, int C, const float *bia
                            int32_t *part_idx, float *out, int64_t *idx, void *stream);
 int64_t hitadv_max_over_points_scratch(int B, int C);
 
+/* Fused shared linear layer + max over points on the f32 matrix cores (MFMA 32x32x2 f32, exact f32):
+ *   out[b,c] = act(max_n (X[b,n,:] . Wt[:,c]) + bias[c]),  idx[b,c] = first arg-max point,
+ * i.e. `conv3 -> bn3 -> (relu) -> torch.max(x, 2)` of model/feature_models.py:173-175 (STN3d), :215-217 (STNkd)
+ * and :139-140 (PointNetEncoder) with the BatchNorm folded into (Wt, bias).  The [B*N,Cout] activation is
+ * never materialised.  X [B*N,Cin] points-major, Wt [Cin,Cout]; Cin in {64,128}, Cout % 64 == 0.
+ * part_val / part_idx: scratch of hitadv_linear_max_fwd_scratch(B,N,Cout) entries each. */
+int hitadv_linear_max_fwd(const float *X, const float *Wt, const float *bias, int B, int N, int Cin, int Cout,
+                          int relu, float *part_val, int32_t *part_idx, float *out, int64_t *idx, void *stream);
+int64_t hitadv_linear_max_fwd_scratch(int B, int N, int Cout);
+
 #ifdef __cplusplus
 }
 #endif

@@ -483,6 +483,54 @@ def test_max_over_points_and_linear_max_bwd(A):
     assert (dx[:, 1:] == 0).all()
 
 
+@pytest.mark.parametrize("B,Np,Cin,Cout", [(3, 500, 128, 1024), (2, 1024, 128, 1024), (5, 77, 64, 192), (1, 64, 128, 64),
+                                           (32, 1024, 128, 1024)])
+def test_linear_max_fwd_mfma(A, B, Np, Cin, Cout):
+    """Fused shared layer + max over points (f32 MFMA) vs  (x @ Wt).view(B,N,C).max(1)  evaluated in float64."""
+    g = torch.Generator().manual_seed(B * 1000 + Np)
+    x = torch.randn(B * Np, Cin, generator=g)
+    Wt = torch.randn(Cin, Cout, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g)
+    y = (x.double() @ Wt.double()).view(B, Np, Cout)
+    ref_val, ref_idx = y.max(dim=1)
+    val, idx = A.linear_max_fwd(cu(x), cu(Wt), B, Np)
+    assert idx.dtype == torch.int64 and val.shape == (B, Cout)
+    close(val, ref_val.float(), rtol=2e-6, atol=2e-5)
+    # the arg-max is the reference's wherever the runner-up is further away than f32 noise ...
+    top2 = y.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert clear.float().mean() > 0.9
+    assert torch.equal(idx.cpu()[clear], ref_idx[clear])
+    # ... and everywhere it points at a point whose activation IS the reported maximum
+    close(y.gather(1, idx.cpu().unsqueeze(1)).squeeze(1).float(), val, rtol=2e-6, atol=2e-5)
+    # bias + ReLU in the merge pass; bitwise reproducible; agrees with the unfused HIP path's indices where clear
+    val2, idx2 = A.linear_max_fwd(cu(x), cu(Wt), B, Np, bias=cu(bias), relu=True)
+    assert torch.equal(idx2, idx) and torch.equal(val2, (val + cu(bias)).clamp_min(0.))
+    v3, i3 = A.linear_max_fwd(cu(x), cu(Wt), B, Np)
+    assert torch.equal(v3, val) and torch.equal(i3, idx)
+    _, iu = A.max_over_points(cu(x) @ cu(Wt), B, Np)
+    assert torch.equal(iu.cpu()[clear], idx.cpu()[clear])
+
+
+def test_linear_max_fwd_ties_and_errors(A):
+    """Duplicate points give exactly equal activations: the lowest point index wins, across MFMA tiles,
+    lane halves and point splits.  Unsupported shapes are refused, not silently mis-computed."""
+    g = torch.Generator().manual_seed(3)
+    B, Np, Cin, Cout = 2, 1024, 128, 256
+    base = torch.randn(B, 8, Cin, generator=g)
+    x = base.repeat_interleave(Np // 8, dim=1).reshape(B * Np, Cin)   # every point is one of 8 rows, runs of 128
+    Wt = torch.randn(Cin, Cout, generator=g)
+    val, idx = A.linear_max_fwd(cu(x), cu(Wt), B, Np)
+    assert (idx.cpu() % (Np // 8) == 0).all()                            # first point of the winning run
+    xs = x.view(B, Np, Cin).flip(1).reshape(B * Np, Cin).contiguous()
+    _, idx_f = A.linear_max_fwd(cu(xs), cu(Wt), B, Np)
+    assert (idx_f.cpu() % (Np // 8) == 0).all()
+    with pytest.raises(A._lib.HitAdvLibraryError):
+        A.linear_max_fwd(cu(torch.randn(64, 96)), cu(torch.randn(96, 64)), 1, 64)
+    with pytest.raises(A._lib.HitAdvLibraryError):
+        A.linear_max_fwd(cu(torch.randn(64, 128)), cu(torch.randn(128, 100)), 1, 64)
+
+
 def test_fused_regulariser_matches_torch_composition(A):
     """hitadv_regulariser_{fwd,bwd} vs the reference's composition of ChamferDist (on [B,3,N], quirk Q1),
     transformation_loss, curv_std_loss and the scale_const weighting, evaluated by the CPU oracle + autograd."""

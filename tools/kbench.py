@@ -108,6 +108,26 @@ def main():
     bq = torch.empty(B, 51, 49, dtype=torch.int32, device='cuda')
     us = timed(lambda s=s0: lib.hitadv_query_ball_point(B, N, 51, ctypes.c_float(0.22), 49, p(new_xyz), p(x), p(bq), s), a.reps)
     out['ball_query_m51_ns49'] = dict(us=round(us, 2))
+    # victim helper: fused 128->1024 shared layer + max over points on the f32 matrix cores, and what it replaced
+    h2 = torch.randn(B * N, 128, generator=g).cuda()
+    Wt = (torch.randn(128, 1024, generator=g) * 0.1).cuda()
+    bias = torch.randn(1024, generator=g).cuda()
+    n = lib.hitadv_linear_max_fwd_scratch(B, N, 1024)
+    pv, pi = torch.empty(n, device='cuda'), torch.empty(n, device='cuda', dtype=torch.int32)
+    mo, mi = torch.empty(B, 1024, device='cuda'), torch.empty(B, 1024, device='cuda', dtype=torch.int64)
+    us = timed(lambda s=s0: lib.hitadv_linear_max_fwd(p(h2), p(Wt), p(bias), B, N, 128, 1024, 1, p(pv), p(pi), p(mo),
+                                                      p(mi), s), a.reps)
+    out['linear_max_fwd_128x1024(+merge)'] = dict(us=round(us, 2), TFLOPs=round(2 * B * N * 128 * 1024 / us / 1e6, 1),
+                                                  frac_of_157TF=round(2 * B * N * 128 * 1024 / us / 1e6 / 157.3, 3))
+    yb = torch.empty(B * N, 1024, device='cuda')
+    n2 = lib.hitadv_max_over_points_scratch(B, 1024)
+    pv2, pi2 = torch.empty(n2, device='cuda'), torch.empty(n2, device='cuda', dtype=torch.int32)
+
+    def unfused(s=s0):
+        torch.mm(h2, Wt, out=yb)  # torch's current stream is the one `s` names, eagerly and under capture
+        lib.hitadv_max_over_points(p(yb), B, N, 1024, p(bias), 1, p(pv2), p(pi2), p(mo), p(mi), s)
+    us = timed(unfused, a.reps)
+    out['mm+max_over_points_128x1024'] = dict(us=round(us, 2))
     print(json.dumps(out))
 
 
