@@ -1,0 +1,446 @@
+// PointNet victim (model/feature_models.py:71-230 in eval mode, BatchNorm folded) as hand-written kernels:
+// the per-point MLP stacks in front of the three 128->1024 layers, their input-gradient chains, and the
+// small FC stacks, all on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain).
+//
+//   rowmlp_fwd<STAGE>   64 points of one cloud per block; the chain of shared layers runs tile-resident:
+//                       layer output (accumulator layout: column on the lane) -> LDS -> next layer's A operand.
+//        STAGE 0 (STN3d)   x -> relu(s1) -> relu(s2)                                 feature_models.py:168-171
+//        STAGE 1 (encoder) x @ T3 -> relu(e1) -> relu(t1) -> relu(t2)                :119-128, :210-213
+//        STAGE 2 (encoder) h1 @ T64 -> relu(e2)                                      :131-137
+//   rowmlp_bwd<STAGE>   the same tiles backwards (input gradient only; weights are constants of the attack):
+//                       ReLU masks from the saved activations, per-cloud transform gradients as per-tile
+//                       partials (summed in tile order by sum_partials -> deterministic).
+//   fc_layer            out[B,NOUT] = act(in[B,K] @ Wt[K,NOUT] + bias), 32 clouds per MFMA row block, K split
+//                       over the waves of a block, partial tiles added in wave order.  With `mask` the input is
+//                       gated by (mask > 0): the same kernel is the backward of a ReLU'd FC layer.
+//
+// Weights: Wt = [Cin][Cout] (forward operand), Wr = [Cout][Cin] (backward operand); both are kept by the caller.
+#include "common.hpp"
+#include "hitadv.h"
+
+namespace hitadv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int PM_TM = 64;    // points per block tile
+constexpr int PM_L64 = 68;   // LDS row stride of a 64-wide tile (conflict-free ds_read_b128)
+constexpr int PM_L128 = 132;
+
+// K index consumed by MFMA step t on lane half h: four consecutive steps of a lane are one float4 of A.
+__device__ __forceinline__ int kmap(int t, int h) { return 8 * (t >> 2) + 4 * h + (t & 3); }
+
+__device__ __forceinline__ void zero(f32x16 &a) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) a[e] = 0.f;
+}
+
+// acc[rb] += A[row_base + 32*rb .. +32)[0..K) @ Bm[0..K)[col .. col+32)
+//   A: LDS tile, row stride lda floats.   Bm element (k, c):  TRANSB ? W[c*ldw + k] : W[k*ldw + c].
+template <int K, int NRB, bool TRANSB>
+__device__ __forceinline__ void mfma_rows(const float *sA, int lda, int row_base, const float *__restrict__ W, int ldw,
+                                          int col, f32x16 (&acc)[NRB], int r, int h) {
+  float w[K / 2];
+#pragma unroll
+  for (int t = 0; t < K / 2; ++t)
+    w[t] = TRANSB ? W[(size_t)(col + r) * ldw + kmap(t, h)] : W[(size_t)kmap(t, h) * ldw + col + r];
+#pragma unroll
+  for (int j = 0; j < K / 8; ++j) {
+    float av[NRB][4];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const float4 a = *reinterpret_cast<const float4 *>(sA + (row_base + 32 * rb + r) * lda + 8 * j + 4 * h);
+      av[rb][0] = a.x; av[rb][1] = a.y; av[rb][2] = a.z; av[rb][3] = a.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb][i], w[4 * j + i], acc[rb], 0, 0, 0);
+  }
+}
+
+// accumulator element e of a 32x32 tile sits at row (e&3) + 8*(e>>2) + 4*h, column r
+__device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+// Coalesced float4 copy of a [rows x W] tile of a points-major matrix into LDS (rows past `rows` -> 0);
+// with MASK the value is gated by (gate > 0) -- the ReLU backward on load.
+template <int W, bool MASK>
+__device__ __forceinline__ void load_tile(const float *__restrict__ src, const float *__restrict__ gate, int rows,
+                                          float *dst, int ld) {
+#pragma unroll
+  for (int u = 0; u < PM_TM * W / 4 / 256; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    const int n = e / (W / 4), c4 = e % (W / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < rows) {
+      v = *reinterpret_cast<const float4 *>(src + (size_t)n * W + 4 * c4);
+      if (MASK) {
+        const float4 g = *reinterpret_cast<const float4 *>(gate + (size_t)n * W + 4 * c4);
+        v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
+        v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+      }
+    }
+    *reinterpret_cast<float4 *>(dst + n * ld + 4 * c4) = v;
+  }
+}
+
+struct RowMlpFwd {
+  const float *x;    // [B,3,N]      (stage 0, 1)
+  const float *T;    // [B,9] (stage 1) / [B,64,64] (stage 2)
+  const float *hin;  // [B*N,64]     (stage 2: h1)
+  const float *W0, *b0;  // 3->64   Wt [3,64]     (stage 0: s1, stage 1: e1)
+  const float *W1, *b1;  // 64->64  Wt [64,64]    (stage 1: t1)
+  const float *W2, *b2;  // 64->128 Wt [64,128]   (s2 / t2 / e2)
+  float *xp;         // [B*N,3]   transformed points         (stage 1)
+  float *o0;         // [B*N,64]  a1 (stage 0) / h1 (stage 1) / h1 @ T64 (stage 2)
+  float *o1;         // [B*N,64]  relu(t1)                   (stage 1)
+  float *o2;         // [B*N,128] relu(last layer)
+  int N;
+};
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
+  __shared__ float4 sA4[PM_TM * PM_L64 / 4], sB4[PM_TM * PM_L64 / 4];
+  __shared__ float sX[PM_TM * 3], sXp[PM_TM * 3];
+  float *sA = reinterpret_cast<float *>(sA4), *sB = reinterpret_cast<float *>(sB4);
+  const int b = blockIdx.y, n0 = blockIdx.x * PM_TM, N = a.N;
+  const int rows = min(PM_TM, N - n0);
+  const size_t row0 = (size_t)b * N + n0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  if (STAGE < 2) {
+    if (threadIdx.x < 192) {
+      const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+      sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
+    }
+    __syncthreads();
+    const float *xin = sX;
+    if (STAGE == 1) {  // x' = x @ T3   (torch.bmm(x, trans), :124)
+      if (threadIdx.x < 192) {
+        const int n = threadIdx.x / 3, j = threadIdx.x % 3;
+        const float *T = a.T + (size_t)b * 9;
+        const float v = fmaf(sX[n * 3 + 2], T[6 + j], fmaf(sX[n * 3 + 1], T[3 + j], sX[n * 3] * T[j]));
+        sXp[threadIdx.x] = v;
+        if (a.xp != nullptr && n < rows) a.xp[row0 * 3 + threadIdx.x] = v;
+      }
+      __syncthreads();
+      xin = sXp;
+    }
+    {  // 3 -> 64, ReLU: one column per lane, 16 rows per thread
+      const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+      const float w0 = a.W0[c], w1 = a.W0[64 + c], w2 = a.W0[128 + c], bb = a.b0[c];
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int n = q * 16 + i;
+        float v = fmaf(xin[n * 3 + 2], w2, fmaf(xin[n * 3 + 1], w1, fmaf(xin[n * 3], w0, bb)));
+        v = v > 0.f ? v : 0.f;
+        sA[n * PM_L64 + c] = v;
+        if (n < rows) a.o0[(row0 + n) * 64 + c] = v;
+      }
+    }
+    __syncthreads();
+  } else {  // h1' = h1 @ T64   (torch.bmm(x, trans_feat), :131)
+    load_tile<64, false>(a.hin + row0 * 64, nullptr, rows, sB, PM_L64);
+    __syncthreads();
+    const int rb = wave & 1, cb = wave >> 1;
+    f32x16 acc[1];
+    zero(acc[0]);
+    mfma_rows<64, 1, false>(sB, PM_L64, 32 * rb, a.T + (size_t)b * 4096, 64, 32 * cb, acc, r, h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
+      sA[n * PM_L64 + c] = acc[0][e];
+      if (a.o0 != nullptr && n < rows) a.o0[(row0 + n) * 64 + c] = acc[0][e];
+    }
+    __syncthreads();
+  }
+
+  const float *sIn = sA;
+  if (STAGE == 1) {  // t1: 64 -> 64, ReLU
+    const int rb = wave & 1, cb = wave >> 1;
+    f32x16 acc[1];
+    zero(acc[0]);
+    mfma_rows<64, 1, false>(sA, PM_L64, 32 * rb, a.W1, 64, 32 * cb, acc, r, h);
+    const float bb = a.b1[32 * cb + r];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
+      float v = acc[0][e] + bb;
+      v = v > 0.f ? v : 0.f;
+      sB[n * PM_L64 + c] = v;
+      if (n < rows) a.o1[(row0 + n) * 64 + c] = v;
+    }
+    __syncthreads();
+    sIn = sB;
+  }
+  {  // 64 -> 128, ReLU: wave w owns columns 32w..32w+31 for all 64 rows
+    f32x16 acc[2];
+    zero(acc[0]);
+    zero(acc[1]);
+    mfma_rows<64, 2, false>(sIn, PM_L64, 0, a.W2, 128, 32 * wave, acc, r, h);
+    const int c = 32 * wave + r;
+    const float bb = a.b2[c];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = 32 * rb + acc_row(e, h);
+        float v = acc[rb][e] + bb;
+        v = v > 0.f ? v : 0.f;
+        if (n < rows) a.o2[(row0 + n) * 128 + c] = v;
+      }
+  }
+}
+
+struct RowMlpBwd {
+  const float *dA2;   // [B*N,128] gradient at the output of the 64->128 layer (post-ReLU), from linear_max_bwd
+  const float *A2;    // [B*N,128] saved relu(64->128) output (mask)
+  const float *W2r;   // [128,64]
+  const float *A1;    // [B*N,64]  stage 0: a1s, stage 1: relu(t1) (mask)
+  const float *W1r;   // [64,64]   stage 1: t1
+  const float *H1;    // [B*N,64]  stage 1: mask of e1's ReLU; stage 2: left operand of dT64
+  const float *dH1in; // [B*N,64]  stage 1: gradient arriving at h1 from stage 2
+  const float *W0r;   // [64,3]    stage 0: s1, stage 1: e1
+  const float *T;     // stage 1: [B,9], stage 2: [B,64,64]
+  const float *x;     // [B,3,N]   stage 1 (left operand of dT3)
+  const float *dPin;  // [B,3,N]   stage 0: gradient arriving at the points from stage 1
+  float *dTpart;      // stage 1: [B,tiles,9]; stage 2: [B,tiles,64,64]
+  float *out;         // stage 0: dX [B,3,N]; stage 1: dPts [B,3,N]; stage 2: dH1 [B*N,64]
+  int N;
+};
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
+  __shared__ float4 sD4[PM_TM * PM_L128 / 4], sE4[PM_TM * PM_L64 / 4], sF4[PM_TM * PM_L64 / 4];
+  __shared__ float sX[PM_TM * 3], sG[PM_TM * 3];
+  float *sD = reinterpret_cast<float *>(sD4), *sE = reinterpret_cast<float *>(sE4), *sF = reinterpret_cast<float *>(sF4);
+  const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, n0 = tile * PM_TM, N = a.N;
+  const int rows = min(PM_TM, N - n0);
+  const size_t row0 = (size_t)b * N + n0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int rb = wave & 1, cb = wave >> 1;
+
+  load_tile<128, true>(a.dA2 + row0 * 128, a.A2 + row0 * 128, rows, sD, PM_L128);  // ReLU of the 64->128 layer
+  if (STAGE == 2) load_tile<64, false>(a.H1 + row0 * 64, nullptr, rows, sF, PM_L64);
+  if (STAGE == 1 && threadIdx.x < 192) {
+    const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+    sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
+  }
+  __syncthreads();
+  {  // through the 64->128 layer: [64,128] @ W2r[128,64]
+    f32x16 acc[1];
+    zero(acc[0]);
+    mfma_rows<128, 1, false>(sD, PM_L128, 32 * rb, a.W2r, 64, 32 * cb, acc, r, h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
+      float v = acc[0][e];
+      if (STAGE != 2) v = (n < rows && a.A1[(row0 + n) * 64 + c] > 0.f) ? v : 0.f;
+      sE[n * PM_L64 + c] = v;
+    }
+  }
+  __syncthreads();
+
+  if (STAGE == 2) {
+    // (a) dT64 partial of this tile:  sum_n h1[n,i] * d[n,j]   (A = h1^T, B = d, K = 64 points)
+    {
+      f32x16 acc;
+      zero(acc);
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        const int n = 2 * t + h;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sF[n * PM_L64 + 32 * rb + r], sE[n * PM_L64 + 32 * cb + r], acc, 0, 0, 0);
+      }
+      float *o = a.dTpart + ((size_t)b * ntiles + tile) * 4096;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[(32 * rb + acc_row(e, h)) * 64 + 32 * cb + r] = acc[e];
+    }
+    // (b) dH1 = d @ T64^T
+    {
+      f32x16 acc[1];
+      zero(acc[0]);
+      mfma_rows<64, 1, true>(sE, PM_L64, 32 * rb, a.T + (size_t)b * 4096, 64, 32 * cb, acc, r, h);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = 32 * rb + acc_row(e, h);
+        if (n < rows) a.out[(row0 + n) * 64 + 32 * cb + r] = acc[0][e];
+      }
+    }
+    return;
+  }
+
+  const float *sIn = sE;
+  if (STAGE == 1) {  // through t1, add the gradient arriving at h1 from the encoder, through e1's ReLU
+    f32x16 acc[1];
+    zero(acc[0]);
+    mfma_rows<64, 1, false>(sE, PM_L64, 32 * rb, a.W1r, 64, 32 * cb, acc, r, h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
+      float v = 0.f;
+      if (n < rows) {
+        const size_t o = (row0 + n) * 64 + c;
+        v = a.H1[o] > 0.f ? acc[0][e] + a.dH1in[o] : 0.f;
+      }
+      sF[n * PM_L64 + c] = v;
+    }
+    __syncthreads();
+    sIn = sF;
+  }
+  if (threadIdx.x < 192) {  // 64 -> 3 backwards:  g[n,c] = sum_k d[n,k] * W0r[k,c]
+    const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+    float v = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const float4 d = *reinterpret_cast<const float4 *>(sIn + n * PM_L64 + 4 * k4);
+      v = fmaf(d.x, a.W0r[(4 * k4) * 3 + c], v);
+      v = fmaf(d.y, a.W0r[(4 * k4 + 1) * 3 + c], v);
+      v = fmaf(d.z, a.W0r[(4 * k4 + 2) * 3 + c], v);
+      v = fmaf(d.w, a.W0r[(4 * k4 + 3) * 3 + c], v);
+    }
+    if (STAGE == 0) {
+      if (n < rows) {
+        const size_t o = ((size_t)b * 3 + c) * N + n0 + n;
+        a.out[o] = v + a.dPin[o];
+      }
+    } else {
+      sG[n * 3 + c] = v;
+    }
+  }
+  if (STAGE == 1) {
+    __syncthreads();
+    const float *T = a.T + (size_t)b * 9;
+    if (threadIdx.x < 192) {  // dPts[n,i] = sum_j g[n,j] * T3[i,j]
+      const int i = threadIdx.x >> 6, n = threadIdx.x & 63;
+      if (n < rows)
+        a.out[((size_t)b * 3 + i) * N + n0 + n] =
+            fmaf(sG[n * 3 + 2], T[i * 3 + 2], fmaf(sG[n * 3 + 1], T[i * 3 + 1], sG[n * 3] * T[i * 3]));
+    } else if (threadIdx.x < 192 + 9) {  // dT3 partial[i,j] = sum_n x[n,i] * g[n,j], ascending n
+      const int q = threadIdx.x - 192, i = q / 3, j = q % 3;
+      float v = 0.f;
+      for (int n = 0; n < PM_TM; ++n) v = fmaf(sX[n * 3 + i], sG[n * 3 + j], v);
+      a.dTpart[((size_t)b * ntiles + tile) * 9 + q] = v;
+    }
+  }
+}
+
+// out[b,m] = sum_t part[b,t,m] (+ extra[b,m]), ascending t.
+__global__ __launch_bounds__(256) void sum_partials_k(const float *__restrict__ part, const float *__restrict__ extra,
+                                                      int T, int M, float *__restrict__ out, long long total) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const long long b = e / M;
+  const int m = (int)(e % M);
+  const float *p = part + (size_t)b * T * M + m;
+  float v = extra ? extra[e] : 0.f;
+  for (int t = 0; t < T; ++t) v += p[(size_t)t * M];
+  out[e] = v;
+}
+
+// One 32(clouds) x 32(columns) output tile per block; the block's NW waves split K, partial tiles are added in
+// wave order.  in[B,K] (gated by mask > 0 when mask != nullptr), Wt[K,NOUT].
+__global__ __launch_bounds__(1024) void fc_layer_k(const float *__restrict__ in, const float *__restrict__ mask,
+                                                   const float *__restrict__ Wt, const float *__restrict__ bias, int B,
+                                                   int K, int NOUT, int relu, float *__restrict__ out) {
+  extern __shared__ float part[];  // NW x 1024
+  const int NW = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int col = blockIdx.x * 32 + r, row = blockIdx.y * 32 + r;
+  const int kper = ((K + NW - 1) / NW + 7) & ~7;  // K slice per wave, multiple of 8
+  const int k0 = wave * kper, k1 = min(K, k0 + kper);
+  const bool rok = row < B, cok = col < NOUT;
+  f32x16 acc;
+  zero(acc);
+  for (int kb = k0; kb < k1; kb += 32) {  // 16 MFMA steps per trip, loads first
+    float av[16], wv[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = kb + kmap(t, h);
+      const bool kok = k < k1;
+      float v = (kok && rok) ? in[(size_t)row * K + k] : 0.f;
+      if (mask != nullptr && kok && rok) v = mask[(size_t)row * K + k] > 0.f ? v : 0.f;
+      av[t] = v;
+      wv[t] = (kok && cok) ? Wt[(size_t)k * NOUT + col] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wv[t], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) part[(wave * 16 + e) * 64 + lane] = acc[e];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 1024; o += blockDim.x) {
+    const int e = o >> 6, l = o & 63;
+    const int orow = blockIdx.y * 32 + acc_row(e, l >> 5), ocol = blockIdx.x * 32 + (l & 31);
+    if (orow < B && ocol < NOUT) {
+      float v = bias ? bias[ocol] : 0.f;
+      for (int w = 0; w < NW; ++w) v += part[(w * 16 + e) * 64 + l];
+      if (relu) v = v > 0.f ? v : 0.f;
+      out[(size_t)orow * NOUT + ocol] = v;
+    }
+  }
+}
+
+}  // namespace hitadv
+
+using namespace hitadv;
+
+extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const float *hin, const float *W0,
+                                          const float *b0, const float *W1, const float *b1, const float *W2,
+                                          const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N,
+                                          void *stream) {
+  if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || !W2 || !b2 || !o2) return HITADV_E_ARG;
+  if (stage < 2 && (!x || !W0 || !b0 || !o0)) return HITADV_E_ARG;
+  if (stage == 1 && (!T || !W1 || !b1 || !o1)) return HITADV_E_ARG;
+  if (stage == 2 && (!T || !hin)) return HITADV_E_ARG;
+  RowMlpFwd a{x, T, hin, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N};
+  dim3 grid((N + PM_TM - 1) / PM_TM, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (stage == 0) rowmlp_fwd_k<0><<<grid, 256, 0, s>>>(a);
+  else if (stage == 1) rowmlp_fwd_k<1><<<grid, 256, 0, s>>>(a);
+  else rowmlp_fwd_k<2><<<grid, 256, 0, s>>>(a);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t hitadv_pointnet_rowmlp_tiles(int N) { return N > 0 ? (N + PM_TM - 1) / PM_TM : 0; }
+
+extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dA2, const float *A2, const float *W2r,
+                                          const float *A1, const float *W1r, const float *H1, const float *dH1in,
+                                          const float *W0r, const float *T, const float *x, const float *dPin,
+                                          float *dTpart, float *out, int B, int N, void *stream) {
+  if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || !dA2 || !A2 || !W2r || !out) return HITADV_E_ARG;
+  if (stage == 0 && (!A1 || !W0r || !dPin)) return HITADV_E_ARG;
+  if (stage == 1 && (!A1 || !W1r || !H1 || !dH1in || !W0r || !T || !x || !dTpart)) return HITADV_E_ARG;
+  if (stage == 2 && (!H1 || !T || !dTpart)) return HITADV_E_ARG;
+  RowMlpBwd a{dA2, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out, N};
+  dim3 grid((N + PM_TM - 1) / PM_TM, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (stage == 0) rowmlp_bwd_k<0><<<grid, 256, 0, s>>>(a);
+  else if (stage == 1) rowmlp_bwd_k<1><<<grid, 256, 0, s>>>(a);
+  else rowmlp_bwd_k<2><<<grid, 256, 0, s>>>(a);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out,
+                                   void *stream) {
+  if (!part || !out || B <= 0 || T <= 0 || M <= 0) return HITADV_E_ARG;
+  const long long total = (long long)B * M;
+  sum_partials_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(part, extra, T, M, out, total);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_fc_layer(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K,
+                               int NOUT, int relu, float *out, void *stream) {
+  if (!in || !Wt || !out || B <= 0 || K <= 0 || NOUT <= 0) return HITADV_E_ARG;
+  int nw = (K + 63) / 64;  // 64 K-values (32 MFMA steps) per wave
+  nw = nw < 1 ? 1 : (nw > 16 ? 16 : nw);
+  dim3 grid((NOUT + 31) / 32, (B + 31) / 32);
+  fc_layer_k<<<grid, 64 * nw, (size_t)nw * 1024 * sizeof(float), (hipStream_t)stream>>>(in, mask, Wt, bias, B, K, NOUT,
+                                                                                         relu, out);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}

@@ -178,6 +178,82 @@ class _LinearReLU(torch.autograd.Function):
         return torch.mm(torch.ops.aten.threshold_backward(g, y, 0), W), None, None, None
 
 
+class _PointNetHip(torch.autograd.Function):
+    """logits, trans_feat = f(x) and d/dx of it, entirely on libhitadv_hip (f32 MFMA kernels, csrc/pointnet.hip +
+    the fused 128->1024 layers of csrc/victim.hip): 21 launches forward, 20 backward, no rocBLAS/MIOpen.
+    Weights are constants (no weight gradients: the attack never uses them)."""
+
+    @staticmethod
+    def forward(ctx, x, v):
+        from .. import ops
+        B, _, N = x.shape
+        R = B * N
+        E = lambda *s: torch.empty(*s, device=x.device)  # noqa: E731
+        # STN3d
+        a1s, a2s = E(R, 64), E(R, 128)
+        ops.pointnet_rowmlp_fwd(0, B, N, v.s2_w, v.s2_b, a2s, x=x, W0=v.s1_w, b0=v.s1_b, o0=a1s)
+        gs, js = ops.linear_max_fwd(a2s, v.s3_w, B, N, bias=v.s3_b, relu=True)
+        f4s = ops.fc_layer(gs, v.s4_w, v.s4_b, relu=True)
+        f5s = ops.fc_layer(f4s, v.s5_w, v.s5_b, relu=True)
+        T3 = ops.fc_layer(f5s, v.s6_w, v.s6_b)
+        # input transform, first encoder layer, STNkd
+        h1, a1t, a2t = E(R, 64), E(R, 64), E(R, 128)
+        ops.pointnet_rowmlp_fwd(1, B, N, v.t2_w, v.t2_b, a2t, x=x, T=T3, W0=v.e1_w, b0=v.e1_b, W1=v.t1_w, b1=v.t1_b,
+                                o0=h1, o1=a1t)
+        gt, jt = ops.linear_max_fwd(a2t, v.t3_w, B, N, bias=v.t3_b, relu=True)
+        f4t = ops.fc_layer(gt, v.t4_w, v.t4_b, relu=True)
+        f5t = ops.fc_layer(f4t, v.t5_w, v.t5_b, relu=True)
+        T64 = ops.fc_layer(f5t, v.t6_w, v.t6_b)
+        # feature transform, encoder tail, classifier head
+        a2e = E(R, 128)
+        ops.pointnet_rowmlp_fwd(2, B, N, v.e2_w, v.e2_b, a2e, T=T64, hin=h1)
+        g, je = ops.linear_max_fwd(a2e, v.e3_w, B, N, bias=v.e3_b, relu=False)
+        f1 = ops.fc_layer(g, v.h1_w, v.h1_b, relu=True)
+        f2 = ops.fc_layer(f1, v.h2_w, v.h2_b, relu=True)
+        logits = ops.fc_layer(f2, v.h3_w, v.h3_b)
+        ctx.save_for_backward(x, a1s, a2s, gs, js, f4s, f5s, T3, h1, a1t, a2t, gt, jt, f4t, f5t, T64, a2e, je, f1, f2)
+        ctx.view = v
+        ctx.set_materialize_grads(False)
+        return logits, T64.view(B, 64, 64)
+
+    @staticmethod
+    def backward(ctx, dlogits, dT64_ext):
+        from .. import ops
+        x, a1s, a2s, gs, js, f4s, f5s, T3, h1, a1t, a2t, gt, jt, f4t, f5t, T64, a2e, je, f1, f2 = ctx.saved_tensors
+        v = ctx.view
+        B, _, N = x.shape
+        R = B * N
+        E = lambda *s: torch.empty(*s, device=x.device)  # noqa: E731
+        tiles = ops.pointnet_rowmlp_tiles(N)
+        if dlogits is None:
+            dlogits = torch.zeros(B, v.h3_w.shape[1], device=x.device)
+        # head and encoder tail
+        d = ops.fc_layer(dlogits.contiguous(), v.h3_wr)
+        d = ops.fc_layer(d, v.h2_wr, mask=f2)
+        dg = ops.fc_layer(d, v.h1_wr, mask=f1)
+        dA2 = ops.linear_max_bwd(dg, v.e3_wr, je, N)
+        dTp, dH1 = E(B, tiles, 4096), E(R, 64)
+        ops.pointnet_rowmlp_bwd(2, B, N, dA2, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp)
+        dT64 = ops.sum_partials(dTp, None if dT64_ext is None else dT64_ext.reshape(B, 4096).contiguous())
+        # STNkd, first encoder layer, input transform
+        d = ops.fc_layer(dT64, v.t6_wr)
+        d = ops.fc_layer(d, v.t5_wr, mask=f5t)
+        dgt = ops.fc_layer(d, v.t4_wr, mask=f4t)
+        dA2 = ops.linear_max_bwd(dgt, v.t3_wr, jt, N, gt)
+        dTp, dPts = E(B, tiles, 9), E(B, 3, N)
+        ops.pointnet_rowmlp_bwd(1, B, N, dA2, a2t, v.t2_wr, dPts, A1=a1t, W1r=v.t1_wr, H1=h1, dH1in=dH1, W0r=v.e1_wr,
+                                T=T3, x=x, dTpart=dTp)
+        dT3 = ops.sum_partials(dTp)
+        # STN3d
+        d = ops.fc_layer(dT3, v.s6_wr)
+        d = ops.fc_layer(d, v.s5_wr, mask=f5s)
+        dgs = ops.fc_layer(d, v.s4_wr, mask=f4s)
+        dA2 = ops.linear_max_bwd(dgs, v.s3_wr, js, N, gs)
+        dX = E(B, 3, N)
+        ops.pointnet_rowmlp_bwd(0, B, N, dA2, a2s, v.s2_wr, dX, A1=a1s, W0r=v.s1_wr, dPin=dPts)
+        return dX, None
+
+
 class FoldedPointNet(nn.Module):
     """Inference-mode restatement of ``PointNetFeatureModel`` for the attack loop (still plain
     PyTorch-ROCm ops: rocBLAS/hipBLASLt GEMMs + elementwise).  Algebraically identical to the module
@@ -258,9 +334,13 @@ class FoldedPointNet(nn.Module):
         g = self._lin_max(self._lin(self._lin(x, p + '1'), p + '2'), p + '3', B, N, True)
         return self._lin(self._lin(self._lin(g, p + '4'), p + '5'), p + '6', relu=False)
 
+    hip_engine = True  # CUDA tensors: run on libhitadv_hip's own kernels (_PointNetHip); False = PyTorch-ROCm ops
+
     def forward(self, x):
         """x [B,3,N] -> (logits [B,k], trans_feat [B,64,64])"""
         B, _, N = x.shape
+        if x.is_cuda and self.hip_engine and x.dtype == torch.float32:
+            return _PointNetHip.apply(x.contiguous(), self)
         pts = x.transpose(1, 2)  # [B,N,3] view
         trans = self._tnet(pts.reshape(B * N, 3), B, N, 's').view(B, 3, 3)
         h = self._lin(torch.bmm(pts, trans).reshape(B * N, 3), 'e1')  # [B*N,64]

@@ -270,6 +270,39 @@ def linear_max_fwd_supported(Cin, Cout):
     return Cin in (64, 128) and Cout % 64 == 0
 
 
+def fc_layer(x, Wt, bias=None, relu=False, mask=None):
+    """act((x gated by mask > 0) @ Wt + bias): x [B,K], Wt [K,NOUT] -> [B,NOUT] (f32 MFMA, K split over the waves of a block)."""
+    B, K = x.shape
+    NOUT = Wt.shape[1]
+    out = torch.empty(B, NOUT, device=x.device)
+    _lib.call("hitadv_fc_layer", _p(x), _p(mask), _p(Wt), _p(bias), B, K, NOUT, 1 if relu else 0, _p(out), _stream())
+    return out
+
+
+def sum_partials(part, extra=None):
+    """part [B,T,M] (+ extra [B,M]) -> [B,M], summed in ascending T."""
+    B, T, M = part.shape
+    out = torch.empty(B, M, device=part.device)
+    _lib.call("hitadv_sum_partials", _p(part), _p(extra), B, T, M, _p(out), _stream())
+    return out
+
+
+def pointnet_rowmlp_fwd(stage, B, N, W2, b2, o2, x=None, T=None, hin=None, W0=None, b0=None, W1=None, b1=None,
+                        xp=None, o0=None, o1=None):
+    _lib.call("hitadv_pointnet_rowmlp_fwd", stage, _p(x), _p(T), _p(hin), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2),
+              _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, _stream())
+
+
+def pointnet_rowmlp_bwd(stage, B, N, dA2, A2, W2r, out, A1=None, W1r=None, H1=None, dH1in=None, W0r=None, T=None,
+                        x=None, dPin=None, dTpart=None):
+    _lib.call("hitadv_pointnet_rowmlp_bwd", stage, _p(dA2), _p(A2), _p(W2r), _p(A1), _p(W1r), _p(H1), _p(dH1in),
+              _p(W0r), _p(T), _p(x), _p(dPin), _p(dTpart), _p(out), B, N, _stream())
+
+
+def pointnet_rowmlp_tiles(N):
+    return int(_lib.load().hitadv_pointnet_rowmlp_tiles(N))
+
+
 def topk_rows(P, K, largest=True):
     """Row-wise top-K of a matrix [..., M] -> (vals[..., K], idx[..., K] int64), sorted, ties -> lower column."""
     P = _dev(P.detach(), "P")

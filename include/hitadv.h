@@ -225,6 +225,44 @@ int hitadv_linear_max_fwd(const float *X, const float *Wt, const float *bias, in
                           int relu, float *part_val, int32_t *part_idx, float *out, int64_t *idx, void *stream);
 int64_t hitadv_linear_max_fwd_scratch(int B, int N, int Cout);
 
+/* ------------------------------------------------------------------ PointNet victim, attack-time view
+ * The eval.py victim (model/feature_models.py:71-230: PointNetFeatureModel = PointNetEncoder + STN3d + STNkd) in
+ * eval mode with every BatchNorm folded into the layer in front of it, as four building blocks that together
+ * with hitadv_linear_max_fwd / hitadv_linear_max_bwd give logits = f(x) and d logits / d x without any
+ * rocBLAS / MIOpen call.  Activations are points-major [B*N,C]; x and its gradient are [B,3,N] as the attack
+ * holds them.  Wt = [Cin,Cout] (forward operand), Wr = [Cout,Cin] (backward operand).  All f32 MFMA.
+ *
+ * hitadv_pointnet_rowmlp_fwd: the shared per-point layers in front of a 128->1024 layer, 64 points per block.
+ *   stage 0 (STN3d, :168-171)       x -> o0 = relu(x W0 + b0) [.,64] -> o2 = relu(o0 W2 + b2) [.,128]
+ *   stage 1 (encoder + STNkd, :119-128, :210-213)
+ *                                   xp = x @ T[b] (T [B,3,3]) -> o0 = relu(xp W0 + b0) -> o1 = relu(o0 W1 + b1) [.,64]
+ *                                   -> o2 = relu(o1 W2 + b2)
+ *   stage 2 (encoder, :129-137)     o0 = hin @ T[b] (T [B,64,64]) -> o2 = relu(o0 W2 + b2)
+ * Unused pointers of a stage may be NULL; so may xp (stage 1) and o0 (stage 2) when the caller does not need them. */
+int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const float *hin, const float *W0,
+                               const float *b0, const float *W1, const float *b1, const float *W2, const float *b2,
+                               float *xp, float *o0, float *o1, float *o2, int B, int N, void *stream);
+/* Number of 64-point tiles per cloud = leading dimension of the dTpart scratch below. */
+int64_t hitadv_pointnet_rowmlp_tiles(int N);
+/* Input-gradient chain of the same stages.  dA2 [B*N,128] is the gradient at the (post-ReLU) output of the 64->128
+ * layer (from hitadv_linear_max_bwd); A2 / A1 / H1 are the activations saved by the forward (ReLU masks).
+ *   stage 2: out = dH1 [B*N,64] = (dA2 . [A2>0]) W2r @ T^T;  dTpart [B,tiles,64,64] = per-tile  h1^T @ (.)
+ *   stage 1: through t2, t1, + dH1in, e1's ReLU, e1 -> g [.,3];  out = dPts [B,3,N] = g @ T^T;
+ *            dTpart [B,tiles,9] = per-tile x^T @ g
+ *   stage 0: through s2, s1 -> [.,3], + dPin;  out = dX [B,3,N]
+ * The per-tile partials are summed in tile order by hitadv_sum_partials (deterministic). */
+int hitadv_pointnet_rowmlp_bwd(int stage, const float *dA2, const float *A2, const float *W2r, const float *A1,
+                               const float *W1r, const float *H1, const float *dH1in, const float *W0r,
+                               const float *T, const float *x, const float *dPin, float *dTpart, float *out, int B,
+                               int N, void *stream);
+/* out[b,m] = (extra ? extra[b,m] : 0) + sum_t part[b,t,m], ascending t. */
+int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out, void *stream);
+/* out[B,NOUT] = act(in'[B,K] @ Wt[K,NOUT] + bias), in' = in gated by (mask > 0) when mask != NULL (the backward of a
+ * ReLU'd layer: in = dOut, mask = the saved output, Wt = that layer's Wr).  bias may be NULL.  The fc1/fc2/fc3
+ * stacks of :176-186 (STN3d), :218-228 (STNkd) and :88-91 (classifier head). */
+int hitadv_fc_layer(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K, int NOUT,
+                    int relu, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

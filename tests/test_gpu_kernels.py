@@ -531,6 +531,72 @@ def test_linear_max_fwd_ties_and_errors(A):
         A.linear_max_fwd(cu(torch.randn(64, 128)), cu(torch.randn(128, 100)), 1, 64)
 
 
+@pytest.mark.parametrize("B,K,NOUT", [(32, 1024, 512), (32, 512, 256), (32, 256, 9), (4, 256, 4096), (33, 256, 40),
+                                      (5, 9, 256), (32, 4096, 256), (7, 40, 256), (1, 70, 33)])
+def test_fc_layer_mfma(A, B, K, NOUT):
+    g = torch.Generator().manual_seed(K + NOUT)
+    x = torch.randn(B, K, generator=g)
+    Wt = torch.randn(K, NOUT, generator=g) / K ** 0.5
+    bias = torch.randn(NOUT, generator=g)
+    mask = torch.randn(B, K, generator=g)
+    ref = x.double() @ Wt.double()
+    close(A.fc_layer(cu(x), cu(Wt)), ref.float(), rtol=1e-5, atol=1e-5)
+    close(A.fc_layer(cu(x), cu(Wt), cu(bias), relu=True), (ref + bias.double()).clamp_min(0.).float(), rtol=1e-5, atol=1e-5)
+    refm = (x.double() * (mask > 0)) @ Wt.double()
+    got = A.fc_layer(cu(x), cu(Wt), mask=cu(mask))
+    close(got, refm.float(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(got, A.fc_layer(cu(x), cu(Wt), mask=cu(mask)))
+    part = torch.randn(B, 5, NOUT, generator=g)
+    close(A.sum_partials(cu(part)), part.sum(1), rtol=1e-6, atol=1e-6)
+    close(A.sum_partials(cu(part), cu(bias.expand(B, NOUT).contiguous())), part.sum(1) + bias, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,Np", [(4, 1024), (3, 1000), (2, 77), (33, 256)])
+def test_pointnet_engine_matches_module(B, Np):
+    """The HIP PointNet engine (rowmlp / linear_max / fc_layer kernels) against the nn.Module evaluated in float64
+    on the CPU: logits, trans_feat and the input gradient -- also for a gradient arriving through trans_feat."""
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    torch.manual_seed(B + Np)
+    m = PointNetFeatureModel(40, normal_channel=False).eval()
+    with torch.no_grad():  # non-trivial BatchNorm statistics so that the folding is exercised
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.1)
+    data, _ = synth_batch(B, Np, first=40)
+    x = data[:, :, :3].transpose(1, 2).contiguous()
+    g = torch.Generator().manual_seed(1)
+    wl, wt = torch.randn(B, 40, generator=g), torch.randn(B, 64, 64, generator=g) * 0.05
+    md = PointNetFeatureModel(40, normal_channel=False).double().eval()
+    md.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    xd = x.double().requires_grad_()
+    ld, td = md(xd)
+    gl, = torch.autograd.grad((ld * wl.double()).sum(), xd, retain_graph=True)
+    gboth, = torch.autograd.grad((ld * wl.double()).sum() + (td * wt.double()).sum(), xd)
+    view = m.cuda().attack_view()
+    assert view.hip_engine
+    xc = cu(x).requires_grad_()
+    lh, th = view(xc)
+    close(lh, ld.float(), rtol=1e-4, atol=2e-5)
+    close(th, td.float(), rtol=1e-4, atol=2e-5)
+    gh, = torch.autograd.grad((lh * cu(wl)).sum(), xc, retain_graph=True)
+    scale = float(gl.abs().max())
+    close(gh, gl.float(), rtol=1e-3, atol=2e-5 * scale)
+    gh2, = torch.autograd.grad((lh * cu(wl)).sum() + (th * cu(wt)).sum(), xc)
+    close(gh2, gboth.float(), rtol=1e-3, atol=2e-5 * float(gboth.abs().max()))
+    # bitwise reproducible, and the same function as the PyTorch-op formulation of the view
+    l2, _ = view(xc)
+    assert torch.equal(l2, lh)
+    view.hip_engine = False
+    xt = cu(x).requires_grad_()
+    lt, tt = view(xt)
+    gt, = torch.autograd.grad((lt * cu(wl)).sum(), xt)
+    close(lh, lt, rtol=1e-4, atol=2e-5)
+    close(gh, gt, rtol=1e-3, atol=2e-5 * scale)
+
+
 def test_fused_regulariser_matches_torch_composition(A):
     """hitadv_regulariser_{fwd,bwd} vs the reference's composition of ChamferDist (on [B,3,N], quirk Q1),
     transformation_loss, curv_std_loss and the scale_const weighting, evaluated by the CPU oracle + autograd."""
