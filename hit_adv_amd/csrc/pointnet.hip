@@ -338,48 +338,139 @@ __global__ __launch_bounds__(256) void sum_partials_k(const float *__restrict__ 
   out[e] = v;
 }
 
-// One 32(clouds) x 32(columns) output tile per block; the block's NW waves split K, partial tiles are added in
-// wave order.  in[B,K] (gated by mask > 0 when mask != nullptr), Wt[K,NOUT].
-__global__ __launch_bounds__(1024) void fc_layer_k(const float *__restrict__ in, const float *__restrict__ mask,
-                                                   const float *__restrict__ Wt, const float *__restrict__ bias, int B,
-                                                   int K, int NOUT, int relu, float *__restrict__ out) {
-  extern __shared__ float part[];  // NW x 1024
-  const int NW = blockDim.x >> 6;
+// out[B,NOUT] = act(in'[B,K] @ Wt[K,NOUT] + bias) for a handful of rows (one per cloud): weight-read bound, so
+// the work is spread as wide as the weights allow: block = one 32(clouds) x 32(columns) output tile x one
+// 128-deep K chunk; its 4 waves take 32 K-values each (16 MFMA steps), the input chunk is staged through LDS with
+// coalesced loads (gated by mask > 0 on the way in: the ReLU backward).  K chunks of a tile meet through global
+// partials: every block publishes its partial, the LAST one to arrive (atomic ticket) adds all of them in chunk
+// order, applies bias / ReLU and writes the tile -> one launch, deterministic.  The ticket resets itself (the next
+// launch on the stream sees the reset: kernel boundaries order it).
+constexpr int FC_CH = 128;
+constexpr int FC_LD = FC_CH + 4;
+constexpr int FC_TICKETS = 16384;  // fixed-size ticket area at the head of the scratch (one per output tile)
+
+__global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, const float *__restrict__ mask,
+                                                  const float *__restrict__ Wt, const float *__restrict__ bias, int B,
+                                                  int K, int NOUT, int relu, int chunk, float *__restrict__ out,
+                                                  float *part, int *ticket) {
+  __shared__ float4 sA4[32 * FC_LD / 4];
+  __shared__ float red[4 * 1024];
+  __shared__ int s_last;
+  float *sA = reinterpret_cast<float *>(sA4);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int col = blockIdx.x * 32 + r, row = blockIdx.y * 32 + r;
-  const int kper = ((K + NW - 1) / NW + 7) & ~7;  // K slice per wave, multiple of 8
-  const int k0 = wave * kper, k1 = min(K, k0 + kper);
-  const bool rok = row < B, cok = col < NOUT;
+  const int cbk = blockIdx.x, rbk = blockIdx.y, ks = blockIdx.z, KS = gridDim.z;
+  const int tile = rbk * gridDim.x + cbk, ntile = gridDim.x * gridDim.y;
+  const int col = cbk * 32 + r, row0 = rbk * 32;
+  const int kb0 = ks * chunk, kb1 = min(K, kb0 + chunk);
+  const bool cok = col < NOUT;
   f32x16 acc;
   zero(acc);
-  for (int kb = k0; kb < k1; kb += 32) {  // 16 MFMA steps per trip, loads first
-    float av[16], wv[16];
+  for (int kc = kb0; kc < kb1; kc += FC_CH) {
+    float wv[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int k = kb + kmap(t, h);
-      const bool kok = k < k1;
-      float v = (kok && rok) ? in[(size_t)row * K + k] : 0.f;
-      if (mask != nullptr && kok && rok) v = mask[(size_t)row * K + k] > 0.f ? v : 0.f;
-      av[t] = v;
-      wv[t] = (kok && cok) ? Wt[(size_t)k * NOUT + col] : 0.f;
+    for (int t = 0; t < 16; ++t) {  // this wave's 32 rows of Wt, in flight while the input chunk is staged
+      const int k = kc + 32 * wave + kmap(t, h);
+      wv[t] = (k < kb1 && cok) ? Wt[(size_t)k * NOUT + col] : 0.f;
     }
+    if (kc != kb0) __syncthreads();
+    if ((K & 3) == 0) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wv[t], acc, 0, 0, 0);
+      for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + 256 * u, rr = e >> 5, k = kc + 4 * (e & 31);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + rr < B && k < kb1) {
+          const size_t o = (size_t)(row0 + rr) * K + k;
+          v = *reinterpret_cast<const float4 *>(in + o);
+          if (mask != nullptr) {
+            const float4 g = *reinterpret_cast<const float4 *>(mask + o);
+            v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
+            v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+          }
+        }
+        *reinterpret_cast<float4 *>(sA + rr * FC_LD + 4 * (e & 31)) = v;
+      }
+    } else {
+      for (int e = threadIdx.x; e < 32 * FC_CH; e += 256) {
+        const int rr = e >> 7, k = kc + (e & 127);
+        float v = 0.f;
+        if (row0 + rr < B && k < kb1) {
+          const size_t o = (size_t)(row0 + rr) * K + k;
+          v = in[o];
+          if (mask != nullptr) v = mask[o] > 0.f ? v : 0.f;
+        }
+        sA[rr * FC_LD + (e & 127)] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = *reinterpret_cast<const float4 *>(sA + r * FC_LD + 32 * wave + 8 * j + 4 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[4 * j], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[4 * j + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[4 * j + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[4 * j + 3], acc, 0, 0, 0);
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 16; ++e) part[(wave * 16 + e) * 64 + lane] = acc[e];
+  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[e];
   __syncthreads();
-  for (int o = threadIdx.x; o < 1024; o += blockDim.x) {
-    const int e = o >> 6, l = o & 63;
-    const int orow = blockIdx.y * 32 + acc_row(e, l >> 5), ocol = blockIdx.x * 32 + (l & 31);
+  float v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int o = threadIdx.x + 256 * u;
+    v[u] = ((red[o] + red[1024 + o]) + red[2048 + o]) + red[3072 + o];
+  }
+  if (KS > 1) {
+    // No fences (an agent-scope release costs a whole-L2 write-back per wave, ~0.1 us per block, serialised):
+    // partials and ticket are relaxed agent-scope atomics (sc1: written through to / read from the point of
+    // coherence across XCDs); the barrier's vmcnt(0) orders a block's partial stores before its ticket.
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      __hip_atomic_store(&part[((size_t)ks * ntile + tile) * 1024 + threadIdx.x + 256 * u], v[u], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores are acknowledged ...
+    __syncthreads();                                   // ... for every wave of the block, before its ticket is drawn
+    if (threadIdx.x == 0)
+      s_last = __hip_atomic_fetch_add(&ticket[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == KS - 1;
+    __syncthreads();
+    if (!s_last) return;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q0 = 0; q0 < KS; q0 += 8) {  // 32 loads in flight per thread, then added in chunk order
+      float t[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          t[u][i] = q0 + i < KS ? __hip_atomic_load(&part[((size_t)(q0 + i) * ntile + tile) * 1024 + threadIdx.x + 256 * u],
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[u] += t[u][i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = a[u];
+    if (threadIdx.x == 0) __hip_atomic_store(&ticket[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int o = threadIdx.x + 256 * u, e = o >> 6, l = o & 63;
+    const int orow = row0 + acc_row(e, l >> 5), ocol = cbk * 32 + (l & 31);
     if (orow < B && ocol < NOUT) {
-      float v = bias ? bias[ocol] : 0.f;
-      for (int w = 0; w < NW; ++w) v += part[(w * 16 + e) * 64 + l];
-      if (relu) v = v > 0.f ? v : 0.f;
-      out[(size_t)orow * NOUT + ocol] = v;
+      float y = v[u] + (bias ? bias[ocol] : 0.f);
+      if (relu) y = y > 0.f ? y : 0.f;
+      out[(size_t)orow * NOUT + ocol] = y;
     }
   }
+}
+
+static void fc_split(int B, int K, int NOUT, int *chunk, int *KS, int *tiles) {
+  int c = FC_CH * ((K + FC_CH * 32 - 1) / (FC_CH * 32));  // at most 32 K chunks per tile
+  *chunk = c;
+  *KS = (K + c - 1) / c;
+  *tiles = ((NOUT + 31) / 32) * ((B + 31) / 32);
 }
 
 }  // namespace hitadv
@@ -433,14 +524,23 @@ extern "C" int hitadv_sum_partials(const float *part, const float *extra, int B,
   return 0;
 }
 
+extern "C" int64_t hitadv_fc_layer_scratch_floats(int B, int K, int NOUT) {
+  if (B <= 0 || K <= 0 || NOUT <= 0) return 0;
+  int chunk, KS, tiles;
+  fc_split(B, K, NOUT, &chunk, &KS, &tiles);
+  return (int64_t)FC_TICKETS + (KS > 1 ? (int64_t)KS * tiles * 1024 : 0);
+}
+
 extern "C" int hitadv_fc_layer(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K,
-                               int NOUT, int relu, float *out, void *stream) {
-  if (!in || !Wt || !out || B <= 0 || K <= 0 || NOUT <= 0) return HITADV_E_ARG;
-  int nw = (K + 63) / 64;  // 64 K-values (32 MFMA steps) per wave
-  nw = nw < 1 ? 1 : (nw > 16 ? 16 : nw);
-  dim3 grid((NOUT + 31) / 32, (B + 31) / 32);
-  fc_layer_k<<<grid, 64 * nw, (size_t)nw * 1024 * sizeof(float), (hipStream_t)stream>>>(in, mask, Wt, bias, B, K, NOUT,
-                                                                                         relu, out);
+                               int NOUT, int relu, float *out, float *scratch, void *stream) {
+  if (!in || !Wt || !out || !scratch || B <= 0 || K <= 0 || NOUT <= 0) return HITADV_E_ARG;
+  if ((K & 3) == 0 && (((uintptr_t)in | (uintptr_t)mask) & 15)) return HITADV_E_ARG;
+  int chunk, KS, tiles;
+  fc_split(B, K, NOUT, &chunk, &KS, &tiles);
+  if (tiles > FC_TICKETS) return HITADV_E_ARG;
+  dim3 grid((NOUT + 31) / 32, (B + 31) / 32, KS);
+  fc_layer_k<<<grid, 256, 0, (hipStream_t)stream>>>(in, mask, Wt, bias, B, K, NOUT, relu, chunk, out, scratch + FC_TICKETS,
+                                                    reinterpret_cast<int *>(scratch));
   HITADV_LAUNCH_CHECK();
   return 0;
 }

@@ -270,12 +270,32 @@ def linear_max_fwd_supported(Cin, Cout):
     return Cin in (64, 128) and Cout % 64 == 0
 
 
+_fc_scratch = {}
+
+
+def _fc_scratch_for(x, n):
+    """Zero-initialised split-K scratch, one per (device, stream): calls on one stream are ordered, calls on
+    different streams (attack_many) must not share tickets.  Grown on demand, never shrunk."""
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    t = _fc_scratch.get(key)
+    if t is None or t.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("fc_layer scratch must exist before graph capture: run one eager pass on this stream first")
+        t = torch.zeros(max(n, 1 << 20), device=x.device)
+        _fc_scratch[key] = t
+    return t
+
+
 def fc_layer(x, Wt, bias=None, relu=False, mask=None):
-    """act((x gated by mask > 0) @ Wt + bias): x [B,K], Wt [K,NOUT] -> [B,NOUT] (f32 MFMA, K split over the waves of a block)."""
+    """act((x gated by mask > 0) @ Wt + bias): x [B,K], Wt [K,NOUT] -> [B,NOUT] (f32 MFMA, split-K over blocks,
+    the last block of a tile to arrive reduces in chunk order: one launch, deterministic)."""
+    x, Wt = _dev(x, "x"), _dev(Wt, "Wt")
     B, K = x.shape
     NOUT = Wt.shape[1]
     out = torch.empty(B, NOUT, device=x.device)
-    _lib.call("hitadv_fc_layer", _p(x), _p(mask), _p(Wt), _p(bias), B, K, NOUT, 1 if relu else 0, _p(out), _stream())
+    scratch = _fc_scratch_for(x, _lib.load().hitadv_fc_layer_scratch_floats(B, K, NOUT))
+    _lib.call("hitadv_fc_layer", _p(x), _p(mask), _p(Wt), _p(bias), B, K, NOUT, 1 if relu else 0, _p(out), _p(scratch),
+              _stream())
     return out
 
 

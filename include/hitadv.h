@@ -259,9 +259,12 @@ int hitadv_pointnet_rowmlp_bwd(int stage, const float *dA2, const float *A2, con
 int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out, void *stream);
 /* out[B,NOUT] = act(in'[B,K] @ Wt[K,NOUT] + bias), in' = in gated by (mask > 0) when mask != NULL (the backward of a
  * ReLU'd layer: in = dOut, mask = the saved output, Wt = that layer's Wr).  bias may be NULL.  The fc1/fc2/fc3
- * stacks of :176-186 (STN3d), :218-228 (STNkd) and :88-91 (classifier head). */
+ * stacks of :176-186 (STN3d), :218-228 (STNkd) and :88-91 (classifier head).
+ * scratch: hitadv_fc_layer_scratch_floats(B,K,NOUT) floats that the caller ZEROES ONCE (its first 16384 words
+ * are the split-K tickets, which every call leaves at zero again); calls that may run concurrently need their own. */
 int hitadv_fc_layer(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K, int NOUT,
-                    int relu, float *out, void *stream);
+                    int relu, float *out, float *scratch, void *stream);
+int64_t hitadv_fc_layer_scratch_floats(int B, int K, int NOUT);
 
 #ifdef __cplusplus
 }

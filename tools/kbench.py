@@ -128,6 +128,16 @@ def main():
         lib.hitadv_max_over_points(p(yb), B, N, 1024, p(bias), 1, p(pv2), p(pi2), p(mo), p(mi), s)
     us = timed(unfused, a.reps)
     out['mm+max_over_points_128x1024'] = dict(us=round(us, 2))
+    # PointNet engine building blocks
+    fcs = torch.zeros(lib.hitadv_fc_layer_scratch_floats(B, 4096, 4096) + (1 << 20), device='cuda')
+    for K, NOUT in ((1024, 512), (512, 256), (256, 9), (256, 4096), (256, 40), (40, 256), (256, 512), (512, 1024),
+                    (4096, 256), (9, 256)):
+        xin = torch.randn(B, K, generator=g).cuda()
+        wt = torch.randn(K, NOUT, generator=g).cuda()
+        bo = torch.randn(NOUT, generator=g).cuda()
+        oo = torch.empty(B, NOUT, device='cuda')
+        us = timed(lambda s=s0: lib.hitadv_fc_layer(p(xin), p(xin), p(wt), p(bo), B, K, NOUT, 1, p(oo), p(fcs), s), a.reps)
+        out['fc_layer_%dx%d' % (K, NOUT)] = dict(us=round(us, 2))
     print(json.dumps(out))
 
 
