@@ -65,6 +65,14 @@ class _Workspace:
         self.adv_loss = torch.zeros((), **f)
         self.dist_loss = torch.zeros((), **f)
         self.graph = None
+        # buffers of the autograd-free iteration (_iteration_fused)
+        self.inv_den = torch.empty(B, N, **f)
+        self.gp, self.gs = torch.empty(B, C, 3, **f), torch.empty(B, C, **f)
+        self.gp_reg, self.gs_reg = torch.empty(B, C, 3, **f), torch.empty(B, C, **f)
+        self.g_adv = torch.empty(B, 3, N, **f)
+        self.deform_part = torch.empty(ops.deform_bwd_scratch(B, N, C), **f)
+        self.reg_scratch = torch.empty(ops.regulariser_scratch(B), **f)
+        self.scaled = torch.zeros((), **f)
 
     def reset_step(self):
         for t in (self.m_p, self.v_p, self.m_s, self.v_s, self.step):
@@ -195,6 +203,8 @@ class HiT_ADV:
     # ------------------------------------------------------------------ one inner iteration
     def _iteration(self, ws):
         """Everything between two Adam steps (:156-246), host-sync free."""
+        if self.fused_regulariser and hasattr(self.adv_func, 'fused'):
+            return self._iteration_fused(ws)
         with torch.no_grad():
             ws.P.clamp_(-self.budget, self.budget)
             ws.sigma.clamp_(self.min_sigm, self.max_sigm)
@@ -229,6 +239,34 @@ class HiT_ADV:
         ws.adv_loss.copy_(adv_loss.detach())
         if dist_loss is not None:
             ws.dist_loss.copy_(dist_loss.detach())
+
+    def _iteration_fused(self, ws):
+        """The same iteration with the chain rule written out instead of recorded: autograd is used for the victim
+        only (any nn.Module), every other forward / backward is an explicit kernel call on workspace buffers, and
+        gradient sums ride inside the consuming kernels (victim + regulariser into deform_bwd's upstream; deformation +
+        regulariser into Adam).  9 launches around the victim instead of ~37.  The projection of (perturb, sigma)
+        (:157-158) is applied by the Adam kernel right after the update -- the parameters every forward pass sees
+        are the same (the initial draws already lie inside the box)."""
+        regs = (self.cd_weight, self.ker_weight, self.hide_weight)
+        rng = (self.min_sigm, self.max_sigm)
+        P, sigma = ws.P.detach(), ws.sigma.detach()
+        ops.deform_fwd_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den)
+        x = ws.adv.detach().requires_grad_()
+        logits = self._logits(x)
+        ops.best_update(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, counter=ws.step)
+        _, dlogits = self.adv_func.fused(logits, ws.target, loss_out=ws.adv_loss)
+        g_victim, = torch.autograd.grad(logits, x, grad_outputs=dlogits)
+        if any(w != 0 for w in regs):
+            ops.regulariser_fwd_into(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.scale_const, regs, rng, ws.reg_scratch,
+                                     ws.dist_loss, ws.scaled)
+            ops.regulariser_bwd_add(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.reg_scratch, g_victim.contiguous(), regs,
+                                    rng, ws.gp_reg, ws.gs_reg, ws.g_adv)
+            g_adv, gp2, gs2 = ws.g_adv, ws.gp_reg, ws.gs_reg
+        else:
+            g_adv, gp2, gs2 = g_victim.contiguous(), None, None
+        ops.deform_bwd_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den, g_adv, ws.deform_part, ws.gp, ws.gs)
+        ops.adam_step_sum(P, sigma, ws.gp, gp2, ws.gs, gs2, ws.m_p, ws.v_p, ws.m_s, ws.v_s, ws.step,
+                          self.attack_lr * 5, self.attack_lr * 3, (-self.budget, self.budget), rng)
 
     def _warm_up(self, ws):
         """Two eager passes of the iteration on ``ws.stream``; the second under PyTorch's sync-debug mode set

@@ -40,6 +40,9 @@ PROTOTYPES = {
     "hitadv_regulariser_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hitadv_regulariser_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hitadv_regulariser_scratch_floats": [_I],
+    "hitadv_regulariser_bwd_add": [_P] * 8 + [_I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "hitadv_adam_step_sum": [_P, _P, _P, _P, _P, _c.c_int64, _F, _F, _F, _P, _P, _P, _P, _P, _c.c_int64, _F, _F, _F, _P, _P],
+    "hitadv_adv_loss": [_I, _P, _P, _I, _I, _F, _P, _P, _P],
     "hitadv_linear_max_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "hitadv_max_over_points": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hitadv_max_over_points_scratch": [_I, _I],

@@ -108,6 +108,97 @@ __global__ __launch_bounds__(256) void adam_k(float *__restrict__ p0, const floa
 
 __global__ void bump_k(int32_t *c) { *c += 1; }
 
+// Adam on (perturb, sigma) with the gradient given as a sum of two terms (the deformation's and the regulariser's),
+// followed by the projection the reference applies at the top of the NEXT iteration (HiT_ADV.py:157-158:
+// perturb.clamp(-budget, budget), sigma.clamp(min_sigm, max_sigm)) -- same parameter values at every forward pass.
+// `step` holds the 1-based step number (the caller's per-iteration kernel bumped it already).
+__global__ __launch_bounds__(256) void adam2_k(float *__restrict__ p0, const float *__restrict__ g0,
+                                               const float *__restrict__ h0, float *__restrict__ m0,
+                                               float *__restrict__ v0, long long n0, float lr0, float lo0, float hi0,
+                                               float *__restrict__ p1, const float *__restrict__ g1,
+                                               const float *__restrict__ h1, float *__restrict__ m1,
+                                               float *__restrict__ v1, long long n1, float lr1, float lo1, float hi1,
+                                               const int32_t *__restrict__ step) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n0 + n1) return;
+  const bool second = e >= n0;
+  const long long i = second ? e - n0 : e;
+  float *p = second ? p1 : p0;
+  const float *g = second ? g1 : g0;
+  const float *hh = second ? h1 : h0;
+  float *m = second ? m1 : m0;
+  float *v = second ? v1 : v0;
+  const double lr = second ? (double)lr1 : (double)lr0;
+  const float lo = second ? lo1 : lo0, hi = second ? hi1 : hi0;
+  const int t = *step;
+  const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
+  const double bc1 = 1.0 - pow(beta1, (double)t);
+  const double bc2 = 1.0 - pow(beta2, (double)t);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float gi = hh ? g[i] + hh[i] : g[i];
+  const float mi = m[i] + (gi - m[i]) * (float)(1.0 - beta1);
+  const float vi = v[i] * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = __builtin_sqrtf(vi) / bc2_sqrt + (float)eps;
+  float q = p[i] - (step_size * mi) / denom;
+  if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);
+  p[i] = q;
+}
+
+// Adversarial losses of util/adv_utils.py on logits[B,K] with their gradient, one launch:
+//   kind 0  UntargetedLogitsAdvLoss (:50-67)   mean_b max(z_t - max_{j != t} z_j + kappa, 0)
+//   kind 1  LogitsAdvLoss           (:18-35)   mean_b max(max_{j != t} z_j - z_t + kappa, 0)
+//   kind 2  CrossEntropyAdvLoss     (:77-85)   mean_b (logsumexp(z) - z_t)
+// "max over the others" is the reference's max((1-onehot)*z - onehot*10000): the true class takes part with -10000.
+// One wave per cloud; the mean is taken in cloud order by wave 0 of the single block.
+__global__ __launch_bounds__(1024) void adv_loss_k(int kind, const float *__restrict__ logits,
+                                                   const int64_t *__restrict__ target, int B, int K, float kappa,
+                                                   float *__restrict__ loss, float *__restrict__ dlogits) {
+  extern __shared__ float per[];  // B
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int b = wave; b < B; b += nw) {
+    const float *z = logits + (size_t)b * K;
+    float *d = dlogits + (size_t)b * K;
+    const int t = (int)target[b];
+    const float invB = 1.0f / (float)B;
+    if (kind == 2) {
+      float mx = -__builtin_inff();
+      for (int j = lane; j < K; j += 64) mx = fmaxf(mx, z[j]);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, HITADV_WAVE));
+      float se = 0.f;
+      for (int j = lane; j < K; j += 64) se += __expf(z[j] - mx);
+      se = wave_sum(se);
+      const float lse = mx + __logf(se);
+      for (int j = lane; j < K; j += 64) d[j] = (__expf(z[j] - lse) - (j == t ? 1.0f : 0.f)) * invB;
+      if (lane == 0) per[b] = lse - z[t];
+    } else {
+      unsigned long long key = 0ull;
+      for (int j = lane; j < K; j += 64) {
+        const float v = j == t ? -10000.f : z[j];
+        const unsigned long long k = ((unsigned long long)ordered_bits(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+        key = k > key ? k : key;
+      }
+      key = wave_max_u64(key);
+      const int o = (int)(0xFFFFFFFFu - (uint32_t)(key & 0xffffffffu));
+      const float other = o == t ? -10000.f : z[o];
+      const float margin = kind == 0 ? (z[t] - other) + kappa : (other - z[t]) + kappa;
+      const bool on = margin >= 0.f;  // torch's clamp(min=0) passes the gradient at the boundary
+      const float s = on ? (kind == 0 ? invB : -invB) : 0.f;
+      for (int j = lane; j < K; j += 64) d[j] = (j == t ? s : 0.f) - ((j == o && o != t) ? s : 0.f);
+      if (lane == 0) per[b] = margin > 0.f ? margin : 0.f;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += per[b];
+    loss[0] = a / (float)B;
+  }
+}
+
 }  // namespace hitadv
 
 using namespace hitadv;
@@ -142,6 +233,33 @@ extern "C" int hitadv_adam_step(float *perturb, const float *g_perturb, float *m
                                                          lr_perturb, sigma, g_sigma, m_sigma, v_sigma, n_sigma,
                                                          lr_sigma, step);
   bump_k<<<1, 1, 0, s>>>(step);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_adam_step_sum(float *perturb, const float *g_perturb, const float *g_perturb2, float *m_perturb,
+                                    float *v_perturb, int64_t n_perturb, float lr_perturb, float lo_perturb,
+                                    float hi_perturb, float *sigma, const float *g_sigma, const float *g_sigma2,
+                                    float *m_sigma, float *v_sigma, int64_t n_sigma, float lr_sigma, float lo_sigma,
+                                    float hi_sigma, const int32_t *step, void *stream) {
+  if (!perturb || !g_perturb || !m_perturb || !v_perturb || !step || n_perturb <= 0 || n_sigma < 0)
+    return HITADV_E_ARG;
+  if (n_sigma > 0 && (!sigma || !g_sigma || !m_sigma || !v_sigma)) return HITADV_E_ARG;
+  const long long total = n_perturb + n_sigma;
+  adam2_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      perturb, g_perturb, g_perturb2, m_perturb, v_perturb, n_perturb, lr_perturb, lo_perturb, hi_perturb, sigma,
+      g_sigma, g_sigma2, m_sigma, v_sigma, n_sigma, lr_sigma, lo_sigma, hi_sigma, step);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_adv_loss(int kind, const float *logits, const int64_t *target, int B, int K, float kappa,
+                               float *loss, float *dlogits, void *stream) {
+  if (kind < 0 || kind > 2 || !logits || !target || !loss || !dlogits || B <= 0 || K <= 0 || B > 8192)
+    return HITADV_E_ARG;
+  const int threads = B >= 16 ? 1024 : 64 * B;
+  adv_loss_k<<<1, threads, (size_t)B * sizeof(float), (hipStream_t)stream>>>(kind, logits, target, B, K, kappa, loss,
+                                                                             dlogits);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

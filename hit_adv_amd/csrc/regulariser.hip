@@ -139,10 +139,10 @@ __global__ __launch_bounds__(256) void reg_backward(const float *__restrict__ P,
                                                     const float *__restrict__ go, int B, int N, int C, float cd_w,
                                                     float ker_w, float hide_w, float min_s, float inv_range,
                                                     float *__restrict__ gP, float *__restrict__ gS,
-                                                    float *__restrict__ gA) {
+                                                    float *__restrict__ gA, const float *__restrict__ addA) {
   const long long nP = (long long)B * C * 3, nS = (long long)B * C, nA = (long long)B * 3 * N;
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  const float k = go[0] * scal[0];  // upstream * mean(scale_const)
+  const float k = (go ? go[0] : 1.0f) * scal[0];  // upstream * mean(scale_const)
   if (e < nP) {
     gP[e] = ker_w != 0.f ? k * (ker_w / (float)C) * scal[1] * P[e] : 0.f;
   } else if (e < nP + nS) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void reg_backward(const float *__restrict__ P,
       const int arg = (int)per_cloud[(size_t)b * 8 + 3 + row];
       g = k * (cd_w / (3.0f * (float)B)) * 2.0f * (adv[i] - ori[((size_t)b * 3 + arg) * N + n]);
     }
-    gA[i] = g;
+    gA[i] = addA ? g + addA[i] : g;
   }
 }
 
@@ -205,7 +205,25 @@ extern "C" int hitadv_regulariser_bwd(const float *perturb, const float *sigma, 
   const long long total = (long long)B * C * 3 + (long long)B * C + (long long)B * 3 * N;
   reg_backward<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
       perturb, sigma, adv, ori, hide_ref, per_cloud, scal, grad_out, B, N, C, cd_w, ker_w, hide_w, min_sigm, inv_range,
-      grad_perturb, grad_sigma, grad_adv);
+      grad_perturb, grad_sigma, grad_adv, nullptr);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_regulariser_bwd_add(const float *perturb, const float *sigma, const float *adv, const float *ori,
+                                          const float *hide_ref, const float *scratch, const float *grad_out,
+                                          const float *add_adv, int B, int N, int C, float cd_w, float ker_w,
+                                          float hide_w, float min_sigm, float max_sigm, float *grad_perturb,
+                                          float *grad_sigma, float *grad_adv, void *stream) {
+  if (!perturb || !sigma || !adv || !ori || !hide_ref || !scratch || !grad_perturb || !grad_sigma || !grad_adv ||
+      B <= 0 || N <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  const float *per_cloud = scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
+  const float inv_range = 1.0f / (max_sigm - min_sigm + 1e-7f);
+  const long long total = (long long)B * C * 3 + (long long)B * C + (long long)B * 3 * N;
+  reg_backward<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      perturb, sigma, adv, ori, hide_ref, per_cloud, scal, grad_out, B, N, C, cd_w, ker_w, hide_w, min_sigm, inv_range,
+      grad_perturb, grad_sigma, grad_adv, add_adv);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

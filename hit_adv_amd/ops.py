@@ -193,16 +193,81 @@ def regulariser(perturb, sigma, adv, ori, hide_ref, scale_const, weights, sig_ra
     return Regulariser.apply(perturb, sigma, adv, ori, hide_ref, scale_const, weights, sig_range, dist_out)
 
 
+# --------------------------------------------------------------------------- the same pieces without autograd
+# (explicit forward / backward calls on caller-owned buffers: what HiT_ADV._iteration_fused strings together)
+def deform_fwd_into(ori, central, perturb, sigma, adv, inv_den):
+    B, _, N = ori.shape
+    _lib.call("hitadv_deform_fwd", _p(ori), _p(central), _p(perturb), _p(sigma), B, N, central.shape[2], _p(adv),
+              _p(inv_den), _stream())
+
+
+def deform_bwd_scratch(B, N, C):
+    return int(_lib.load().hitadv_deform_bwd_scratch_floats(B, N, C))
+
+
+def deform_bwd_into(ori, central, perturb, sigma, adv, inv_den, g_adv, partials, gp, gs):
+    B, _, N = ori.shape
+    _lib.call("hitadv_deform_bwd", _p(ori), _p(central), _p(perturb), _p(sigma), _p(adv), _p(inv_den), _p(g_adv), B, N,
+              central.shape[2], _p(partials), _p(gp), _p(gs), _stream())
+
+
+def regulariser_scratch(B):
+    return int(_lib.load().hitadv_regulariser_scratch_floats(B))
+
+
+def regulariser_fwd_into(perturb, sigma, adv, ori, hide_ref, scale_const, weights, sig_range, scratch, dist_out,
+                         scaled_out):
+    B, _, N = adv.shape
+    cd, ker, hide = (ctypes.c_float(float(w)) for w in weights)
+    lo, hi = (ctypes.c_float(float(v)) for v in sig_range)
+    _lib.call("hitadv_regulariser_fwd", _p(perturb), _p(sigma), _p(adv), _p(ori), _p(hide_ref), _p(scale_const), B, N,
+              sigma.shape[1], cd, ker, hide, lo, hi, _p(scratch), _p(dist_out), _p(scaled_out), _stream())
+
+
+def regulariser_bwd_add(perturb, sigma, adv, ori, hide_ref, scratch, add_adv, weights, sig_range, gp, gs, ga):
+    """Gradients of the scaled regulariser (upstream 1) into gp / gs, and ga = its adv term + add_adv."""
+    B, _, N = adv.shape
+    cd, ker, hide = (ctypes.c_float(float(w)) for w in weights)
+    lo, hi = (ctypes.c_float(float(v)) for v in sig_range)
+    _lib.call("hitadv_regulariser_bwd_add", _p(perturb), _p(sigma), _p(adv), _p(ori), _p(hide_ref), _p(scratch), None,
+              _p(add_adv), B, N, sigma.shape[1], cd, ker, hide, lo, hi, _p(gp), _p(gs), _p(ga), _stream())
+
+
+def adam_step_sum(perturb, sigma, gp, gp2, gs, gs2, m_p, v_p, m_s, v_s, step, lr_p, lr_s, clamp_p, clamp_s):
+    """Adam on both groups with gradient g + g2 (g2 may be None) and the projection onto ``clamp_*`` afterwards;
+    ``step`` (device int32[1]) already holds the 1-based step number."""
+    _lib.call("hitadv_adam_step_sum", _p(perturb), _p(gp), _p(gp2), _p(m_p), _p(v_p), perturb.numel(),
+              ctypes.c_float(lr_p), ctypes.c_float(clamp_p[0]), ctypes.c_float(clamp_p[1]), _p(sigma), _p(gs), _p(gs2),
+              _p(m_s), _p(v_s), sigma.numel(), ctypes.c_float(lr_s), ctypes.c_float(clamp_s[0]),
+              ctypes.c_float(clamp_s[1]), _p(step), _stream())
+
+
+ADV_UNTARGETED, ADV_TARGETED, ADV_CROSS_ENTROPY = 0, 1, 2
+
+
+def adv_loss(kind, logits, target, kappa=0., loss_out=None):
+    """(loss, d loss / d logits) of the util/adv_utils.py losses in one launch; ``loss_out`` (0-d) is written if given."""
+    logits = _dev(logits.detach(), "logits")
+    target = _dev(target, "target", torch.int64)
+    B, K = logits.shape
+    loss = loss_out if loss_out is not None else torch.empty((), device=logits.device)
+    d = torch.empty_like(logits)
+    _lib.call("hitadv_adv_loss", kind, _p(logits), _p(target), B, K, ctypes.c_float(float(kappa)), _p(loss), _p(d),
+              _stream())
+    return loss, d
+
+
 # --------------------------------------------------------------------------- attack state
-def best_update(logits, label, perturb, sigma, adv, state):
-    """In-place update of the best-so-far buffers in ``state`` (see hitadv_best_update)."""
+def best_update(logits, label, perturb, sigma, adv, state, counter=None):
+    """In-place update of the best-so-far buffers in ``state`` (see hitadv_best_update); ``counter`` (device
+    int32[1], optional) is incremented once per call."""
     B, K = logits.shape
     N = adv.shape[2]
     C = sigma.shape[1]
     _lib.call("hitadv_best_update", _p(logits), _p(label), _p(perturb), _p(sigma), _p(adv), B, K, N, C,
               _p(state["bestdist"]), _p(state["bestscore"]), _p(state["o_bestdist"]), _p(state["o_bestscore"]),
-              _p(state["o_bestattack"]), _p(state["pred"]), _p(state["dist_val"]), _p(state.get("iter")),
-              _stream())
+              _p(state["o_bestattack"]), _p(state["pred"]), _p(state["dist_val"]),
+              _p(counter if counter is not None else state.get("iter")), _stream())
 
 
 def adam_step(perturb, sigma, g_perturb, g_sigma, m_p, v_p, m_s, v_s, step, lr_p, lr_s):

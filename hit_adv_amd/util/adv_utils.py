@@ -26,6 +26,11 @@ class LogitsAdvLoss(nn.Module):
         true, other = _true_and_best_other(logits, targets)
         return (other - true + self.kappa).clamp(min=0.).mean()
 
+    def fused(self, logits, targets, loss_out=None):
+        """(loss, d loss / d logits) in one HIP launch (hitadv_adv_loss); CUDA tensors only."""
+        from .. import ops
+        return ops.adv_loss(ops.ADV_TARGETED, logits, targets, self.kappa, loss_out)
+
 
 class UntargetedLogitsAdvLoss(nn.Module):
     """Untargeted margin loss, util/adv_utils.py:38-67 (the one eval.py:84 hands to HiT-ADV)."""
@@ -38,9 +43,18 @@ class UntargetedLogitsAdvLoss(nn.Module):
         true, other = _true_and_best_other(logits, targets)
         return (true - other + self.kappa).clamp(min=0.).mean()
 
+    def fused(self, logits, targets, loss_out=None):
+        """(loss, d loss / d logits) in one HIP launch (hitadv_adv_loss); CUDA tensors only."""
+        from .. import ops
+        return ops.adv_loss(ops.ADV_UNTARGETED, logits, targets, self.kappa, loss_out)
+
 
 class CrossEntropyAdvLoss(nn.Module):
     """util/adv_utils.py:70-85."""
 
     def forward(self, logits, targets):
         return F.cross_entropy(logits, targets)
+
+    def fused(self, logits, targets, loss_out=None):
+        from .. import ops
+        return ops.adv_loss(ops.ADV_CROSS_ENTROPY, logits, targets, 0., loss_out)

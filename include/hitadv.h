@@ -128,6 +128,21 @@ int hitadv_adam_step(float *perturb, const float *g_perturb, float *m_perturb, f
                      int64_t n_perturb, float lr_perturb, float *sigma, const float *g_sigma,
                      float *m_sigma, float *v_sigma, int64_t n_sigma, float lr_sigma,
                      int32_t *step, void *stream);
+/* The same step with the gradient given as g + g2 (g2 may be NULL: the deformation's and the regulariser's terms
+ * need no separate add), followed by the projection the reference applies at the top of the next iteration
+ * (ShapeAttack/HiT_ADV.py:157-158; skipped for a group when lo > hi).  *step is the 1-based step number and is
+ * NOT modified (pass the counter that hitadv_best_update bumps once per iteration). */
+int hitadv_adam_step_sum(float *perturb, const float *g_perturb, const float *g_perturb2, float *m_perturb,
+                         float *v_perturb, int64_t n_perturb, float lr_perturb, float lo_perturb, float hi_perturb,
+                         float *sigma, const float *g_sigma, const float *g_sigma2, float *m_sigma, float *v_sigma,
+                         int64_t n_sigma, float lr_sigma, float lo_sigma, float hi_sigma, const int32_t *step,
+                         void *stream);
+
+/* Adversarial loss on logits[B,K] and its gradient in one launch (util/adv_utils.py):
+ *   kind 0 UntargetedLogitsAdvLoss (:38-67), kind 1 LogitsAdvLoss (:6-35), kind 2 CrossEntropyAdvLoss (:70-85);
+ * *loss = mean over the batch, dlogits[B,K] = d loss / d logits.  kappa is ignored for kind 2.  B <= 8192. */
+int hitadv_adv_loss(int kind, const float *logits, const int64_t *target, int B, int K, float kappa, float *loss,
+                    float *dlogits, void *stream);
 
 /* The three distance regularisers of the HiT-ADV loss, fused with the per-sample weighting
  * (ShapeAttack/HiT_ADV.py:229-245):  dist = cd_w*mean_b Q1_b + ker_w*(|P|_F+|1-sigma|_F)/C + hide_w*mean_b cos_b,
@@ -145,6 +160,13 @@ int hitadv_regulariser_bwd(const float *perturb, const float *sigma, const float
                            const float *hide_ref, const float *scratch, const float *grad_out, int B, int N,
                            int C, float cd_w, float ker_w, float hide_w, float min_sigm, float max_sigm,
                            float *grad_perturb, float *grad_sigma, float *grad_adv, void *stream);
+/* Same, with grad_out optional (NULL = 1) and grad_adv = (regulariser's term) + add_adv[B,3,N] when add_adv != NULL:
+ * the victim's input gradient joins here instead of in a separate add. */
+int hitadv_regulariser_bwd_add(const float *perturb, const float *sigma, const float *adv, const float *ori,
+                               const float *hide_ref, const float *scratch, const float *grad_out,
+                               const float *add_adv, int B, int N, int C, float cd_w, float ker_w, float hide_w,
+                               float min_sigm, float max_sigm, float *grad_perturb, float *grad_sigma,
+                               float *grad_adv, void *stream);
 int64_t hitadv_regulariser_scratch_floats(int B);
 
 /* ------------------------------------------------------------------ farthest point sampling */

@@ -410,6 +410,53 @@ def test_best_update_and_adam_match_host_logic(A):
     close(ds, s, rtol=1e-5, atol=1e-6)
 
 
+def test_adam_step_sum_and_projection(A):
+    """hitadv_adam_step_sum == torch.optim.Adam on the summed gradient followed by the reference's clamp."""
+    g = torch.Generator().manual_seed(8)
+    p = (torch.randn(3, 7, 3, generator=g) * 0.1).requires_grad_()
+    s = (0.1 + torch.rand(3, 7, generator=g)).requires_grad_()
+    opt = torch.optim.Adam([{'params': p, 'lr': 0.05}, {'params': s, 'lr': 0.03}], weight_decay=0.)
+    dp, ds = p.detach().clone().cuda(), s.detach().clone().cuda()
+    m_p, v_p, m_s, v_s = (torch.zeros_like(t) for t in (dp, dp, ds, ds))
+    step = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for it in range(25):
+        gp, gp2 = torch.randn(3, 7, 3, generator=g), torch.randn(3, 7, 3, generator=g)
+        gs, gs2 = torch.randn(3, 7, generator=g), torch.randn(3, 7, generator=g)
+        p.grad, s.grad = gp + gp2, gs + gs2
+        opt.step()
+        with torch.no_grad():
+            p.clamp_(-0.3, 0.3)
+            s.clamp_(0.1, 1.2)
+        step += 1  # what hitadv_best_update does once per iteration
+        A.adam_step_sum(dp, ds, cu(gp), cu(gp2), cu(gs), cu(gs2) if it % 2 else None, m_p, v_p, m_s, v_s, step, 0.05,
+                        0.03, (-0.3, 0.3), (0.1, 1.2)) if it % 2 else \
+            A.adam_step_sum(dp, ds, cu(gp + gp2), None, cu(gs), cu(gs2), m_p, v_p, m_s, v_s, step, 0.05, 0.03,
+                            (-0.3, 0.3), (0.1, 1.2))
+        close(dp, p, rtol=1e-5, atol=1e-6)
+        close(ds, s, rtol=1e-5, atol=1e-6)
+    assert step.item() == 25 and float(dp.abs().max()) <= float(np.float32(0.3))
+
+
+@pytest.mark.parametrize("B,K", [(32, 40), (5, 16), (1, 40), (70, 130)])
+def test_fused_adv_losses_match_reference_modules(A, B, K):
+    """hitadv_adv_loss (value + gradient in one launch) vs the torch formulation of util/adv_utils.py under autograd,
+    which the oracle tests pin to the reference (fixture g6)."""
+    from hit_adv_amd.util.adv_utils import CrossEntropyAdvLoss, LogitsAdvLoss, UntargetedLogitsAdvLoss
+    g = torch.Generator().manual_seed(B + K)
+    logits = torch.randn(B, K, generator=g) * 8
+    target = torch.randint(0, K, (B,), generator=g)
+    logits[0, target[0]] = 100.  # confidently right: untargeted margin active, targeted inactive
+    for mod in (UntargetedLogitsAdvLoss(30.), UntargetedLogitsAdvLoss(0.), LogitsAdvLoss(5.), CrossEntropyAdvLoss()):
+        z = logits.clone().requires_grad_()
+        ref = mod(z, target)
+        gref, = torch.autograd.grad(ref, z)
+        out = torch.zeros((), device='cuda')
+        loss, d = mod.fused(cu(logits), cu(target), loss_out=out)
+        assert loss.data_ptr() == out.data_ptr()
+        close(loss, ref, rtol=2e-6, atol=1e-6)
+        close(d, gref, rtol=1e-5, atol=1e-7)
+
+
 # ------------------------------------------------------------------ full-size properties (cfg2 sizes)
 def test_full_size_properties_b32_n1024(A):
     from hit_adv_amd.pytorch3d_ops import knn_points
