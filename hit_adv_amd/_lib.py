@@ -50,7 +50,7 @@ PROTOTYPES = {
     "hitadv_linear_max_fwd_scratch": [_I, _I, _I],
     "hitadv_pointnet_rowmlp_fwd": [_I] + [_P] * 13 + [_I, _I, _P],
     "hitadv_pointnet_rowmlp_tiles": [_I],
-    "hitadv_pointnet_rowmlp_bwd": [_I] + [_P] * 13 + [_I, _I, _P],
+    "hitadv_pointnet_rowmlp_bwd": [_I, _P, _P, _P, _P, _I] + [_P] * 12 + [_I, _I, _P],
     "hitadv_sum_partials": [_P, _P, _I, _I, _I, _P, _P],
     "hitadv_fc_layer": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "hitadv_fc_layer_scratch_floats": [_I, _I, _I],

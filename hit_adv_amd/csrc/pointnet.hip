@@ -33,15 +33,19 @@ __device__ __forceinline__ void zero(f32x16 &a) {
   for (int e = 0; e < 16; ++e) a[e] = 0.f;
 }
 
-// acc[rb] += A[row_base + 32*rb .. +32)[0..K) @ Bm[0..K)[col .. col+32)
-//   A: LDS tile, row stride lda floats.   Bm element (k, c):  TRANSB ? W[c*ldw + k] : W[k*ldw + c].
-template <int K, int NRB, bool TRANSB>
-__device__ __forceinline__ void mfma_rows(const float *sA, int lda, int row_base, const float *__restrict__ W, int ldw,
-                                          int col, f32x16 (&acc)[NRB], int r, int h) {
-  float w[K / 2];
+// B operand of a [.,K] x [K,32] product, held in registers: element (k, c) is TRANSB ? W[c*ldw + k] : W[k*ldw + c].
+// Loaded at the top of a kernel so that its latency overlaps the tile loads.
+template <int K, bool TRANSB>
+__device__ __forceinline__ void load_w(const float *__restrict__ W, int ldw, int col, int r, int h, float (&w)[K / 2]) {
 #pragma unroll
   for (int t = 0; t < K / 2; ++t)
     w[t] = TRANSB ? W[(size_t)(col + r) * ldw + kmap(t, h)] : W[(size_t)kmap(t, h) * ldw + col + r];
+}
+
+// acc[rb] += A[row_base + 32*rb .. +32)[0..K) @ Bm   (A: LDS tile, row stride lda floats; Bm: load_w registers)
+template <int K, int NRB>
+__device__ __forceinline__ void mfma_apply(const float *sA, int lda, int row_base, const float (&w)[K / 2],
+                                           f32x16 (&acc)[NRB], int r, int h) {
 #pragma unroll
   for (int j = 0; j < K / 8; ++j) {
     float av[NRB][4];
@@ -61,25 +65,23 @@ __device__ __forceinline__ void mfma_rows(const float *sA, int lda, int row_base
 // accumulator element e of a 32x32 tile sits at row (e&3) + 8*(e>>2) + 4*h, column r
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
-// Coalesced float4 copy of a [rows x W] tile of a points-major matrix into LDS (rows past `rows` -> 0);
-// with MASK the value is gated by (gate > 0) -- the ReLU backward on load.
-template <int W, bool MASK>
-__device__ __forceinline__ void load_tile(const float *__restrict__ src, const float *__restrict__ gate, int rows,
-                                          float *dst, int ld) {
+// Coalesced float4 fetch of a [rows x W] tile of a points-major matrix into registers (rows past `rows` -> 0) ...
+template <int W>
+__device__ __forceinline__ void fetch_tile(const float *__restrict__ src, int rows, float4 (&v)[PM_TM * W / 4 / 256]) {
 #pragma unroll
   for (int u = 0; u < PM_TM * W / 4 / 256; ++u) {
     const int e = threadIdx.x + 256 * u;
     const int n = e / (W / 4), c4 = e % (W / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < rows) {
-      v = *reinterpret_cast<const float4 *>(src + (size_t)n * W + 4 * c4);
-      if (MASK) {
-        const float4 g = *reinterpret_cast<const float4 *>(gate + (size_t)n * W + 4 * c4);
-        v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
-        v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
-      }
-    }
-    *reinterpret_cast<float4 *>(dst + n * ld + 4 * c4) = v;
+    v[u] = n < rows ? *reinterpret_cast<const float4 *>(src + (size_t)n * W + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+// ... and its store into an LDS tile of row stride ld.
+template <int W>
+__device__ __forceinline__ void stash_tile(const float4 (&v)[PM_TM * W / 4 / 256], float *dst, int ld) {
+#pragma unroll
+  for (int u = 0; u < PM_TM * W / 4 / 256; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    *reinterpret_cast<float4 *>(dst + (e / (W / 4)) * ld + 4 * (e % (W / 4))) = v[u];
   }
 }
 
@@ -107,8 +109,22 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
   const size_t row0 = (size_t)b * N + n0;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
+  const int rb = wave & 1, cb = wave >> 1;
+
+  // every global operand is requested up front; the layer chain below then only waits on LDS and the matrix cores
+  float w2[32], w1[32];
+  load_w<64, false>(a.W2, 128, 32 * wave, r, h, w2);
+  const float bias2 = a.b2[32 * wave + r];
+  float bias1 = 0.f;
+  if (STAGE == 1) {
+    load_w<64, false>(a.W1, 64, 32 * cb, r, h, w1);
+    bias1 = a.b1[32 * cb + r];
+  }
+  if (STAGE == 2) load_w<64, false>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1);
 
   if (STAGE < 2) {
+    const int c0 = threadIdx.x & 63;
+    const float w00 = a.W0[c0], w01 = a.W0[64 + c0], w02 = a.W0[128 + c0], bb = a.b0[c0];
     if (threadIdx.x < 192) {
       const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
       sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
@@ -127,25 +143,25 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
       xin = sXp;
     }
     {  // 3 -> 64, ReLU: one column per lane, 16 rows per thread
-      const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-      const float w0 = a.W0[c], w1 = a.W0[64 + c], w2 = a.W0[128 + c], bb = a.b0[c];
+      const int q = threadIdx.x >> 6;
 #pragma unroll 4
       for (int i = 0; i < 16; ++i) {
         const int n = q * 16 + i;
-        float v = fmaf(xin[n * 3 + 2], w2, fmaf(xin[n * 3 + 1], w1, fmaf(xin[n * 3], w0, bb)));
+        float v = fmaf(xin[n * 3 + 2], w02, fmaf(xin[n * 3 + 1], w01, fmaf(xin[n * 3], w00, bb)));
         v = v > 0.f ? v : 0.f;
-        sA[n * PM_L64 + c] = v;
-        if (n < rows) a.o0[(row0 + n) * 64 + c] = v;
+        sA[n * PM_L64 + c0] = v;
+        if (n < rows) a.o0[(row0 + n) * 64 + c0] = v;
       }
     }
     __syncthreads();
   } else {  // h1' = h1 @ T64   (torch.bmm(x, trans_feat), :131)
-    load_tile<64, false>(a.hin + row0 * 64, nullptr, rows, sB, PM_L64);
+    float4 t[4];
+    fetch_tile<64>(a.hin + row0 * 64, rows, t);
+    stash_tile<64>(t, sB, PM_L64);
     __syncthreads();
-    const int rb = wave & 1, cb = wave >> 1;
     f32x16 acc[1];
     zero(acc[0]);
-    mfma_rows<64, 1, false>(sB, PM_L64, 32 * rb, a.T + (size_t)b * 4096, 64, 32 * cb, acc, r, h);
+    mfma_apply<64, 1>(sB, PM_L64, 32 * rb, w1, acc, r, h);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
@@ -157,15 +173,13 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
 
   const float *sIn = sA;
   if (STAGE == 1) {  // t1: 64 -> 64, ReLU
-    const int rb = wave & 1, cb = wave >> 1;
     f32x16 acc[1];
     zero(acc[0]);
-    mfma_rows<64, 1, false>(sA, PM_L64, 32 * rb, a.W1, 64, 32 * cb, acc, r, h);
-    const float bb = a.b1[32 * cb + r];
+    mfma_apply<64, 1>(sA, PM_L64, 32 * rb, w1, acc, r, h);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
-      float v = acc[0][e] + bb;
+      float v = acc[0][e] + bias1;
       v = v > 0.f ? v : 0.f;
       sB[n * PM_L64 + c] = v;
       if (n < rows) a.o1[(row0 + n) * 64 + c] = v;
@@ -177,23 +191,29 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
     f32x16 acc[2];
     zero(acc[0]);
     zero(acc[1]);
-    mfma_rows<64, 2, false>(sIn, PM_L64, 0, a.W2, 128, 32 * wave, acc, r, h);
+    mfma_apply<64, 2>(sIn, PM_L64, 0, w2, acc, r, h);
     const int c = 32 * wave + r;
-    const float bb = a.b2[c];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int n = 32 * rb + acc_row(e, h);
-        float v = acc[rb][e] + bb;
+        const int n = 32 * q + acc_row(e, h);
+        float v = acc[q][e] + bias2;
         v = v > 0.f ? v : 0.f;
         if (n < rows) a.o2[(row0 + n) * 128 + c] = v;
       }
   }
 }
 
+// Backward of a stage, starting from the gradient at the max-pooled output of its 128->Cout layer: the block
+// first GATHERS its 64 points' rows of  dA2[n,:] = sum_{j : argmax[b,j] == n} dg[b,j] * W3r[j,:]  straight into the
+// LDS tile (the max routes each channel's gradient to one point; channels are taken in ascending order, points of
+// even / odd index by the two halves of the block -> no atomics, bitwise reproducible), then runs the chain.
 struct RowMlpBwd {
-  const float *dA2;   // [B*N,128] gradient at the output of the 64->128 layer (post-ReLU), from linear_max_bwd
+  const float *dg;     // [B,Cout]  gradient at the max-pooled (and ReLU'd, if gmask) output
+  const float *gmask;  // [B,Cout]  the ReLU'd forward output (gradient passes where > 0) or NULL
+  const int64_t *idx;  // [B,Cout]  arg-max point of every channel
+  const float *W3r;    // [Cout,128]
   const float *A2;    // [B*N,128] saved relu(64->128) output (mask)
   const float *W2r;   // [128,64]
   const float *A1;    // [B*N,64]  stage 0: a1s, stage 1: relu(t1) (mask)
@@ -206,38 +226,134 @@ struct RowMlpBwd {
   const float *dPin;  // [B,3,N]   stage 0: gradient arriving at the points from stage 1
   float *dTpart;      // stage 1: [B,tiles,9]; stage 2: [B,tiles,64,64]
   float *out;         // stage 0: dX [B,3,N]; stage 1: dPts [B,3,N]; stage 2: dH1 [B*N,64]
-  int N;
+  int N, Cout;
 };
+
+constexpr int BW_CH = 4;  // Cout <= 256 * BW_CH
 
 template <int STAGE>
 __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
-  __shared__ float4 sD4[PM_TM * PM_L128 / 4], sE4[PM_TM * PM_L64 / 4], sF4[PM_TM * PM_L64 / 4];
+  __shared__ float4 sD4[PM_TM * PM_L128 / 4], sEF4[2 * PM_TM * PM_L64 / 4];
   __shared__ float sX[PM_TM * 3], sG[PM_TM * 3];
-  float *sD = reinterpret_cast<float *>(sD4), *sE = reinterpret_cast<float *>(sE4), *sF = reinterpret_cast<float *>(sF4);
-  const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, n0 = tile * PM_TM, N = a.N;
+  __shared__ int s_cnt[2][BW_CH][4];
+  float *sD = reinterpret_cast<float *>(sD4), *sE = reinterpret_cast<float *>(sEF4), *sF = sE + PM_TM * PM_L64;
+  int2 *list = reinterpret_cast<int2 *>(sEF4);  // [2][256 * BW_CH] (channel | point << 16, gradient bits); dead before sE/sF are written
+  const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, n0 = tile * PM_TM, N = a.N, Cout = a.Cout;
   const int rows = min(PM_TM, N - n0);
   const size_t row0 = (size_t)b * N + n0;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int rb = wave & 1, cb = wave >> 1;
 
-  load_tile<128, true>(a.dA2 + row0 * 128, a.A2 + row0 * 128, rows, sD, PM_L128);  // ReLU of the 64->128 layer
-  if (STAGE == 2) load_tile<64, false>(a.H1 + row0 * 64, nullptr, rows, sF, PM_L64);
+  // ---- which channels route their gradient into this tile (ordered compaction, ascending channel)
+  int mn[BW_CH];
+  float mg[BW_CH];
+  unsigned rank[BW_CH];
+#pragma unroll
+  for (int ch = 0; ch < BW_CH; ++ch) {
+    const int j = ch * 256 + threadIdx.x;
+    int n = -1;
+    float g = 0.f;
+    if (j < Cout) {
+      n = (int)a.idx[(size_t)b * Cout + j] - n0;
+      g = a.dg[(size_t)b * Cout + j];
+      if (a.gmask != nullptr) g = a.gmask[(size_t)b * Cout + j] > 0.f ? g : 0.f;
+    }
+    const bool hit = n >= 0 && n < rows && g != 0.f;
+    const unsigned long long m0 = __ballot(hit && !(n & 1)), m1 = __ballot(hit && (n & 1));
+    if (lane == 0) {
+      s_cnt[0][ch][wave] = __popcll(m0);
+      s_cnt[1][ch][wave] = __popcll(m1);
+    }
+    mn[ch] = hit ? n : -1;
+    mg[ch] = g;
+    rank[ch] = __popcll(((n & 1) ? m1 : m0) & ((1ull << lane) - 1ull));
+  }
+  // ---- everything else this block will need from global memory, requested now
+  float w2[64], w1[32];
+  load_w<128, false>(a.W2r, 64, 32 * cb, r, h, w2);
+  if (STAGE == 1) load_w<64, false>(a.W1r, 64, 32 * cb, r, h, w1);
+  if (STAGE == 2) load_w<64, true>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1);
+  float m1v[16], mhv[16], dhv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int n = 32 * rb + acc_row(e, h);
+    const size_t o = (row0 + n) * 64 + 32 * cb + r;
+    const bool in = n < rows;
+    m1v[e] = (STAGE != 2 && in) ? a.A1[o] : 0.f;
+    mhv[e] = (STAGE == 1 && in) ? a.H1[o] : 0.f;
+    dhv[e] = (STAGE == 1 && in) ? a.dH1in[o] : 0.f;
+  }
+  float4 a2[8], h1t[4];
+  fetch_tile<128>(a.A2 + row0 * 128, rows, a2);
+  if (STAGE == 2) fetch_tile<64>(a.H1 + row0 * 64, rows, h1t);
   if (STAGE == 1 && threadIdx.x < 192) {
     const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
     sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
   }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    *reinterpret_cast<float4 *>(sD + (e >> 5) * PM_L128 + 4 * (e & 31)) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  int total[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    int run = 0;
+#pragma unroll
+    for (int ch = 0; ch < BW_CH; ++ch)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int c = s_cnt[p][ch][w];
+        if (w == wave && mn[ch] >= 0 && (mn[ch] & 1) == p)
+          list[p * 256 * BW_CH + run + rank[ch]] = make_int2((ch * 256 + (int)threadIdx.x) | (mn[ch] << 16), __float_as_int(mg[ch]));
+        run += c;
+      }
+    total[p] = run;
+  }
+  __syncthreads();
+  {  // ---- gather: half-block p takes the points of parity p, one column per thread, channels in list order
+    const int p = threadIdx.x >> 7, c = threadIdx.x & 127;
+    const int cnt = p ? total[1] : total[0];
+    const int2 *L = list + p * 256 * BW_CH;
+    for (int q = 0; q < cnt; q += 8) {
+      int2 en[8];
+      float wv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        en[i] = q + i < cnt ? L[q + i] : make_int2(0, 0);
+        wv[i] = q + i < cnt ? a.W3r[(size_t)(en[i].x & 0xffff) * 128 + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (q + i < cnt) {
+          float *d = sD + (en[i].x >> 16) * PM_L128 + c;
+          *d = fmaf(__int_as_float(en[i].y), wv[i], *d);
+        }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {  // ReLU of the 64->128 layer
+    const int e = threadIdx.x + 256 * u;
+    float4 *d = reinterpret_cast<float4 *>(sD + (e >> 5) * PM_L128 + 4 * (e & 31));
+    float4 v = *d;
+    v.x = a2[u].x > 0.f ? v.x : 0.f; v.y = a2[u].y > 0.f ? v.y : 0.f;
+    v.z = a2[u].z > 0.f ? v.z : 0.f; v.w = a2[u].w > 0.f ? v.w : 0.f;
+    *d = v;
+  }
+  if (STAGE == 2) stash_tile<64>(h1t, sF, PM_L64);
   __syncthreads();
   {  // through the 64->128 layer: [64,128] @ W2r[128,64]
     f32x16 acc[1];
     zero(acc[0]);
-    mfma_rows<128, 1, false>(sD, PM_L128, 32 * rb, a.W2r, 64, 32 * cb, acc, r, h);
+    mfma_apply<128, 1>(sD, PM_L128, 32 * rb, w2, acc, r, h);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
       float v = acc[0][e];
-      if (STAGE != 2) v = (n < rows && a.A1[(row0 + n) * 64 + c] > 0.f) ? v : 0.f;
-      sE[n * PM_L64 + c] = v;
+      if (STAGE != 2) v = m1v[e] > 0.f ? v : 0.f;
+      sE[(32 * rb + acc_row(e, h)) * PM_L64 + 32 * cb + r] = v;
     }
   }
   __syncthreads();
@@ -260,7 +376,7 @@ __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
     {
       f32x16 acc[1];
       zero(acc[0]);
-      mfma_rows<64, 1, true>(sE, PM_L64, 32 * rb, a.T + (size_t)b * 4096, 64, 32 * cb, acc, r, h);
+      mfma_apply<64, 1>(sE, PM_L64, 32 * rb, w1, acc, r, h);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = 32 * rb + acc_row(e, h);
@@ -274,17 +390,10 @@ __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
   if (STAGE == 1) {  // through t1, add the gradient arriving at h1 from the encoder, through e1's ReLU
     f32x16 acc[1];
     zero(acc[0]);
-    mfma_rows<64, 1, false>(sE, PM_L64, 32 * rb, a.W1r, 64, 32 * cb, acc, r, h);
+    mfma_apply<64, 1>(sE, PM_L64, 32 * rb, w1, acc, r, h);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
-      float v = 0.f;
-      if (n < rows) {
-        const size_t o = (row0 + n) * 64 + c;
-        v = a.H1[o] > 0.f ? acc[0][e] + a.dH1in[o] : 0.f;
-      }
-      sF[n * PM_L64 + c] = v;
-    }
+    for (int e = 0; e < 16; ++e)
+      sF[(32 * rb + acc_row(e, h)) * PM_L64 + 32 * cb + r] = mhv[e] > 0.f ? acc[0][e] + dhv[e] : 0.f;
     __syncthreads();
     sIn = sF;
   }
@@ -497,15 +606,18 @@ extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float
 
 extern "C" int64_t hitadv_pointnet_rowmlp_tiles(int N) { return N > 0 ? (N + PM_TM - 1) / PM_TM : 0; }
 
-extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dA2, const float *A2, const float *W2r,
+extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const float *gmask, const int64_t *idx,
+                                          const float *W3r, int Cout, const float *A2, const float *W2r,
                                           const float *A1, const float *W1r, const float *H1, const float *dH1in,
                                           const float *W0r, const float *T, const float *x, const float *dPin,
                                           float *dTpart, float *out, int B, int N, void *stream) {
-  if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || !dA2 || !A2 || !W2r || !out) return HITADV_E_ARG;
+  if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || N > 65535 || Cout <= 0 || Cout > 256 * BW_CH || !dg || !idx ||
+      !W3r || !A2 || !W2r || !out)
+    return HITADV_E_ARG;
   if (stage == 0 && (!A1 || !W0r || !dPin)) return HITADV_E_ARG;
   if (stage == 1 && (!A1 || !W1r || !H1 || !dH1in || !W0r || !T || !x || !dTpart)) return HITADV_E_ARG;
   if (stage == 2 && (!H1 || !T || !dTpart)) return HITADV_E_ARG;
-  RowMlpBwd a{dA2, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out, N};
+  RowMlpBwd a{dg, gmask, idx, W3r, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out, N, Cout};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   hipStream_t s = (hipStream_t)stream;
   if (stage == 0) rowmlp_bwd_k<0><<<grid, 256, 0, s>>>(a);

@@ -180,7 +180,7 @@ class _LinearReLU(torch.autograd.Function):
 
 class _PointNetHip(torch.autograd.Function):
     """logits, trans_feat = f(x) and d/dx of it, entirely on libhitadv_hip (f32 MFMA kernels, csrc/pointnet.hip +
-    the fused 128->1024 layers of csrc/victim.hip): 21 launches forward, 20 backward, no rocBLAS/MIOpen.
+    the fused 128->1024 layers of csrc/victim.hip): 21 launches forward, 14 backward, no rocBLAS/MIOpen.
     Weights are constants (no weight gradients: the attack never uses them)."""
 
     @staticmethod
@@ -231,26 +231,23 @@ class _PointNetHip(torch.autograd.Function):
         d = ops.fc_layer(dlogits.contiguous(), v.h3_wr)
         d = ops.fc_layer(d, v.h2_wr, mask=f2)
         dg = ops.fc_layer(d, v.h1_wr, mask=f1)
-        dA2 = ops.linear_max_bwd(dg, v.e3_wr, je, N)
         dTp, dH1 = E(B, tiles, 4096), E(R, 64)
-        ops.pointnet_rowmlp_bwd(2, B, N, dA2, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp)
+        ops.pointnet_rowmlp_bwd(2, B, N, dg, je, v.e3_wr, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp)
         dT64 = ops.sum_partials(dTp, None if dT64_ext is None else dT64_ext.reshape(B, 4096).contiguous())
         # STNkd, first encoder layer, input transform
         d = ops.fc_layer(dT64, v.t6_wr)
         d = ops.fc_layer(d, v.t5_wr, mask=f5t)
         dgt = ops.fc_layer(d, v.t4_wr, mask=f4t)
-        dA2 = ops.linear_max_bwd(dgt, v.t3_wr, jt, N, gt)
         dTp, dPts = E(B, tiles, 9), E(B, 3, N)
-        ops.pointnet_rowmlp_bwd(1, B, N, dA2, a2t, v.t2_wr, dPts, A1=a1t, W1r=v.t1_wr, H1=h1, dH1in=dH1, W0r=v.e1_wr,
-                                T=T3, x=x, dTpart=dTp)
+        ops.pointnet_rowmlp_bwd(1, B, N, dgt, jt, v.t3_wr, a2t, v.t2_wr, dPts, gmask=gt, A1=a1t, W1r=v.t1_wr, H1=h1,
+                                dH1in=dH1, W0r=v.e1_wr, T=T3, x=x, dTpart=dTp)
         dT3 = ops.sum_partials(dTp)
         # STN3d
         d = ops.fc_layer(dT3, v.s6_wr)
         d = ops.fc_layer(d, v.s5_wr, mask=f5s)
         dgs = ops.fc_layer(d, v.s4_wr, mask=f4s)
-        dA2 = ops.linear_max_bwd(dgs, v.s3_wr, js, N, gs)
         dX = E(B, 3, N)
-        ops.pointnet_rowmlp_bwd(0, B, N, dA2, a2s, v.s2_wr, dX, A1=a1s, W0r=v.s1_wr, dPin=dPts)
+        ops.pointnet_rowmlp_bwd(0, B, N, dgs, js, v.s3_wr, a2s, v.s2_wr, dX, gmask=gs, A1=a1s, W0r=v.s1_wr, dPin=dPts)
         return dX, None
 
 

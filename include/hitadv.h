@@ -266,17 +266,21 @@ int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const 
                                float *xp, float *o0, float *o1, float *o2, int B, int N, void *stream);
 /* Number of 64-point tiles per cloud = leading dimension of the dTpart scratch below. */
 int64_t hitadv_pointnet_rowmlp_tiles(int N);
-/* Input-gradient chain of the same stages.  dA2 [B*N,128] is the gradient at the (post-ReLU) output of the 64->128
- * layer (from hitadv_linear_max_bwd); A2 / A1 / H1 are the activations saved by the forward (ReLU masks).
+/* Input-gradient chain of the same stages, starting at the max-pooled output of the stage's 128->Cout layer:
+ * dg [B,Cout] is the gradient there, idx [B,Cout] the arg-max point of every channel (hitadv_linear_max_fwd),
+ * gmask [B,Cout] the ReLU'd forward output (NULL when that layer has no ReLU), W3r [Cout,128] the layer's weights.
+ * Each 64-point block gathers  dA2[n,:] = sum_{j: idx[b,j]==n} dg[b,j] * W3r[j,:]  for its own points in LDS (fixed
+ * order, no atomics; what hitadv_linear_max_bwd writes to HBM), then runs the chain; A2 / A1 / H1 are the activations
+ * saved by the forward (ReLU masks).  Cout <= 1024, N <= 65535.
  *   stage 2: out = dH1 [B*N,64] = (dA2 . [A2>0]) W2r @ T^T;  dTpart [B,tiles,64,64] = per-tile  h1^T @ (.)
  *   stage 1: through t2, t1, + dH1in, e1's ReLU, e1 -> g [.,3];  out = dPts [B,3,N] = g @ T^T;
  *            dTpart [B,tiles,9] = per-tile x^T @ g
  *   stage 0: through s2, s1 -> [.,3], + dPin;  out = dX [B,3,N]
  * The per-tile partials are summed in tile order by hitadv_sum_partials (deterministic). */
-int hitadv_pointnet_rowmlp_bwd(int stage, const float *dA2, const float *A2, const float *W2r, const float *A1,
-                               const float *W1r, const float *H1, const float *dH1in, const float *W0r,
-                               const float *T, const float *x, const float *dPin, float *dTpart, float *out, int B,
-                               int N, void *stream);
+int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const float *gmask, const int64_t *idx, const float *W3r,
+                               int Cout, const float *A2, const float *W2r, const float *A1, const float *W1r,
+                               const float *H1, const float *dH1in, const float *W0r, const float *T, const float *x,
+                               const float *dPin, float *dTpart, float *out, int B, int N, void *stream);
 /* out[b,m] = (extra ? extra[b,m] : 0) + sum_t part[b,t,m], ascending t. */
 int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out, void *stream);
 /* out[B,NOUT] = act(in'[B,K] @ Wt[K,NOUT] + bias), in' = in gated by (mask > 0) when mask != NULL (the backward of a
