@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
 
 // Backward of a stage, starting from the gradient at the max-pooled output of its 128->Cout layer: the block
 // first GATHERS its 64 points' rows of  dA2[n,:] = sum_{j : argmax[b,j] == n} dg[b,j] * W3r[j,:]  straight into the
-// LDS tile (the max routes each channel's gradient to one point; channels are taken in ascending order, points of
-// even / odd index by the two halves of the block -> no atomics, bitwise reproducible), then runs the chain.
+// LDS tile (the max routes each channel's gradient to one point; channels are taken in ascending order -> no
+// atomics, bitwise reproducible), then runs the chain.
 struct RowMlpBwd {
   const float *dg;     // [B,Cout]  gradient at the max-pooled (and ReLU'd, if gmask) output
   const float *gmask;  // [B,Cout]  the ReLU'd forward output (gradient passes where > 0) or NULL
@@ -235,9 +235,11 @@ template <int STAGE>
 __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
   __shared__ float4 sD4[PM_TM * PM_L128 / 4], sEF4[2 * PM_TM * PM_L64 / 4];
   __shared__ float sX[PM_TM * 3], sG[PM_TM * 3];
-  __shared__ int s_cnt[2][BW_CH][4];
+  __shared__ int s_cnt[BW_CH][4];
+  __shared__ unsigned long long s_present;  // points of this tile that receive any gradient
+  __shared__ int s_rowmap[PM_TM];           // compact index -> point
   float *sD = reinterpret_cast<float *>(sD4), *sE = reinterpret_cast<float *>(sEF4), *sF = sE + PM_TM * PM_L64;
-  int2 *list = reinterpret_cast<int2 *>(sEF4);  // [2][256 * BW_CH] (channel | point << 16, gradient bits); dead before sE/sF are written
+  int2 *list = reinterpret_cast<int2 *>(sEF4);  // [256 * BW_CH] (channel | point << 16, gradient bits); dead before sE/sF are written
   const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, n0 = tile * PM_TM, N = a.N, Cout = a.Cout;
   const int rows = min(PM_TM, N - n0);
   const size_t row0 = (size_t)b * N + n0;
@@ -245,29 +247,21 @@ __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
   const int r = lane & 31, h = lane >> 5;
   const int rb = wave & 1, cb = wave >> 1;
 
-  // ---- which channels route their gradient into this tile (ordered compaction, ascending channel)
+  if (threadIdx.x == 0) s_present = 0ull;
+  __syncthreads();
+  // ---- global requests, oldest first: the arg-max table (needed first), then everything the chain will need
   int mn[BW_CH];
   float mg[BW_CH];
-  unsigned rank[BW_CH];
 #pragma unroll
   for (int ch = 0; ch < BW_CH; ++ch) {
     const int j = ch * 256 + threadIdx.x;
-    int n = -1;
-    float g = 0.f;
+    mn[ch] = -1;
+    mg[ch] = 0.f;
     if (j < Cout) {
-      n = (int)a.idx[(size_t)b * Cout + j] - n0;
-      g = a.dg[(size_t)b * Cout + j];
-      if (a.gmask != nullptr) g = a.gmask[(size_t)b * Cout + j] > 0.f ? g : 0.f;
+      mn[ch] = (int)a.idx[(size_t)b * Cout + j] - n0;
+      mg[ch] = a.dg[(size_t)b * Cout + j];
+      if (a.gmask != nullptr) mg[ch] = a.gmask[(size_t)b * Cout + j] > 0.f ? mg[ch] : 0.f;
     }
-    const bool hit = n >= 0 && n < rows && g != 0.f;
-    const unsigned long long m0 = __ballot(hit && !(n & 1)), m1 = __ballot(hit && (n & 1));
-    if (lane == 0) {
-      s_cnt[0][ch][wave] = __popcll(m0);
-      s_cnt[1][ch][wave] = __popcll(m1);
-    }
-    mn[ch] = hit ? n : -1;
-    mg[ch] = g;
-    rank[ch] = __popcll(((n & 1) ? m1 : m0) & ((1ull << lane) - 1ull));
   }
   // ---- everything else this block will need from global memory, requested now
   float w2[64], w1[32];
@@ -284,54 +278,83 @@ __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
     mhv[e] = (STAGE == 1 && in) ? a.H1[o] : 0.f;
     dhv[e] = (STAGE == 1 && in) ? a.dH1in[o] : 0.f;
   }
-  float4 a2[8], h1t[4];
+  float4 a2[8];  // ReLU mask of the 64->128 layer
   fetch_tile<128>(a.A2 + row0 * 128, rows, a2);
-  if (STAGE == 2) fetch_tile<64>(a.H1 + row0 * 64, rows, h1t);
-  if (STAGE == 1 && threadIdx.x < 192) {
-    const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
-    sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
-  }
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int e = threadIdx.x + 256 * u;
     *reinterpret_cast<float4 *>(sD + (e >> 5) * PM_L128 + 4 * (e & 31)) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __syncthreads();
-  int total[2];
+  float4 h1t[4];
+  if (STAGE == 2) fetch_tile<64>(a.H1 + row0 * 64, rows, h1t);
+  if (STAGE == 1 && threadIdx.x < 192) {
+    const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+    sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
+  }
+  // ---- which channels route their gradient into this tile: ordered compaction (ascending channel) into one list
+  unsigned rank[BW_CH];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    int run = 0;
-#pragma unroll
-    for (int ch = 0; ch < BW_CH; ++ch)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int c = s_cnt[p][ch][w];
-        if (w == wave && mn[ch] >= 0 && (mn[ch] & 1) == p)
-          list[p * 256 * BW_CH + run + rank[ch]] = make_int2((ch * 256 + (int)threadIdx.x) | (mn[ch] << 16), __float_as_int(mg[ch]));
-        run += c;
-      }
-    total[p] = run;
+  for (int ch = 0; ch < BW_CH; ++ch) {
+    const int n = mn[ch];
+    const bool hit = n >= 0 && n < rows && mg[ch] != 0.f;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_cnt[ch][wave] = __popcll(m);
+    if (hit) atomicOr(&s_present, 1ull << n);  // integer OR: order-independent
+    mn[ch] = hit ? n : -1;
+    rank[ch] = __popcll(m & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-  {  // ---- gather: half-block p takes the points of parity p, one column per thread, channels in list order
-    const int p = threadIdx.x >> 7, c = threadIdx.x & 127;
-    const int cnt = p ? total[1] : total[0];
-    const int2 *L = list + p * 256 * BW_CH;
-    for (int q = 0; q < cnt; q += 8) {
-      int2 en[8];
-      float wv[8];
+  // Only a few points of a tile win any channel (~6 of 64 in the bench workload, one of them often > 100 channels):
+  // points are renumbered 0..D-1 so that the gather below needs one 32-row block (two only if D > 32).
+  const unsigned long long present = s_present;
+  const int D = __popcll(present);
+  if (threadIdx.x < PM_TM && ((present >> threadIdx.x) & 1ull))
+    s_rowmap[__popcll(present & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
+  int M = 0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        en[i] = q + i < cnt ? L[q + i] : make_int2(0, 0);
-        wv[i] = q + i < cnt ? a.W3r[(size_t)(en[i].x & 0xffff) * 128 + c] : 0.f;
+  for (int ch = 0; ch < BW_CH; ++ch)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w == wave && mn[ch] >= 0)
+        list[M + rank[ch]] = make_int2((ch * 256 + (int)threadIdx.x) | (__popcll(present & ((1ull << mn[ch]) - 1ull)) << 16),
+                                       __float_as_int(mg[ch]));
+      M += s_cnt[ch][w];
+    }
+  __syncthreads();
+  {  // ---- gather on the matrix cores:  dA2[D,128] = S[D,M] @ W3r[list,:]  with S[i,k] = g_k if channel k routes to
+     //      the i-th winning point (one non-zero per column, built on the fly from the list).  Wave w owns columns
+     //      32w..32w+31; K runs over the list in order -> a fixed fmaf chain per output, and a point that wins hundreds
+     //      of channels costs M/2 MFMAs per wave instead of a serial chain of dependent row adds.
+    f32x16 acc[2];
+    zero(acc[0]);
+    zero(acc[1]);
+    const float *Wc = a.W3r + 32 * wave + r;
+    const bool two = D > 32;  // block-uniform
+    for (int q = 0; q < M; q += 32) {
+      int2 en[16];
+      float bv[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int k = q + 2 * t + h;
+        en[t] = k < M ? list[k] : make_int2(0, 0);
+        bv[t] = k < M ? Wc[(size_t)(en[t].x & 0xffff) * 128] : 0.f;
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (q + i < cnt) {
-          float *d = sD + (en[i].x >> 16) * PM_L128 + c;
-          *d = fmaf(__int_as_float(en[i].y), wv[i], *d);
-        }
+      for (int t = 0; t < 16; ++t) {
+        const bool ok = q + 2 * t + h < M;
+        const int i = en[t].x >> 16;
+        const float g = __int_as_float(en[t].y);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((ok && i == r) ? g : 0.f, bv[t], acc[0], 0, 0, 0);
+        if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((ok && i == 32 + r) ? g : 0.f, bv[t], acc[1], 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = 32 * q + acc_row(e, h);
+        if (i < D) sD[s_rowmap[i] * PM_L128 + 32 * wave + r] = acc[q][e];
+      }
   }
   __syncthreads();
 #pragma unroll
