@@ -160,10 +160,10 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--concurrent", type=int, default=2,
+    ap.add_argument("--concurrent", type=int, default=3,
                     help="independent attack() batches in flight per GPU (separate HIP streams; 1 = strictly serial)")
     args = ap.parse_args()
 

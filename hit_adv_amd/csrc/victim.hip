@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void max_over_points_merge(const float *__rest
 //             ds_read_b128), double buffered, one barrier per tile; every wave reads the same tile
 //   compute : per tile and wave 2x2 accumulators of 32x32, CIN/2 MFMA steps each
 //   epilogue: accumulator layout = column on the lane, 16 rows in registers -> running (max, first
-//             arg-max) per lane; the two lane halves are merged once at the end.
+//             arg-max) per lane; the two lane halves are merged once at the end.  Two accumulator sets
+//             alternate: the scan of tile t runs between the MFMA groups of tile t+1.
 // Partials [B,S,Cout] go through max_over_points_merge (bias, ReLU, split order = ascending points).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LF_TM = 64;
@@ -205,56 +206,93 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
 
   float bv[2] = {-__builtin_inff(), -__builtin_inff()};
   int bi[2] = {n0, n0};
+  // accumulator element e of tile (rb, cb): row 32*rb + (e&3) + 8*(e>>2) + 4*h, column 32*cb + r
+  auto update = [&](const f32x16 (&acc)[2][2], int tile, int rb, int e, bool ragged) {
+    const int n = n0 + tile * LF_TM + 4 * h + 32 * rb + (e & 3) + 8 * (e >> 2);
+    const bool live = !ragged || n < n1;  // rows past the split's end are zero-filled: keep them out
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const float v = live ? acc[rb][cb][e] : -__builtin_inff();
+      const bool g = v > bv[cb];
+      bv[cb] = g ? v : bv[cb];
+      bi[cb] = g ? n : bi[cb];
+    }
+  };
+  auto epilogue = [&](const f32x16 (&acc)[2][2], int tile) {
+    const bool ragged = n0 + (tile + 1) * LF_TM > n1;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) update(acc, tile, rb, e, ragged);
+  };
+  // One tile of MFMAs into `cur`; the max / arg-max scan of the PREVIOUS tile's accumulators (`prev`, never ragged)
+  // is spread between the MFMA groups so that the VALU work issues in the shadow of the matrix pipe.
+  constexpr int EPJ = 32 / (CIN / 8);  // (rb, e) pairs scanned per K group
+  auto tile_step = [&](f32x16 (&cur)[2][2], int buf, const f32x16 (&prev)[2][2], int prev_tile, bool have_prev) {
+    const float *a = sA + (size_t)buf * LF_TM * LDA + r * LDA + 4 * h;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cur[i][j][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CIN / 8; ++j) {
+      const float4 a0 = *reinterpret_cast<const float4 *>(a + 8 * j);
+      const float4 a1 = *reinterpret_cast<const float4 *>(a + 32 * LDA + 8 * j);
+      const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+      const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = 4 * j + i;
+        cur[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], w[0][t], cur[0][0], 0, 0, 0);
+        cur[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], w[1][t], cur[0][1], 0, 0, 0);
+        cur[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], w[0][t], cur[1][0], 0, 0, 0);
+        cur[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], w[1][t], cur[1][1], 0, 0, 0);
+      }
+      if (have_prev) {
+#pragma unroll
+        for (int u = 0; u < EPJ; ++u) {
+          const int q = EPJ * j + u;
+          update(prev, prev_tile, q >> 4, q & 15, false);
+        }
+      }
+    }
+  };
+
+  f32x16 accA[2][2], accB[2][2];
   fetch(0);
   stash(0);
   __syncthreads();
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const bool more = tile + 1 < ntiles;
-    if (more) fetch(tile + 1);
-    if (active) {
-      const float *a = sA + (size_t)(tile & 1) * LF_TM * LDA + r * LDA + 4 * h;
-      f32x16 acc[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#pragma unroll
-      for (int j = 0; j < CIN / 8; ++j) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(a + 8 * j);
-        const float4 a1 = *reinterpret_cast<const float4 *>(a + 32 * LDA + 8 * j);
-        const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
-        const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int t = 4 * j + i;
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], w[0][t], acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], w[1][t], acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], w[0][t], acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], w[1][t], acc[1][1], 0, 0, 0);
-        }
-      }
-      // accumulator element e of tile (rb, cb): row 32*rb + (e&3) + 8*(e>>2) + 4*h, column 32*cb + r
-      const int nb = n0 + tile * LF_TM + 4 * h;
-      const bool ragged = n0 + (tile + 1) * LF_TM > n1;  // rows past the split's end are zero-filled: keep them out
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int n = nb + 32 * rb + (e & 3) + 8 * (e >> 2);
-          const bool live = !ragged || n < n1;
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            const float v = live ? acc[rb][cb][e] : -__builtin_inff();
-            const bool g = v > bv[cb];
-            bv[cb] = g ? v : bv[cb];
-            bi[cb] = g ? n : bi[cb];
-          }
-        }
-    }
-    if (more) stash((tile + 1) & 1);
+  {  // tile 0: nothing to scan yet
+    const bool more = 1 < ntiles;
+    if (more) fetch(1);
+    if (active) tile_step(accA, 0, accB, 0, false);
+    if (more) stash(1);
     __syncthreads();
+  }
+  int tile = 1;
+  while (true) {
+    if (tile >= ntiles) {
+      if (active) epilogue(accA, tile - 1);
+      break;
+    }
+    bool more = tile + 1 < ntiles;
+    if (more) fetch(tile + 1);
+    if (active) tile_step(accB, 1, accA, tile - 1, true);
+    if (more) stash(0);
+    __syncthreads();
+    ++tile;
+    if (tile >= ntiles) {
+      if (active) epilogue(accB, tile - 1);
+      break;
+    }
+    more = tile + 1 < ntiles;
+    if (more) fetch(tile + 1);
+    if (active) tile_step(accA, 0, accB, tile - 1, true);
+    if (more) stash(1);
+    __syncthreads();
+    ++tile;
   }
   if (!active) return;
 #pragma unroll
@@ -272,7 +310,9 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
 
 static void linear_max_split(int B, int N, int Cout, int *S, int *rows) {
   const int colgroups = (Cout + 255) / 256;
-  int want = (512 + B * colgroups - 1) / (B * colgroups);  // aim at >= 2 blocks per CU
+  // One block per CU and as many 64-point tiles per block as that allows: every block first loads its 32 KB/wave of
+  // W into registers (~4 us), so fewer, longer blocks win (measured at B=32: 256 blocks 75.6 us, 512: 79.9, 1024: 86.5).
+  int want = (256 + B * colgroups - 1) / (B * colgroups);
   const int maxs = (N + LF_TM - 1) / LF_TM;
   want = want < 1 ? 1 : (want > maxs ? maxs : want);
   int per = (N + want - 1) / want;
