@@ -205,6 +205,46 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
   }
 }
 
+// dA2[D,32 columns of this wave] = S[D,M] @ W3r[list,:]: the gather of the max-pool gradient as MFMAs.  S[i,k] = g_k if
+// list entry k routes to the i-th winning point of the tile (one non-zero per column, built on the fly); the list is
+// padded with zero-gradient entries to a multiple of 32, so the loop body is branch-free.  TWO: more than 32 winning
+// points -> a second row block.
+template <bool TWO>
+__device__ __forceinline__ void gather_rows(const int2 *list, int M, const float *__restrict__ Wc, int r, int h,
+                                            f32x16 (&acc)[2]) {
+  if (M <= 0) return;
+  int2 en[16];
+  float bv[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    en[t] = list[2 * t + h];
+    bv[t] = Wc[(size_t)(en[t].x & 0xffff) * 128];
+  }
+  for (int q = 0; q < M; q += 32) {
+    int2 en2[16];
+    float bv2[16];
+    if (q + 32 < M) {  // the next 32 rows of W3r are requested before this batch's MFMAs start
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        en2[t] = list[q + 32 + 2 * t + h];
+        bv2[t] = Wc[(size_t)(en2[t].x & 0xffff) * 128];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = en[t].x >> 16;
+      const float g = __int_as_float(en[t].y);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(i == r ? g : 0.f, bv[t], acc[0], 0, 0, 0);
+      if (TWO) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(i == 32 + r ? g : 0.f, bv[t], acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      en[t] = en2[t];
+      bv[t] = bv2[t];
+    }
+  }
+}
+
 // Backward of a stage, starting from the gradient at the max-pooled output of its 128->Cout layer: the block
 // first GATHERS its 64 points' rows of  dA2[n,:] = sum_{j : argmax[b,j] == n} dg[b,j] * W3r[j,:]  straight into the
 // LDS tile (the max routes each channel's gradient to one point; channels are taken in ascending order -> no
@@ -249,7 +289,7 @@ __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
 
   if (threadIdx.x == 0) s_present = 0ull;
   __syncthreads();
-  // ---- global requests, oldest first: the arg-max table (needed first), then everything the chain will need
+  // ---- the arg-max table of the cloud
   int mn[BW_CH];
   float mg[BW_CH];
 #pragma unroll
@@ -263,30 +303,11 @@ __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
       if (a.gmask != nullptr) mg[ch] = a.gmask[(size_t)b * Cout + j] > 0.f ? mg[ch] : 0.f;
     }
   }
-  // ---- everything else this block will need from global memory, requested now
-  float w2[64], w1[32];
-  load_w<128, false>(a.W2r, 64, 32 * cb, r, h, w2);
-  if (STAGE == 1) load_w<64, false>(a.W1r, 64, 32 * cb, r, h, w1);
-  if (STAGE == 2) load_w<64, true>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1);
-  float m1v[16], mhv[16], dhv[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int n = 32 * rb + acc_row(e, h);
-    const size_t o = (row0 + n) * 64 + 32 * cb + r;
-    const bool in = n < rows;
-    m1v[e] = (STAGE != 2 && in) ? a.A1[o] : 0.f;
-    mhv[e] = (STAGE == 1 && in) ? a.H1[o] : 0.f;
-    dhv[e] = (STAGE == 1 && in) ? a.dH1in[o] : 0.f;
-  }
-  float4 a2[8];  // ReLU mask of the 64->128 layer
-  fetch_tile<128>(a.A2 + row0 * 128, rows, a2);
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int e = threadIdx.x + 256 * u;
     *reinterpret_cast<float4 *>(sD + (e >> 5) * PM_L128 + 4 * (e & 31)) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  float4 h1t[4];
-  if (STAGE == 2) fetch_tile<64>(a.H1 + row0 * 64, rows, h1t);
   if (STAGE == 1 && threadIdx.x < 192) {
     const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
     sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
@@ -320,42 +341,46 @@ __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
                                        __float_as_int(mg[ch]));
       M += s_cnt[ch][w];
     }
+  if (threadIdx.x < 32) list[M + threadIdx.x] = make_int2(0, 0);  // zero-gradient padding to a multiple of 32
   __syncthreads();
-  {  // ---- gather on the matrix cores:  dA2[D,128] = S[D,M] @ W3r[list,:]  with S[i,k] = g_k if channel k routes to
-     //      the i-th winning point (one non-zero per column, built on the fly from the list).  Wave w owns columns
-     //      32w..32w+31; K runs over the list in order -> a fixed fmaf chain per output, and a point that wins hundreds
-     //      of channels costs M/2 MFMAs per wave instead of a serial chain of dependent row adds.
-    f32x16 acc[2];
-    zero(acc[0]);
-    zero(acc[1]);
-    const float *Wc = a.W3r + 32 * wave + r;
-    const bool two = D > 32;  // block-uniform
-    for (int q = 0; q < M; q += 32) {
-      int2 en[16];
-      float bv[16];
+  // ---- gather on the matrix cores:  dA2[D,128] = S[D,M] @ W3r[list,:]  with S[i,k] = g_k if channel k routes to
+  //      the i-th winning point (one non-zero per column, built on the fly from the list).  Wave w owns columns
+  //      32w..32w+31; K runs over the list in order -> a fixed fmaf chain per output, and a point that wins hundreds
+  //      of channels costs M/2 MFMAs per wave instead of a serial chain of dependent row adds.
+  f32x16 gacc[2];
+  zero(gacc[0]);
+  zero(gacc[1]);
+  if (D > 32)  // block-uniform
+    gather_rows<true>(list, M, a.W3r + 32 * wave + r, r, h, gacc);
+  else
+    gather_rows<false>(list, M, a.W3r + 32 * wave + r, r, h, gacc);
+  // ---- everything the chain will need from global memory, requested while the gather's last MFMAs run (the gather
+  //      itself wants the registers: 32 rows of W3r in flight per lane, double buffered)
+  float w2[64], w1[32];
+  load_w<128, false>(a.W2r, 64, 32 * cb, r, h, w2);
+  if (STAGE == 1) load_w<64, false>(a.W1r, 64, 32 * cb, r, h, w1);
+  if (STAGE == 2) load_w<64, true>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1);
+  float m1v[16], mhv[16], dhv[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int k = q + 2 * t + h;
-        en[t] = k < M ? list[k] : make_int2(0, 0);
-        bv[t] = k < M ? Wc[(size_t)(en[t].x & 0xffff) * 128] : 0.f;
-      }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const bool ok = q + 2 * t + h < M;
-        const int i = en[t].x >> 16;
-        const float g = __int_as_float(en[t].y);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((ok && i == r) ? g : 0.f, bv[t], acc[0], 0, 0, 0);
-        if (two) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((ok && i == 32 + r) ? g : 0.f, bv[t], acc[1], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = 32 * q + acc_row(e, h);
-        if (i < D) sD[s_rowmap[i] * PM_L128 + 32 * wave + r] = acc[q][e];
-      }
+  for (int e = 0; e < 16; ++e) {
+    const int n = 32 * rb + acc_row(e, h);
+    const size_t o = (row0 + n) * 64 + 32 * cb + r;
+    const bool in = n < rows;
+    m1v[e] = (STAGE != 2 && in) ? a.A1[o] : 0.f;
+    mhv[e] = (STAGE == 1 && in) ? a.H1[o] : 0.f;
+    dhv[e] = (STAGE == 1 && in) ? a.dH1in[o] : 0.f;
   }
+  float4 a2[8];  // ReLU mask of the 64->128 layer
+  fetch_tile<128>(a.A2 + row0 * 128, rows, a2);
+  float4 h1t[4];
+  if (STAGE == 2) fetch_tile<64>(a.H1 + row0 * 64, rows, h1t);
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = 32 * q + acc_row(e, h);
+      if (i < D) sD[s_rowmap[i] * PM_L128 + 32 * wave + r] = gacc[q][e];
+    }
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < 8; ++u) {  // ReLU of the 64->128 layer

@@ -138,6 +138,28 @@ def main():
         oo = torch.empty(B, NOUT, device='cuda')
         us = timed(lambda s=s0: lib.hitadv_fc_layer(p(xin), p(xin), p(wt), p(bo), B, K, NOUT, 1, p(oo), p(fcs), s), a.reps)
         out['fc_layer_%dx%d' % (K, NOUT)] = dict(us=round(us, 2))
+    # rowmlp_bwd stage 0 with the arg-max table of a real forward pass (hot points) and with a uniform one
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    torch.manual_seed(0)
+    view = PointNetFeatureModel(40, normal_channel=False).cuda().eval().attack_view()
+    xin3 = x.transpose(1, 2).contiguous()
+    R = B * N
+    a1s, a2s = torch.empty(R, 64, device='cuda'), torch.empty(R, 128, device='cuda')
+    ops.pointnet_rowmlp_fwd(0, B, N, view.s2_w, view.s2_b, a2s, x=xin3, W0=view.s1_w, b0=view.s1_b, o0=a1s)
+    gs, js = ops.linear_max_fwd(a2s, view.s3_w, B, N, bias=view.s3_b, relu=True)
+    dgs = torch.randn(B, 1024, generator=g).cuda()
+    dpin, dx = torch.zeros(B, 3, N, device='cuda'), torch.empty(B, 3, N, device='cuda')
+    ju = (torch.arange(1024, device='cuda') % N).expand(B, 1024).contiguous()
+    ones = torch.ones(B, 1024, device='cuda')
+    for name, jj, gm in (('real_argmax', js, gs), ('uniform_argmax', ju, ones)):
+        us = timed(lambda s=s0: lib.hitadv_pointnet_rowmlp_bwd(0, p(dgs), p(gm), p(jj), p(view.s3_wr), 1024, p(a2s),
+                                                               p(view.s2_wr), p(a1s), None, None, None, p(view.s1_wr),
+                                                               None, None, p(dpin), None, p(dx), B, N, s), a.reps)
+        out['rowmlp_bwd0_' + name] = dict(us=round(us, 2))
+    us = timed(lambda s=s0: lib.hitadv_pointnet_rowmlp_fwd(0, p(xin3), None, None, p(view.s1_w), p(view.s1_b), None, None,
+                                                           p(view.s2_w), p(view.s2_b), None, p(a1s), None, p(a2s), B, N, s),
+               a.reps)
+    out['rowmlp_fwd0'] = dict(us=round(us, 2))
     print(json.dumps(out))
 
 
