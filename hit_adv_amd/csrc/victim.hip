@@ -161,7 +161,7 @@ constexpr int LF_TM = 64;
 
 template <int CIN>
 __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict__ X, const float *__restrict__ Wt,
-                                                        int N, int Cout, int rows_per_split,
+                                                        int B_, int N, int Cout, int rows_per_split, int S, int ncg,
                                                         float *__restrict__ pval, int32_t *__restrict__ pidx) {
   constexpr int LDA = CIN + 4;
   constexpr int KS = CIN / 2;            // MFMA steps per output tile
@@ -169,7 +169,24 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
   constexpr int ST = LF_TM * F4_ROW / 256;  // float4 staged per thread per tile
   extern __shared__ float4 sA4[];        // 2 x LF_TM x LDA floats
   float *sA = reinterpret_cast<float *>(sA4);
-  const int cg = blockIdx.x, s = blockIdx.y, b = blockIdx.z, S = gridDim.y;
+  // XCD-aware block order: consecutive workgroup ids go to consecutive XCDs (8, each with its own L2), and the NCG
+  // column-group blocks of one (cloud, split) all stream the SAME x tiles -> they are given ids that are congruent
+  // mod 8, so the tiles come from HBM once and from that XCD's L2 three more times (PMC: 70 MB -> see DESIGN.md).
+  int cg, s, b;
+  {
+    const int NCG = ncg, id = blockIdx.x, nrg = S * B_;
+    if ((nrg & 7) == 0) {
+      const int xcd = id & 7, slot = id >> 3;
+      cg = slot % NCG;
+      const int rg = (slot / NCG) * 8 + xcd;
+      s = rg % S;
+      b = rg / S;
+    } else {
+      cg = id % NCG;
+      s = (id / NCG) % S;
+      b = id / (NCG * S);
+    }
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int col0 = cg * 256 + wave * 64;
@@ -368,15 +385,16 @@ extern "C" int hitadv_linear_max_fwd(const float *X, const float *Wt, const floa
   hipStream_t s = (hipStream_t)stream;
   int S, rows;
   linear_max_split(B, N, Cout, &S, &rows);
-  dim3 grid((Cout + 255) / 256, S, B);
+  const int ncg = (Cout + 255) / 256;
+  dim3 grid((unsigned)(ncg * S * B));
   const size_t shm = (size_t)2 * LF_TM * (Cin + 4) * sizeof(float);
   if (Cin == 128) {
     static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_TM * 132 * 4);
     (void)once;
-    linear_max_fwd_k<128><<<grid, 256, shm, s>>>(X, Wt, N, Cout, rows, part_val, part_idx);
+    linear_max_fwd_k<128><<<grid, 256, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx);
   } else {
-    linear_max_fwd_k<64><<<grid, 256, shm, s>>>(X, Wt, N, Cout, rows, part_val, part_idx);
+    linear_max_fwd_k<64><<<grid, 256, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx);
   }
   const long long total = (long long)B * Cout;
   max_over_points_merge<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part_val, part_idx, Cout, S, bias, relu, out,
