@@ -119,10 +119,25 @@ def hot_loop_kernels(dev):
         torch.cuda.synchronize()
         return round(t0.elapsed_time(t1) * 1e3 / reps, 2)
 
-    return {"deform_fwd_us": timed(lambda: lib.hitadv_deform_fwd(p(ori), p(central), p(P), p(sig), B, N, C, p(adv), p(inv), s)),
-            "deform_bwd_us": timed(lambda: lib.hitadv_deform_bwd(p(ori), p(central), p(P), p(sig), p(adv), p(inv), p(up),
-                                                                 B, N, C, p(part), p(gp), p(gs), s)),
-            "pairs_per_launch": B * N * C}
+    out = {"deform_fwd_us": timed(lambda: lib.hitadv_deform_fwd(p(ori), p(central), p(P), p(sig), B, N, C, p(adv), p(inv), s)),
+           "deform_bwd_us": timed(lambda: lib.hitadv_deform_bwd(p(ori), p(central), p(P), p(sig), p(adv), p(inv), p(up),
+                                                                B, N, C, p(part), p(gp), p(gs), s)),
+           "pairs_per_launch": B * N * C}
+    # the kernel that dominates the loop (37 % of its device time): the victim's 128->1024 shared layer fused with the
+    # max over points, on the f32 matrix cores (157.3 TFLOP/s dense f32 MFMA peak, MI355X_MICROARCH.md)
+    h2 = torch.randn(B * N, 128, generator=g).to(dev)
+    Wt = (torch.randn(128, 1024, generator=g) * 0.1).to(dev)
+    bias = torch.randn(1024, generator=g).to(dev)
+    n = lib.hitadv_linear_max_fwd_scratch(B, N, 1024)
+    pv, pi = torch.empty(n, device=dev), torch.empty(n, device=dev, dtype=torch.int32)
+    mo, mi = torch.empty(B, 1024, device=dev), torch.empty(B, 1024, device=dev, dtype=torch.int64)
+    us = timed(lambda: lib.hitadv_linear_max_fwd(p(h2), p(Wt), p(bias), B, N, 128, 1024, 1, p(pv), p(pi), p(mo), p(mi), s),
+               reps=400)
+    flops = 2.0 * B * N * 128 * 1024
+    out["linear_max_fwd"] = {"bound": "mfma", "us_per_launch": us, "achieved": round(flops / us / 1e6, 1), "peak": 157.3,
+                             "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / 157.3, 4), "dtype": "f32",
+                             "flops_per_launch": flops}
+    return out
 
 
 def cpu_baseline():
