@@ -1,0 +1,17 @@
+"""Targeted AdvPC attack, interface of the reference's CW/AdvPC.py::CWAdvPC (ctor :14-38, attack :40-180)."""
+from ._family import _CWFamily
+
+
+class CWAdvPC(_CWFamily):
+    """Class for CW AdvPC attack (targeted: success means ``pred == target`` while the auto-encoder view leaves ``y_truth``)."""
+    targeted = True
+    fresh = True  # predictions re-evaluated without grad after the clip (:113-124)
+
+    def __init__(self, model, ae_model, adv_func, dist_func, attack_lr=1e-2, binary_step=2, num_iter=200, GAMMA=0.5,
+                 clip_func=None, verbose=True):
+        self._setup(model, adv_func, dist_func, attack_lr, binary_step, num_iter, GAMMA, clip_func, verbose,
+                    ae_model=ae_model)
+
+    def attack(self, data, target, y_truth):
+        """data [B,num_points,3], target [B], y_truth [B] -> (o_bestdist float64 [B], float32 [B,num_points,3], successes)."""
+        return self._run(data, target, y_truth)

@@ -32,15 +32,18 @@ class CWPerturb:
         out = self.model(self.pre_head(x)) if self.pre_head is not None else self.model(x)
         return out[0] if isinstance(out, tuple) else out
 
-    def attack(self, data, target):
+    def attack(self, data, target, _channel_first=False):
         """data [B,num_points,3 or 6] (or channel-first [B,3|6,num_points>6]), target [B]
         -> (float64 ndarray [B,num_points,3], number of samples with a successful step)."""
         B, K = data.shape[:2]
         data = data.float().cuda().detach()
-        if data.shape[1] > 6:
-            data = data.transpose(1, 2).contiguous()
-        if data.shape[1] == 6:
-            data = data[:, :3, :]
+        if _channel_first:  # CWPerturbT hands over [B,3,num_points] (PerturbT.py:53)
+            K = data.shape[2]
+        else:
+            if data.shape[1] > 6:
+                data = data.transpose(1, 2).contiguous()
+            if data.shape[1] == 6:
+                data = data[:, :3, :]
         ori = data.clone().detach().contiguous()
         target = target.long().cuda().detach()
         dev = ori.device

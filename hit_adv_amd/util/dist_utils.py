@@ -126,3 +126,98 @@ class CurvStdDist(nn.Module):
         a = curvature_std(ori_data, ori_normal, self.k)[0]
         b = curvature_std(adv_data, ori_normal, self.k)[0]
         return torch.nn.PairwiseDistance(p=2)(a, b).mean()
+
+
+class LaplacianDist(nn.Module):
+    """util/dist_utils.py:178-229: sum over every point's k neighbours of |delta_neighbour|^2 (delta = adv - ori,
+    [B,3,K]; ``nearest_indices`` [B,K,k] from ``KNN_indices``).  The neighbour search runs on the HIP kNN kernel
+    (fp32 direct form) where the reference builds a float64 Gram matrix and a full top-k."""
+
+    def __init__(self, k):
+        super().__init__()
+        self.k = k
+
+    def forward(self, adv_pc, ori_pc, nearest_indices, weights=None, batch_avg=True):
+        delta = adv_pc - ori_pc  # [B,3,K]
+        B, _, K = delta.shape
+        k = nearest_indices.shape[2]
+        nbr = torch.gather(delta, 2, nearest_indices.reshape(B, 1, K * k).expand(-1, 3, -1))  # [B,3,K*k]
+        dist = torch.sum(torch.norm(nbr.view(B, 3, K, k), dim=1) ** 2, dim=[1, 2])
+        return _apply_weights(dist, weights, batch_avg)
+
+    def KNN_indices(self, x):
+        """x [B,3,K] -> (squared distances [B,K,k] float64, indices [B,K,k]) of the k nearest other points."""
+        pts = x.clone().detach().float().transpose(2, 1).contiguous()
+        nn_ = knn_points(pts, pts, K=self.k + 1)
+        return nn_.dists[..., 1:].double(), nn_.idx[..., 1:]
+
+
+class FarthestDist(nn.Module):
+    """util/dist_utils.py:297-325: per added cluster the largest pairwise point distance, summed over clusters.
+    adv_pc [B,num_add,cl_num_p,3]."""
+
+    def forward(self, adv_pc, weights=None, batch_avg=True):
+        delta = adv_pc[:, :, None, :, :] - adv_pc[:, :, :, None, :] + 1e-7
+        norm = torch.norm(delta, p=2, dim=-1)  # [B,na,np,np]
+        far = norm.max(dim=2)[0].max(dim=2)[0].sum(dim=1)
+        return _apply_weights(far, weights, batch_avg)
+
+
+class FarChamferDist(nn.Module):
+    """util/dist_utils.py:328-365 (constraint of the adding-clusters attack)."""
+
+    def __init__(self, num_add, chamfer_method='adv2ori', chamfer_weight=0.1):
+        super().__init__()
+        self.num_add = num_add
+        self.far_dist = FarthestDist()
+        self.chamfer_dist = ChamferDist(method=chamfer_method)
+        self.cd_w = chamfer_weight
+
+    def forward(self, adv_pc, ori_pc, weights=None, batch_avg=True):
+        B = adv_pc.shape[0]
+        chamfer_loss = self.chamfer_dist(adv_pc, ori_pc, weights=weights, batch_avg=batch_avg)
+        far_loss = self.far_dist(adv_pc.view(B, self.num_add, -1, 3), weights=weights, batch_avg=batch_avg)
+        return far_loss + chamfer_loss * self.cd_w
+
+
+class L2ChamferDist(nn.Module):
+    """util/dist_utils.py:368-409 (constraint of the adding-objects attack)."""
+
+    def __init__(self, num_add, chamfer_method='adv2ori', chamfer_weight=0.2):
+        super().__init__()
+        self.num_add = num_add
+        self.chamfer_dist = ChamferDist(method=chamfer_method)
+        self.cd_w = chamfer_weight
+        self.l2_dist = L2Dist()
+
+    def forward(self, adv_pc, ori_pc, adv_obj, ori_obj, weights=None, batch_avg=True):
+        B = adv_pc.shape[0]
+        chamfer_loss = self.chamfer_dist(adv_pc, ori_pc, weights=weights, batch_avg=batch_avg)
+        l2_loss = self.l2_dist(adv_obj.view(B, -1, 3), ori_obj.view(B, -1, 3), weights=weights, batch_avg=batch_avg)
+        return l2_loss + self.cd_w * chamfer_loss
+
+
+class CurvDist(nn.Module):
+    """util/dist_utils.py:498-561 (GeoA3's curvature consistency): mean_n (kappa_adv(n) - kappa_ori(nn_ori(n)))^2, the
+    adversarial curvature measured against the normal of the nearest original point.  All three neighbour searches
+    are HIP kNN launches."""
+
+    def __init__(self, curv_loss_knn=2):
+        super().__init__()
+        self.curv_loss_knn = curv_loss_knn
+
+    @staticmethod
+    def _kappa(pc, normal, k):
+        pts = pc.permute(0, 2, 1).contiguous()
+        nbr = knn_gather(pts, knn_points(pts, pts, K=k + 1).idx)[:, :, 1:, :]  # [B,N,k,3]
+        vec = nbr - pts.unsqueeze(2)
+        vec = vec / vec.norm(2, dim=3, keepdim=True).clamp(min=1e-12)
+        return (vec * normal.permute(0, 2, 1).unsqueeze(2)).sum(3).abs().mean(2)
+
+    def forward(self, ori_data, adv_data, ori_normal):
+        ori_kappa = self._kappa(ori_data, ori_normal, 2)  # the reference's _get_kappa_ori default k=2 (:506,510)
+        adv_pts = adv_data.permute(0, 2, 1).contiguous()
+        nn_idx = knn_points(adv_pts, ori_data.permute(0, 2, 1).contiguous(), K=1).idx  # [B,N,1]
+        normal = knn_gather(ori_normal.permute(0, 2, 1).contiguous(), nn_idx).squeeze(2).permute(0, 2, 1)
+        adv_kappa = self._kappa(adv_data, normal, self.curv_loss_knn)
+        return ((adv_kappa - torch.gather(ori_kappa, 1, nn_idx.squeeze(-1))) ** 2).mean(-1).mean()

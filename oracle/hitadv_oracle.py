@@ -560,15 +560,18 @@ def cw_knn_attack(model, adv_func, dist_func, clip_func, data, target, attack_lr
 
 
 def cw_perturb_attack(model, adv_func, dist_func, data, target, attack_lr=1e-2, init_weight=10.,
-                      max_weight=80., binary_step=10, num_iter=500, clip_func=None, trace=None):
+                      max_weight=80., binary_step=10, num_iter=500, clip_func=None, trace=None, _n_points=None):
     """CPU restatement of CW/Perturb.py::CWPerturb.attack (:46-202), host-side bookkeeping as in the
     reference (numpy float64 bounds, strict '<' best tracking, success = pred == target)."""
     B, N = data.shape[:2]
     pc = data.float().detach()
-    if pc.shape[1] > 6:
-        pc = pc.transpose(1, 2).contiguous()
-    if pc.shape[1] == 6:
-        pc = pc[:, :3, :]
+    if _n_points is not None:  # CWPerturbT: the caller already transposed to [B,3,N] (PerturbT.py:53)
+        N = _n_points
+    else:
+        if pc.shape[1] > 6:
+            pc = pc.transpose(1, 2).contiguous()
+        if pc.shape[1] == 6:
+            pc = pc[:, :3, :]
     ori = pc.clone().detach()
     target = target.long().detach()
     label = target.numpy()
@@ -686,6 +689,286 @@ def cw_aof_attack(model, adv_func, clip_func, data, target, attack_lr=1e-2, bina
     success = (torch.argmax(logits_of(adv_pc), dim=-1) != target).sum().item()
     return adv_pc.detach().numpy().transpose((0, 2, 1)), success
 
+
+
+def cw_perturbt_attack(model, adv_func, dist_func, data, target, **kw):
+    """CW/PerturbT.py::CWPerturbT.attack (:44-183) = CWPerturb.attack on the always-transposed input (:53), no pre_head."""
+    return cw_perturb_attack(model, adv_func, dist_func, data.transpose(1, 2).contiguous(), target,
+                             _n_points=data.shape[1], **kw)
+
+
+def cw_family_attack(model, adv_func, clip_func, data, target, y_truth=None, ae_model=None, spectral=False,
+                     targeted=False, fresh=True, final_clip=True, attack_lr=1e-2, binary_step=2, num_iter=200,
+                     GAMMA=0.5, low_pass=100, trace=None):
+    """CPU restatement of the four un-weighted CW variants (host-side numpy bookkeeping as in the reference):
+      CW/AdvPC.py::CWAdvPC.attack    (:40-180)  ae_model, targeted, fresh
+      CW/UAdvPC.py::CWUAdvPC.attack  (:40-167)  ae_model
+      CW/TAOF.py::CWTAOF.attack      (:83-242)  spectral, targeted, fresh, no final clip
+      CW/UAEAOF.py::CWUAEAOF.attack  (:85-241)  spectral, ae_model
+    Order of the backward calls as in the reference: full cloud, auto-encoder view, low-frequency view."""
+    B, N = data.shape[:2]
+    ori = data.float().detach().transpose(1, 2).contiguous().clone()
+    target = target.long().detach()
+    label = target.numpy()
+    y = y_truth.long().numpy() if y_truth is not None else None
+    o_bestdist, o_bestscore = np.array([1e10] * B), np.array([-1] * B)
+    o_bestattack = np.zeros((B, 3, N))
+    input_val = None
+    if spectral and ae_model is not None:
+        w_full, w_lfc, w_ae = 1 - 2 * GAMMA, GAMMA, GAMMA
+    elif spectral:
+        w_full, w_lfc, w_ae = 1 - GAMMA, GAMMA, 0.
+    else:
+        w_full, w_lfc, w_ae = 1 - GAMMA, 0., GAMMA
+
+    def logits_of(x):
+        out = model(x)
+        return out[0] if isinstance(out, tuple) else out
+
+    for step in range(binary_step):
+        adv = ori.clone().detach() + torch.randn((B, 3, N)) * 1e-7
+        if spectral:
+            _, V = laplace_eig(adv)
+            projs = torch.bmm(adv, V)
+            hfc = torch.bmm(projs[..., low_pass:], V[..., low_pass:].transpose(2, 1)).detach().clone()
+            var = torch.bmm(projs[..., :low_pass], V[..., :low_pass].transpose(2, 1)).detach().clone().requires_grad_()
+        else:
+            var, hfc = adv.requires_grad_(), None
+        opt = torch.optim.Adam([var], lr=attack_lr, weight_decay=0.)
+        for it in range(num_iter):
+            full = var + hfc if spectral else var
+            logits = logits_of(full)
+            opt.zero_grad()
+            (w_full * adv_func(logits, target).mean()).backward()
+            ae_logits = lfc_logits = None
+            if ae_model is not None:
+                ae_logits = logits_of(ae_model(full))
+                (w_ae * adv_func(ae_logits, target).mean()).backward()
+            if spectral:
+                lfc_logits = logits_of(var)
+                (w_lfc * adv_func(lfc_logits, target).mean()).backward()
+            opt.step()
+            with torch.no_grad():
+                adv = clip_func((var + hfc if spectral else var).detach().clone(), ori)
+                if spectral:
+                    coeff = torch.bmm(adv, V)
+                    hfc.data = torch.bmm(coeff[..., low_pass:], V[..., low_pass:].transpose(2, 1))
+                    var.data = torch.bmm(coeff[..., :low_pass], V[..., :low_pass].transpose(2, 1))
+                else:
+                    var.data = adv
+                if fresh:
+                    pred = torch.argmax(logits_of(adv), dim=1).numpy()
+                    lfc_pred = torch.argmax(logits_of(var), dim=1).numpy() if spectral else None
+                    ae_pred = torch.argmax(logits_of(ae_model(adv)), dim=1).numpy() if ae_model is not None else None
+                else:
+                    pred = torch.argmax(logits, dim=1).numpy()
+                    lfc_pred = torch.argmax(lfc_logits, dim=1).numpy() if spectral else None
+                    ae_pred = torch.argmax(ae_logits, dim=1).numpy() if ae_model is not None else None
+            dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2])).numpy()
+            input_val = adv.detach().numpy().copy()
+            for e in range(B):
+                other = lfc_pred if spectral else ae_pred
+                if targeted:
+                    ok = pred[e] == label[e] and other[e] != y[e]
+                elif spectral and ae_model is not None:
+                    ok = pred[e] != label[e] and lfc_pred[e] != label[e] and ae_pred[e] != label[e]
+                else:
+                    ok = pred[e] != label[e] and (other[e] != label[e] or GAMMA < 0.001)
+                if dist_val[e] < o_bestdist[e] and ok:
+                    o_bestdist[e], o_bestscore[e] = dist_val[e], pred[e]
+                    o_bestattack[e] = input_val[e]
+            if trace is not None:
+                trace.append(dict(step=step, it=it, adv=input_val.copy()))
+    fail = o_bestscore < 0
+    o_bestattack[fail] = input_val[fail]
+    adv_pc = torch.tensor(o_bestattack).to(ori)
+    if final_clip:
+        adv_pc = clip_func(adv_pc, ori)
+    preds = torch.argmax(logits_of(adv_pc), dim=-1)
+    success = ((preds == target) if targeted else (preds != target)).sum().item()
+    return o_bestdist, adv_pc.detach().numpy().transpose((0, 2, 1)), success
+
+
+def critical_points(model, pc, label, num):
+    """CW/Add.py::get_critical_points (:14-43): the ``num`` points with the largest squared input gradient of the CE."""
+    x = pc.clone().detach().float().requires_grad_()
+    out = model(x)
+    logits = out[0] if isinstance(out, tuple) else out
+    torch.nn.functional.cross_entropy(logits, label.long()).backward()
+    _, idx = torch.sum(x.grad.data ** 2, dim=1).topk(k=num, dim=-1)
+    return torch.stack([pc[i, :, idx[i]] for i in range(label.shape[0])], dim=0).clone().detach()
+
+
+def cw_add_attack(model, adv_func, dist_func, data, target, init_points, attack_lr=1e-2, init_weight=5e3,
+                  max_weight=4e4, binary_step=10, num_iter=500):
+    """CPU restatement of CW/Add.py::CWAdd.attack (:79-220) and, with ``init_points`` = the flattened cluster
+    initialisation, of CW/Add_Cluster.py::CWAddClusters.attack (:132-278).  dist_func(adv[B,n,3], ori[B,K,3], weights=,
+    batch_avg=)."""
+    B, N = data.shape[:2]
+    ori = data.float().detach().transpose(1, 2).contiguous()
+    target = target.long().detach()
+    label = target.numpy()
+    lower, upper = np.zeros((B,)), np.ones((B,)) * max_weight
+    weight = np.ones((B,)) * init_weight
+    o_bestdist, o_bestscore = np.array([1e10] * B), np.array([-1] * B)
+    n_add = init_points.shape[2]
+    o_bestattack = np.zeros((B, 3, n_add))
+    input_val = None
+    for step in range(binary_step):
+        adv = (init_points + torch.randn((B, 3, n_add)) * 1e-7).requires_grad_()
+        bestdist, bestscore = np.array([1e10] * B), np.array([-1] * B)
+        opt = torch.optim.Adam([adv], lr=attack_lr, weight_decay=0.)
+        for it in range(num_iter):
+            out = model(torch.cat([ori, adv], dim=-1))
+            logits = out[0] if isinstance(out, tuple) else out
+            pred = torch.argmax(logits, dim=-1).numpy()
+            dist_val = dist_func(adv.transpose(1, 2).contiguous(), ori.transpose(1, 2).contiguous(),
+                                 batch_avg=False).detach().numpy()
+            input_val = adv.detach().numpy().copy()
+            for e in range(B):
+                if pred[e] == label[e]:
+                    if dist_val[e] < bestdist[e]:
+                        bestdist[e], bestscore[e] = dist_val[e], pred[e]
+                    if dist_val[e] < o_bestdist[e]:
+                        o_bestdist[e], o_bestscore[e] = dist_val[e], pred[e]
+                        o_bestattack[e] = input_val[e]
+            adv_loss = adv_func(logits, target).mean()
+            dist_loss = dist_func(adv.transpose(1, 2).contiguous(), ori.transpose(1, 2).contiguous(),
+                                  weights=torch.from_numpy(weight)).mean()
+            opt.zero_grad()
+            (adv_loss + dist_loss).backward()
+            opt.step()
+        for e in range(B):
+            if bestscore[e] == label[e] and bestscore[e] != -1 and bestdist[e] <= o_bestdist[e]:
+                lower[e] = max(lower[e], weight[e])
+            else:
+                upper[e] = min(upper[e], weight[e])
+            weight[e] = (lower[e] + upper[e]) / 2.
+    fail = lower == 0.
+    o_bestattack[fail] = input_val[fail]
+    out = np.concatenate([ori.numpy(), o_bestattack], axis=-1)
+    return o_bestdist, out.transpose((0, 2, 1)), int((lower > 0.).sum())
+
+
+
+def cw_add_objects_attack(model, adv_func, dist_func, data, target, object_pc, centers, attack_lr=1e-2, init_weight=5.,
+                          max_weight=40., binary_step=5, num_iter=500):
+    """CPU restatement of CW/Add_Objects.py::CWAddObjects.attack (:187-367) given the processed ``object_pc``
+    [num_add,obj_num_p,3] (ctor :88-92) and the cluster ``centers`` [B,num_add,3] (``_init_centers`` :100-146).
+    dist_func(adv[B,n,3], ori[B,K,3], adv_obj, ori_obj, weights=, batch_avg=)."""
+    B, N = data.shape[:2]
+    num_add, obj_num_p = object_pc.shape[:2]
+    ori = data.float().detach().transpose(1, 2).contiguous()
+    target = target.long().detach()
+    label = target.numpy()
+    lower, upper = np.zeros((B,)), np.ones((B,)) * max_weight
+    weight = np.ones((B,)) * init_weight
+    o_bestdist, o_bestscore = np.array([1e10] * B), np.array([-1] * B)
+    n_add = num_add * obj_num_p
+    o_bestattack = np.zeros((B, 3, n_add))
+    shifts = torch.from_numpy(np.asarray(centers)).float()
+    objects = torch.from_numpy(np.tile(object_pc, (B, 1, 1, 1))).float()
+    input_val = None
+
+    def rotate_shift(points, angles, sh):  # :148-185, rotation about y by angles[...,0]
+        c, s_ = torch.cos(angles[..., 0]), torch.sin(angles[..., 0])
+        z, o = torch.zeros_like(c), torch.ones_like(c)
+        rot = torch.stack([c, z, s_, z, o, z, -s_, z, c], dim=-1).view(B * num_add, 3, 3)
+        return torch.bmm(points.view(B * num_add, obj_num_p, 3), rot).view(B, num_add, obj_num_p, 3) + sh[:, :, None, :]
+
+    for step in range(binary_step):
+        adv_objects = (objects + torch.randn((B, num_add, obj_num_p, 3)) * 1e-7).requires_grad_()
+        adv_shifts = (shifts + torch.randn((B, num_add, 3)) * 1e-7).requires_grad_()
+        adv_angles = (torch.rand((B, num_add, 3)) * np.pi).requires_grad_()
+        bestdist, bestscore = np.array([1e10] * B), np.array([-1] * B)
+        opt = torch.optim.Adam([adv_objects, adv_shifts, adv_angles], lr=attack_lr, weight_decay=0.)
+        for it in range(num_iter):
+            adv = rotate_shift(adv_objects, adv_angles, adv_shifts).view(B, n_add, 3).transpose(1, 2).contiguous()
+            out = model(torch.cat([ori, adv], dim=-1))
+            logits = out[0] if isinstance(out, tuple) else out
+            pred = torch.argmax(logits, dim=-1).numpy()
+            adv_t, ori_t = adv.transpose(1, 2).contiguous(), ori.transpose(1, 2).contiguous()
+            dist_val = dist_func(adv_t, ori_t, adv_objects, objects, batch_avg=False).detach().numpy()
+            input_val = adv.detach().numpy().copy()
+            for e in range(B):
+                if pred[e] == label[e]:
+                    if dist_val[e] < bestdist[e]:
+                        bestdist[e], bestscore[e] = dist_val[e], pred[e]
+                    if dist_val[e] < o_bestdist[e]:
+                        o_bestdist[e], o_bestscore[e] = dist_val[e], pred[e]
+                        o_bestattack[e] = input_val[e]
+            adv_loss = adv_func(logits, target).mean()
+            dist_loss = dist_func(adv_t, ori_t, adv_objects, objects, weights=torch.from_numpy(weight)).mean()
+            opt.zero_grad()
+            (adv_loss + dist_loss).backward()
+            opt.step()
+            with torch.no_grad():
+                adv_angles.data = adv_angles.data % (2. * np.pi)
+        for e in range(B):
+            if bestscore[e] == label[e] and bestscore[e] != -1 and bestdist[e] <= o_bestdist[e]:
+                lower[e] = max(lower[e], weight[e])
+            else:
+                upper[e] = min(upper[e], weight[e])
+            weight[e] = (lower[e] + upper[e]) / 2.
+    fail = lower == 0.
+    o_bestattack[fail] = input_val[fail]
+    out = np.concatenate([ori.numpy(), o_bestattack], axis=-1)
+    return o_bestdist, out.transpose((0, 2, 1)), int((lower > 0.).sum())
+
+# --------------------------------------------------------------------------
+# remaining distance operators               util/dist_utils.py:178-229, 297-409, 498-561
+# --------------------------------------------------------------------------
+
+
+def laplacian_knn_indices(x, k):
+    """LaplacianDist.KNN_indices (:217-229): float64 Gram distances, top-(k+1), self dropped."""
+    pc = x.clone().detach().double()
+    inner = -2. * torch.matmul(pc.transpose(2, 1), pc)
+    xx = torch.sum(pc ** 2, dim=1, keepdim=True)
+    dist = xx + inner + xx.transpose(2, 1)
+    neg_value, idx = (-dist).topk(k=k + 1, dim=-1)
+    return -(neg_value[..., 1:]), idx[..., 1:]
+
+
+def laplacian_dist(adv_pc, ori_pc, nearest_indices, weights=None, batch_avg=True):
+    """LaplacianDist.forward (:186-215)."""
+    delta = adv_pc - ori_pc
+    delta = delta.unsqueeze(3).expand(-1, -1, -1, nearest_indices.shape[2])
+    nbr = torch.gather(delta, 2, nearest_indices.unsqueeze(1).expand(-1, 3, -1, -1))
+    return _weighted(torch.sum(torch.norm(nbr, dim=1) ** 2, dim=[1, 2]), weights, batch_avg)
+
+
+def farthest_dist(adv_pc, weights=None, batch_avg=True):
+    """FarthestDist.forward (:304-325); adv_pc [B,num_add,cl_num_p,3]."""
+    delta = adv_pc[:, :, None, :, :] - adv_pc[:, :, :, None, :] + 1e-7
+    norm = torch.norm(delta, p=2, dim=-1)
+    far = torch.sum(torch.max(torch.max(norm, dim=2)[0], dim=2)[0], dim=1)
+    return _weighted(far, weights, batch_avg)
+
+
+def far_chamfer_dist(adv_pc, ori_pc, num_add, weights=None, batch_avg=True, method='adv2ori', chamfer_weight=0.1):
+    """FarChamferDist.forward (:347-365)."""
+    B = adv_pc.shape[0]
+    return (farthest_dist(adv_pc.view(B, num_add, -1, 3), weights, batch_avg) +
+            chamfer_dist(adv_pc, ori_pc, weights, batch_avg, method) * chamfer_weight)
+
+
+def l2_chamfer_dist(adv_pc, ori_pc, adv_obj, ori_obj, weights=None, batch_avg=True, method='adv2ori',
+                    chamfer_weight=0.2):
+    """L2ChamferDist.forward (:387-409)."""
+    B = adv_pc.shape[0]
+    return (l2_dist(adv_obj.view(B, -1, 3), ori_obj.view(B, -1, 3), weights, batch_avg) +
+            chamfer_weight * chamfer_dist(adv_pc, ori_pc, weights, batch_avg, method))
+
+
+def curv_dist(ori_data, adv_data, ori_normal, curv_loss_knn=2):
+    """CurvDist.forward (:503-508) with the canonical kNN (direct-form distances, ties -> lower index)."""
+    ori_kappa = kappa_ori(ori_data, ori_normal, 2)[0]
+    adv_pts, ori_pts = adv_data.permute(0, 2, 1), ori_data.permute(0, 2, 1)
+    nn_idx = knn_points(adv_pts, ori_pts, 1)[1]
+    normal = knn_gather(ori_normal.permute(0, 2, 1), nn_idx).permute(0, 3, 1, 2).squeeze(3).contiguous()
+    adv_kappa = kappa_ori(adv_data, normal, curv_loss_knn)[0]
+    return ((adv_kappa - torch.gather(ori_kappa, 1, nn_idx.squeeze(-1))) ** 2).mean(-1).mean()
 
 # --------------------------------------------------------------------------
 # eval_ASR metric phase                      util/other_utils.py:15-101

@@ -21,6 +21,9 @@ Fixture index:
   g11_pointnet2.npz    PointNet++ SSG (seeded init + seeded FPS starts): FPS / ball-query tables, logits, input grad
   g12_pct.npz          PCT (seeded init + seeded FPS starts): logits, input gradient, first FPS table
   g13_aof.npz          CWAOF.attack trajectory (torch.symeig served by torch.linalg.eigh) with the toy victim
+  g14..g18             CWPerturbT / CWAdvPC / CWUAdvPC / CWTAOF / CWUAEAOF trajectories (toy victim, toy auto-encoder)
+  g19..g21             CWAdd (Chamfer and Hausdorff) / CWAddClusters / CWAddObjects results
+  g22_dist_more.npz    LaplacianDist, FarthestDist, FarChamferDist, L2ChamferDist, CurvDist values and gradients
   g10_dgcnn.npz        DGCNN_cls (seeded init, eval mode): logits, input gradient, first-layer kNN table
 """
 import io
@@ -484,8 +487,201 @@ def g8():
     print('wrote g8_state_dicts.json', {k: (len(v) if isinstance(v, dict) else v)
                                         for k, v in shapes.items()})
 
+# ------------------------------------------------------------------ G14-G18: the remaining un-weighted CW variants
+class ToyAE(torch.nn.Module):
+    """Stand-in auto-encoder ([B,3,K] -> [B,3,K]); the reference ships none.  Weights are stored in the fixture."""
+
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.Conv1d(3, 8, 1)
+        self.dec = torch.nn.Conv1d(8, 3, 1)
+
+    def forward(self, x):
+        return x + 0.1 * self.dec(torch.tanh(self.enc(x)))
+
+
+def toy_ae(seed):
+    torch.manual_seed(seed)
+    return ToyAE().eval()
+
+
+def _runner_up(model, xyz):
+    """(clean prediction, second-best class): an easy target so that the few iterations of a fixture reach it."""
+    with torch.no_grad():
+        top2 = model(xyz.transpose(1, 2).contiguous()).topk(2, dim=1).indices
+    return top2[:, 0].contiguous(), top2[:, 1].contiguous()
+
+
+def _recording_clip(budget, sink):
+    clip = clip_utils.ClipPointsLinf(budget=budget)
+
+    def rec(pc, ori_pc):
+        r = clip(pc, ori_pc)
+        sink.append(r.detach().clone())
+        return r
+    return rec
+
+
+def _weights(model, prefix):
+    return {prefix + k: v for k, v in model.state_dict().items()}
+
+
+def g14():
+    from CW.PerturbT import CWPerturbT
+    model = toy_victim(21)
+    data, _ = synth_batch(3, 256, first=110)
+    xyz = data[:, :, :3].contiguous()
+    clean, target = _runner_up(model, xyz)
+    advs = []
+    att = CWPerturbT(model, adv_utils.LogitsAdvLoss(kappa=0.), dist_utils.L2Dist(), attack_lr=3e-2, init_weight=10.,
+                     max_weight=80., binary_step=3, num_iter=10, clip_func=_recording_clip(0.3, advs))
+    torch.manual_seed(31)
+    with redirect_stdout(io.StringIO()):
+        best, succ = att.attack(xyz, target)
+    save('g14_cwperturbt.npz', dict(data=xyz, target=target, seed=31, adv_trace=torch.stack(advs), best=best,
+                                    success_num=int(succ), **_weights(model, 'w_')))
+
+
+def _family_fixture(name, cls_path, seed, spectral, ae, targeted, gamma, num_iter=5, lr=3e-2):
+    import importlib
+    torch.symeig = lambda L, eigenvectors=True: torch.linalg.eigh(L)
+    mod_name, cls_name = cls_path.rsplit('.', 1)
+    cls = getattr(importlib.import_module(mod_name), cls_name)
+    model, aem = toy_victim(seed), toy_ae(seed + 1)
+    data, _ = synth_batch(2, 256, first=120 + seed)
+    xyz = data[:, :, :3].contiguous()
+    clean, second = _runner_up(model, xyz)
+    target = second if targeted else clean
+    advs = []
+    clipf = _recording_clip(0.3, advs)
+    adv_f = adv_utils.LogitsAdvLoss(kappa=0.) if targeted else adv_utils.UntargetedLogitsAdvLoss(kappa=30.)
+    kw = dict(attack_lr=lr, binary_step=2, num_iter=num_iter, GAMMA=gamma, clip_func=clipf)
+    if spectral:
+        kw['low_pass'] = 40
+    args = (model, aem, adv_f, dist_utils.L2Dist()) if ae else (model, adv_f, dist_utils.L2Dist())
+    att = cls(*args, **kw)
+    torch.manual_seed(seed + 2)
+    with redirect_stdout(io.StringIO()):
+        out = att.attack(xyz, target, clean) if targeted else att.attack(xyz, target)
+    bestdist, final, succ = out
+    for p in model.parameters():
+        p.requires_grad = True
+    save(name, dict(data=xyz, target=target, y_truth=clean, seed=seed + 2, adv_trace=torch.stack(advs[:10]), num_iter=num_iter, lr=lr,
+                    bestdist=bestdist, final=final, success_num=int(succ), gamma=gamma,
+                    **_weights(model, 'w_'), **_weights(aem, 'ae_')))
+
+
+def g15():
+    _family_fixture('g15_advpc.npz', 'CW.AdvPC.CWAdvPC', 40, spectral=False, ae=True, targeted=True, gamma=0.5, num_iter=10,
+                    lr=6e-2)
+
+
+def g16():
+    _family_fixture('g16_uadvpc.npz', 'CW.UAdvPC.CWUAdvPC', 50, spectral=False, ae=True, targeted=False, gamma=0.5)
+
+
+def g17():
+    _family_fixture('g17_taof.npz', 'CW.TAOF.CWTAOF', 60, spectral=True, ae=False, targeted=True, gamma=0.25)
+
+
+def g18():
+    _family_fixture('g18_uaeaof.npz', 'CW.UAEAOF.CWUAEAOF', 70, spectral=True, ae=True, targeted=False, gamma=0.25)
+
+
+# ------------------------------------------------------------------ G19-G21: the point / cluster / object adding attacks
+def _add_setup(seed, first):
+    model = toy_victim(seed)
+    data, _ = synth_batch(2, 256, first=first)
+    xyz = data[:, :, :3].contiguous()
+    return model, xyz, _runner_up(model, xyz)[1]
+
+
+def g19():
+    from CW.Add import CWAdd, get_critical_points
+    model, xyz, target = _add_setup(80, 200)
+    cri = get_critical_points(model, xyz.transpose(1, 2).contiguous(), target, 32)
+    out = {}
+    for tag, dist in (('chamfer', dist_utils.ChamferDist(method='adv2ori')), ('hausdorff', dist_utils.HausdorffDist(method='adv2ori'))):
+        att = CWAdd(model, adv_utils.LogitsAdvLoss(kappa=0.), dist, attack_lr=6e-2, init_weight=5., max_weight=40.,
+                    binary_step=3, num_iter=12, num_add=32)
+        torch.manual_seed(83)
+        with redirect_stdout(io.StringIO()):
+            bestdist, final, succ = att.attack(xyz, target)
+        out.update({tag + '_bestdist': bestdist, tag + '_final': final, tag + '_success_num': int(succ)})
+    save('g19_cwadd.npz', dict(data=xyz, target=target, seed=83, critical=cri, **out, **_weights(model, 'w_')))
+
+
+def g20():
+    from CW.Add_Cluster import CWAddClusters
+    model, xyz, target = _add_setup(90, 210)
+    att = CWAddClusters(model, adv_utils.LogitsAdvLoss(kappa=0.), dist_utils.FarChamferDist(num_add=3, chamfer_weight=0.1),
+                        attack_lr=3e-2, init_weight=5., max_weight=30., binary_step=3, num_iter=8, num_add=3, cl_num_p=16)
+    torch.manual_seed(93)
+    np.random.seed(94)
+    with redirect_stdout(io.StringIO()):
+        centers = att._init_centers(xyz.transpose(1, 2).contiguous(), target)
+    torch.manual_seed(93)
+    np.random.seed(94)
+    with redirect_stdout(io.StringIO()):
+        bestdist, final, succ = att.attack(xyz, target)
+    save('g20_cwaddclusters.npz', dict(data=xyz, target=target, seed=93, np_seed=94, centers=centers, bestdist=bestdist,
+                                       final=final, success_num=int(succ), **_weights(model, 'w_')))
+
+
+def g21():
+    from CW.Add_Objects import CWAddObjects
+    model, xyz, target = _add_setup(100, 220)
+    obj = synth_batch(1, 128, first=230)[0][0, :, :3].numpy().astype(np.float64)
+    np.random.seed(104)
+    att = CWAddObjects(model, adv_utils.LogitsAdvLoss(kappa=0.), dist_utils.L2ChamferDist(num_add=2, chamfer_weight=0.2),
+                       obj.copy(), attack_lr=6e-2, init_weight=1., max_weight=40., binary_step=3, num_iter=14, num_add=2,
+                       obj_num_p=24, scaling=0.3)
+    object_pc = att.object_pc.copy()
+    np.random.seed(105)
+    centers = att._init_centers(xyz.transpose(1, 2).contiguous(), target)
+    torch.manual_seed(103)
+    np.random.seed(105)
+    with redirect_stdout(io.StringIO()):
+        bestdist, final, succ = att.attack(xyz, target)
+    save('g21_cwaddobjects.npz', dict(data=xyz, target=target, seed=103, np_seed=104, obj=obj, object_pc=object_pc,
+                                      centers=centers,
+                                      bestdist=bestdist, final=final, success_num=int(succ), **_weights(model, 'w_')))
+
+
+# ------------------------------------------------------------------ G22: the remaining distance operators
+def g22():
+    data, _ = synth_batch(3, 256, first=300)
+    ori = data[:, :, :3].transpose(1, 2).contiguous()
+    normal = data[:, :, 3:].transpose(1, 2).contiguous()
+    g = torch.Generator().manual_seed(5)
+    adv = (ori + 0.03 * torch.randn(ori.shape, generator=g)).requires_grad_()
+    w = torch.tensor([0.5, 2.0, 1.25])
+    out = dict(ori=ori, normal=normal, adv=adv.detach(), weights=w)
+    lap = dist_utils.LaplacianDist(k=6)
+    val, idx = lap.KNN_indices(ori)
+    out['lap_knn_value'], out['lap_knn_idx'] = val, idx
+    d = lap(adv, ori, idx, weights=w, batch_avg=False)
+    out['lap'] = d
+    out['lap_grad'], = torch.autograd.grad(d.sum(), adv)
+    clusters = (0.2 * torch.randn(3, 4, 16, 3, generator=g)).requires_grad_()
+    d = dist_utils.FarthestDist()(clusters, weights=w, batch_avg=False)
+    out['clusters'], out['far'] = clusters.detach(), d
+    out['far_grad'], = torch.autograd.grad(d.sum(), clusters)
+    added = (ori[:, :, :64].transpose(1, 2) + 0.05 * torch.randn(3, 64, 3, generator=g)).contiguous().requires_grad_()
+    d = dist_utils.FarChamferDist(num_add=4, chamfer_weight=0.1)(added, ori.transpose(1, 2).contiguous(), weights=w, batch_avg=False)
+    out['added'], out['farchamfer'] = added.detach(), d
+    out['farchamfer_grad'], = torch.autograd.grad(d.sum(), added)
+    obj0 = 0.1 * torch.randn(3, 4, 16, 3, generator=g)
+    obj1 = (obj0 + 0.01 * torch.randn(3, 4, 16, 3, generator=g)).requires_grad_()
+    d = dist_utils.L2ChamferDist(num_add=4, chamfer_weight=0.2)(added, ori.transpose(1, 2).contiguous(), obj1, obj0,
+                                                                 weights=w, batch_avg=False)
+    out['obj0'], out['obj1'], out['l2chamfer'] = obj0, obj1.detach(), d
+    out['curv'] = dist_utils.CurvDist(curv_loss_knn=2)(ori, adv.detach(), normal)
+    save('g22_dist_more.npz', out)
+
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13',
+                             'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20', 'g21', 'g22']
     for name in which:
         globals()[name]()

@@ -5,6 +5,7 @@ unmodified reference in the build container.  These tests need no GPU and no
 reference tree.
 """
 import numpy as np
+import pytest
 import torch
 
 from helpers import T, golden, golden_json, hp_from_fixture, toy_from_fixture
@@ -200,3 +201,131 @@ def test_g13_aof_trajectory():
         close(rec['adv'], fx['adv_trace'][i], rtol=1e-4, atol=1e-5)
     close(final, fx['final'], rtol=1e-4, atol=1e-5)
     assert succ == int(fx['success_num'])
+
+
+# ------------------------------------------------------------------ g14-g22: the remaining CW attacks and distance operators
+class _ToyAE(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.Conv1d(3, 8, 1)
+        self.dec = torch.nn.Conv1d(8, 3, 1)
+
+    def forward(self, x):
+        return x + 0.1 * self.dec(torch.tanh(self.enc(x)))
+
+
+def toy_ae_from_fixture(fx):
+    m = _ToyAE()
+    m.load_state_dict({k[3:]: T(fx[k]) for k in fx if k.startswith('ae_')})
+    return m.eval()
+
+
+def test_g14_cwperturbt_trajectory():
+    fx = golden('g14_cwperturbt.npz')
+    model = toy_from_fixture(fx)
+    torch.manual_seed(int(fx['seed']))
+    trace = []
+    best, succ, _ = O.cw_perturbt_attack(model, lambda l, t: O.logits_adv_loss(l, t, 0.), O.l2_dist, T(fx['data']),
+                                         T(fx['target']), attack_lr=3e-2, init_weight=10., max_weight=80., binary_step=3,
+                                         num_iter=10, clip_func=lambda pc, ori: O.clip_points_linf(pc, ori, 0.3),
+                                         trace=trace)
+    for i, rec in enumerate(trace):
+        close(rec['adv'], fx['adv_trace'][i], rtol=1e-4, atol=1e-5)
+    close(best, fx['best'], rtol=1e-4, atol=1e-5)
+    assert succ == int(fx['success_num']) == 3
+
+
+FAMILY = {  # fixture -> switches of oracle.cw_family_attack / the product classes
+    'g15_advpc.npz': dict(ae=True, spectral=False, targeted=True, fresh=True, final_clip=True),
+    'g16_uadvpc.npz': dict(ae=True, spectral=False, targeted=False, fresh=False, final_clip=True),
+    'g17_taof.npz': dict(ae=False, spectral=True, targeted=True, fresh=True, final_clip=False),
+    'g18_uaeaof.npz': dict(ae=True, spectral=True, targeted=False, fresh=False, final_clip=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FAMILY))
+def test_g15_g18_cw_family_trajectories(name):
+    fx, sw = golden(name), FAMILY[name]
+    model = toy_from_fixture(fx)
+    aem = toy_ae_from_fixture(fx) if sw['ae'] else None
+    adv_f = (lambda l, t: O.logits_adv_loss(l, t, 0.)) if sw['targeted'] else (lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.))
+    torch.manual_seed(int(fx['seed']))
+    trace = []
+    bestdist, final, succ = O.cw_family_attack(
+        model, adv_f, lambda pc, ori: O.clip_points_linf(pc, ori, 0.3), T(fx['data']), T(fx['target']),
+        y_truth=T(fx['y_truth']) if sw['targeted'] else None, ae_model=aem, spectral=sw['spectral'],
+        targeted=sw['targeted'], fresh=sw['fresh'], final_clip=sw['final_clip'], attack_lr=float(fx['lr']), binary_step=2,
+        num_iter=int(fx['num_iter']), GAMMA=float(fx['gamma']), low_pass=40, trace=trace)
+    for i in range(10):
+        close(trace[i]['adv'], fx['adv_trace'][i], rtol=1e-4, atol=1e-5)
+    close(final, fx['final'], rtol=1e-4, atol=1e-5)
+    close(bestdist, fx['bestdist'], rtol=1e-5)
+    assert succ == int(fx['success_num'])
+
+
+def test_g19_cwadd_results():
+    fx = golden('g19_cwadd.npz')
+    model = toy_from_fixture(fx)
+    ori = T(fx['data']).transpose(1, 2).contiguous()
+    cri = O.critical_points(model, ori, T(fx['target']), 32)
+    assert torch.equal(cri, T(fx['critical']))
+    for tag, dist in (('chamfer', O.chamfer_dist), ('hausdorff', O.hausdorff_dist)):
+        torch.manual_seed(int(fx['seed']))
+        bestdist, final, succ = O.cw_add_attack(model, lambda l, t: O.logits_adv_loss(l, t, 0.), dist, T(fx['data']),
+                                                T(fx['target']), cri, attack_lr=6e-2, init_weight=5., max_weight=40.,
+                                                binary_step=3, num_iter=12)
+        close(final, fx[tag + '_final'], rtol=1e-4, atol=1e-5)
+        close(bestdist, fx[tag + '_bestdist'], rtol=1e-4)
+        assert succ == int(fx[tag + '_success_num'])
+
+
+def test_g20_cwaddclusters_result():
+    fx = golden('g20_cwaddclusters.npz')
+    model = toy_from_fixture(fx)
+    B = fx['data'].shape[0]
+    init = T(fx['centers']).float().view(B, -1, 3).transpose(1, 2).contiguous()
+    torch.manual_seed(int(fx['seed']))
+    bestdist, final, succ = O.cw_add_attack(
+        model, lambda l, t: O.logits_adv_loss(l, t, 0.),
+        lambda a, o, weights=None, batch_avg=True: O.far_chamfer_dist(a, o, 3, weights, batch_avg, chamfer_weight=0.1),
+        T(fx['data']), T(fx['target']), init, attack_lr=3e-2, init_weight=5., max_weight=30., binary_step=3, num_iter=8)
+    close(final, fx['final'], rtol=1e-4, atol=1e-5)
+    close(bestdist, fx['bestdist'], rtol=1e-4)
+    assert succ == int(fx['success_num'])
+
+
+def test_g21_cwaddobjects_result():
+    fx = golden('g21_cwaddobjects.npz')
+    model = toy_from_fixture(fx)
+    torch.manual_seed(int(fx['seed']))
+    bestdist, final, succ = O.cw_add_objects_attack(
+        model, lambda l, t: O.logits_adv_loss(l, t, 0.),
+        lambda a, o, ao, oo, weights=None, batch_avg=True: O.l2_chamfer_dist(a, o, ao, oo, weights, batch_avg, chamfer_weight=0.2),
+        T(fx['data']), T(fx['target']), fx['object_pc'], fx['centers'], attack_lr=6e-2, init_weight=1., max_weight=40.,
+        binary_step=3, num_iter=14)
+    close(final, fx['final'], rtol=1e-4, atol=1e-5)
+    close(bestdist, fx['bestdist'], rtol=1e-4)
+    assert succ == int(fx['success_num'])
+
+
+def test_g22_more_distance_operators():
+    fx = golden('g22_dist_more.npz')
+    ori, adv, normal, w = T(fx['ori']), T(fx['adv']).requires_grad_(), T(fx['normal']), T(fx['weights'])
+    val, idx = O.laplacian_knn_indices(ori, 6)
+    assert torch.equal(idx, T(fx['lap_knn_idx']))
+    close(val, fx['lap_knn_value'], rtol=1e-9, atol=1e-12)
+    d = O.laplacian_dist(adv, ori, idx, w, batch_avg=False)
+    close(d, fx['lap'], rtol=1e-6)
+    close(torch.autograd.grad(d.sum(), adv)[0], fx['lap_grad'], rtol=1e-5, atol=1e-7)
+    cl = T(fx['clusters']).requires_grad_()
+    d = O.farthest_dist(cl, w, batch_avg=False)
+    close(d, fx['far'], rtol=1e-6)
+    close(torch.autograd.grad(d.sum(), cl)[0], fx['far_grad'], rtol=1e-5, atol=1e-7)
+    added = T(fx['added']).requires_grad_()
+    ori_t = ori.transpose(1, 2).contiguous()
+    d = O.far_chamfer_dist(added, ori_t, 4, w, batch_avg=False, chamfer_weight=0.1)
+    close(d, fx['farchamfer'], rtol=1e-5)
+    close(torch.autograd.grad(d.sum(), added)[0], fx['farchamfer_grad'], rtol=1e-4, atol=1e-6)
+    d = O.l2_chamfer_dist(added, ori_t, T(fx['obj1']), T(fx['obj0']), w, batch_avg=False, chamfer_weight=0.2)
+    close(d, fx['l2chamfer'], rtol=1e-5)
+    close(O.curv_dist(ori, adv.detach(), normal, 2), fx['curv'], rtol=1e-5)
