@@ -34,6 +34,21 @@ def create_logger(save_path='', file_type='', level='debug'):
     return logger
 
 
+def load_checkpoint(model, checkpoint, strict=True):
+    """Load a reference-style checkpoint into ``model``: a path or an already loaded object; the weights sit under
+    'model_state_dict' (eval.py:79,123), 'state_dict' (save_checkpoint, other_utils.py:173-184) or at top level, with an
+    optional DataParallel 'module.' prefix.  Returns the loaded object."""
+    obj = torch.load(checkpoint, map_location='cpu') if isinstance(checkpoint, (str, bytes, os.PathLike)) else checkpoint
+    sd = obj
+    for key in ('model_state_dict', 'state_dict'):
+        if isinstance(obj, dict) and key in obj:
+            sd = obj[key]
+            break
+    sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+    model.load_state_dict(sd, strict=strict)
+    return obj
+
+
 def shard_indices(n_batches, rank, world):
     """Batches owned by ``rank``: r, r+world, ... (round-robin keeps shuffle=False order per rank)."""
     return list(range(rank, n_batches, world))

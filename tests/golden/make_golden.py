@@ -24,6 +24,7 @@ Fixture index:
   g14..g18             CWPerturbT / CWAdvPC / CWUAdvPC / CWTAOF / CWUAEAOF trajectories (toy victim, toy auto-encoder)
   g19..g21             CWAdd (Chamfer and Hausdorff) / CWAddClusters / CWAddObjects results
   g22_dist_more.npz    LaplacianDist, FarthestDist, FarChamferDist, L2ChamferDist, CurvDist values and gradients
+  g23_datasets.npz     ModelNetDataLoader / PartNormalDataset items read from the tiny tree in g23_dataset_tree.json
   g10_dgcnn.npz        DGCNN_cls (seeded init, eval mode): logits, input gradient, first-layer kNN table
 """
 import io
@@ -679,9 +680,59 @@ def g22():
     out['curv'] = dist_utils.CurvDist(curv_loss_knn=2)(ori, adv.detach(), normal)
     save('g22_dist_more.npz', out)
 
+# ------------------------------------------------------------------ G23: dataset readers on a tiny synthetic tree
+def g23():
+    import argparse
+    import tempfile
+    from Dataset.ModelNet import ModelNetDataLoader
+    from Dataset.ShapeNetDataLoader import PartNormalDataset
+    rng = np.random.RandomState(7)
+    files = {}
+    shapes = [('airplane', 'airplane_0001'), ('airplane', 'airplane_0002'), ('night_stand', 'night_stand_0001')]
+    files['modelnet40_shape_names.txt'] = 'airplane\nnight_stand\n'
+    files['modelnet40_train.txt'] = 'airplane_0001\n'
+    files['modelnet40_test.txt'] = 'airplane_0002\nnight_stand_0001\n'
+    for cls, sid in shapes:
+        pts = rng.randn(40, 6)
+        files['%s/%s.txt' % (cls, sid)] = ''.join(','.join('%.6f' % v for v in row) + '\n' for row in pts)
+    files['synsetoffset2category.txt'] = 'Airplane\t02691156\nBag\t02773838\n'
+    tokens = {'02691156': ['aaa1', 'aaa2', 'aaa3'], '02773838': ['bbb1', 'bbb2']}
+    split = {'train': ['shape_data/02691156/aaa1', 'shape_data/02773838/bbb1'], 'val': ['shape_data/02691156/aaa2'],
+             'test': ['shape_data/02691156/aaa3', 'shape_data/02773838/bbb2']}
+    for k, v in split.items():
+        files['train_test_split/shuffled_%s_file_list.json' % k] = json.dumps(v)
+    for syn, toks in tokens.items():
+        for t in toks:
+            pts = np.concatenate([rng.randn(30, 6), rng.randint(0, 4, (30, 1))], axis=1)
+            files['%s/%s.txt' % (syn, t)] = ''.join(' '.join('%.6f' % v for v in row) + '\n' for row in pts)
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        for rel, text in files.items():
+            path = os.path.join(root, rel)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            open(path, 'w').write(text)
+        with redirect_stdout(io.StringIO()):
+            for tag, uniform, normals, process in (('plain', False, True, False), ('fps', True, False, False),
+                                                   ('cached', False, True, True)):
+                args = argparse.Namespace(num_point=16, use_uniform_sample=uniform, use_normals=normals, num_category=40)
+                np.random.seed(11)
+                ds = ModelNetDataLoader(root, args, split='test', process_data=process)
+                items = [ds[i] for i in range(len(ds))]
+                out['modelnet_%s_points' % tag] = np.stack([p for p, _ in items])
+                out['modelnet_%s_labels' % tag] = np.array([l for _, l in items])
+            for tag, sp, normals in (('test', 'test', True), ('trainval', 'trainval', False)):
+                np.random.seed(13)
+                ds = PartNormalDataset(root=root, npoints=12, split=sp, normal_channel=normals)
+                items = [ds[i] for i in range(len(ds))]
+                out['shapenet_%s_points' % tag] = np.stack([p for p, _ in items])
+                out['shapenet_%s_labels' % tag] = np.array([l for _, l in items])
+    with open(os.path.join(HERE, 'g23_dataset_tree.json'), 'w') as f:
+        json.dump(files, f, indent=0, sort_keys=True)
+    save('g23_datasets.npz', out)
+
 
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13',
-                             'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20', 'g21', 'g22']
+                             'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20', 'g21', 'g22', 'g23']
     for name in which:
         globals()[name]()
