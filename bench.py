@@ -131,7 +131,8 @@ def hot_loop_kernels(dev):
     n = lib.hitadv_linear_max_fwd_scratch(B, N, 1024)
     pv, pi = torch.empty(n, device=dev), torch.empty(n, device=dev, dtype=torch.int32)
     mo, mi = torch.empty(B, 1024, device=dev), torch.empty(B, 1024, device=dev, dtype=torch.int64)
-    us = timed(lambda: lib.hitadv_linear_max_fwd(p(h2), p(Wt), p(bias), B, N, 128, 1024, 1, p(pv), p(pi), p(mo), p(mi), s),
+    tk = torch.zeros(4096, device=dev, dtype=torch.int32)  # split tickets (self-resetting)
+    us = timed(lambda: lib.hitadv_linear_max_fwd(p(h2), p(Wt), p(bias), B, N, 128, 1024, 1, p(pv), p(pi), p(mo), p(mi), p(tk), s),
                reps=400)
     flops = 2.0 * B * N * 128 * 1024
     out["linear_max_fwd"] = {"bound": "mfma", "us_per_launch": us, "achieved": round(flops / us / 1e6, 1), "peak": 157.3,

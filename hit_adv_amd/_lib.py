@@ -46,7 +46,7 @@ PROTOTYPES = {
     "hitadv_linear_max_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "hitadv_max_over_points": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hitadv_max_over_points_scratch": [_I, _I],
-    "hitadv_linear_max_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hitadv_linear_max_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hitadv_linear_max_fwd_scratch": [_I, _I, _I],
     "hitadv_pointnet_rowmlp_fwd": [_I] + [_P] * 13 + [_I, _I, _P],
     "hitadv_pointnet_rowmlp_tiles": [_I],

@@ -162,7 +162,9 @@ constexpr int LF_TM = 64;
 template <int CIN>
 __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict__ X, const float *__restrict__ Wt,
                                                         int B_, int N, int Cout, int rows_per_split, int S, int ncg,
-                                                        float *__restrict__ pval, int32_t *__restrict__ pidx) {
+                                                        float *pval, int32_t *pidx, const float *__restrict__ bias,
+                                                        int relu, float *__restrict__ out, int64_t *__restrict__ idx,
+                                                        int *tickets) {
   constexpr int LDA = CIN + 4;
   constexpr int KS = CIN / 2;            // MFMA steps per output tile
   constexpr int F4_ROW = CIN / 4;        // float4 per row of x
@@ -311,18 +313,50 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
     __syncthreads();
     ++tile;
   }
-  if (!active) return;
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {  // the other half of the wave holds the same column, other rows
     const float ov = __shfl_xor(bv[cb], 32, HITADV_WAVE);
     const int oi = __shfl_xor(bi[cb], 32, HITADV_WAVE);
     if (ov > bv[cb] || (ov == bv[cb] && oi < bi[cb])) { bv[cb] = ov; bi[cb] = oi; }
-    if (h == 0) {
-      const size_t o = ((size_t)b * S + s) * Cout + col0 + 32 * cb + r;
-      pval[o] = bv[cb];
-      pidx[o] = bi[cb];
+    if (active && h == 0) {
+      const int c = col0 + 32 * cb + r;
+      if (S == 1 && tickets != nullptr) {  // nothing to merge: finish here
+        float v = bv[cb] + (bias ? bias[c] : 0.f);  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
+        out[(size_t)b * Cout + c] = relu ? (v > 0.f ? v : 0.f) : v;  // max and ReLU commute
+        idx[(size_t)b * Cout + c] = bi[cb];
+      } else {
+        const size_t o = ((size_t)b * S + s) * Cout + c;
+        __hip_atomic_store(&pval[o], bv[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pidx[o], bi[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
+  if (tickets == nullptr || S == 1) return;  // partials only: the caller merges them (max_over_points_merge)
+  // The S splits of a (cloud, column group) meet here: the last block to draw the group's ticket merges the partials in
+  // split order (= ascending points, so ties keep the first point), adds the bias, applies the ReLU and writes the
+  // result.  Same fence-free protocol as fc_layer_k (csrc/pointnet.hip): write-through stores, vmcnt(0), barrier, ticket.
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(&tickets[b * ncg + cg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+  __syncthreads();
+  if (!s_last) return;
+  const int c = cg * 256 + threadIdx.x;
+  if (c < Cout) {
+    float best = 0.f;
+    int bidx = 0;
+    for (int q = 0; q < S; ++q) {
+      const size_t o = ((size_t)b * S + q) * Cout + c;
+      const float v = __hip_atomic_load(&pval[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int vi = __hip_atomic_load(&pidx[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (q == 0 || v > best) { best = v; bidx = vi; }
+    }
+    best += bias ? bias[c] : 0.f;
+    out[(size_t)b * Cout + c] = relu ? (best > 0.f ? best : 0.f) : best;
+    idx[(size_t)b * Cout + c] = bidx;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&tickets[b * ncg + cg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 static void linear_max_split(int B, int N, int Cout, int *S, int *rows) {
@@ -378,7 +412,7 @@ extern "C" int64_t hitadv_linear_max_fwd_scratch(int B, int N, int Cout) {
 
 extern "C" int hitadv_linear_max_fwd(const float *X, const float *Wt, const float *bias, int B, int N, int Cin, int Cout,
                                      int relu, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
-                                     void *stream) {
+                                     int32_t *tickets, void *stream) {
   if (!X || !Wt || !part_val || !part_idx || !out || !idx || B <= 0 || N <= 0 || Cout <= 0 || (Cout & 63) ||
       (Cin != 64 && Cin != 128) || ((uintptr_t)X & 15))
     return HITADV_E_ARG;
@@ -392,13 +426,17 @@ extern "C" int hitadv_linear_max_fwd(const float *X, const float *Wt, const floa
     static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_TM * 132 * 4);
     (void)once;
-    linear_max_fwd_k<128><<<grid, 256, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx);
+    linear_max_fwd_k<128><<<grid, 256, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
+                                                 tickets);
   } else {
-    linear_max_fwd_k<64><<<grid, 256, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx);
+    linear_max_fwd_k<64><<<grid, 256, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
+                                                tickets);
   }
-  const long long total = (long long)B * Cout;
-  max_over_points_merge<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part_val, part_idx, Cout, S, bias, relu, out,
-                                                                         idx, total);
+  if (tickets == nullptr) {
+    const long long total = (long long)B * Cout;
+    max_over_points_merge<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(part_val, part_idx, Cout, S, bias, relu, out,
+                                                                           idx, total);
+  }
   HITADV_LAUNCH_CHECK();
   return 0;
 }

@@ -31,6 +31,22 @@ def _dev(t, name, dtype=torch.float32):
     return t.contiguous()
 
 
+_fc_scratch = {}
+
+
+def _fc_scratch_for(x, n):
+    """Zero-initialised split-K scratch, one per (device, stream): calls on one stream are ordered, calls on
+    different streams (attack_many) must not share tickets.  Grown on demand, never shrunk."""
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    t = _fc_scratch.get(key)
+    if t is None or t.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("fc_layer scratch must exist before graph capture: run one eager pass on this stream first")
+        t = torch.zeros(max(n, 1 << 20), device=x.device)
+        _fc_scratch[key] = t
+    return t
+
+
 # --------------------------------------------------------------------------- pairwise / set minima
 def pairwise_sqdist(x, y, form=FORM_GRAM):
     """x[B,N,D], y[B,M,D] -> P[B,N,M] (no autograd; see NNMin for the differentiable reductions)."""
@@ -326,29 +342,14 @@ def linear_max_fwd(x, Wt, B, N, bias=None, relu=False):
     pi = torch.empty(n, device=x.device, dtype=torch.int32)
     out = torch.empty(B, Cout, device=x.device)
     idx = torch.empty(B, Cout, device=x.device, dtype=torch.int64)
+    tickets = _fc_scratch_for(x, 1 << 14)  # zeroed, self-resetting; shared with fc_layer (never concurrent on a stream)
     _lib.call("hitadv_linear_max_fwd", _p(x), _p(Wt), _p(bias), B, N, Cin, Cout, 1 if relu else 0, _p(pv), _p(pi),
-              _p(out), _p(idx), _stream())
+              _p(out), _p(idx), _p(tickets), _stream())
     return out, idx
 
 
 def linear_max_fwd_supported(Cin, Cout):
     return Cin in (64, 128) and Cout % 64 == 0
-
-
-_fc_scratch = {}
-
-
-def _fc_scratch_for(x, n):
-    """Zero-initialised split-K scratch, one per (device, stream): calls on one stream are ordered, calls on
-    different streams (attack_many) must not share tickets.  Grown on demand, never shrunk."""
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
-    t = _fc_scratch.get(key)
-    if t is None or t.numel() < n:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("fc_layer scratch must exist before graph capture: run one eager pass on this stream first")
-        t = torch.zeros(max(n, 1 << 20), device=x.device)
-        _fc_scratch[key] = t
-    return t
 
 
 def fc_layer(x, Wt, bias=None, relu=False, mask=None):

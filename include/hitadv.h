@@ -242,9 +242,13 @@ int64_t hitadv_max_over_points_scratch(int B, int C);
  * i.e. `conv3 -> bn3 -> (relu) -> torch.max(x, 2)` of model/feature_models.py:173-175 (STN3d), :215-217 (STNkd)
  * and :139-140 (PointNetEncoder) with the BatchNorm folded into (Wt, bias).  The [B*N,Cout] activation is
  * never materialised.  X [B*N,Cin] points-major, Wt [Cin,Cout]; Cin in {64,128}, Cout % 64 == 0.
- * part_val / part_idx: scratch of hitadv_linear_max_fwd_scratch(B,N,Cout) entries each. */
+ * part_val / part_idx: scratch of hitadv_linear_max_fwd_scratch(B,N,Cout) entries each.
+ * tickets: B * ceil(Cout/256) int32 that the caller ZEROES ONCE (every call leaves them at zero; calls that may run
+ * concurrently need their own): the point splits of a cloud are then merged by the last block to finish, inside the
+ * same launch.  NULL = merge with a second, tiny launch. */
 int hitadv_linear_max_fwd(const float *X, const float *Wt, const float *bias, int B, int N, int Cin, int Cout,
-                          int relu, float *part_val, int32_t *part_idx, float *out, int64_t *idx, void *stream);
+                          int relu, float *part_val, int32_t *part_idx, float *out, int64_t *idx, int32_t *tickets,
+                          void *stream);
 int64_t hitadv_linear_max_fwd_scratch(int B, int N, int Cout);
 
 /* ------------------------------------------------------------------ PointNet victim, attack-time view
