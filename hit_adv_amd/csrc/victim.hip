@@ -147,11 +147,11 @@ __global__ __launch_bounds__(256) void max_over_points_merge(const float *__rest
 // matrix cores (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fmaf chain).  The [B*N,Cout] activation
 // (134 MB for PointNet's 128->1024 layer at B=32) never exists: not written, not re-read.
 //
-//   block   = 4 waves; one cloud, one split of its points, 256 output channels (64 per wave)
-//   W       : the wave's 64 columns x CIN rows live in VGPRs for the whole kernel (2*CIN/2 registers)
+//   block   = 8 waves (two per SIMD); one cloud, one split of its points, 256 output channels (32 per wave)
+//   W       : the wave's 32 columns x CIN rows live in VGPRs for the whole kernel (CIN/2 registers)
 //   x       : 64-point tiles, global -> registers -> LDS (row stride CIN+4 floats: conflict-free
 //             ds_read_b128), double buffered, one barrier per tile; every wave reads the same tile
-//   compute : per tile and wave 2x2 accumulators of 32x32, CIN/2 MFMA steps each
+//   compute : per tile and wave 2 (rows) x NCB (columns) accumulators of 32x32, CIN/2 MFMA steps each
 //   epilogue: accumulator layout = column on the lane, 16 rows in registers -> running (max, first
 //             arg-max) per lane; the two lane halves are merged once at the end.  Two accumulator sets
 //             alternate: the scan of tile t runs between the MFMA groups of tile t+1.
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void max_over_points_merge(const float *__rest
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LF_TM = 64;
 
-template <int CIN>
-__global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict__ X, const float *__restrict__ Wt,
+template <int CIN, int NCB, int NT>
+__global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__ X, const float *__restrict__ Wt,
                                                         int B_, int N, int Cout, int rows_per_split, int S, int ncg,
                                                         float *pval, int32_t *pidx, const float *__restrict__ bias,
                                                         int relu, float *__restrict__ out, int64_t *__restrict__ idx,
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
   constexpr int LDA = CIN + 4;
   constexpr int KS = CIN / 2;            // MFMA steps per output tile
   constexpr int F4_ROW = CIN / 4;        // float4 per row of x
-  constexpr int ST = LF_TM * F4_ROW / 256;  // float4 staged per thread per tile
+  constexpr int ST = LF_TM * F4_ROW / NT;  // float4 staged per thread per tile
   extern __shared__ float4 sA4[];        // 2 x LF_TM x LDA floats
   float *sA = reinterpret_cast<float *>(sA4);
   // XCD-aware block order: consecutive workgroup ids go to consecutive XCDs (8, each with its own L2), and the NCG
@@ -191,17 +191,17 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
   }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int col0 = cg * 256 + wave * 64;
+  const int col0 = cg * 256 + wave * 32 * NCB;  // NT/64 waves x 32*NCB columns = 256 per block
   const bool active = col0 < Cout;  // wave-uniform
   const int n0 = s * rows_per_split, n1 = min(N, n0 + rows_per_split);
   const int ntiles = (n1 - n0 + LF_TM - 1) / LF_TM;
   X += (size_t)b * N * CIN;
 
   // step t of the K loop consumes k = 8*(t/4) + 4*h + t%4: a lane's four consecutive steps are one float4 of x
-  float w[2][KS];
+  float w[NCB][KS];
   const float *wp = Wt + (active ? col0 : 0) + r;  // idle waves (Cout not a multiple of 256) load in range, use nothing
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+  for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int t = 0; t < KS; ++t) w[cb][t] = wp[(size_t)(8 * (t >> 2) + 4 * h + (t & 3)) * Cout + 32 * cb];
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
   auto fetch = [&](int tile) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
-      const int e = threadIdx.x + 256 * u;
+      const int e = threadIdx.x + NT * u;
       const int n = n0 + tile * LF_TM + e / F4_ROW;
       st[u] = n < n1 ? *reinterpret_cast<const float4 *>(X + (size_t)n * CIN + 4 * (e % F4_ROW))
                      : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -218,26 +218,31 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
   auto stash = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
-      const int e = threadIdx.x + 256 * u;
+      const int e = threadIdx.x + NT * u;
       *reinterpret_cast<float4 *>(sA + (size_t)buf * LF_TM * LDA + (e / F4_ROW) * LDA + 4 * (e % F4_ROW)) = st[u];
     }
   };
 
-  float bv[2] = {-__builtin_inff(), -__builtin_inff()};
-  int bi[2] = {n0, n0};
+  float bv[NCB];
+  int bi[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    bv[cb] = -__builtin_inff();
+    bi[cb] = n0;
+  }
   // accumulator element e of tile (rb, cb): row 32*rb + (e&3) + 8*(e>>2) + 4*h, column 32*cb + r
-  auto update = [&](const f32x16 (&acc)[2][2], int tile, int rb, int e, bool ragged) {
+  auto update = [&](const f32x16 (&acc)[2][NCB], int tile, int rb, int e, bool ragged) {
     const int n = n0 + tile * LF_TM + 4 * h + 32 * rb + (e & 3) + 8 * (e >> 2);
     const bool live = !ragged || n < n1;  // rows past the split's end are zero-filled: keep them out
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
       const float v = live ? acc[rb][cb][e] : -__builtin_inff();
       const bool g = v > bv[cb];
       bv[cb] = g ? v : bv[cb];
       bi[cb] = g ? n : bi[cb];
     }
   };
-  auto epilogue = [&](const f32x16 (&acc)[2][2], int tile) {
+  auto epilogue = [&](const f32x16 (&acc)[2][NCB], int tile) {
     const bool ragged = n0 + (tile + 1) * LF_TM > n1;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -247,12 +252,12 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
   // One tile of MFMAs into `cur`; the max / arg-max scan of the PREVIOUS tile's accumulators (`prev`, never ragged)
   // is spread between the MFMA groups so that the VALU work issues in the shadow of the matrix pipe.
   constexpr int EPJ = 32 / (CIN / 8);  // (rb, e) pairs scanned per K group
-  auto tile_step = [&](f32x16 (&cur)[2][2], int buf, const f32x16 (&prev)[2][2], int prev_tile, bool have_prev) {
+  auto tile_step = [&](f32x16 (&cur)[2][NCB], int buf, const f32x16 (&prev)[2][NCB], int prev_tile, bool have_prev) {
     const float *a = sA + (size_t)buf * LF_TM * LDA + r * LDA + 4 * h;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NCB; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) cur[i][j][e] = 0.f;
 #pragma unroll
@@ -264,10 +269,10 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int t = 4 * j + i;
-        cur[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], w[0][t], cur[0][0], 0, 0, 0);
-        cur[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], w[1][t], cur[0][1], 0, 0, 0);
-        cur[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], w[0][t], cur[1][0], 0, 0, 0);
-        cur[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], w[1][t], cur[1][1], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) cur[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[i], w[cb][t], cur[0][cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) cur[1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[i], w[cb][t], cur[1][cb], 0, 0, 0);
       }
       if (have_prev) {
 #pragma unroll
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
     }
   };
 
-  f32x16 accA[2][2], accB[2][2];
+  f32x16 accA[2][NCB], accB[2][NCB];
   fetch(0);
   stash(0);
   __syncthreads();
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
     ++tile;
   }
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {  // the other half of the wave holds the same column, other rows
+  for (int cb = 0; cb < NCB; ++cb) {  // the other half of the wave holds the same column, other rows
     const float ov = __shfl_xor(bv[cb], 32, HITADV_WAVE);
     const int oi = __shfl_xor(bi[cb], 32, HITADV_WAVE);
     if (ov > bv[cb] || (ov == bv[cb] && oi < bi[cb])) { bv[cb] = ov; bi[cb] = oi; }
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256) void linear_max_fwd_k(const float *__restrict_
   __syncthreads();
   if (!s_last) return;
   const int c = cg * 256 + threadIdx.x;
-  if (c < Cout) {
+  if (threadIdx.x < 256 && c < Cout) {
     float best = 0.f;
     int bidx = 0;
     for (int q = 0; q < S; ++q) {
@@ -422,15 +427,17 @@ extern "C" int hitadv_linear_max_fwd(const float *X, const float *Wt, const floa
   const int ncg = (Cout + 255) / 256;
   dim3 grid((unsigned)(ncg * S * B));
   const size_t shm = (size_t)2 * LF_TM * (Cin + 4) * sizeof(float);
+  // 8 waves x 32 columns per block: two waves per SIMD keep the matrix pipe busy across each other's LDS waits and
+  // epilogue scans (measured at B=32: 69.1 us; 4 waves x 64 columns, one wave per SIMD: 73.0 us)
   if (Cin == 128) {
-    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128>),
+    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128, 1, 512>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_TM * 132 * 4);
     (void)once;
-    linear_max_fwd_k<128><<<grid, 256, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
-                                                 tickets);
+    linear_max_fwd_k<128, 1, 512><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu,
+                                                          out, idx, tickets);
   } else {
-    linear_max_fwd_k<64><<<grid, 256, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
-                                                tickets);
+    linear_max_fwd_k<64, 1, 512><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out,
+                                                         idx, tickets);
   }
   if (tickets == nullptr) {
     const long long total = (long long)B * Cout;
