@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void max_over_points_merge(const float *__rest
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LF_TM = 64;
 
-template <int CIN, int NCB, int NT>
+template <int CIN, int NCB, int NT, bool PIPE>
 __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__ X, const float *__restrict__ Wt,
                                                         int B_, int N, int Cout, int rows_per_split, int S, int ncg,
                                                         float *pval, int32_t *pidx, const float *__restrict__ bias,
@@ -288,6 +288,18 @@ __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__
   fetch(0);
   stash(0);
   __syncthreads();
+  if (!PIPE) {  // one accumulator set: the scan of a tile follows its own MFMAs (another wave of the SIMD fills the gap)
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const bool more = tile + 1 < ntiles;
+      if (more) fetch(tile + 1);
+      if (active) {
+        tile_step(accA, tile & 1, accB, 0, false);
+        epilogue(accA, tile);
+      }
+      if (more) stash((tile + 1) & 1);
+      __syncthreads();
+    }
+  } else {
   {  // tile 0: nothing to scan yet
     const bool more = 1 < ntiles;
     if (more) fetch(1);
@@ -317,6 +329,7 @@ __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__
     if (more) stash(1);
     __syncthreads();
     ++tile;
+  }
   }
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {  // the other half of the wave holds the same column, other rows
@@ -429,15 +442,17 @@ extern "C" int hitadv_linear_max_fwd(const float *X, const float *Wt, const floa
   const size_t shm = (size_t)2 * LF_TM * (Cin + 4) * sizeof(float);
   // 8 waves x 32 columns per block: two waves per SIMD keep the matrix pipe busy across each other's LDS waits and
   // epilogue scans (measured at B=32: 69.1 us; 4 waves x 64 columns, one wave per SIMD: 73.0 us)
+  // 8 waves x 32 columns per block, two accumulator sets.  Measured at B=32 (us incl. merge): this 68.9; one set 71.1;
+  // 4 waves x 64 columns (one wave per SIMD) 73.0; 512 blocks 75.4; forced to 128 VGPRs for 4 waves per SIMD 74.9-76.7.
   if (Cin == 128) {
-    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128, 1, 512>),
+    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128, 1, 512, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_TM * 132 * 4);
     (void)once;
-    linear_max_fwd_k<128, 1, 512><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu,
-                                                          out, idx, tickets);
+    linear_max_fwd_k<128, 1, 512, true><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias,
+                                                                relu, out, idx, tickets);
   } else {
-    linear_max_fwd_k<64, 1, 512><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out,
-                                                         idx, tickets);
+    linear_max_fwd_k<64, 1, 512, true><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu,
+                                                               out, idx, tickets);
   }
   if (tickets == nullptr) {
     const long long total = (long long)B * Cout;
