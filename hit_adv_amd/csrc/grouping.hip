@@ -224,3 +224,80 @@ extern "C" int hitadv_three_interpolate_grad(int b, int c, int n, int m, const f
   HITADV_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// EdgeConv's neighbour reduction (model/dgcnn_cls.py:16-43 + conv/bn/LeakyReLU/max of :93-112), after the algebraic
+// split  W [x_j - x_i ; x_i] = Wa x_j + (Wb - Wa) x_i :   out[i,c] = lrelu( V[i,c] + max_{j in nbr(i)} U[j,c] ).
+// The k-times larger edge tensor [B,2C,N,k] never exists; the per-edge 1x1 convolution became two per-POINT GEMMs
+// (U, V) and this gather-max.  A lane owns 4 consecutive channels of one point (float4 rows of U: coalesced).
+namespace hitadv {
+
+__global__ __launch_bounds__(256) void edge_max_fwd_k(const float *__restrict__ U, const float *__restrict__ V,
+                                                      const int64_t *__restrict__ idx, int N, int C, int k, float slope,
+                                                      float *__restrict__ out, int32_t *__restrict__ arg,
+                                                      long long total4) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, i, c4)
+  if (e >= total4) return;
+  const int c4n = C >> 2;
+  const int c4 = (int)(e % c4n);
+  const long long bi = e / c4n;  // b * N + i
+  const long long b = bi / N;
+  const int64_t *nb = idx + bi * k;
+  float4 best = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+  int4 bj = make_int4(0, 0, 0, 0);
+  for (int t = 0; t < k; ++t) {
+    const int j = (int)nb[t];
+    const float4 u = *reinterpret_cast<const float4 *>(U + ((size_t)(b * N + j)) * C + 4 * c4);
+    if (u.x > best.x) { best.x = u.x; bj.x = j; }
+    if (u.y > best.y) { best.y = u.y; bj.y = j; }
+    if (u.z > best.z) { best.z = u.z; bj.z = j; }
+    if (u.w > best.w) { best.w = u.w; bj.w = j; }
+  }
+  const float4 v = *reinterpret_cast<const float4 *>(V + (size_t)bi * C + 4 * c4);
+  float4 o = make_float4(best.x + v.x, best.y + v.y, best.z + v.z, best.w + v.w);
+  o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+  o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+  *reinterpret_cast<float4 *>(out + (size_t)bi * C + 4 * c4) = o;
+  *reinterpret_cast<int4 *>(arg + (size_t)bi * C + 4 * c4) = bj;
+}
+
+// dV[i,c] = dout[i,c] * lrelu'(out[i,c]);  dU[arg[i,c], c] += dV[i,c]  (dU zero-filled by the caller's launch order:
+// this kernel is preceded by a memset on the same stream).  The scatter uses float atomics: a point can be the winning
+// neighbour of many others, and which of them are there is only known through the forward's arg table.
+__global__ __launch_bounds__(256) void edge_max_bwd_k(const float *__restrict__ dout, const float *__restrict__ out,
+                                                      const int32_t *__restrict__ arg, int N, int C, float slope,
+                                                      float *__restrict__ dU, float *__restrict__ dV, long long total) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, i, c)
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const long long b = e / ((long long)N * C);
+  const float g = dout[e] * (out[e] > 0.f ? 1.0f : slope);
+  dV[e] = g;
+  atomicAdd(dU + ((size_t)(b * N + arg[e])) * C + c, g);
+}
+
+}  // namespace hitadv
+
+extern "C" int hitadv_edge_max_fwd(const float *U, const float *V, const int64_t *idx, int B, int N, int C, int k,
+                                   float slope, float *out, int32_t *arg, void *stream) {
+  if (!U || !V || !idx || !out || !arg || B <= 0 || N <= 0 || C <= 0 || (C & 3) || k <= 0 ||
+      (((uintptr_t)U | (uintptr_t)V | (uintptr_t)out | (uintptr_t)arg) & 15))
+    return HITADV_E_ARG;
+  const long long total4 = (long long)B * N * (C >> 2);
+  hitadv::edge_max_fwd_k<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(U, V, idx, N, C, k, slope, out,
+                                                                                         arg, total4);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_edge_max_bwd(const float *dout, const float *out, const int32_t *arg, int B, int N, int C,
+                                   float slope, float *dU, float *dV, void *stream) {
+  if (!dout || !out || !arg || !dU || !dV || B <= 0 || N <= 0 || C <= 0) return HITADV_E_ARG;
+  const long long total = (long long)B * N * C;
+  hipError_t e = hipMemsetAsync(dU, 0, (size_t)total * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  hitadv::edge_max_bwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(dout, out, arg, N, C, slope, dU,
+                                                                                        dV, total);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}

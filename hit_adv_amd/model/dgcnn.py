@@ -79,3 +79,97 @@ class DGCNN_cls(nn.Module):
         g = self.dp1(F.leaky_relu(self.bn6(self.linear1(g)), negative_slope=0.2))
         g = self.dp2(F.leaky_relu(self.bn7(self.linear2(g)), negative_slope=0.2))
         return self.linear3(g)
+
+
+# --------------------------------------------------------------------------------------------
+# Attack-time view: the same function, re-planned for the GPU.
+# --------------------------------------------------------------------------------------------
+def _bn_affine(bn):
+    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return s, bn.bias - bn.running_mean * s
+
+
+class FoldedDGCNN(nn.Module):
+    """Inference-mode restatement of ``DGCNN_cls`` for the attack loop (weights are constants of an attack).
+
+    * every eval-mode BatchNorm is folded into the layer in front of it, activations are points-major ``[B*N, C]``;
+    * **EdgeConv without the edge tensor**: the 1x1 convolution on ``[x_j - x_i ; x_i]`` is linear, so
+      ``W e_ij = Wa x_j + (Wb - Wa) x_i``; LeakyReLU is monotonic, so
+      ``max_j lrelu(bn(W e_ij)) = lrelu(V_i + max_j U_j)`` with the per-POINT products ``U = X (s Wa)^T`` and
+      ``V = X (s (Wb - Wa))^T + t``.  Two GEMMs on N rows replace one on N*k rows, and the gather / max / activation is
+      one HIP kernel (``hitadv_edge_max_fwd``; backward ``hitadv_edge_max_bwd``) -- the ``[B,2C,N,k]`` tensor, its
+      permute/contiguous copy and MIOpen's 1x1 Conv2d are gone;
+    * the neighbour graphs come from ``knn`` above (HIP kernels), exactly as in the module.
+
+    Same function as the module up to fp32 re-association (``tests/test_dgcnn.py``, ``test_dgcnn_attack_view_on_gpu``).
+    Build it with ``DGCNN_cls.attack_view()``; ``refresh`` re-folds the module's current weights in place."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.k = m.k
+        for name, t in self._folded(m).items():
+            self.register_buffer(name, t.detach().clone())
+
+    @staticmethod
+    def _folded(m):
+        assert not m.training, "attack_view() folds running statistics: call model.eval() first"
+        out = {}
+        with torch.no_grad():
+            for l, (conv, bn) in enumerate(((m.conv1[0], m.bn1), (m.conv2[0], m.bn2), (m.conv3[0], m.bn3),
+                                            (m.conv4[0], m.bn4)), start=1):
+                W = conv.weight.reshape(conv.weight.shape[0], -1)  # [Cout, 2Cin]
+                cin = W.shape[1] // 2
+                s, t = _bn_affine(bn)
+                out['u%d_w' % l] = (W[:, :cin] * s[:, None]).t().contiguous()               # [Cin, Cout]
+                out['v%d_w' % l] = ((W[:, cin:] - W[:, :cin]) * s[:, None]).t().contiguous()
+                out['v%d_b' % l] = t.clone()
+            s, t = _bn_affine(m.bn5)
+            out['c5_w'] = (m.conv5[0].weight.reshape(m.conv5[0].weight.shape[0], -1) * s[:, None]).t().contiguous()
+            out['c5_b'] = t.clone()
+            s, t = _bn_affine(m.bn6)
+            out['l1_w'] = (m.linear1.weight * s[:, None]).t().contiguous()
+            out['l1_b'] = t.clone()
+            s, t = _bn_affine(m.bn7)
+            out['l2_w'] = (m.linear2.weight * s[:, None]).t().contiguous()
+            out['l2_b'] = m.linear2.bias * s + t
+            out['l3_w'] = m.linear3.weight.t().contiguous()
+            out['l3_b'] = m.linear3.bias.clone()
+        return out
+
+    def refresh(self, m):
+        for name, t in self._folded(m).items():
+            getattr(self, name).copy_(t)
+        return self
+
+    def _edge(self, h, B, N, l):
+        """h [B*N,Cin] -> [B*N,Cout]"""
+        with torch.no_grad():
+            idx = knn(h.detach().view(B, N, -1).transpose(1, 2), self.k)  # [B,N,k]
+        U = torch.mm(h, getattr(self, 'u%d_w' % l))
+        V = torch.addmm(getattr(self, 'v%d_b' % l), h, getattr(self, 'v%d_w' % l))
+        C = U.shape[1]
+        if h.is_cuda:
+            return ops.edge_max(U.view(B, N, C), V.view(B, N, C), idx, 0.2).view(B * N, C)
+        nbr = U.view(B, N, C).gather(1, idx.reshape(B, N * self.k, 1).expand(B, N * self.k, C)).view(B, N, self.k, C)
+        return F.leaky_relu(nbr.max(dim=2)[0] + V.view(B, N, C), negative_slope=0.2).view(B * N, C)
+
+    def forward(self, x):
+        """x [B,3,N] -> logits [B,classes]"""
+        B, _, N = x.shape
+        h = x.transpose(1, 2).reshape(B * N, 3)
+        feats = []
+        for l in (1, 2, 3, 4):
+            h = self._edge(h, B, N, l)
+            feats.append(h)
+        h = F.leaky_relu(torch.addmm(self.c5_b, torch.cat(feats, dim=1), self.c5_w), negative_slope=0.2).view(B, N, -1)
+        g = torch.cat((h.max(dim=1)[0], h.mean(dim=1)), dim=1)
+        g = F.leaky_relu(torch.addmm(self.l1_b, g, self.l1_w), negative_slope=0.2)
+        g = F.leaky_relu(torch.addmm(self.l2_b, g, self.l2_w), negative_slope=0.2)
+        return torch.addmm(self.l3_b, g, self.l3_w)
+
+
+def _attack_view(self):
+    return FoldedDGCNN(self)
+
+
+DGCNN_cls.attack_view = _attack_view

@@ -389,6 +389,38 @@ def pointnet_rowmlp_tiles(N):
     return int(_lib.load().hitadv_pointnet_rowmlp_tiles(N))
 
 
+class EdgeMax(torch.autograd.Function):
+    """out[b,i,:] = lrelu(V[b,i,:] + max_{j in idx[b,i,:]} U[b,j,:])  -- EdgeConv's gather / max / activation after the
+    1x1 convolution has been split into two per-point products (see hitadv_edge_max_fwd).  U, V [B,N,C], idx [B,N,k]."""
+
+    @staticmethod
+    def forward(ctx, U, V, idx, slope):
+        U, V = _dev(U, "U"), _dev(V, "V")
+        idx = _dev(idx, "idx", torch.int64)
+        B, N, C = U.shape
+        out = torch.empty_like(U)
+        arg = torch.empty(B, N, C, device=U.device, dtype=torch.int32)
+        _lib.call("hitadv_edge_max_fwd", _p(U), _p(V), _p(idx), B, N, C, idx.shape[2], ctypes.c_float(slope), _p(out),
+                  _p(arg), _stream())
+        ctx.save_for_backward(out, arg)
+        ctx.slope = slope
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, arg = ctx.saved_tensors
+        B, N, C = out.shape
+        dout = dout.contiguous()
+        dU, dV = torch.empty_like(out), torch.empty_like(out)
+        _lib.call("hitadv_edge_max_bwd", _p(dout), _p(out), _p(arg), B, N, C, ctypes.c_float(ctx.slope), _p(dU), _p(dV),
+                  _stream())
+        return dU, dV, None, None
+
+
+def edge_max(U, V, idx, slope=0.2):
+    return EdgeMax.apply(U, V, idx, slope)
+
+
 def topk_rows(P, K, largest=True):
     """Row-wise top-K of a matrix [..., M] -> (vals[..., K], idx[..., K] int64), sorted, ties -> lower column."""
     P = _dev(P.detach(), "P")

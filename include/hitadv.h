@@ -296,6 +296,19 @@ int hitadv_fc_layer(const float *in, const float *mask, const float *Wt, const f
                     int relu, float *out, float *scratch, void *stream);
 int64_t hitadv_fc_layer_scratch_floats(int B, int K, int NOUT);
 
+/* ------------------------------------------------------------------ DGCNN victim: EdgeConv neighbour reduction
+ * get_graph_feature + Conv2d(1x1) + BatchNorm2d + LeakyReLU + max over the k neighbours (model/dgcnn_cls.py:16-43,
+ * 93-112) with the convolution split algebraically into two per-point products U = X (s Wa)^T, V = X (s (Wb - Wa))^T + t
+ * (W = [Wa | Wb] acting on [x_j - x_i ; x_i], BatchNorm scale s / shift t folded):
+ *   out[b,i,c] = lrelu(V[b,i,c] + max_{j in idx[b,i,:]} U[b,j,c]),  arg[b,i,c] = the winning j.
+ * U, V, out [B,N,C] points-major, C % 4 == 0, idx [B,N,k] int64; the [B,2C,N,k] edge tensor is never built. */
+int hitadv_edge_max_fwd(const float *U, const float *V, const int64_t *idx, int B, int N, int C, int k, float slope,
+                        float *out, int32_t *arg, void *stream);
+/* dV = dout * lrelu'(out);  dU[b,j,c] = sum_{i: arg[b,i,c]==j} dV[b,i,c]  (dU is zero-filled here; float atomics, so the
+ * summation order -- not the set of terms -- varies between runs, like the reference's index_select backward). */
+int hitadv_edge_max_bwd(const float *dout, const float *out, const int32_t *arg, int B, int N, int C, float slope,
+                        float *dU, float *dV, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

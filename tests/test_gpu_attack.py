@@ -340,6 +340,63 @@ def test_dgcnn_victim_on_gpu_and_under_attack():
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-3, atol=1e-4)
 
 
+def test_dgcnn_attack_view_and_edge_max_kernels():
+    """The folded DGCNN view on the GPU: the EdgeConv neighbour-max kernels against their torch formulation (forward
+    bitwise, arg table consistent, backward to rounding -- the scatter uses float atomics), the view against the module
+    (same neighbour tables up to fp32 near-ties), and HiT-ADV using it by default."""
+    import argparse
+    from hit_adv_amd import ops
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.dgcnn import DGCNN_cls, FoldedDGCNN
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    g = torch.Generator().manual_seed(2)
+    B, N, C, k = 3, 200, 64, 7
+    U = torch.randn(B, N, C, generator=g).cuda().requires_grad_()
+    V = torch.randn(B, N, C, generator=g).cuda().requires_grad_()
+    idx = torch.randint(0, N, (B, N, k), generator=g).cuda()
+    w = torch.randn(B, N, C, generator=g).cuda()
+    out = ops.edge_max(U, V, idx, 0.2)
+    nbr = U.gather(1, idx.reshape(B, N * k, 1).expand(B, N * k, C)).view(B, N, k, C)
+    ref = torch.nn.functional.leaky_relu(nbr.max(dim=2)[0] + V, negative_slope=0.2)
+    assert torch.equal(out, ref)
+    gu, gv = torch.autograd.grad((out * w).sum(), [U, V])
+    ru, rv = torch.autograd.grad((ref * w).sum(), [U, V])
+    assert torch.equal(gv, rv)
+    close(gu, ru, rtol=1e-5, atol=1e-5)
+
+    torch.manual_seed(5)
+    m = DGCNN_cls(argparse.Namespace(k=5, emb_dims=1024, dropout=0.2), output_channels=40).eval().cuda()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+    view = m.attack_view()
+    assert isinstance(view, FoldedDGCNN)
+    data, _ = synth_batch(4, 512, first=1300)
+    x = data[:, :, :3].transpose(1, 2).contiguous().cuda()
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    la, lb = m(xa), view(xb)
+    close(lb, la, rtol=2e-3, atol=2e-4)
+    wl = torch.randn(4, 40, device='cuda', generator=torch.Generator('cuda').manual_seed(1))
+    ga, = torch.autograd.grad((la * wl).sum(), xa)
+    gb, = torch.autograd.grad((lb * wl).sum(), xb)
+    assert float((gb - ga).norm()) <= 2e-2 * float(ga.norm())
+    label = la.argmax(1)
+    outs = []
+    for fast in (False, True):
+        att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), binary_step=1, num_iter=5, cd_weight=1e-4, ker_weight=1.,
+                      hide_weight=1., curv_loss_knn=16, central_num=64, total_central_num=96, max_sigm=1.2,
+                      min_sigm=0.1, budget=0.55, verbose=False, fast_victim=fast)
+        torch.manual_seed(8)
+        best, _ = att.attack(data, label)
+        assert att.last_graph_used and (att._view is not None) == fast
+        ws = next(iter(att._ws.values()))
+        outs.append((ws.central.clone(), ws.adv.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])                 # same saliency ranking -> same centres
+    close(outs[0][1], outs[1][1], rtol=1e-2, atol=2e-3)        # five Adam steps on slightly different gradients
+
+
 def test_pointnet2_victim_on_gpu():
     """PointNet++ SSG with HIP FPS / ball query against the reference (fixture g11): same FPS table bit for bit,
     same ball-query table (up to points within fp32 noise of the sphere: the reference thresholds Gram-form
