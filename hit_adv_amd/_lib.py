@@ -52,6 +52,7 @@ PROTOTYPES = {
     "hitadv_pointnet_rowmlp_tiles": [_I],
     "hitadv_pointnet_rowmlp_bwd": [_I, _P, _P, _P, _P, _I] + [_P] * 12 + [_I, _I, _P],
     "hitadv_sum_partials": [_P, _P, _I, _I, _I, _P, _P],
+    "hitadv_knn_features": [_P, _P, _I, _I, _I, _I, _P, _P],
     "hitadv_edge_max_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "hitadv_edge_max_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     "hitadv_fc_layer": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],

@@ -369,3 +369,150 @@ extern "C" int hitadv_knn_points_bwd(const float *q, const float *p, const void 
   HITADV_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// k nearest neighbours in FEATURE space (DGCNN's dynamic graph, model/dgcnn_cls.py:7-13) without the [B,N,N] score
+// matrix: scores  s_ij = (-|x_i|^2 + 2 x_i.x_j) - |x_j|^2  (the reference's expression, larger = closer) come out of the
+// f32 matrix cores tile by tile and go straight into per-lane sorted lists.
+//   block = 4 waves = 128 queries of one cloud; reference points stream through LDS in 32-point tiles (double buffered,
+//   shared by the waves); wave w holds its 32 queries' features in registers as the MFMA B operand, so the accumulator
+//   has the QUERY on the lane and 16 reference points in registers: a lane scans its 16 scores against its own list
+//   (KB entries, compile-time indices, no scratch).  Each query is served by two lanes (the halves of the wave see
+//   disjoint reference rows); their lists are merged at the end.  Ties -> lower index.
+namespace hitadv {
+
+typedef float f32x16_k __attribute__((ext_vector_type(16)));
+
+template <int D, int KB>
+__global__ __launch_bounds__(256) void knn_feat_k(const float *__restrict__ X, const float *__restrict__ xx, int N, int K,
+                                                  int64_t *__restrict__ idx) {
+  constexpr int LD = D + 4;
+  constexpr int ST = 32 * (D / 4) / 256;  // float4 staged per thread per 32-point tile (D=64: 2, D=128: 4)
+  constexpr int TILE_F = 2 * 32 * LD, MERGE_F = 2 * 4 * 32 * 2 * KB;  // floats: reference tiles / final merge
+  __shared__ float4 sR4[(TILE_F > MERGE_F ? TILE_F : MERGE_F) / 4];
+  __shared__ float sXX[2][32];
+  float *sR = reinterpret_cast<float *>(sR4);
+  const int b = blockIdx.y, q0 = blockIdx.x * 128;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  X += (size_t)b * N * D;
+  xx += (size_t)b * N;
+  const int q = q0 + 32 * wave + r;       // this lane's query
+  const int qc = q < N ? q : N - 1;       // clamp for loads
+  float qreg[D / 2];
+#pragma unroll
+  for (int t = 0; t < D / 2; ++t) qreg[t] = X[(size_t)qc * D + 8 * (t >> 2) + 4 * h + (t & 3)];
+  const float qxx = xx[qc];
+  float lv[KB];
+  int li[KB];
+#pragma unroll
+  for (int t = 0; t < KB; ++t) {
+    lv[t] = -__builtin_inff();
+    li[t] = 0x7fffffff;
+  }
+  const int ntiles = (N + 31) / 32;
+  float4 st[ST];
+  float stx = 0.f;
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < ST; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      const int n = tile * 32 + e / (D / 4);
+      st[u] = n < N ? *reinterpret_cast<const float4 *>(X + (size_t)n * D + 4 * (e % (D / 4))) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (threadIdx.x < 32) stx = tile * 32 + threadIdx.x < N ? xx[tile * 32 + threadIdx.x] : __builtin_inff();
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < ST; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      *reinterpret_cast<float4 *>(sR + buf * 32 * LD + (e / (D / 4)) * LD + 4 * (e % (D / 4))) = st[u];
+    }
+    if (threadIdx.x < 32) sXX[buf][threadIdx.x] = stx;
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const bool more = tile + 1 < ntiles;
+    if (more) fetch(tile + 1);
+    const float *a = sR + (tile & 1) * 32 * LD + r * LD + 4 * h;
+    f32x16_k acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < D / 8; ++j) {
+      const float4 av = *reinterpret_cast<const float4 *>(a + 8 * j);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, qreg[4 * j], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, qreg[4 * j + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, qreg[4 * j + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qreg[4 * j + 3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {  // reference row of element e: (e&3) + 8*(e>>2) + 4*h, ascending in e
+      const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const float s = (2.0f * acc[e] - qxx) - sXX[tile & 1][rr];  // -inf for rows past N
+      if (s > lv[KB - 1]) {
+        const int j = tile * 32 + rr;
+#pragma unroll
+        for (int t = KB - 1; t > 0; --t) {
+          const bool sh = s > lv[t - 1];
+          const bool wr = s > lv[t];
+          const float nv = sh ? lv[t - 1] : s;
+          const int ni = sh ? li[t - 1] : j;
+          lv[t] = wr ? nv : lv[t];
+          li[t] = wr ? ni : li[t];
+        }
+        const bool w0 = s > lv[0];
+        lv[0] = w0 ? s : lv[0];
+        li[0] = w0 ? j : li[0];
+      }
+    }
+    if (more) stash((tile + 1) & 1);
+    __syncthreads();
+  }
+  // merge the two halves' lists of every query (LDS: the reference tiles are dead)
+  float *mv = sR;                                  // [4 waves][32 queries][2][KB]
+  int *mi = reinterpret_cast<int *>(sR + 4 * 32 * 2 * KB);
+  const int slot = ((wave * 32 + r) * 2 + h) * KB;
+#pragma unroll
+  for (int t = 0; t < KB; ++t) {
+    mv[slot + t] = lv[t];
+    mi[slot + t] = li[t];
+  }
+  __syncthreads();
+  if (h == 0 && q < N) {
+    const int s0 = ((wave * 32 + r) * 2) * KB, s1 = s0 + KB;
+    int p0 = 0, p1 = 0;
+    int64_t *o = idx + ((size_t)b * N + q) * K;
+    for (int t = 0; t < K; ++t) {
+      const float v0 = mv[s0 + p0], v1 = mv[s1 + p1];
+      const int i0 = mi[s0 + p0], i1 = mi[s1 + p1];
+      const bool take0 = v0 > v1 || (v0 == v1 && i0 < i1);
+      o[t] = take0 ? i0 : i1;
+      p0 += take0 ? 1 : 0;
+      p1 += take0 ? 0 : 1;
+      if (p0 >= KB) p0 = KB - 1, mv[s0 + p0] = -__builtin_inff(), mi[s0 + p0] = 0x7fffffff;  // exhausted list
+      if (p1 >= KB) p1 = KB - 1, mv[s1 + p1] = -__builtin_inff(), mi[s1 + p1] = 0x7fffffff;
+    }
+  }
+}
+
+}  // namespace hitadv
+
+extern "C" int hitadv_knn_features(const float *X, const float *xx, int B, int N, int D, int K, int64_t *idx,
+                                   void *stream) {
+  if (!X || !xx || !idx || B <= 0 || N <= 0 || K <= 0 || K > 20 || K > N || (D != 64 && D != 128) || ((uintptr_t)X & 15))
+    return HITADV_E_ARG;
+  dim3 grid((N + 127) / 128, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (D == 64) {
+    if (K <= 8) hitadv::knn_feat_k<64, 8><<<grid, 256, 0, s>>>(X, xx, N, K, idx);
+    else hitadv::knn_feat_k<64, 20><<<grid, 256, 0, s>>>(X, xx, N, K, idx);
+  } else {
+    if (K <= 8) hitadv::knn_feat_k<128, 8><<<grid, 256, 0, s>>>(X, xx, N, K, idx);
+    else hitadv::knn_feat_k<128, 20><<<grid, 256, 0, s>>>(X, xx, N, K, idx);
+  }
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}

@@ -144,7 +144,11 @@ class FoldedDGCNN(nn.Module):
     def _edge(self, h, B, N, l):
         """h [B*N,Cin] -> [B*N,Cout]"""
         with torch.no_grad():
-            idx = knn(h.detach().view(B, N, -1).transpose(1, 2), self.k)  # [B,N,k]
+            D = h.shape[1]
+            if h.is_cuda and ops.knn_features_supported(D, self.k):
+                idx = ops.knn_features(h.view(B, N, D), self.k)  # fused MFMA scores + selection, no [B,N,N] matrix
+            else:
+                idx = knn(h.detach().view(B, N, -1).transpose(1, 2), self.k)  # [B,N,k]
         U = torch.mm(h, getattr(self, 'u%d_w' % l))
         V = torch.addmm(getattr(self, 'v%d_b' % l), h, getattr(self, 'v%d_w' % l))
         C = U.shape[1]

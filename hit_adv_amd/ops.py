@@ -421,6 +421,21 @@ def edge_max(U, V, idx, slope=0.2):
     return EdgeMax.apply(U, V, idx, slope)
 
 
+def knn_features(x, K):
+    """x [B,N,D] points-major features (D in {64,128}) -> idx [B,N,K] int64 of the K nearest points in feature space
+    (closest first, ties -> lower index); no [B,N,N] score matrix (hitadv_knn_features)."""
+    x = _dev(x.detach(), "x")
+    B, N, D = x.shape
+    xx = (x * x).sum(dim=2)
+    idx = torch.empty(B, N, K, device=x.device, dtype=torch.int64)
+    _lib.call("hitadv_knn_features", _p(x), _p(xx), B, N, D, K, _p(idx), _stream())
+    return idx
+
+
+def knn_features_supported(D, K):
+    return D in (64, 128) and K <= 20
+
+
 def topk_rows(P, K, largest=True):
     """Row-wise top-K of a matrix [..., M] -> (vals[..., K], idx[..., K] int64), sorted, ties -> lower column."""
     P = _dev(P.detach(), "P")

@@ -309,6 +309,12 @@ int hitadv_edge_max_fwd(const float *U, const float *V, const int64_t *idx, int 
 int hitadv_edge_max_bwd(const float *dout, const float *out, const int32_t *arg, int B, int N, int C, float slope,
                         float *dU, float *dV, void *stream);
 
+/* k nearest neighbours in feature space for DGCNN's dynamic graph (model/dgcnn_cls.py:7-13: topk of
+ * -|x_i|^2 + 2 x_i.x_j - |x_j|^2), fused: the scores come off the f32 matrix cores tile by tile and go straight into
+ * per-lane sorted lists -- no [B,N,N] matrix.  X [B,N,D] points-major (D in {64,128}, 16-byte aligned), xx [B,N] = |x|^2,
+ * K <= 20.  idx [B,N,K] int64, closest first (the point itself), ties -> lower index. */
+int hitadv_knn_features(const float *X, const float *xx, int B, int N, int D, int K, int64_t *idx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

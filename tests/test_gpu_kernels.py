@@ -644,6 +644,33 @@ def test_pointnet_engine_matches_module(B, Np):
     close(gh, gt, rtol=1e-3, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("B,Np,D,K", [(2, 1024, 64, 5), (3, 500, 64, 20), (2, 1024, 128, 5), (1, 130, 128, 20), (2, 33, 64, 8)])
+def test_knn_features_mfma(A, B, Np, D, K):
+    """Fused feature-space kNN (MFMA scores + per-lane selection) against the reference's expression evaluated in float64:
+    identical neighbour sets wherever the K-th and (K+1)-th scores are further apart than fp32 noise, self at rank 0,
+    descending scores, duplicates resolved towards the lower index."""
+    g = torch.Generator().manual_seed(B * 100 + D + K)
+    x = torch.randn(B, Np, D, generator=g)
+    x[0, 7] = x[0, 3]  # exact duplicate: point 3 and 7 see identical scores everywhere
+    xd = x.double()
+    inner = -2 * torch.matmul(xd, xd.transpose(2, 1))
+    xx = (xd ** 2).sum(2, keepdim=True)
+    score = -xx - inner - xx.transpose(2, 1)
+    top = score.topk(K + 1, dim=-1)
+    idx = A.knn_features(cu(x), K).cpu()
+    assert idx.dtype == torch.int64 and idx.shape == (B, Np, K)
+    got = score.gather(2, idx)
+    assert (got[..., :-1] >= got[..., 1:] - 1e-3).all()                       # closest first
+    clear = (top.values[..., K - 1] - top.values[..., K]) > 1e-3               # unambiguous K-set
+    assert clear.float().mean() > 0.95
+    same = (idx.sort(dim=-1).values == top.indices[..., :K].sort(dim=-1).values).all(-1)
+    assert same[clear].all()
+    self_first = idx[..., 0] == torch.arange(Np)[None, :]
+    self_first[0, 7] = self_first[0, 7] | (idx[0, 7, 0] == 3)                  # the duplicate pair: lower index first
+    assert self_first.all() and idx[0, 7, 0] == 3 and idx[0, 3, 0] == 3
+    assert torch.equal(idx, A.knn_features(cu(x), K).cpu())
+
+
 def test_fused_regulariser_matches_torch_composition(A):
     """hitadv_regulariser_{fwd,bwd} vs the reference's composition of ChamferDist (on [B,3,N], quirk Q1),
     transformation_loss, curv_std_loss and the scale_const weighting, evaluated by the CPU oracle + autograd."""
