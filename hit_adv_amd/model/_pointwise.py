@@ -1,0 +1,49 @@
+"""1x1 convolutions of the point-cloud victims as GEMMs.
+
+MIOpen has no tuned solver for the shapes these networks feed to ``Conv1d(k=1)`` / ``Conv2d(1x1)`` (tens of thousands of
+tiny "images": [B*npoint, C, nsample]); on gfx950 it falls back to ``naive_conv_*`` kernels -- 15 ms forward and 24 ms
+backward PER CALL in PCT's Local_op (rocprofv3, profiles/), and ``MIOpenBatchNormFwdInferSpatialEst`` adds 1.5 ms per
+BatchNorm.  A 1x1 convolution is a matrix product, so in eval mode on the GPU the layer is evaluated as one GEMM with
+the BatchNorm folded into its weights; parameters, buffers and state_dict layout are untouched (the modules stay
+``nn.Conv*`` / ``nn.BatchNorm*``), training mode and CPU tensors go through the modules themselves.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _folded(conv, bn):
+    W = conv.weight.reshape(conv.out_channels, -1)  # [Cout, Cin]
+    b = conv.bias
+    if bn is not None:
+        s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        W = W * s[:, None]
+        b = bn.bias - bn.running_mean * s if b is None else (b - bn.running_mean) * s + bn.bias
+    return W, b
+
+
+def _fast(conv, bn, x):
+    return x.is_cuda and not conv.training and (bn is None or not bn.training)
+
+
+def conv1x1(conv, bn, x):
+    """bn(conv(x)) for channels-major x [B, Cin, ...]; ``bn`` may be None."""
+    if not _fast(conv, bn, x):
+        y = conv(x)
+        return bn(y) if bn is not None else y
+    W, b = _folded(conv, bn)
+    shp = x.shape
+    y = torch.matmul(W, x.reshape(shp[0], shp[1], -1))  # [B, Cout, L]
+    if b is not None:
+        y = y + b[None, :, None]
+    return y.view(shp[0], -1, *shp[2:])
+
+
+def linear_pm(conv, bn, x):
+    """The same layer applied to points-major x [..., Cin] -> [..., Cout] (one GEMM, no permutes)."""
+    W, b = _folded(conv, bn)
+    return F.linear(x, W, b)
+
+
+def fast_pm(conv, bn, x):
+    """Whether the points-major fast path applies (eval mode, CUDA)."""
+    return _fast(conv, bn, x)

@@ -1,6 +1,7 @@
 """PCT victim (cfg5 of BASELINE.json).  Parameter names follow the reference's model/pct_cls.py (Pct :27-75,
 Local_op :6-24, Point_Transformer_Last :77-109, SA_Layer :111-139): 113 state_dict entries
-(tests/golden/g8_state_dicts.json).  Attention / MLPs stay PyTorch-ROCm; the neighbourhood construction of
+(tests/golden/g8_state_dicts.json).  Attention / MLPs stay PyTorch-ROCm (every 1x1 convolution as a GEMM with its
+BatchNorm folded in eval mode, see _pointwise.py); the neighbourhood construction of
 ``sample_and_group`` (model/pct_utils.py:111-140) runs in HIP:
 
 * ``fps`` (util/other_utils.py:254-272): random first index from the CPU generator (:264), then
@@ -15,6 +16,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..pytorch3d_ops import knn_points
+from ._pointwise import conv1x1, fast_pm, linear_pm
 from .pointnet2 import index_points
 
 
@@ -50,6 +52,9 @@ class Local_op(nn.Module):
 
     def forward(self, x):
         b, n, s, d = x.shape
+        if fast_pm(self.conv1, self.bn1, x):  # x is already points-major: two GEMMs and a max over the neighbours
+            h = F.relu(linear_pm(self.conv2, self.bn2, F.relu(linear_pm(self.conv1, self.bn1, x))))
+            return h.max(dim=2)[0].permute(0, 2, 1)
         h = x.permute(0, 1, 3, 2).reshape(-1, d, s)
         h = F.relu(self.bn1(self.conv1(h)))
         h = F.relu(self.bn2(self.conv2(h)))
@@ -70,10 +75,10 @@ class SA_Layer(nn.Module):
         self.softmax = nn.Softmax(dim=-1)
 
     def forward(self, x):
-        attention = self.softmax(torch.bmm(self.q_conv(x).permute(0, 2, 1), self.k_conv(x)))
+        attention = self.softmax(torch.bmm(conv1x1(self.q_conv, None, x).permute(0, 2, 1), conv1x1(self.k_conv, None, x)))
         attention = attention / (1e-9 + attention.sum(dim=1, keepdim=True))
-        x_r = torch.bmm(self.v_conv(x), attention)
-        return x + self.act(self.after_norm(self.trans_conv(x - x_r)))
+        x_r = torch.bmm(conv1x1(self.v_conv, None, x), attention)
+        return x + self.act(conv1x1(self.trans_conv, self.after_norm, x - x_r))
 
 
 class Point_Transformer_Last(nn.Module):
@@ -88,7 +93,7 @@ class Point_Transformer_Last(nn.Module):
         self.sa3, self.sa4 = SA_Layer(channels), SA_Layer(channels)
 
     def forward(self, x):
-        h = F.relu(self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x))))))
+        h = F.relu(conv1x1(self.conv2, self.bn2, F.relu(conv1x1(self.conv1, self.bn1, x))))
         outs = []
         for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
             h = sa(h)
@@ -120,13 +125,13 @@ class Pct(nn.Module):
     def forward(self, x):
         B = x.shape[0]
         xyz = x.permute(0, 2, 1)
-        h = F.relu(self.bn2(self.conv2(F.relu(self.bn1(self.conv1(x)))))).permute(0, 2, 1)
+        h = F.relu(conv1x1(self.conv2, self.bn2, F.relu(conv1x1(self.conv1, self.bn1, x)))).permute(0, 2, 1)
         new_xyz, grouped = sample_and_group(npoint=512, radius=0.15, nsample=32, xyz=xyz, points=h)
         f0 = self.gather_local_0(grouped)
         new_xyz, grouped = sample_and_group(npoint=256, radius=0.2, nsample=32, xyz=new_xyz, points=f0.permute(0, 2, 1))
         f1 = self.gather_local_1(grouped)
-        h = self.conv_fuse(torch.cat([self.pt_last(f1), f1], dim=1))
-        g = F.adaptive_max_pool1d(h, 1).view(B, -1)
+        h = self.conv_fuse[2](conv1x1(self.conv_fuse[0], self.conv_fuse[1], torch.cat([self.pt_last(f1), f1], dim=1)))
+        g = h.max(dim=2)[0] if h.is_cuda else F.adaptive_max_pool1d(h, 1).view(B, -1)
         g = self.dp1(F.leaky_relu(self.bn6(self.linear1(g)), negative_slope=0.2))
         g = self.dp2(F.leaky_relu(self.bn7(self.linear2(g)), negative_slope=0.2))
         return self.linear3(g)
