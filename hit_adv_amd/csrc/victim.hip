@@ -158,6 +158,12 @@ __global__ __launch_bounds__(256) void max_over_points_merge(const float *__rest
 // Partials [B,S,Cout] go through max_over_points_merge (bias, ReLU, split order = ascending points).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int LF_TM = 64;
+// One accumulator set (138 VGPRs) rather than two (256 + spills): alone it is 3 % slower (71.1 vs 68.9 us at B=32), but
+// it leaves half of the register file to kernels of other streams -- with three attacks in flight 16.8 vs 16.1 clouds/s.
+#ifndef LM_PIPE_DEFAULT
+#define LM_PIPE_DEFAULT false
+#endif
+constexpr bool LM_PIPE = LM_PIPE_DEFAULT;
 
 template <int CIN, int NCB, int NT, bool PIPE>
 __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__ X, const float *__restrict__ Wt,
@@ -442,13 +448,13 @@ extern "C" int hitadv_linear_max_fwd(const float *X, const float *Wt, const floa
   const size_t shm = (size_t)2 * LF_TM * (Cin + 4) * sizeof(float);
   // 8 waves x 32 columns per block: two waves per SIMD keep the matrix pipe busy across each other's LDS waits and
   // epilogue scans (measured at B=32: 69.1 us; 4 waves x 64 columns, one wave per SIMD: 73.0 us)
-  // 8 waves x 32 columns per block, two accumulator sets.  Measured at B=32 (us incl. merge): this 68.9; one set 71.1;
-  // 4 waves x 64 columns (one wave per SIMD) 73.0; 512 blocks 75.4; forced to 128 VGPRs for 4 waves per SIMD 74.9-76.7.
+  // 8 waves x 32 columns per block.  Measured at B=32 (us incl. merge): two accumulator sets 68.9; one set 71.1 (chosen,
+  // see LM_PIPE); 4 waves x 64 columns (one wave per SIMD) 73.0; 512 blocks 75.4; forced to 128 VGPRs 74.9-76.7.
   if (Cin == 128) {
-    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128, 1, 512, true>),
+    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128, 1, 512, LM_PIPE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_TM * 132 * 4);
     (void)once;
-    linear_max_fwd_k<128, 1, 512, true><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias,
+    linear_max_fwd_k<128, 1, 512, LM_PIPE><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias,
                                                                 relu, out, idx, tickets);
   } else {
     linear_max_fwd_k<64, 1, 512, true><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu,
