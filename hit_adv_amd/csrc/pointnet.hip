@@ -273,13 +273,15 @@ constexpr int BW_CH = 4;  // Cout <= 256 * BW_CH
 
 template <int STAGE>
 __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
-  __shared__ float4 sD4[PM_TM * PM_L128 / 4], sEF4[2 * PM_TM * PM_L64 / 4];
+  // LDS footprint kept at 51 KB (sD + sE) so that blocks of other kernels fit beside two of these on a CU: the second
+  // 64-wide tile (sF) reuses sD, which is dead once every wave has finished the 128-deep product
+  __shared__ float4 sD4[PM_TM * PM_L128 / 4], sEF4[PM_TM * PM_L64 / 4];
   __shared__ float sX[PM_TM * 3], sG[PM_TM * 3];
   __shared__ int s_cnt[BW_CH][4];
   __shared__ unsigned long long s_present;  // points of this tile that receive any gradient
   __shared__ int s_rowmap[PM_TM];           // compact index -> point
-  float *sD = reinterpret_cast<float *>(sD4), *sE = reinterpret_cast<float *>(sEF4), *sF = sE + PM_TM * PM_L64;
-  int2 *list = reinterpret_cast<int2 *>(sEF4);  // [256 * BW_CH] (channel | point << 16, gradient bits); dead before sE/sF are written
+  float *sD = reinterpret_cast<float *>(sD4), *sE = reinterpret_cast<float *>(sEF4), *sF = sD;
+  int2 *list = reinterpret_cast<int2 *>(sEF4);  // [256 * BW_CH + 32] (channel | point << 16, gradient bits); dead before sE is written
   const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, n0 = tile * PM_TM, N = a.N, Cout = a.Cout;
   const int rows = min(PM_TM, N - n0);
   const size_t row0 = (size_t)b * N + n0;
@@ -391,7 +393,6 @@ __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
     v.z = a2[u].z > 0.f ? v.z : 0.f; v.w = a2[u].w > 0.f ? v.w : 0.f;
     *d = v;
   }
-  if (STAGE == 2) stash_tile<64>(h1t, sF, PM_L64);
   __syncthreads();
   {  // through the 64->128 layer: [64,128] @ W2r[128,64]
     f32x16 acc[1];
@@ -405,6 +406,10 @@ __global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
     }
   }
   __syncthreads();
+  if (STAGE == 2) {  // sD is dead: it now takes the h1 tile (left operand of the transform gradient)
+    stash_tile<64>(h1t, sF, PM_L64);
+    __syncthreads();
+  }
 
   if (STAGE == 2) {
     // (a) dT64 partial of this tile:  sum_n h1[n,i] * d[n,j]   (A = h1^T, B = d, K = 64 points)
