@@ -272,7 +272,7 @@ struct RowMlpBwd {
 constexpr int BW_CH = 4;  // Cout <= 256 * BW_CH
 
 template <int STAGE>
-__global__ __launch_bounds__(256) void rowmlp_bwd_k(RowMlpBwd a) {
+__global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   // LDS footprint kept at 51 KB (sD + sE) so that blocks of other kernels fit beside two of these on a CU: the second
   // 64-wide tile (sF) reuses sD, which is dead once every wave has finished the 128-deep product
   __shared__ float4 sD4[PM_TM * PM_L128 / 4], sEF4[PM_TM * PM_L64 / 4];
