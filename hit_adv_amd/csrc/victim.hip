@@ -164,6 +164,12 @@ constexpr int LF_TM = 64;
 #define LM_PIPE_DEFAULT false
 #endif
 constexpr bool LM_PIPE = LM_PIPE_DEFAULT;
+// Two LDS tiles (67.6 KB).  One tile (33.8 KB, an extra barrier per tile) measured the same within noise, alone (71.6 us)
+// and with three attacks in flight (17.57 vs 17.66 clouds/s), so the double buffer stays.
+#ifndef LM_DBUF_DEFAULT
+#define LM_DBUF_DEFAULT true
+#endif
+constexpr bool LM_DBUF = LM_DBUF_DEFAULT;
 
 template <int CIN, int NCB, int NT, bool PIPE>
 __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__ X, const float *__restrict__ Wt,
@@ -299,10 +305,11 @@ __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__
       const bool more = tile + 1 < ntiles;
       if (more) fetch(tile + 1);
       if (active) {
-        tile_step(accA, tile & 1, accB, 0, false);
+        tile_step(accA, LM_DBUF ? (tile & 1) : 0, accB, 0, false);
         epilogue(accA, tile);
       }
-      if (more) stash((tile + 1) & 1);
+      if (!LM_DBUF) __syncthreads();  // single LDS tile: every wave is done reading before it is overwritten
+      if (more) stash(LM_DBUF ? ((tile + 1) & 1) : 0);
       __syncthreads();
     }
   } else {
@@ -445,7 +452,7 @@ extern "C" int hitadv_linear_max_fwd(const float *X, const float *Wt, const floa
   linear_max_split(B, N, Cout, &S, &rows);
   const int ncg = (Cout + 255) / 256;
   dim3 grid((unsigned)(ncg * S * B));
-  const size_t shm = (size_t)2 * LF_TM * (Cin + 4) * sizeof(float);
+  const size_t shm = (size_t)(LM_DBUF ? 2 : 1) * LF_TM * (Cin + 4) * sizeof(float);
   // 8 waves x 32 columns per block: two waves per SIMD keep the matrix pipe busy across each other's LDS waits and
   // epilogue scans (measured at B=32: 69.1 us; 4 waves x 64 columns, one wave per SIMD: 73.0 us)
   // 8 waves x 32 columns per block.  Measured at B=32 (us incl. merge): two accumulator sets 68.9; one set 71.1 (chosen,
