@@ -394,7 +394,8 @@ class HiTADVOracle:
                  binary_step=10, num_iter=500, clip_func=None, cd_weight=0, curv_weight=0,
                  ker_weight=0, hide_weight=0, curv_loss_knn=32, central_num=32,
                  total_central_num=128, max_sigm=0.7, min_sigm=0.1, budget=0.1, alpha=1):
-        self.model = model.eval()
+        model.eval()  # (not `model = model.eval()`: the reference's FeatureModel.eval() returns None)
+        self.model = model
         self.adv_func = adv_func
         self.hp = dict(attack_lr=attack_lr, init_weight=init_weight, max_weight=max_weight,
                        binary_step=binary_step, num_iter=num_iter, cd_weight=cd_weight,
