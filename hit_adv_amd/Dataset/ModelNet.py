@@ -18,83 +18,82 @@ from torch.utils.data import Dataset
 
 
 def pc_normalize(pc):
-    pc = pc - np.mean(pc, axis=0)
-    return pc / np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+    """Centre on the mean, scale the farthest point onto the unit sphere."""
+    centred = pc - pc.mean(axis=0)
+    return centred / np.sqrt((centred ** 2).sum(axis=1)).max()
 
 
 def farthest_point_sample(point, npoint):
-    """point [N,D] -> the npoint rows picked by FPS on xyz, random start from ``np.random`` (as the reference)."""
-    N = point.shape[0]
+    """point [N,D] -> the npoint rows picked by farthest point sampling on xyz.  One ``np.random.randint`` draw for the
+    start, first arg-max on ties: the selection (and the RNG stream) of the reference's loop."""
     xyz = point[:, :3]
-    centroids = np.zeros((npoint,))
-    distance = np.ones((N,)) * 1e10
-    farthest = np.random.randint(0, N)
+    chosen = np.empty(npoint, dtype=np.int64)
+    nearest = np.full(xyz.shape[0], 1e10)
+    cur = np.random.randint(0, xyz.shape[0])
     for i in range(npoint):
-        centroids[i] = farthest
-        dist = np.sum((xyz - xyz[farthest, :]) ** 2, -1)
-        mask = dist < distance
-        distance[mask] = dist[mask]
-        farthest = np.argmax(distance, -1)
-    return point[centroids.astype(np.int32)]
+        chosen[i] = cur
+        np.minimum(nearest, ((xyz - xyz[cur]) ** 2).sum(-1), out=nearest)
+        cur = int(nearest.argmax())
+    return point[chosen]
 
 
 class ModelNetDataLoader(Dataset):
     """``args`` needs ``num_point``, ``use_uniform_sample``, ``use_normals``, ``num_category`` (eval.py's parser)."""
 
     def __init__(self, root, args, split='train', process_data=False):
-        self.root = root
-        self.npoints = args.num_point
-        self.process_data = process_data
-        self.uniform = args.use_uniform_sample
-        self.use_normals = args.use_normals
-        self.num_category = args.num_category
-        tag = 'modelnet10' if self.num_category == 10 else 'modelnet40'
-        self.catfile = os.path.join(self.root, tag + '_shape_names.txt')
-        self.cat = [line.rstrip() for line in open(self.catfile)]
-        self.classes = dict(zip(self.cat, range(len(self.cat))))
-        assert split in ('train', 'test')
-        ids = [line.rstrip() for line in open(os.path.join(self.root, '%s_%s.txt' % (tag, split)))]
-        names = ['_'.join(x.split('_')[0:-1]) for x in ids]
-        self.datapath = [(names[i], os.path.join(self.root, names[i], ids[i]) + '.txt') for i in range(len(ids))]
+        if split not in ('train', 'test'):
+            raise AssertionError(split)
+        self.root, self.process_data = root, process_data
+        self.npoints, self.uniform = args.num_point, args.use_uniform_sample
+        self.use_normals, self.num_category = args.use_normals, args.num_category
+        family = 'modelnet%d' % (10 if self.num_category == 10 else 40)
+        self.catfile = os.path.join(root, family + '_shape_names.txt')
+        self.cat = self._lines(self.catfile)
+        self.classes = {name: i for i, name in enumerate(self.cat)}
+        self.datapath = []
+        for shape_id in self._lines(os.path.join(root, '%s_%s.txt' % (family, split))):
+            cls = shape_id.rsplit('_', 1)[0]  # 'night_stand_0001' -> 'night_stand'
+            self.datapath.append((cls, os.path.join(root, cls, shape_id) + '.txt'))
         print('The size of %s data is %d' % (split, len(self.datapath)))
-        self.save_path = os.path.join(root, 'modelnet%d_%s_%dpts%s.dat' % (self.num_category, split, self.npoints,
-                                                                         '_fps' if self.uniform else ''))
-        if self.process_data:
-            if not os.path.exists(self.save_path):
-                print('Processing data %s (only running in the first time)...' % self.save_path)
-                self.list_of_points = [None] * len(self.datapath)
-                self.list_of_labels = [None] * len(self.datapath)
-                for index in range(len(self.datapath)):
-                    self.list_of_points[index], self.list_of_labels[index] = self._read(index)
-                with open(self.save_path, 'wb') as f:
-                    pickle.dump([self.list_of_points, self.list_of_labels], f)
-            else:
-                print('Load processed data from %s...' % self.save_path)
-                with open(self.save_path, 'rb') as f:
-                    self.list_of_points, self.list_of_labels = pickle.load(f)
+        suffix = '_fps' if self.uniform else ''
+        self.save_path = os.path.join(root, 'modelnet%d_%s_%dpts%s.dat' % (self.num_category, split, self.npoints, suffix))
+        if process_data:
+            self.list_of_points, self.list_of_labels = self._cached()
+
+    @staticmethod
+    def _lines(path):
+        with open(path) as f:
+            return [line.rstrip() for line in f]
+
+    def _cached(self):
+        """The reference's pickle cache: ``[list_of_points, list_of_labels]`` in ``self.save_path``."""
+        if os.path.exists(self.save_path):
+            print('Load processed data from %s...' % self.save_path)
+            with open(self.save_path, 'rb') as f:
+                return pickle.load(f)
+        print('Processing data %s (only running in the first time)...' % self.save_path)
+        pairs = [self._read(i) for i in range(len(self.datapath))]
+        points, labels = [p for p, _ in pairs], [l for _, l in pairs]
+        with open(self.save_path, 'wb') as f:
+            pickle.dump([points, labels], f)
+        return points, labels
 
     def _read(self, index):
-        name, path = self.datapath[index]
-        label = np.array([self.classes[name]]).astype(np.int32)
-        point_set = np.loadtxt(path, delimiter=',').astype(np.float32)
-        if self.uniform:
-            point_set = farthest_point_sample(point_set, self.npoints)
-        else:
-            point_set = point_set[0:self.npoints, :]
-        return point_set, label
+        cls, path = self.datapath[index]
+        cloud = np.loadtxt(path, delimiter=',').astype(np.float32)
+        cloud = farthest_point_sample(cloud, self.npoints) if self.uniform else cloud[:self.npoints, :]
+        return cloud, np.array([self.classes[cls]]).astype(np.int32)
 
     def __len__(self):
         return len(self.datapath)
 
     def _get_item(self, index):
         if self.process_data:
-            point_set, label = self.list_of_points[index], self.list_of_labels[index]
+            cloud, label = self.list_of_points[index], self.list_of_labels[index]
         else:
-            point_set, label = self._read(index)
-        point_set[:, 0:3] = pc_normalize(point_set[:, 0:3])
-        if not self.use_normals:
-            point_set = point_set[:, 0:3]
-        return point_set, label[0]
+            cloud, label = self._read(index)
+        cloud[:, 0:3] = pc_normalize(cloud[:, 0:3])  # in place, as the reference: a cached cloud is normalised again
+        return (cloud if self.use_normals else cloud[:, 0:3]), label[0]
 
     def __getitem__(self, index):
         return self._get_item(index)
