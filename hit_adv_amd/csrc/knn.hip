@@ -410,6 +410,35 @@ __global__ __launch_bounds__(256) void knn_feat_k(const float *__restrict__ X, c
     lv[t] = -__builtin_inff();
     li[t] = 0x7fffffff;
   }
+  constexpr int BUF = 4;  // pending-candidate depth
+  float pv[BUF];
+  int pj[BUF];
+  int np = 0;
+#pragma unroll
+  for (int t = 0; t < BUF; ++t) {
+    pv[t] = -__builtin_inff();
+    pj[t] = 0x7fffffff;
+  }
+  auto insert = [&](float s, int j) {  // behind every entry >= s: equal scores keep ascending reference index
+#pragma unroll
+    for (int t = KB - 1; t > 0; --t) {
+      const bool sh = s > lv[t - 1];
+      const bool wr = s > lv[t];
+      const float nv = sh ? lv[t - 1] : s;
+      const int ni = sh ? li[t - 1] : j;
+      lv[t] = wr ? nv : lv[t];
+      li[t] = wr ? ni : li[t];
+    }
+    const bool w0 = s > lv[0];
+    lv[0] = w0 ? s : lv[0];
+    li[0] = w0 ? j : li[0];
+  };
+  auto flush = [&]() {  // oldest first
+#pragma unroll
+    for (int t = BUF - 1; t >= 0; --t)
+      if (np > t) insert(pv[t], pj[t]);
+    np = 0;
+  };
   const int ntiles = (N + 31) / 32;
   float4 st[ST];
   float stx = 0.f;
@@ -452,25 +481,23 @@ __global__ __launch_bounds__(256) void knn_feat_k(const float *__restrict__ X, c
     for (int e = 0; e < 16; ++e) {  // reference row of element e: (e&3) + 8*(e>>2) + 4*h, ascending in e
       const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
       const float s = (2.0f * acc[e] - qxx) - sXX[tile & 1][rr];  // -inf for rows past N
-      if (s > lv[KB - 1]) {
-        const int j = tile * 32 + rr;
+      // accepted candidates are parked in a BUF-deep per-lane shift register; the sorted insert (executed by the whole
+      // wave whenever ANY lane needs it) runs once per BUF acceptances of the fastest-filling lane, not per score
+      const bool accept = s > lv[KB - 1];
 #pragma unroll
-        for (int t = KB - 1; t > 0; --t) {
-          const bool sh = s > lv[t - 1];
-          const bool wr = s > lv[t];
-          const float nv = sh ? lv[t - 1] : s;
-          const int ni = sh ? li[t - 1] : j;
-          lv[t] = wr ? nv : lv[t];
-          li[t] = wr ? ni : li[t];
-        }
-        const bool w0 = s > lv[0];
-        lv[0] = w0 ? s : lv[0];
-        li[0] = w0 ? j : li[0];
+      for (int t = BUF - 1; t > 0; --t) {
+        pv[t] = accept ? pv[t - 1] : pv[t];
+        pj[t] = accept ? pj[t - 1] : pj[t];
       }
+      pv[0] = accept ? s : pv[0];
+      pj[0] = accept ? tile * 32 + rr : pj[0];
+      np += accept ? 1 : 0;
+      if (__ballot(np == BUF)) flush();
     }
     if (more) stash((tile + 1) & 1);
     __syncthreads();
   }
+  flush();
   // merge the two halves' lists of every query (LDS: the reference tiles are dead)
   float *mv = sR;                                  // [4 waves][32 queries][2][KB]
   int *mi = reinterpret_cast<int *>(sR + 4 * 32 * 2 * KB);

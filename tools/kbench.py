@@ -161,6 +161,12 @@ def main():
                                                            p(view.s2_w), p(view.s2_b), None, p(a1s), None, p(a2s), B, N, s),
                a.reps)
     out['rowmlp_fwd0'] = dict(us=round(us, 2))
+    for D in (64, 128):
+        feat = torch.randn(B, N, D, generator=g).cuda()
+        fx = (feat * feat).sum(2)
+        fi = torch.empty(B, N, 5, dtype=torch.int64, device='cuda')
+        us = timed(lambda s=s0: lib.hitadv_knn_features(p(feat), p(fx), B, N, D, 5, p(fi), s), a.reps)
+        out['knn_features_D%d_K5' % D] = dict(us=round(us, 2), TFLOPs=round(2.0 * B * N * N * D / us / 1e6, 1))
     print(json.dumps(out))
 
 
