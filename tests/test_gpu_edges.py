@@ -131,3 +131,30 @@ def test_attack_state_kernels_small_shapes(A):
     out = A.regulariser(P.cuda(), sig.cuda(), adv.cuda(), (adv * 0.9).cuda(), torch.rand(B, C, generator=g).cuda(),
                         torch.tensor([7.0]).cuda(), (1e-4, 1.0, 1.0), (0.1, 1.2), d)
     assert torch.isfinite(out) and abs(out.item() - 7.0 * d.item()) < 1e-5 * abs(out.item()) + 1e-9
+
+
+@pytest.mark.parametrize("B,n", [(1, 1000), (3, 2048), (5, 130)])
+def test_hit_adv_pointnet_engine_odd_shapes_graph_equals_eager(B, n):
+    """HiT-ADV on the HIP PointNet engine at shapes off the bench's (a single cloud, N not a multiple of the 64-point
+    tiles, the 2048-point clouds of cfg4): the captured-graph run and the eager run agree bit for bit, and the victim's
+    logits at the returned clouds match the plain module's."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(1)
+    m = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    data, _ = synth_batch(B, n, first=2000)
+    with torch.no_grad():
+        label = m(data[:, :, :3].transpose(1, 2).contiguous().cuda())[0].argmax(1)
+    res = {}
+    for graph in (False, True):
+        att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), binary_step=2, num_iter=6, cd_weight=1e-4, ker_weight=1.,
+                      hide_weight=1., curv_loss_knn=16, central_num=min(64, n // 4), total_central_num=min(96, n // 2),
+                      max_sigm=1.2, min_sigm=0.1, budget=0.55, verbose=False, use_graph=graph)
+        torch.manual_seed(4)
+        res[graph] = att.attack(data, label)
+        assert att.last_graph_used == graph
+    assert np.array_equal(res[False][0], res[True][0]) and int(res[False][1]) == int(res[True][1])
+    adv = torch.from_numpy(res[True][0]).float().transpose(1, 2).contiguous().cuda()
+    with torch.no_grad():
+        np.testing.assert_allclose(m.attack_view()(adv)[0].cpu().numpy(), m(adv)[0].cpu().numpy(), rtol=1e-3, atol=1e-4)
