@@ -111,6 +111,43 @@ def test_hit_adv_graph_and_eager_agree_and_prints_progress():
     close(outs[0][0], ref_best, rtol=1e-3, atol=1e-4)  # 45 chaotic Adam steps apart in fp32
 
 
+def test_hit_adv_pointnet_engine_follows_the_cpu_oracle():
+    """The bench's own victim: HiT-ADV with the PointNet HIP engine (f32 MFMA victim kernels, autograd-free iteration,
+    hipGraph) against the CPU oracle driving the plain nn.Module -- same centres bit for bit, the iterates of a whole
+    binary step within fp32 re-association noise, same returned clouds and success count."""
+    import copy
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(3)
+    cpu_model = PointNetFeatureModel(40, normal_channel=False).eval()
+    with torch.no_grad():
+        for mod in cpu_model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.05)
+                mod.running_var.uniform_(0.8, 1.2)
+    gpu_model = copy.deepcopy(cpu_model)
+    data, _ = synth_batch(3, 256, first=3000)
+    with torch.no_grad():
+        label = cpu_model(data[:, :, :3].transpose(1, 2).contiguous())[0].argmax(1)
+    hp = dict(binary_step=2, num_iter=8, cd_weight=1e-4, ker_weight=1., hide_weight=1., curv_loss_knn=16, central_num=32,
+              total_central_num=64, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+    att = HiT_ADV(gpu_model, UntargetedLogitsAdvLoss(30.), verbose=False, **hp)
+    torch.manual_seed(12)
+    best, succ = att.attack(data, label)
+    assert att.last_graph_used and att._view is not None and att._view.hip_engine
+    ws = next(iter(att._ws.values()))
+    trace = []
+    oracle = O.HiTADVOracle(cpu_model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), **hp)
+    torch.manual_seed(12)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obest, osucc = oracle.attack(data, label, trace=trace)
+    assert len(trace) == 16
+    close(ws.adv, trace[-1]['adv'], rtol=2e-3, atol=2e-4)      # last iterate of the second binary step
+    close(best, obest, rtol=2e-3, atol=2e-4)
+    assert int(succ) == int(osucc)
+
+
 def test_cwknn_follows_reference_trajectory():
     from hit_adv_amd.CW.kNN import CWKNN
     from hit_adv_amd.util.adv_utils import LogitsAdvLoss
