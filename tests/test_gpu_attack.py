@@ -252,6 +252,38 @@ def test_uniform_loss_and_eval_asr_on_gpu():
     close(got['curv_std'], want['curv_std'], rtol=1e-5)
 
 
+def test_eval_asr_with_batches_in_flight_equals_sequential():
+    """eval_ASR(in_flight=3) groups the loader's batches into HiT_ADV.attack_many calls: same ASR and metric means as the
+    one-attack-at-a-time loop (the concurrent attacks return what back-to-back attack() calls return)."""
+    import argparse
+    import logging
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    from hit_adv_amd.util.other_utils import eval_ASR
+    torch.manual_seed(0)
+    m = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    batches = []
+    for i in range(4):
+        d, _ = synth_batch(4, 1024, first=4000 + 4 * i)
+        with torch.no_grad():
+            lab = m(d[:, :, :3].transpose(1, 2).contiguous().cuda())[0].argmax(1).cpu()
+        batches.append((d, lab))
+    args = argparse.Namespace(k=5)
+    log = logging.getLogger('hitadv-test-inflight')
+    out = {}
+    for group in (1, 3):
+        att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), binary_step=2, num_iter=5, cd_weight=1e-4, ker_weight=1.,
+                      hide_weight=1., curv_loss_knn=16, central_num=32, total_central_num=64, max_sigm=1.2, min_sigm=0.1,
+                      budget=0.55, verbose=False)
+        torch.manual_seed(21)
+        asr = eval_ASR(m, batches, args, att, logger=log, in_flight=group)
+        out[group] = (asr, dict(eval_ASR.last))
+    assert out[1][0] == out[3][0]
+    for key in ('knn', 'uniform', 'curv_std', 'at_num', 'at_denom', 'batches'):
+        assert out[1][1][key] == out[3][1][key], key
+
+
 def test_pointnet_attack_view_on_gpu_and_in_the_attack():
     """The folded PointNet view agrees with the module on the GPU, and HiT_ADV with/without it tells the
     same story on a short run (same centres, same first-iterate logits to fp32 rounding)."""
