@@ -125,7 +125,11 @@ class HiT_ADV:
         if not (self.fast_victim and hasattr(self.model, 'attack_view')):
             return self.model
         if self._view is None:
-            self._view = self.model.attack_view()
+            try:
+                self._view = self.model.attack_view()
+            except NotImplementedError:  # a configuration the view does not cover: the module itself is the victim
+                self.fast_victim = False
+                return self.model
         return self._view
 
     def _logits(self, x):
