@@ -43,6 +43,29 @@ def victim():
     return PointNetFeatureModel(40, normal_channel=False).eval()
 
 
+def graph_timed(launch, per_graph=20, reps=50):
+    """Average duration (us) of one launch: `per_graph` back-to-back launches captured into a hipGraph (the host's ctypes
+    call rate must not open gaps between launches), replayed `reps` times between two events recorded on the stream the
+    replays run on, after an untimed pass that lets the clocks settle under this kernel's load."""
+    import ctypes
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(per_graph):
+            launch(stream)
+    for _ in range(reps):
+        g.replay()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        g.replay()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) * 1e3 / (reps * per_graph)
+
+
 def pairwise_roofline(dev):
     """K1: materialising 1024x1024 pairwise kernel at B=32, timed with events on the launch stream."""
     from hit_adv_amd import ops
@@ -55,25 +78,7 @@ def pairwise_roofline(dev):
     from hit_adv_amd import _lib
     lib = _lib.load()
     ptrs = (ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(P.data_ptr()))
-    # 20 back-to-back launches captured into a hipGraph (the host's ctypes call rate must not open gaps
-    # between launches), replayed between two events recorded on the stream the replays run on
-    per_graph, reps = 20, 50
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for _ in range(per_graph):
-            lib.hitadv_pairwise_sqdist(*ptrs, B_PER_GPU, NPOINT, NPOINT, 3, ops.FORM_GRAM, stream)
-    for _ in range(reps):  # untimed: lets the clocks settle under this kernel's load
-        g.replay()
-    torch.cuda.synchronize()
-    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0.record()
-    for _ in range(reps):
-        g.replay()
-    t1.record()
-    torch.cuda.synchronize()
-    us = t0.elapsed_time(t1) * 1e3 / (reps * per_graph)
+    us = graph_timed(lambda stream: lib.hitadv_pairwise_sqdist(*ptrs, B_PER_GPU, NPOINT, NPOINT, 3, ops.FORM_GRAM, stream))
     alg_bytes = (4 * NPOINT * NPOINT + 12 * (NPOINT + NPOINT)) * B_PER_GPU  # 4,218,880 B / cloud pair
     achieved = alg_bytes / (us * 1e-6) / 1e9
     # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of tools/kbench.py at
@@ -132,8 +137,8 @@ def hot_loop_kernels(dev):
     pv, pi = torch.empty(n, device=dev), torch.empty(n, device=dev, dtype=torch.int32)
     mo, mi = torch.empty(B, 1024, device=dev), torch.empty(B, 1024, device=dev, dtype=torch.int64)
     tk = torch.zeros(4096, device=dev, dtype=torch.int32)  # split tickets (self-resetting)
-    us = timed(lambda: lib.hitadv_linear_max_fwd(p(h2), p(Wt), p(bias), B, N, 128, 1024, 1, p(pv), p(pi), p(mo), p(mi), p(tk), s),
-               reps=400)
+    us = round(graph_timed(lambda st: lib.hitadv_linear_max_fwd(p(h2), p(Wt), p(bias), B, N, 128, 1024, 1, p(pv), p(pi), p(mo),
+                                                                p(mi), p(tk), st)), 2)
     flops = 2.0 * B * N * 128 * 1024
     out["linear_max_fwd"] = {"bound": "mfma", "us_per_launch": us, "achieved": round(flops / us / 1e6, 1), "peak": 157.3,
                              "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / 157.3, 4), "dtype": "f32",
