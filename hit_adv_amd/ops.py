@@ -35,13 +35,13 @@ _fc_scratch = {}
 
 
 def _fc_scratch_for(x, n):
-    """Zero-initialised split-K scratch, one per (device, stream): calls on one stream are ordered, calls on
-    different streams (attack_many) must not share tickets.  Grown on demand, never shrunk."""
+    """Zero-initialised ticket / split-K scratch, one per (device, stream): calls on one stream are ordered, calls on
+    different streams (attack_many) must not share tickets.  Grown on demand, never shrunk.  Created on first use of a
+    stream -- also inside a graph capture (the zero-fill then becomes a node of that graph, which is harmless: tickets
+    are zero between launches anyway; the tensor keeps its block of the graph's pool alive)."""
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     t = _fc_scratch.get(key)
     if t is None or t.numel() < n:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("fc_layer scratch must exist before graph capture: run one eager pass on this stream first")
         t = torch.zeros(max(n, 1 << 20), device=x.device)
         _fc_scratch[key] = t
     return t
