@@ -685,8 +685,8 @@ def test_pointnet_engine_captures_on_a_fresh_stream():
         logits = view(x)[0]
         g, = torch.autograd.grad((logits * w).sum(), x)
         return logits, g
-    l_ref, g_ref = step()
-    torch.cuda.synchronize()
+    l_ref, g_ref = (t.detach().clone() for t in step())  # keep no autograd node of the eager pass alive: its
+    torch.cuda.synchronize()                             # AccumulateGrad is bound to the default stream
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         l_out, g_out = step()
