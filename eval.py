@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Evaluation driver: attack the test split with HiT-ADV and report the attack success rate and the three imperceptibility
+metrics -- the job of the reference's eval.py (flags :22-70, wiring :73-135), on MI355X, on one or many GPUs.
+
+    python eval.py --model pointnet --checkpoint Checkpoint/PN_NT.checkpoint --data_path <modelnet40_normal_resampled>
+    python eval.py --synthetic 6 --batch_size 32 --num_iter 500            # no dataset / weights on the box
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 eval.py ...
+
+The reference's flag names keep their meaning.  What differs: the attack's own three knobs sit in this parser
+(``--attack_lr --binary_step --num_iter``; the reference reads them from a second parser, FGM/CWPert_args.py:39-44), the
+paths it hard-codes are flags (``--checkpoint --data_path``), and under torch.distributed every rank attacks the batches
+``rank, rank+world, ...`` and the counters meet in one all-reduce (util/other_utils.py here).  Rank 0 prints the
+reference's four "Overall ..." log lines and one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser('HiT-ADV evaluation (MI355X)')
+    # the reference's flags (eval.py:24-66); those it parses and never reads are accepted and ignored
+    p.add_argument('--use_cpu', action='store_true', help='ignored: there is no CPU path')
+    p.add_argument('--process_data', action='store_true', help='cache the sampled split as a .dat file')
+    p.add_argument('--batch_size', type=int, default=32,
+                   help='clouds per attack() call (the reference defaults to 256; its published runs use 32)')
+    p.add_argument('--num_class', type=int, default=40)
+    p.add_argument('--use_normals', action='store_true', default=True)
+    p.add_argument('--adv_func', type=str, default='logits', choices=['logits', 'cross_entropy'],
+                   help="'logits' = UntargetedLogitsAdvLoss(kappa), what eval.py:84,126 hands to the attack")
+    p.add_argument('--budget', type=float, default=0.55)
+    p.add_argument('--attack_type', type=str, default='HiT-ADV')
+    p.add_argument('--num_iter', type=int, default=100, help='inner iterations per binary-search step')
+    p.add_argument('--mu', type=float, default=1.)
+    p.add_argument('--gpu', type=str, default=None, help='device index when not launched by torchrun')
+    p.add_argument('--num_point', type=int, default=1024)
+    p.add_argument('--use_uniform_sample', action='store_true')
+    p.add_argument('--num_category', default=40, type=int, choices=[10, 16, 40])
+    p.add_argument('--model', type=str, default='pointnet', choices=['pointnet', 'dgcnn', 'pointnet++', 'pct'])
+    p.add_argument('--emb_dims', type=int, default=1024)
+    p.add_argument('--dropout', type=float, default=0.2)
+    p.add_argument('--k', type=int, default=5, help='DGCNN graph degree and the neighbour count of the Uniform metric')
+    p.add_argument('--curv_loss_knn', type=int, default=16)
+    p.add_argument('--cd_weight', type=float, default=0.0001)
+    p.add_argument('--ker_weight', type=float, default=1.)
+    p.add_argument('--hide_weight', type=float, default=1.)
+    p.add_argument('--max_sigm', type=float, default=1.2)
+    p.add_argument('--min_sigm', type=float, default=0.1)
+    p.add_argument('--central_num', type=int, default=192)
+    p.add_argument('--total_central_num', type=int, default=256)
+    p.add_argument('--dataset', type=str, default='ModelNet', choices=['ModelNet', 'ShapeNetPart'])
+    p.add_argument('--defense_method', type=str, default=None)
+    p.add_argument('--eval_defense_method', type=str, default=None)
+    p.add_argument('--kappa', type=float, default=30.)
+    # the attack's knobs (FGM/CWPert_args.py:39-44 in the reference)
+    p.add_argument('--attack_lr', type=float, default=1e-2)
+    p.add_argument('--binary_step', type=int, default=10)
+    # what the reference hard-codes (eval.py:79,87,92)
+    p.add_argument('--checkpoint', type=str, default='Checkpoint/PN_NT.checkpoint')
+    p.add_argument('--data_path', type=str, default=None)
+    p.add_argument('--num_workers', type=int, default=10)
+    p.add_argument('--log_dir', type=str, default='./log')
+    # additions
+    p.add_argument('--synthetic', type=int, default=0, metavar='BATCHES',
+                   help='attack this many batches of synthetic clouds instead of a dataset; a missing checkpoint then '
+                        'means a seeded random-init victim')
+    p.add_argument('--synthetic_kind', type=str, default='gaussian', choices=['gaussian', 'sphere'])
+    p.add_argument('--in_flight', type=int, default=3, help='attack() calls kept in flight per GPU (1 = one at a time)')
+    p.add_argument('--seed', type=int, default=0)
+    return p.parse_args(argv)
+
+
+def build_model(args):
+    if args.model == 'pointnet':
+        from hit_adv_amd.model.pointnet import PointNetFeatureModel
+        return PointNetFeatureModel(args.num_class, normal_channel=False)
+    if args.model == 'dgcnn':
+        from hit_adv_amd.model.dgcnn import DGCNN_cls
+        return DGCNN_cls(args, output_channels=args.num_class)
+    if args.model == 'pointnet++':
+        from hit_adv_amd.model.pointnet2 import get_model
+        return get_model(args.num_class, normal_channel=False)
+    from hit_adv_amd.model.pct import Pct
+    return Pct(args, output_channels=args.num_class)
+
+
+def build_loader(args):
+    if args.synthetic > 0:
+        from hit_adv_amd.Dataset.synthetic import SyntheticClouds
+        data = SyntheticClouds(args.synthetic * args.batch_size, args.num_point, args.synthetic_kind, num_class=args.num_class)
+        return torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=False, num_workers=0)
+    if args.data_path is None:
+        raise SystemExit('eval.py: give --data_path (dataset root) or --synthetic BATCHES')
+    if args.dataset == 'ModelNet':
+        from hit_adv_amd.Dataset.ModelNet import ModelNetDataLoader
+        data = ModelNetDataLoader(root=args.data_path, args=args, split='test', process_data=args.process_data)
+    else:
+        from hit_adv_amd.Dataset.ShapeNetDataLoader import PartNormalDataset
+        data = PartNormalDataset(root=args.data_path, npoints=args.num_point, split='test', normal_channel=True)
+    return torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
+
+
+class _SelfLabelled:
+    """Synthetic clouds carry random labels; a random-init victim gets its own prediction as the label instead (the
+    bench does the same), so every cloud counts as clean-correct and the success rate measures the attack."""
+
+    def __init__(self, loader, model):
+        self.loader, self.model = loader, model
+
+    def __iter__(self):
+        for points, _ in self.loader:
+            with torch.no_grad():
+                out = self.model(points[:, :, :3].transpose(1, 2).contiguous().cuda())
+            yield points, (out[0] if isinstance(out, tuple) else out).argmax(1).cpu()
+
+    def __len__(self):
+        return len(self.loader)
+
+
+class _ShapeNetAsPairs:
+    """PartNormalDataset yields (points, class, part labels); eval_ASR wants (points, class)."""
+
+    def __init__(self, loader):
+        self.loader = loader
+
+    def __iter__(self):
+        for item in self.loader:
+            yield item[0], item[1].reshape(-1)
+
+    def __len__(self):
+        return len(self.loader)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('eval.py: no GPU visible; the attack runs in HIP kernels only')
+    local = int(os.environ.get('LOCAL_RANK', args.gpu if args.gpu is not None else '0'))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.util.adv_utils import CrossEntropyAdvLoss, UntargetedLogitsAdvLoss
+    from hit_adv_amd.util.other_utils import create_logger, eval_ASR, load_checkpoint
+
+    args.step_size = args.budget * 2 / args.num_iter  # eval.py:80
+    logger = create_logger(args.log_dir, 'eval_last' if world == 1 else 'eval_last_r%d' % rank, 'info')
+    torch.manual_seed(args.seed)
+    model = build_model(args)
+    if os.path.exists(args.checkpoint):
+        load_checkpoint(model, args.checkpoint)
+        weights = args.checkpoint
+    elif args.synthetic > 0:
+        weights = 'random init (seed %d)' % args.seed
+    else:
+        raise SystemExit('eval.py: checkpoint %r not found' % args.checkpoint)
+    model = model.cuda().eval()
+    torch.manual_seed(args.seed + 1 + rank)  # the attack draws its FPS starts and initial offsets from the global RNG
+
+    loader = build_loader(args)
+    if args.dataset == 'ShapeNetPart' and args.synthetic == 0:
+        loader = _ShapeNetAsPairs(loader)
+    if args.synthetic > 0 and weights.startswith('random init'):
+        loader = _SelfLabelled(loader, model)
+    adv_func = UntargetedLogitsAdvLoss(kappa=args.kappa) if args.adv_func == 'logits' else CrossEntropyAdvLoss()
+    attacker = HiT_ADV(model, adv_func=adv_func, attack_lr=args.attack_lr, central_num=args.central_num,
+                       total_central_num=args.total_central_num, init_weight=10., max_weight=80.,
+                       binary_step=args.binary_step, num_iter=args.num_iter, clip_func=None, cd_weight=args.cd_weight,
+                       ker_weight=args.ker_weight, hide_weight=args.hide_weight, curv_loss_knn=args.curv_loss_knn,
+                       max_sigm=args.max_sigm, min_sigm=args.min_sigm, budget=args.budget, verbose=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eval_ASR(model, loader, args, attacker, logger=logger, in_flight=args.in_flight)
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    if rank == 0:
+        r = eval_ASR.last
+        print(json.dumps(dict(ASR=r['ASR'], knn=r['knn'], uniform=r['uniform'], curv_std=r['curv_std'],
+                              clean_correct=r['at_denom'], batches=r['batches'], batch_size=args.batch_size,
+                              world=world, model=args.model, weights=weights, seconds=round(seconds, 3),
+                              clouds_per_s=round(r['batches'] * args.batch_size / seconds, 3))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,35 @@
+"""Synthetic stand-in for the ModelNet40 test split when no dataset is on the box: clouds with the
+statistics ``pc_normalize`` leaves behind (centred, max-norm 1; Dataset/ModelNet.py:12-17 of the reference), unit normals
+and a label in [0, 40).  Every cloud is a pure function of its id, so any rank of any run draws the same cloud."""
+import torch
+from torch.utils.data import Dataset
+
+
+class SyntheticClouds(Dataset):
+    """``kind='gaussian'``: iid normal points (the bench workload).  ``kind='sphere'``: points on the unit sphere with 1 %
+    radial noise and the outward direction as normal -- a surface-like cloud, whose kNN statistics are closer to a scan."""
+
+    def __init__(self, count, npoints=1024, kind='gaussian', first=0, num_class=40):
+        if kind not in ('gaussian', 'sphere'):
+            raise ValueError("kind must be 'gaussian' or 'sphere', got %r" % (kind,))
+        self.count, self.npoints, self.kind, self.first, self.num_class = count, npoints, kind, first, num_class
+
+    def __len__(self):
+        return self.count
+
+    def __getitem__(self, index):
+        if not 0 <= index < self.count:
+            raise IndexError(index)
+        g = torch.Generator('cpu').manual_seed(1234 + self.first + index)
+        xyz = torch.randn(self.npoints, 3, generator=g)
+        if self.kind == 'gaussian':
+            xyz = xyz - xyz.mean(0, keepdim=True)
+            xyz = xyz / xyz.norm(dim=1).max()
+            normal = torch.nn.functional.normalize(torch.randn(self.npoints, 3, generator=g), dim=1)
+        else:
+            normal = torch.nn.functional.normalize(xyz, dim=1)
+            xyz = normal * (1. + 0.01 * torch.randn(self.npoints, 1, generator=g))
+            xyz = xyz - xyz.mean(0, keepdim=True)
+            xyz = xyz / xyz.norm(dim=1).max()
+        label = torch.randint(0, self.num_class, (1,), generator=g)
+        return torch.cat([xyz, normal], 1), label[0]
