@@ -73,6 +73,9 @@ def parse_args(argv=None):
                         'means a seeded random-init victim')
     p.add_argument('--synthetic_kind', type=str, default='gaussian', choices=['gaussian', 'sphere'])
     p.add_argument('--in_flight', type=int, default=3, help='attack() calls kept in flight per GPU (1 = one at a time)')
+    p.add_argument('--metric_k', type=int, default=None,
+                   help="neighbour count of the Uniform metric when it should differ from --k (the reference uses --k for "
+                        "both, other_utils.py:74; the metric's smallest ball holds 1.6 %% of the points, so k+1 <= 16 at 1024)")
     p.add_argument('--seed', type=int, default=0)
     return p.parse_args(argv)
 
@@ -178,6 +181,11 @@ def main(argv=None):
                        binary_step=args.binary_step, num_iter=args.num_iter, clip_func=None, cd_weight=args.cd_weight,
                        ker_weight=args.ker_weight, hide_weight=args.hide_weight, curv_loss_knn=args.curv_loss_knn,
                        max_sigm=args.max_sigm, min_sigm=args.min_sigm, budget=args.budget, verbose=False)
+    if args.metric_k is not None:
+        args.k = args.metric_k  # the victim is built; from here on --k is only the metric's
+    if args.k + 1 > int(args.num_point * 0.016):
+        raise SystemExit('eval.py: the Uniform metric takes k+1 = %d neighbours inside balls of %d points; give --metric_k'
+                         % (args.k + 1, int(args.num_point * 0.016)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eval_ASR(model, loader, args, attacker, logger=logger, in_flight=args.in_flight)
@@ -188,6 +196,8 @@ def main(argv=None):
         print(json.dumps(dict(ASR=r['ASR'], knn=r['knn'], uniform=r['uniform'], curv_std=r['curv_std'],
                               clean_correct=r['at_denom'], batches=r['batches'], batch_size=args.batch_size,
                               world=world, model=args.model, weights=weights, seconds=round(seconds, 3),
+                              attack_seconds=round(eval_ASR.last_seconds['attack'], 3),
+                              metric_seconds=round(eval_ASR.last_seconds['metrics'], 3),
                               clouds_per_s=round(r['batches'] * args.batch_size / seconds, 3))))
     if world > 1:
         dist.destroy_process_group()

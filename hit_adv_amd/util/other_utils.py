@@ -6,6 +6,7 @@ running sums are combined by ONE all-reduce (RCCL over xGMI on GPUs, gloo in the
 """
 import logging
 import os
+import time
 from datetime import datetime
 
 import torch
@@ -119,13 +120,19 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
             at_denom += ok_ori.sum().float().item()
             at_num += ok_ori.sum().float().item() - (ok_ori & ok_adv).sum().float().item()
 
+    seconds = dict(attack=0., metrics=0.)  # both phases end in a D2H copy, so host clocks see the device time
+
     def flush(pending):
+        t0 = time.perf_counter()
         if len(pending) > 1:
             results = val_attack.attack_many(pending)
         else:
             results = [val_attack.attack(*pending[0])]
+        t1 = time.perf_counter()
         for (ori_data, label), res in zip(pending, results):
             score(ori_data, label, res[0])
+        seconds['attack'] += t1 - t0
+        seconds['metrics'] += time.perf_counter() - t1
 
     group = max(1, int(in_flight)) if hasattr(val_attack, 'attack_many') else 1
     pending = []
@@ -147,6 +154,7 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
     eval_ASR.last = dict(ASR=ASR, knn=knn_sum / total_batches, uniform=uni_sum / total_batches,
                          curv_std=curv_sum / total_batches, at_num=at_num, at_denom=at_denom,
                          batches=total_batches, world=world)
+    eval_ASR.last_seconds = seconds  # this rank's own clocks, not part of the (rank-independent) result
     if rank == 0:
         logger.info('Overall attack success rate: %s', ASR)
         logger.info('Overall KNN dist: %s', knn_sum / total_batches)
