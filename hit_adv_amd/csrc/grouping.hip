@@ -233,8 +233,8 @@ extern "C" int hitadv_three_interpolate_grad(int b, int c, int n, int m, const f
 namespace hitadv {
 
 __global__ __launch_bounds__(256) void edge_max_fwd_k(const float *__restrict__ U, const float *__restrict__ V,
-                                                      const int64_t *__restrict__ idx, int N, int C, int k, float slope,
-                                                      float *__restrict__ out, int32_t *__restrict__ arg,
+                                                      int ld, const int64_t *__restrict__ idx, int N, int C, int k,
+                                                      float slope, float *__restrict__ out, int32_t *__restrict__ arg,
                                                       long long total4) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, i, c4)
   if (e >= total4) return;
@@ -247,13 +247,13 @@ __global__ __launch_bounds__(256) void edge_max_fwd_k(const float *__restrict__ 
   int4 bj = make_int4(0, 0, 0, 0);
   for (int t = 0; t < k; ++t) {
     const int j = (int)nb[t];
-    const float4 u = *reinterpret_cast<const float4 *>(U + ((size_t)(b * N + j)) * C + 4 * c4);
+    const float4 u = *reinterpret_cast<const float4 *>(U + ((size_t)(b * N + j)) * ld + 4 * c4);
     if (u.x > best.x) { best.x = u.x; bj.x = j; }
     if (u.y > best.y) { best.y = u.y; bj.y = j; }
     if (u.z > best.z) { best.z = u.z; bj.z = j; }
     if (u.w > best.w) { best.w = u.w; bj.w = j; }
   }
-  const float4 v = *reinterpret_cast<const float4 *>(V + (size_t)bi * C + 4 * c4);
+  const float4 v = *reinterpret_cast<const float4 *>(V + (size_t)bi * ld + 4 * c4);
   float4 o = make_float4(best.x + v.x, best.y + v.y, best.z + v.z, best.w + v.w);
   o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
   o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
@@ -261,43 +261,264 @@ __global__ __launch_bounds__(256) void edge_max_fwd_k(const float *__restrict__ 
   *reinterpret_cast<int4 *>(arg + (size_t)bi * C + 4 * c4) = bj;
 }
 
-// dV[i,c] = dout[i,c] * lrelu'(out[i,c]);  dU[arg[i,c], c] += dV[i,c]  (dU zero-filled by the caller's launch order:
-// this kernel is preceded by a memset on the same stream).  The scatter uses float atomics: a point can be the winning
-// neighbour of many others, and which of them are there is only known through the forward's arg table.
+// Backward.  dV[i,c] = dout[i,c] * lrelu'(out[i,c]);  dU[j,c] = sum over the points i that list j as a neighbour AND whose
+// winner for channel c was j (arg[i,c] == j) of dV[i,c].  A scatter with float atomics would do it in one pass, but the
+// order of the additions -- and with it the low bits of the result -- would change from run to run.  Instead the
+// neighbour table is turned around first (who lists j?), and every (j, c) then GATHERS its terms in ascending i:
+// same bits every run, no zero-fill, no atomics on floats.
+//
+// reverse_graph_k: one block per cloud.  Pass over the N*k edges setting bit i of row j in an LDS bit matrix
+// (atomicOr on integers: order-free), J rows at a time (all N rows at once up to N = 1024); a row's popcount is the
+// in-degree, its set bits in ascending order are the in-list.  Duplicate entries of a neighbour list collapse into one
+// bit, which is what the gather wants (it tests arg[i,c] == j once per listed i).  rowptr [B,N+1], col [B,N*k] int32.
+#define RG_THREADS 1024
+#define RG_BITMAP_WORDS 30720  // 120 KB of the CU's 160 KB
+
+__device__ __forceinline__ void rg_fill_rows(const int64_t *__restrict__ nb, int E, int k, int N, int j0, int rows, int RS,
+                                             uint32_t *bm) {
+  for (int w = threadIdx.x; w < rows * RS; w += RG_THREADS) bm[w] = 0u;
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += RG_THREADS) {
+    const long long j = nb[e] - j0;
+    if (j >= 0 && j < rows && nb[e] < N) {
+      const int i = e / k;
+      atomicOr(&bm[(int)j * RS + (i >> 5)], 1u << (i & 31));
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(RG_THREADS) void reverse_graph_k(const int64_t *__restrict__ idx, int N, int k, int W, int J,
+                                                              int32_t *__restrict__ rowptr, int32_t *__restrict__ col) {
+  extern __shared__ uint32_t rg_sm[];
+  uint32_t *bm = rg_sm;                                  // J rows of W (+1 pad: a thread per row walks its words)
+  int32_t *part = (int32_t *)(rg_sm + RG_BITMAP_WORDS);  // RG_THREADS partial sums, ping-pong
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int E = N * k, RS = W + 1;
+  const int64_t *nb = idx + (size_t)b * E;
+  int32_t *rp = rowptr + (size_t)b * (N + 1);
+  int32_t *cl = col + (size_t)b * E;
+  const int npass = (N + J - 1) / J;
+  for (int p = 0; p < npass; ++p) {  // in-degrees
+    const int j0 = p * J, rows = min(J, N - j0);
+    rg_fill_rows(nb, E, k, N, j0, rows, RS, bm);
+    for (int r = tid; r < rows; r += RG_THREADS) {
+      int c = 0;
+      for (int w = 0; w < W; ++w) c += __popc(bm[r * RS + w]);
+      rp[j0 + r] = c;
+    }
+    if (npass > 1) __syncthreads();
+  }
+  __syncthreads();
+  // exclusive scan of rp[0..N) in place, rp[N] = total: a chunk per thread, then the chunk sums across the block
+  const int chunk = (N + RG_THREADS - 1) / RG_THREADS;
+  const int lo = min(tid * chunk, N), hi = min(lo + chunk, N);
+  int sum = 0;
+  for (int j = lo; j < hi; ++j) sum += rp[j];
+  int32_t *src = part, *dst = part + RG_THREADS;
+  src[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < RG_THREADS; d <<= 1) {
+    dst[tid] = src[tid] + (tid >= d ? src[tid - d] : 0);
+    __syncthreads();
+    int32_t *t = src; src = dst; dst = t;
+  }
+  int run = src[tid] - sum;  // exclusive prefix of this thread's chunk
+  if (tid == RG_THREADS - 1) rp[N] = src[tid];
+  for (int j = lo; j < hi; ++j) { const int d = rp[j]; rp[j] = run; run += d; }
+  __syncthreads();  // rp[] is read back below by other threads: global memory, same block
+  for (int p = 0; p < npass; ++p) {  // in-lists
+    const int j0 = p * J, rows = min(J, N - j0);
+    if (npass > 1) rg_fill_rows(nb, E, k, N, j0, rows, RS, bm);  // a single pass still holds the bit matrix
+    for (int r = tid; r < rows; r += RG_THREADS) {
+      int pos = rp[j0 + r];
+      for (int w = 0; w < W; ++w) {
+        uint32_t bits = bm[r * RS + w];
+        while (bits) {
+          cl[pos++] = (w << 5) + __builtin_ctz(bits);
+          bits &= bits - 1;
+        }
+      }
+    }
+    if (npass > 1) __syncthreads();
+  }
+}
+
+// One lane per (b, j, 4 channels), like the forward.  Blocks are renumbered so that the blocks of one cloud run on one
+// XCD: every (i, c) row of arg / dout / out is visited once per neighbour that lists... k times in all, and those
+// re-reads should hit that XCD's L2.
 __global__ __launch_bounds__(256) void edge_max_bwd_k(const float *__restrict__ dout, const float *__restrict__ out,
-                                                      const int32_t *__restrict__ arg, int N, int C, float slope,
-                                                      float *__restrict__ dU, float *__restrict__ dV, long long total) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, i, c)
-  if (e >= total) return;
-  const int c = (int)(e % C);
-  const long long b = e / ((long long)N * C);
-  const float g = dout[e] * (out[e] > 0.f ? 1.0f : slope);
-  dV[e] = g;
-  atomicAdd(dU + ((size_t)(b * N + arg[e])) * C + c, g);
+                                                      const int32_t *__restrict__ arg, const int32_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ col, int N, int C, int E, float slope,
+                                                      float *__restrict__ dU, float *__restrict__ dV, int ldg,
+                                                      long long total4) {
+  long long blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const long long e = blk * 256 + threadIdx.x;  // (b, j, c4)
+  if (e >= total4) return;
+  const int c4n = C >> 2;
+  const int c4 = (int)(e % c4n);
+  const long long bj = e / c4n;
+  const long long b = bj / N;
+  const int j = (int)(bj - b * N);
+  const float4 *d4 = reinterpret_cast<const float4 *>(dout), *o4 = reinterpret_cast<const float4 *>(out);
+  const int4 *a4 = reinterpret_cast<const int4 *>(arg);
+  {
+    const float4 d = d4[e], o = o4[e];
+    *reinterpret_cast<float4 *>(dV + (size_t)bj * ldg + 4 * c4) = make_float4(d.x * (o.x > 0.f ? 1.0f : slope), d.y * (o.y > 0.f ? 1.0f : slope),
+                                                    d.z * (o.z > 0.f ? 1.0f : slope), d.w * (o.w > 0.f ? 1.0f : slope));
+  }
+  const int32_t *rp = rowptr + b * (N + 1);
+  const int32_t *cl = col + b * E;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = rp[j], end = rp[j + 1]; t < end; ++t) {
+    const long long src = (b * N + cl[t]) * c4n + c4;
+    const int4 a = a4[src];
+    if (a.x == j || a.y == j || a.z == j || a.w == j) {
+      const float4 d = d4[src], o = o4[src];
+      if (a.x == j) acc.x += d.x * (o.x > 0.f ? 1.0f : slope);
+      if (a.y == j) acc.y += d.y * (o.y > 0.f ? 1.0f : slope);
+      if (a.z == j) acc.z += d.z * (o.z > 0.f ? 1.0f : slope);
+      if (a.w == j) acc.w += d.w * (o.w > 0.f ? 1.0f : slope);
+    }
+  }
+  *reinterpret_cast<float4 *>(dU + (size_t)bj * ldg + 4 * c4) = acc;
 }
 
 }  // namespace hitadv
 
-extern "C" int hitadv_edge_max_fwd(const float *U, const float *V, const int64_t *idx, int B, int N, int C, int k,
-                                   float slope, float *out, int32_t *arg, void *stream) {
-  if (!U || !V || !idx || !out || !arg || B <= 0 || N <= 0 || C <= 0 || (C & 3) || k <= 0 ||
-      (((uintptr_t)U | (uintptr_t)V | (uintptr_t)out | (uintptr_t)arg) & 15))
-    return HITADV_E_ARG;
-  const long long total4 = (long long)B * N * (C >> 2);
-  hitadv::edge_max_fwd_k<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(U, V, idx, N, C, k, slope, out,
-                                                                                         arg, total4);
+// ---------------------------------------------------------------------------------------------------
+// DGCNN's global pooling (model/dgcnn_cls.py:117-121): LeakyReLU of the embedding layer's pre-activation Z [B,N,C], then
+// max and mean over the points, concatenated -> [B,2C].  One pass over Z (the activation tensor itself is never
+// written): a block owns 64 channels of one cloud, 16 lanes x float4 across the channels, 16 row groups down the points;
+// the row groups are combined in fixed order, so the mean is the same bits every run.  arg = first point attaining the max.
+namespace hitadv {
+
+__global__ __launch_bounds__(256) void lrelu_pool_fwd_k(const float *__restrict__ Z, int N, int C, float slope,
+                                                        float *__restrict__ out, int32_t *__restrict__ arg) {
+  __shared__ float s_sum[16][64], s_best[16][64];
+  __shared__ int s_arg[16][64];
+  const int lane = threadIdx.x & 15, rg = threadIdx.x >> 4, b = blockIdx.y;
+  const int c = blockIdx.x * 64 + lane * 4;
+  const float4 *z4 = reinterpret_cast<const float4 *>(Z + (size_t)b * N * C + c);
+  const int stride4 = C >> 2;
+  float sum[4] = {0.f, 0.f, 0.f, 0.f}, best[4];
+  int bi[4] = {0, 0, 0, 0};
+  for (int q = 0; q < 4; ++q) best[q] = -__builtin_inff();
+  for (int i = rg; i < N; i += 16) {
+    const float4 z = z4[(size_t)i * stride4];
+    const float v[4] = {z.x, z.y, z.z, z.w};
+    for (int q = 0; q < 4; ++q) {
+      sum[q] += v[q] > 0.f ? v[q] : v[q] * slope;
+      if (v[q] > best[q]) { best[q] = v[q]; bi[q] = i; }
+    }
+  }
+  for (int q = 0; q < 4; ++q) {
+    s_sum[rg][lane * 4 + q] = sum[q];
+    s_best[rg][lane * 4 + q] = best[q];
+    s_arg[rg][lane * 4 + q] = bi[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int t = threadIdx.x;
+    float tot = 0.f, bst = -__builtin_inff();
+    int ba = 0;
+    for (int g = 0; g < 16; ++g) {
+      tot += s_sum[g][t];
+      const float v = s_best[g][t];
+      if (v > bst || (v == bst && s_arg[g][t] < ba)) { bst = v; ba = s_arg[g][t]; }
+    }
+    const int cc = blockIdx.x * 64 + t;
+    out[(size_t)b * 2 * C + cc] = bst > 0.f ? bst : bst * slope;
+    out[(size_t)b * 2 * C + C + cc] = tot / (float)N;
+    arg[(size_t)b * C + cc] = ba;
+  }
+}
+
+// dZ[b,i,c] = lrelu'(Z[b,i,c]) * ( g[b,C+c] / N  +  (i == arg[b,c]) * g[b,c] )
+__global__ __launch_bounds__(256) void lrelu_pool_bwd_k(const float *__restrict__ Z, const float *__restrict__ g,
+                                                        const int32_t *__restrict__ arg, int N, int C, float slope,
+                                                        float *__restrict__ dZ, long long total4) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, i, c4)
+  if (e >= total4) return;
+  const int c4n = C >> 2;
+  const int c4 = (int)(e % c4n);
+  const long long bi = e / c4n;
+  const long long b = bi / N;
+  const int i = (int)(bi - b * N);
+  const float4 z = reinterpret_cast<const float4 *>(Z)[e];
+  const float4 gmax = *reinterpret_cast<const float4 *>(g + b * 2 * C + 4 * c4);
+  const float4 gmean = *reinterpret_cast<const float4 *>(g + b * 2 * C + C + 4 * c4);
+  const int4 a = *reinterpret_cast<const int4 *>(arg + b * C + 4 * c4);
+  const float inv = 1.0f / (float)N;
+  float4 d;
+  d.x = (gmean.x * inv + (a.x == i ? gmax.x : 0.f)) * (z.x > 0.f ? 1.0f : slope);
+  d.y = (gmean.y * inv + (a.y == i ? gmax.y : 0.f)) * (z.y > 0.f ? 1.0f : slope);
+  d.z = (gmean.z * inv + (a.z == i ? gmax.z : 0.f)) * (z.z > 0.f ? 1.0f : slope);
+  d.w = (gmean.w * inv + (a.w == i ? gmax.w : 0.f)) * (z.w > 0.f ? 1.0f : slope);
+  reinterpret_cast<float4 *>(dZ)[e] = d;
+}
+
+}  // namespace hitadv
+
+extern "C" int hitadv_lrelu_pool_fwd(const float *Z, int B, int N, int C, float slope, float *out, int32_t *arg,
+                                     void *stream) {
+  if (!Z || !out || !arg || B <= 0 || N <= 0 || C <= 0 || (C & 63) || ((uintptr_t)Z & 15)) return HITADV_E_ARG;
+  hitadv::lrelu_pool_fwd_k<<<dim3(C / 64, B), 256, 0, (hipStream_t)stream>>>(Z, N, C, slope, out, arg);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int hitadv_edge_max_bwd(const float *dout, const float *out, const int32_t *arg, int B, int N, int C,
-                                   float slope, float *dU, float *dV, void *stream) {
-  if (!dout || !out || !arg || !dU || !dV || B <= 0 || N <= 0 || C <= 0) return HITADV_E_ARG;
-  const long long total = (long long)B * N * C;
-  hipError_t e = hipMemsetAsync(dU, 0, (size_t)total * sizeof(float), (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  hitadv::edge_max_bwd_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(dout, out, arg, N, C, slope, dU,
-                                                                                        dV, total);
+extern "C" int hitadv_lrelu_pool_bwd(const float *Z, const float *g, const int32_t *arg, int B, int N, int C, float slope,
+                                     float *dZ, void *stream) {
+  if (!Z || !g || !arg || !dZ || B <= 0 || N <= 0 || C <= 0 || (C & 63) ||
+      (((uintptr_t)Z | (uintptr_t)dZ | (uintptr_t)g | (uintptr_t)arg) & 15))
+    return HITADV_E_ARG;
+  const long long total4 = (long long)B * N * (C >> 2);
+  hitadv::lrelu_pool_bwd_k<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(Z, g, arg, N, C, slope, dZ,
+                                                                                          total4);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_edge_max_fwd(const float *U, const float *V, int ld, const int64_t *idx, int B, int N, int C, int k,
+                                   float slope, float *out, int32_t *arg, void *stream) {
+  if (!U || !V || !idx || !out || !arg || B <= 0 || N <= 0 || C <= 0 || (C & 3) || k <= 0 || ld < C || (ld & 3) ||
+      (((uintptr_t)U | (uintptr_t)V | (uintptr_t)out | (uintptr_t)arg) & 15))
+    return HITADV_E_ARG;
+  const long long total4 = (long long)B * N * (C >> 2);
+  hitadv::edge_max_fwd_k<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(U, V, ld, idx, N, C, k, slope,
+                                                                                         out, arg, total4);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t hitadv_edge_max_bwd_scratch_ints(int B, int N, int k) {
+  if (B <= 0 || N <= 0 || k <= 0) return HITADV_E_ARG;
+  return (int64_t)B * ((int64_t)N + 1 + (int64_t)N * k);
+}
+
+extern "C" int hitadv_edge_max_bwd(const float *dout, const float *out, const int32_t *arg, const int64_t *idx, int B,
+                                   int N, int C, int k, float slope, float *dU, float *dV, int ldg, int32_t *scratch,
+                                   void *stream) {
+  if (!dout || !out || !arg || !idx || !dU || !dV || !scratch || B <= 0 || N <= 0 || C <= 0 || (C & 3) || k <= 0 ||
+      ldg < C || (ldg & 3) ||
+      (long long)N * k > 0x7fffffffLL ||
+      (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)arg | (uintptr_t)dU | (uintptr_t)dV) & 15))
+    return HITADV_E_ARG;
+  const int W = (N + 31) / 32;
+  if (W + 1 > RG_BITMAP_WORDS) return HITADV_E_ARG;  // N > 983,008: one bit row no longer fits
+  const int J = RG_BITMAP_WORDS / (W + 1);
+  int32_t *rowptr = scratch, *col = scratch + (size_t)B * (N + 1);
+  const size_t shm = (size_t)(RG_BITMAP_WORDS + 2 * RG_THREADS) * 4;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&hitadv::reverse_graph_k),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  (void)once;
+  hitadv::reverse_graph_k<<<B, RG_THREADS, shm, (hipStream_t)stream>>>(idx, N, k, W, J, rowptr, col);
+  HITADV_LAUNCH_CHECK();
+  const long long total4 = (long long)B * N * (C >> 2);
+  hitadv::edge_max_bwd_k<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      dout, out, arg, rowptr, col, N, C, N * k, slope, dU, dV, ldg, total4);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

@@ -120,9 +120,10 @@ class FoldedDGCNN(nn.Module):
                 W = conv.weight.reshape(conv.weight.shape[0], -1)  # [Cout, 2Cin]
                 cin = W.shape[1] // 2
                 s, t = _bn_affine(bn)
-                out['u%d_w' % l] = (W[:, :cin] * s[:, None]).t().contiguous()               # [Cin, Cout]
-                out['v%d_w' % l] = ((W[:, cin:] - W[:, :cin]) * s[:, None]).t().contiguous()
-                out['v%d_b' % l] = t.clone()
+                u = (W[:, :cin] * s[:, None]).t()                    # [Cin, Cout]: acts on the neighbour x_j
+                v = ((W[:, cin:] - W[:, :cin]) * s[:, None]).t()     # acts on the centre x_i
+                out['uv%d_w' % l] = torch.cat((u, v), dim=1).contiguous()  # one GEMM yields [U | V]
+                out['uv%d_b' % l] = torch.cat((torch.zeros_like(t), t))
             s, t = _bn_affine(m.bn5)
             out['c5_w'] = (m.conv5[0].weight.reshape(m.conv5[0].weight.shape[0], -1) * s[:, None]).t().contiguous()
             out['c5_b'] = t.clone()
@@ -149,13 +150,13 @@ class FoldedDGCNN(nn.Module):
                 idx = ops.knn_features(h.view(B, N, D), self.k)  # fused MFMA scores + selection, no [B,N,N] matrix
             else:
                 idx = knn(h.detach().view(B, N, -1).transpose(1, 2), self.k)  # [B,N,k]
-        U = torch.mm(h, getattr(self, 'u%d_w' % l))
-        V = torch.addmm(getattr(self, 'v%d_b' % l), h, getattr(self, 'v%d_w' % l))
-        C = U.shape[1]
+        UV = torch.addmm(getattr(self, 'uv%d_b' % l), h, getattr(self, 'uv%d_w' % l))  # [B*N, 2C]
+        C = UV.shape[1] // 2
         if h.is_cuda:
-            return ops.edge_max(U.view(B, N, C), V.view(B, N, C), idx, 0.2).view(B * N, C)
-        nbr = U.view(B, N, C).gather(1, idx.reshape(B, N * self.k, 1).expand(B, N * self.k, C)).view(B, N, self.k, C)
-        return F.leaky_relu(nbr.max(dim=2)[0] + V.view(B, N, C), negative_slope=0.2).view(B * N, C)
+            return ops.edge_max_fused(UV.view(B, N, 2 * C), idx, 0.2).view(B * N, C)
+        U, V = UV[:, :C].reshape(B, N, C), UV[:, C:].reshape(B, N, C)
+        nbr = U.gather(1, idx.reshape(B, N * self.k, 1).expand(B, N * self.k, C)).view(B, N, self.k, C)
+        return F.leaky_relu(nbr.max(dim=2)[0] + V, negative_slope=0.2).view(B * N, C)
 
     def forward(self, x):
         """x [B,3,N] -> logits [B,classes]"""
@@ -165,8 +166,12 @@ class FoldedDGCNN(nn.Module):
         for l in (1, 2, 3, 4):
             h = self._edge(h, B, N, l)
             feats.append(h)
-        h = F.leaky_relu(torch.addmm(self.c5_b, torch.cat(feats, dim=1), self.c5_w), negative_slope=0.2).view(B, N, -1)
-        g = torch.cat((h.max(dim=1)[0], h.mean(dim=1)), dim=1)
+        z = torch.addmm(self.c5_b, torch.cat(feats, dim=1), self.c5_w).view(B, N, -1)
+        if z.is_cuda and ops.lrelu_pool_supported(z.shape[2]):
+            g = ops.lrelu_pool(z, 0.2)  # activation + both poolings in one pass over z
+        else:
+            h = F.leaky_relu(z, negative_slope=0.2)
+            g = torch.cat((h.max(dim=1)[0], h.mean(dim=1)), dim=1)
         g = F.leaky_relu(torch.addmm(self.l1_b, g, self.l1_w), negative_slope=0.2)
         g = F.leaky_relu(torch.addmm(self.l2_b, g, self.l2_w), negative_slope=0.2)
         return torch.addmm(self.l3_b, g, self.l3_w)

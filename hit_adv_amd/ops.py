@@ -391,34 +391,75 @@ def pointnet_rowmlp_tiles(N):
 
 class EdgeMax(torch.autograd.Function):
     """out[b,i,:] = lrelu(V[b,i,:] + max_{j in idx[b,i,:]} U[b,j,:])  -- EdgeConv's gather / max / activation after the
-    1x1 convolution has been split into two per-point products (see hitadv_edge_max_fwd).  U, V [B,N,C], idx [B,N,k]."""
+    1x1 convolution has been split into two per-point products (see hitadv_edge_max_fwd).  UV [B,N,2C] = [U | V] (the
+    two products come out of one GEMM), idx [B,N,k]; the gradient comes back as [dU | dV] for one GEMM too."""
 
     @staticmethod
-    def forward(ctx, U, V, idx, slope):
-        U, V = _dev(U, "U"), _dev(V, "V")
+    def forward(ctx, UV, idx, slope):
+        UV = _dev(UV, "UV")
         idx = _dev(idx, "idx", torch.int64)
-        B, N, C = U.shape
-        out = torch.empty_like(U)
-        arg = torch.empty(B, N, C, device=U.device, dtype=torch.int32)
-        _lib.call("hitadv_edge_max_fwd", _p(U), _p(V), _p(idx), B, N, C, idx.shape[2], ctypes.c_float(slope), _p(out),
-                  _p(arg), _stream())
-        ctx.save_for_backward(out, arg)
+        B, N, C2 = UV.shape
+        C = C2 // 2
+        out = torch.empty(B, N, C, device=UV.device)
+        arg = torch.empty(B, N, C, device=UV.device, dtype=torch.int32)
+        _lib.call("hitadv_edge_max_fwd", _p(UV), ctypes.c_void_p(UV.data_ptr() + 4 * C), C2, _p(idx), B, N, C,
+                  idx.shape[2], ctypes.c_float(slope), _p(out), _p(arg), _stream())
+        ctx.save_for_backward(out, arg, idx)
         ctx.slope = slope
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        out, arg = ctx.saved_tensors
+        out, arg, idx = ctx.saved_tensors
         B, N, C = out.shape
+        k = idx.shape[2]
         dout = dout.contiguous()
-        dU, dV = torch.empty_like(out), torch.empty_like(out)
-        _lib.call("hitadv_edge_max_bwd", _p(dout), _p(out), _p(arg), B, N, C, ctypes.c_float(ctx.slope), _p(dU), _p(dV),
-                  _stream())
-        return dU, dV, None, None
+        dUV = torch.empty(B, N, 2 * C, device=out.device)
+        scratch = torch.empty(B * (N + 1 + N * k), device=out.device, dtype=torch.int32)
+        _lib.call("hitadv_edge_max_bwd", _p(dout), _p(out), _p(arg), _p(idx), B, N, C, k, ctypes.c_float(ctx.slope),
+                  _p(dUV), ctypes.c_void_p(dUV.data_ptr() + 4 * C), 2 * C, _p(scratch), _stream())
+        return dUV, None, None
 
 
 def edge_max(U, V, idx, slope=0.2):
-    return EdgeMax.apply(U, V, idx, slope)
+    """U, V [B,N,C] separate tensors (concatenated here); ``edge_max_fused`` takes the [U | V] product directly."""
+    return EdgeMax.apply(torch.cat((U, V), dim=2), idx, slope)
+
+
+def edge_max_fused(UV, idx, slope=0.2):
+    return EdgeMax.apply(UV, idx, slope)
+
+
+class LReluPool(torch.autograd.Function):
+    """[max_i lrelu(Z[b,i,:]) | mean_i lrelu(Z[b,i,:])] -> [B,2C] from the pre-activation Z [B,N,C] (hitadv_lrelu_pool_fwd)."""
+
+    @staticmethod
+    def forward(ctx, Z, slope):
+        Z = _dev(Z, "Z")
+        B, N, C = Z.shape
+        out = torch.empty(B, 2 * C, device=Z.device)
+        arg = torch.empty(B, C, device=Z.device, dtype=torch.int32)
+        _lib.call("hitadv_lrelu_pool_fwd", _p(Z), B, N, C, ctypes.c_float(slope), _p(out), _p(arg), _stream())
+        ctx.save_for_backward(Z, arg)
+        ctx.slope = slope
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Z, arg = ctx.saved_tensors
+        B, N, C = Z.shape
+        g = g.contiguous()
+        dZ = torch.empty_like(Z)
+        _lib.call("hitadv_lrelu_pool_bwd", _p(Z), _p(g), _p(arg), B, N, C, ctypes.c_float(ctx.slope), _p(dZ), _stream())
+        return dZ, None
+
+
+def lrelu_pool(Z, slope=0.2):
+    return LReluPool.apply(Z, slope)
+
+
+def lrelu_pool_supported(C):
+    return C % 64 == 0
 
 
 def knn_features(x, K):

@@ -301,13 +301,27 @@ int64_t hitadv_fc_layer_scratch_floats(int B, int K, int NOUT);
  * 93-112) with the convolution split algebraically into two per-point products U = X (s Wa)^T, V = X (s (Wb - Wa))^T + t
  * (W = [Wa | Wb] acting on [x_j - x_i ; x_i], BatchNorm scale s / shift t folded):
  *   out[b,i,c] = lrelu(V[b,i,c] + max_{j in idx[b,i,:]} U[b,j,c]),  arg[b,i,c] = the winning j.
- * U, V, out [B,N,C] points-major, C % 4 == 0, idx [B,N,k] int64; the [B,2C,N,k] edge tensor is never built. */
-int hitadv_edge_max_fwd(const float *U, const float *V, const int64_t *idx, int B, int N, int C, int k, float slope,
-                        float *out, int32_t *arg, void *stream);
-/* dV = dout * lrelu'(out);  dU[b,j,c] = sum_{i: arg[b,i,c]==j} dV[b,i,c]  (dU is zero-filled here; float atomics, so the
- * summation order -- not the set of terms -- varies between runs, like the reference's index_select backward). */
-int hitadv_edge_max_bwd(const float *dout, const float *out, const int32_t *arg, int B, int N, int C, float slope,
-                        float *dU, float *dV, void *stream);
+ * out, arg [B,N,C] points-major, C % 4 == 0; U and V are [B,N,C] views with a row pitch of ld floats (ld = C for two
+ * separate tensors; ld = 2C with V = U + C when one product X [Wu | Wv] produced both); idx [B,N,k] int64; the
+ * [B,2C,N,k] edge tensor is never built. */
+int hitadv_edge_max_fwd(const float *U, const float *V, int ld, const int64_t *idx, int B, int N, int C, int k,
+                        float slope, float *out, int32_t *arg, void *stream);
+/* dV = dout * lrelu'(out);  dU[b,j,c] = sum_{i: arg[b,i,c]==j} dV[b,i,c], the terms added in ascending i: the neighbour
+ * table is reversed on the device first (integer atomics only) and every (j,c) gathers its terms, so the result is the
+ * same bit pattern on every run (torch's index_select backward, which the reference goes through, is not).
+ * idx: the table the forward was given; dU, dV: [B,N,C] views with a row pitch of ldg floats (as U, V in the forward);
+ * scratch: hitadv_edge_max_bwd_scratch_ints(B,N,k) int32, contents irrelevant. */
+int hitadv_edge_max_bwd(const float *dout, const float *out, const int32_t *arg, const int64_t *idx, int B, int N, int C,
+                        int k, float slope, float *dU, float *dV, int ldg, int32_t *scratch, void *stream);
+int64_t hitadv_edge_max_bwd_scratch_ints(int B, int N, int k);
+
+/* DGCNN's pooling after the embedding layer (model/dgcnn_cls.py:117-121: LeakyReLU, adaptive_max_pool1d and
+ * adaptive_avg_pool1d over the points, concatenated), from the layer's PRE-activation Z [B,N,C] points-major, C % 64 == 0:
+ *   out[b,c] = max_i lrelu(Z[b,i,c]),  out[b,C+c] = mean_i lrelu(Z[b,i,c]),  arg[b,c] = first i attaining the max.
+ * One pass over Z, fixed summation order.  Backward: dZ[b,i,c] = lrelu'(Z) * (g[b,C+c]/N + (i == arg[b,c]) g[b,c]). */
+int hitadv_lrelu_pool_fwd(const float *Z, int B, int N, int C, float slope, float *out, int32_t *arg, void *stream);
+int hitadv_lrelu_pool_bwd(const float *Z, const float *g, const int32_t *arg, int B, int N, int C, float slope, float *dZ,
+                          void *stream);
 
 /* k nearest neighbours in feature space for DGCNN's dynamic graph (model/dgcnn_cls.py:7-13: topk of
  * -|x_i|^2 + 2 x_i.x_j - |x_j|^2), fused: the scores come off the f32 matrix cores tile by tile and go straight into

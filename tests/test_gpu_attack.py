@@ -411,7 +411,7 @@ def test_dgcnn_victim_on_gpu_and_under_attack():
 
 def test_dgcnn_attack_view_and_edge_max_kernels():
     """The folded DGCNN view on the GPU: the EdgeConv neighbour-max kernels against their torch formulation (forward
-    bitwise, arg table consistent, backward to rounding -- the scatter uses float atomics), the view against the module
+    bitwise, backward bitwise against the ascending-i sequential sum and reproducible), the view against the module
     (same neighbour tables up to fp32 near-ties), and HiT-ADV using it by default."""
     import argparse
     from hit_adv_amd import ops
@@ -432,6 +432,16 @@ def test_dgcnn_attack_view_and_edge_max_kernels():
     ru, rv = torch.autograd.grad((ref * w).sum(), [U, V])
     assert torch.equal(gv, rv)
     close(gu, ru, rtol=1e-5, atol=1e-5)
+    # the backward gathers its terms in ascending i: bit for bit the sequential sum, and the same bits on every run
+    slot = nbr.max(dim=2)[1]  # [B,N,C] winning slot (no ties between distinct rows of a randn U)
+    arg = torch.gather(idx.unsqueeze(-1).expand(B, N, k, C), 2, slot.unsqueeze(2)).squeeze(2).cpu()
+    seq = torch.zeros(B, N, C)
+    gv_cpu = gv.cpu()
+    for i in range(N):
+        seq.scatter_add_(1, arg[:, i:i + 1, :], gv_cpu[:, i:i + 1, :])
+    assert torch.equal(gu.cpu(), seq)
+    gu2, = torch.autograd.grad((ops.edge_max(U, V, idx, 0.2) * w).sum(), [U])
+    assert torch.equal(gu, gu2)
 
     torch.manual_seed(5)
     m = DGCNN_cls(argparse.Namespace(k=5, emb_dims=1024, dropout=0.2), output_channels=40).eval().cuda()

@@ -133,6 +133,36 @@ def test_attack_state_kernels_small_shapes(A):
     assert torch.isfinite(out) and abs(out.item() - 7.0 * d.item()) < 1e-5 * abs(out.item()) + 1e-9
 
 
+@pytest.mark.parametrize("B,n,C,k", [(2, 2048, 8, 3), (1, 1100, 4, 40), (3, 33, 64, 1), (2, 3000, 4, 2)])
+def test_edge_max_backward_reversed_graph_sizes(A, B, n, C, k):
+    """The gather-form backward where the bit matrix of the reversed neighbour table needs several passes (N > 1024), N
+    is no multiple of 32, lists repeat an entry, hubs collect thousands of edges, and some points are listed by nobody:
+    bit for bit the ascending-i sequential sum."""
+    g = torch.Generator().manual_seed(n + k)
+    U = torch.randn(B, n, C, generator=g).cuda().requires_grad_()
+    V = torch.randn(B, n, C, generator=g).cuda().requires_grad_()
+    idx = torch.randint(0, n, (B, n, k), generator=g)
+    idx[:, ::3, 0] = 7  # a hub
+    idx[:, :, -1] = idx[:, :, 0]  # a repeated entry in every list (k > 1)
+    idx[idx == 5] = 6  # nobody lists point 5
+    w = torch.randn(B, n, C, generator=g).cuda()
+    idx_d = idx.cuda()
+    out = A.edge_max(U, V, idx_d, 0.2)
+    gu, gv = torch.autograd.grad((out * w).sum(), [U, V])
+    nbr = U.detach().cpu().gather(1, idx.reshape(B, n * k, 1).expand(B, n * k, C)).view(B, n, k, C)
+    top, slot = nbr.max(dim=2)
+    ref = torch.nn.functional.leaky_relu(top + V.detach().cpu(), negative_slope=0.2)
+    assert torch.equal(out.detach().cpu(), ref)
+    arg = torch.gather(idx.unsqueeze(-1).expand(B, n, k, C), 2, slot.unsqueeze(2)).squeeze(2)
+    dv = w.cpu() * torch.where(ref > 0, torch.ones(()), torch.full((), 0.2))
+    assert torch.equal(gv.cpu(), dv)
+    seq = torch.zeros(B, n, C)
+    for i in range(n):
+        seq.scatter_add_(1, arg[:, i:i + 1, :], dv[:, i:i + 1, :])
+    assert torch.equal(gu.cpu(), seq)
+    assert float(gu[:, 5].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("B,n", [(1, 1000), (3, 2048), (5, 130)])
 def test_hit_adv_pointnet_engine_odd_shapes_graph_equals_eager(B, n):
     """HiT-ADV on the HIP PointNet engine at shapes off the bench's (a single cloud, N not a multiple of the 64-point

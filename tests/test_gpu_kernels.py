@@ -671,6 +671,32 @@ def test_knn_features_mfma(A, B, Np, D, K):
     assert torch.equal(idx, A.knn_features(cu(x), K).cpu())
 
 
+@pytest.mark.parametrize("B,n,C", [(3, 1000, 128), (2, 17, 64), (4, 1024, 1024)])
+def test_lrelu_pool_matches_torch(A, B, n, C):
+    """DGCNN's activation + max/mean pooling in one pass: max bit-exact, mean to summation order, arg = first maximiser,
+    gradient against autograd of the torch composition, bitwise reproducible."""
+    g = torch.Generator().manual_seed(C + n)
+    z = torch.randn(B, n, C, generator=g)
+    z[:, 3, :5] = z[:, 9, :5] = 50.0  # a tie for the maximum: the earlier point takes the gradient
+    za, zb = z.cuda().requires_grad_(), z.cuda().requires_grad_()
+    w = torch.randn(B, 2 * C, generator=g).cuda()
+    out = A.lrelu_pool(za, 0.2)
+    h = torch.nn.functional.leaky_relu(zb, negative_slope=0.2)
+    ref = torch.cat((h.max(dim=1)[0], h.mean(dim=1)), dim=1)
+    assert torch.equal(out[:, :C], ref[:, :C])
+    close(out[:, C:], ref[:, C:], rtol=1e-5, atol=1e-6)
+    ga, = torch.autograd.grad((out * w).sum(), za)
+    # reference gradient with the tie routed to the first maximiser (torch's max picks an unspecified one)
+    first = (h == h.max(dim=1, keepdim=True)[0]).float().argmax(dim=1)  # [B,C]
+    onehot = torch.zeros_like(h).scatter_(1, first.unsqueeze(1), 1.0)
+    slope = torch.where(zb > 0, 1.0, 0.2)
+    gb = (onehot * w[:, None, :C] + w[:, None, C:] / n) * slope
+    close(ga, gb, rtol=1e-6, atol=1e-7)
+    assert float(ga[:, 9, :5].abs().max()) <= float((w[:, C:C + 5].abs() / n).max()) + 1e-7  # tie: no max-gradient at point 9
+    out2 = A.lrelu_pool(za, 0.2)
+    assert torch.equal(out, out2)
+
+
 def test_pointnet_engine_captures_on_a_fresh_stream():
     """The standard torch.cuda.graph pattern (capture on the graph's own side stream, no eager pass on THAT stream first)
     works: the engine's ticket scratch is created inside the capture, and replays reproduce the eager result bit for bit."""
