@@ -236,7 +236,9 @@ __global__ __launch_bounds__(256) void edge_max_fwd_k(const float *__restrict__ 
                                                       int ld, const int64_t *__restrict__ idx, int N, int C, int k,
                                                       float slope, float *__restrict__ out, int32_t *__restrict__ arg,
                                                       long long total4) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, i, c4)
+  long long blk = blockIdx.x;  // blocks of one cloud on one XCD: its U rows are gathered k times, from that L2
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const long long e = blk * 256 + threadIdx.x;  // (b, i, c4)
   if (e >= total4) return;
   const int c4n = C >> 2;
   const int c4 = (int)(e % c4n);
@@ -267,80 +269,76 @@ __global__ __launch_bounds__(256) void edge_max_fwd_k(const float *__restrict__ 
 // neighbour table is turned around first (who lists j?), and every (j, c) then GATHERS its terms in ascending i:
 // same bits every run, no zero-fill, no atomics on floats.
 //
-// reverse_graph_k: one block per cloud.  Pass over the N*k edges setting bit i of row j in an LDS bit matrix
-// (atomicOr on integers: order-free), J rows at a time (all N rows at once up to N = 1024); a row's popcount is the
-// in-degree, its set bits in ascending order are the in-list.  Duplicate entries of a neighbour list collapse into one
-// bit, which is what the gather wants (it tests arg[i,c] == j once per listed i).  rowptr [B,N+1], col [B,N*k] int32.
-#define RG_THREADS 1024
-#define RG_BITMAP_WORDS 30720  // 120 KB of the CU's 160 KB
-
-__device__ __forceinline__ void rg_fill_rows(const int64_t *__restrict__ nb, int E, int k, int N, int j0, int rows, int RS,
-                                             uint32_t *bm) {
-  for (int w = threadIdx.x; w < rows * RS; w += RG_THREADS) bm[w] = 0u;
-  __syncthreads();
-  for (int e = threadIdx.x; e < E; e += RG_THREADS) {
-    const long long j = nb[e] - j0;
-    if (j >= 0 && j < rows && nb[e] < N) {
-      const int i = e / k;
-      atomicOr(&bm[(int)j * RS + (i >> 5)], 1u << (i & 31));
-    }
-  }
-  __syncthreads();
-}
+// reverse_graph_k: a block owns J consecutive target points j of one cloud.  It walks the cloud's N*k edges once: edges
+// into its range set bit i of row j in an LDS bit matrix and bump j's edge count (integer LDS atomics: order-free);
+// edges into LOWER ranges are only counted -- that count is where this block's share of the list array begins, so no
+// block waits for another.  A row's set bits, read in ascending order, are the in-list.  A neighbour list that repeats
+// an entry yields one bit but two counts: segments may end with unused slots, hence span[j] = (begin, end) rather than
+// a compact CSR.  The gather tests arg[i,c] == j once per listed i, which is what the de-duplication wants.
+#define RG_THREADS 256
+#define RG_BITMAP_WORDS 15360  // 60 KB: two blocks per CU
 
 __global__ __launch_bounds__(RG_THREADS) void reverse_graph_k(const int64_t *__restrict__ idx, int N, int k, int W, int J,
-                                                              int32_t *__restrict__ rowptr, int32_t *__restrict__ col) {
+                                                              int2 *__restrict__ span, int32_t *__restrict__ col) {
   extern __shared__ uint32_t rg_sm[];
-  uint32_t *bm = rg_sm;                                  // J rows of W (+1 pad: a thread per row walks its words)
-  int32_t *part = (int32_t *)(rg_sm + RG_BITMAP_WORDS);  // RG_THREADS partial sums, ping-pong
-  const int b = blockIdx.x, tid = threadIdx.x;
+  uint32_t *bm = rg_sm;                               // J rows of W words (+1 pad: a thread per row walks its words)
+  int32_t *cnt = (int32_t *)(rg_sm + RG_BITMAP_WORDS);  // J edge counts, then their exclusive prefix
+  int32_t *red = cnt + RG_THREADS;                    // block reduction / scan workspace (2 x RG_THREADS)
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int j0 = blockIdx.x * J, rows = min(J, N - j0);
   const int E = N * k, RS = W + 1;
   const int64_t *nb = idx + (size_t)b * E;
-  int32_t *rp = rowptr + (size_t)b * (N + 1);
-  int32_t *cl = col + (size_t)b * E;
-  const int npass = (N + J - 1) / J;
-  for (int p = 0; p < npass; ++p) {  // in-degrees
-    const int j0 = p * J, rows = min(J, N - j0);
-    rg_fill_rows(nb, E, k, N, j0, rows, RS, bm);
-    for (int r = tid; r < rows; r += RG_THREADS) {
-      int c = 0;
-      for (int w = 0; w < W; ++w) c += __popc(bm[r * RS + w]);
-      rp[j0 + r] = c;
-    }
-    if (npass > 1) __syncthreads();
-  }
+  for (int w = tid; w < rows * RS; w += RG_THREADS) bm[w] = 0u;
+  cnt[tid] = 0;
   __syncthreads();
-  // exclusive scan of rp[0..N) in place, rp[N] = total: a chunk per thread, then the chunk sums across the block
-  const int chunk = (N + RG_THREADS - 1) / RG_THREADS;
-  const int lo = min(tid * chunk, N), hi = min(lo + chunk, N);
-  int sum = 0;
-  for (int j = lo; j < hi; ++j) sum += rp[j];
-  int32_t *src = part, *dst = part + RG_THREADS;
-  src[tid] = sum;
+  int below = 0;
+  auto edge = [&](int e, long long j) {
+    if (j < 0 || j >= N) return;  // the reference does not bound-check idx either; such an edge feeds nobody
+    if (j < j0) {
+      ++below;
+    } else if (j < j0 + rows) {
+      const int i = e / k;
+      atomicOr(&bm[(int)(j - j0) * RS + (i >> 5)], 1u << (i & 31));
+      atomicAdd(&cnt[(int)(j - j0)], 1);
+    }
+  };
+  int e = tid;
+  for (; e + 7 * RG_THREADS < E; e += 8 * RG_THREADS) {  // eight table entries in flight per lane
+    long long j[8];
+    for (int u = 0; u < 8; ++u) j[u] = nb[e + u * RG_THREADS];
+    for (int u = 0; u < 8; ++u) edge(e + u * RG_THREADS, j[u]);
+  }
+  for (; e < E; e += RG_THREADS) edge(e, nb[e]);
+  // block sum of `below`, and the exclusive scan of cnt[0..J) (J <= RG_THREADS: one entry per thread)
+  int32_t *src = red, *dst = red + RG_THREADS;
+  src[tid] = below;
+  __syncthreads();
+  for (int d = RG_THREADS >> 1; d > 0; d >>= 1) {
+    if (tid < d) src[tid] += src[tid + d];
+    __syncthreads();
+  }
+  const int base = src[0];
+  __syncthreads();
+  const int mine = cnt[tid];
+  src[tid] = mine;
   __syncthreads();
   for (int d = 1; d < RG_THREADS; d <<= 1) {
     dst[tid] = src[tid] + (tid >= d ? src[tid - d] : 0);
     __syncthreads();
     int32_t *t = src; src = dst; dst = t;
   }
-  int run = src[tid] - sum;  // exclusive prefix of this thread's chunk
-  if (tid == RG_THREADS - 1) rp[N] = src[tid];
-  for (int j = lo; j < hi; ++j) { const int d = rp[j]; rp[j] = run; run += d; }
-  __syncthreads();  // rp[] is read back below by other threads: global memory, same block
-  for (int p = 0; p < npass; ++p) {  // in-lists
-    const int j0 = p * J, rows = min(J, N - j0);
-    if (npass > 1) rg_fill_rows(nb, E, k, N, j0, rows, RS, bm);  // a single pass still holds the bit matrix
-    for (int r = tid; r < rows; r += RG_THREADS) {
-      int pos = rp[j0 + r];
-      for (int w = 0; w < W; ++w) {
-        uint32_t bits = bm[r * RS + w];
-        while (bits) {
-          cl[pos++] = (w << 5) + __builtin_ctz(bits);
-          bits &= bits - 1;
-        }
+  if (tid < rows) {
+    const int begin = base + src[tid] - mine;
+    int pos = begin;
+    int32_t *cl = col + (size_t)b * E;
+    for (int w = 0; w < W; ++w) {
+      uint32_t bits = bm[tid * RS + w];
+      while (bits) {
+        cl[pos++] = (w << 5) + __builtin_ctz(bits);
+        bits &= bits - 1;
       }
     }
-    if (npass > 1) __syncthreads();
+    span[(size_t)b * N + j0 + tid] = make_int2(begin, pos);
   }
 }
 
@@ -348,7 +346,7 @@ __global__ __launch_bounds__(RG_THREADS) void reverse_graph_k(const int64_t *__r
 // XCD: every (i, c) row of arg / dout / out is visited once per neighbour that lists... k times in all, and those
 // re-reads should hit that XCD's L2.
 __global__ __launch_bounds__(256) void edge_max_bwd_k(const float *__restrict__ dout, const float *__restrict__ out,
-                                                      const int32_t *__restrict__ arg, const int32_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ arg, const int2 *__restrict__ span,
                                                       const int32_t *__restrict__ col, int N, int C, int E, float slope,
                                                       float *__restrict__ dU, float *__restrict__ dV, int ldg,
                                                       long long total4) {
@@ -368,12 +366,10 @@ __global__ __launch_bounds__(256) void edge_max_bwd_k(const float *__restrict__ 
     *reinterpret_cast<float4 *>(dV + (size_t)bj * ldg + 4 * c4) = make_float4(d.x * (o.x > 0.f ? 1.0f : slope), d.y * (o.y > 0.f ? 1.0f : slope),
                                                     d.z * (o.z > 0.f ? 1.0f : slope), d.w * (o.w > 0.f ? 1.0f : slope));
   }
-  const int32_t *rp = rowptr + b * (N + 1);
+  const int2 seg = span[bj];
   const int32_t *cl = col + b * E;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t = rp[j], end = rp[j + 1]; t < end; ++t) {
-    const long long src = (b * N + cl[t]) * c4n + c4;
-    const int4 a = a4[src];
+  auto take = [&](long long src, const int4 &a) {
     if (a.x == j || a.y == j || a.z == j || a.w == j) {
       const float4 d = d4[src], o = o4[src];
       if (a.x == j) acc.x += d.x * (o.x > 0.f ? 1.0f : slope);
@@ -381,6 +377,19 @@ __global__ __launch_bounds__(256) void edge_max_bwd_k(const float *__restrict__ 
       if (a.z == j) acc.z += d.z * (o.z > 0.f ? 1.0f : slope);
       if (a.w == j) acc.w += d.w * (o.w > 0.f ? 1.0f : slope);
     }
+  };
+  int t = seg.x;
+  const int end = seg.y;
+  for (; t + 4 <= end; t += 4) {  // four listed points at a time: their arg rows are fetched together
+    long long src[4];
+    int4 a[4];
+    for (int u = 0; u < 4; ++u) src[u] = (b * N + cl[t + u]) * c4n + c4;
+    for (int u = 0; u < 4; ++u) a[u] = a4[src[u]];
+    for (int u = 0; u < 4; ++u) take(src[u], a[u]);
+  }
+  for (; t < end; ++t) {
+    const long long src = (b * N + cl[t]) * c4n + c4;
+    take(src, a4[src]);
   }
   *reinterpret_cast<float4 *>(dU + (size_t)bj * ldg + 4 * c4) = acc;
 }
@@ -405,14 +414,20 @@ __global__ __launch_bounds__(256) void lrelu_pool_fwd_k(const float *__restrict_
   float sum[4] = {0.f, 0.f, 0.f, 0.f}, best[4];
   int bi[4] = {0, 0, 0, 0};
   for (int q = 0; q < 4; ++q) best[q] = -__builtin_inff();
-  for (int i = rg; i < N; i += 16) {
-    const float4 z = z4[(size_t)i * stride4];
+  auto take = [&](const float4 &z, int i) {
     const float v[4] = {z.x, z.y, z.z, z.w};
     for (int q = 0; q < 4; ++q) {
       sum[q] += v[q] > 0.f ? v[q] : v[q] * slope;
       if (v[q] > best[q]) { best[q] = v[q]; bi[q] = i; }
     }
+  };
+  int i = rg;
+  for (; i + 112 < N; i += 128) {  // eight rows in flight per lane; consumed in row order, so the sums keep their order
+    float4 z[8];
+    for (int u = 0; u < 8; ++u) z[u] = z4[(size_t)(i + 16 * u) * stride4];
+    for (int u = 0; u < 8; ++u) take(z[u], i + 16 * u);
   }
+  for (; i < N; i += 16) take(z4[(size_t)i * stride4], i);
   for (int q = 0; q < 4; ++q) {
     s_sum[rg][lane * 4 + q] = sum[q];
     s_best[rg][lane * 4 + q] = best[q];
@@ -495,7 +510,7 @@ extern "C" int hitadv_edge_max_fwd(const float *U, const float *V, int ld, const
 
 extern "C" int64_t hitadv_edge_max_bwd_scratch_ints(int B, int N, int k) {
   if (B <= 0 || N <= 0 || k <= 0) return HITADV_E_ARG;
-  return (int64_t)B * ((int64_t)N + 1 + (int64_t)N * k);
+  return (int64_t)B * (2 * (int64_t)N + (int64_t)N * k);
 }
 
 extern "C" int hitadv_edge_max_bwd(const float *dout, const float *out, const int32_t *arg, const int64_t *idx, int B,
@@ -504,21 +519,23 @@ extern "C" int hitadv_edge_max_bwd(const float *dout, const float *out, const in
   if (!dout || !out || !arg || !idx || !dU || !dV || !scratch || B <= 0 || N <= 0 || C <= 0 || (C & 3) || k <= 0 ||
       ldg < C || (ldg & 3) ||
       (long long)N * k > 0x7fffffffLL ||
-      (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)arg | (uintptr_t)dU | (uintptr_t)dV) & 15))
+      (((uintptr_t)dout | (uintptr_t)out | (uintptr_t)arg | (uintptr_t)dU | (uintptr_t)dV) & 15) ||
+      ((uintptr_t)scratch & 7))
     return HITADV_E_ARG;
   const int W = (N + 31) / 32;
-  if (W + 1 > RG_BITMAP_WORDS) return HITADV_E_ARG;  // N > 983,008: one bit row no longer fits
-  const int J = RG_BITMAP_WORDS / (W + 1);
-  int32_t *rowptr = scratch, *col = scratch + (size_t)B * (N + 1);
-  const size_t shm = (size_t)(RG_BITMAP_WORDS + 2 * RG_THREADS) * 4;
+  if (W + 1 > RG_BITMAP_WORDS) return HITADV_E_ARG;  // N > 491,488: one bit row no longer fits
+  const int J = min(RG_THREADS, RG_BITMAP_WORDS / (W + 1));
+  int2 *span = reinterpret_cast<int2 *>(scratch);
+  int32_t *col = scratch + (size_t)B * 2 * N;
+  const size_t shm = (size_t)(RG_BITMAP_WORDS + 3 * RG_THREADS) * 4;
   static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&hitadv::reverse_graph_k),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   (void)once;
-  hitadv::reverse_graph_k<<<B, RG_THREADS, shm, (hipStream_t)stream>>>(idx, N, k, W, J, rowptr, col);
+  hitadv::reverse_graph_k<<<dim3((N + J - 1) / J, B), RG_THREADS, shm, (hipStream_t)stream>>>(idx, N, k, W, J, span, col);
   HITADV_LAUNCH_CHECK();
   const long long total4 = (long long)B * N * (C >> 2);
   hitadv::edge_max_bwd_k<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      dout, out, arg, rowptr, col, N, C, N * k, slope, dU, dV, ldg, total4);
+      dout, out, arg, span, col, N, C, N * k, slope, dU, dV, ldg, total4);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

@@ -374,30 +374,38 @@ extern "C" int hitadv_knn_points_bwd(const float *q, const float *p, const void 
 // k nearest neighbours in FEATURE space (DGCNN's dynamic graph, model/dgcnn_cls.py:7-13) without the [B,N,N] score
 // matrix: scores  s_ij = (-|x_i|^2 + 2 x_i.x_j) - |x_j|^2  (the reference's expression, larger = closer) come out of the
 // f32 matrix cores tile by tile and go straight into per-lane sorted lists.
-//   block = 4 waves = 128 queries of one cloud; reference points stream through LDS in 32-point tiles (double buffered,
-//   shared by the waves); wave w holds its 32 queries' features in registers as the MFMA B operand, so the accumulator
-//   has the QUERY on the lane and 16 reference points in registers: a lane scans its 16 scores against its own list
-//   (KB entries, compile-time indices, no scratch).  Each query is served by two lanes (the halves of the wave see
-//   disjoint reference rows); their lists are merged at the end.  Ties -> lower index.
+//   block = 8 waves = 128 queries of one cloud; reference points stream through LDS 64 at a time (two 32-point tiles,
+//   double buffered, shared by the waves); waves w and w+4 hold the same 32 queries' features in registers as the MFMA
+//   B operand and take the even / odd tile, so the accumulator has the QUERY on the lane and 16 reference points in
+//   registers: a lane scans its 16 scores against its own list (KB entries, compile-time indices, no scratch).  Two
+//   waves per SIMD: one wave's selection (VALU) runs under the other's matrix instructions -- with one wave per SIMD
+//   the two phases alternated and the kernel took twice as long.  Each query is served by four lanes (two waves x the
+//   halves of a wave, disjoint reference rows); their lists are merged at the end.  Ties -> lower index.
 namespace hitadv {
 
 typedef float f32x16_k __attribute__((ext_vector_type(16)));
 
+// LDS floats of knn_feat_k: the double-buffered reference tiles (2 x 64 points) or, after the scan, the 4 x 128 lists
+__host__ __device__ constexpr int knn_feat_main_floats(int D, int KB) {
+  return 2 * 64 * (D + 4) > 128 * 4 * KB * 2 ? 2 * 64 * (D + 4) : 128 * 4 * KB * 2;
+}
+__host__ __device__ constexpr int knn_feat_lds_bytes(int D, int KB) { return (knn_feat_main_floats(D, KB) + 2 * 64) * 4; }
+
 template <int D, int KB>
-__global__ __launch_bounds__(256) void knn_feat_k(const float *__restrict__ X, const float *__restrict__ xx, int N, int K,
+__global__ __launch_bounds__(512) void knn_feat_k(const float *__restrict__ X, const float *__restrict__ xx, int N, int K,
                                                   int64_t *__restrict__ idx) {
   constexpr int LD = D + 4;
-  constexpr int ST = 32 * (D / 4) / 256;  // float4 staged per thread per 32-point tile (D=64: 2, D=128: 4)
-  constexpr int TILE_F = 2 * 32 * LD, MERGE_F = 2 * 4 * 32 * 2 * KB;  // floats: reference tiles / final merge
-  __shared__ float4 sR4[(TILE_F > MERGE_F ? TILE_F : MERGE_F) / 4];
-  __shared__ float sXX[2][32];
-  float *sR = reinterpret_cast<float *>(sR4);
+  constexpr int ST = 64 * (D / 4) / 512;  // float4 staged per thread per 64-point step (D=64: 2, D=128: 4)
+  extern __shared__ float4 knn_feat_sm[];  // knn_feat_lds_bytes<D,KB>(): max(reference tiles, final merge) + |x|^2
+  float *sR = reinterpret_cast<float *>(knn_feat_sm);
+  float(*sXX)[64] = reinterpret_cast<float(*)[64]>(sR + knn_feat_main_floats(D, KB));
   const int b = blockIdx.y, q0 = blockIdx.x * 128;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int qg = wave & 3, half = wave >> 2;  // query group; which tile of a step
   const int r = lane & 31, h = lane >> 5;
   X += (size_t)b * N * D;
   xx += (size_t)b * N;
-  const int q = q0 + 32 * wave + r;       // this lane's query
+  const int q = q0 + 32 * qg + r;         // this lane's query
   const int qc = q < N ? q : N - 1;       // clamp for loads
   float qreg[D / 2];
 #pragma unroll
@@ -439,33 +447,35 @@ __global__ __launch_bounds__(256) void knn_feat_k(const float *__restrict__ X, c
       if (np > t) insert(pv[t], pj[t]);
     np = 0;
   };
-  const int ntiles = (N + 31) / 32;
+  const int ntiles = (N + 31) / 32, nsteps = (N + 63) / 64;
   float4 st[ST];
   float stx = 0.f;
-  auto fetch = [&](int tile) {
+  auto fetch = [&](int step) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
-      const int e = threadIdx.x + 256 * u;
-      const int n = tile * 32 + e / (D / 4);
+      const int e = threadIdx.x + 512 * u;
+      const int n = step * 64 + e / (D / 4);
       st[u] = n < N ? *reinterpret_cast<const float4 *>(X + (size_t)n * D + 4 * (e % (D / 4))) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (threadIdx.x < 32) stx = tile * 32 + threadIdx.x < N ? xx[tile * 32 + threadIdx.x] : __builtin_inff();
+    if (threadIdx.x < 64) stx = step * 64 + threadIdx.x < N ? xx[step * 64 + threadIdx.x] : __builtin_inff();
   };
   auto stash = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
-      const int e = threadIdx.x + 256 * u;
-      *reinterpret_cast<float4 *>(sR + buf * 32 * LD + (e / (D / 4)) * LD + 4 * (e % (D / 4))) = st[u];
+      const int e = threadIdx.x + 512 * u;
+      *reinterpret_cast<float4 *>(sR + buf * 64 * LD + (e / (D / 4)) * LD + 4 * (e % (D / 4))) = st[u];
     }
-    if (threadIdx.x < 32) sXX[buf][threadIdx.x] = stx;
+    if (threadIdx.x < 64) sXX[buf][threadIdx.x] = stx;
   };
   fetch(0);
   stash(0);
   __syncthreads();
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const bool more = tile + 1 < ntiles;
-    if (more) fetch(tile + 1);
-    const float *a = sR + (tile & 1) * 32 * LD + r * LD + 4 * h;
+  for (int step = 0; step < nsteps; ++step) {
+    const bool more = step + 1 < nsteps;
+    if (more) fetch(step + 1);
+    const int tile = 2 * step + half;
+    if (tile < ntiles) {
+    const float *a = sR + (step & 1) * 64 * LD + (32 * half + r) * LD + 4 * h;
     f32x16_k acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(256) void knn_feat_k(const float *__restrict__ X, c
 #pragma unroll
     for (int e = 0; e < 16; ++e) {  // reference row of element e: (e&3) + 8*(e>>2) + 4*h, ascending in e
       const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-      const float s = (2.0f * acc[e] - qxx) - sXX[tile & 1][rr];  // -inf for rows past N
+      const float s = (2.0f * acc[e] - qxx) - sXX[step & 1][32 * half + rr];  // -inf for rows past N
       // accepted candidates are parked in a BUF-deep per-lane shift register; the sorted insert (executed by the whole
       // wave whenever ANY lane needs it) runs once per BUF acceptances of the fastest-filling lane, not per score
       const bool accept = s > lv[KB - 1];
@@ -494,33 +504,37 @@ __global__ __launch_bounds__(256) void knn_feat_k(const float *__restrict__ X, c
       np += accept ? 1 : 0;
       if (__ballot(np == BUF)) flush();
     }
-    if (more) stash((tile + 1) & 1);
+    }
+    if (more) stash((step + 1) & 1);
     __syncthreads();
   }
   flush();
-  // merge the two halves' lists of every query (LDS: the reference tiles are dead)
-  float *mv = sR;                                  // [4 waves][32 queries][2][KB]
-  int *mi = reinterpret_cast<int *>(sR + 4 * 32 * 2 * KB);
-  const int slot = ((wave * 32 + r) * 2 + h) * KB;
+  // merge the four lists of every query (LDS: the reference tiles are dead)
+  float *mv = sR;                                  // [128 queries][4 lists][KB]
+  int *mi = reinterpret_cast<int *>(sR + 128 * 4 * KB);
+  const int slot = ((qg * 32 + r) * 4 + 2 * half + h) * KB;
 #pragma unroll
   for (int t = 0; t < KB; ++t) {
     mv[slot + t] = lv[t];
     mi[slot + t] = li[t];
   }
   __syncthreads();
-  if (h == 0 && q < N) {
-    const int s0 = ((wave * 32 + r) * 2) * KB, s1 = s0 + KB;
-    int p0 = 0, p1 = 0;
+  if (half == 0 && h == 0 && q < N) {
+    const int s0 = (qg * 32 + r) * 4 * KB;
+    int p[4] = {0, 0, 0, 0};
     int64_t *o = idx + ((size_t)b * N + q) * K;
     for (int t = 0; t < K; ++t) {
-      const float v0 = mv[s0 + p0], v1 = mv[s1 + p1];
-      const int i0 = mi[s0 + p0], i1 = mi[s1 + p1];
-      const bool take0 = v0 > v1 || (v0 == v1 && i0 < i1);
-      o[t] = take0 ? i0 : i1;
-      p0 += take0 ? 1 : 0;
-      p1 += take0 ? 0 : 1;
-      if (p0 >= KB) p0 = KB - 1, mv[s0 + p0] = -__builtin_inff(), mi[s0 + p0] = 0x7fffffff;  // exhausted list
-      if (p1 >= KB) p1 = KB - 1, mv[s1 + p1] = -__builtin_inff(), mi[s1 + p1] = 0x7fffffff;
+      float bv = -__builtin_inff();
+      int bi = 0x7fffffff, bl = 0;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const float v = p[l] < KB ? mv[s0 + l * KB + p[l]] : -__builtin_inff();
+        const int i = p[l] < KB ? mi[s0 + l * KB + p[l]] : 0x7fffffff;
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bl = l; }
+      }
+      o[t] = bi;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) p[l] += bl == l ? 1 : 0;
     }
   }
 }
@@ -533,13 +547,22 @@ extern "C" int hitadv_knn_features(const float *X, const float *xx, int B, int N
     return HITADV_E_ARG;
   dim3 grid((N + 127) / 128, B);
   hipStream_t s = (hipStream_t)stream;
+#define HITADV_KNN_FEAT(DD, KK)                                                                                          \
+  do {                                                                                                                 \
+    constexpr int shm = hitadv::knn_feat_lds_bytes(DD, KK);                                                            \
+    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&hitadv::knn_feat_k<DD, KK>),                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, shm);                            \
+    (void)once;                                                                                                        \
+    hitadv::knn_feat_k<DD, KK><<<grid, 512, shm, s>>>(X, xx, N, K, idx);                                                \
+  } while (0)
   if (D == 64) {
-    if (K <= 8) hitadv::knn_feat_k<64, 8><<<grid, 256, 0, s>>>(X, xx, N, K, idx);
-    else hitadv::knn_feat_k<64, 20><<<grid, 256, 0, s>>>(X, xx, N, K, idx);
+    if (K <= 8) HITADV_KNN_FEAT(64, 8);
+    else HITADV_KNN_FEAT(64, 20);
   } else {
-    if (K <= 8) hitadv::knn_feat_k<128, 8><<<grid, 256, 0, s>>>(X, xx, N, K, idx);
-    else hitadv::knn_feat_k<128, 20><<<grid, 256, 0, s>>>(X, xx, N, K, idx);
+    if (K <= 8) HITADV_KNN_FEAT(128, 8);
+    else HITADV_KNN_FEAT(128, 20);
   }
+#undef HITADV_KNN_FEAT
   HITADV_LAUNCH_CHECK();
   return 0;
 }

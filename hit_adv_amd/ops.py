@@ -415,7 +415,7 @@ class EdgeMax(torch.autograd.Function):
         k = idx.shape[2]
         dout = dout.contiguous()
         dUV = torch.empty(B, N, 2 * C, device=out.device)
-        scratch = torch.empty(B * (N + 1 + N * k), device=out.device, dtype=torch.int32)
+        scratch = torch.empty(B * (2 * N + N * k), device=out.device, dtype=torch.int32)
         _lib.call("hitadv_edge_max_bwd", _p(dout), _p(out), _p(arg), _p(idx), B, N, C, k, ctypes.c_float(ctx.slope),
                   _p(dUV), ctypes.c_void_p(dUV.data_ptr() + 4 * C), 2 * C, _p(scratch), _stream())
         return dUV, None, None
