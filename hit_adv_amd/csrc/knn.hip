@@ -377,28 +377,35 @@ extern "C" int hitadv_knn_points_bwd(const float *q, const float *p, const void 
 //   block = 8 waves = 128 queries of one cloud; reference points stream through LDS 64 at a time (two 32-point tiles,
 //   double buffered, shared by the waves); waves w and w+4 hold the same 32 queries' features in registers as the MFMA
 //   B operand and take the even / odd tile, so the accumulator has the QUERY on the lane and 16 reference points in
-//   registers: a lane scans its 16 scores against its own list (KB entries, compile-time indices, no scratch).  Two
-//   waves per SIMD: one wave's selection (VALU) runs under the other's matrix instructions -- with one wave per SIMD
-//   the two phases alternated and the kernel took twice as long.  Each query is served by four lanes (two waves x the
-//   halves of a wave, disjoint reference rows); their lists are merged at the end.  Ties -> lower index.
+//   registers: a lane scans its 16 scores against its own list (KB entries, compile-time indices, no scratch).  Each
+//   query is served by four lanes (two waves x the halves of a wave, disjoint reference rows), so a list sees a quarter
+//   of the candidates; the four lists are merged at the end.  Ties -> lower index.
+//   Measured at B=32, N=1024, K=5 (tools/tune/knnfeat_tune.hip): D=64 74 us, of which 47 is the bare MFMA + staging loop
+//   and 27 the selection (VALU time adds to f32-MFMA time on this chip, see below); D=128 111 us (87 + 24).
 namespace hitadv {
 
 typedef float f32x16_k __attribute__((ext_vector_type(16)));
 
-// LDS floats of knn_feat_k: the double-buffered reference tiles (2 x 64 points) or, after the scan, the 4 x 128 lists
+#ifndef KF_SUB
+#define KF_SUB 2  // 32-point tiles per wave per step: a step stages KF_STEP = 64 * KF_SUB reference points
+#endif
+#define KF_STEP (64 * KF_SUB)
+// LDS floats of knn_feat_k: the double-buffered reference tiles (2 x KF_STEP points) or, after the scan, the 4 x 128 lists
 __host__ __device__ constexpr int knn_feat_main_floats(int D, int KB) {
-  return 2 * 64 * (D + 4) > 128 * 4 * KB * 2 ? 2 * 64 * (D + 4) : 128 * 4 * KB * 2;
+  return 2 * KF_STEP * (D + 4) > 128 * 4 * KB * 2 ? 2 * KF_STEP * (D + 4) : 128 * 4 * KB * 2;
 }
-__host__ __device__ constexpr int knn_feat_lds_bytes(int D, int KB) { return (knn_feat_main_floats(D, KB) + 2 * 64) * 4; }
+__host__ __device__ constexpr int knn_feat_lds_bytes(int D, int KB) {
+  return (knn_feat_main_floats(D, KB) + 2 * KF_STEP) * 4;
+}
 
 template <int D, int KB>
 __global__ __launch_bounds__(512) void knn_feat_k(const float *__restrict__ X, const float *__restrict__ xx, int N, int K,
                                                   int64_t *__restrict__ idx) {
   constexpr int LD = D + 4;
-  constexpr int ST = 64 * (D / 4) / 512;  // float4 staged per thread per 64-point step (D=64: 2, D=128: 4)
+  constexpr int ST = KF_STEP * (D / 4) / 512;  // float4 staged per thread per step
   extern __shared__ float4 knn_feat_sm[];  // knn_feat_lds_bytes<D,KB>(): max(reference tiles, final merge) + |x|^2
   float *sR = reinterpret_cast<float *>(knn_feat_sm);
-  float(*sXX)[64] = reinterpret_cast<float(*)[64]>(sR + knn_feat_main_floats(D, KB));
+  float(*sXX)[KF_STEP] = reinterpret_cast<float(*)[KF_STEP]>(sR + knn_feat_main_floats(D, KB));
   const int b = blockIdx.y, q0 = blockIdx.x * 128;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int qg = wave & 3, half = wave >> 2;  // query group; which tile of a step
@@ -418,7 +425,13 @@ __global__ __launch_bounds__(512) void knn_feat_k(const float *__restrict__ X, c
     lv[t] = -__builtin_inff();
     li[t] = 0x7fffffff;
   }
-  constexpr int BUF = 4;  // pending-candidate depth
+#ifndef KF_BUF
+#define KF_BUF 4
+#endif
+#ifndef KF_MODE
+#define KF_MODE 0  // tuning only (tools/tune/knnfeat_tune.hip): 1 = never flush, 2 = no selection at all
+#endif
+  constexpr int BUF = KF_BUF;  // pending-candidate depth
   float pv[BUF];
   int pj[BUF];
   int np = 0;
@@ -447,63 +460,78 @@ __global__ __launch_bounds__(512) void knn_feat_k(const float *__restrict__ X, c
       if (np > t) insert(pv[t], pj[t]);
     np = 0;
   };
-  const int ntiles = (N + 31) / 32, nsteps = (N + 63) / 64;
+  const int ntiles = (N + 31) / 32, nsteps = (N + KF_STEP - 1) / KF_STEP;
   float4 st[ST];
   float stx = 0.f;
   auto fetch = [&](int step) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
-      const int n = step * 64 + e / (D / 4);
+      const int n = step * KF_STEP + e / (D / 4);
       st[u] = n < N ? *reinterpret_cast<const float4 *>(X + (size_t)n * D + 4 * (e % (D / 4))) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (threadIdx.x < 64) stx = step * 64 + threadIdx.x < N ? xx[step * 64 + threadIdx.x] : __builtin_inff();
+    if (threadIdx.x < KF_STEP) stx = step * KF_STEP + threadIdx.x < N ? xx[step * KF_STEP + threadIdx.x] : __builtin_inff();
   };
   auto stash = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
-      *reinterpret_cast<float4 *>(sR + buf * 64 * LD + (e / (D / 4)) * LD + 4 * (e % (D / 4))) = st[u];
+      *reinterpret_cast<float4 *>(sR + buf * KF_STEP * LD + (e / (D / 4)) * LD + 4 * (e % (D / 4))) = st[u];
     }
-    if (threadIdx.x < 64) sXX[buf][threadIdx.x] = stx;
+    if (threadIdx.x < KF_STEP) sXX[buf][threadIdx.x] = stx;
   };
   fetch(0);
   stash(0);
   __syncthreads();
+  // f32 MFMAs and VALU instructions do not overlap on gfx950 (tools/tune/mfma_valu_overlap.hip: V fmas between two
+  // dependent MFMAs add their full 4 cycles each, at one and at two waves per SIMD), so the selection's VALU work is
+  // paid on top of the matrix time whatever the schedule; it simply follows the tile's products.
   for (int step = 0; step < nsteps; ++step) {
     const bool more = step + 1 < nsteps;
     if (more) fetch(step + 1);
-    const int tile = 2 * step + half;
-    if (tile < ntiles) {
-    const float *a = sR + (step & 1) * 64 * LD + (32 * half + r) * LD + 4 * h;
-    f32x16_k acc;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int sub = 0; sub < KF_SUB; ++sub) {
+      const int trow = 32 * (2 * sub + half);  // this wave's tile inside the step: waves w / w+4 alternate
+      const int tile = (KF_STEP / 32) * step + 2 * sub + half;
+      if (tile < ntiles) {
+        const float *a = sR + (step & 1) * KF_STEP * LD + (trow + r) * LD + 4 * h;
+        f32x16_k acc;
 #pragma unroll
-    for (int j = 0; j < D / 8; ++j) {
-      const float4 av = *reinterpret_cast<const float4 *>(a + 8 * j);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, qreg[4 * j], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, qreg[4 * j + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, qreg[4 * j + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qreg[4 * j + 3], acc, 0, 0, 0);
-    }
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {  // reference row of element e: (e&3) + 8*(e>>2) + 4*h, ascending in e
-      const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
-      const float s = (2.0f * acc[e] - qxx) - sXX[step & 1][32 * half + rr];  // -inf for rows past N
-      // accepted candidates are parked in a BUF-deep per-lane shift register; the sorted insert (executed by the whole
-      // wave whenever ANY lane needs it) runs once per BUF acceptances of the fastest-filling lane, not per score
-      const bool accept = s > lv[KB - 1];
+        for (int j = 0; j < D / 8; ++j) {
+          const float4 av = *reinterpret_cast<const float4 *>(a + 8 * j);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, qreg[4 * j], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, qreg[4 * j + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, qreg[4 * j + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qreg[4 * j + 3], acc, 0, 0, 0);
+        }
 #pragma unroll
-      for (int t = BUF - 1; t > 0; --t) {
-        pv[t] = accept ? pv[t - 1] : pv[t];
-        pj[t] = accept ? pj[t - 1] : pj[t];
+        for (int e = 0; e < 16; ++e) {  // reference row of element e: (e&3) + 8*(e>>2) + 4*h, ascending in e
+          const int rr = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float s = (2.0f * acc[e] - qxx) - sXX[step & 1][trow + rr];  // -inf for rows past N
+#if KF_MODE == 2
+          lv[0] = fmaxf(lv[0], s);
+#else
+          // accepted candidates are parked in a BUF-deep per-lane shift register; the sorted insert (executed by the
+          // whole wave whenever ANY lane needs it) runs once per BUF acceptances of the fastest-filling lane
+          const bool accept = s > lv[KB - 1];
+#pragma unroll
+          for (int t = BUF - 1; t > 0; --t) {
+            pv[t] = accept ? pv[t - 1] : pv[t];
+            pj[t] = accept ? pj[t - 1] : pj[t];
+          }
+          pv[0] = accept ? s : pv[0];
+          pj[0] = accept ? tile * 32 + rr : pj[0];
+          np += accept ? 1 : 0;
+#if KF_MODE == 0
+          if (__ballot(np == BUF)) flush();
+#else
+          np = np == BUF ? 0 : np;
+#endif
+#endif
+        }
       }
-      pv[0] = accept ? s : pv[0];
-      pj[0] = accept ? tile * 32 + rr : pj[0];
-      np += accept ? 1 : 0;
-      if (__ballot(np == BUF)) flush();
-    }
     }
     if (more) stash((step + 1) & 1);
     __syncthreads();
@@ -555,11 +583,14 @@ extern "C" int hitadv_knn_features(const float *X, const float *xx, int B, int N
     (void)once;                                                                                                        \
     hitadv::knn_feat_k<DD, KK><<<grid, 512, shm, s>>>(X, xx, N, K, idx);                                                \
   } while (0)
+  // list length = K rounded up to an instantiated size: a shorter list means a tighter threshold and a cheaper insert
   if (D == 64) {
-    if (K <= 8) HITADV_KNN_FEAT(64, 8);
+    if (K <= 5) HITADV_KNN_FEAT(64, 5);
+    else if (K <= 8) HITADV_KNN_FEAT(64, 8);
     else HITADV_KNN_FEAT(64, 20);
   } else {
-    if (K <= 8) HITADV_KNN_FEAT(128, 8);
+    if (K <= 5) HITADV_KNN_FEAT(128, 5);
+    else if (K <= 8) HITADV_KNN_FEAT(128, 8);
     else HITADV_KNN_FEAT(128, 20);
   }
 #undef HITADV_KNN_FEAT

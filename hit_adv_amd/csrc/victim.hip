@@ -240,26 +240,56 @@ __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     bv[cb] = -__builtin_inff();
-    bi[cb] = n0;
+    bi[cb] = -1;
   }
-  // accumulator element e of tile (rb, cb): row 32*rb + (e&3) + 8*(e>>2) + 4*h, column 32*cb + r
+  // accumulator element e of tile (rb, cb): row 32*rb + (e&3) + 8*(e>>2) + 4*h, column 32*cb + r.
+  // The scan costs matrix time (VALU instructions do not overlap f32 MFMAs on this chip, tools/tune/
+  // mfma_valu_overlap.hip), so it is three instructions per value: compare, keep the value, keep a wave-uniform CODE
+  // (tile, rb, e) of where it came from -- the point index is decoded from the code once, after the last tile.
+  // (a tile's 32 values are scanned into a tile-local best whose code rb*16+e is an inline constant; the tile number
+  // joins once per tile)
+  float tv[NCB];
+  int tc[NCB];
   auto update = [&](const f32x16 (&acc)[2][NCB], int tile, int rb, int e, bool ragged) {
-    const int n = n0 + tile * LF_TM + 4 * h + 32 * rb + (e & 3) + 8 * (e >> 2);
-    const bool live = !ragged || n < n1;  // rows past the split's end are zero-filled: keep them out
+    bool live = true;
+    if (ragged) live = n0 + tile * LF_TM + 4 * h + 32 * rb + (e & 3) + 8 * (e >> 2) < n1;  // zero-filled rows stay out
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       const float v = live ? acc[rb][cb][e] : -__builtin_inff();
-      const bool g = v > bv[cb];
-      bv[cb] = g ? v : bv[cb];
-      bi[cb] = g ? n : bi[cb];
+      if (rb == 0 && e == 0) {
+        tv[cb] = v;
+        tc[cb] = 0;
+      } else {
+        const bool g = v > tv[cb];
+        tv[cb] = g ? v : tv[cb];
+        tc[cb] = g ? rb * 16 + e : tc[cb];
+      }
+      if (rb == 1 && e == 15) {  // earlier tiles hold earlier points: they keep ties
+        const bool g = tv[cb] > bv[cb];
+        bv[cb] = g ? tv[cb] : bv[cb];
+        bi[cb] = g ? tile * 32 + tc[cb] : bi[cb];
+      }
+    }
+  };
+  auto decode = [&]() {  // code -> point index; nothing won (all rows -inf): the split's first point
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int c = bi[cb];
+      bi[cb] = c < 0 ? n0 : n0 + (c >> 5) * LF_TM + 4 * h + 32 * ((c >> 4) & 1) + (c & 3) + 8 * ((c & 15) >> 2);
     }
   };
   auto epilogue = [&](const f32x16 (&acc)[2][NCB], int tile) {
-    const bool ragged = n0 + (tile + 1) * LF_TM > n1;
+    if (n0 + (tile + 1) * LF_TM > n1) {  // wave-uniform: only a split's last tile can be ragged
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) update(acc, tile, rb, e, ragged);
+        for (int e = 0; e < 16; ++e) update(acc, tile, rb, e, true);
+    } else {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) update(acc, tile, rb, e, false);
+    }
   };
   // One tile of MFMAs into `cur`; the max / arg-max scan of the PREVIOUS tile's accumulators (`prev`, never ragged)
   // is spread between the MFMA groups so that the VALU work issues in the shadow of the matrix pipe.
@@ -272,10 +302,19 @@ __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__
       for (int j = 0; j < NCB; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) cur[i][j][e] = 0.f;
+    // the A operands of K group j+1 are read from LDS while the MFMAs of group j run: left to itself the compiler reuses
+    // one register set for every group and waits out an LDS round trip per eight MFMAs (20 % of the tile)
+    float4 pa0[2], pa1[2];
+    pa0[0] = *reinterpret_cast<const float4 *>(a);
+    pa1[0] = *reinterpret_cast<const float4 *>(a + 32 * LDA);
 #pragma unroll
     for (int j = 0; j < CIN / 8; ++j) {
-      const float4 a0 = *reinterpret_cast<const float4 *>(a + 8 * j);
-      const float4 a1 = *reinterpret_cast<const float4 *>(a + 32 * LDA + 8 * j);
+      if (j + 1 < CIN / 8) {
+        pa0[(j + 1) & 1] = *reinterpret_cast<const float4 *>(a + 8 * (j + 1));
+        pa1[(j + 1) & 1] = *reinterpret_cast<const float4 *>(a + 32 * LDA + 8 * (j + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads above this group's MFMAs
+      const float4 a0 = pa0[j & 1], a1 = pa1[j & 1];
       const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
       const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -344,6 +383,7 @@ __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__
     ++tile;
   }
   }
+  decode();
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {  // the other half of the wave holds the same column, other rows
     const float ov = __shfl_xor(bv[cb], 32, HITADV_WAVE);
