@@ -44,6 +44,44 @@ def linear_pm(conv, bn, x):
     return F.linear(x, W, b)
 
 
+class _LinearReLU(torch.autograd.Function):
+    """relu(x W^T + b) with the bias and the ReLU applied in the GEMM's epilogue (hipBLASLt through
+    ``torch._addmm_activation``, which has no autograd formula of its own): the separate activation pass over the
+    [points, Cout] tensor -- a read and a write as large as the GEMM's own output -- is gone."""
+
+    @staticmethod
+    def forward(ctx, x2, W, b):
+        y = torch._addmm_activation(b, x2, W.t(), use_gelu=False)
+        ctx.save_for_backward(x2, W, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, W, y = ctx.saved_tensors
+        gm = torch.ops.aten.threshold_backward(g.contiguous(), y, 0)
+        dx = gm @ W if ctx.needs_input_grad[0] else None
+        dW = gm.t() @ x2 if ctx.needs_input_grad[1] else None
+        db = gm.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dW, db
+
+
+WEIGHT_GRADS = False  # True: the fused layers also return gradients for the (eval-mode) parameters
+
+
+def linear_relu_pm(conv, bn, x):
+    """relu(bn(conv(.))) applied to points-major x [..., Cin] -> [..., Cout].  A custom autograd node cannot tell
+    whether a backward pass wants its weight gradient (``needs_input_grad`` only says the weights COULD receive one), so
+    the folded weights enter as constants unless ``WEIGHT_GRADS`` is set: an attack differentiates with respect to the
+    points, and the weight-gradient GEMM would cost as much as the input-gradient one."""
+    W, b = _folded(conv, bn)
+    if b is None or not x.is_cuda:
+        return F.relu(F.linear(x, W, b))
+    if not WEIGHT_GRADS:
+        W, b = W.detach(), b.detach()
+    y = _LinearReLU.apply(x.reshape(-1, x.shape[-1]), W, b)
+    return y.view(*x.shape[:-1], W.shape[0])
+
+
 def fast_pm(conv, bn, x):
     """Whether the points-major fast path applies (eval mode, CUDA)."""
     return _fast(conv, bn, x)

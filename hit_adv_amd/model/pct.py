@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..pytorch3d_ops import knn_points
-from ._pointwise import conv1x1, fast_pm, linear_pm
+from ._pointwise import conv1x1, fast_pm, linear_relu_pm
 from .pointnet2 import index_points
 
 
@@ -53,7 +53,7 @@ class Local_op(nn.Module):
     def forward(self, x):
         b, n, s, d = x.shape
         if fast_pm(self.conv1, self.bn1, x):  # x is already points-major: two GEMMs and a max over the neighbours
-            h = F.relu(linear_pm(self.conv2, self.bn2, F.relu(linear_pm(self.conv1, self.bn1, x))))
+            h = linear_relu_pm(self.conv2, self.bn2, linear_relu_pm(self.conv1, self.bn1, x))
             return h.max(dim=2)[0].permute(0, 2, 1)
         h = x.permute(0, 1, 3, 2).reshape(-1, d, s)
         h = F.relu(self.bn1(self.conv1(h)))

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ._pointwise import fast_pm, linear_pm
+from ._pointwise import fast_pm, linear_relu_pm
 
 
 def index_points(points, idx):
@@ -75,7 +75,7 @@ class PointNetSetAbstraction(nn.Module):
         if fast_pm(self.mlp_convs[0], self.mlp_bns[0], grouped):
             h = grouped  # [B,npoint,nsample,C+D] is already points-major: the shared MLP is a chain of GEMMs
             for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-                h = F.relu(linear_pm(conv, bn, h))
+                h = linear_relu_pm(conv, bn, h)
             return new_xyz.permute(0, 2, 1), h.max(dim=2)[0].permute(0, 2, 1)
         h = grouped.permute(0, 3, 2, 1)  # [B,C+D,nsample,npoint]
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
