@@ -33,14 +33,16 @@ def get_Laplace_from_pc(ori_pc, k=30):
     e, v = torch.linalg.eigh(L)
     return e.to(ori_pc), v.to(ori_pc)
 
+from ._victim import Victim
 
 class CWAOF:
     """Class for the AOF attack (constructor of CW/AOF.py:58-81)."""
 
     def __init__(self, model, adv_func, dist_func, attack_lr=1e-2, binary_step=2, num_iter=200, GAMMA=0.5,
-                 low_pass=100, clip_func=None, verbose=True):
+                 low_pass=100, clip_func=None, verbose=True, fast_victim=True):
         self.model = model.cuda()
         self.model.eval()
+        self._victim = Victim(self.model, fast_victim)
         self.adv_func = adv_func
         self.dist_func = dist_func  # stored, unused (as in the reference)
         self.attack_lr = attack_lr
@@ -52,8 +54,7 @@ class CWAOF:
         self.verbose = verbose
 
     def _logits(self, x):
-        out = self.model(x)
-        return out[0] if isinstance(out, tuple) else out
+        return self._victim(x)
 
     def _split(self, pc, V):
         coeff = torch.bmm(pc, V)
@@ -63,6 +64,7 @@ class CWAOF:
 
     def attack(self, data, target):
         """data [B,num_points,3|6], target [B] (true labels; untargeted) -> (float32 ndarray [B,num_points,3], successes)."""
+        self._victim.prepare()
         B, K = data.shape[:2]
         data = data.float().cuda().detach().transpose(1, 2).contiguous()
         if data.shape[1] == 6:

@@ -33,14 +33,16 @@ def get_critical_points(model, pc, label, num):
             idx = torch.sort(score, dim=-1, descending=True, stable=True).indices[:, :num]
         return torch.gather(pc.to(idx.device), 2, idx.unsqueeze(1).expand(-1, pc.shape[1], -1)).clone().detach()
 
+from ._victim import Victim
 
 class CWAdd:
     """Class for CW attack (adding points)."""
 
     def __init__(self, model, adv_func, dist_func, attack_lr=1e-2, init_weight=5e3, max_weight=4e4, binary_step=10,
-                 num_iter=500, num_add=512, verbose=True):
+                 num_iter=500, num_add=512, verbose=True, fast_victim=True):
         self.model = model.cuda()
         self.model.eval()
+        self._victim = Victim(self.model, fast_victim)
         self.adv_func = adv_func
         self.dist_func = dist_func
         self.attack_lr = attack_lr
@@ -52,8 +54,7 @@ class CWAdd:
         self.verbose = verbose
 
     def _logits(self, x):
-        out = self.model(x)
-        return out[0] if isinstance(out, tuple) else out
+        return self._victim(x)
 
     def _init_points(self, ori, target):
         """[B,3,n_add] starting positions of the added points (overridden by the cluster / object variants)."""
@@ -65,6 +66,7 @@ class CWAdd:
 
     def attack(self, data, target):
         """data [B,num_points,3], target [B] -> (o_bestdist float64 [B], float64 [B,num_points+n_add,3], successes)."""
+        self._victim.prepare()
         B, K = data.shape[:2]
         ori = data.float().cuda().detach().transpose(1, 2).contiguous()
         target = target.long().cuda().detach()

@@ -18,14 +18,16 @@ def normalize_points_np(points):
     assert np.sum(np.isnan(points)) == 0
     return points
 
+from ._victim import Victim
 
 class CWAddObjects:
     """Class for CW attack (adding objects)."""
 
     def __init__(self, model, adv_func, dist_func, object_pc, attack_lr=1e-2, init_weight=5., max_weight=40.,
-                 binary_step=5, num_iter=500, num_add=3, obj_num_p=64, scaling=0.3, verbose=True):
+                 binary_step=5, num_iter=500, num_add=3, obj_num_p=64, scaling=0.3, verbose=True, fast_victim=True):
         self.model = model.cuda()
         self.model.eval()
+        self._victim = Victim(self.model, fast_victim)
         self.adv_func = adv_func
         self.dist_func = dist_func
         self.attack_lr = attack_lr
@@ -46,8 +48,7 @@ class CWAddObjects:
         return normalize_points_np(pc) * scaling
 
     def _logits(self, x):
-        out = self.model(x)
-        return out[0] if isinstance(out, tuple) else out
+        return self._victim(x)
 
     def _init_centers(self, pc, label):
         """pc [B,3,K] -> np.ndarray [B,num_add,3]: the surface point closest to the mean of each of the largest DBSCAN
@@ -83,6 +84,7 @@ class CWAddObjects:
 
     def attack(self, data, target):
         """data [B,num_points,3], target [B] -> (o_bestdist float64 [B], float64 [B,num_points+num_add*obj_num_p,3], successes)."""
+        self._victim.prepare()
         B, K = data.shape[:2]
         ori = data.float().cuda().detach().transpose(1, 2).contiguous()
         target = target.long().cuda().detach()

@@ -9,14 +9,16 @@ Device-resident restatement: the per-iteration ``.cpu().numpy()`` copies and the
 import torch
 import torch.optim as optim
 
+from ._victim import Victim
 
 class CWPerturb:
     """Class for CW attack."""
 
     def __init__(self, model, adv_func, dist_func, attack_lr=1e-2, init_weight=10., max_weight=80.,
-                 binary_step=10, num_iter=500, pre_head=None, clip_func=None, verbose=True):
+                 binary_step=10, num_iter=500, pre_head=None, clip_func=None, verbose=True, fast_victim=True):
         self.model = model.cuda()
         self.model.eval()
+        self._victim = Victim(self.model, fast_victim)
         self.adv_func = adv_func
         self.dist_func = dist_func
         self.attack_lr = attack_lr
@@ -29,12 +31,12 @@ class CWPerturb:
         self.verbose = verbose
 
     def _logits(self, x):
-        out = self.model(self.pre_head(x)) if self.pre_head is not None else self.model(x)
-        return out[0] if isinstance(out, tuple) else out
+        return self._victim(self.pre_head(x) if self.pre_head is not None else x)
 
     def attack(self, data, target, _channel_first=False):
         """data [B,num_points,3 or 6] (or channel-first [B,3|6,num_points>6]), target [B]
         -> (float64 ndarray [B,num_points,3], number of samples with a successful step)."""
+        self._victim.prepare()
         B, K = data.shape[:2]
         data = data.float().cuda().detach()
         if _channel_first:  # CWPerturbT hands over [B,3,num_points] (PerturbT.py:53)

@@ -16,6 +16,7 @@ import torch.optim as optim
 
 from .AOF import get_Laplace_from_pc
 
+from ._victim import Victim
 
 class _CWFamily:
     spectral = False
@@ -28,6 +29,7 @@ class _CWFamily:
                ae_model=None, low_pass=None):
         self.model = model.cuda()
         self.model.eval()
+        self._victim = Victim(self.model, getattr(self, 'fast_victim', True))
         self.ae_model = None
         if ae_model is not None:
             self.ae_model = ae_model.cuda()
@@ -43,8 +45,7 @@ class _CWFamily:
         self.verbose = verbose
 
     def _logits(self, x):
-        out = self.model(x)
-        return out[0] if isinstance(out, tuple) else out
+        return self._victim(x)
 
     def _split(self, pc, V):
         coeff = torch.bmm(pc, V)
@@ -73,6 +74,7 @@ class _CWFamily:
         return ok & ((other != target) | (self.GAMMA < 0.001))
 
     def _run(self, data, target, y_truth=None):
+        self._victim.prepare()
         B, K = data.shape[:2]
         ori = data.float().cuda().detach().transpose(1, 2).contiguous()
         target = target.long().cuda().detach()

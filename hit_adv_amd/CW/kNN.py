@@ -7,13 +7,16 @@ backwards -- then ``clip_func``.  Success is ``pred == target`` (targeted attack
 import torch
 import torch.optim as optim
 
+from ._victim import Victim
 
 class CWKNN:
     """Class for CW attack (constructor of CW/kNN.py:18-38)."""
 
-    def __init__(self, model, adv_func, dist_func, clip_func, attack_lr=1e-3, num_iter=2500, verbose=True):
+    def __init__(self, model, adv_func, dist_func, clip_func, attack_lr=1e-3, num_iter=2500, verbose=True,
+                 fast_victim=True):
         self.model = model.cuda()
         self.model.eval()
+        self._victim = Victim(self.model, fast_victim)
         self.adv_func = adv_func
         self.dist_func = dist_func
         self.clip_func = clip_func
@@ -22,14 +25,14 @@ class CWKNN:
         self.verbose = verbose
 
     def _logits(self, x):
-        out = self.model(x)
-        return out[0] if isinstance(out, tuple) else out
+        return self._victim(x)
 
     def _clip(self, adv, ori, normal):
         return self.clip_func(adv, ori)
 
     def attack(self, data, target):
         """data [B,num_points,3 or 6], target [B] -> (float32 ndarray [B,num_points,3], success count)."""
+        self._victim.prepare()
         B, K = data.shape[:2]
         pc = data.float().cuda().detach().transpose(1, 2).contiguous()
         normal = None if pc.shape[1] == 3 else pc[:, 3:, :]
