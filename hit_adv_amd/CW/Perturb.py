@@ -4,18 +4,23 @@ weight, Adam on the xyz of every point, best-result tracking.  Success means ``p
 is written for targeted attacks, :107,134,141,178).
 
 Device-resident restatement: the per-iteration ``.cpu().numpy()`` copies and the Python loop over samples
-(:127-145) become a few [B]-sized tensor ops; the bisection keeps the reference's float64 bounds.
+(:127-145) become a few [B]-sized tensor ops on fixed buffers; the bisection keeps the reference's float64 bounds.  One
+iteration -- victim forward / backward, losses, Adam, clip, best tracking -- is captured into a hipGraph and replayed
+``binary_step x num_iter`` times when nothing in it needs the host (util/graph_loop.py).
 """
 import torch
-import torch.optim as optim
 
+from .. import ops
+from ..util.graph_loop import IterationGraph
 from ._victim import Victim
+
 
 class CWPerturb:
     """Class for CW attack."""
 
     def __init__(self, model, adv_func, dist_func, attack_lr=1e-2, init_weight=10., max_weight=80.,
-                 binary_step=10, num_iter=500, pre_head=None, clip_func=None, verbose=True, fast_victim=True):
+                 binary_step=10, num_iter=500, pre_head=None, clip_func=None, verbose=True, fast_victim=True,
+                 use_graph='auto'):
         self.model = model.cuda()
         self.model.eval()
         self._victim = Victim(self.model, fast_victim)
@@ -29,6 +34,8 @@ class CWPerturb:
         self.clip_func = clip_func
         self.pre_head = pre_head
         self.verbose = verbose
+        self.use_graph = use_graph  # 'auto': replay one captured iteration when the victim and the losses allow it
+        self.last_graph_used = False
 
     def _logits(self, x):
         return self._victim(self.pre_head(x) if self.pre_head is not None else x)
@@ -52,48 +59,86 @@ class CWPerturb:
         f64 = dict(device=dev, dtype=torch.float64)
         lower = torch.zeros(B, **f64)
         upper = torch.full((B,), float(self.max_weight), **f64)
+        # state of the loop: fixed addresses (updated in place), so that one iteration can be captured and replayed
         weight = torch.full((B,), float(self.init_weight), **f64)
         o_bestdist = torch.full((B,), 1e10, **f64)
         o_bestscore = torch.full((B,), -1, device=dev, dtype=torch.int64)
         o_bestattack = torch.zeros(B, 3, K, device=dev)
-        report_every = max(1, self.num_iter // 5)
-        last_input = ori
-        for binary_step in range(self.binary_step):
-            adv = (ori.clone() + torch.randn((B, 3, K)).cuda() * 1e-7).requires_grad_()
-            bestdist = torch.full((B,), 1e10, **f64)
-            bestscore = torch.full((B,), -1, device=dev, dtype=torch.int64)
-            opt = optim.Adam([adv], lr=self.attack_lr, weight_decay=0.)
-            adv_loss = torch.zeros((), device=dev)
-            dist_loss = torch.zeros((), device=dev)
-            for iteration in range(self.num_iter):
-                logits = self._logits(adv)
-                pred = logits.argmax(dim=1)
-                if self.verbose and iteration % report_every == 0:
-                    print('Step {}, iteration {}, success {}/{}\nadv_loss: {:.4f}, dist_loss: {:.4f}'.format(
-                        binary_step, iteration, (pred == target).sum().item(), B, adv_loss.item(), dist_loss.item()))
-                with torch.no_grad():
-                    last_input = adv.detach().clone()  # what the reference calls input_val (:125)
-                    dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2])).double()
-                    hit = pred == target
-                    better = hit & (dist_val < bestdist)
-                    bestdist = torch.where(better, dist_val, bestdist)
-                    bestscore = torch.where(better, pred, bestscore)
-                    o_better = hit & (dist_val < o_bestdist)
-                    o_bestdist = torch.where(o_better, dist_val, o_bestdist)
-                    o_bestscore = torch.where(o_better, pred, o_bestscore)
-                    o_bestattack = torch.where(o_better[:, None, None], adv.detach(), o_bestattack)
-                adv_loss = self.adv_func(logits, target).mean()
-                dist_loss = self.dist_func(adv, ori, weight).mean()
-                opt.zero_grad()
-                (adv_loss + dist_loss).backward()
-                opt.step()
+        bestdist = torch.full((B,), 1e10, **f64)
+        bestscore = torch.full((B,), -1, device=dev, dtype=torch.int64)
+        last_input = ori.clone()
+        adv = ori.clone().requires_grad_()
+        m, v = torch.zeros_like(ori), torch.zeros_like(ori)
+        step = torch.zeros(1, device=dev, dtype=torch.int32)
+        adv_loss, dist_loss = torch.zeros((), device=dev), torch.zeros((), device=dev)
+        hits = torch.zeros((), device=dev, dtype=torch.int64)
+
+        def iteration():
+            logits = self._logits(adv)
+            pred = logits.argmax(dim=1)
+            with torch.no_grad():
+                last_input.copy_(adv)  # what the reference calls input_val (:125)
+                dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2])).double()
+                hit = pred == target
+                hits.copy_(hit.sum())
+                better = hit & (dist_val < bestdist)
+                bestdist.copy_(torch.where(better, dist_val, bestdist))
+                bestscore.copy_(torch.where(better, pred, bestscore))
+                o_better = hit & (dist_val < o_bestdist)
+                o_bestdist.copy_(torch.where(o_better, dist_val, o_bestdist))
+                o_bestscore.copy_(torch.where(o_better, pred, o_bestscore))
+                o_bestattack.copy_(torch.where(o_better[:, None, None], adv, o_bestattack))
+            a = self.adv_func(logits, target).mean()
+            d = self.dist_func(adv, ori, weight).mean()
+            g, = torch.autograd.grad(a + d, adv)
+            with torch.no_grad():
+                adv_loss.copy_(a)
+                dist_loss.copy_(d)
+                ops.adam_single(adv, g, m, v, step, self.attack_lr)  # torch.optim.Adam's update (:119, defaults)
                 if self.clip_func is not None:
-                    adv.data = self.clip_func(adv.clone().detach(), ori)
+                    adv.copy_(self.clip_func(adv.clone(), ori))
+
+        def start_step(init):
+            with torch.no_grad():
+                adv.copy_(init)
+                m.zero_()
+                v.zero_()
+                step.zero_()
+                bestdist.fill_(1e10)
+                bestscore.fill_(-1)
+
+        def start_search():
+            with torch.no_grad():
+                weight.fill_(float(self.init_weight))
+                o_bestdist.fill_(1e10)
+                o_bestscore.fill_(-1)
+                o_bestattack.zero_()
+                last_input.copy_(ori)
+
+        total = self.binary_step * self.num_iter
+        loop = IterationGraph(iteration, self.use_graph if total >= 16 else False, 'the CW perturbation iteration')
+        if loop.probe():
+            start_search()
+            start_step(ori)
+            loop.capture()
+        start_search()
+        report_every = max(1, self.num_iter // 5)
+        for binary_step in range(self.binary_step):
+            start_step(ori.clone() + torch.randn((B, 3, K)).cuda() * 1e-7)
+            loop.enter()
+            for it in range(self.num_iter):
+                loop.step()
+                if self.verbose and it % report_every == 0:
+                    print('Step {}, iteration {}, success {}/{}\nadv_loss: {:.4f}, dist_loss: {:.4f}'.format(
+                        binary_step, it, hits.item(), B, adv_loss.item(), dist_loss.item()))
+            loop.leave_step()
             with torch.no_grad():  # bisection, :172-184
                 ok = (bestscore == target) & (bestscore != -1) & (bestdist <= o_bestdist)
                 lower = torch.where(ok, torch.maximum(lower, weight), lower)
                 upper = torch.where(ok, upper, torch.minimum(upper, weight))
-                weight = (lower + upper) / 2.
+                weight.copy_((lower + upper) / 2.)
+        loop.leave()
+        self.last_graph_used = loop.reason is None
         with torch.no_grad():
             fail = lower == 0.
             # failures get input_val, i.e. the iterate that ENTERED the last iteration (:189-193)

@@ -1,19 +1,22 @@
 """kNN attack (AAAI'20 "Robust Adversarial Objects"), interface of the reference's CW/kNN.py::CWKNN.
 
-Every iteration runs the victim forward/backward on PyTorch-ROCm plus ``dist_func`` -- normally
-ChamferkNNDist, i.e. the fused Chamfer NN-min kernel and the top-(k+1) kNN kernel with their HIP
-backwards -- then ``clip_func``.  Success is ``pred == target`` (targeted attack, CW/kNN.py:86,146).
+Every iteration runs the victim forward/backward plus ``dist_func`` -- normally ChamferkNNDist, i.e. the fused Chamfer
+NN-min kernel and the top-(k+1) kNN kernel with their HIP backwards -- then Adam and ``clip_func``; the iteration works
+on fixed buffers and is replayed as one hipGraph when nothing in it needs the host (util/graph_loop.py).  Success is
+``pred == target`` (targeted attack, CW/kNN.py:86,146).
 """
 import torch
-import torch.optim as optim
 
+from .. import ops
+from ..util.graph_loop import IterationGraph
 from ._victim import Victim
+
 
 class CWKNN:
     """Class for CW attack (constructor of CW/kNN.py:18-38)."""
 
     def __init__(self, model, adv_func, dist_func, clip_func, attack_lr=1e-3, num_iter=2500, verbose=True,
-                 fast_victim=True):
+                 fast_victim=True, use_graph='auto'):
         self.model = model.cuda()
         self.model.eval()
         self._victim = Victim(self.model, fast_victim)
@@ -23,6 +26,8 @@ class CWKNN:
         self.attack_lr = attack_lr
         self.num_iter = num_iter
         self.verbose = verbose
+        self.use_graph = use_graph  # 'auto': replay one captured iteration when the victim and the losses allow it
+        self.last_graph_used = False
 
     def _logits(self, x):
         return self._victim(x)
@@ -35,29 +40,54 @@ class CWKNN:
         self._victim.prepare()
         B, K = data.shape[:2]
         pc = data.float().cuda().detach().transpose(1, 2).contiguous()
-        normal = None if pc.shape[1] == 3 else pc[:, 3:, :]
+        normal = None if pc.shape[1] == 3 else pc[:, 3:, :].contiguous()
         ori = pc[:, :3, :].contiguous().clone().detach()
         target = target.long().cuda().detach()
-        # the reference draws the jitter on the CPU generator and moves it over (:64-65)
-        adv = (ori.clone() + torch.randn((B, 3, K)).cuda() * 1e-7).requires_grad_()
-        opt = optim.Adam([adv], lr=self.attack_lr, weight_decay=0.)
         ori_pts = ori.transpose(1, 2).contiguous()
-        adv_loss = torch.zeros((), device=ori.device)
-        dist_loss = torch.zeros((), device=ori.device)
-        report_every = max(1, self.num_iter // 5)
-        for iteration in range(self.num_iter):
+        dev = ori.device
+        # the reference draws the jitter on the CPU generator and moves it over (:64-65)
+        start = (ori.clone() + torch.randn((B, 3, K)).cuda() * 1e-7)
+        # state of the loop: fixed addresses, so that one iteration can be captured and replayed
+        adv = start.clone().requires_grad_()
+        m, v = torch.zeros_like(start), torch.zeros_like(start)
+        step = torch.zeros(1, device=dev, dtype=torch.int32)
+        adv_loss, dist_loss = torch.zeros((), device=dev), torch.zeros((), device=dev)
+        hits = torch.zeros((), device=dev, dtype=torch.int64)
+
+        def iteration():
             logits = self._logits(adv)
-            if self.verbose and iteration % report_every == 0:
-                hit = (logits.argmax(dim=1) == target).sum().item()
+            a = self.adv_func(logits, target).mean()
+            d = self.dist_func(adv.transpose(1, 2).contiguous(), ori_pts).mean() * K
+            g, = torch.autograd.grad(a + d, adv)
+            with torch.no_grad():
+                hits.copy_((logits.argmax(dim=1) == target).sum())
+                adv_loss.copy_(a)
+                dist_loss.copy_(d)
+                ops.adam_single(adv, g, m, v, step, self.attack_lr)  # torch.optim.Adam's update (:74, defaults)
+                if self.clip_func is not None:
+                    adv.copy_(self._clip(adv.clone(), ori, normal))
+
+        def reset():
+            with torch.no_grad():
+                adv.copy_(start)
+                m.zero_()
+                v.zero_()
+                step.zero_()
+
+        loop = IterationGraph(iteration, self.use_graph if self.num_iter >= 16 else False, 'the kNN attack iteration')
+        if loop.probe():
+            reset()
+            loop.capture()
+        reset()
+        loop.enter()
+        report_every = max(1, self.num_iter // 5)
+        for it in range(self.num_iter):
+            loop.step()
+            if self.verbose and it % report_every == 0:
                 print('Iteration {}/{}, success {}/{}\nadv_loss: {:.4f}, dist_loss: {:.4f}'.format(
-                    iteration, self.num_iter, hit, B, adv_loss.item(), dist_loss.item()))
-            adv_loss = self.adv_func(logits, target).mean()
-            dist_loss = self.dist_func(adv.transpose(1, 2).contiguous(), ori_pts).mean() * K
-            opt.zero_grad()
-            (adv_loss + dist_loss).backward()
-            opt.step()
-            if self.clip_func is not None:
-                adv.data = self._clip(adv.clone().detach(), ori, normal)
+                    it, self.num_iter, hits.item(), B, adv_loss.item(), dist_loss.item()))
+        loop.leave()
+        self.last_graph_used = loop.reason is None
         with torch.no_grad():
             success_num = (self._logits(adv).argmax(dim=-1) == target).sum().item()
         if self.verbose:

@@ -294,6 +294,14 @@ def adam_step(perturb, sigma, g_perturb, g_sigma, m_p, v_p, m_s, v_s, step, lr_p
               ctypes.c_float(lr_s), _p(step), _stream())
 
 
+def adam_single(p, g, m, v, step, lr):
+    """torch.optim.Adam's default update (betas 0.9/0.999, eps 1e-8, no weight decay) of ONE tensor in place; ``step`` is a
+    device int32[1] that counts the updates."""
+    g = g.contiguous()
+    _lib.call("hitadv_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), ctypes.c_float(lr), None, None, None, None, 0,
+              ctypes.c_float(0.), _p(step), _stream())
+
+
 # --------------------------------------------------------------------------- FPS
 def fps_from_start(xyz, npoint, start):
     """xyz[B,N,3], start[B] int64 -> idx[B,npoint] int64 (ShapeAttack/HiT_ADV.py:489-510 semantics)."""

@@ -11,9 +11,8 @@ from .set_distance import chamfer, hausdorff
 
 
 def _apply_weights(loss, weights, batch_avg):
-    if weights is None:
-        weights = torch.ones(loss.shape[0])
-    loss = loss * weights.float().to(loss.device)
+    if weights is not None:  # None = all ones (the reference multiplies by torch.ones, dist_utils.py:33-35): x * 1 == x,
+        loss = loss * weights.float().to(loss.device)  # and leaving it out keeps a host->device copy out of the loop
     return loss.mean() if batch_avg else loss
 
 

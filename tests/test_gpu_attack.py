@@ -364,7 +364,8 @@ def test_cwperturb_follows_reference_trajectory():
         return out
 
     att = CWPerturb(toy_from_fixture(fx), LogitsAdvLoss(kappa=5.), L2Dist(), attack_lr=1e-2, init_weight=10.,
-                    max_weight=80., binary_step=3, num_iter=10, clip_func=recording_clip, verbose=False)
+                    max_weight=80., binary_step=3, num_iter=10, clip_func=recording_clip, verbose=False,
+                    use_graph=False)  # the recording hook reads every iterate back: a host round trip per iteration
     torch.manual_seed(int(fx['seed']))
     best, succ = att.attack(T(fx['data']), T(fx['target']))
     assert len(trace) == 30 and best.dtype == np.float64 and best.shape == fx['best'].shape
@@ -732,13 +733,71 @@ def test_cwperturbt_follows_reference_trajectory():
     fx = golden('g14_cwperturbt.npz')
     trace = []
     att = CWPerturbT(toy_from_fixture(fx), LogitsAdvLoss(kappa=0.), L2Dist(), attack_lr=3e-2, init_weight=10.,
-                     max_weight=80., binary_step=3, num_iter=10, clip_func=_recording(0.3, trace), verbose=False)
+                     max_weight=80., binary_step=3, num_iter=10, clip_func=_recording(0.3, trace), verbose=False,
+                     use_graph=False)
     torch.manual_seed(int(fx['seed']))
     best, succ = att.attack(T(fx['data']), T(fx['target']))
+    assert len(trace) == 30
     for i in range(30):
         np.testing.assert_allclose(trace[i], fx['adv_trace'][i], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(best, fx['best'], rtol=1e-4, atol=2e-5)
     assert succ == int(fx['success_num']) and best.dtype == np.float64
+
+
+@pytest.mark.parametrize("victim", ["pointnet", "dgcnn"])
+def test_cw_attacks_replayed_as_graphs_equal_the_eager_loops(victim):
+    """CWKNN / CWUKNN / CWPerturb with a real victim (through its attack view): the captured-and-replayed iteration gives
+    the result of the eager loop (same kernels, same order: equal to the last bit for PointNet and DGCNN, whose views
+    are reproducible), the capture really happens, and a body that needs the host falls back to the eager loop."""
+    import argparse
+    from hit_adv_amd.CW import CWKNN, CWPerturb, CWUKNN
+    from hit_adv_amd.util.adv_utils import LogitsAdvLoss, UntargetedLogitsAdvLoss
+    from hit_adv_amd.util.clip_utils import ClipPointsLinf, ProjectInnerClipLinf
+    from hit_adv_amd.util.dist_utils import ChamferkNNDist, L2Dist
+    torch.manual_seed(3)
+    if victim == "pointnet":
+        from hit_adv_amd.model.pointnet import PointNetFeatureModel
+        model = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    else:
+        from hit_adv_amd.model.dgcnn import DGCNN_cls
+        model = DGCNN_cls(argparse.Namespace(k=5, emb_dims=1024, dropout=0.2), output_channels=40).cuda().eval()
+    data, _ = synth_batch(4, 512, first=900)
+    with torch.no_grad():
+        out = model(data[:, :, :3].transpose(1, 2).contiguous().cuda())
+        label = (out[0] if isinstance(out, tuple) else out).argmax(1).cpu()
+    target = (label + 1) % 40
+    cases = [
+        (lambda g: CWPerturb(model, LogitsAdvLoss(kappa=5.), L2Dist(), attack_lr=1e-2, binary_step=2, num_iter=12,
+                             clip_func=ClipPointsLinf(budget=0.18), verbose=False, use_graph=g), data[:, :, :3], target),
+        (lambda g: CWKNN(model, LogitsAdvLoss(kappa=5.), ChamferkNNDist(), ClipPointsLinf(budget=0.18), attack_lr=1e-2,
+                         num_iter=20, verbose=False, use_graph=g), data[:, :, :3], target),
+        (lambda g: CWUKNN(model, UntargetedLogitsAdvLoss(kappa=5.), ChamferkNNDist(), ProjectInnerClipLinf(budget=0.18),
+                          attack_lr=1e-2, num_iter=20, verbose=False, use_graph=g), data, label),
+    ]
+    kept = []
+    for make, x, y in cases:
+        results = []
+        for graph in (True, False):
+            att = make(graph)
+            torch.manual_seed(11)
+            results.append(att.attack(x, y))
+            assert att.last_graph_used == graph
+        np.testing.assert_array_equal(results[0][0], results[1][0])
+        assert results[0][1] == results[1][1]
+        kept.append(results[1])
+    # a body with a host round trip: 'auto' notices in the probe and runs the eager loop; the probe's two extra passes
+    # leave neither the random draws nor the result changed
+    seen = []
+
+    def peeking_clip(pc, ori):
+        seen.append(float(pc.abs().max().item()))
+        return ClipPointsLinf(budget=0.18)(pc, ori)
+    att = CWKNN(model, LogitsAdvLoss(kappa=5.), ChamferkNNDist(), peeking_clip, attack_lr=1e-2, num_iter=20, verbose=False)
+    torch.manual_seed(11)
+    peeked = att.attack(data[:, :, :3], target)
+    assert not att.last_graph_used and len(seen) >= 20
+    np.testing.assert_array_equal(peeked[0], kept[1][0])
+    assert peeked[1] == kept[1][1]
 
 
 @pytest.mark.parametrize("name,cls,ae,targeted,spectral", [

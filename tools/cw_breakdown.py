@@ -17,16 +17,19 @@ from helpers import synth_batch  # noqa: E402
 from victim_breakdown import build  # noqa: E402
 
 
+ITERS = 300
+
+
 def attacks(model):
     from hit_adv_amd.CW import CWAOF, CWKNN, CWPerturb
     from hit_adv_amd.util.adv_utils import LogitsAdvLoss
     from hit_adv_amd.util.clip_utils import ProjectInnerClipLinf
     from hit_adv_amd.util.dist_utils import ChamferkNNDist, L2Dist
     adv = LogitsAdvLoss(kappa=30.)
-    yield 'CWPerturb', 40, CWPerturb(model, adv, L2Dist(), attack_lr=1e-2, binary_step=1, num_iter=40, verbose=False)
-    yield 'CWKNN', 40, CWKNN(model, adv, ChamferkNNDist(), ProjectInnerClipLinf(budget=0.18), attack_lr=1e-3, num_iter=40,
+    yield 'CWPerturb', ITERS, CWPerturb(model, adv, L2Dist(), attack_lr=1e-2, binary_step=1, num_iter=ITERS, verbose=False)
+    yield 'CWKNN', ITERS, CWKNN(model, adv, ChamferkNNDist(), ProjectInnerClipLinf(budget=0.18), attack_lr=1e-3, num_iter=ITERS,
                              verbose=False)
-    yield 'CWAOF', 40, CWAOF(model, adv, L2Dist(), attack_lr=1e-2, binary_step=1, num_iter=40, clip_func=ProjectInnerClipLinf(budget=0.18),
+    yield 'CWAOF', ITERS, CWAOF(model, adv, L2Dist(), attack_lr=1e-2, binary_step=1, num_iter=ITERS, clip_func=ProjectInnerClipLinf(budget=0.18),
                              verbose=False)
 
 
@@ -49,7 +52,8 @@ def main():
                     t0 = time.perf_counter()
                     att.attack(data, target)
                     torch.cuda.synchronize()
-                    out['%s/%s' % (name, label)] = round((time.perf_counter() - t0) / iters * 1e3, 3)
+                    out['%s/%s' % (name, label)] = [round((time.perf_counter() - t0) / iters * 1e3, 3),
+                                                    'graph' if getattr(att, 'last_graph_used', False) else 'eager']
                 except Exception as e:  # noqa: BLE001
                     out['%s/%s' % (name, label)] = 'failed: %s' % (str(e)[:80],)
     print(json.dumps(out))
