@@ -56,6 +56,9 @@ PROTOTYPES = {
     "hitadv_edge_max_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "hitadv_edge_max_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P],
     "hitadv_edge_max_bwd_scratch_ints": [_I, _I, _I],
+    "hitadv_group_add_relu_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "hitadv_group_add_relu_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "hitadv_group_add_relu_bwd_scratch_ints": [_I, _I, _I, _I],
     "hitadv_lrelu_pool_fwd": [_P, _I, _I, _I, _F, _P, _P, _P],
     "hitadv_lrelu_pool_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "hitadv_fc_layer": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
@@ -63,7 +66,7 @@ PROTOTYPES = {
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,
             "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_linear_max_fwd_scratch": _c.c_int64, "hitadv_pointnet_rowmlp_tiles": _c.c_int64, "hitadv_fc_layer_scratch_floats": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64,
-            "hitadv_edge_max_bwd_scratch_ints": _c.c_int64}
+            "hitadv_edge_max_bwd_scratch_ints": _c.c_int64, "hitadv_group_add_relu_bwd_scratch_ints": _c.c_int64}
 
 _lib = None
 

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void edge_max_fwd_k(const float *__restrict__ 
 // neighbour table is turned around first (who lists j?), and every (j, c) then GATHERS its terms in ascending i:
 // same bits every run, no zero-fill, no atomics on floats.
 //
-// reverse_graph_k: a block owns J consecutive target points j of one cloud.  It walks the cloud's N*k edges once: edges
+// reverse_graph_k (S neighbour lists of k entries pointing at N targets; S == N for EdgeConv): a block owns J
+// consecutive target points j of one cloud.  It walks the cloud's S*k edges once: edges
 // into its range set bit i of row j in an LDS bit matrix and bump j's edge count (integer LDS atomics: order-free);
 // edges into LOWER ranges are only counted -- that count is where this block's share of the list array begins, so no
 // block waits for another.  A row's set bits, read in ascending order, are the in-list.  A neighbour list that repeats
@@ -278,15 +279,16 @@ __global__ __launch_bounds__(256) void edge_max_fwd_k(const float *__restrict__ 
 #define RG_THREADS 256
 #define RG_BITMAP_WORDS 15360  // 60 KB: two blocks per CU
 
-__global__ __launch_bounds__(RG_THREADS) void reverse_graph_k(const int64_t *__restrict__ idx, int N, int k, int W, int J,
-                                                              int2 *__restrict__ span, int32_t *__restrict__ col) {
+__global__ __launch_bounds__(RG_THREADS) void reverse_graph_k(const int64_t *__restrict__ idx, int S, int N, int k, int W,
+                                                              int J, int2 *__restrict__ span,
+                                                              int32_t *__restrict__ col) {  // S lists -> N targets
   extern __shared__ uint32_t rg_sm[];
   uint32_t *bm = rg_sm;                               // J rows of W words (+1 pad: a thread per row walks its words)
   int32_t *cnt = (int32_t *)(rg_sm + RG_BITMAP_WORDS);  // J edge counts, then their exclusive prefix
   int32_t *red = cnt + RG_THREADS;                    // block reduction / scan workspace (2 x RG_THREADS)
   const int b = blockIdx.y, tid = threadIdx.x;
   const int j0 = blockIdx.x * J, rows = min(J, N - j0);
-  const int E = N * k, RS = W + 1;
+  const int E = S * k, RS = W + 1;
   const int64_t *nb = idx + (size_t)b * E;
   for (int w = tid; w < rows * RS; w += RG_THREADS) bm[w] = 0u;
   cnt[tid] = 0;
@@ -496,6 +498,150 @@ extern "C" int hitadv_lrelu_pool_bwd(const float *Z, const float *g, const int32
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// First shared layer of a "sample and group" block (PointNet++ set abstraction, pointnet2_utils.py:161-205; PCT
+// Local_op, pct_utils.py:98-140) without the grouped tensor.  The reference gathers [B,S,ns,Cin] neighbour features,
+// subtracts the centre, concatenates and runs a 1x1 convolution over S*ns rows; the convolution is linear, so
+//   W [x_j - c_i ; c_i] + t  =  Wa x_j + ((Wb - Wa) c_i + t)  =  U[j] + V[i]
+// with U = one GEMM over the N points and V = one over the S centres (ns times fewer rows, no gather, no concat):
+//   H[b,i,s,:] = relu(U[b, idx[b,i,s], :] + V[b,i,:]).
+// Backward: the ReLU mask is recomputed from U + V (H is not read), dV[i] = sum_s dH[i,s]*mask, and dU[j] GATHERS its
+// contributions over the reversed neighbour table (reverse_graph_k) in ascending (i, s): no atomics, same bits each run.
+namespace hitadv {
+
+__global__ __launch_bounds__(256) void group_add_relu_fwd_k(const float *__restrict__ U, const float *__restrict__ V,
+                                                            const int64_t *__restrict__ idx, int N, int S, int ns, int C,
+                                                            float *__restrict__ H, long long total4) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, i, s, c4)
+  if (e >= total4) return;
+  const int c4n = C >> 2;
+  const int c4 = (int)(e % c4n);
+  const long long bis = e / c4n;  // (b * S + i) * ns + s
+  const long long bi = bis / ns;
+  const long long b = bi / S;
+  const long long j = idx[bis];
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j >= 0 && j < N) {
+    const float4 u = *reinterpret_cast<const float4 *>(U + ((size_t)(b * N + j)) * C + 4 * c4);
+    const float4 v = *reinterpret_cast<const float4 *>(V + (size_t)bi * C + 4 * c4);
+    o = make_float4(fmaxf(u.x + v.x, 0.f), fmaxf(u.y + v.y, 0.f), fmaxf(u.z + v.z, 0.f), fmaxf(u.w + v.w, 0.f));
+  }
+  reinterpret_cast<float4 *>(H)[e] = o;
+}
+
+// dV[b,i,c] = sum_s dH[b,i,s,c] * [U[b,idx[b,i,s],c] + V[b,i,c] > 0]   (one lane per (b, i, 4 channels), s ascending)
+__global__ __launch_bounds__(256) void group_add_relu_dv_k(const float *__restrict__ dH, const float *__restrict__ U,
+                                                           const float *__restrict__ V, const int64_t *__restrict__ idx,
+                                                           int N, int S, int ns, int C, float *__restrict__ dV,
+                                                           long long total4) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, i, c4)
+  if (e >= total4) return;
+  const int c4n = C >> 2;
+  const int c4 = (int)(e % c4n);
+  const long long bi = e / c4n;
+  const long long b = bi / S;
+  const float4 v = *reinterpret_cast<const float4 *>(V + (size_t)bi * C + 4 * c4);
+  const int64_t *nb = idx + bi * ns;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < ns; ++t) {
+    const long long j = nb[t];
+    if (j < 0 || j >= N) continue;
+    const float4 u = *reinterpret_cast<const float4 *>(U + ((size_t)(b * N + j)) * C + 4 * c4);
+    const float4 d = *reinterpret_cast<const float4 *>(dH + ((size_t)(bi * ns + t)) * C + 4 * c4);
+    acc.x += u.x + v.x > 0.f ? d.x : 0.f;
+    acc.y += u.y + v.y > 0.f ? d.y : 0.f;
+    acc.z += u.z + v.z > 0.f ? d.z : 0.f;
+    acc.w += u.w + v.w > 0.f ? d.w : 0.f;
+  }
+  *reinterpret_cast<float4 *>(dV + (size_t)bi * C + 4 * c4) = acc;
+}
+
+// dU[b,j,c] = sum over the lists i that contain j, over the slots s with idx[b,i,s] == j (a ball query pads a list by
+// repeating an entry), of dH[b,i,s,c] * mask -- one wave per (b, j): the wave reads list i with one load, ballots the
+// matching slots, and its lanes (4 channels each) add the rows in ascending (i, s).
+__global__ __launch_bounds__(64) void group_add_relu_du_k(const float *__restrict__ dH, const float *__restrict__ U,
+                                                          const float *__restrict__ V, const int64_t *__restrict__ idx,
+                                                          const int2 *__restrict__ span, const int32_t *__restrict__ col,
+                                                          int N, int S, int ns, int C, float *__restrict__ dU) {
+  long long blk = blockIdx.x;  // (b, j); the blocks of one cloud on one XCD (its dH rows are read once, U/V/idx from L2)
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const long long b = blk / N;
+  const int j = (int)(blk - b * N);
+  const int lane = threadIdx.x;
+  const int2 seg = span[blk];
+  const int32_t *cl = col + b * (long long)S * ns;
+  const int c4n = C >> 2;
+  for (int base = 0; base < c4n; base += 64) {  // C <= 256: one trip; every lane stays in the loop for the ballots
+    const int c4 = base + lane;
+    const bool live = c4 < c4n;
+    const int cc = live ? c4 : 0;
+    const float4 u = *reinterpret_cast<const float4 *>(U + ((size_t)(b * N + j)) * C + 4 * cc);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = seg.x; t < seg.y; ++t) {
+      const long long bi = b * S + cl[t];
+      const long long mine = lane < ns ? idx[bi * ns + lane] : -1;
+      unsigned long long hit = __ballot(mine == j);
+      const float4 v = *reinterpret_cast<const float4 *>(V + (size_t)bi * C + 4 * cc);
+      const bool mx = u.x + v.x > 0.f, my = u.y + v.y > 0.f, mz = u.z + v.z > 0.f, mw = u.w + v.w > 0.f;
+      while (hit) {
+        const int sl = __builtin_ctzll(hit);
+        hit &= hit - 1;
+        const float4 d = *reinterpret_cast<const float4 *>(dH + ((size_t)(bi * ns + sl)) * C + 4 * cc);
+        acc.x += mx ? d.x : 0.f;
+        acc.y += my ? d.y : 0.f;
+        acc.z += mz ? d.z : 0.f;
+        acc.w += mw ? d.w : 0.f;
+      }
+    }
+    if (live) *reinterpret_cast<float4 *>(dU + ((size_t)(b * N + j)) * C + 4 * c4) = acc;
+  }
+}
+
+}  // namespace hitadv
+
+extern "C" int hitadv_group_add_relu_fwd(const float *U, const float *V, const int64_t *idx, int B, int N, int S, int ns,
+                                         int C, float *H, void *stream) {
+  if (!U || !V || !idx || !H || B <= 0 || N <= 0 || S <= 0 || ns <= 0 || C <= 0 || (C & 3) ||
+      (((uintptr_t)U | (uintptr_t)V | (uintptr_t)H) & 15))
+    return HITADV_E_ARG;
+  const long long total4 = (long long)B * S * ns * (C >> 2);
+  hitadv::group_add_relu_fwd_k<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(U, V, idx, N, S, ns, C, H,
+                                                                                              total4);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t hitadv_group_add_relu_bwd_scratch_ints(int B, int N, int S, int ns) {
+  if (B <= 0 || N <= 0 || S <= 0 || ns <= 0) return HITADV_E_ARG;
+  return (int64_t)B * (2 * (int64_t)N + (int64_t)S * ns);
+}
+
+extern "C" int hitadv_group_add_relu_bwd(const float *dH, const float *U, const float *V, const int64_t *idx, int B, int N,
+                                         int S, int ns, int C, float *dU, float *dV, int32_t *scratch, void *stream) {
+  if (!dH || !U || !V || !idx || !dU || !dV || !scratch || B <= 0 || N <= 0 || S <= 0 || ns <= 0 || ns > 64 || C <= 0 ||
+      (C & 3) || (long long)S * ns > 0x7fffffffLL || (long long)B * N > 0x7fffffffLL ||
+      (((uintptr_t)dH | (uintptr_t)U | (uintptr_t)V | (uintptr_t)dU | (uintptr_t)dV) & 15) || ((uintptr_t)scratch & 7))
+    return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long long tv = (long long)B * S * (C >> 2);
+  hitadv::group_add_relu_dv_k<<<(unsigned)((tv + 255) / 256), 256, 0, s>>>(dH, U, V, idx, N, S, ns, C, dV, tv);
+  HITADV_LAUNCH_CHECK();
+  const int W = (S + 31) / 32;
+  if (W + 1 > RG_BITMAP_WORDS) return HITADV_E_ARG;
+  const int J = min(RG_THREADS, RG_BITMAP_WORDS / (W + 1));
+  int2 *span = reinterpret_cast<int2 *>(scratch);
+  int32_t *col = scratch + (size_t)B * 2 * N;
+  const size_t shm = (size_t)(RG_BITMAP_WORDS + 3 * RG_THREADS) * 4;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&hitadv::reverse_graph_k),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  (void)once;
+  hitadv::reverse_graph_k<<<dim3((N + J - 1) / J, B), RG_THREADS, shm, s>>>(idx, S, N, ns, W, J, span, col);
+  HITADV_LAUNCH_CHECK();
+  hitadv::group_add_relu_du_k<<<(unsigned)((long long)B * N), 64, 0, s>>>(dH, U, V, idx, span, col, N, S, ns, C, dU);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int hitadv_edge_max_fwd(const float *U, const float *V, int ld, const int64_t *idx, int B, int N, int C, int k,
                                    float slope, float *out, int32_t *arg, void *stream) {
   if (!U || !V || !idx || !out || !arg || B <= 0 || N <= 0 || C <= 0 || (C & 3) || k <= 0 || ld < C || (ld & 3) ||
@@ -531,7 +677,8 @@ extern "C" int hitadv_edge_max_bwd(const float *dout, const float *out, const in
   static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&hitadv::reverse_graph_k),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   (void)once;
-  hitadv::reverse_graph_k<<<dim3((N + J - 1) / J, B), RG_THREADS, shm, (hipStream_t)stream>>>(idx, N, k, W, J, span, col);
+  hitadv::reverse_graph_k<<<dim3((N + J - 1) / J, B), RG_THREADS, shm, (hipStream_t)stream>>>(idx, N, N, k, W, J, span,
+                                                                                          col);
   HITADV_LAUNCH_CHECK();
   const long long total4 = (long long)B * N * (C >> 2);
   hitadv::edge_max_bwd_k<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(

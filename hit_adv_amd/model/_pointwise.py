@@ -82,6 +82,19 @@ def linear_relu_pm(conv, bn, x):
     return y.view(*x.shape[:-1], W.shape[0])
 
 
+def split_first_layer(conv, bn, n_rel):
+    """The first shared layer of a sample-and-group block, W [rel ; rest] + t with rel = (neighbour - centre)[:n_rel],
+    as the pair (W, t) of the folded layer: the caller forms U = [x_j ; rest_j] W^T per POINT and V = -c_i W[:, :n_rel]^T
+    + t (PointNet++) or V = c_i (W_centre - W_rel)^T + t (PCT) per CENTRE, and ``ops.group_add_relu`` does the rest.
+    Constants unless ``WEIGHT_GRADS`` (see linear_relu_pm)."""
+    W, b = _folded(conv, bn)
+    if b is None:
+        b = torch.zeros(W.shape[0], device=W.device, dtype=W.dtype)
+    if not WEIGHT_GRADS:
+        W, b = W.detach(), b.detach()
+    return W, b
+
+
 def fast_pm(conv, bn, x):
     """Whether the points-major fast path applies (eval mode, CUDA)."""
     return _fast(conv, bn, x)

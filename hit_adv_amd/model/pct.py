@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..pytorch3d_ops import knn_points
-from ._pointwise import conv1x1, fast_pm, linear_relu_pm
+from ._pointwise import conv1x1, fast_pm, linear_relu_pm, split_first_layer
 from .pointnet2 import index_points
 
 
@@ -49,6 +49,27 @@ class Local_op(nn.Module):
         self.conv2 = nn.Conv1d(out_channels, out_channels, kernel_size=1, bias=False)
         self.bn1 = nn.BatchNorm1d(out_channels)
         self.bn2 = nn.BatchNorm1d(out_channels)
+
+    def from_points(self, xyz, points, npoint, nsample):
+        """sample_and_group + forward without the grouped tensor (eval mode on the GPU): xyz [B,N,3], points [B,N,D] ->
+        (new_xyz [B,S,3], features [B,S,C] points-major).  The first convolution is split over the neighbour and the
+        centre, W [x_j - c_i ; c_i] = Wa x_j + (Wb - Wa) c_i: one GEMM over the N points, one over the S centres and
+        ``hitadv_group_add_relu`` replace the [B,S,nsample,2D] gather / subtract / concat and a GEMM over S*nsample rows.
+        Draws the FPS start exactly where ``sample_and_group`` does."""
+        xyz = xyz.contiguous()
+        D = points.shape[-1]
+        fps_idx = fps(xyz, npoint)
+        new_xyz = index_points(xyz, fps_idx)
+        idx = knn_point(nsample, xyz, new_xyz)
+        W, t = split_first_layer(self.conv1, self.bn1, D)
+        U = torch.matmul(points, W[:, :D].t())
+        V = torch.addmm(t, index_points(points, fps_idx).reshape(-1, D), (W[:, D:] - W[:, :D]).t()).view(-1, npoint, W.shape[0])
+        h = linear_relu_pm(self.conv2, self.bn2, ops.group_add_relu(U, V, idx))
+        return new_xyz, h.max(dim=2)[0]
+
+    def fast(self, points, nsample):
+        return (fast_pm(self.conv1, self.bn1, points) and self.conv1.in_channels == 2 * points.shape[-1] and
+                ops.group_add_relu_supported(self.conv1.out_channels, nsample))
 
     def forward(self, x):
         b, n, s, d = x.shape
@@ -126,10 +147,16 @@ class Pct(nn.Module):
         B = x.shape[0]
         xyz = x.permute(0, 2, 1)
         h = F.relu(conv1x1(self.conv2, self.bn2, F.relu(conv1x1(self.conv1, self.bn1, x)))).permute(0, 2, 1)
-        new_xyz, grouped = sample_and_group(npoint=512, radius=0.15, nsample=32, xyz=xyz, points=h)
-        f0 = self.gather_local_0(grouped)
-        new_xyz, grouped = sample_and_group(npoint=256, radius=0.2, nsample=32, xyz=new_xyz, points=f0.permute(0, 2, 1))
-        f1 = self.gather_local_1(grouped)
+        if self.gather_local_0.fast(h, 32):
+            new_xyz, p0 = self.gather_local_0.from_points(xyz, h, 512, 32)
+            new_xyz, p1 = self.gather_local_1.from_points(new_xyz, p0, 256, 32)
+            f1 = p1.permute(0, 2, 1)
+        else:
+            new_xyz, grouped = sample_and_group(npoint=512, radius=0.15, nsample=32, xyz=xyz, points=h)
+            f0 = self.gather_local_0(grouped)
+            new_xyz, grouped = sample_and_group(npoint=256, radius=0.2, nsample=32, xyz=new_xyz,
+                                                points=f0.permute(0, 2, 1))
+            f1 = self.gather_local_1(grouped)
         h = self.conv_fuse[2](conv1x1(self.conv_fuse[0], self.conv_fuse[1], torch.cat([self.pt_last(f1), f1], dim=1)))
         g = h.max(dim=2)[0] if h.is_cuda else F.adaptive_max_pool1d(h, 1).view(B, -1)
         g = self.dp1(F.leaky_relu(self.bn6(self.linear1(g)), negative_slope=0.2))

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ._pointwise import fast_pm, linear_relu_pm
+from ._pointwise import fast_pm, linear_relu_pm, split_first_layer
 
 
 def index_points(points, idx):
@@ -68,6 +68,9 @@ class PointNetSetAbstraction(nn.Module):
         xyz = xyz.permute(0, 2, 1).contiguous()
         if points is not None:
             points = points.permute(0, 2, 1)
+        if (not self.group_all and fast_pm(self.mlp_convs[0], self.mlp_bns[0], xyz) and
+                ops.group_add_relu_supported(self.mlp_convs[0].out_channels, self.nsample)):
+            return self._grouped_from_points(xyz, points)
         if self.group_all:
             new_xyz, grouped = sample_and_group_all(xyz, points)
         else:
@@ -81,6 +84,27 @@ class PointNetSetAbstraction(nn.Module):
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
             h = F.relu(bn(conv(h)))
         return new_xyz.permute(0, 2, 1), torch.max(h, 2)[0]
+
+
+def _grouped_from_points(self, xyz, points):
+    """The grouping path without the grouped tensor (eval mode on the GPU).  The first 1x1 convolution acts on
+    [x_j - c_i ; f_j]; split over its inputs it is W [x_j ; f_j] - Wx c_i: one GEMM over the N points (U), one over the S
+    centres (V) and ``hitadv_group_add_relu`` replace the [B,S,nsample,3+D] gather / subtract / concat and a GEMM over
+    S*nsample rows.  Same random FPS start, same ball query as ``sample_and_group``."""
+    B, N, _ = xyz.shape
+    new_xyz = index_points(xyz, farthest_point_sample(xyz, self.npoint))
+    idx = query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+    W, t = split_first_layer(self.mlp_convs[0], self.mlp_bns[0], 3)
+    src = xyz if points is None else torch.cat([xyz, points], dim=-1)
+    U = torch.matmul(src, W.t())
+    V = torch.addmm(t, new_xyz.reshape(-1, 3), -W[:, :3].t()).view(B, self.npoint, W.shape[0])
+    h = ops.group_add_relu(U, V, idx)
+    for conv, bn in list(zip(self.mlp_convs, self.mlp_bns))[1:]:
+        h = linear_relu_pm(conv, bn, h)
+    return new_xyz.permute(0, 2, 1), h.max(dim=2)[0].permute(0, 2, 1)
+
+
+PointNetSetAbstraction._grouped_from_points = _grouped_from_points
 
 
 class get_model(nn.Module):

@@ -438,6 +438,43 @@ def edge_max_fused(UV, idx, slope=0.2):
     return EdgeMax.apply(UV, idx, slope)
 
 
+class GroupAddReLU(torch.autograd.Function):
+    """H[b,i,s,:] = relu(U[b, idx[b,i,s], :] + V[b,i,:]) -- the first shared layer of a sample-and-group block after the
+    1x1 convolution has been split over the neighbour and the centre (hitadv_group_add_relu_fwd).  U [B,N,C], V [B,S,C],
+    idx [B,S,ns] -> [B,S,ns,C]."""
+
+    @staticmethod
+    def forward(ctx, U, V, idx):
+        U, V = _dev(U, "U"), _dev(V, "V")
+        idx = _dev(idx, "idx", torch.int64)
+        B, N, C = U.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        H = torch.empty(B, S, ns, C, device=U.device)
+        _lib.call("hitadv_group_add_relu_fwd", _p(U), _p(V), _p(idx), B, N, S, ns, C, _p(H), _stream())
+        ctx.save_for_backward(U, V, idx)
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        U, V, idx = ctx.saved_tensors
+        B, N, C = U.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        dH = dH.contiguous()
+        dU, dV = torch.empty_like(U), torch.empty_like(V)
+        scratch = torch.empty(B * (2 * N + S * ns), device=U.device, dtype=torch.int32)
+        _lib.call("hitadv_group_add_relu_bwd", _p(dH), _p(U), _p(V), _p(idx), B, N, S, ns, C, _p(dU), _p(dV), _p(scratch),
+                  _stream())
+        return dU, dV, None
+
+
+def group_add_relu(U, V, idx):
+    return GroupAddReLU.apply(U, V, idx)
+
+
+def group_add_relu_supported(C, ns):
+    return C % 4 == 0 and ns <= 64
+
+
 class LReluPool(torch.autograd.Function):
     """[max_i lrelu(Z[b,i,:]) | mean_i lrelu(Z[b,i,:])] -> [B,2C] from the pre-activation Z [B,N,C] (hitadv_lrelu_pool_fwd)."""
 

@@ -323,6 +323,20 @@ int hitadv_lrelu_pool_fwd(const float *Z, int B, int N, int C, float slope, floa
 int hitadv_lrelu_pool_bwd(const float *Z, const float *g, const int32_t *arg, int B, int N, int C, float slope, float *dZ,
                           void *stream);
 
+/* First shared layer of a sample-and-group block (PointNet++ set abstraction, model/pointnet2_utils.py:161-205; PCT
+ * Local_op, model/pct_utils.py:98-140) with the 1x1 convolution split over its two inputs, W [x_j - c_i ; c_i] + t =
+ * Wa x_j + ((Wb - Wa) c_i + t):  H[b,i,s,:] = relu(U[b, idx[b,i,s], :] + V[b,i,:]).
+ * U [B,N,C] (one product over the N points), V [B,S,C] (one over the S centres), idx [B,S,ns] int64 (entries outside
+ * [0,N) give a zero row), H [B,S,ns,C]; C % 4 == 0.  The [B,S,ns,Cin] gather / subtract / concat never exists. */
+int hitadv_group_add_relu_fwd(const float *U, const float *V, const int64_t *idx, int B, int N, int S, int ns, int C,
+                              float *H, void *stream);
+/* dV[b,i,:] = sum_s dH[b,i,s,:] * mask,  dU[b,j,:] = sum_{(i,s): idx[b,i,s]==j} dH[b,i,s,:] * mask in ascending (i,s),
+ * mask = [U + V > 0] recomputed (H is not needed); no float atomics.  ns <= 64.
+ * scratch: hitadv_group_add_relu_bwd_scratch_ints(B,N,S,ns) int32, 8-byte aligned, contents irrelevant. */
+int hitadv_group_add_relu_bwd(const float *dH, const float *U, const float *V, const int64_t *idx, int B, int N, int S,
+                              int ns, int C, float *dU, float *dV, int32_t *scratch, void *stream);
+int64_t hitadv_group_add_relu_bwd_scratch_ints(int B, int N, int S, int ns);
+
 /* k nearest neighbours in feature space for DGCNN's dynamic graph (model/dgcnn_cls.py:7-13: topk of
  * -|x_i|^2 + 2 x_i.x_j - |x_j|^2), fused: the scores come off the f32 matrix cores tile by tile and go straight into
  * per-lane sorted lists -- no [B,N,N] matrix.  X [B,N,D] points-major (D in {64,128}, 16-byte aligned), xx [B,N] = |x|^2,

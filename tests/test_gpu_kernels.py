@@ -697,6 +697,38 @@ def test_lrelu_pool_matches_torch(A, B, n, C):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("B,n,S,ns,C", [(2, 300, 70, 32, 128), (3, 1024, 128, 64, 128), (1, 64, 64, 5, 256), (2, 130, 33, 7, 8)])
+def test_group_add_relu_matches_torch(A, B, n, S, ns, C):
+    """The split first layer of a sample-and-group block: forward bitwise against relu(U[idx] + V), gradients bitwise
+    against the sums taken in ascending (list, slot) order, lists with repeated entries (ball-query padding) included,
+    reproducible."""
+    g = torch.Generator().manual_seed(n + S + ns)
+    U = torch.randn(B, n, C, generator=g)
+    V = torch.randn(B, S, C, generator=g)
+    idx = torch.randint(0, n, (B, S, ns), generator=g)
+    idx[:, :, ns // 2:] = idx[:, :, :1]  # padded lists: the first entry repeated
+    idx[idx == 3] = 4                    # point 3 is in no list
+    w = torch.randn(B, S, ns, C, generator=g)
+    Ua, Va = U.cuda().requires_grad_(), V.cuda().requires_grad_()
+    H = A.group_add_relu(Ua, Va, idx.cuda())
+    ref = torch.relu(U.gather(1, idx.reshape(B, S * ns, 1).expand(B, S * ns, C)).view(B, S, ns, C) + V[:, :, None, :])
+    assert torch.equal(H.detach().cpu(), ref)
+    gu, gv = torch.autograd.grad((H * w.cuda()).sum(), [Ua, Va])
+    gm = w * (ref > 0)
+    dv = torch.zeros(B, S, C)
+    for t in range(ns):
+        dv += gm[:, :, t, :]
+    assert torch.equal(gv.cpu(), dv)
+    du = torch.zeros(B, n, C)
+    for i in range(S):
+        for t in range(ns):
+            du.scatter_add_(1, idx[:, i, t].view(B, 1, 1).expand(B, 1, C), gm[:, i, t, :].unsqueeze(1))
+    assert torch.equal(gu.cpu(), du)
+    assert float(gu[:, 3].abs().max()) == 0.0
+    gu2, = torch.autograd.grad((A.group_add_relu(Ua, Va, idx.cuda()) * w.cuda()).sum(), [Ua])
+    assert torch.equal(gu, gu2)
+
+
 def test_pointnet_engine_captures_on_a_fresh_stream():
     """The standard torch.cuda.graph pattern (capture on the graph's own side stream, no eager pass on THAT stream first)
     works: the engine's ticket scratch is created inside the capture, and replays reproduce the eager result bit for bit."""
