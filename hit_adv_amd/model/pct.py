@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..pytorch3d_ops import knn_points
-from ._pointwise import conv1x1, fast_pm, linear_relu_pm, split_first_layer
+from ._pointwise import conv1x1, fast_pm, linear_pm, linear_relu_pm, split_first_layer
 from .pointnet2 import index_points
 
 
@@ -95,6 +95,15 @@ class SA_Layer(nn.Module):
         self.act = nn.ReLU()
         self.softmax = nn.Softmax(dim=-1)
 
+    def forward_pm(self, x):
+        """The same layer on points-major x [B,N,C] (eval mode on the GPU): the 1x1 convolutions are GEMMs over B*N rows,
+        the attention products take their transposes through the BLAS flags -- no permuted copies in either direction."""
+        q = linear_pm(self.q_conv, None, x)  # q_conv and k_conv share their weight (:116): one product serves both
+        attention = self.softmax(torch.bmm(q, q.transpose(1, 2)))
+        attention = attention / (1e-9 + attention.sum(dim=1, keepdim=True))
+        x_r = torch.bmm(attention.transpose(1, 2), linear_pm(self.v_conv, None, x))
+        return x + linear_relu_pm(self.trans_conv, self.after_norm, x - x_r)
+
     def forward(self, x):
         attention = self.softmax(torch.bmm(conv1x1(self.q_conv, None, x).permute(0, 2, 1), conv1x1(self.k_conv, None, x)))
         attention = attention / (1e-9 + attention.sum(dim=1, keepdim=True))
@@ -112,6 +121,15 @@ class Point_Transformer_Last(nn.Module):
         self.bn2 = nn.BatchNorm1d(channels)
         self.sa1, self.sa2 = SA_Layer(channels), SA_Layer(channels)
         self.sa3, self.sa4 = SA_Layer(channels), SA_Layer(channels)
+
+    def forward_pm(self, x):
+        """x [B,N,C] points-major -> [B,N,4C]."""
+        h = linear_relu_pm(self.conv2, self.bn2, linear_relu_pm(self.conv1, self.bn1, x))
+        outs = []
+        for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
+            h = sa.forward_pm(h)
+            outs.append(h)
+        return torch.cat(outs, dim=2)
 
     def forward(self, x):
         h = F.relu(conv1x1(self.conv2, self.bn2, F.relu(conv1x1(self.conv1, self.bn1, x))))
@@ -143,8 +161,26 @@ class Pct(nn.Module):
         self.dp2 = nn.Dropout(p=args.dropout)
         self.linear3 = nn.Linear(256, output_channels)
 
+    def _forward_points_major(self, x):
+        """Eval mode on the GPU: every tensor stays points-major [B,N,C], so each 1x1 convolution is one GEMM with the
+        BatchNorm folded in and bias / ReLU in its epilogue, and nothing is permuted or copied between layers."""
+        xyz = x.permute(0, 2, 1).contiguous()
+        h = linear_relu_pm(self.conv2, self.bn2, linear_relu_pm(self.conv1, self.bn1, xyz))
+        new_xyz, p0 = self.gather_local_0.from_points(xyz, h, 512, 32)
+        new_xyz, p1 = self.gather_local_1.from_points(new_xyz, p0, 256, 32)
+        z = linear_pm(self.conv_fuse[0], self.conv_fuse[1], torch.cat([self.pt_last.forward_pm(p1), p1], dim=2))
+        if ops.lrelu_pool_supported(z.shape[2]):
+            g = ops.lrelu_pool(z.contiguous(), 0.2)[:, :z.shape[2]]  # activation + max over the points in one pass
+        else:
+            g = F.leaky_relu(z, negative_slope=0.2).max(dim=1)[0]
+        g = self.dp1(F.leaky_relu(self.bn6(self.linear1(g)), negative_slope=0.2))
+        g = self.dp2(F.leaky_relu(self.bn7(self.linear2(g)), negative_slope=0.2))
+        return self.linear3(g)
+
     def forward(self, x):
         B = x.shape[0]
+        if fast_pm(self.conv1, self.bn1, x) and not self.training:
+            return self._forward_points_major(x)
         xyz = x.permute(0, 2, 1)
         h = F.relu(conv1x1(self.conv2, self.bn2, F.relu(conv1x1(self.conv1, self.bn1, x)))).permute(0, 2, 1)
         if self.gather_local_0.fast(h, 32):
