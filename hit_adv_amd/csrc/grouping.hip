@@ -557,40 +557,49 @@ __global__ __launch_bounds__(256) void group_add_relu_dv_k(const float *__restri
 }
 
 // dU[b,j,c] = sum over the lists i that contain j, over the slots s with idx[b,i,s] == j (a ball query pads a list by
-// repeating an entry), of dH[b,i,s,c] * mask -- one wave per (b, j): the wave reads list i with one load, ballots the
-// matching slots, and its lanes (4 channels each) add the rows in ascending (i, s).
+// repeating an entry), of dH[b,i,s,c] * mask.  G lanes (G = C/4 rounded up to a power of two, at most 64) serve one
+// target point: they read list i G entries at a time, ballot the matching slots, and each lane (4 channels) adds the rows
+// in ascending (i, s).  A wave therefore holds 64/G targets (4 at C = 64).
+template <int G>
 __global__ __launch_bounds__(64) void group_add_relu_du_k(const float *__restrict__ dH, const float *__restrict__ U,
                                                           const float *__restrict__ V, const int64_t *__restrict__ idx,
                                                           const int2 *__restrict__ span, const int32_t *__restrict__ col,
-                                                          int N, int S, int ns, int C, float *__restrict__ dU) {
-  long long blk = blockIdx.x;  // (b, j); the blocks of one cloud on one XCD (its dH rows are read once, U/V/idx from L2)
+                                                          int N, int S, int ns, int C, long long targets,
+                                                          float *__restrict__ dU) {
+  constexpr int TPW = 64 / G;  // targets per wave
+  long long blk = blockIdx.x;  // the blocks of one cloud on one XCD (its dH rows are read once, U / V / idx from L2)
   if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
-  const long long b = blk / N;
-  const int j = (int)(blk - b * N);
-  const int lane = threadIdx.x;
-  const int2 seg = span[blk];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const long long tgt = blk * TPW + grp;  // (b, j)
+  if (tgt >= targets) return;
+  const long long b = tgt / N;
+  const int j = (int)(tgt - b * N);
+  const int2 seg = span[tgt];
   const int32_t *cl = col + b * (long long)S * ns;
   const int c4n = C >> 2;
-  for (int base = 0; base < c4n; base += 64) {  // C <= 256: one trip; every lane stays in the loop for the ballots
-    const int c4 = base + lane;
+  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+  for (int base = 0; base < c4n; base += G) {  // C <= 256: one trip; every lane of the group stays in for the ballots
+    const int c4 = base + gl;
     const bool live = c4 < c4n;
     const int cc = live ? c4 : 0;
     const float4 u = *reinterpret_cast<const float4 *>(U + ((size_t)(b * N + j)) * C + 4 * cc);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = seg.x; t < seg.y; ++t) {
       const long long bi = b * S + cl[t];
-      const long long mine = lane < ns ? idx[bi * ns + lane] : -1;
-      unsigned long long hit = __ballot(mine == j);
       const float4 v = *reinterpret_cast<const float4 *>(V + (size_t)bi * C + 4 * cc);
       const bool mx = u.x + v.x > 0.f, my = u.y + v.y > 0.f, mz = u.z + v.z > 0.f, mw = u.w + v.w > 0.f;
-      while (hit) {
-        const int sl = __builtin_ctzll(hit);
-        hit &= hit - 1;
-        const float4 d = *reinterpret_cast<const float4 *>(dH + ((size_t)(bi * ns + sl)) * C + 4 * cc);
-        acc.x += mx ? d.x : 0.f;
-        acc.y += my ? d.y : 0.f;
-        acc.z += mz ? d.z : 0.f;
-        acc.w += mw ? d.w : 0.f;
+      for (int s0 = 0; s0 < ns; s0 += G) {
+        const long long mine = s0 + gl < ns ? idx[bi * ns + s0 + gl] : -1;
+        unsigned long long hit = (__ballot(mine == j) >> (grp * G)) & gmask;
+        while (hit) {
+          const int sl = s0 + __builtin_ctzll(hit);
+          hit &= hit - 1;
+          const float4 d = *reinterpret_cast<const float4 *>(dH + ((size_t)(bi * ns + sl)) * C + 4 * cc);
+          acc.x += mx ? d.x : 0.f;
+          acc.y += my ? d.y : 0.f;
+          acc.z += mz ? d.z : 0.f;
+          acc.w += mw ? d.w : 0.f;
+        }
       }
     }
     if (live) *reinterpret_cast<float4 *>(dU + ((size_t)(b * N + j)) * C + 4 * c4) = acc;
@@ -637,7 +646,14 @@ extern "C" int hitadv_group_add_relu_bwd(const float *dH, const float *U, const 
   (void)once;
   hitadv::reverse_graph_k<<<dim3((N + J - 1) / J, B), RG_THREADS, shm, s>>>(idx, S, N, ns, W, J, span, col);
   HITADV_LAUNCH_CHECK();
-  hitadv::group_add_relu_du_k<<<(unsigned)((long long)B * N), 64, 0, s>>>(dH, U, V, idx, span, col, N, S, ns, C, dU);
+  const long long targets = (long long)B * N;
+  const int c4n = C >> 2;
+  if (c4n <= 16)
+    hitadv::group_add_relu_du_k<16><<<(unsigned)((targets + 3) / 4), 64, 0, s>>>(dH, U, V, idx, span, col, N, S, ns, C, targets, dU);
+  else if (c4n <= 32)
+    hitadv::group_add_relu_du_k<32><<<(unsigned)((targets + 1) / 2), 64, 0, s>>>(dH, U, V, idx, span, col, N, S, ns, C, targets, dU);
+  else
+    hitadv::group_add_relu_du_k<64><<<(unsigned)targets, 64, 0, s>>>(dH, U, V, idx, span, col, N, S, ns, C, targets, dU);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
