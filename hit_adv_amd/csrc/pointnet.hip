@@ -450,8 +450,8 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
     __syncthreads();
     sIn = sF;
   }
-  if (threadIdx.x < 192) {  // 64 -> 3 backwards:  g[n,c] = sum_k d[n,k] * W0r[k,c]
-    const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+  if (wave < 3) {  // 64 -> 3 backwards:  g[n,c] = sum_k d[n,k] * W0r[k,c]; c is the wave: W0r comes through scalar loads
+    const int c = wave, n = lane;
     float v = 0.f;
 #pragma unroll
     for (int k4 = 0; k4 < 16; ++k4) {
