@@ -265,7 +265,10 @@ struct RowMlpBwd {
   const float *x;     // [B,3,N]   stage 1 (left operand of dT3)
   const float *dPin;  // [B,3,N]   stage 0: gradient arriving at the points from stage 1
   float *dTpart;      // stage 1: [B,tiles,9]; stage 2: [B,tiles,64,64]
-  float *out;         // stage 0: dX [B,3,N]; stage 1: dPts [B,3,N]; stage 2: dH1 [B*N,64]
+  float *out;         // stage 0: dX [B,3,N]; stage 1: dPts [B,3,N]; stage 2: dH1 [B*N,64] (ONLY the rows in pres_out)
+  const unsigned long long *pres_in;  // [B,tiles] bit n: row n of the incoming gradient (dH1in / dPin) is non-zero;
+                                      // NULL: every row may be (stage 2 has no incoming gradient: NULL = none)
+  unsigned long long *pres_out;       // [B,tiles] rows of this tile that receive any gradient in this stage, or NULL
   int N, Cout;
 };
 
@@ -289,7 +292,16 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   const int r = lane & 31, h = lane >> 5;
   const int rb = wave & 1, cb = wave >> 1;
 
-  if (threadIdx.x == 0) s_present = 0ull;
+  // A max-pool routes every channel's gradient to ONE point, so only a few points of a tile (~6-12 of 64 in the bench
+  // workload) receive any gradient -- and every operation of the chain is row-wise: a point with a zero gradient row
+  // stays zero through every layer.  The whole stage therefore runs on the COMPACTED rows: the points hit by this
+  // stage's gather plus those the previous stage reported (pres_in), renumbered 0..D-1.  One 32-row block instead of
+  // two halves the matrix work (waves with rb >= R skip it), masks and incoming gradients are fetched for D rows only,
+  // and zero rows add exact zeros, so the result is bit for bit that of the dense chain.
+  const unsigned long long rowmask = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+  const unsigned long long incoming =
+      (STAGE == 2 ? 0ull : (a.pres_in != nullptr ? a.pres_in[(size_t)b * ntiles + tile] : ~0ull)) & rowmask;
+  if (threadIdx.x == 0) s_present = incoming;
   __syncthreads();
   // ---- the arg-max table of the cloud
   int mn[BW_CH];
@@ -304,11 +316,6 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
       mg[ch] = a.dg[(size_t)b * Cout + j];
       if (a.gmask != nullptr) mg[ch] = a.gmask[(size_t)b * Cout + j] > 0.f ? mg[ch] : 0.f;
     }
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = threadIdx.x + 256 * u;
-    *reinterpret_cast<float4 *>(sD + (e >> 5) * PM_L128 + 4 * (e & 31)) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (STAGE == 1 && threadIdx.x < 192) {
     const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
@@ -327,10 +334,26 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
     rank[ch] = __popcll(m & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-  // Only a few points of a tile win any channel (~6 of 64 in the bench workload, one of them often > 100 channels):
-  // points are renumbered 0..D-1 so that the gather below needs one 32-row block (two only if D > 32).
   const unsigned long long present = s_present;
   const int D = __popcll(present);
+  const int R = (D + 31) >> 5;  // 32-row blocks of compacted points: 0, 1 or 2
+  if (threadIdx.x == 0 && a.pres_out != nullptr) a.pres_out[(size_t)b * ntiles + tile] = present;
+  if (D == 0) {  // block-uniform: nothing arrives in this tile
+    if (STAGE == 2) {
+      float4 *o = reinterpret_cast<float4 *>(a.dTpart + ((size_t)b * ntiles + tile) * 4096);
+      for (int e = threadIdx.x; e < 1024; e += 256) o[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      if (STAGE == 1 && threadIdx.x < 9) a.dTpart[((size_t)b * ntiles + tile) * 9 + threadIdx.x] = 0.f;
+      if (threadIdx.x < 192) {
+        const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+        if (n < rows) {
+          const size_t o = ((size_t)b * 3 + c) * N + n0 + n;
+          a.out[o] = STAGE == 0 ? 0.f + a.dPin[o] : 0.f;
+        }
+      }
+    }
+    return;
+  }
   if (threadIdx.x < PM_TM && ((present >> threadIdx.x) & 1ull))
     s_rowmap[__popcll(present & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
   int M = 0;
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   if (threadIdx.x < 32) list[M + threadIdx.x] = make_int2(0, 0);  // zero-gradient padding to a multiple of 32
   __syncthreads();
   // ---- gather on the matrix cores:  dA2[D,128] = S[D,M] @ W3r[list,:]  with S[i,k] = g_k if channel k routes to
-  //      the i-th winning point (one non-zero per column, built on the fly from the list).  Wave w owns columns
+  //      the i-th compacted point (one non-zero per column, built on the fly from the list).  Wave w owns columns
   //      32w..32w+31; K runs over the list in order -> a fixed fmaf chain per output, and a point that wins hundreds
   //      of channels costs M/2 MFMAs per wave instead of a serial chain of dependent row adds.
   f32x16 gacc[2];
@@ -357,44 +380,71 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   else
     gather_rows<false>(list, M, a.W3r + 32 * wave + r, r, h, gacc);
   // ---- everything the chain will need from global memory, requested while the gather's last MFMAs run (the gather
-  //      itself wants the registers: 32 rows of W3r in flight per lane, double buffered)
+  //      itself wants the registers: 32 rows of W3r in flight per lane, double buffered).  Rows are the compacted ones.
+  const bool act = rb < R;  // wave-uniform: this wave's 32-row block holds compacted points
   float w2[64], w1[32];
-  load_w<128, false>(a.W2r, 64, 32 * cb, r, h, w2);
-  if (STAGE == 1) load_w<64, false>(a.W1r, 64, 32 * cb, r, h, w1);
-  if (STAGE == 2) load_w<64, true>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1);
+  if (act) load_w<128, false>(a.W2r, 64, 32 * cb, r, h, w2);
   float m1v[16], mhv[16], dhv[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
-    const int n = 32 * rb + acc_row(e, h);
-    const size_t o = (row0 + n) * 64 + 32 * cb + r;
-    const bool in = n < rows;
-    m1v[e] = (STAGE != 2 && in) ? a.A1[o] : 0.f;
-    mhv[e] = (STAGE == 1 && in) ? a.H1[o] : 0.f;
-    dhv[e] = (STAGE == 1 && in) ? a.dH1in[o] : 0.f;
+    const int i = 32 * rb + acc_row(e, h);
+    const bool in = act && i < D;
+    m1v[e] = (STAGE != 2 && in) ? a.A1[(row0 + s_rowmap[i]) * 64 + 32 * cb + r] : 0.f;
   }
-  float4 a2[8];  // ReLU mask of the 64->128 layer
-  fetch_tile<128>(a.A2 + row0 * 128, rows, a2);
+  float4 a2[8];  // ReLU mask of the 64->128 layer, compacted rows
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    const int i = e >> 5;
+    a2[u] = i < D ? *reinterpret_cast<const float4 *>(a.A2 + (row0 + s_rowmap[i]) * 128 + 4 * (e & 31))
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float4 h1t[4];
-  if (STAGE == 2) fetch_tile<64>(a.H1 + row0 * 64, rows, h1t);
+  if (STAGE == 2) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      const int i = e >> 4;
+      h1t[u] = i < D ? *reinterpret_cast<const float4 *>(a.H1 + (row0 + s_rowmap[i]) * 64 + 4 * (e & 15))
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int i = 32 * q + acc_row(e, h);
-      if (i < D) sD[s_rowmap[i] * PM_L128 + 32 * wave + r] = gacc[q][e];
+      if (q < R) sD[i * PM_L128 + 32 * wave + r] = gacc[q][e];  // rows D..32R-1 are zeros of the accumulator
     }
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < 8; ++u) {  // ReLU of the 64->128 layer
     const int e = threadIdx.x + 256 * u;
-    float4 *d = reinterpret_cast<float4 *>(sD + (e >> 5) * PM_L128 + 4 * (e & 31));
-    float4 v = *d;
-    v.x = a2[u].x > 0.f ? v.x : 0.f; v.y = a2[u].y > 0.f ? v.y : 0.f;
-    v.z = a2[u].z > 0.f ? v.z : 0.f; v.w = a2[u].w > 0.f ? v.w : 0.f;
-    *d = v;
+    if ((e >> 5) < 32 * R) {
+      float4 *d = reinterpret_cast<float4 *>(sD + (e >> 5) * PM_L128 + 4 * (e & 31));
+      float4 v = *d;
+      v.x = a2[u].x > 0.f ? v.x : 0.f; v.y = a2[u].y > 0.f ? v.y : 0.f;
+      v.z = a2[u].z > 0.f ? v.z : 0.f; v.w = a2[u].w > 0.f ? v.w : 0.f;
+      *d = v;
+    }
   }
   __syncthreads();
-  {  // through the 64->128 layer: [64,128] @ W2r[128,64]
+  if (act) {  // through the 64->128 layer: [32R,128] @ W2r[128,64]
+    // what only the layers behind this product need is requested now: its 64 MFMAs cover the round trip, and the
+    // registers of the gather and of the mask pass are free again (requested earlier, stage 1 spilled 35 VGPRs)
+    if (STAGE == 1) load_w<64, false>(a.W1r, 64, 32 * cb, r, h, w1);
+    if (STAGE == 2) load_w<64, true>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1);
+    if (STAGE == 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = 32 * rb + acc_row(e, h);
+        const bool in = i < D;
+        const int p = in ? s_rowmap[i] : 0;
+        const size_t o = (row0 + p) * 64 + 32 * cb + r;
+        mhv[e] = in ? a.H1[o] : 0.f;
+        dhv[e] = (in && ((incoming >> p) & 1ull)) ? a.dH1in[o] : 0.f;  // rows outside pres_in were never written
+      }
+    }
     f32x16 acc[1];
     zero(acc[0]);
     mfma_apply<128, 1>(sD, PM_L128, 32 * rb, w2, acc, r, h);
@@ -406,18 +456,17 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
     }
   }
   __syncthreads();
-  if (STAGE == 2) {  // sD is dead: it now takes the h1 tile (left operand of the transform gradient)
+  if (STAGE == 2) {  // sD is dead: it now takes the h1 rows (left operand of the transform gradient)
     stash_tile<64>(h1t, sF, PM_L64);
     __syncthreads();
   }
 
   if (STAGE == 2) {
-    // (a) dT64 partial of this tile:  sum_n h1[n,i] * d[n,j]   (A = h1^T, B = d, K = 64 points)
+    // (a) dT64 partial of this tile:  sum_n h1[n,i] * d[n,j]   (A = h1^T, B = d, K = the compacted points, ascending)
     {
       f32x16 acc;
       zero(acc);
-#pragma unroll
-      for (int t = 0; t < 32; ++t) {
+      for (int t = 0; t < 16 * R; ++t) {
         const int n = 2 * t + h;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sF[n * PM_L64 + 32 * rb + r], sE[n * PM_L64 + 32 * cb + r], acc, 0, 0, 0);
       }
@@ -425,15 +474,15 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[(32 * rb + acc_row(e, h)) * 64 + 32 * cb + r] = acc[e];
     }
-    // (b) dH1 = d @ T64^T
-    {
+    // (b) dH1 = d @ T64^T, written for the compacted points only (the next stage reads exactly those rows)
+    if (act) {
       f32x16 acc[1];
       zero(acc[0]);
       mfma_apply<64, 1>(sE, PM_L64, 32 * rb, w1, acc, r, h);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int n = 32 * rb + acc_row(e, h);
-        if (n < rows) a.out[(row0 + n) * 64 + 32 * cb + r] = acc[0][e];
+        const int i = 32 * rb + acc_row(e, h);
+        if (i < D) a.out[(row0 + s_rowmap[i]) * 64 + 32 * cb + r] = acc[0][e];
       }
     }
     return;
@@ -441,47 +490,58 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
 
   const float *sIn = sE;
   if (STAGE == 1) {  // through t1, add the gradient arriving at h1 from the encoder, through e1's ReLU
-    f32x16 acc[1];
-    zero(acc[0]);
-    mfma_apply<64, 1>(sE, PM_L64, 32 * rb, w1, acc, r, h);
+    if (act) {
+      f32x16 acc[1];
+      zero(acc[0]);
+      mfma_apply<64, 1>(sE, PM_L64, 32 * rb, w1, acc, r, h);
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
-      sF[(32 * rb + acc_row(e, h)) * PM_L64 + 32 * cb + r] = mhv[e] > 0.f ? acc[0][e] + dhv[e] : 0.f;
+      for (int e = 0; e < 16; ++e)
+        sF[(32 * rb + acc_row(e, h)) * PM_L64 + 32 * cb + r] = mhv[e] > 0.f ? acc[0][e] + dhv[e] : 0.f;
+    }
     __syncthreads();
     sIn = sF;
   }
-  if (wave < 3) {  // 64 -> 3 backwards:  g[n,c] = sum_k d[n,k] * W0r[k,c]; c is the wave: W0r comes through scalar loads
-    const int c = wave, n = lane;
+  if (wave < 3) {  // 64 -> 3 backwards:  g[i,c] = sum_k d[i,k] * W0r[k,c]; c is the wave: W0r comes through scalar loads
+    const int c = wave, i = lane;
     float v = 0.f;
+    if (i < D) {
 #pragma unroll
-    for (int k4 = 0; k4 < 16; ++k4) {
-      const float4 d = *reinterpret_cast<const float4 *>(sIn + n * PM_L64 + 4 * k4);
-      v = fmaf(d.x, a.W0r[(4 * k4) * 3 + c], v);
-      v = fmaf(d.y, a.W0r[(4 * k4 + 1) * 3 + c], v);
-      v = fmaf(d.z, a.W0r[(4 * k4 + 2) * 3 + c], v);
-      v = fmaf(d.w, a.W0r[(4 * k4 + 3) * 3 + c], v);
+      for (int k4 = 0; k4 < 16; ++k4) {
+        const float4 d = *reinterpret_cast<const float4 *>(sIn + i * PM_L64 + 4 * k4);
+        v = fmaf(d.x, a.W0r[(4 * k4) * 3 + c], v);
+        v = fmaf(d.y, a.W0r[(4 * k4 + 1) * 3 + c], v);
+        v = fmaf(d.z, a.W0r[(4 * k4 + 2) * 3 + c], v);
+        v = fmaf(d.w, a.W0r[(4 * k4 + 3) * 3 + c], v);
+      }
     }
-    if (STAGE == 0) {
+    sG[i * 3 + c] = v;  // compacted row i
+  }
+  __syncthreads();
+  if (STAGE == 0) {
+    if (wave < 3) {
+      const int c = wave, n = lane;
       if (n < rows) {
         const size_t o = ((size_t)b * 3 + c) * N + n0 + n;
+        const float v = ((present >> n) & 1ull) ? sG[__popcll(present & ((1ull << n) - 1ull)) * 3 + c] : 0.f;
         a.out[o] = v + a.dPin[o];
       }
-    } else {
-      sG[n * 3 + c] = v;
     }
-  }
-  if (STAGE == 1) {
-    __syncthreads();
+  } else {
     const float *T = a.T + (size_t)b * 9;
-    if (threadIdx.x < 192) {  // dPts[n,i] = sum_j g[n,j] * T3[i,j]
-      const int i = threadIdx.x >> 6, n = threadIdx.x & 63;
-      if (n < rows)
-        a.out[((size_t)b * 3 + i) * N + n0 + n] =
-            fmaf(sG[n * 3 + 2], T[i * 3 + 2], fmaf(sG[n * 3 + 1], T[i * 3 + 1], sG[n * 3] * T[i * 3]));
-    } else if (threadIdx.x < 192 + 9) {  // dT3 partial[i,j] = sum_n x[n,i] * g[n,j], ascending n
+    if (wave < 3) {  // dPts[n,i] = sum_j g[n,j] * T3[i,j]
+      const int i = wave, n = lane;
+      if (n < rows) {
+        float v = 0.f;
+        if ((present >> n) & 1ull) {
+          const float *g = sG + __popcll(present & ((1ull << n) - 1ull)) * 3;
+          v = fmaf(g[2], T[i * 3 + 2], fmaf(g[1], T[i * 3 + 1], g[0] * T[i * 3]));
+        }
+        a.out[((size_t)b * 3 + i) * N + n0 + n] = v;
+      }
+    } else if (threadIdx.x < 192 + 9) {  // dT3 partial[i,j] = sum_n x[n,i] * g[n,j], ascending n (the others add zero)
       const int q = threadIdx.x - 192, i = q / 3, j = q % 3;
       float v = 0.f;
-      for (int n = 0; n < PM_TM; ++n) v = fmaf(sX[n * 3 + i], sG[n * 3 + j], v);
+      for (int ci = 0; ci < D; ++ci) v = fmaf(sX[s_rowmap[ci] * 3 + i], sG[ci * 3 + j], v);
       a.dTpart[((size_t)b * ntiles + tile) * 9 + q] = v;
     }
   }
@@ -663,14 +723,17 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
                                           const float *W3r, int Cout, const float *A2, const float *W2r,
                                           const float *A1, const float *W1r, const float *H1, const float *dH1in,
                                           const float *W0r, const float *T, const float *x, const float *dPin,
-                                          float *dTpart, float *out, int B, int N, void *stream) {
+                                          float *dTpart, float *out, const uint64_t *pres_in, uint64_t *pres_out, int B,
+                                          int N, void *stream) {
   if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || N > 65535 || Cout <= 0 || Cout > 256 * BW_CH || !dg || !idx ||
       !W3r || !A2 || !W2r || !out)
     return HITADV_E_ARG;
   if (stage == 0 && (!A1 || !W0r || !dPin)) return HITADV_E_ARG;
   if (stage == 1 && (!A1 || !W1r || !H1 || !dH1in || !W0r || !T || !x || !dTpart)) return HITADV_E_ARG;
   if (stage == 2 && (!H1 || !T || !dTpart)) return HITADV_E_ARG;
-  RowMlpBwd a{dg, gmask, idx, W3r, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out, N, Cout};
+  RowMlpBwd a{dg, gmask, idx, W3r, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out,
+              reinterpret_cast<const unsigned long long *>(pres_in), reinterpret_cast<unsigned long long *>(pres_out), N,
+              Cout};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   hipStream_t s = (hipStream_t)stream;
   if (stage == 0) rowmlp_bwd_k<0><<<grid, 256, 0, s>>>(a);

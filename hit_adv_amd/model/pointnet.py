@@ -232,7 +232,10 @@ class _PointNetHip(torch.autograd.Function):
         d = ops.fc_layer(d, v.h2_wr, mask=f2)
         dg = ops.fc_layer(d, v.h1_wr, mask=f1)
         dTp, dH1 = E(B, tiles, 4096), E(R, 64)
-        ops.pointnet_rowmlp_bwd(2, B, N, dg, je, v.e3_wr, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp)
+        # which points of a tile receive any gradient: handed from stage to stage, each stage works on those rows only
+        pres2 = torch.empty(B, tiles, device=x.device, dtype=torch.int64)
+        pres1 = torch.empty(B, tiles, device=x.device, dtype=torch.int64)
+        ops.pointnet_rowmlp_bwd(2, B, N, dg, je, v.e3_wr, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp, pres_out=pres2)
         dT64 = ops.sum_partials(dTp, None if dT64_ext is None else dT64_ext.reshape(B, 4096).contiguous())
         # STNkd, first encoder layer, input transform
         d = ops.fc_layer(dT64, v.t6_wr)
@@ -240,14 +243,15 @@ class _PointNetHip(torch.autograd.Function):
         dgt = ops.fc_layer(d, v.t4_wr, mask=f4t)
         dTp, dPts = E(B, tiles, 9), E(B, 3, N)
         ops.pointnet_rowmlp_bwd(1, B, N, dgt, jt, v.t3_wr, a2t, v.t2_wr, dPts, gmask=gt, A1=a1t, W1r=v.t1_wr, H1=h1,
-                                dH1in=dH1, W0r=v.e1_wr, T=T3, x=x, dTpart=dTp)
+                                dH1in=dH1, W0r=v.e1_wr, T=T3, x=x, dTpart=dTp, pres_in=pres2, pres_out=pres1)
         dT3 = ops.sum_partials(dTp)
         # STN3d
         d = ops.fc_layer(dT3, v.s6_wr)
         d = ops.fc_layer(d, v.s5_wr, mask=f5s)
         dgs = ops.fc_layer(d, v.s4_wr, mask=f4s)
         dX = E(B, 3, N)
-        ops.pointnet_rowmlp_bwd(0, B, N, dgs, js, v.s3_wr, a2s, v.s2_wr, dX, gmask=gs, A1=a1s, W0r=v.s1_wr, dPin=dPts)
+        ops.pointnet_rowmlp_bwd(0, B, N, dgs, js, v.s3_wr, a2s, v.s2_wr, dX, gmask=gs, A1=a1s, W0r=v.s1_wr, dPin=dPts,
+                                pres_in=pres1)
         return dX, None
 
 

@@ -388,9 +388,11 @@ def pointnet_rowmlp_fwd(stage, B, N, W2, b2, o2, x=None, T=None, hin=None, W0=No
 
 
 def pointnet_rowmlp_bwd(stage, B, N, dg, idx, W3r, A2, W2r, out, gmask=None, A1=None, W1r=None, H1=None, dH1in=None,
-                        W0r=None, T=None, x=None, dPin=None, dTpart=None):
+                        W0r=None, T=None, x=None, dPin=None, dTpart=None, pres_in=None, pres_out=None):
+    """``pres_in`` / ``pres_out``: int64 [B, tiles] row-presence bit sets handed from stage to stage (see hitadv.h)."""
     _lib.call("hitadv_pointnet_rowmlp_bwd", stage, _p(dg), _p(gmask), _p(idx), _p(W3r), W3r.shape[0], _p(A2), _p(W2r),
-              _p(A1), _p(W1r), _p(H1), _p(dH1in), _p(W0r), _p(T), _p(x), _p(dPin), _p(dTpart), _p(out), B, N, _stream())
+              _p(A1), _p(W1r), _p(H1), _p(dH1in), _p(W0r), _p(T), _p(x), _p(dPin), _p(dTpart), _p(out), _p(pres_in),
+              _p(pres_out), B, N, _stream())
 
 
 def pointnet_rowmlp_tiles(N):

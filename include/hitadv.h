@@ -280,11 +280,17 @@ int64_t hitadv_pointnet_rowmlp_tiles(int N);
  *   stage 1: through t2, t1, + dH1in, e1's ReLU, e1 -> g [.,3];  out = dPts [B,3,N] = g @ T^T;
  *            dTpart [B,tiles,9] = per-tile x^T @ g
  *   stage 0: through s2, s1 -> [.,3], + dPin;  out = dX [B,3,N]
- * The per-tile partials are summed in tile order by hitadv_sum_partials (deterministic). */
+ * The per-tile partials are summed in tile order by hitadv_sum_partials (deterministic).
+ * Row sparsity: a max-pool sends each channel's gradient to one point, and the chain is row-wise, so only the points
+ * that receive something are processed.  pres_out [B,tiles] (or NULL) receives, per tile, the bit set of those points;
+ * pres_in [B,tiles] is the previous stage's pres_out and says which rows of dH1in (stage 1) / dPin (stage 0) are
+ * non-zero -- stage 2 writes ONLY the rows of dH1 in its pres_out, and stage 1 reads dH1in only at pres_in rows.
+ * pres_in == NULL: every row of the incoming gradient may be non-zero (dense behaviour; dH1in fully defined). */
 int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const float *gmask, const int64_t *idx, const float *W3r,
                                int Cout, const float *A2, const float *W2r, const float *A1, const float *W1r,
                                const float *H1, const float *dH1in, const float *W0r, const float *T, const float *x,
-                               const float *dPin, float *dTpart, float *out, int B, int N, void *stream);
+                               const float *dPin, float *dTpart, float *out, const uint64_t *pres_in,
+                               uint64_t *pres_out, int B, int N, void *stream);
 /* out[b,m] = (extra ? extra[b,m] : 0) + sum_t part[b,t,m], ascending t. */
 int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out, void *stream);
 /* out[B,NOUT] = act(in'[B,K] @ Wt[K,NOUT] + bias), in' = in gated by (mask > 0) when mask != NULL (the backward of a
