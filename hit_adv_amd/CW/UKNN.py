@@ -1,8 +1,6 @@
 """Untargeted kNN attack, interface of the reference's CW/UKNN.py::CWUKNN (:41-159): identical to
 CWKNN except that ``clip_func`` also receives the normals (:120-122) and success means
 ``pred != target`` (:87,153)."""
-import torch
-
 from .kNN import CWKNN
 
 

@@ -24,7 +24,6 @@ ZeroDivisionError (quirk Q4); the per-100-iteration stopwatch lines are not prin
 """
 import warnings
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

@@ -8,8 +8,6 @@ distance ((dx*dx+dy*dy)+dz*dz), K smallest in ascending order, ties -> lower ind
 """
 from collections import namedtuple
 
-import torch
-
 from . import ops
 
 _KNN = namedtuple("KNN", "dists idx knn")

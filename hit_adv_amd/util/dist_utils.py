@@ -5,7 +5,6 @@ The set reductions and the kNN search run in HIP kernels; what is left in torch 
 import torch
 import torch.nn as nn
 
-from .. import ops
 from ..pytorch3d_ops import knn_gather, knn_points
 from .set_distance import chamfer, hausdorff
 

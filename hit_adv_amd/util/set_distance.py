@@ -5,7 +5,6 @@ The two min-reductions never see a materialised [B,N2,N1] matrix: one fused HIP 
 (hitadv_nn_min) yields both directions' minima and arg-minima, and autograd flows through the
 saved arg-minima exactly as it does through ``torch.min`` in the reference.
 """
-import torch
 import torch.nn as nn
 
 from .. import ops

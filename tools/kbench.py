@@ -14,8 +14,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hit_adv_amd import _lib, ops  # noqa: E402
-from hit_adv_amd.pointnet2_ops import _ext  # noqa: E402
-from hit_adv_amd.pytorch3d_ops import knn_points  # noqa: E402
 
 
 def timed(fn, reps):
