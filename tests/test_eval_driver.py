@@ -74,6 +74,26 @@ def test_driver_runs_on_synthetic_clouds(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,extra", [("dgcnn", ["--k", "5"]), ("dgcnn", ["--k", "20", "--metric_k", "5"]),
+                                         ("pointnet++", []), ("pct", ["--synthetic_kind", "sphere"])])
+def test_driver_runs_every_victim(tmp_path, model, extra):
+    """The four victims of eval.py:109-121 through the driver (short attack, synthetic clouds, random-init weights)."""
+    args = ['--log_dir', str(tmp_path), '--model', model, '--synthetic', '2', '--batch_size', '4', '--num_iter', '3',
+            '--binary_step', '2', '--central_num', '16', '--total_central_num', '32', '--checkpoint', '/nonexistent'] + extra
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'eval.py')] + args, capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _last_json(out.stdout)
+    assert r['model'] == model and r['batches'] == 2 and r['clean_correct'] == 8 and 0. <= r['ASR'] <= 1.
+    assert all(r[k] == r[k] for k in ('knn', 'uniform', 'curv_std'))
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'eval.py'), '--model', model, '--synthetic', '1', '--k', '20',
+                          '--checkpoint', '/nonexistent', '--log_dir', str(tmp_path)], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT) if model == 'dgcnn' and '--metric_k' in extra else None
+    if bad is not None:  # k + 1 neighbours do not fit the Uniform metric's smallest ball: a clear message, no traceback
+        assert bad.returncode != 0 and 'metric_k' in (bad.stderr + bad.stdout)
+
+
+@pytest.mark.gpu
 def test_driver_under_torchrun_matches_the_plain_run(tmp_path):
     """One rank through the launcher the 8-GPU run uses (RCCL process group, rank-sharded batches, one all-reduce)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')

@@ -437,6 +437,25 @@ def test_adam_step_sum_and_projection(A):
     assert step.item() == 25 and float(dp.abs().max()) <= float(np.float32(0.3))
 
 
+def test_adam_single_matches_torch_adam(A):
+    """The one-tensor Adam the captured CW loops use (hitadv_adam_step with an empty second group) against
+    torch.optim.Adam's defaults over 30 steps."""
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(3, 3, 257, generator=g)
+    grads = [torch.randn(3, 3, 257, generator=g) * (0.1 + i % 3) for i in range(30)]
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-2, weight_decay=0.)
+    p = p0.clone().cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros(1, device='cuda', dtype=torch.int32)
+    for gr in grads:
+        ref.grad = gr.clone()
+        opt.step()
+        A.adam_single(p, gr.cuda(), m, v, step, 1e-2)
+    assert int(step.item()) == 30
+    close(p, ref.detach(), rtol=2e-6, atol=2e-7)
+
+
 @pytest.mark.parametrize("B,K", [(32, 40), (5, 16), (1, 40), (70, 130)])
 def test_fused_adv_losses_match_reference_modules(A, B, K):
     """hitadv_adv_loss (value + gradient in one launch) vs the torch formulation of util/adv_utils.py under autograd,
