@@ -273,6 +273,10 @@ struct RowMlpBwd {
 };
 
 constexpr int BW_CH = 4;  // Cout <= 256 * BW_CH
+#ifndef BW_MFMA_GATHER_DEFAULT
+#define BW_MFMA_GATHER_DEFAULT true
+#endif
+constexpr bool BW_MFMA_GATHER = BW_MFMA_GATHER_DEFAULT;  // see the gather step of rowmlp_bwd_k
 
 template <int STAGE>
 __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
@@ -372,13 +376,43 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   //      the i-th compacted point (one non-zero per column, built on the fly from the list).  Wave w owns columns
   //      32w..32w+31; K runs over the list in order -> a fixed fmaf chain per output, and a point that wins hundreds
   //      of channels costs M/2 MFMAs per wave instead of a serial chain of dependent row adds.
+  //      BW_MFMA_GATHER = false selects the plain form instead -- two waves, a column per lane, one fmaf per list entry
+  //      into the LDS tile, the W3r rows of the next eight entries in flight: a fifth of the instruction slots, but a
+  //      dependent LDS round trip per entry.  Measured: 28.8 instead of 24.2 us per launch alone, and the same 19.0
+  //      clouds/s with three attacks in flight (the gather is worth 3.8 % there either way), so the MFMA form stays.
   f32x16 gacc[2];
-  zero(gacc[0]);
-  zero(gacc[1]);
-  if (D > 32)  // block-uniform
-    gather_rows<true>(list, M, a.W3r + 32 * wave + r, r, h, gacc);
-  else
-    gather_rows<false>(list, M, a.W3r + 32 * wave + r, r, h, gacc);
+  if (BW_MFMA_GATHER) {
+    zero(gacc[0]);
+    zero(gacc[1]);
+    if (D > 32)  // block-uniform
+      gather_rows<true>(list, M, a.W3r + 32 * wave + r, r, h, gacc);
+    else
+      gather_rows<false>(list, M, a.W3r + 32 * wave + r, r, h, gacc);
+  } else {
+    for (int e = threadIdx.x; e < 32 * R * 32; e += 256)
+      *reinterpret_cast<float4 *>(sD + (e >> 5) * PM_L128 + 4 * (e & 31)) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const float *Wc = a.W3r + threadIdx.x;  // this lane's column of W3r
+      float *col = sD + threadIdx.x;
+      float wq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wq[u] = Wc[(list[u].x & 0xffff) * 128];  // the list is padded with 32 zero-gradient entries
+      for (int k0 = 0; k0 < M; k0 += 8) {
+        float wn[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wn[u] = Wc[(list[k0 + 8 + u].x & 0xffff) * 128];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int2 en = list[k0 + u];
+          float *p = col + (en.x >> 16) * PM_L128;
+          *p = fmaf(__int_as_float(en.y), wq[u], *p);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wq[u] = wn[u];
+      }
+    }
+  }
   // ---- everything the chain will need from global memory, requested while the gather's last MFMAs run (the gather
   //      itself wants the registers: 32 rows of W3r in flight per lane, double buffered).  Rows are the compacted ones.
   const bool act = rb < R;  // wave-uniform: this wave's 32-row block holds compacted points
@@ -409,13 +443,15 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  if (BW_MFMA_GATHER) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = 32 * q + acc_row(e, h);
-      if (q < R) sD[i * PM_L128 + 32 * wave + r] = gacc[q][e];  // rows D..32R-1 are zeros of the accumulator
-    }
+      for (int e = 0; e < 16; ++e) {
+        const int i = 32 * q + acc_row(e, h);
+        if (q < R) sD[i * PM_L128 + 32 * wave + r] = gacc[q][e];  // rows D..32R-1 are zeros of the accumulator
+      }
+  }
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < 8; ++u) {  // ReLU of the 64->128 layer
