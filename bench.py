@@ -23,7 +23,6 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 B_PER_GPU, NPOINT, NUM_ITER, BINARY_STEP = 32, 1024, 500, 10
 HP = dict(attack_lr=1e-2, central_num=192, total_central_num=256, init_weight=10., max_weight=80.,
@@ -33,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md, HBM3E spec peak
 
 
 def synth(first, count):
-    from helpers import synth_batch
+    from hit_adv_amd.Dataset.synthetic import synth_batch
     return synth_batch(count, NPOINT, first=first)
 
 

@@ -33,3 +33,33 @@ class SyntheticClouds(Dataset):
             xyz = xyz / xyz.norm(dim=1).max()
         label = torch.randint(0, self.num_class, (1,), generator=g)
         return torch.cat([xyz, normal], 1), label[0]
+
+
+def synth_cloud(cloud_id, n):
+    """One bench / fixture cloud: ``(xyz|normal [n,6], label [1])``, a pure function of its id."""
+    g = torch.Generator('cpu').manual_seed(1234 + cloud_id)
+    xyz = torch.randn(n, 3, generator=g)
+    xyz = xyz - xyz.mean(0, keepdim=True)
+    xyz = xyz / xyz.norm(dim=1).max()
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    label = torch.randint(0, 40, (1,), generator=g)
+    return torch.cat([xyz, nrm], 1), label
+
+
+def synth_batch(b, n, first=0):
+    """``b`` consecutive clouds starting at id ``first``: ``(data [b,n,6], label [b])``."""
+    cl = [synth_cloud(first + i, n) for i in range(b)]
+    return torch.stack([c[0] for c in cl]), torch.cat([c[1] for c in cl])
+
+
+class ToyVictim(torch.nn.Module):
+    """The < 1K-parameter victim (shared 3->16 layer, max over points, 16->40) that smoke runs and fixtures carry."""
+
+    def __init__(self, classes=40, width=16):
+        super().__init__()
+        self.conv = torch.nn.Conv1d(3, width, 1)
+        self.fc = torch.nn.Linear(width, classes)
+
+    def forward(self, x):
+        h = torch.relu(self.conv(x))
+        return self.fc(torch.max(h, 2)[0])

@@ -23,33 +23,7 @@ def T(a):
     return t
 
 
-def synth_cloud(cloud_id, n):
-    """Synthetic input of BASELINE.md section 3 (same rule as tests/golden/make_golden.py)."""
-    g = torch.Generator('cpu').manual_seed(1234 + cloud_id)
-    xyz = torch.randn(n, 3, generator=g)
-    xyz = xyz - xyz.mean(0, keepdim=True)
-    xyz = xyz / xyz.norm(dim=1).max()
-    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
-    label = torch.randint(0, 40, (1,), generator=g)
-    return torch.cat([xyz, nrm], 1), label
-
-
-def synth_batch(b, n, first=0):
-    cl = [synth_cloud(first + i, n) for i in range(b)]
-    return torch.stack([c[0] for c in cl]), torch.cat([c[1] for c in cl])
-
-
-class ToyVictim(torch.nn.Module):
-    """The < 1K-parameter victim whose weights travel inside fixtures g5/g5b/g7."""
-
-    def __init__(self, classes=40, width=16):
-        super().__init__()
-        self.conv = torch.nn.Conv1d(3, width, 1)
-        self.fc = torch.nn.Linear(width, classes)
-
-    def forward(self, x):
-        h = torch.relu(self.conv(x))
-        return self.fc(torch.max(h, 2)[0])
+from hit_adv_amd.Dataset.synthetic import ToyVictim, synth_batch, synth_cloud  # noqa: E402,F401
 
 
 def toy_from_fixture(fx):

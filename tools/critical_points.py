@@ -8,8 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from helpers import synth_batch  # noqa: E402
+from hit_adv_amd.Dataset.synthetic import synth_batch  # noqa: E402
 from hit_adv_amd import ops  # noqa: E402
 from hit_adv_amd.model.pointnet import PointNetFeatureModel  # noqa: E402
 

@@ -11,9 +11,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
-from helpers import synth_batch  # noqa: E402
+from hit_adv_amd.Dataset.synthetic import synth_batch  # noqa: E402
 from victim_breakdown import build  # noqa: E402
 
 
