@@ -35,6 +35,11 @@ class CWKNN:
     def _clip(self, adv, ori, normal):
         return self.clip_func(adv, ori)
 
+    @staticmethod
+    def _success(pred, target):
+        """What the progress lines and the returned count call a success (:90,:141: the targeted criterion)."""
+        return pred == target
+
     def attack(self, data, target):
         """data [B,num_points,3 or 6], target [B] -> (float32 ndarray [B,num_points,3], success count)."""
         self._victim.prepare()
@@ -60,7 +65,7 @@ class CWKNN:
             d = self.dist_func(adv.transpose(1, 2).contiguous(), ori_pts).mean() * K
             g, = torch.autograd.grad(a + d, adv)
             with torch.no_grad():
-                hits.copy_((logits.argmax(dim=1) == target).sum())
+                hits.copy_(self._success(logits.argmax(dim=1), target).sum())
                 adv_loss.copy_(a)
                 dist_loss.copy_(d)
                 ops.adam_single(adv, g, m, v, step, self.attack_lr)  # torch.optim.Adam's update (:74, defaults)
@@ -89,7 +94,7 @@ class CWKNN:
         loop.leave()
         self.last_graph_used = loop.reason is None
         with torch.no_grad():
-            success_num = (self._logits(adv).argmax(dim=-1) == target).sum().item()
+            success_num = self._success(self._logits(adv).argmax(dim=-1), target).sum().item()
         if self.verbose:
             print('Successfully attack {}/{}'.format(success_num, B))
         return adv.transpose(1, 2).contiguous().detach().cpu().numpy(), success_num

@@ -32,7 +32,10 @@ class ClipPointsLinf(nn.Module):
 
 
 class ProjectInnerPoints(nn.Module):
-    """Push points that moved inside the surface back onto it, util/clip_utils.py:90-140."""
+    """Push points that moved inside the surface back onto it, util/clip_utils.py:90-140.
+
+    Reference quirk kept (Q7): its second cross product (:121) names no ``dim``, which under the reference's PyTorch
+    selects the first dimension of size 3 -- the batch dimension for a batch of exactly three clouds."""
 
     @torch.no_grad()
     def forward(self, pc, ori_pc, normal=None):
@@ -42,7 +45,7 @@ class ProjectInnerPoints(nn.Module):
         inside = (delta * normal).sum(dim=1) < 0.
         vng = torch.cross(normal, delta, dim=1)
         vng_len = vng.pow(2).sum(dim=1).pow(0.5)
-        vref = torch.cross(vng, normal, dim=1)
+        vref = torch.cross(vng, normal, dim=0 if pc.shape[0] == 3 else 1)
         vref_len = vref.pow(2).sum(dim=1).pow(0.5)
         proj = delta * vref / (vref_len[:, None, :] + 1e-9)
         proj = torch.where((inside & (vng_len < 1e-6))[:, None, :], torch.zeros_like(proj), proj)

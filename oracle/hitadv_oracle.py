@@ -201,14 +201,16 @@ def clip_points_linf(pc, ori_pc, budget):
 
 
 def project_inner_points(pc, ori_pc, normal=None):
-    """util/clip_utils.py:98-140."""
+    """util/clip_utils.py:98-140.  Quirk Q7 kept: the second cross product (:121) is written without ``dim``, which
+    under the reference's PyTorch means "the first dimension of size 3" -- the BATCH dimension when B == 3
+    (fixture g24 has B = 3, g6 has B = 2)."""
     if normal is None:
         return pc
     diff = pc - ori_pc
     inner = torch.sum(diff * normal, dim=1) < 0.
     vng = torch.cross(normal, diff, dim=1)
     vng_norm = torch.sum(vng ** 2, dim=1) ** 0.5
-    vref = torch.cross(vng, normal, dim=1)
+    vref = torch.cross(vng, normal, dim=0 if pc.shape[0] == 3 else 1)
     vref_norm = torch.sum(vref ** 2, dim=1) ** 0.5
     proj = diff * vref / (vref_norm[:, None, :] + 1e-9)
     opposite = (inner & (vng_norm < 1e-6))[:, None, :].expand_as(proj)
@@ -524,23 +526,30 @@ class HiTADVOracle:
 
 
 def cw_knn_attack(model, adv_func, dist_func, clip_func, data, target, attack_lr=1e-3,
-                  num_iter=2500, trace=None):
-    """CPU restatement of CW/kNN.py::CWKNN.attack (:40-151).
+                  num_iter=2500, trace=None, pre_head=None, untargeted=False):
+    """CPU restatement of CW/kNN.py::CWKNN.attack (:40-151) and, with ``untargeted=True``, of
+    CW/UKNN.py::CWUKNN.attack (:41-159).
 
-    data [B,N,3] (or [B,N,6]: normals are split off and unused, :58-62).
+    data [B,N,3] or [B,N,6] (normals are split off, :58-62; only CWUKNN hands them on, to its clip, UKNN.py:120-122).
     Draws ``torch.randn(B,3,N)`` from the global CPU generator (:65).
-    ``dist_func(adv[B,N,3], ori[B,N,3])`` and ``clip_func(adv[B,3,N], ori[B,3,N])``.
-    Success here means ``pred == target`` (targeted attack, :86,146).
+    ``dist_func(adv[B,N,3], ori[B,N,3])``; ``clip_func(adv[B,3,N], ori[B,3,N])`` (CWKNN) or
+    ``clip_func(adv, ori, normal)`` (CWUKNN).  ``pre_head`` (CWUKNN only, UKNN.py:82-85,141-144) runs in front of
+    every victim forward.  Success means ``pred == target`` (kNN.py:86,146) or ``pred != target`` (UKNN.py:95,149).
     """
     B, N = data.shape[:2]
     pc = data.float().detach().transpose(1, 2).contiguous()
+    normal = None if pc.shape[1] == 3 else pc[:, 3:, :]
     ori = pc[:, :3, :].clone().detach()
     target = target.long().detach()
     adv = (ori.clone().detach() + torch.randn((B, 3, N)) * 1e-7).requires_grad_()
     opt = torch.optim.Adam([adv], lr=attack_lr, weight_decay=0.)
+
+    def logits_of(x):
+        out = model(pre_head(x) if pre_head is not None else x)
+        return out[0] if isinstance(out, tuple) else out
+
     for it in range(num_iter):
-        out = model(adv)
-        logits = out[0] if isinstance(out, tuple) else out
+        logits = logits_of(adv)
         adv_loss = adv_func(logits, target).mean()
         dist_loss = dist_func(adv.transpose(1, 2).contiguous(),
                               ori.transpose(1, 2).contiguous()).mean() * N
@@ -549,15 +558,22 @@ def cw_knn_attack(model, adv_func, dist_func, clip_func, data, target, attack_lr
         loss.backward()
         opt.step()
         if clip_func is not None:
-            adv.data = clip_func(adv.clone().detach(), ori)
+            adv.data = clip_func(adv.clone().detach(), ori, normal) if untargeted else clip_func(adv.clone().detach(), ori)
         if trace is not None:
             trace.append(dict(it=it, adv_loss=adv_loss.item(), dist_loss=dist_loss.item(),
                               adv=adv.detach().clone().numpy()))
     with torch.no_grad():
-        out = model(adv)
-        logits = out[0] if isinstance(out, tuple) else out
-        success = (torch.argmax(logits, dim=-1) == target).sum().item()
+        pred = torch.argmax(logits_of(adv), dim=-1)
+        success = ((pred != target) if untargeted else (pred == target)).sum().item()
     return adv.transpose(1, 2).contiguous().detach().numpy(), success
+
+
+def cw_uknn_attack(model, adv_func, dist_func, clip_func, data, target, attack_lr=1e-3, num_iter=2500, pre_head=None,
+                   trace=None):
+    """CW/UKNN.py::CWUKNN.attack (:41-159): the kNN attack with the untargeted criterion, ``pre_head`` and a clip
+    that sees the normals."""
+    return cw_knn_attack(model, adv_func, dist_func, clip_func, data, target, attack_lr=attack_lr, num_iter=num_iter,
+                         trace=trace, pre_head=pre_head, untargeted=True)
 
 
 def cw_perturb_attack(model, adv_func, dist_func, data, target, attack_lr=1e-2, init_weight=10.,

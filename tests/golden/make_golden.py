@@ -25,6 +25,7 @@ Fixture index:
   g19..g21             CWAdd (Chamfer and Hausdorff) / CWAddClusters / CWAddObjects results
   g22_dist_more.npz    LaplacianDist, FarthestDist, FarChamferDist, L2ChamferDist, CurvDist values and gradients
   g23_datasets.npz     ModelNetDataLoader / PartNormalDataset items read from the tiny tree in g23_dataset_tree.json
+  g24_cwuknn.npz       CWUKNN.attack trajectories (ProjectInnerClipLinf, pre_head): L2Dist and ChamferkNNDist
   g10_dgcnn.npz        DGCNN_cls (seeded init, eval mode): logits, input gradient, first-layer kNN table
 """
 import io
@@ -731,8 +732,44 @@ def g23():
     save('g23_datasets.npz', out)
 
 
+# ------------------------------------------------------------------ G24
+class CentreHead(torch.nn.Module):
+    """The pre_head of fixture g24: subtracts every cloud's centroid (a parameter-free stand-in for the defence
+    modules the reference passes as ``pre_head``; the test rebuilds it from this description)."""
+
+    def forward(self, x):
+        return x - x.mean(dim=2, keepdim=True)
+
+
+def g24():
+    from CW.UKNN import CWUKNN
+    model = toy_victim(30)
+    data, _ = synth_batch(3, 256, first=90)  # [B,N,6]: CWUKNN hands the normals to its clip (UKNN.py:120-122)
+    with torch.no_grad():
+        label = model(CentreHead()(data[:, :, :3].transpose(1, 2).contiguous())).argmax(1)
+    out = dict(data=data, target=label, **{'w_' + k: v for k, v in model.state_dict().items()})
+    for tag, dist, seed in (('l2', dist_utils.L2Dist(), 31), ('cham', dist_utils.ChamferkNNDist(), 33)):
+        advs = []
+        clip = clip_utils.ProjectInnerClipLinf(budget=0.3)
+
+        def recording_clip(pc, ori_pc, normal):
+            r = clip(pc, ori_pc, normal)
+            advs.append(r.detach().clone())
+            return r
+
+        att = CWUKNN(model, adv_utils.UntargetedLogitsAdvLoss(kappa=15.), dist, recording_clip, attack_lr=3e-2,
+                     num_iter=10, pre_head=CentreHead())
+        torch.manual_seed(seed)
+        with redirect_stdout(io.StringIO()) as log:
+            final, succ = att.attack(data, label)
+        out.update({tag + '_seed': seed, tag + '_adv_trace': torch.stack(advs), tag + '_final': final,
+                    tag + '_success_num': int(succ),
+                    tag + '_last_line': np.array(log.getvalue().strip().splitlines()[-1])})
+    save('g24_cwuknn.npz', out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13',
-                             'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20', 'g21', 'g22', 'g23']
+                             'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20', 'g21', 'g22', 'g23', 'g24']
     for name in which:
         globals()[name]()

@@ -8,6 +8,26 @@ import torch
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+PARITY = {}  # test id -> worst achieved errors of its float comparisons (dumped by conftest at session end)
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, what=None):
+    """assert_allclose(a, b) that also RECORDS what was achieved: the largest |a-b|, the largest |a-b|/|b| over the
+    elements with |b| above the absolute tolerance, and |a-b|_max / |b|_max, per test, next to the bound asserted."""
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a64.shape == b64.shape and a64.size:
+        err = np.abs(a64 - b64)
+        big = np.abs(b64) > max(atol, 1e-30)
+        rec = dict(max_abs=float(err.max()), max_rel=float((err[big] / np.abs(b64[big])).max()) if big.any() else 0.0,
+                   max_abs_over_scale=float(err.max() / max(np.abs(b64).max(), 1e-30)), rtol=rtol, atol=atol, n=int(a64.size))
+        test = os.environ.get('PYTEST_CURRENT_TEST', 'unknown').split(' ')[0]
+        rows = PARITY.setdefault(test, [])
+        rows.append(dict(what=what or 'cmp%d' % len(rows), **rec))
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
 def golden(name):
     z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return {k: z[k] for k in z.files}

@@ -7,16 +7,15 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import close as _close
 from helpers import T, golden, hp_from_fixture, synth_batch, toy_from_fixture
 from oracle import hitadv_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 
-def close(a, b, rtol=1e-4, atol=1e-6):
-    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
-    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
-    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+def close(a, b, rtol=0.0001, atol=1e-6, what=None):
+    _close(a, b, rtol=rtol, atol=atol, what=what)
 
 
 def _attacker(fx, **kw):
@@ -187,13 +186,98 @@ def test_cwknn_follows_reference_trajectory():
                                     direct_chamfer_knn, lambda pc, ori: O.clip_points_linf(pc, ori, 0.18),
                                     T(fx['data']), T(fx['target']), attack_lr=1e-2, num_iter=10, trace=otrace)
     for i, row in enumerate(trace):
-        np.testing.assert_allclose(row, otrace[i]['adv'], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(final, ofinal, rtol=1e-4, atol=1e-5)
+        close(row, otrace[i]['adv'], rtol=1e-4, atol=1e-5)
+    close(final, ofinal, rtol=1e-4, atol=1e-5)
     assert succ == osucc
     ori = np.transpose(fx['data'], (0, 2, 1))
     for i, row in enumerate(trace):
         assert np.abs(row - ori).max() <= 0.18 + 1e-6
         assert np.abs(row - fx['adv_trace'][i]).max() <= 2 * 1e-2 * (i + 1) + 1e-6
+
+
+def test_cwuknn_follows_reference_trajectory(capsys):
+    """CW/UKNN.py:14-159 as captured in fixture g24: constructor with ``pre_head`` in the reference's position, clip
+    that receives the normals (ProjectInnerClipLinf, clip_utils.py:143-170, B = 3: quirk Q7), untargeted criterion in
+    the printed and returned counts."""
+    from hit_adv_amd.CW.UKNN import CWUKNN
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    from hit_adv_amd.util.clip_utils import ProjectInnerClipLinf
+    from hit_adv_amd.util.dist_utils import ChamferkNNDist, L2Dist
+    fx = golden('g24_cwuknn.npz')
+
+    class CentreHead(torch.nn.Module):
+        def forward(self, x):
+            return x - x.mean(dim=2, keepdim=True)
+
+    def direct_chamfer_knn(adv, ori):  # ChamferkNNDist with direct-form distances (see the CWKNN test)
+        P = O.pairwise_sqdist_direct(ori, adv)
+        cham = P.min(dim=1).values.mean(dim=1)
+        S = torch.sort(O.pairwise_sqdist_direct(adv, adv), dim=-1, stable=True).values[..., 1:6].mean(-1)
+        with torch.no_grad():
+            mask = (S > (S.mean(-1) + 1.05 * S.std(-1))[:, None]).float()
+        return cham * 5. + (S * mask).mean(1) * 3.
+
+    for tag, dist, odist in (('l2', L2Dist(), O.l2_dist), ('cham', ChamferkNNDist(), direct_chamfer_knn)):
+        trace = []
+        clip = ProjectInnerClipLinf(budget=0.3)
+
+        def recording_clip(pc, ori, normal):
+            assert normal is not None and normal.shape == pc.shape
+            out = clip(pc, ori, normal)
+            trace.append(out.detach().cpu().numpy().copy())
+            return out
+
+        # positional arguments exactly as the reference's signature has them: (..., attack_lr, num_iter, pre_head)
+        att = CWUKNN(toy_from_fixture(fx), UntargetedLogitsAdvLoss(kappa=15.), dist, recording_clip, 3e-2, 10, CentreHead())
+        assert att.pre_head is not None and att.verbose
+        torch.manual_seed(int(fx[tag + '_seed']))
+        final, succ = att.attack(T(fx['data']), T(fx['target']))
+        printed = capsys.readouterr().out.strip().splitlines()
+        assert final.dtype == np.float32 and final.shape == fx[tag + '_final'].shape
+        cpu_victim = toy_from_fixture(fx)
+        torch.manual_seed(int(fx[tag + '_seed']))
+        otrace = []
+        ofinal, osucc = O.cw_uknn_attack(cpu_victim, lambda l, t: O.untargeted_logits_adv_loss(l, t, 15.), odist,
+                                         lambda pc, ori, nrm: O.project_inner_clip_linf(pc, ori, nrm, 0.3),
+                                         T(fx['data']), T(fx['target']), attack_lr=3e-2, num_iter=10,
+                                         pre_head=CentreHead(), trace=otrace)
+        for i, row in enumerate(trace):
+            close(row, otrace[i]['adv'], rtol=1e-4, atol=1e-5, what='%s iterate %d vs oracle' % (tag, i))
+        close(final, ofinal, rtol=1e-4, atol=1e-5, what=tag + ' result vs oracle')
+        assert succ == osucc
+        assert printed[-1] == 'Successfully attack {}/{}'.format(succ, 3)
+        ori = np.transpose(fx['data'][:, :, :3], (0, 2, 1))
+        for i, row in enumerate(trace):
+            assert np.abs(row - ori).max() <= 0.3 + 1e-6
+        if tag == 'l2':  # a distance without cancellation noise: the reference's own trajectory is the target
+            for i, row in enumerate(trace):
+                close(row, fx['l2_adv_trace'][i], rtol=1e-4, atol=1e-5, what='l2 iterate %d vs reference' % i)
+            close(final, fx['l2_final'], rtol=1e-4, atol=1e-5, what='l2 result vs reference')
+            assert succ == int(fx['l2_success_num']) and printed[-1] == str(fx['l2_last_line'])
+        else:  # Gram-form noise amplified by Adam's first steps (see the CWKNN test): envelope only
+            for i, row in enumerate(trace):
+                assert np.abs(row - fx['cham_adv_trace'][i]).max() <= 2 * 3e-2 * (i + 1) + 1e-6
+
+
+def test_clip_operators_match_reference_vectors():
+    """Product util/clip_utils.py on the GPU against g6 (captured from util/clip_utils.py:5-170)."""
+    from hit_adv_amd.util import clip_utils
+    fx = golden('g6_adv_clip.npz')
+    pc, ori, nrm = (T(fx[k]).cuda() for k in ('pc', 'ori', 'normal'))
+    close(clip_utils.ClipPointsL2(budget=1.5)(pc, ori), fx['clip_l2'], rtol=1e-6, atol=1e-7, what='ClipPointsL2')
+    close(clip_utils.ClipPointsLinf(budget=0.18)(pc, ori), fx['clip_linf'], rtol=0, atol=0, what='ClipPointsLinf')
+    close(clip_utils.ProjectInnerPoints()(pc.clone(), ori, nrm), fx['project_inner'], rtol=1e-5, atol=1e-6,
+          what='ProjectInnerPoints')
+    close(clip_utils.ProjectInnerClipLinf(budget=0.18)(pc.clone(), ori, nrm), fx['project_clip'], rtol=1e-5, atol=1e-6,
+          what='ProjectInnerClipLinf')
+    assert clip_utils.ProjectInnerPoints()(pc, ori, None) is pc  # no normals: untouched (:107-109)
+    # B = 3 (quirk Q7: the reference's second cross product runs along the batch dimension), against the oracle
+    g = torch.Generator().manual_seed(5)
+    ori3 = torch.randn(3, 3, 64, generator=g)
+    pc3 = ori3 + 0.2 * torch.randn(3, 3, 64, generator=g)
+    n3 = torch.nn.functional.normalize(torch.randn(3, 3, 64, generator=g), dim=1)
+    close(clip_utils.ProjectInnerClipLinf(budget=0.18)(pc3.cuda(), ori3.cuda(), n3.cuda()),
+          O.project_inner_clip_linf(pc3, ori3, n3, 0.18), rtol=1e-5, atol=1e-6, what='ProjectInnerClipLinf B=3')
 
 
 def test_pointnet_victim_loads_reference_layout_and_runs():
@@ -370,8 +454,8 @@ def test_cwperturb_follows_reference_trajectory():
     best, succ = att.attack(T(fx['data']), T(fx['target']))
     assert len(trace) == 30 and best.dtype == np.float64 and best.shape == fx['best'].shape
     for i, row in enumerate(trace):
-        np.testing.assert_allclose(row, fx['adv_trace'][i], rtol=1e-4, atol=2e-6)
-    np.testing.assert_allclose(best, fx['best'], rtol=1e-4, atol=2e-6)
+        close(row, fx['adv_trace'][i], rtol=1e-4, atol=2e-6)
+    close(best, fx['best'], rtol=1e-4, atol=2e-6)
     assert succ == int(fx['success_num'])
 
 
@@ -407,7 +491,7 @@ def test_dgcnn_victim_on_gpu_and_under_attack():
         assert att.last_graph_used == graph
     # torch's gather backward (edge features) accumulates with atomics, so DGCNN gradients are not bitwise
     # reproducible run to run; graph and eager agree to rounding instead of bit for bit
-    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-3, atol=1e-4)
+    close(outs[0], outs[1], rtol=1e-3, atol=1e-4)
 
 
 def test_dgcnn_attack_view_and_edge_max_kernels():
@@ -660,8 +744,8 @@ def test_cwaof_follows_reference_trajectory():
     torch.manual_seed(int(fx['seed']))
     final, succ = att.attack(T(fx['data']), T(fx['target']))
     for i in range(10):
-        np.testing.assert_allclose(trace[i], fx['adv_trace'][i], rtol=1e-3, atol=2e-4)
-    np.testing.assert_allclose(final, fx['final'], rtol=1e-3, atol=2e-4)
+        close(trace[i], fx['adv_trace'][i], rtol=1e-3, atol=2e-4)
+    close(final, fx['final'], rtol=1e-3, atol=2e-4)
     assert succ == int(fx['success_num']) and final.dtype == np.float32
 
 
@@ -739,8 +823,8 @@ def test_cwperturbt_follows_reference_trajectory():
     best, succ = att.attack(T(fx['data']), T(fx['target']))
     assert len(trace) == 30
     for i in range(30):
-        np.testing.assert_allclose(trace[i], fx['adv_trace'][i], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(best, fx['best'], rtol=1e-4, atol=2e-5)
+        close(trace[i], fx['adv_trace'][i], rtol=1e-4, atol=2e-5)
+    close(best, fx['best'], rtol=1e-4, atol=2e-5)
     assert succ == int(fx['success_num']) and best.dtype == np.float64
 
 
@@ -824,9 +908,9 @@ def test_cw_family_follows_reference_trajectories(name, cls, ae, targeted, spect
     bestdist, final, succ = out
     tol = dict(rtol=1e-3, atol=2e-4) if spectral else dict(rtol=1e-4, atol=2e-5)  # rocSOLVER vs LAPACK eigenbasis
     for i in range(10):
-        np.testing.assert_allclose(trace[i], fx['adv_trace'][i], **tol)
-    np.testing.assert_allclose(final, fx['final'], **tol)
-    np.testing.assert_allclose(bestdist, fx['bestdist'], rtol=1e-3)
+        close(trace[i], fx['adv_trace'][i], **tol)
+    close(final, fx['final'], **tol)
+    close(bestdist, fx['bestdist'], rtol=1e-3)
     assert succ == int(fx['success_num']) and final.dtype == np.float32 and bestdist.dtype == np.float64
     for p in model.parameters():
         p.requires_grad = True
@@ -891,8 +975,8 @@ def test_cwadd_family_matches_reference():
                                                    num_iter=12)
             assert final.shape == (2, 256 + 32, 3) and final.dtype == np.float64
             if tight:  # added points start off the surface: a well-posed problem, everything must agree
-                np.testing.assert_allclose(final, ofinal, rtol=1e-4, atol=2e-5)
-                np.testing.assert_allclose(bestdist, obest, rtol=1e-4)
+                close(final, ofinal, rtol=1e-4, atol=2e-5)
+                close(bestdist, obest, rtol=1e-4)
                 assert succ == osucc
             else:
                 # the reference's own initialisation duplicates original points: where a duplicate ties with its original
@@ -934,8 +1018,8 @@ def test_cwadd_family_matches_reference():
     torch.manual_seed(int(fx['seed']))
     bestdist, final, succ = att.attack(T(fx['data']), T(fx['target']))
     # objects sit on the surface at a distance from the cloud (no 1e-7 degeneracy): the fixture itself is the target
-    np.testing.assert_allclose(final, fx['final'], rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(bestdist, fx['bestdist'], rtol=1e-4)
+    close(final, fx['final'], rtol=1e-3, atol=1e-4)
+    close(bestdist, fx['bestdist'], rtol=1e-4)
     assert succ == int(fx['success_num'])
 
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import synth_batch
+from helpers import close, synth_batch
 from oracle import c_oracle as N
 from oracle import hitadv_oracle as O
 
@@ -56,7 +56,7 @@ def test_nn_min_backward_one_direction_only_and_scatter_collisions(A):
     my.sum().backward()  # only the y->x direction carries gradient
     xr = x.clone().requires_grad_()
     O.pairwise_sqdist_direct(xr, y).min(1).values.sum().backward()
-    np.testing.assert_allclose(xg.grad.cpu(), xr.grad, rtol=1e-5, atol=1e-5)
+    close(xg.grad.cpu(), xr.grad, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("m,K", [(5000, 17), (3, 3), (70, 64), (2050, 6)])
@@ -83,10 +83,10 @@ def test_deform_many_centres_and_odd_point_counts(A):
     (ref * up).sum().backward()
     Pg, sg = P.detach().cuda().requires_grad_(), sig.detach().cuda().requires_grad_()
     adv = A.deform(ori.cuda(), central.cuda(), Pg, sg)
-    np.testing.assert_allclose(adv.detach().cpu(), ref.detach(), rtol=1e-5, atol=2e-6)
+    close(adv.detach().cpu(), ref.detach(), rtol=1e-5, atol=2e-6)
     (adv * up.cuda()).sum().backward()
-    np.testing.assert_allclose(Pg.grad.cpu(), P.grad, rtol=2e-4, atol=1e-5 * float(P.grad.abs().max()))
-    np.testing.assert_allclose(sg.grad.cpu(), sig.grad, rtol=2e-4, atol=1e-5 * float(sig.grad.abs().max()))
+    close(Pg.grad.cpu(), P.grad, rtol=2e-4, atol=1e-5 * float(P.grad.abs().max()))
+    close(sg.grad.cpu(), sig.grad, rtol=2e-4, atol=1e-5 * float(sig.grad.abs().max()))
 
 
 def test_fps_maximum_and_unsupported_sizes(A):
@@ -187,4 +187,4 @@ def test_hit_adv_pointnet_engine_odd_shapes_graph_equals_eager(B, n):
     assert np.array_equal(res[False][0], res[True][0]) and int(res[False][1]) == int(res[True][1])
     adv = torch.from_numpy(res[True][0]).float().transpose(1, 2).contiguous().cuda()
     with torch.no_grad():
-        np.testing.assert_allclose(m.attack_view()(adv)[0].cpu().numpy(), m(adv)[0].cpu().numpy(), rtol=1e-3, atol=1e-4)
+        close(m.attack_view()(adv)[0].cpu().numpy(), m(adv)[0].cpu().numpy(), rtol=1e-3, atol=1e-4)

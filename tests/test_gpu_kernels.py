@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import close as _close
 from helpers import T, golden, synth_batch
 from oracle import c_oracle as N
 from oracle import hitadv_oracle as O
@@ -29,10 +30,8 @@ def cu(t):
     return t.cuda()
 
 
-def close(a, b, rtol=1e-5, atol=1e-6):
-    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
-    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
-    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+def close(a, b, rtol=1e-05, atol=1e-6, what=None):
+    _close(a, b, rtol=rtol, atol=atol, what=what)
 
 
 def clouds(b, n, first=0):

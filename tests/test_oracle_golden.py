@@ -167,6 +167,25 @@ def test_g7_cwknn_trajectory():
     assert final.dtype == np.float32
 
 
+def test_g24_cwuknn_trajectories():
+    """CW/UKNN.py:41-159 with ProjectInnerClipLinf (clip_utils.py:143-170) and a pre_head, as captured from the reference."""
+    fx = golden('g24_cwuknn.npz')
+    model = toy_from_fixture(fx)
+    head = lambda x: x - x.mean(dim=2, keepdim=True)  # noqa: E731  the fixture's CentreHead
+    for tag, dist in (('l2', O.l2_dist), ('cham', O.chamfer_knn_dist)):
+        torch.manual_seed(int(fx[tag + '_seed']))
+        trace = []
+        final, succ = O.cw_uknn_attack(
+            model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 15.), dist,
+            lambda pc, ori, nrm: O.project_inner_clip_linf(pc, ori, nrm, 0.3), T(fx['data']), T(fx['target']),
+            attack_lr=3e-2, num_iter=10, pre_head=head, trace=trace)
+        for i, rec in enumerate(trace):
+            close(rec['adv'], fx[tag + '_adv_trace'][i], rtol=1e-4, atol=1e-6)
+        close(final, fx[tag + '_final'], rtol=1e-4, atol=1e-6)
+        assert succ == int(fx[tag + '_success_num'])
+        assert final.dtype == np.float32
+
+
 def test_g8_pointnet_state_dict_layout_recorded():
     shapes = golden_json('g8_state_dicts.json')
     assert len(shapes['pointnet']) == 111
