@@ -116,7 +116,10 @@ class CWPerturb:
                 last_input.copy_(ori)
 
         total = self.binary_step * self.num_iter
-        loop = IterationGraph(iteration, self.use_graph if total >= 16 else False, 'the CW perturbation iteration')
+        graph = self.use_graph if total >= 16 else False
+        loop = IterationGraph(iteration, graph, 'the CW perturbation iteration')
+        if graph not in (False, 'never'):
+            self._victim.open_feed(B, K, total, dev)  # a sampling victim's draws, device-resident
         if loop.probe():
             start_search()
             start_step(ori)
@@ -125,6 +128,7 @@ class CWPerturb:
         report_every = max(1, self.num_iter // 5)
         for binary_step in range(self.binary_step):
             start_step(ori.clone() + torch.randn((B, 3, K)).cuda() * 1e-7)
+            self._victim.load(binary_step * self.num_iter, self.num_iter)  # this step's forward passes, drawn now
             loop.enter()
             for it in range(self.num_iter):
                 loop.step()
@@ -138,6 +142,7 @@ class CWPerturb:
                 upper = torch.where(ok, upper, torch.minimum(upper, weight))
                 weight.copy_((lower + upper) / 2.)
         loop.leave()
+        self._victim.close_feed()
         self.last_graph_used = loop.reason is None
         with torch.no_grad():
             fail = lower == 0.

@@ -5,9 +5,26 @@ module's current weights at the start of every ``attack()``.  ``fast_victim=Fals
 module itself (the reference's behaviour, ShapeAttack/HiT_ADV.py has the same switch)."""
 
 
+from ..model import _sampling
+
+
 class Victim:
     def __init__(self, model, fast=True):
-        self.model, self.fast, self.view = model, fast, None
+        self.model, self.fast, self.view, self.feed = model, fast, None, None
+
+    def open_feed(self, B, N, capacity, device):
+        """A victim that draws FPS start indices from the CPU generator in every forward pass (PointNet++, PCT) reads
+        them from a device-resident table inside a captured loop (model/_sampling.py); ``load`` fills it range by range
+        at the points where the reference's forward passes would have drawn.  No-op for deterministic victims."""
+        highs = _sampling.plan_of(self.model, N)
+        self.feed = _sampling.StartFeed.empty(highs, B, max(2, capacity), device) if highs else None
+
+    def load(self, offset, forwards):
+        if self.feed is not None:
+            self.feed.load(offset, forwards)
+
+    def close_feed(self):
+        self.feed = None
 
     def prepare(self):
         if not (self.fast and hasattr(self.model, 'attack_view')):
@@ -21,5 +38,6 @@ class Victim:
             self.fast, self.view = False, None
 
     def __call__(self, x):
-        out = (self.view if self.view is not None else self.model)(x)
+        with _sampling.using(self.feed):
+            out = (self.view if self.view is not None else self.model)(x)
         return out[0] if isinstance(out, tuple) else out

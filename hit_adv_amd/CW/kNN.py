@@ -79,11 +79,15 @@ class CWKNN:
                 v.zero_()
                 step.zero_()
 
-        loop = IterationGraph(iteration, self.use_graph if self.num_iter >= 16 else False, 'the kNN attack iteration')
+        graph = self.use_graph if self.num_iter >= 16 else False
+        loop = IterationGraph(iteration, graph, 'the kNN attack iteration')
+        if graph not in (False, 'never'):
+            self._victim.open_feed(B, K, self.num_iter + 1, dev)  # a sampling victim's draws, device-resident
         if loop.probe():
             reset()
             loop.capture()
         reset()
+        self._victim.load(0, self.num_iter + 1)  # drawn where the reference's first forward pass would draw
         loop.enter()
         report_every = max(1, self.num_iter // 5)
         for it in range(self.num_iter):
@@ -95,6 +99,7 @@ class CWKNN:
         self.last_graph_used = loop.reason is None
         with torch.no_grad():
             success_num = self._success(self._logits(adv).argmax(dim=-1), target).sum().item()
+        self._victim.close_feed()
         if self.verbose:
             print('Successfully attack {}/{}'.format(success_num, B))
         return adv.transpose(1, 2).contiguous().detach().cpu().numpy(), success_num

@@ -28,6 +28,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from ..model import _sampling
 from ..pytorch3d_ops import knn_gather, knn_points
 from ..util.dist_utils import ChamferDist, curvature_std
 
@@ -64,6 +65,7 @@ class _Workspace:
         self.adv_loss = torch.zeros((), **f)
         self.dist_loss = torch.zeros((), **f)
         self.graph = None
+        self.feed = None  # pre-drawn FPS starts of a sampling victim (set per attack by _setup)
         # buffers of the autograd-free iteration (_iteration_fused)
         self.inv_den = torch.empty(B, N, **f)
         self.gp, self.gs = torch.empty(B, C, 3, **f), torch.empty(B, C, **f)
@@ -131,8 +133,10 @@ class HiT_ADV:
                 return self.model
         return self._view
 
-    def _logits(self, x):
-        out = self._victim()(x)
+    def _logits(self, x, feed=None):
+        """Victim forward; ``feed`` = this attack's pre-drawn FPS starts for a victim that samples (model/_sampling.py)."""
+        with _sampling.using(feed):
+            out = self._victim()(x)
         return out[0] if isinstance(out, tuple) else out
 
     def get_gradient(self, data, target):
@@ -212,7 +216,7 @@ class HiT_ADV:
             ws.P.clamp_(-self.budget, self.budget)
             ws.sigma.clamp_(self.min_sigm, self.max_sigm)
         adv = ops.deform(ws.ori, ws.central, ws.P, ws.sigma)
-        logits = self._logits(adv)
+        logits = self._logits(adv, ws.feed)
         ops.best_update(logits.detach(), ws.target, ws.P.detach(), ws.sigma.detach(), adv.detach(), ws.state)
 
         adv_loss = self.adv_func(logits, ws.target)
@@ -255,7 +259,7 @@ class HiT_ADV:
         P, sigma = ws.P.detach(), ws.sigma.detach()
         ops.deform_fwd_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den)
         x = ws.adv.detach().requires_grad_()
-        logits = self._logits(x)
+        logits = self._logits(x, ws.feed)
         ops.best_update(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, counter=ws.step)
         _, dlogits = self.adv_func.fused(logits, ws.target, loss_out=ws.adv_loss)
         g_victim, = torch.autograd.grad(logits, x, grad_outputs=dlogits)
@@ -282,7 +286,11 @@ class HiT_ADV:
         try:
             ws.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(ws.stream):
+                if ws.feed is not None:
+                    ws.feed.seek(0)
                 self._iteration(ws)  # unguarded: lets library handles / lazy initialisation happen
+                if ws.feed is not None:
+                    ws.feed.seek(0)  # both passes read row 0: a one-iteration attack has no row 1
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")  # "prototype feature" notice
                     torch.cuda.set_sync_debug_mode("error")
@@ -306,7 +314,7 @@ class HiT_ADV:
         last, and they are not kept across attack() calls (capturing costs ~0.1 s against seconds of replays)."""
         for ws in wss:
             ws.graph = None
-        if self.use_graph in (False, 'never'):
+        if self.use_graph in (False, 'never') or self.num_iter * self.binary_step == 0:
             return
         reason = None
         for ws in wss:
@@ -353,12 +361,21 @@ class HiT_ADV:
         lo, hi = central_kappa.min(), central_kappa.max()
         ws.hide_ref.copy_(((central_kappa - lo) / (hi - lo + 1e-7)).squeeze(-1))
         ws.scale_const.fill_(self.init_weight)
-        draws_p, draws_s = [], []
+        # A victim that samples (PointNet++, PCT) draws its FPS starts from the same CPU generator in every forward
+        # pass: per binary step the reference's order is rand(B,C,3), rand(B,C), then num_iter forward passes' worth of
+        # randint draws.  Taking them here, in that order, keeps a seeded run on the reference's trajectory and leaves
+        # nothing in the iteration that needs the host (the iteration becomes capturable).
+        highs = _sampling.plan_of(self.model, K)
+        draws_p, draws_s, starts = [], [], []
         for _ in range(self.binary_step):
             draws_p.append(torch.rand(B, C, 3) * torch.tensor(self.budget))
             draws_s.append(torch.rand((B, C)))
+            if highs:
+                starts.append(_sampling.StartFeed.draw(highs, B, self.num_iter))
         ws.rand_P = torch.stack(draws_p).to(dev) if draws_p else None
         ws.rand_S = torch.stack(draws_s).to(dev) if draws_s else None
+        ws.feed = (_sampling.StartFeed(highs, B, self.binary_step * self.num_iter, dev, table=torch.cat(starts))
+                   if starts else None)
         return ws
 
     def _reset_search(self, ws):
@@ -377,6 +394,8 @@ class HiT_ADV:
         (or eager iterations), per-sample bisection of the distance weight -- no host synchronisation unless
         ``verbose`` asks for the reference's progress lines."""
         B, C, st = ws.B, ws.C, ws.state
+        if ws.feed is not None:
+            ws.feed.seek(binary_step * self.num_iter)  # this step's rows (the warm-up passes moved the cursor)
         with torch.no_grad():
             ws.P.copy_(ws.rand_P[binary_step])
             ws.sigma.copy_(torch.ones((B, C), device=ws.P.device) * self.min_sigm

@@ -4,7 +4,8 @@ Local_op :6-24, Point_Transformer_Last :77-109, SA_Layer :111-139): 113 state_di
 BatchNorm folded in eval mode, see _pointwise.py); the neighbourhood construction of
 ``sample_and_group`` (model/pct_utils.py:111-140) runs in HIP:
 
-* ``fps`` (util/other_utils.py:254-272): random first index from the CPU generator (:264), then
+* ``fps`` (util/other_utils.py:254-272): random first index from the CPU generator (:264) or from an attack's
+  pre-drawn feed (_sampling.py), then
   ``hitadv_fps_from_start``.  The reference maximises sqrt of a clamped Gram-form distance; sqrt is monotone, so
   the selected indices are those of the squared direct-form distance except for fp32 near-ties;
 * ``knn_point`` (pct_utils.py:98-109, ``topk(..., sorted=False)``): ``hitadv_knn_points`` (sorted; the consumer
@@ -16,14 +17,14 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..pytorch3d_ops import knn_points
+from . import _sampling
 from ._pointwise import conv1x1, fast_pm, linear_pm, linear_relu_pm, split_first_layer
 from .pointnet2 import index_points
 
 
 def fps(xyz, M):
     B, N, _ = xyz.shape
-    inds = torch.randint(0, N, size=(B,), dtype=torch.long)
-    return ops.fps_from_start(xyz, M, inds.to(xyz.device))
+    return ops.fps_from_start(xyz, M, _sampling.next_start(B, N, xyz.device))
 
 
 def knn_point(nsample, xyz, new_xyz):
@@ -160,6 +161,11 @@ class Pct(nn.Module):
         self.bn7 = nn.BatchNorm1d(256)
         self.dp2 = nn.Dropout(p=args.dropout)
         self.linear3 = nn.Linear(256, output_channels)
+
+    def fps_start_plan(self, N):
+        """One ``randint(0, high, (B,))`` per FPS call of a forward pass, in call order: 512 of the N points, then 256
+        of those 512 (:62,65)."""
+        return [N, 512]
 
     def _forward_points_major(self, x):
         """Eval mode on the GPU: every tensor stays points-major [B,N,C], so each 1x1 convolution is one GEMM with the

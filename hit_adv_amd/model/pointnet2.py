@@ -3,7 +3,8 @@ model/pointnet2_cls_ssg.py::get_model (:6-42) and model/pointnet2_utils.py::Poin
 79 state_dict entries (tests/golden/g8_state_dicts.json).  The MLPs stay PyTorch-ROCm; the geometry runs in HIP:
 
 * ``farthest_point_sample`` (pointnet2_utils.py:63-84): the random first index is drawn from the CPU generator
-  exactly as the reference does (:75), the 512/128 sequential arg-max steps run in ``hitadv_fps_from_start``;
+  exactly as the reference does (:75) -- or read from an attack's pre-drawn feed (_sampling.py), which makes the
+  forward pass capturable --, the 512/128 sequential arg-max steps run in ``hitadv_fps_from_start``;
 * ``query_ball_point`` (:87-107): ``hitadv_query_ball_point_inclusive`` (d^2 <= r^2, first nsample in index order,
   padded with the first hit) instead of a [B,S,N] distance matrix + full sort.
 """
@@ -12,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from . import _sampling
 from ._pointwise import fast_pm, linear_relu_pm, split_first_layer
 
 
@@ -24,8 +26,7 @@ def index_points(points, idx):
 
 def farthest_point_sample(xyz, npoint):
     B, N, _ = xyz.shape
-    start = torch.randint(0, N, (B,), dtype=torch.long)
-    return ops.fps_from_start(xyz, npoint, start.to(xyz.device))
+    return ops.fps_from_start(xyz, npoint, _sampling.next_start(B, N, xyz.device))
 
 
 def query_ball_point(radius, nsample, xyz, new_xyz):
@@ -124,6 +125,11 @@ class get_model(nn.Module):
         self.bn2 = nn.BatchNorm1d(256)
         self.drop2 = nn.Dropout(0.4)
         self.fc3 = nn.Linear(256, num_class)
+
+    def fps_start_plan(self, N):
+        """One ``randint(0, high, (B,))`` per FPS call of a forward pass, in call order (sa1 samples the N input
+        points, sa2 the 512 centres of sa1; sa3 groups everything and draws nothing)."""
+        return [N, self.sa1.npoint]
 
     def forward(self, xyz):
         B = xyz.shape[0]

@@ -147,6 +147,65 @@ def test_hit_adv_pointnet_engine_follows_the_cpu_oracle():
     assert int(succ) == int(osucc)
 
 
+@pytest.mark.parametrize("victim", ["pointnet", "toy"])
+def test_hit_adv_batch32_follows_the_cpu_oracle(victim):
+    """cfg2's batch: B = 32, N = 1024, C = 192, T = 256 (eval.py sizes).  The batch-coupled pieces -- global min / max in
+    the centre scoring and in the normalised centre curvature (HiT_ADV.py:67-70,342-343), whole-batch norms of the
+    transformation loss (:310-311), mean(scale_const) weighting -- only show at the real batch size: centres bit-equal,
+    every iterate against the oracle's (eager loop so that each one can be read), then the graph run's result."""
+    import copy
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.Dataset.synthetic import ToyVictim
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(5)
+    if victim == "pointnet":
+        cpu_model, iters, steps = PointNetFeatureModel(40, normal_channel=False).eval(), 5, 1
+        with torch.no_grad():
+            for mod in cpu_model.modules():
+                if isinstance(mod, torch.nn.BatchNorm1d):
+                    mod.running_mean.normal_(0, 0.05)
+                    mod.running_var.uniform_(0.8, 1.2)
+    else:
+        cpu_model, iters, steps = ToyVictim().eval(), 10, 2
+        with torch.no_grad():
+            cpu_model.conv.weight.mul_(3.0)
+            cpu_model.fc.weight.mul_(4.0)
+    gpu_model = copy.deepcopy(cpu_model)
+    data, _ = synth_batch(32, 1024, first=7000)
+    with torch.no_grad():
+        out = cpu_model(data[:, :, :3].transpose(1, 2).contiguous())
+        label = (out[0] if isinstance(out, tuple) else out).argmax(1)
+    hp = dict(binary_step=steps, num_iter=iters, attack_lr=1e-2, init_weight=10., max_weight=80., cd_weight=1e-4,
+              ker_weight=1., hide_weight=1., curv_loss_knn=16, central_num=192, total_central_num=256, max_sigm=1.2,
+              min_sigm=0.1, budget=0.55)
+    trace = []
+    oracle = O.HiTADVOracle(cpu_model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), **hp)
+    torch.manual_seed(21)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obest, osucc = oracle.attack(data, label, trace=trace)
+    assert len(trace) == iters * steps
+
+    att = HiT_ADV(gpu_model, UntargetedLogitsAdvLoss(30.), verbose=False, use_graph=False, **hp)
+    rec = _Recorder(att)
+    torch.manual_seed(21)
+    best, succ = att.attack(data, label)
+    ws = next(iter(att._ws.values()))
+    assert torch.equal(ws.central.cpu(), oracle.state['central'])  # same 192 centres in all 32 clouds
+    tol = dict(rtol=1e-4, atol=2e-5)
+    for i, row in enumerate(rec.rows):
+        close(row['adv'], trace[i]['adv'], what='iterate %d' % i, **tol)
+        close(row['adv_loss'], trace[i]['adv_loss'], rtol=1e-4, atol=1e-5, what='adv_loss %d' % i)
+    close(best, obest, what='result (eager)', **tol)
+    assert int(succ) == int(osucc)
+
+    att = HiT_ADV(copy.deepcopy(cpu_model), UntargetedLogitsAdvLoss(30.), verbose=False, use_graph=True, **hp)
+    torch.manual_seed(21)
+    gbest, gsucc = att.attack(data, label)
+    assert att.last_graph_used
+    assert np.array_equal(gbest, best) and int(gsucc) == int(succ)  # graph replay == eager loop, bitwise
+
+
 def test_cwknn_follows_reference_trajectory():
     from hit_adv_amd.CW.kNN import CWKNN
     from hit_adv_amd.util.adv_utils import LogitsAdvLoss
