@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: attacked point-clouds/sec of HiT-ADV (PointNet victim, N=1024, 500 iters).
+"""Benchmarks of the HiT-ADV hot path on MI355X.  Headline (default, ``--config cfg2``): attacked point-clouds/sec of
+HiT-ADV on the PointNet victim, N=1024, 500 iterations x 10 binary steps, batch 32 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one full ``HiT_ADV.attack()`` over one batch of 32 synthetic clouds (cfg2 of
-BASELINE.json: the reference's eval.py hyper-parameters with num_iter=500, binary_step=10, i.e.
-5000 inner iterations).  Inputs are resident in HBM before the timed region.  With N > 1 every rank
-attacks its own 32 clouds (independent shards, weak scaling, no data-path collective); the only
-collectives are the barrier/MAX for timing and one SUM all-reduce of the success counters.
+One "step" = one full attack over one batch of synthetic clouds, inputs resident in HBM before the timed region:
+  cfg2  HiT_ADV.attack(), 32 clouds x 1024 points, PointNet victim           (BASELINE.json configs[1], the metric's config)
+  cfg3  HiT_ADV.attack(), 32 clouds x 1024 points per GPU, DGCNN victim, k=5 (configs[2]: 256 clouds over 8 GPUs)
+  cfg4  HiT_ADV.attack(), 64 clouds x 2048 points, PointNet++ SSG victim     (configs[3])
+  cfg5  CWAdvPC + CWKNN + CWAOF, one after the other, 32 clouds x 1024 points, PCT victim (configs[4])
+With N > 1 every rank attacks its own batches (independent shards, weak scaling, no data-path collective); the only
+collectives are the barrier / MAX for timing and one SUM all-reduce of the success counters.
 
-Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement" for the field definitions.
+Rank 0 prints ONE JSON line; DESIGN.md section "Measurement" defines every field.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
 import time
+import warnings
 
 import torch
 import torch.distributed as dist
@@ -24,29 +29,78 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_PER_GPU, NPOINT, NUM_ITER, BINARY_STEP = 32, 1024, 500, 10
+NUM_ITER, BINARY_STEP = 500, 10
 HP = dict(attack_lr=1e-2, central_num=192, total_central_num=256, init_weight=10., max_weight=80.,
           cd_weight=1e-4, ker_weight=1., hide_weight=1., curv_loss_knn=16, max_sigm=1.2, min_sigm=0.1,
           budget=0.55)  # eval.py:126-133 / :48-62 defaults
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md, HBM3E spec peak
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md, HBM3E spec peak
+F32_MFMA_PEAK = 157.3   # TFLOP/s, dense f32-input MFMA (= the f32 vector peak), same guide
+
+CONFIGS = {
+    'cfg2': dict(victim='pointnet', B=32, N=1024, classes=40, attack='hit_adv', steps=3, warmup=1, concurrent=3,
+                 metric="attacked point-clouds/sec (HiT-ADV, PointNet, N=1024, 500 iters)",
+                 workload="cfg2: synthetic ModelNet40-shaped clouds, 1024 pts, batch 32 per GPU, PointNet victim (random "
+                          "init, eval mode), HiT-ADV eval.py hyper-parameters, num_iter=500 x binary_step=10 = 5000 inner "
+                          "iterations per attack()"),
+    'cfg3': dict(victim='dgcnn', B=32, N=1024, classes=40, attack='hit_adv', steps=2, warmup=1, concurrent=2,
+                 metric="attacked point-clouds/sec (HiT-ADV, DGCNN k=5, N=1024, 500 iters)",
+                 workload="cfg3: synthetic ModelNet40-shaped clouds, 1024 pts, batch 32 per GPU (256 over 8 GPUs), DGCNN "
+                          "victim k=5 (random init, eval mode), HiT-ADV eval.py hyper-parameters, 500 x 10 iterations"),
+    'cfg4': dict(victim='pointnet++', B=64, N=2048, classes=16, attack='hit_adv', steps=1, warmup=0, concurrent=1,
+                 metric="attacked point-clouds/sec (HiT-ADV, PointNet++ SSG, N=2048, 500 iters)",
+                 workload="cfg4: synthetic ShapeNetPart-shaped clouds, 2048 pts, batch 64, PointNet++ SSG victim (16 object "
+                          "categories, random init, eval mode), HiT-ADV eval.py hyper-parameters, 500 x 10 iterations"),
+    'cfg5': dict(victim='pct', B=32, N=1024, classes=40, attack='cw_sweep', steps=1, warmup=0, concurrent=1,
+                 metric="point-clouds/sec through the AdvPC + kNN + AOF sweep (PCT, N=1024)",
+                 workload="cfg5: synthetic ModelNet40-shaped clouds, 1024 pts, batch 32, PCT victim (random init, eval mode); "
+                          "every cloud is attacked by CWAdvPC (2 x 200 iterations, point-wise stand-in auto-encoder: the "
+                          "reference ships none), CWKNN (2500 iterations, ChamferkNNDist) and CWAOF (2 x 200 iterations, "
+                          "low_pass 100), constructor defaults of CW/AdvPC.py, CW/kNN.py, CW/AOF.py, ClipPointsLinf(0.18)"),
+}
 
 
-def synth(first, count):
+def synth(first, count, npoint):
     from hit_adv_amd.Dataset.synthetic import synth_batch
-    return synth_batch(count, NPOINT, first=first)
+    return synth_batch(count, npoint, first=first)
 
 
-def victim():
-    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+def build_victim(cfg):
     torch.manual_seed(0)
-    return PointNetFeatureModel(40, normal_channel=False).eval()
+    name = cfg['victim']
+    if name == 'pointnet':
+        from hit_adv_amd.model.pointnet import PointNetFeatureModel
+        return PointNetFeatureModel(cfg['classes'], normal_channel=False).eval()
+    if name == 'dgcnn':
+        from hit_adv_amd.model.dgcnn import DGCNN_cls
+        return DGCNN_cls(argparse.Namespace(k=5, emb_dims=1024, dropout=0.2), output_channels=cfg['classes']).eval()
+    if name == 'pointnet++':
+        from hit_adv_amd.model.pointnet2 import get_model
+        return get_model(cfg['classes'], normal_channel=False).eval()
+    from hit_adv_amd.model.pct import Pct
+    return Pct(argparse.Namespace(dropout=0.2), output_channels=cfg['classes']).eval()
 
 
+class ToyAE(torch.nn.Module):
+    """Point-wise stand-in for AdvPC's auto-encoder ([B,3,K] -> [B,3,K]); the reference ships no auto-encoder."""
+
+    def __init__(self):
+        super().__init__()
+        self.enc, self.dec = torch.nn.Conv1d(3, 16, 1), torch.nn.Conv1d(16, 3, 1)
+
+    def forward(self, x):
+        return x + 0.05 * self.dec(torch.tanh(self.enc(x)))
+
+
+def logits_of(model, x):
+    out = model(x)
+    return out[0] if isinstance(out, tuple) else out
+
+
+# --------------------------------------------------------------------------------------------- kernel timing
 def graph_timed(launch, per_graph=20, reps=50):
     """Average duration (us) of one launch: `per_graph` back-to-back launches captured into a hipGraph (the host's ctypes
     call rate must not open gaps between launches), replayed `reps` times between two events recorded on the stream the
     replays run on, after an untimed pass that lets the clocks settle under this kernel's load."""
-    import ctypes
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
@@ -65,41 +119,78 @@ def graph_timed(launch, per_graph=20, reps=50):
     return t0.elapsed_time(t1) * 1e3 / (reps * per_graph)
 
 
-def pairwise_roofline(dev):
-    """K1: materialising 1024x1024 pairwise kernel at B=32, timed with events on the launch stream."""
-    from hit_adv_amd import ops
-    x = torch.randn(B_PER_GPU, NPOINT, 3, device=dev)
-    y = torch.randn(B_PER_GPU, NPOINT, 3, device=dev)
-    for _ in range(20):
-        P = ops.pairwise_sqdist(x, y, ops.FORM_GRAM)
-    P = torch.empty(B_PER_GPU, NPOINT, NPOINT, device=dev)
-    import ctypes
-    from hit_adv_amd import _lib
-    lib = _lib.load()
-    ptrs = (ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(P.data_ptr()))
-    us = graph_timed(lambda stream: lib.hitadv_pairwise_sqdist(*ptrs, B_PER_GPU, NPOINT, NPOINT, 3, ops.FORM_GRAM, stream))
-    alg_bytes = (4 * NPOINT * NPOINT + 12 * (NPOINT + NPOINT)) * B_PER_GPU  # SURVEY 8(d): 4,218,880 B / cloud pair
-    achieved = alg_bytes / (us * 1e-6) / 1e9
-    # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of tools/kbench.py at
-    # the same B/N, corrected per MI355X_MICROARCH.md: WRITE_SIZE exact, FETCH_SIZE x2); null if absent.
-    traffic = None
+def _traffic(kernel_key):
+    """HBM bytes per launch from the newest committed PMC summary (separate rocprofv3 --pmc passes of tools/kbench.py at
+    the same sizes, corrected per MI355X_MICROARCH.md: WRITE_SIZE exact, FETCH_SIZE x2).  Not measured in this run: the
+    counters need the profiler; `traffic_source` in the line names the file."""
     import glob
+    best = (None, None)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*kbench_traffic.json"))):
         with open(path) as f:
-            traffic = json.load(f).get("hitadv::pairwise3_vec4<1>", {}).get("hbm_bytes_per_launch", traffic)
-    return dict(kernel="pairwise3_vec4<gram> (hitadv_pairwise_sqdist, B=32, 1024x1024)", bound="hbm",
-                achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=traffic, us_per_launch=round(us, 2), algorithmic_bytes=alg_bytes)
+            v = json.load(f).get(kernel_key, {}).get("hbm_bytes_per_launch")
+        if v is not None:
+            best = (v, os.path.relpath(path, ROOT))
+    return best
 
 
-def hot_loop_kernels(dev):
-    """Informational: the attack loop's own kernels (deformation fwd/bwd) at cfg2 sizes, C-ABI calls
-    timed with events on the launch stream."""
-    import ctypes
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def roofline_pairwise(dev, B=32, N=1024):
+    """K1: the materialising 1024x1024 pairwise kernel (the kernel north_star's >= 70 %-of-HBM target names)."""
+    from hit_adv_amd import _lib, ops
+    lib = _lib.load()
+    x, y = torch.randn(B, N, 3, device=dev), torch.randn(B, N, 3, device=dev)
+    P = torch.empty(B, N, N, device=dev)
+    us = graph_timed(lambda s: lib.hitadv_pairwise_sqdist(_p(x), _p(y), _p(P), B, N, N, 3, ops.FORM_GRAM, s))
+    alg = (4 * N * N + 12 * (N + N)) * B  # SURVEY 8(d): 4,218,880 B per cloud pair
+    ach = alg / (us * 1e-6) / 1e9
+    traffic, src = _traffic("hitadv::pairwise3_vec4<1>")
+    return dict(kernel="pairwise3_vec4<gram> (hitadv_pairwise_sqdist, B=%d, %dx%d)" % (B, N, N), bound="hbm",
+                achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+                traffic_source=src, us_per_launch=round(us, 2), algorithmic_bytes=alg)
+
+
+def roofline_knn_features(dev, B=32, N=1024, D=64, k=5):
+    """cfg3's dominant own kernel: DGCNN's feature-space kNN graph (scores on the f32 matrix cores, selection in the
+    same launch); 2*B*N*N*D flop per launch, three launches per forward (D = 64, 64, 128)."""
+    from hit_adv_amd import _lib
+    lib = _lib.load()
+    f = torch.randn(B, N, D, device=dev)
+    xx = (f * f).sum(-1).contiguous()
+    idx = torch.empty(B, N, k, device=dev, dtype=torch.int64)
+    us = graph_timed(lambda s: lib.hitadv_knn_features(_p(f), _p(xx), B, N, D, k, _p(idx), s))
+    flops = 2.0 * B * N * N * D
+    ach = flops / us / 1e6
+    return dict(kernel="knn_feat_k<%d,%d> (hitadv_knn_features, B=%d, N=%d)" % (D, k, B, N), bound="mfma",
+                achieved=round(ach, 1), peak=F32_MFMA_PEAK, unit="TFLOP/s", frac=round(ach / F32_MFMA_PEAK, 4), traffic=None,
+                us_per_launch=round(us, 2), flops_per_launch=flops, dtype="f32")
+
+
+def roofline_group_add_relu(dev, B, N, S, ns, C, what):
+    """cfg4 / cfg5: first layer of a sample-and-group block, H[b,s,j,:] = relu(U[b, idx[b,s,j], :] + V[b,s,:]).
+    Algorithmic bytes: H written once (4*B*S*ns*C), U and V read once (4*B*(N+S)*C), idx read once (8*B*S*ns)."""
+    from hit_adv_amd import _lib
+    lib = _lib.load()
+    U, V = torch.randn(B, N, C, device=dev), torch.randn(B, S, C, device=dev)
+    idx = torch.randint(0, N, (B, S, ns), device=dev, dtype=torch.int64)
+    H = torch.empty(B, S, ns, C, device=dev)
+    us = graph_timed(lambda s: lib.hitadv_group_add_relu_fwd(_p(U), _p(V), _p(idx), B, N, S, ns, C, _p(H), s))
+    alg = 4 * B * S * ns * C + 4 * B * (N + S) * C + 8 * B * S * ns
+    ach = alg / (us * 1e-6) / 1e9
+    return dict(kernel="group_add_relu_fwd_k (%s: B=%d, N=%d, S=%d, nsample=%d, C=%d)" % (what, B, N, S, ns, C), bound="hbm",
+                achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                us_per_launch=round(us, 2), algorithmic_bytes=alg)
+
+
+def hot_loop_kernels(dev, B=32, N=1024):
+    """Informational: kernels that ARE on cfg2's loop -- the deformation pair and V1 (the victim's 128->1024 shared layer
+    fused with the max over points, on the f32 matrix cores)."""
     from hit_adv_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(1)
-    B, N, C = B_PER_GPU, NPOINT, HP['central_num']
+    C = HP['central_num']
     ori = torch.randn(B, 3, N, generator=g).to(dev)
     central = ori[:, :, :C].contiguous()
     P = (torch.rand(B, C, 3, generator=g) * 0.55).to(dev)
@@ -108,27 +199,12 @@ def hot_loop_kernels(dev):
     adv, inv = torch.empty_like(ori), torch.empty(B, N, device=dev)
     part = torch.empty(lib.hitadv_deform_bwd_scratch_floats(B, N, C), device=dev)
     gp, gs = torch.empty_like(P), torch.empty_like(sig)
-    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-
-    def timed(fn, reps=200):
-        for _ in range(10):
-            fn()
-        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        t0.record()
-        for _ in range(reps):
-            fn()
-        t1.record()
-        torch.cuda.synchronize()
-        return round(t0.elapsed_time(t1) * 1e3 / reps, 2)
-
-    out = {"deform_fwd_us": timed(lambda: lib.hitadv_deform_fwd(p(ori), p(central), p(P), p(sig), B, N, C, p(adv), p(inv), s)),
-           "deform_bwd_us": timed(lambda: lib.hitadv_deform_bwd(p(ori), p(central), p(P), p(sig), p(adv), p(inv), p(up),
-                                                                B, N, C, p(part), p(gp), p(gs), s)),
+    out = {"deform_fwd_us": round(graph_timed(lambda s: lib.hitadv_deform_fwd(_p(ori), _p(central), _p(P), _p(sig), B, N, C,
+                                                                               _p(adv), _p(inv), s)), 2),
+           "deform_bwd_us": round(graph_timed(lambda s: lib.hitadv_deform_bwd(_p(ori), _p(central), _p(P), _p(sig), _p(adv),
+                                                                               _p(inv), _p(up), B, N, C, _p(part), _p(gp),
+                                                                               _p(gs), s)), 2),
            "pairs_per_launch": B * N * C}
-    # the kernel that dominates the loop (37 % of its device time): the victim's 128->1024 shared layer fused with the
-    # max over points, on the f32 matrix cores (157.3 TFLOP/s dense f32 MFMA peak, MI355X_MICROARCH.md)
     h2 = torch.randn(B * N, 128, generator=g).to(dev)
     Wt = (torch.randn(128, 1024, generator=g) * 0.1).to(dev)
     bias = torch.randn(1024, generator=g).to(dev)
@@ -136,27 +212,50 @@ def hot_loop_kernels(dev):
     pv, pi = torch.empty(n, device=dev), torch.empty(n, device=dev, dtype=torch.int32)
     mo, mi = torch.empty(B, 1024, device=dev), torch.empty(B, 1024, device=dev, dtype=torch.int64)
     tk = torch.zeros(4096, device=dev, dtype=torch.int32)  # split tickets (self-resetting)
-    us = round(graph_timed(lambda st: lib.hitadv_linear_max_fwd(p(h2), p(Wt), p(bias), B, N, 128, 1024, 1, p(pv), p(pi), p(mo),
-                                                                p(mi), p(tk), st)), 2)
+    us = round(graph_timed(lambda st: lib.hitadv_linear_max_fwd(_p(h2), _p(Wt), _p(bias), B, N, 128, 1024, 1, _p(pv), _p(pi),
+                                                                _p(mo), _p(mi), _p(tk), st)), 2)
     flops = 2.0 * B * N * 128 * 1024
-    out["linear_max_fwd"] = {"bound": "mfma", "us_per_launch": us, "achieved": round(flops / us / 1e6, 1), "peak": 157.3,
-                             "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / 157.3, 4), "dtype": "f32",
-                             "flops_per_launch": flops}
+    out["linear_max_fwd"] = {"bound": "mfma", "us_per_launch": us, "achieved": round(flops / us / 1e6, 1),
+                             "peak": F32_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / F32_MFMA_PEAK, 4),
+                             "dtype": "f32", "flops_per_launch": flops}
     return out
 
 
-def cpu_baseline():
-    """The CPU oracle (op-for-op restatement of the reference) on this box's host cores, bounded:
-    setup once + 1 warm-up + 2 timed inner iterations at B=32, extrapolated to 10 x 500."""
-    from oracle import hitadv_oracle as O
+def pointnet_forward_flops(B, N, classes=40):
+    """Dense flop count of one PointNetFeatureModel forward (model/feature_models.py:71-230): per point the three
+    3/64 -> 64 -> 128 -> 1024 stacks and the two learned transforms, per cloud the nine FC layers."""
+    per_point = 2 * (3 * 64 + 64 * 128 + 128 * 1024)          # STN3d shared layers
+    per_point += 2 * (3 * 3 + 3 * 64)                          # input transform, first encoder layer
+    per_point += 2 * (64 * 64 + 64 * 128 + 128 * 1024)         # STNkd shared layers
+    per_point += 2 * (64 * 64 + 64 * 128 + 128 * 1024)         # feature transform, encoder tail
+    per_cloud = 2 * (1024 * 512 + 512 * 256) * 3 + 2 * 256 * (9 + 4096 + classes)
+    return float(B) * (N * per_point + per_cloud)
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+def _cores():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 32))  # more intra-op threads than this only adds contention for these op sizes
+    return max(1, min(avail, 32)), avail  # more intra-op threads than this only adds contention for these op sizes
+
+
+def cpu_baseline_hit_adv(cfg, timed_iters):
+    """The CPU oracle (op-for-op restatement of the reference; for PointNet++ the victim samples / groups through
+    oracle/victim_geometry.py) on this box's host cores, bounded: setup once + 1 warm-up + `timed_iters` timed inner
+    iterations at the config's batch, extrapolated to 10 x 500."""
+    from oracle import hitadv_oracle as O
+    from oracle import victim_geometry as VG
+    cores, avail = _cores()
     torch.set_num_threads(cores)
-    data, label = synth(0, B_PER_GPU)
-    model = victim()
+    B, N = cfg['B'], cfg['N']
+    data, _ = synth(0, B, N)
+    model = build_victim(cfg)
+    if cfg['victim'] in ('pointnet++', 'pct'):
+        model = VG.CpuVictim(model)
+    with torch.no_grad():
+        label = logits_of(model, data[:, :, :3].transpose(1, 2).contiguous()).argmax(1)
     att = O.HiTADVOracle(model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.),
                          binary_step=BINARY_STEP, num_iter=NUM_ITER, **HP)
     torch.manual_seed(1)
@@ -166,102 +265,259 @@ def cpu_baseline():
     t_setup = time.perf_counter() - t0
     att.inner_iteration(st)
     t0 = time.perf_counter()
-    n_timed = 2
-    for _ in range(n_timed):
+    for _ in range(timed_iters):
         att.inner_iteration(st)
-    t_iter = (time.perf_counter() - t0) / n_timed
+    t_iter = (time.perf_counter() - t0) / timed_iters
     total = t_setup + t_iter * NUM_ITER * BINARY_STEP
-    return dict(value=B_PER_GPU / total, unit="clouds/s", cores=cores, host_cpus=avail, kind="port",
-                sample="setup (%.1f s) + 1 warm-up + %d timed inner iterations at B=32 (%.2f s/iter), "
-                       "extrapolated to %d x %d iterations" % (t_setup, n_timed, t_iter, BINARY_STEP, NUM_ITER),
+    return dict(value=B / total, unit="clouds/s", cores=cores, host_cpus=avail, kind="port",
+                sample="setup (%.1f s) + 1 warm-up + %d timed inner iterations at B=%d (%.2f s/iter), extrapolated to "
+                       "%d x %d iterations" % (t_setup, timed_iters, B, t_iter, BINARY_STEP, NUM_ITER),
                 s_per_iteration=round(t_iter, 3))
+
+
+def cpu_baseline_cw_sweep(cfg):
+    """The three oracle attacks of the sweep on the CPU, a few iterations each, extrapolated to their full lengths."""
+    from oracle import hitadv_oracle as O
+    from oracle import victim_geometry as VG
+    cores, avail = _cores()
+    torch.set_num_threads(cores)
+    B, N = cfg['B'], cfg['N']
+    data, _ = synth(0, B, N)
+    xyz = data[:, :, :3].contiguous()
+    model = VG.CpuVictim(build_victim(cfg))
+    torch.manual_seed(2)
+    ae = ToyAE().eval()
+    with torch.no_grad():
+        label = logits_of(model, xyz.transpose(1, 2).contiguous()).argmax(1)
+    target = (label + 1) % cfg['classes']
+    clip = lambda pc, ori: O.clip_points_linf(pc, ori, 0.18)  # noqa: E731
+    n = 3
+
+    def per_iteration(run):
+        t0 = time.perf_counter()
+        run(1)
+        t1 = time.perf_counter()
+        run(1 + n)
+        return max(1e-9, (time.perf_counter() - t1) - (t1 - t0)) / n, t1 - t0
+
+    it_adv, f_adv = per_iteration(lambda k: O.cw_family_attack(model, lambda l, t: O.logits_adv_loss(l, t, 0.), clip, xyz, target,
+                                                               y_truth=label, ae_model=ae, targeted=True, fresh=True,
+                                                               binary_step=1, num_iter=k))
+    it_knn, f_knn = per_iteration(lambda k: O.cw_knn_attack(model, lambda l, t: O.logits_adv_loss(l, t, 15.), O.chamfer_knn_dist,
+                                                            clip, xyz, target, num_iter=k))
+    it_aof, f_aof = per_iteration(lambda k: O.cw_aof_attack(model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), clip,
+                                                            xyz, label, binary_step=1, num_iter=k))
+    # f_* = one call with a single iteration (setup + 1 iteration + final forward); AdvPC and AOF run two binary steps
+    total = (2 * f_adv + 398 * it_adv) + (f_knn + 2499 * it_knn) + (2 * f_aof + 398 * it_aof)
+    return dict(value=B / total, unit="clouds/s", cores=cores, host_cpus=avail, kind="port",
+                sample="per attack: one 1-iteration call + %d further timed iterations at B=%d (AdvPC %.2f, kNN %.2f, AOF %.2f "
+                       "s/iter), extrapolated to 2x200 + 2500 + 2x200 iterations" % (n, B, it_adv, it_knn, it_aof),
+                s_per_iteration=dict(advpc=round(it_adv, 3), knn=round(it_knn, 3), aof=round(it_aof, 3)))
+
+
+# --------------------------------------------------------------------------------------------- the timed job
+def make_runner(cfg, model, dev, concurrent):
+    """Returns (run(batches) -> successes, prewarm(batch), info() -> dict, inner iterations per step)."""
+    from hit_adv_amd.util.adv_utils import LogitsAdvLoss, UntargetedLogitsAdvLoss
+    if cfg['attack'] == 'hit_adv':
+        from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+        att = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=BINARY_STEP, num_iter=NUM_ITER,
+                      verbose=False, **HP)
+
+        def run(todo):
+            ok = 0
+            for i in range(0, len(todo), concurrent):
+                group = todo[i:i + concurrent]
+                res = att.attack_many(group) if len(group) > 1 else [att.attack(*group[0])]
+                ok += sum(int(n) for _, n in res)
+            return ok
+
+        def prewarm(batch):  # library handles, lazy initialisation: a 4-iteration attack that is not a step
+            short = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=1, num_iter=4, verbose=False, **HP)
+            short.attack(*batch)
+
+        return run, prewarm, lambda: dict(hip_graph=att.last_graph_used, num_iter=NUM_ITER, binary_step=BINARY_STEP,
+                                          central_num=HP["central_num"]), NUM_ITER * BINARY_STEP
+
+    from hit_adv_amd import CW
+    from hit_adv_amd.util.clip_utils import ClipPointsLinf
+    from hit_adv_amd.util.dist_utils import ChamferkNNDist, L2Dist
+    torch.manual_seed(2)
+    ae = ToyAE().eval().to(dev)
+    clip = ClipPointsLinf(budget=0.18)
+    made = {}
+
+    def attacks(short):
+        kw = dict(verbose=False)
+        a = CW.CWAdvPC(model, ae, LogitsAdvLoss(kappa=0.), L2Dist(), clip_func=clip, **kw,
+                       **(dict(binary_step=1, num_iter=2) if short else {}))
+        k = CW.CWKNN(model, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), clip, **kw, **(dict(num_iter=20) if short else {}))
+        f = CW.CWAOF(model, UntargetedLogitsAdvLoss(kappa=30.), L2Dist(), clip_func=clip, **kw,
+                     **(dict(binary_step=1, num_iter=2) if short else {}))
+        return a, k, f
+
+    def sweep(batch, short=False):
+        data, label = batch
+        xyz = data[:, :, :3].contiguous()
+        target = (label + 1) % cfg['classes']
+        a, k, f = attacks(short)
+        t = [time.perf_counter()]
+        _, _, s1 = a.attack(xyz, target, label)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        _, s2 = k.attack(xyz, target)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        _, s3 = f.attack(xyz, label)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        if not short:
+            made['graph'] = k.last_graph_used
+            made.setdefault('seconds', []).append([round(t[i + 1] - t[i], 3) for i in range(3)])
+        return int(s1) + int(s2) + int(s3)
+
+    def run(todo):
+        return sum(sweep(b) for b in todo)
+
+    def info():
+        sec = made.get('seconds', [[0, 0, 0]])[-1]
+        return dict(hip_graph_knn=made.get('graph'), attacks=["CWAdvPC 2x200", "CWKNN 2500", "CWAOF 2x200"],
+                    seconds_per_attack_last_step=dict(advpc=sec[0], knn=sec[1], aof=sec[2]))
+
+    return run, (lambda batch: sweep(batch, short=True)), info, 2 * 200 + 2500 + 2 * 200
+
+
+def reduce_over_ranks(elapsed_s, succeeded, attacked, dev, world, collectives):
+    """MAX of the elapsed time and SUM of the success counters over the ranks (RCCL; gloo in the CPU test of this
+    function).  Returns (elapsed, succeeded, attacked); `collectives` counts the calls a rank makes."""
+    elapsed = torch.tensor([elapsed_s], device=dev, dtype=torch.float64)
+    counters = torch.tensor([float(succeeded), float(attacked)], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)  # the path's one real collective (ASR aggregation)
+        collectives['all_reduce_max'] += 1
+        collectives['all_reduce_sum'] += 1
+    return elapsed.item(), counters[0].item(), counters[1].item()
+
+
+def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_step, in_flight, info, collectives):
+    """The fields every configuration's line carries (throughput is whole-job: clouds of all ranks / max-over-ranks time)."""
+    B, N = cfg['B'], cfg['N']
+    clouds = steps * B * world
+    return {
+        "metric": cfg['metric'], "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg['workload'], "batch_per_gpu": B, "num_point": N,
+                   "parallelism": "independent batch shards, 1 process per GPU",
+                   "attacks_in_flight_per_gpu": in_flight, **info},
+        "cloud_iterations_per_s": clouds * iters_per_step / elapsed,
+        "attack_success": {"succeeded": succeeded, "attacked": attacked},
+        # what RCCL saw: the calls each rank made in this run (all zero in a single-process run)
+        "collectives_per_rank": dict(collectives, world=world, backend="nccl (RCCL)" if world > 1 else None),
+    }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--concurrent", type=int, default=3,
+    ap.add_argument("--no-single", action="store_true", help="cfg2: skip the extra one-attack-in-flight measurement")
+    ap.add_argument("--concurrent", type=int, default=None,
                     help="independent attack() batches in flight per GPU (separate HIP streams; 1 = strictly serial)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    steps = cfg['steps'] if args.steps is None else args.steps
+    warmup = cfg['warmup'] if args.warmup is None else args.warmup
+    concurrent = max(1, cfg['concurrent'] if args.concurrent is None else args.concurrent)
+    B, N = cfg['B'], cfg['N']
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    collectives = dict(barrier=0, all_reduce_max=0, all_reduce_sum=0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
     from hit_adv_amd import _lib
-    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
-    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
     _lib.load()  # fail loudly if the HIP library is missing
 
-    model = victim().to(dev)
-    att = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=BINARY_STEP,
-                  num_iter=NUM_ITER, verbose=False, **HP)
-    nbatch = args.warmup + args.steps
+    model = build_victim(cfg).to(dev)
+    run, prewarm, info, iters_per_step = make_runner(cfg, model, dev, concurrent)
+    nbatch = warmup + steps
+    extra = 2 if (args.config == 'cfg2' and not args.no_single and world == 1) else 0
     batches = []
-    for s in range(nbatch):  # every (rank, step) attacks distinct clouds; all resident in HBM up front
-        data, _ = synth((rank * nbatch + s) * B_PER_GPU, B_PER_GPU)
+    for s in range(nbatch + extra + 1):  # every (rank, step) attacks distinct clouds; all resident in HBM up front
+        data, _ = synth((rank * (nbatch + extra + 1) + s) * B, B, N)
         data = data.to(dev)
         with torch.no_grad():  # labels = clean predictions, so every cloud starts correctly classified
-            label = model(data[:, :, :3].transpose(1, 2).contiguous())[0].argmax(1)
+            label = logits_of(model, data[:, :, :3].transpose(1, 2).contiguous()).argmax(1)
         batches.append((data, label))
 
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+            collectives['barrier'] += 1
         torch.cuda.synchronize()
 
-    def run(todo):
-        """Attack the given steps, `--concurrent` at a time (each step keeps single-call semantics)."""
-        ok = 0
-        for i in range(0, len(todo), max(1, args.concurrent)):
-            group = todo[i:i + max(1, args.concurrent)]
-            res = att.attack_many(group) if len(group) > 1 else [att.attack(*group[0])]
-            ok += sum(int(n) for _, n in res)
-        return ok
-
     torch.manual_seed(1234 + rank)
-    run(batches[:args.warmup])
-    sync()
-    t0 = time.perf_counter()
-    succ = run(batches[args.warmup:])
-    sync()
-    elapsed = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    counters = torch.tensor([float(succ), float(args.steps * B_PER_GPU)], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)  # the path's one real collective (ASR aggregation)
-    elapsed = elapsed.item()
+    single = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        prewarm(batches[-1])
+        run(batches[:warmup])
+        sync()
+        t0 = time.perf_counter()
+        succ = run(batches[warmup:nbatch])
+        sync()
+        elapsed = time.perf_counter() - t0
+        if extra:  # informational: the same attack with ONE batch in flight (latency of the dependent kernel chain)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for b in batches[nbatch:nbatch + extra]:
+                run([b])
+            torch.cuda.synchronize()
+            single = (time.perf_counter() - t1) / extra
+    per_attack = 3 if cfg['attack'] == 'cw_sweep' else 1
+    elapsed, succeeded, attacked = reduce_over_ranks(elapsed, succ, steps * B * per_attack, dev, world, collectives)
 
     if rank == 0:
-        clouds = args.steps * B_PER_GPU * world
-        line = {
-            "metric": "attacked point-clouds/sec (HiT-ADV, PointNet, N=1024, 500 iters)",
-            "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2: synthetic ModelNet40-shaped clouds, 1024 pts, batch 32 per GPU, "
-                                   "PointNet victim (random init, eval mode), HiT-ADV eval.py hyper-parameters, "
-                                   "num_iter=500 x binary_step=10 = 5000 inner iterations per attack()",
-                       "batch_per_gpu": B_PER_GPU, "num_point": NPOINT, "num_iter": NUM_ITER,
-                       "binary_step": BINARY_STEP, "central_num": HP["central_num"],
-                       "parallelism": "independent batch shards, 1 process per GPU", "hip_graph": att.last_graph_used,
-                       "attacks_in_flight_per_gpu": min(max(1, args.concurrent), args.steps)},
-            "cloud_iterations_per_s": clouds * NUM_ITER * BINARY_STEP / elapsed,
-            "attack_success": {"succeeded": counters[0].item(), "attacked": counters[1].item()},
-            "roofline": pairwise_roofline(dev),
-            "hot_loop_kernels": hot_loop_kernels(dev),
-        }
+        in_flight = min(concurrent, max(1, steps)) if cfg['attack'] == 'hit_adv' else 1
+        line = headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_step, in_flight, info(),
+                        collectives)
+        if args.config == 'cfg2':
+            line["roofline"] = roofline_pairwise(dev)
+            line["hot_loop_kernels"] = hot_loop_kernels(dev)
+            flops = pointnet_forward_flops(B, N)
+            eff = elapsed / steps / iters_per_step * 1e6  # wall time per B=32 iteration, all attacks in flight counted
+            line["end_to_end"] = {
+                "flops_per_iteration": flops, "us_per_iteration": round(eff, 2), "attacks_in_flight": in_flight,
+                "achieved_tflops": round(flops / eff / 1e6, 1),
+                "frac_of_f32_mfma_peak": round(flops / eff / 1e6 / F32_MFMA_PEAK, 4),
+                "note": "dense flops of the victim's forward pass per B=32 iteration (the input-gradient pass is sparse "
+                        "behind the max-pool and not counted) over wall time per iteration = ms_per_step / 5000"}
+            if single is not None:
+                line["single_attack"] = {"value": B / single, "unit": "clouds/s", "ms_per_step": single * 1e3, "steps": extra,
+                                         "attacks_in_flight_per_gpu": 1,
+                                         "us_per_iteration": round(single / iters_per_step * 1e6, 2)}
+        elif args.config == 'cfg3':
+            line["roofline"] = roofline_knn_features(dev)
+        elif args.config == 'cfg4':
+            line["roofline"] = roofline_group_add_relu(dev, B, N, 512, 32, 64, "PointNet++ sa1")
+        else:
+            line["roofline"] = roofline_group_add_relu(dev, B, 512, 256, 32, 256, "PCT gather_local_1")
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            if cfg['attack'] == 'hit_adv':
+                line["cpu_baseline"] = cpu_baseline_hit_adv(cfg, 5 if args.config == 'cfg2' else 2)
+            else:
+                line["cpu_baseline"] = cpu_baseline_cw_sweep(cfg)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if world > 1:

@@ -95,10 +95,11 @@ def build_model(args):
 
 
 def build_loader(args):
+    from hit_adv_amd.util.other_utils import rank_loader
     if args.synthetic > 0:
         from hit_adv_amd.Dataset.synthetic import SyntheticClouds
         data = SyntheticClouds(args.synthetic * args.batch_size, args.num_point, args.synthetic_kind, num_class=args.num_class)
-        return torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=False, num_workers=0)
+        return rank_loader(data, args.batch_size, num_workers=0)
     if args.data_path is None:
         raise SystemExit('eval.py: give --data_path (dataset root) or --synthetic BATCHES')
     if args.dataset == 'ModelNet':
@@ -107,7 +108,7 @@ def build_loader(args):
     else:
         from hit_adv_amd.Dataset.ShapeNetDataLoader import PartNormalDataset
         data = PartNormalDataset(root=args.data_path, npoints=args.num_point, split='test', normal_channel=True)
-    return torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
+    return rank_loader(data, args.batch_size, num_workers=args.num_workers)  # each rank reads only its own batches
 
 
 class _SelfLabelled:
@@ -116,6 +117,7 @@ class _SelfLabelled:
 
     def __init__(self, loader, model):
         self.loader, self.model = loader, model
+        self.rank_sharded = getattr(loader, 'rank_sharded', False)
 
     def __iter__(self):
         for points, _ in self.loader:
@@ -132,6 +134,7 @@ class _ShapeNetAsPairs:
 
     def __init__(self, loader):
         self.loader = loader
+        self.rank_sharded = getattr(loader, 'rank_sharded', False)
 
     def __iter__(self):
         for item in self.loader:

@@ -55,6 +55,33 @@ def shard_indices(n_batches, rank, world):
     return list(range(rank, n_batches, world))
 
 
+class RankBatchSampler(torch.utils.data.Sampler):
+    """batch_sampler that yields only the batches ``shard_indices`` gives this rank (in-order batches of ``batch_size``
+    consecutive samples, as ``shuffle=False`` forms them): a rank's DataLoader workers then read and parse only that
+    rank's files, instead of every rank loading the whole split and dropping the other ranks' batches."""
+
+    def __init__(self, n_samples, batch_size, rank, world):
+        self.n, self.bs, self.rank, self.world = n_samples, batch_size, rank, world
+
+    def __iter__(self):
+        for b in shard_indices(-(-self.n // self.bs), self.rank, self.world):
+            yield list(range(b * self.bs, min(self.n, (b + 1) * self.bs)))
+
+    def __len__(self):
+        return len(shard_indices(-(-self.n // self.bs), self.rank, self.world))
+
+
+def rank_loader(dataset, batch_size, num_workers=0, rank=None, world=None):
+    """DataLoader over this rank's batches only; ``eval_ASR`` recognises it (``rank_sharded``) and does not filter again."""
+    if rank is None or world is None:
+        on = dist.is_available() and dist.is_initialized()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    loader = torch.utils.data.DataLoader(dataset, batch_sampler=RankBatchSampler(len(dataset), batch_size, rank, world),
+                                         num_workers=num_workers)
+    loader.rank_sharded = True
+    return loader
+
+
 def all_reduce_sums(values, device):
     """SUM-all-reduce a short list of python floats; identity when not distributed."""
     t = torch.tensor(values, dtype=torch.float64, device=device)
@@ -136,8 +163,9 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
 
     group = max(1, int(in_flight)) if hasattr(val_attack, 'attack_many') else 1
     pending = []
+    presharded = getattr(test_loader, 'rank_sharded', False)  # rank_loader(): only this rank's batches arrive
     for i, (ori_data, label) in enumerate(test_loader):
-        if i % world != rank:
+        if not presharded and i % world != rank:
             continue
         n_batches += 1
         pending.append((ori_data.float().to(device), label.long().to(device)))

@@ -103,3 +103,34 @@ def test_shard_indices_partition():
         for world in (1, 2, 3, 8):
             parts = [shard_indices(n, r, world) for r in range(world)]
             assert sorted(sum(parts, [])) == list(range(n))
+
+
+def test_rank_loader_reads_only_its_own_batches():
+    """rank_loader (batch_sampler level sharding): the union over ranks is the shuffle=False batch sequence, a rank never
+    touches another rank's samples, and eval_ASR does not filter a pre-sharded loader a second time."""
+    from hit_adv_amd.util.other_utils import RankBatchSampler, rank_loader, shard_indices
+
+    class Counting(torch.utils.data.Dataset):
+        def __init__(self):
+            self.seen = []
+
+        def __len__(self):
+            return 11
+
+        def __getitem__(self, i):
+            self.seen.append(i)
+            return torch.full((4, 6), float(i)), torch.tensor(i % 40)
+
+    plain = [b[1].tolist() for b in torch.utils.data.DataLoader(Counting(), batch_size=3, shuffle=False)]
+    for world in (1, 2, 3):
+        got = {}
+        for rank in range(world):
+            ds = Counting()
+            loader = rank_loader(ds, 3, rank=rank, world=world)
+            assert loader.rank_sharded and len(loader) == len(shard_indices(4, rank, world))
+            mine = [b[1].tolist() for b in loader]
+            assert sorted(ds.seen) == sorted(sum(mine, []))  # nothing outside this rank's batches was read
+            for j, b in zip(shard_indices(4, rank, world), mine):
+                got[j] = b
+        assert [got[j] for j in range(4)] == plain
+    assert list(RankBatchSampler(0, 3, 0, 2)) == []

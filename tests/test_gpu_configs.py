@@ -1,0 +1,313 @@
+"""BASELINE.json configs 3, 4 and 5 at workload size on the GPU, against the CPU oracle.
+
+cfg3  ModelNet40-shaped 1024-point clouds, DGCNN victim (k = 5, eval.py:48), one rank's shard of 32 clouds
+cfg4  ShapeNetPart-shaped 2048-point clouds, batch 64, PointNet++ SSG victim
+cfg5  1024-point clouds, batch 32, PCT victim under the AdvPC + kNN + AOF sweep (CW/AdvPC.py, CW/kNN.py, CW/AOF.py)
+
+The oracle (oracle/hitadv_oracle.py) drives the victims' plain nn.Module on the CPU with the reference's own sampling /
+grouping arithmetic (oracle/victim_geometry.py; pinned to fixtures g10-g12 in tests/test_dgcnn.py and
+tests/test_victims_cpu.py).  Short runs: the trajectories are chaotic over hundreds of Adam steps, not over a handful.
+Every tolerance is what the comparison needs, stated where it is asserted; what was ACHIEVED is recorded by
+helpers.close() into gpurun_out/parity_report_gpu.json.
+"""
+import argparse
+import contextlib
+import copy
+import io
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, synth_batch
+from oracle import c_oracle as N
+from oracle import hitadv_oracle as O
+from oracle import victim_geometry as VG
+
+pytestmark = pytest.mark.gpu
+
+HP = dict(attack_lr=1e-2, init_weight=10., max_weight=80., cd_weight=1e-4, ker_weight=1., hide_weight=1.,
+          curv_loss_knn=16, central_num=192, total_central_num=256, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+
+
+def _shake_bn(model, spread=0.1):
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                mod.running_mean.normal_(0, spread)
+                mod.running_var.uniform_(0.7, 1.3)
+    return model
+
+
+def _labels(model, data):
+    with torch.no_grad():
+        out = model(data[:, :, :3].transpose(1, 2).contiguous())
+    return (out[0] if isinstance(out, tuple) else out).argmax(1)
+
+
+class _Iterates:
+    """Wraps an attacker's iteration: the deformed clouds and predictions of every pass (eager loop)."""
+
+    def __init__(self, att):
+        self.rows, self.inner = [], att._iteration
+        att._iteration = self
+
+    def __call__(self, ws):
+        self.inner(ws)
+        torch.cuda.synchronize()
+        self.rows.append(dict(adv=ws.adv.cpu().numpy().copy(), pred=ws.state['pred'].cpu().numpy().copy()))
+
+
+def test_cfg3_dgcnn_batch32_hit_adv_vs_cpu_oracle():
+    """One rank's shard of cfg3: B = 32, N = 1024, DGCNN(k=5).  Same 192 centres per cloud as the oracle, iterates of a
+    five-iteration run against the oracle's, graph run == eager run."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.dgcnn import DGCNN_cls
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(11)
+    cpu_model = _shake_bn(DGCNN_cls(argparse.Namespace(k=5, emb_dims=1024, dropout=0.2), output_channels=40).eval())
+    data, _ = synth_batch(32, 1024, first=8000)
+    label = _labels(cpu_model, data)
+    hp = dict(binary_step=1, num_iter=5, **HP)
+    trace = []
+    oracle = O.HiTADVOracle(cpu_model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), **hp)
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obest, osucc = oracle.attack(data, label, trace=trace)
+
+    att = HiT_ADV(copy.deepcopy(cpu_model), UntargetedLogitsAdvLoss(30.), verbose=False, use_graph=False, **hp)
+    rec = _Iterates(att)
+    torch.manual_seed(3)
+    best, succ = att.attack(data, label)
+    assert att._view is not None  # the folded EdgeConv view (csrc: knn_features, edge_max, lrelu_pool) is what ran
+    ws = next(iter(att._ws.values()))
+    same = (ws.central.cpu() == oracle.state['central']).all(dim=1).float().mean().item()
+    # the centre ranking uses 0.001 * normalised saliency: a victim gradient that differs in its last bits (the view
+    # re-associates EdgeConv; feature-space neighbour near-ties) may swap two all-but-tied candidates
+    assert same >= 0.995, same
+    # fp32 feature-space kNN near-ties route a few gradients differently (see test_dgcnn.py): 5 Adam steps of
+    # lr 0.05 / 0.03 on slightly different gradients
+    for i, row in enumerate(rec.rows):
+        close(row['adv'], trace[i]['adv'], rtol=1e-2, atol=3e-3, what='cfg3 iterate %d' % i)
+        assert (row['pred'] == trace[i]['pred']).mean() >= 0.9
+    close(best, obest, rtol=1e-2, atol=3e-3, what='cfg3 result')
+    att = HiT_ADV(copy.deepcopy(cpu_model), UntargetedLogitsAdvLoss(30.), verbose=False, use_graph=True, **hp)
+    torch.manual_seed(3)
+    gbest, gsucc = att.attack(data, label)
+    assert att.last_graph_used and np.array_equal(gbest, best) and int(gsucc) == int(succ)  # no float atomics left
+
+
+def _record_tables(mod, names):
+    """Record the index tables the named geometry functions of ``mod`` return (GPU run), for replay in float64."""
+    log = {n: [] for n in names}
+    saved = {n: getattr(mod, n) for n in names}
+
+    def wrap(n):
+        def f(*a, **k):
+            out = saved[n](*a, **k)
+            log[n].append(out.detach().cpu())
+            return out
+        return f
+    for n in names:
+        setattr(mod, n, wrap(n))
+    return log, saved
+
+
+def _replay_tables(mod, log):
+    saved = {n: getattr(mod, n) for n in log}
+    its = {n: iter(rows) for n, rows in log.items()}
+    for n in log:
+        setattr(mod, n, (lambda n: lambda *a, **k: next(its[n]))(n))
+    return saved
+
+
+def _restore(mod, saved):
+    for n, f in saved.items():
+        setattr(mod, n, f)
+
+
+def test_cfg4_pointnet2_batch64_2048_points_tables_and_float64_module():
+    """cfg4's forward / input gradient at B = 64, N = 2048: FPS tables bit-exact against the C oracle on the same
+    start indices, ball-query tables against the reference's Gram-form rule (boundary points within fp32 noise of the
+    sphere may differ), logits and input gradient against the float64 module evaluated on the SAME tables."""
+    from hit_adv_amd.model import _sampling
+    from hit_adv_amd.model import pointnet2 as P2
+    torch.manual_seed(13)
+    m = _shake_bn(P2.get_model(16, normal_channel=False).eval())  # ShapeNetPart: 16 object categories
+    data, _ = synth_batch(64, 2048, first=9000)
+    x = data[:, :, :3].transpose(1, 2).contiguous()
+    gm = copy.deepcopy(m).cuda()
+    torch.manual_seed(17)
+    feed = _sampling.feed_for(gm, 64, 2048, 1, 'cuda')
+    log, saved = _record_tables(P2, ['farthest_point_sample', 'query_ball_point'])
+    try:
+        xg = x.cuda().requires_grad_()
+        with _sampling.using(feed):
+            logits, _ = gm(xg)
+        w = torch.randn(64, 16, generator=torch.Generator().manual_seed(4))
+        (logits * w.cuda()).sum().backward()
+    finally:
+        _restore(P2, saved)
+    fps1, fps2 = log['farthest_point_sample']
+    ball1, ball2 = log['query_ball_point']
+    starts = feed.table.cpu()[0]  # [2, B]
+    pts = x.transpose(1, 2).contiguous()
+    assert torch.equal(fps1, N.fps_from_start(pts, 512, starts[0]))
+    l1_xyz = VG.index_points(pts, fps1)
+    assert torch.equal(fps2, N.fps_from_start(l1_xyz, 128, starts[1]))
+    ref1 = VG.query_ball_point(0.2, 32, pts, l1_xyz)
+    ref2 = VG.query_ball_point(0.4, 64, l1_xyz, VG.index_points(l1_xyz, fps2))
+    assert (ball1 != ref1).float().mean().item() < 1e-3 and (ball2 != ref2).float().mean().item() < 1e-3
+    md = copy.deepcopy(m).double()
+    saved = _replay_tables(P2, log)
+    try:
+        xd = x.double().requires_grad_()
+        ld, _ = md(xd)
+        (ld * w.double()).sum().backward()
+    finally:
+        _restore(P2, saved)
+    close(logits, ld, rtol=1e-4, atol=1e-5, what='cfg4 logits vs float64 module')
+    scale = float(xd.grad.abs().max())
+    close(xg.grad, xd.grad, rtol=1e-3, atol=1e-5 * scale, what='cfg4 input gradient vs float64 module')
+
+
+def test_cfg4_pointnet2_batch64_hit_adv_vs_cpu_oracle_and_graph():
+    """HiT-ADV on cfg4 (B = 64, N = 2048, PointNet++ SSG): two iterations against the CPU oracle (same random draws in
+    the reference's order: the victim's FPS starts come from the attack's pre-drawn feed), and the loop is captured."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model import pointnet2 as P2
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(13)
+    cpu_model = _shake_bn(P2.get_model(16, normal_channel=False).eval())
+    data, _ = synth_batch(64, 2048, first=9000)
+    victim = VG.CpuVictim(cpu_model)
+    torch.manual_seed(2)
+    label = _labels(victim, data)
+    hp = dict(binary_step=1, num_iter=2, **HP)
+    trace = []
+    oracle = O.HiTADVOracle(victim, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), **hp)
+    torch.manual_seed(7)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obest, osucc = oracle.attack(data, label, trace=trace)
+    att = HiT_ADV(copy.deepcopy(cpu_model), UntargetedLogitsAdvLoss(30.), verbose=False, use_graph=False, **hp)
+    rec = _Iterates(att)
+    torch.manual_seed(7)
+    best, succ = att.attack(data, label)
+    ws = next(iter(att._ws.values()))
+    assert ws.feed is not None and ws.feed.table.shape == (2, 2, 64)
+    same = (ws.central.cpu() == oracle.state['central']).all(dim=1).float().mean().item()
+    assert same >= 0.995, same
+    # boundary points of the ball query (Gram form in the reference, direct form here) change a few groups
+    for i, row in enumerate(rec.rows):
+        close(row['adv'], trace[i]['adv'], rtol=5e-3, atol=2e-3, what='cfg4 iterate %d' % i)
+    close(best, obest, rtol=5e-3, atol=2e-3, what='cfg4 result')
+    att = HiT_ADV(copy.deepcopy(cpu_model), UntargetedLogitsAdvLoss(30.), verbose=False, use_graph='always',
+                  binary_step=1, num_iter=4, **HP)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')  # "not capturable, running the eager loop" would be a failure here
+        torch.manual_seed(7)
+        gbest, _ = att.attack(data, label)
+    assert att.last_graph_used and np.isfinite(gbest).all()
+
+
+class _ToyAE(torch.nn.Module):
+    """Point-wise auto-encoder stand-in (the reference ships no auto-encoder for AdvPC): [B,3,K] -> [B,3,K]."""
+
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.Conv1d(3, 16, 1)
+        self.dec = torch.nn.Conv1d(16, 3, 1)
+
+    def forward(self, x):
+        return x + 0.05 * self.dec(torch.tanh(self.enc(x)))
+
+
+def _pct():
+    from hit_adv_amd.model import pct as PCT
+    torch.manual_seed(19)
+    return _shake_bn(PCT.Pct(argparse.Namespace(dropout=0.2), output_channels=40).eval())
+
+
+def _direct_chamfer_knn(adv, ori):
+    P = O.pairwise_sqdist_direct(ori, adv)
+    cham = P.min(dim=1).values.mean(dim=1)
+    S = torch.sort(O.pairwise_sqdist_direct(adv, adv), dim=-1, stable=True).values[..., 1:6].mean(-1)
+    with torch.no_grad():
+        mask = (S > (S.mean(-1) + 1.05 * S.std(-1))[:, None]).float()
+    return cham * 5. + (S * mask).mean(1) * 3.
+
+
+@pytest.mark.parametrize("which", ["advpc", "knn", "aof"])
+def test_cfg5_pct_batch32_cw_sweep_vs_cpu_oracle(which):
+    """cfg5 at B = 32, N = 1024 with the real PCT victim: each attack of the sweep for a few iterations against its oracle
+    restatement (O.cw_family_attack / O.cw_knn_attack / O.cw_aof_attack) driving the plain PCT module on the CPU."""
+    from hit_adv_amd import CW
+    from hit_adv_amd.util.adv_utils import LogitsAdvLoss, UntargetedLogitsAdvLoss
+    from hit_adv_amd.util.clip_utils import ClipPointsLinf
+    from hit_adv_amd.util.dist_utils import ChamferkNNDist, L2Dist
+    cpu_model = _pct()
+    victim = VG.CpuVictim(cpu_model)
+    data, _ = synth_batch(32, 1024, first=10000)
+    xyz = data[:, :, :3].contiguous()
+    torch.manual_seed(1)
+    label = _labels(victim, xyz)
+    target = (label + 1) % 40
+    clip_o = lambda pc, ori: O.clip_points_linf(pc, ori, 0.18)  # noqa: E731
+    trace, otrace = [], []
+    clip = ClipPointsLinf(budget=0.18)
+
+    def recording_clip(pc, ori):
+        out = clip(pc, ori)
+        trace.append(out.detach().cpu().numpy().copy())
+        return out
+
+    gpu_model = copy.deepcopy(cpu_model)
+    iters = 6
+    # PCT's sampler: the reference maximises sqrt(clamped Gram distance), the HIP FPS the direct-form squared distance --
+    # the same arg-max except for fp32 near-ties, after which the two sample different subsets (fixture g12: < 2 % of the
+    # table); plus Adam's sign-like first steps.  Hence an envelope of the step size, and a tight bound on the MEDIAN.
+    if which == "knn":
+        att = CW.CWKNN(gpu_model, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), recording_clip, attack_lr=1e-2,
+                       num_iter=iters, verbose=False)
+        torch.manual_seed(23)
+        final, succ = att.attack(xyz, target)
+        torch.manual_seed(23)
+        ofinal, osucc = O.cw_knn_attack(victim, lambda l, t: O.logits_adv_loss(l, t, 15.), _direct_chamfer_knn, clip_o,
+                                        xyz, target, attack_lr=1e-2, num_iter=iters, trace=otrace)
+        orows = [r['adv'] for r in otrace]
+        lr = 1e-2
+    elif which == "advpc":
+        torch.manual_seed(5)
+        ae = _ToyAE().eval()
+        att = CW.CWAdvPC(gpu_model, copy.deepcopy(ae), LogitsAdvLoss(kappa=0.), L2Dist(), attack_lr=1e-2, binary_step=1,
+                         num_iter=iters, GAMMA=0.25, clip_func=recording_clip, verbose=False)
+        torch.manual_seed(23)
+        bestdist, final, succ = att.attack(xyz, target, label)
+        torch.manual_seed(23)
+        obest, ofinal, osucc = O.cw_family_attack(victim, lambda l, t: O.logits_adv_loss(l, t, 0.), clip_o, xyz, target,
+                                                  y_truth=label, ae_model=ae, targeted=True, fresh=True, attack_lr=1e-2,
+                                                  binary_step=1, num_iter=iters, GAMMA=0.25, trace=otrace)
+        orows = [r['adv'] for r in otrace]
+        lr = 1e-2
+    else:
+        att = CW.CWAOF(gpu_model, UntargetedLogitsAdvLoss(kappa=30.), L2Dist(), attack_lr=1e-2, binary_step=1,
+                       num_iter=iters, GAMMA=0.25, low_pass=100, clip_func=recording_clip, verbose=False)
+        torch.manual_seed(23)
+        final, succ = att.attack(xyz, label)
+        torch.manual_seed(23)
+        ofinal, osucc = O.cw_aof_attack(victim, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), clip_o, xyz, label,
+                                        attack_lr=1e-2, binary_step=1, num_iter=iters, GAMMA=0.25, low_pass=100,
+                                        trace=otrace)
+        orows = [r['adv'] for r in otrace]
+        lr = 1e-2
+    rows = trace[:iters]
+    assert len(rows) == iters and len(orows) >= iters
+    ori = xyz.transpose(1, 2).numpy()
+    for i in range(iters):
+        err = np.abs(rows[i] - orows[i])
+        assert np.abs(rows[i] - ori).max() <= 0.18 + 1e-6
+        assert err.max() <= 2 * lr * (i + 1) + 1e-6, (i, err.max())        # Adam's reach
+        assert np.median(err) <= 2e-4, (i, float(np.median(err)))           # the bulk of the cloud follows the oracle
+        close(np.median(err), 0., rtol=0, atol=2e-4, what='cfg5 %s iterate %d: median |gpu - oracle|' % (which, i))
+    assert final.shape == ofinal.shape and abs(int(succ) - int(osucc)) <= 2
