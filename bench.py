@@ -218,6 +218,19 @@ def hot_loop_kernels(dev, B=32, N=1024):
     out["linear_max_fwd"] = {"bound": "mfma", "us_per_launch": us, "achieved": round(flops / us / 1e6, 1),
                              "peak": F32_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(flops / us / 1e6 / F32_MFMA_PEAK, 4),
                              "dtype": "f32", "flops_per_launch": flops}
+    # the form the loop runs by default: both operands as three bf16 pieces, six bf16 MFMAs per 16 values of k in an
+    # fp32 accumulator (fp32-accurate; csrc/victim_bf3.hip).  Priced against the SAME 2*B*N*Cin*Cout useful flops; the
+    # matrix cores execute 6/8 x 16 = 12x fewer cycles per useful flop than the f32 MFMA form would
+    W3 = torch.empty(3, 1024, 128, device=dev, dtype=torch.int16)
+    lib.hitadv_split_weights_bf16x3(_p(Wt.t().contiguous()), 1024, 128, _p(W3), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    n3 = lib.hitadv_linear_max_fwd_bf16x3_scratch(B, N, 1024)
+    pv3, pi3 = torch.empty(n3, device=dev), torch.empty(n3, device=dev, dtype=torch.int32)
+    us3 = round(graph_timed(lambda st: lib.hitadv_linear_max_fwd_bf16x3(_p(h2), _p(W3), _p(bias), B, N, 128, 1024, 1, _p(pv3),
+                                                                        _p(pi3), _p(mo), _p(mi), _p(tk), st)), 2)
+    out["linear_max_fwd_bf16x3"] = {"bound": "mfma", "us_per_launch": us3, "useful_tflops": round(flops / us3 / 1e6, 1),
+                                    "executed_bf16_tflops": round(6 * flops / us3 / 1e6, 1), "peak_bf16": 2500.0,
+                                    "frac_of_bf16_peak": round(6 * flops / us3 / 1e6 / 2500.0, 4), "dtype": "3 x bf16 -> f32",
+                                    "flops_per_launch": flops}
     return out
 
 

@@ -64,7 +64,9 @@ class _Workspace:
                           dist_val=torch.zeros(B, **f))
         self.adv_loss = torch.zeros((), **f)
         self.dist_loss = torch.zeros((), **f)
-        self.graph = None
+        self.graph = None       # one inner iteration
+        self.graph_many = None  # `chunk` inner iterations (see HiT_ADV._chunk)
+        self.chunk = 1
         self.feed = None  # pre-drawn FPS starts of a sampling victim (set per attack by _setup)
         # buffers of the autograd-free iteration (_iteration_fused)
         self.inv_den = torch.empty(B, N, **f)
@@ -88,7 +90,8 @@ class HiT_ADV:
     def __init__(self, model, adv_func, attack_lr=1e-2, init_weight=10., max_weight=80., binary_step=10,
                  num_iter=500, clip_func=None, cd_weight=0, curv_weight=0, ker_weight=0, hide_weight=0,
                  curv_loss_knn=32, central_num=32, total_central_num=128, max_sigm=0.7, min_sigm=0.1,
-                 budget=0.1, alpha=1, use_graph='auto', verbose=True, fast_victim=True, fused_regulariser=True):
+                 budget=0.1, alpha=1, use_graph='auto', verbose=True, fast_victim=True, fused_regulariser=True,
+                 iterations_per_graph='auto'):
         self.model = model.cuda()
         self.model.eval()
         self.adv_func = adv_func
@@ -113,6 +116,7 @@ class HiT_ADV:
         self.verbose = verbose
         self.fast_victim = fast_victim
         self.fused_regulariser = fused_regulariser
+        self.iterations_per_graph = iterations_per_graph  # 'auto': what the victim's view asks for (PointNet engine: 10)
         self._view = None
         self._chamfer = ChamferDist()
         self._ws = {}
@@ -305,6 +309,16 @@ class HiT_ADV:
             torch.cuda.synchronize()
         return reason
 
+    def _chunk(self):
+        """Inner iterations recorded into the second, longer hipGraph of a workspace.  A graph launch costs the host
+        ~0.1 ms for the ~40 kernels of a PointNet iteration; with three attacks in flight that is the whole iteration
+        time, i.e. the host -- not the GPU -- paces the loop.  Replaying u iterations per launch divides that cost by u;
+        the single-iteration graph serves the iterations whose state the host reads back (progress lines) and remainders."""
+        want = self.iterations_per_graph
+        if want == 'auto':
+            want = getattr(self._view, 'iterations_per_graph', 1) if self._view is not None else 1
+        return max(1, min(int(want), self.num_iter))
+
     def _prepare_graphs(self, wss):
         """Warm up every workspace, THEN capture one hipGraph per workspace (``_iteration`` on its stream).
 
@@ -313,7 +327,7 @@ class HiT_ADV:
         (measured).  So all eager work of all workspaces comes first, graphs are captured
         last, and they are not kept across attack() calls (capturing costs ~0.1 s against seconds of replays)."""
         for ws in wss:
-            ws.graph = None
+            ws.graph = ws.graph_many = None
         if self.use_graph in (False, 'never') or self.num_iter * self.binary_step == 0:
             return
         reason = None
@@ -321,17 +335,24 @@ class HiT_ADV:
             reason = reason or self._warm_up(ws)
         if reason is None:
             try:
+                chunk = self._chunk()
                 for ws in wss:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=ws.stream):
                         self._iteration(ws)
-                    ws.graph = g
+                    ws.graph, ws.graph_many, ws.chunk = g, None, 1
+                    if chunk > 1:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=ws.stream):
+                            for _ in range(chunk):
+                                self._iteration(ws)
+                        ws.graph_many, ws.chunk = g, chunk
                 return
             except Exception as e:  # noqa: BLE001
                 reason = e
                 torch.cuda.synchronize()
                 for ws in wss:
-                    ws.graph = None
+                    ws.graph = ws.graph_many = None
         if self.use_graph is True or self.use_graph == 'always':
             raise RuntimeError("the HiT-ADV iteration cannot be captured into a hipGraph: %r" % (reason,))
         warnings.warn("the HiT-ADV iteration is not hipGraph-capturable (%r); running the eager loop" % (reason,))
@@ -404,11 +425,17 @@ class HiT_ADV:
         ws.adv_loss.zero_()
         ws.dist_loss.zero_()
         report_every = max(1, self.num_iter // 5)
-        for iteration in range(self.num_iter):
+        iteration = 0
+        while iteration < self.num_iter:
             report = verbose and iteration % report_every == 0
             if report:
                 prev = (ws.adv_loss.item(), ws.dist_loss.item())
-            if ws.graph is not None:
+            # iterations that may run before the host next looks at the state: a reported iteration runs on its own
+            until = self.num_iter if not verbose else min(self.num_iter, (iteration // report_every + 1) * report_every)
+            many = (not report) and ws.graph_many is not None and until - iteration >= ws.chunk
+            if many:
+                ws.graph_many.replay()
+            elif ws.graph is not None:
                 ws.graph.replay()
             else:
                 self._iteration(ws)
@@ -417,6 +444,7 @@ class HiT_ADV:
                 print('Step {}, iteration {}, success {}/{}\n'
                       'adv_loss: {:.4f}, dist_loss: {:.4f}'.format(binary_step, iteration, success_num, B,
                                                                    prev[0], prev[1]))
+            iteration += ws.chunk if many else 1
         with torch.no_grad():  # (:264-273), on device
             ok = ((st["bestscore"] != ws.target) & (st["bestscore"] != -1)
                   & (st["bestdist"] <= st["o_bestdist"]))

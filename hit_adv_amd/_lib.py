@@ -16,9 +16,9 @@ _P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
 PROTOTYPES = {
     "hitadv_version": [],
     "hitadv_pairwise_sqdist": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "hitadv_nn_min": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "hitadv_nn_min": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hitadv_nn_min_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
-    "hitadv_knn_points": [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
+    "hitadv_knn_points": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "hitadv_knn_points_bwd": [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P],
     "hitadv_topk_rows": [_P, _L, _I, _I, _I, _P, _P, _P],
     "hitadv_deform_fwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
@@ -48,6 +48,9 @@ PROTOTYPES = {
     "hitadv_max_over_points_scratch": [_I, _I],
     "hitadv_linear_max_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hitadv_linear_max_fwd_scratch": [_I, _I, _I],
+    "hitadv_split_weights_bf16x3": [_P, _I, _I, _P, _P],
+    "hitadv_linear_max_fwd_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "hitadv_linear_max_fwd_bf16x3_scratch": [_I, _I, _I],
     "hitadv_pointnet_rowmlp_fwd": [_I] + [_P] * 13 + [_I, _I, _P],
     "hitadv_pointnet_rowmlp_tiles": [_I],
     "hitadv_pointnet_rowmlp_bwd": [_I, _P, _P, _P, _P, _I] + [_P] * 14 + [_I, _I, _P],
@@ -65,7 +68,7 @@ PROTOTYPES = {
     "hitadv_fc_layer_scratch_floats": [_I, _I, _I],
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,
-            "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_linear_max_fwd_scratch": _c.c_int64, "hitadv_pointnet_rowmlp_tiles": _c.c_int64, "hitadv_fc_layer_scratch_floats": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64,
+            "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_linear_max_fwd_scratch": _c.c_int64, "hitadv_linear_max_fwd_bf16x3_scratch": _c.c_int64, "hitadv_pointnet_rowmlp_tiles": _c.c_int64, "hitadv_fc_layer_scratch_floats": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64,
             "hitadv_edge_max_bwd_scratch_ints": _c.c_int64, "hitadv_group_add_relu_bwd_scratch_ints": _c.c_int64}
 
 _lib = None

@@ -11,13 +11,80 @@
     if (e__ != hipSuccess) return (int)e__;         \
   } while (0)
 
+// ---------------------------------------------------------------------------------------------------------------
+// Hand-off of split partials to the last block to arrive (fc_layer_k, linear_max_fwd_k, linear_max_fwd_bf3_k).
+//
+// gfx950 form (default): every partial is stored write-through (relaxed agent-scope atomic store = `sc1`), every storing
+// wave drains its stores (`s_waitcnt vmcnt(0)`), the workgroup meets at a barrier, ONE lane draws the ticket with a
+// relaxed agent-scope fetch_add, the other waves learn the outcome behind a second barrier, and the last workgroup reads
+// every partial with `sc1` loads (relaxed agent-scope atomic loads, which bypass the per-CU L1).  This is the first row
+// of the "Valid forms ... with sc1 loads in place of the acquire" table of MI355X_MICROARCH.md (measured on gfx950 /
+// ROCm 7.2, not an architectural guarantee); an agent-scope release here costs a whole-L2 write-back per publishing
+// block (34 us instead of 6.8 us for a 256-block layer).  tests/test_gpu_handoff.py stresses it under uneven load on
+// three streams.
+//
+// Portable form (-DHITADV_PORTABLE_HANDOFF): agent-scope RELEASE fence before the ticket, agent-scope ACQUIRE fence in the
+// last block before it reads -- what the HIP memory model asks for.  Any target other than gfx950 must use it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(HITADV_PORTABLE_HANDOFF)
+#error "the fence-free split hand-off is validated on gfx950 only: build other targets with -DHITADV_PORTABLE_HANDOFF"
+#endif
+#ifdef HITADV_PORTABLE_HANDOFF
+#define HITADV_HANDOFF_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define HITADV_HANDOFF_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define HITADV_HANDOFF_RELEASE() ((void)0)
+#define HITADV_HANDOFF_ACQUIRE() ((void)0)
+#endif
+
 namespace hitadv {
+
+// Drain this wave's stores, meet the workgroup, draw the ticket of `slot`; true in every thread of the workgroup whose
+// ticket was the last of `total`.  `flag` is a __shared__ int of the caller.
+__device__ __forceinline__ bool handoff_last_arriver(int *tickets, int slot, int total, int *flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores are acknowledged ...
+  __syncthreads();                                   // ... for every wave of the block, before its ticket is drawn
+  if (threadIdx.x == 0) {
+    HITADV_HANDOFF_RELEASE();
+    *flag = __hip_atomic_fetch_add(&tickets[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+  }
+  __syncthreads();
+  const bool last = *flag != 0;
+  if (last) HITADV_HANDOFF_ACQUIRE();
+  return last;
+}
 
 // Canonical squared distance: ((dx*dx + dy*dy) + dz*dz), one fp32 rounding per operation.
 // The translation unit is built with -ffp-contract=off so nothing here fuses into an FMA.
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
   float dx = ax - bx, dy = ay - by, dz = az - bz;
   return (dx * dx + dy * dy) + dz * dz;
+}
+
+// A squared distance as one of three fp32 expressions (include/hitadv.h, HITADV_FORM_*):
+//   0  direct       ((dx*dx + dy*dy) + dz*dz)                                 the project's canonical rule
+//   1  Gram         (|q|^2 + |p|^2) - 2 q.p, every dot product an FMA chain   _Distance.batch_pairwise_dist
+//                   fma(a2,b2, fma(a1,b1, a0*b0)) -- what the GEMM behind     (util/set_distance.py:15-32)
+//                   torch.bmm executes for a K = 3 inner dimension
+//   2  Gram (kNN)   (|p|^2 + (-2 q.p)) + |q|^2, q.p an FMA chain, |.|^2 a     KNNDist (util/dist_utils.py:148-150)
+//                   plain sum of squares ((a0*a0 + a1*a1) + a2*a2)
+// q = the row / query point, p = the column / reference point.  Forms 1 and 2 reproduce the reference's values bit for
+// bit (oracle/pointnet2_oracle.c::pair_value is checked against torch itself, tests/test_oracle_gram.py).
+__device__ __forceinline__ float dot3_fma(float ax, float ay, float az, float bx, float by, float bz) {
+  return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+
+template <int FORM>
+__device__ __forceinline__ float sq_norm(float x, float y, float z) {
+  if (FORM == 1) return dot3_fma(x, y, z, x, y, z);
+  return (x * x + y * y) + z * z;
+}
+
+template <int FORM>
+__device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float rq, float px, float py, float pz, float rp) {
+  if (FORM == 0) return sqdist3(qx, qy, qz, px, py, pz);
+  const float zz = dot3_fma(qx, qy, qz, px, py, pz);
+  if (FORM == 1) return fmaf(-2.0f, zz, rq + rp);  // 2*zz is exact, so this is (rq + rp) - 2*zz rounded once
+  return fmaf(-2.0f, zz, rp) + rq;                 // (rp + (-2*zz)) + rq
 }
 
 // Order-preserving key for non-negative floats (and +inf): the raw bit pattern.

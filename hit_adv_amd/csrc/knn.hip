@@ -1,10 +1,11 @@
-// K nearest neighbours (canonical rule: direct-difference fp32 squared distance, ascending,
-// ties -> lower index) and its backward.
+// K nearest neighbours (ascending, ties -> lower index; distances in one of the forms of common.hpp) and its backward.
 //
-//   K4  knn_topk<KB>   one lane per query and per quarter of the references (4 waves share 64 queries),
-//                      references broadcast from LDS (float4), a sorted
-//                      KB-entry insertion list per lane held entirely in VGPRs (compile-time
-//                      indices only, so nothing spills to scratch).  fp32-VALU-bound.
+//   K4  knn_select<KB>  K <= 32, M <= 2048: one lane per query and per quarter of the references (4 waves share 64
+//                       queries), references resident in LDS (float4).  Selection without a divergent insert: the KB
+//                       smallest DISTANCES are kept sorted in VGPRs by a branch-free v_med3_f32 chain, the INDEX of
+//                       every accepted candidate is appended to a per-lane log in LDS, and the few logged candidates
+//                       that survive are matched to their slots once, at the end.  fp32-VALU-bound.
+//       knn_topk<KB>    every other size: sorted (distance, index) insertion list per lane in VGPRs.
 #include "common.hpp"
 #include "hitadv.h"
 
@@ -18,7 +19,7 @@ constexpr int KNN_RCH = 1024;
 // the queries, is what quadruples the number of waves (2048 at B=32, N=1024) without shrinking a
 // query's work below one lane.  Ties: equal distances are ordered by reference index, in the lists
 // (ascending scan + stable insertion) and in the merge (explicit index compare).
-template <int KB, typename IdxT>
+template <int KB, int FORM, typename IdxT>
 __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, const float *__restrict__ p,
                                                 int N, int M, int K, float *__restrict__ dists,
                                                 IdxT *__restrict__ idx) {
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
   const bool live = i < N;
   const float *qp = q + ((size_t)b * N + (live ? i : N - 1)) * 3;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const float rq = sq_norm<FORM>(qx, qy, qz);
   p += (size_t)b * M * 3;
   float d[KB];
   int ix[KB];
@@ -72,14 +74,14 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
     __syncthreads();
     for (int r = threadIdx.x; r < cnt; r += 256) {
       const float *s = p + (size_t)(c0 + r) * 3;
-      sref[r] = make_float4(s[0], s[1], s[2], 0.f);
+      sref[r] = make_float4(s[0], s[1], s[2], sq_norm<FORM>(s[0], s[1], s[2]));
     }
     __syncthreads();
     const int per = KNN_RCH / 4;
     const int lo = wave * per, hi = min(lo + per, cnt);
     for (int r = lo; r < hi; ++r) {
       const float4 v = sref[r];
-      const float c = sqdist3(qx, qy, qz, v.x, v.y, v.z);
+      const float c = pair_dist<FORM>(qx, qy, qz, rq, v.x, v.y, v.z, v.w);
       // Accepted candidates (closer than the current KB-th best) are parked in a BUF-deep per-lane shift
       // register; the expensive sorted insert runs only when some lane's register is full.  The insert body is
       // executed by the whole wave whenever ANY lane needs it, so batching it per BUF accepted candidates of the
@@ -137,6 +139,163 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
     od[t] = bd;
     oi[t] = (IdxT)bi;
     // advance the winning list
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (bw == w) {
+        pos[w] += 1;
+        const bool more = pos[w] < KB;
+        const int a = (w * KB + (more ? pos[w] : KB - 1)) * 64 + lane;
+        hd[w] = more ? md[a] : __builtin_inff();
+        hi4[w] = more ? mi[a] : 0x7fffffff;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ K4 (K <= 32, M <= 2048)
+// Why not a sorted (distance, index) insertion list: its body (4 VALU instructions per slot) is executed by the whole wave
+// whenever ANY of the 64 lanes accepts a candidate, which for K >= 5 is at almost every reference -- the r01 kernel spent
+// ~110 instructions per reference at K = 17.  Here a reference costs the distance, KB v_med3_f32 (new L[s] =
+// med3(L[s-1], c, L[s]) keeps the KB smallest distances sorted, no branch, no index) and one masked 2-byte LDS store.
+//   * acceptance is strict (c < L[KB-1]) and the scan ascends in reference index, so of equal distances the lower
+//     indices are the ones that get in;
+//   * a lane's log holds every candidate it ever accepted, in ascending index; the final K best are among them (the
+//     threshold only falls).  When a log fills up (KS_CAP >= 2 KB entries) it is compacted in place to the entries that
+//     can still matter (distance <= current threshold: at most KB-1 below it and KB equal to it);
+//   * at the end the surviving entries are matched to the slots of the sorted distance list (equal distances: in log =
+//     index order), distances re-evaluated from the LDS-resident references with the same expression, bit for bit;
+//   * the four waves' lists meet in LDS and wave 0 merges them (K steps, index compare on equal distances).
+__host__ __device__ constexpr int ks_cap(int KB) { return KB <= 8 ? 32 : (KB <= 16 ? 64 : 96); }
+__host__ __device__ constexpr size_t ks_union_bytes(int KB) {
+  return (size_t)4 * 64 * (ks_cap(KB) * 2 > KB * 8 ? ks_cap(KB) * 2 : KB * 8);
+}
+
+template <int KB, int FORM>
+__global__ __launch_bounds__(256) void knn_select(const float *__restrict__ q, const float *__restrict__ p, int N, int M,
+                                                  int K, float *__restrict__ dists, void *__restrict__ idx_out,
+                                                  int idx_is_i64) {
+  constexpr int CAP = ks_cap(KB);
+  extern __shared__ __attribute__((aligned(16))) char ks_smem[];
+  const int Mpad = (M + 3) & ~3;
+  float4 *sref = reinterpret_cast<float4 *>(ks_smem);                                  // [Mpad]
+  unsigned short *slog = reinterpret_cast<unsigned short *>(ks_smem + (size_t)Mpad * 16);  // [4][CAP][64]
+  float *md = reinterpret_cast<float *>(ks_smem + (size_t)Mpad * 16);                  // after the scan: [4][KB][64]
+  int *mi = reinterpret_cast<int *>(md + 4 * KB * 64);
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < N;
+  const float *qp = q + ((size_t)b * N + (live ? i : N - 1)) * 3;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const float rq = sq_norm<FORM>(qx, qy, qz);
+  p += (size_t)b * M * 3;
+  for (int r = threadIdx.x; r < M; r += 256) {
+    const float *s = p + (size_t)r * 3;
+    sref[r] = make_float4(s[0], s[1], s[2], sq_norm<FORM>(s[0], s[1], s[2]));
+  }
+  __syncthreads();
+  float L[KB];
+#pragma unroll
+  for (int t = 0; t < KB; ++t) L[t] = __builtin_inff();
+  unsigned short *mylog = slog + (size_t)wave * CAP * 64 + lane;
+  int cnt = 0;
+  auto dist_of = [&](int j) {
+    const float4 v = sref[j];
+    return pair_dist<FORM>(qx, qy, qz, rq, v.x, v.y, v.z, v.w);
+  };
+  auto compact = [&]() {  // keep the logged candidates that can still be among the K best, in order
+    const float tau = L[KB - 1];
+    int w = 0;
+    for (int e = 0; e < CAP; ++e) {
+      if (e < cnt) {
+        const int j = mylog[e * 64];
+        if (dist_of(j) <= tau) {
+          mylog[w * 64] = (unsigned short)j;
+          ++w;
+        }
+      }
+    }
+    cnt = w;
+  };
+  const int per = (M + 3) >> 2;
+  const int lo = wave * per, hi = min(lo + per, M);
+  for (int r0 = lo; r0 < hi; r0 += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = sref[min(r0 + u, hi - 1)];  // four LDS reads in flight before the first log store
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r0 + u < hi) {  // wave-uniform
+        const float c = pair_dist<FORM>(qx, qy, qz, rq, v[u].x, v[u].y, v[u].z, v[u].w);
+        const bool acc = c < L[KB - 1];
+#pragma unroll
+        for (int t = KB - 1; t > 0; --t) L[t] = __builtin_amdgcn_fmed3f(L[t - 1], c, L[t]);
+        L[0] = __builtin_amdgcn_fmed3f(-__builtin_inff(), c, L[0]);  // = min(c, L[0]) in one instruction
+        if (acc) {
+          mylog[cnt * 64] = (unsigned short)(r0 + u);
+          ++cnt;
+        }
+        if (__builtin_amdgcn_ballot_w64(cnt >= CAP)) compact();
+      }
+    }
+  }
+  // the survivors, matched to their slots (entries of equal distance fill equal slots in log = index order)
+  compact();
+  int I[KB];
+#pragma unroll
+  for (int t = 0; t < KB; ++t) I[t] = 0x7fffffff;
+  int most = cnt;  // wave-uniform trip count: the longest surviving log (<= 2 KB - 1)
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) most = max(most, __shfl_xor(most, m, 64));
+  most = __builtin_amdgcn_readfirstlane(most);
+  for (int e = 0; e < most; ++e) {
+    const bool on = e < cnt;
+    const int j = on ? (int)mylog[e * 64] : 0;
+    const float c = dist_of(j);
+    bool placed = !on;
+#pragma unroll
+    for (int t = 0; t < KB; ++t) {
+      const bool hit = !placed && c == L[t] && I[t] == 0x7fffffff;
+      I[t] = hit ? j : I[t];
+      placed = placed || hit;
+    }
+  }
+  __syncthreads();  // every wave is done with its log: the area becomes the merge buffers
+#pragma unroll
+  for (int t = 0; t < KB; ++t) {
+    md[(wave * KB + t) * 64 + lane] = L[t];
+    mi[(wave * KB + t) * 64 + lane] = I[t];
+  }
+  __syncthreads();
+  if (wave != 0 || !live) return;
+  int pos[4] = {0, 0, 0, 0};
+  float hd[4];
+  int hi4[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    hd[w] = md[(w * KB) * 64 + lane];
+    hi4[w] = mi[(w * KB) * 64 + lane];
+  }
+  float *od = dists + ((size_t)b * N + i) * K;
+  int64_t *o64 = reinterpret_cast<int64_t *>(idx_out) + ((size_t)b * N + i) * K;
+  int32_t *o32 = reinterpret_cast<int32_t *>(idx_out) + ((size_t)b * N + i) * K;
+  for (int t = 0; t < K; ++t) {
+    int bw = 0;
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const bool take = hd[w] < hd[bw] || (hd[w] == hd[bw] && hi4[w] < hi4[bw]);
+      bw = take ? w : bw;
+    }
+    float bd = hd[0];
+    int bi = hi4[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      bd = bw == w ? hd[w] : bd;
+      bi = bw == w ? hi4[w] : bi;
+    }
+    od[t] = bd;
+    if (idx_is_i64) o64[t] = bi;
+    else o32[t] = bi;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       if (bw == w) {
@@ -278,30 +437,64 @@ __global__ __launch_bounds__(256) void knn_bwd_p(const float *__restrict__ q, co
   }
 }
 
-template <typename IdxT>
-static int launch_knn(const float *q, const float *p, int B, int N, int M, int K, float *dists, IdxT *idx,
-                      hipStream_t s) {
+template <int FORM, typename IdxT>
+static int launch_knn_topk(const float *q, const float *p, int B, int N, int M, int K, float *dists, IdxT *idx,
+                           hipStream_t s) {
   dim3 grid((N + 63) / 64, B);
 #define HITADV_KNN_CASE(KB)                                                                          \
   if (K <= KB) {                                                                                     \
     const size_t shm = (size_t)8 * KB * 64 * sizeof(float);                                          \
     if (shm > 48 * 1024)                                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_topk<KB, IdxT>),                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_topk<KB, FORM, IdxT>),           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);               \
-    knn_topk<KB, IdxT><<<grid, 256, shm, s>>>(q, p, N, M, K, dists, idx);                            \
+    knn_topk<KB, FORM, IdxT><<<grid, 256, shm, s>>>(q, p, N, M, K, dists, idx);                      \
     return 0;                                                                                        \
   }
-  HITADV_KNN_CASE(1)
-  HITADV_KNN_CASE(4)
-  HITADV_KNN_CASE(8)
-  HITADV_KNN_CASE(12)
-  HITADV_KNN_CASE(16)
-  HITADV_KNN_CASE(20)
-  HITADV_KNN_CASE(24)
-  HITADV_KNN_CASE(32)
-  HITADV_KNN_CASE(48)
+  if (FORM == 0) {
+    HITADV_KNN_CASE(4)
+    HITADV_KNN_CASE(8)
+    HITADV_KNN_CASE(16)
+    HITADV_KNN_CASE(32)
+  } else {
+    HITADV_KNN_CASE(8)
+  }
   HITADV_KNN_CASE(64)
 #undef HITADV_KNN_CASE
+  return HITADV_E_ARG;
+}
+
+template <int FORM>
+static int launch_knn_select(const float *q, const float *p, int B, int N, int M, int K, float *dists, void *idx,
+                             int idx_is_i64, hipStream_t s) {
+  dim3 grid((N + 63) / 64, B);
+  const size_t refs = (size_t)((M + 3) & ~3) * 16;
+#define HITADV_KS_CASE(KB)                                                                                     \
+  if (K <= KB) {                                                                                               \
+    const size_t shm = refs + ks_union_bytes(KB);                                                              \
+    static int raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_select<KB, FORM>),             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + (int)ks_union_bytes(KB)); \
+    (void)raised;                                                                                              \
+    knn_select<KB, FORM><<<grid, 256, shm, s>>>(q, p, N, M, K, dists, idx, idx_is_i64);                        \
+    return 0;                                                                                                  \
+  }
+  if (FORM == 0) {
+    HITADV_KS_CASE(1)
+    HITADV_KS_CASE(4)
+    HITADV_KS_CASE(5)
+    HITADV_KS_CASE(6)
+    HITADV_KS_CASE(8)
+    HITADV_KS_CASE(12)
+    HITADV_KS_CASE(16)
+    HITADV_KS_CASE(17)
+    HITADV_KS_CASE(20)
+    HITADV_KS_CASE(24)
+  } else {  // KNNDist calls with K = k + 1 = 5 or 6 (util/dist_utils.py:156)
+    HITADV_KS_CASE(5)
+    HITADV_KS_CASE(6)
+    HITADV_KS_CASE(16)
+  }
+  HITADV_KS_CASE(32)
+#undef HITADV_KS_CASE
   return HITADV_E_ARG;
 }
 
@@ -309,13 +502,23 @@ static int launch_knn(const float *q, const float *p, int B, int N, int M, int K
 
 using namespace hitadv;
 
-extern "C" int hitadv_knn_points(const float *q, const float *p, int B, int N, int M, int K, float *dists,
+extern "C" int hitadv_knn_points(const float *q, const float *p, int B, int N, int M, int K, int form, float *dists,
                                  void *idx, int idx_is_i64, void *stream) {
   if (!q || !p || !dists || !idx || B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > 64 || K > M)
     return HITADV_E_ARG;
+  if (form != HITADV_FORM_DIRECT && form != HITADV_FORM_GRAM_KNN) return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
-  int rc = idx_is_i64 ? launch_knn<int64_t>(q, p, B, N, M, K, dists, (int64_t *)idx, s)
-                      : launch_knn<int32_t>(q, p, B, N, M, K, dists, (int32_t *)idx, s);
+  int rc;
+  if (K <= 32 && M <= 2048) {
+    rc = form == HITADV_FORM_DIRECT ? launch_knn_select<0>(q, p, B, N, M, K, dists, idx, idx_is_i64, s)
+                                    : launch_knn_select<2>(q, p, B, N, M, K, dists, idx, idx_is_i64, s);
+  } else if (form == HITADV_FORM_DIRECT) {
+    rc = idx_is_i64 ? launch_knn_topk<0, int64_t>(q, p, B, N, M, K, dists, (int64_t *)idx, s)
+                    : launch_knn_topk<0, int32_t>(q, p, B, N, M, K, dists, (int32_t *)idx, s);
+  } else {
+    rc = idx_is_i64 ? launch_knn_topk<2, int64_t>(q, p, B, N, M, K, dists, (int64_t *)idx, s)
+                    : launch_knn_topk<2, int32_t>(q, p, B, N, M, K, dists, (int32_t *)idx, s);
+  }
   if (rc) return rc;
   HITADV_LAUNCH_CHECK();
   return 0;

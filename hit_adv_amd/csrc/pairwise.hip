@@ -13,15 +13,11 @@
 namespace hitadv {
 
 // ------------------------------------------------------------------------------------ K1
+// x = the row point (i), y = the column point (j); the three forms are defined in common.hpp
 template <int FORM>
 __device__ __forceinline__ float pair_value(float x0, float x1, float x2, float rx, float y0, float y1,
                                             float y2, float ry) {
-  if (FORM == HITADV_FORM_DIRECT) {
-    return sqdist3(x0, x1, x2, y0, y1, y2);
-  } else {
-    float zz = (x0 * y0 + x1 * y1) + x2 * y2;
-    return (rx + ry) - 2.0f * zz;
-  }
+  return pair_dist<FORM>(x0, x1, x2, rx, y0, y1, y2, ry);
 }
 
 constexpr int K1_ROWS = 32;  // 6.31 TB/s vs 6.02 at 16 rows (tools/tune/k1_tune.hip on MI355X)
@@ -41,18 +37,18 @@ __global__ __launch_bounds__(256) void pairwise3_vec4(const float *__restrict__ 
     xs[threadIdx.x * 4 + 0] = a;
     xs[threadIdx.x * 4 + 1] = c;
     xs[threadIdx.x * 4 + 2] = d;
-    xs[threadIdx.x * 4 + 3] = (a * a + c * c) + d * d;
+    xs[threadIdx.x * 4 + 3] = sq_norm<FORM>(a, c, d);
   }
   __syncthreads();
   if (j0 >= M) return;
   const float4 *yp = reinterpret_cast<const float4 *>(y + ((size_t)b * M + j0) * 3);
   const float4 ya = yp[0], yb = yp[1], yc = yp[2];  // (x0 y0 z0 x1)(y1 z1 x2 y2)(z2 x3 y3 z3)
   float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-  if (FORM == HITADV_FORM_GRAM) {
-    r0 = (ya.x * ya.x + ya.y * ya.y) + ya.z * ya.z;
-    r1 = (ya.w * ya.w + yb.x * yb.x) + yb.y * yb.y;
-    r2 = (yb.z * yb.z + yb.w * yb.w) + yc.x * yc.x;
-    r3 = (yc.y * yc.y + yc.z * yc.z) + yc.w * yc.w;
+  if (FORM != HITADV_FORM_DIRECT) {
+    r0 = sq_norm<FORM>(ya.x, ya.y, ya.z);
+    r1 = sq_norm<FORM>(ya.w, yb.x, yb.y);
+    r2 = sq_norm<FORM>(yb.z, yb.w, yc.x);
+    r3 = sq_norm<FORM>(yc.y, yc.z, yc.w);
   }
   float *out = P + ((size_t)b * N + i0) * M + j0;
   auto row = [&](int r) {
@@ -88,13 +84,13 @@ __global__ __launch_bounds__(256) void pairwise3_scalar(const float *__restrict_
     xs[threadIdx.x * 4 + 0] = a;
     xs[threadIdx.x * 4 + 1] = c;
     xs[threadIdx.x * 4 + 2] = d;
-    xs[threadIdx.x * 4 + 3] = (a * a + c * c) + d * d;
+    xs[threadIdx.x * 4 + 3] = sq_norm<FORM>(a, c, d);
   }
   __syncthreads();
   if (j >= M) return;
   const float *yp = y + ((size_t)b * M + j) * 3;
   const float y0 = yp[0], y1 = yp[1], y2 = yp[2];
-  const float ry = (y0 * y0 + y1 * y1) + y2 * y2;
+  const float ry = sq_norm<FORM>(y0, y1, y2);
   float *out = P + ((size_t)b * N + i0) * M + j;
   for (int r = 0; r < rows; ++r)
     out[(size_t)r * M] = pair_value<FORM>(xs[r * 4], xs[r * 4 + 1], xs[r * 4 + 2], xs[r * 4 + 3], y0, y1, y2, ry);
@@ -131,6 +127,7 @@ constexpr int K2_QB = 64 * K2_Q;   // queries per block
 // (2, 4) with hipcc's default SLP packing (tools/tune/k2_tune.hip): 4.3 Tpair/s = 47 T lane-op/s, which
 // is the plain-VALU issue ceiling measured by tools/tune/valu_rate.hip (40-48 T lane-op/s).
 
+template <int FORM>
 __global__ __launch_bounds__(K2_NW * 64) void nn_min3(const float *__restrict__ x, const float *__restrict__ y,
                                                       int N, int M, float *__restrict__ min_x,
                                                       int32_t *__restrict__ arg_x, float *__restrict__ min_y,
@@ -153,7 +150,7 @@ __global__ __launch_bounds__(K2_NW * 64) void nn_min3(const float *__restrict__ 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // keeps the scan bounds in SGPRs
 
-  float qx[K2_Q], qy[K2_Q], qz[K2_Q], best[K2_Q];
+  float qx[K2_Q], qy[K2_Q], qz[K2_Q], qr[K2_Q], best[K2_Q];
   int bi[K2_Q];
 #pragma unroll
   for (int t = 0; t < K2_Q; ++t) {
@@ -162,6 +159,7 @@ __global__ __launch_bounds__(K2_NW * 64) void nn_min3(const float *__restrict__ 
     qx[t] = qp[q * 3 + 0];
     qy[t] = qp[q * 3 + 1];
     qz[t] = qp[q * 3 + 2];
+    qr[t] = sq_norm<FORM>(qx[t], qy[t], qz[t]);  // forms 0 and 1 are symmetric in (query, reference)
     best[t] = __builtin_inff();
     bi[t] = 0;
   }
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(K2_NW * 64) void nn_min3(const float *__restrict__ 
     __syncthreads();
     for (int p = threadIdx.x; p < cnt; p += K2_NW * 64) {
       const float *s = rp + (size_t)(c0 + p) * 3;
-      sref[p] = make_float4(s[0], s[1], s[2], 0.f);
+      sref[p] = make_float4(s[0], s[1], s[2], sq_norm<FORM>(s[0], s[1], s[2]));
     }
     __syncthreads();
     const int per = K2_RCH / K2_NW;
@@ -181,7 +179,7 @@ __global__ __launch_bounds__(K2_NW * 64) void nn_min3(const float *__restrict__ 
       const float4 r = sref[p];
 #pragma unroll
       for (int t = 0; t < K2_Q; ++t) {
-        const float d = sqdist3(qx[t], qy[t], qz[t], r.x, r.y, r.z);
+        const float d = pair_dist<FORM>(qx[t], qy[t], qz[t], qr[t], r.x, r.y, r.z, r.w);
         const bool lt = d < best[t];
         best[t] = lt ? d : best[t];
         bi[t] = lt ? c0 + p : bi[t];
@@ -364,7 +362,7 @@ using namespace hitadv;
 extern "C" int hitadv_pairwise_sqdist(const float *x, const float *y, float *P, int B, int N, int M, int D,
                                       int form, void *stream) {
   if (!x || !y || !P || B <= 0 || N <= 0 || M <= 0 || D <= 0) return HITADV_E_ARG;
-  if (form != HITADV_FORM_DIRECT && form != HITADV_FORM_GRAM) return HITADV_E_ARG;
+  if (form != HITADV_FORM_DIRECT && form != HITADV_FORM_GRAM && form != HITADV_FORM_GRAM_KNN) return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (D == 3) {
     const bool vec = (M % 4 == 0) && (((uintptr_t)y & 15) == 0) && (((uintptr_t)P & 15) == 0);
@@ -372,14 +370,18 @@ extern "C" int hitadv_pairwise_sqdist(const float *x, const float *y, float *P, 
       dim3 grid((M + 1023) / 1024, (N + K1_ROWS - 1) / K1_ROWS, B);
       if (form == HITADV_FORM_DIRECT)
         pairwise3_vec4<HITADV_FORM_DIRECT><<<grid, 256, 0, s>>>(x, y, P, N, M);
-      else
+      else if (form == HITADV_FORM_GRAM)
         pairwise3_vec4<HITADV_FORM_GRAM><<<grid, 256, 0, s>>>(x, y, P, N, M);
+      else
+        pairwise3_vec4<HITADV_FORM_GRAM_KNN><<<grid, 256, 0, s>>>(x, y, P, N, M);
     } else {
       dim3 grid((M + 255) / 256, (N + K1_ROWS - 1) / K1_ROWS, B);
       if (form == HITADV_FORM_DIRECT)
         pairwise3_scalar<HITADV_FORM_DIRECT><<<grid, 256, 0, s>>>(x, y, P, N, M);
-      else
+      else if (form == HITADV_FORM_GRAM)
         pairwise3_scalar<HITADV_FORM_GRAM><<<grid, 256, 0, s>>>(x, y, P, N, M);
+      else
+        pairwise3_scalar<HITADV_FORM_GRAM_KNN><<<grid, 256, 0, s>>>(x, y, P, N, M);
     }
   } else {
     const long long total = (long long)B * N * M;
@@ -389,16 +391,20 @@ extern "C" int hitadv_pairwise_sqdist(const float *x, const float *y, float *P, 
   return 0;
 }
 
-extern "C" int hitadv_nn_min(const float *x, const float *y, int B, int N, int M, int D, float *min_x,
+extern "C" int hitadv_nn_min(const float *x, const float *y, int B, int N, int M, int D, int form, float *min_x,
                              int32_t *arg_x, float *min_y, int32_t *arg_y, float *scratch, void *stream) {
   if (!x || !y || B <= 0 || N <= 0 || M <= 0 || D <= 0) return HITADV_E_ARG;
+  if (form != HITADV_FORM_DIRECT && !(form == HITADV_FORM_GRAM && D == 3)) return HITADV_E_ARG;
   if ((min_x == nullptr) != (arg_x == nullptr) || (min_y == nullptr) != (arg_y == nullptr)) return HITADV_E_ARG;
   if (!min_x && !min_y) return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (D == 3) {
     const int nmax = N > M ? N : M;
     dim3 grid((nmax + K2_QB - 1) / K2_QB, 2, B);
-    nn_min3<<<grid, K2_NW * 64, 0, s>>>(x, y, N, M, min_x, arg_x, min_y, arg_y);
+    if (form == HITADV_FORM_DIRECT)
+      nn_min3<HITADV_FORM_DIRECT><<<grid, K2_NW * 64, 0, s>>>(x, y, N, M, min_x, arg_x, min_y, arg_y);
+    else
+      nn_min3<HITADV_FORM_GRAM><<<grid, K2_NW * 64, 0, s>>>(x, y, N, M, min_x, arg_x, min_y, arg_y);
   } else {
     if (!scratch) return HITADV_E_ARG;
     const long long total = (long long)B * N * M;

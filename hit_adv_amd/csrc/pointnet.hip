@@ -680,19 +680,12 @@ __global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, 
     v[u] = ((red[o] + red[1024 + o]) + red[2048 + o]) + red[3072 + o];
   }
   if (KS > 1) {
-    // No fences (an agent-scope release costs a whole-L2 write-back per wave, ~0.1 us per block, serialised):
-    // partials and ticket are relaxed agent-scope atomics (sc1: written through to / read from the point of
-    // coherence across XCDs); the barrier's vmcnt(0) orders a block's partial stores before its ticket.
+    // partials are written through (sc1) and read back with sc1 loads by the last block to arrive (common.hpp)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       __hip_atomic_store(&part[((size_t)ks * ntile + tile) * 1024 + threadIdx.x + 256 * u], v[u], __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores are acknowledged ...
-    __syncthreads();                                   // ... for every wave of the block, before its ticket is drawn
-    if (threadIdx.x == 0)
-      s_last = __hip_atomic_fetch_add(&ticket[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == KS - 1;
-    __syncthreads();
-    if (!s_last) return;
+    if (!handoff_last_arriver(ticket, tile, KS, &s_last)) return;  // protocol: common.hpp
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (int q0 = 0; q0 < KS; q0 += 8) {  // 32 loads in flight per thread, then added in chunk order
       float t[4][8];

@@ -407,12 +407,7 @@ __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__
   // split order (= ascending points, so ties keep the first point), adds the bias, applies the ReLU and writes the
   // result.  Same fence-free protocol as fc_layer_k (csrc/pointnet.hip): write-through stores, vmcnt(0), barrier, ticket.
   __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    s_last = __hip_atomic_fetch_add(&tickets[b * ncg + cg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
-  __syncthreads();
-  if (!s_last) return;
+  if (!handoff_last_arriver(tickets, b * ncg + cg, S, &s_last)) return;
   const int c = cg * 256 + threadIdx.x;
   if (threadIdx.x < 256 && c < Cout) {
     float best = 0.f;

@@ -1,0 +1,300 @@
+// V1 on the bf16 matrix cores at fp32 accuracy: y = x[B*N,CIN] @ Wt[CIN,Cout] -> max / arg-max over the N points of each
+// cloud (PointNet's 128 -> 1024 shared layer + global max-pool, model/feature_models.py:113-147,165-177), with every
+// fp32 operand carried as THREE bf16 pieces.
+//
+// Why: gfx950 has no reduced-precision f32 MFMA; v_mfma_f32_32x32x2_f32 runs at the f32 vector rate (64 flop / cycle /
+// SIMD, csrc/victim.hip reaches 82 % of it).  v_mfma_f32_32x32x16_bf16 runs 16x faster.  An fp32 value splits EXACTLY into
+// three bf16 numbers, a = a1 + a2 + a3 (8 + 8 + 8 significant bits, each piece the truncation of what the previous ones
+// left), so   a.b = a1.b1 + (a1.b2 + a2.b1) + (a1.b3 + a3.b1 + a2.b2) + [terms below 2^-24 |a.b|],
+// six bf16 MFMAs (every bf16 x bf16 product is exact in fp32, the accumulator is fp32) instead of eight f32 MFMAs per 16
+// values of k: 2.67x less matrix time at the accuracy of an fp32 GEMM (measured against float64: the dropped terms are
+// 4e-8 of the output scale, the fp32 accumulation itself 4e-7 -- tests/test_gpu_attack.py::test_pointnet_engine_*).
+// This is NOT bf16 precision: nothing is rounded to 8 bits.
+//
+//   block   = 8 waves (two per SIMD); one cloud, one split of its points, 256 output channels (32 per wave)
+//   W       : host-side split once per attack (weights are constants), [3][Cout][CIN] bf16; the wave's 32 columns x CIN
+//             rows x 3 pieces live in VGPRs for the whole kernel (96 registers at CIN = 128)
+//   x       : 64-point tiles, global fp32 -> registers -> split (4 VALU per value) -> three bf16 LDS images (row stride
+//             2 CIN + 16 bytes: conflict-free ds_read_b128), double buffered, one barrier per tile
+//   compute : per tile and wave 2 row blocks x (CIN/16 slices) x 6 MFMAs; the next slice's A fragments are read while
+//             the current slice's MFMAs run
+//   epilogue: the accumulator layout is that of the f32 kernel (column on the lane, 16 rows in registers): same running
+//             (max, first arg-max) scan, same split merge by the last block to arrive.
+#include "common.hpp"
+#include "hitadv.h"
+
+namespace hitadv {
+
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int B3_TM = 64;
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast(bf16x8, u); }
+
+// a = hi + mid + lo exactly, each the bf16 truncation of what is left (upper 16 bits of an fp32 = a bf16)
+__device__ __forceinline__ void split3(float a, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+  hi = __float_as_uint(a) & 0xffff0000u;
+  const float r1 = a - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mid);
+  lo = __float_as_uint(r2);  // at most 8 significant bits are left: its lower 16 bits are zero
+}
+
+__device__ __forceinline__ uint32_t pack_hi(uint32_t even, uint32_t odd) {  // two bf16 (upper halves) -> one dword
+  return (even >> 16) | (odd & 0xffff0000u);
+}
+
+template <int CIN>
+__global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restrict__ X, const uint16_t *__restrict__ W3,
+                                                            int B_, int N, int Cout, int rows_per_split, int S, int ncg,
+                                                            float *pval, int32_t *pidx, const float *__restrict__ bias,
+                                                            int relu, float *__restrict__ out, int64_t *__restrict__ idx,
+                                                            int *tickets) {
+  constexpr int NSL = CIN / 16;          // 16-deep MFMA slices
+  constexpr int RS = 2 * CIN + 16;       // bytes per LDS row of one piece
+  constexpr int PIECE = B3_TM * RS;      // bytes per piece image
+  constexpr int G8 = CIN / 8;            // groups of 8 consecutive k per row
+  constexpr int ST = B3_TM * G8 / 512;   // 8-value groups staged per thread per tile
+  extern __shared__ __attribute__((aligned(16))) char sB3[];  // 2 buffers x 3 pieces x PIECE
+  int cg, s, b;
+  {  // XCD-aware block order (see linear_max_fwd_k): the column-group blocks that stream the same x tiles share an XCD
+    const int NCG = ncg, id = blockIdx.x, nrg = S * B_;
+    if ((nrg & 7) == 0) {
+      const int xcd = id & 7, slot = id >> 3;
+      cg = slot % NCG;
+      const int rg = (slot / NCG) * 8 + xcd;
+      s = rg % S;
+      b = rg / S;
+    } else {
+      cg = id % NCG;
+      s = (id / NCG) % S;
+      b = id / (NCG * S);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int col0 = cg * 256 + wave * 32;
+  const bool active = col0 < Cout;  // wave-uniform
+  const int n0 = s * rows_per_split, n1 = min(N, n0 + rows_per_split);
+  const int ntiles = (n1 - n0 + B3_TM - 1) / B3_TM;
+  X += (size_t)b * N * CIN;
+
+  // B operand of slice j, piece p: the lane's column, k = 16 j + 8 h .. + 7 (8 consecutive bf16 = one 16-byte load)
+  uint4 w[3][NSL];
+  {
+    const uint16_t *wp = W3 + (size_t)((active ? col0 : 0) + r) * CIN + 8 * h;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < NSL; ++j)
+        w[p][j] = *reinterpret_cast<const uint4 *>(wp + (size_t)p * Cout * CIN + 16 * j);
+  }
+
+  float4 st[ST][2];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < ST; ++u) {
+      const int e = threadIdx.x + 512 * u;
+      const int n = n0 + tile * B3_TM + e / G8;
+      const float *src = X + (size_t)n * CIN + 8 * (e % G8);
+      // rows past the split read a valid address and are zeroed by selects (an if / else around the two loads sends
+      // ROCm 7.2's Machine Copy Propagation pass into a segmentation fault in this kernel)
+      const bool in = n < n1;
+      const float *sp = in ? src : X;
+      const float4 v0 = *reinterpret_cast<const float4 *>(sp), v1 = *reinterpret_cast<const float4 *>(sp + 4);
+      st[u][0] = make_float4(in ? v0.x : 0.f, in ? v0.y : 0.f, in ? v0.z : 0.f, in ? v0.w : 0.f);
+      st[u][1] = make_float4(in ? v1.x : 0.f, in ? v1.y : 0.f, in ? v1.z : 0.f, in ? v1.w : 0.f);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < ST; ++u) {
+      const int e = threadIdx.x + 512 * u;
+      const float a[8] = {st[u][0].x, st[u][0].y, st[u][0].z, st[u][0].w, st[u][1].x, st[u][1].y, st[u][1].z, st[u][1].w};
+      uint32_t p1[8], p2[8], p3[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) split3(a[i], p1[i], p2[i], p3[i]);
+      char *dst = sB3 + (size_t)buf * 3 * PIECE + (e / G8) * RS + 16 * (e % G8);
+      *reinterpret_cast<uint4 *>(dst) = make_uint4(pack_hi(p1[0], p1[1]), pack_hi(p1[2], p1[3]), pack_hi(p1[4], p1[5]),
+                                                   pack_hi(p1[6], p1[7]));
+      *reinterpret_cast<uint4 *>(dst + PIECE) = make_uint4(pack_hi(p2[0], p2[1]), pack_hi(p2[2], p2[3]),
+                                                           pack_hi(p2[4], p2[5]), pack_hi(p2[6], p2[7]));
+      *reinterpret_cast<uint4 *>(dst + 2 * PIECE) = make_uint4(pack_hi(p3[0], p3[1]), pack_hi(p3[2], p3[3]),
+                                                               pack_hi(p3[4], p3[5]), pack_hi(p3[6], p3[7]));
+    }
+  };
+
+  float bv = -__builtin_inff();
+  int bi = -1;
+  f32x16b acc0, acc1;  // row blocks 0 and 1: element e = row 32*rb + (e&3) + 8*(e>>2) + 4*h, column r (the f32 kernel's layout)
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const bool more = tile + 1 < ntiles;
+    if (more) fetch(tile + 1);
+    if (active) {
+      const char *base = sB3 + (size_t)(tile & 1) * 3 * PIECE + r * RS + 16 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NSL; ++j) {
+        const bf16x8 w0 = as_bf16x8(w[0][j]), w1 = as_bf16x8(w[1][j]), w2 = as_bf16x8(w[2][j]);
+        const bf16x8 f0 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + 32 * j));
+        const bf16x8 f1 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + PIECE + 32 * j));
+        const bf16x8 f2 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + 2 * PIECE + 32 * j));
+        const bf16x8 g0 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + 32 * RS + 32 * j));
+        const bf16x8 g1 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + PIECE + 32 * RS + 32 * j));
+        const bf16x8 g2 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + 2 * PIECE + 32 * RS + 32 * j));
+        // smallest terms first; the two row blocks alternate so that consecutive MFMAs are independent
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w2, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2, w0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, w1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, w0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w0, acc1, 0, 0, 0);
+      }
+      // running (max, first arg-max): a tile-local best with an inline-constant code, joined with the tile number once
+      const bool ragged = n0 + (tile + 1) * B3_TM > n1;  // wave-uniform: only a split's last tile can be ragged
+      const int row0 = n0 + tile * B3_TM + 4 * h;
+      float tv = -__builtin_inff();
+      int tc = 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc0[e];
+        if (ragged) v = row0 + (e & 3) + 8 * (e >> 2) < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
+        const bool g = v > tv;
+        tv = g ? v : tv;
+        tc = g ? e : tc;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = acc1[e];
+        if (ragged) v = row0 + 32 + (e & 3) + 8 * (e >> 2) < n1 ? v : -__builtin_inff();
+        const bool g = v > tv;
+        tv = g ? v : tv;
+        tc = g ? 16 + e : tc;
+      }
+      const bool g = tv > bv;  // earlier tiles hold earlier points: they keep ties
+      bv = g ? tv : bv;
+      bi = g ? tile * 32 + tc : bi;
+    }
+    if (more) stash((tile + 1) & 1);
+    __syncthreads();
+  }
+  // code -> point index; nothing won (all rows -inf): the split's first point
+  bi = bi < 0 ? n0 : n0 + (bi >> 5) * B3_TM + 4 * h + 32 * ((bi >> 4) & 1) + (bi & 3) + 8 * ((bi & 15) >> 2);
+  {  // the other half of the wave holds the same column, other rows
+    const float ov = __shfl_xor(bv, 32, HITADV_WAVE);
+    const int oi = __shfl_xor(bi, 32, HITADV_WAVE);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (active && h == 0) {
+    const int c = col0 + r;
+    if (S == 1) {  // nothing to merge: finish here
+      float v = bv + (bias ? bias[c] : 0.f);  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
+      out[(size_t)b * Cout + c] = relu ? (v > 0.f ? v : 0.f) : v;  // max and ReLU commute
+      idx[(size_t)b * Cout + c] = bi;
+    } else {
+      const size_t o = ((size_t)b * S + s) * Cout + c;
+      __hip_atomic_store(&pval[o], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&pidx[o], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (S == 1) return;
+  // The S splits of a (cloud, column group) meet here: the last block to draw the group's ticket merges the partials in
+  // split order (= ascending points, so ties keep the first point).  Hand-off protocol of fc_layer_k (csrc/pointnet.hip).
+  __shared__ int s_last;
+  if (!handoff_last_arriver(tickets, b * ncg + cg, S, &s_last)) return;
+  const int c = cg * 256 + threadIdx.x;
+  if (threadIdx.x < 256 && c < Cout) {
+    float best = 0.f;
+    int bidx = 0;
+    for (int q = 0; q < S; ++q) {
+      const size_t o = ((size_t)b * S + q) * Cout + c;
+      const float v = __hip_atomic_load(&pval[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int vi = __hip_atomic_load(&pidx[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (q == 0 || v > best) { best = v; bidx = vi; }
+    }
+    best += bias ? bias[c] : 0.f;
+    out[(size_t)b * Cout + c] = relu ? (best > 0.f ? best : 0.f) : best;
+    idx[(size_t)b * Cout + c] = bidx;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&tickets[b * ncg + cg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// W[Cout,CIN] fp32 (row-major, one row per output channel) -> W3[3][Cout][CIN] bf16 pieces
+__global__ __launch_bounds__(256) void split_weights_k(const float *__restrict__ W, uint16_t *__restrict__ W3, long long total) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  uint32_t a, bb, c;
+  split3(W[e], a, bb, c);
+  W3[e] = (uint16_t)(a >> 16);
+  W3[total + e] = (uint16_t)(bb >> 16);
+  W3[2 * total + e] = (uint16_t)(c >> 16);
+}
+
+static void bf3_split(int B, int N, int Cout, int *S, int *rows) {  // as linear_max_split (csrc/victim.hip): one block per CU
+  const int colgroups = (Cout + 255) / 256;
+  int want = (256 + B * colgroups - 1) / (B * colgroups);
+  const int maxs = (N + B3_TM - 1) / B3_TM;
+  want = want < 1 ? 1 : (want > maxs ? maxs : want);
+  int per = (N + want - 1) / want;
+  per = (per + B3_TM - 1) / B3_TM * B3_TM;
+  *rows = per;
+  *S = (N + per - 1) / per;
+}
+
+}  // namespace hitadv
+
+using namespace hitadv;
+
+extern "C" int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream) {
+  if (!W || !W3 || Cout <= 0 || Cin <= 0) return HITADV_E_ARG;
+  const long long total = (long long)Cout * Cin;
+  split_weights_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, W3, total);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout) {
+  if (B <= 0 || N <= 0 || Cout <= 0) return 0;
+  int S, rows;
+  bf3_split(B, N, Cout, &S, &rows);
+  return (int64_t)B * S * Cout;
+}
+
+extern "C" int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin,
+                                            int Cout, int relu, float *part_val, int32_t *part_idx, float *out,
+                                            int64_t *idx, int32_t *tickets, void *stream) {
+  if (!X || !W3 || !part_val || !part_idx || !out || !idx || !tickets || B <= 0 || N <= 0 || Cout <= 0 || (Cout & 63) ||
+      (Cin != 64 && Cin != 128) || ((uintptr_t)X & 15) || ((uintptr_t)W3 & 15))
+    return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int S, rows;
+  bf3_split(B, N, Cout, &S, &rows);
+  const int ncg = (Cout + 255) / 256;
+  dim3 grid((unsigned)(ncg * S * B));
+  const size_t shm = (size_t)2 * 3 * B3_TM * (2 * Cin + 16);
+  if (Cin == 128) {
+    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<128>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 128 + 16));
+    (void)once;
+    linear_max_fwd_bf3_k<128><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
+                                                     tickets);
+  } else {
+    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 64 + 16));
+    (void)once;
+    linear_max_fwd_bf3_k<64><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
+                                                    tickets);
+  }
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}

@@ -191,8 +191,15 @@ class _PointNetHip(torch.autograd.Function):
         E = lambda *s: torch.empty(*s, device=x.device)  # noqa: E731
         # STN3d
         a1s, a2s = E(R, 64), E(R, 128)
+        def lin_max(a, name, relu):
+            """128 -> 1024 shared layer + max over the points: bf16x3 split (fp32-accurate, 2.7x less matrix time) or the
+            f32 MFMA form (``view.matrix_mode = 'f32'``)."""
+            if v.matrix_mode == 'bf16x3':
+                return ops.linear_max_fwd_bf16x3(a, v.pieces(name), B, N, bias=getattr(v, name + '_b'), relu=relu)
+            return ops.linear_max_fwd(a, getattr(v, name + '_w'), B, N, bias=getattr(v, name + '_b'), relu=relu)
+
         ops.pointnet_rowmlp_fwd(0, B, N, v.s2_w, v.s2_b, a2s, x=x, W0=v.s1_w, b0=v.s1_b, o0=a1s)
-        gs, js = ops.linear_max_fwd(a2s, v.s3_w, B, N, bias=v.s3_b, relu=True)
+        gs, js = lin_max(a2s, 's3', True)
         f4s = ops.fc_layer(gs, v.s4_w, v.s4_b, relu=True)
         f5s = ops.fc_layer(f4s, v.s5_w, v.s5_b, relu=True)
         T3 = ops.fc_layer(f5s, v.s6_w, v.s6_b)
@@ -200,14 +207,14 @@ class _PointNetHip(torch.autograd.Function):
         h1, a1t, a2t = E(R, 64), E(R, 64), E(R, 128)
         ops.pointnet_rowmlp_fwd(1, B, N, v.t2_w, v.t2_b, a2t, x=x, T=T3, W0=v.e1_w, b0=v.e1_b, W1=v.t1_w, b1=v.t1_b,
                                 o0=h1, o1=a1t)
-        gt, jt = ops.linear_max_fwd(a2t, v.t3_w, B, N, bias=v.t3_b, relu=True)
+        gt, jt = lin_max(a2t, 't3', True)
         f4t = ops.fc_layer(gt, v.t4_w, v.t4_b, relu=True)
         f5t = ops.fc_layer(f4t, v.t5_w, v.t5_b, relu=True)
         T64 = ops.fc_layer(f5t, v.t6_w, v.t6_b)
         # feature transform, encoder tail, classifier head
         a2e = E(R, 128)
         ops.pointnet_rowmlp_fwd(2, B, N, v.e2_w, v.e2_b, a2e, T=T64, hin=h1)
-        g, je = ops.linear_max_fwd(a2e, v.e3_w, B, N, bias=v.e3_b, relu=False)
+        g, je = lin_max(a2e, 'e3', False)
         f1 = ops.fc_layer(g, v.h1_w, v.h1_b, relu=True)
         f2 = ops.fc_layer(f1, v.h2_w, v.h2_b, relu=True)
         logits = ops.fc_layer(f2, v.h3_w, v.h3_b)
@@ -274,10 +281,14 @@ class FoldedPointNet(nn.Module):
 
     def __init__(self, m):
         super().__init__()
+        self._pieces = {}
         for k, (w, b) in self._folded(m).items():
             self.register_buffer(k + '_w', w.detach().clone())
             self.register_buffer(k + '_b', b.detach().clone())
             self.register_buffer(k + '_wr', w.detach().t().contiguous())  # row-major [Cout,Cin] for dX
+        if self.s3_wr.is_cuda:
+            for name in ('s3', 't3', 'e3'):
+                self.pieces(name)
 
     @staticmethod
     def _folded(m):
@@ -315,7 +326,20 @@ class FoldedPointNet(nn.Module):
             getattr(self, k + '_w').copy_(w)
             getattr(self, k + '_b').copy_(b)
             getattr(self, k + '_wr').copy_(w.t())
+        for name, buf in self._pieces.items():  # re-split in place
+            from .. import ops
+            ops.split_weights_bf16x3(getattr(self, name + '_wr'), out=buf)
         return self
+
+    matrix_mode = 'bf16x3'  # the three 128 -> 1024 layers: 'bf16x3' (three-piece bf16 split, fp32-accurate) or 'f32'
+
+    def pieces(self, name):
+        """bf16 pieces [3,Cout,Cin] of a 128 -> 1024 layer's folded weight, split on first use (weights are constants
+        of an attack; ``refresh`` re-splits them in place)."""
+        if name not in self._pieces:
+            from .. import ops
+            self._pieces[name] = ops.split_weights_bf16x3(getattr(self, name + '_wr'))
+        return self._pieces[name]
 
     def _lin(self, x, name, relu=True):
         w, b = getattr(self, name + '_w'), getattr(self, name + '_b')
@@ -336,6 +360,7 @@ class FoldedPointNet(nn.Module):
         return self._lin(self._lin(self._lin(g, p + '4'), p + '5'), p + '6', relu=False)
 
     hip_engine = True  # CUDA tensors: run on libhitadv_hip's own kernels (_PointNetHip); False = PyTorch-ROCm ops
+    iterations_per_graph = 10  # attack iterations an attack records into one hipGraph (~40 kernels each: launch-cost bound)
 
     def forward(self, x):
         """x [B,3,N] -> (logits [B,k], trans_feat [B,64,64])"""

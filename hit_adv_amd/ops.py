@@ -10,7 +10,45 @@ import torch
 
 from . import _lib
 
-FORM_DIRECT, FORM_GRAM = 0, 1
+FORM_DIRECT, FORM_GRAM, FORM_GRAM_KNN = 0, 1, 2  # include/hitadv.h HITADV_FORM_*
+
+_reference_arithmetic = False
+
+
+class reference_arithmetic:
+    """Switch (``reference_arithmetic.set(True)``) or scope (``with reference_arithmetic(True):``) in which the set
+    distances and KNNDist evaluate squared distances in the reference's own Gram-form fp32 arithmetic
+    (util/set_distance.py:15-32, util/dist_utils.py:148-150) instead of the direct form: their VALUES then equal the
+    reference's bit for bit (minima, k-nearest distances; what remains is the order of the final mean), at the price of
+    the Gram form's cancellation noise (~4 eps (|x|^2 + |y|^2) per entry).  Gradients flow through the same arg-minima /
+    neighbour indices either way and are evaluated as 2 g (x - y)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _reference_arithmetic
+        self.prev, _reference_arithmetic = _reference_arithmetic, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _reference_arithmetic
+        _reference_arithmetic = self.prev
+
+    @staticmethod
+    def set(on):
+        global _reference_arithmetic
+        _reference_arithmetic = bool(on)
+
+    @staticmethod
+    def get():
+        return _reference_arithmetic
+
+
+def _form(explicit, reference_form):
+    if explicit is not None:
+        return reference_form if explicit else FORM_DIRECT
+    return reference_form if _reference_arithmetic else FORM_DIRECT
 
 
 def _stream():
@@ -62,7 +100,7 @@ class NNMin(torch.autograd.Function):
     """(x[B,N,D], y[B,M,D]) -> (min_x[B,N], arg_x[B,N], min_y[B,M], arg_y[B,M])."""
 
     @staticmethod
-    def forward(ctx, x, y):
+    def forward(ctx, x, y, form=FORM_DIRECT):
         x, y = _dev(x, "x"), _dev(y, "y")
         B, N, D = x.shape
         M = y.shape[1]
@@ -72,7 +110,9 @@ class NNMin(torch.autograd.Function):
         arg_x = torch.empty(B, N, device=dev, dtype=torch.int32)
         arg_y = torch.empty(B, M, device=dev, dtype=torch.int32)
         scratch = torch.empty(B, N, M, device=dev) if D != 3 else None
-        _lib.call("hitadv_nn_min", _p(x), _p(y), B, N, M, D, _p(min_x), _p(arg_x), _p(min_y), _p(arg_y),
+        if D != 3:
+            form = FORM_DIRECT  # the generic-D path (quirk Q1's [B,3,N] call) has one form
+        _lib.call("hitadv_nn_min", _p(x), _p(y), B, N, M, D, form, _p(min_x), _p(arg_x), _p(min_y), _p(arg_y),
                   _p(scratch), _stream())
         ctx.save_for_backward(x, y, arg_x, arg_y)
         ctx.mark_non_differentiable(arg_x, arg_y)
@@ -86,22 +126,24 @@ class NNMin(torch.autograd.Function):
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
         if gx is None and gy is None:
-            return None, None
+            return None, None, None
         gmx = g_min_x.contiguous().float() if g_min_x is not None else None
         gmy = g_min_y.contiguous().float() if g_min_y is not None else None
         _lib.call("hitadv_nn_min_bwd", _p(x), _p(y), _p(arg_x), _p(arg_y), _p(gmx), _p(gmy), B, N, M, D,
                   _p(gx), _p(gy), _stream())
-        return gx, gy
+        return gx, gy, None
 
 
-def nn_min(x, y):
-    return NNMin.apply(x, y)
+def nn_min(x, y, reference=None):
+    """Fused nearest-neighbour minima in both directions.  ``reference`` = True / False selects the reference's Gram-form
+    arithmetic or the direct form; None follows the ``reference_arithmetic`` switch."""
+    return NNMin.apply(x, y, _form(reference, FORM_GRAM))
 
 
 # --------------------------------------------------------------------------- kNN
 class KnnPoints(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, p1, p2, K):
+    def forward(ctx, p1, p2, K, form=FORM_DIRECT):
         p1, p2 = _dev(p1, "p1"), _dev(p2, "p2")
         B, N, D = p1.shape
         M = p2.shape[1]
@@ -111,7 +153,7 @@ class KnnPoints(torch.autograd.Function):
             raise RuntimeError("knn_points: need 1 <= K <= min(M, 64), got K=%d, M=%d" % (K, M))
         dists = torch.empty(B, N, K, device=p1.device)
         idx = torch.empty(B, N, K, device=p1.device, dtype=torch.int64)
-        _lib.call("hitadv_knn_points", _p(p1), _p(p2), B, N, M, K, _p(dists), _p(idx), 1, _stream())
+        _lib.call("hitadv_knn_points", _p(p1), _p(p2), B, N, M, K, form, _p(dists), _p(idx), 1, _stream())
         ctx.save_for_backward(p1, p2, idx)
         ctx.mark_non_differentiable(idx)
         return dists, idx
@@ -125,11 +167,16 @@ class KnnPoints(torch.autograd.Function):
         g1 = torch.empty_like(p1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(p2) if ctx.needs_input_grad[1] else None
         if g1 is None and g2 is None:
-            return None, None, None
+            return None, None, None, None
         g = g_dists.contiguous().float()
         _lib.call("hitadv_knn_points_bwd", _p(p1), _p(p2), _p(idx), 1, _p(g), B, N, M, K, _p(g1), _p(g2),
                   _stream())
-        return g1, g2, None
+        return g1, g2, None, None
+
+
+def knn_dist_matrix_form(reference=None):
+    """The distance form KNNDist asks of ``KnnPoints``: its own Gram matrix (util/dist_utils.py:148-150) or direct."""
+    return _form(reference, FORM_GRAM_KNN)
 
 
 # --------------------------------------------------------------------------- deformation
@@ -352,6 +399,33 @@ def linear_max_fwd(x, Wt, B, N, bias=None, relu=False):
     idx = torch.empty(B, Cout, device=x.device, dtype=torch.int64)
     tickets = _fc_scratch_for(x, 1 << 14)  # zeroed, self-resetting; shared with fc_layer (never concurrent on a stream)
     _lib.call("hitadv_linear_max_fwd", _p(x), _p(Wt), _p(bias), B, N, Cin, Cout, 1 if relu else 0, _p(pv), _p(pi),
+              _p(out), _p(idx), _p(tickets), _stream())
+    return out, idx
+
+
+def split_weights_bf16x3(Wr, out=None):
+    """Wr [Cout,Cin] fp32 (row-major, one row per output channel) -> its three bf16 pieces [3,Cout,Cin] (int16 storage)
+    that sum to it exactly; ``out`` = an existing buffer to refill (addresses held by a captured graph stay valid)."""
+    Wr = _dev(Wr, "Wr")
+    Cout, Cin = Wr.shape
+    if out is None:
+        out = torch.empty(3, Cout, Cin, device=Wr.device, dtype=torch.int16)
+    _lib.call("hitadv_split_weights_bf16x3", _p(Wr), Cout, Cin, _p(out), _stream())
+    return out
+
+
+def linear_max_fwd_bf16x3(x, W3, B, N, bias=None, relu=False):
+    """``linear_max_fwd`` on the bf16 matrix cores at fp32 accuracy (three-piece split of both operands, six cross terms
+    in an fp32 accumulator; csrc/victim_bf3.hip).  W3 = split_weights_bf16x3(Wt.t())."""
+    x = _dev(x, "x")
+    _, Cout, Cin = W3.shape
+    n = _lib.load().hitadv_linear_max_fwd_bf16x3_scratch(B, N, Cout)
+    pv = torch.empty(n, device=x.device)
+    pi = torch.empty(n, device=x.device, dtype=torch.int32)
+    out = torch.empty(B, Cout, device=x.device)
+    idx = torch.empty(B, Cout, device=x.device, dtype=torch.int64)
+    tickets = _fc_scratch_for(x, 1 << 14)
+    _lib.call("hitadv_linear_max_fwd_bf16x3", _p(x), _p(W3), _p(bias), B, N, Cin, Cout, 1 if relu else 0, _p(pv), _p(pi),
               _p(out), _p(idx), _p(tickets), _stream())
     return out, idx
 

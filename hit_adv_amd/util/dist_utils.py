@@ -5,8 +5,9 @@ The set reductions and the kNN search run in HIP kernels; what is left in torch 
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..pytorch3d_ops import knn_gather, knn_points
-from .set_distance import chamfer, hausdorff
+from .set_distance import ChamferDistance, HausdorffDistance
 
 
 def _apply_weights(loss, weights, batch_avg):
@@ -34,24 +35,26 @@ class L2Dist(nn.Module):
 class ChamferDist(nn.Module):
     """util/dist_utils.py:44-80."""
 
-    def __init__(self, method='adv2ori'):
+    def __init__(self, method='adv2ori', reference_arithmetic=None):
         super().__init__()
         self.method = method
+        self.chamfer = ChamferDistance(reference_arithmetic)
 
     def forward(self, adv_pc, ori_pc, weights=None, batch_avg=True):
-        fwd, bwd = chamfer(adv_pc, ori_pc)
+        fwd, bwd = self.chamfer(adv_pc, ori_pc)
         return _apply_weights(_select(self.method, fwd, bwd), weights, batch_avg)
 
 
 class HausdorffDist(nn.Module):
     """util/dist_utils.py:83-119."""
 
-    def __init__(self, method='adv2ori'):
+    def __init__(self, method='adv2ori', reference_arithmetic=None):
         super().__init__()
         self.method = method
+        self.hausdorff = HausdorffDistance(reference_arithmetic)
 
     def forward(self, adv_pc, ori_pc, weights=None, batch_avg=True):
-        fwd, bwd = hausdorff(adv_pc, ori_pc)
+        fwd, bwd = self.hausdorff(adv_pc, ori_pc)
         return _apply_weights(_select(self.method, fwd, bwd), weights, batch_avg)
 
 
@@ -62,16 +65,17 @@ class KNNDist(nn.Module):
     k+1 smallest squared distances per point directly (rank 0 is the point itself and is dropped,
     as in :157-158)."""
 
-    def __init__(self, k=5, alpha=1.05):
+    def __init__(self, k=5, alpha=1.05, reference_arithmetic=None):
         super().__init__()
         self.k = k
         self.alpha = alpha
+        self.reference_arithmetic = reference_arithmetic  # True: the Gram matrix of :148-150, bit for bit
 
     def forward(self, pc, weights=None, batch_avg=True):
         if pc.shape[1] == 3:  # [B,3,K] -> [B,K,3]; a [B,K,3] input passes through (:146-147)
             pc = pc.transpose(2, 1)
         pc = pc.contiguous()
-        dists = knn_points(pc, pc, K=self.k + 1).dists
+        dists, _ = ops.KnnPoints.apply(pc, pc, self.k + 1, ops.knn_dist_matrix_form(self.reference_arithmetic))
         value = dists[..., 1:].mean(dim=-1)  # [B,K]
         with torch.no_grad():
             threshold = value.mean(dim=-1) + self.alpha * value.std(dim=-1)
@@ -82,10 +86,11 @@ class KNNDist(nn.Module):
 class ChamferkNNDist(nn.Module):
     """util/dist_utils.py:258-294."""
 
-    def __init__(self, chamfer_method='adv2ori', knn_k=5, knn_alpha=1.05, chamfer_weight=5., knn_weight=3.):
+    def __init__(self, chamfer_method='adv2ori', knn_k=5, knn_alpha=1.05, chamfer_weight=5., knn_weight=3.,
+                 reference_arithmetic=None):
         super().__init__()
-        self.chamfer_dist = ChamferDist(method=chamfer_method)
-        self.knn_dist = KNNDist(k=knn_k, alpha=knn_alpha)
+        self.chamfer_dist = ChamferDist(method=chamfer_method, reference_arithmetic=reference_arithmetic)
+        self.knn_dist = KNNDist(k=knn_k, alpha=knn_alpha, reference_arithmetic=reference_arithmetic)
         self.w1 = chamfer_weight
         self.w2 = knn_weight
 

@@ -11,6 +11,12 @@ from .. import ops
 
 
 class _Distance(nn.Module):
+    """``reference_arithmetic`` = True: squared distances in the reference's own Gram form (values equal the
+    reference's bit for bit), False: direct form, None (default): follow ``ops.reference_arithmetic``."""
+
+    def __init__(self, reference_arithmetic=None):
+        super().__init__()
+        self.reference_arithmetic = reference_arithmetic
 
     def forward(self, preds, gts):
         raise NotImplementedError
@@ -20,10 +26,9 @@ class _Distance(nn.Module):
         Kept for callers that want P itself; evaluated in the reference's Gram form."""
         return ops.pairwise_sqdist(x, y, ops.FORM_GRAM)
 
-    @staticmethod
-    def _nearest(preds, gts):
+    def _nearest(self, preds, gts):
         # rows = gts (N2), columns = preds (N1), as in `P = batch_pairwise_dist(gts, preds)`
-        min_gt, _, min_pred, _ = ops.nn_min(gts, preds)
+        min_gt, _, min_pred, _ = ops.nn_min(gts, preds, self.reference_arithmetic)
         return min_pred, min_gt  # [B,N1] nearest gt of every pred, [B,N2] nearest pred of every gt
 
 

@@ -36,7 +36,11 @@ extern "C" {
 #define HITADV_E_ARG (-1)
 
 #define HITADV_FORM_DIRECT 0 /* ((dx*dx+dy*dy)+dz*dz)                           */
-#define HITADV_FORM_GRAM 1   /* (|x|^2+|y|^2) - 2 x.y  (util/set_distance.py:31) */
+#define HITADV_FORM_GRAM 1   /* (|x|^2+|y|^2) - 2 x.y, dot products as the FMA chain fma(a2,b2,fma(a1,b1,a0*b0)):
+                              * _Distance.batch_pairwise_dist (util/set_distance.py:15-32) as torch.bmm evaluates it on
+                              * an x86 CPU -- the reference's values bit for bit (tests/test_oracle_gram.py)          */
+#define HITADV_FORM_GRAM_KNN 2 /* (|y_j|^2 + (-2 x_i.y_j)) + |x_i|^2, dot product an FMA chain, |.|^2 = (a*a+b*b)+c*c:
+                                * the distance matrix of KNNDist (util/dist_utils.py:148-150), bit for bit             */
 
 /* Library / build identification (static string). */
 const char *hitadv_version(void);
@@ -54,9 +58,10 @@ int hitadv_pairwise_sqdist(const float *x, const float *y, float *P, int B, int 
 /* Fused nearest-neighbour reduction in both directions, no matrix materialised (D == 3):
  *   min_x[b,i] = min_j |x_i - y_j|^2, arg_x[b,i] = lowest such j   (and symmetrically for y).
  * Replaces the two torch.min passes of ChamferDistance/HausdorffDistance.forward
- * (util/set_distance.py:40-50, 58-70).  For D != 3, `scratch` must hold B*N*M floats.
+ * (util/set_distance.py:40-50, 58-70).  `form` = HITADV_FORM_DIRECT, or HITADV_FORM_GRAM (D == 3 only): the minima of
+ * the reference's own Gram-form matrix, bit for bit.  For D != 3, `scratch` must hold B*N*M floats.
  * Any of the four outputs may be NULL only in pairs (min_y/arg_y together). */
-int hitadv_nn_min(const float *x, const float *y, int B, int N, int M, int D, float *min_x,
+int hitadv_nn_min(const float *x, const float *y, int B, int N, int M, int D, int form, float *min_x,
                   int32_t *arg_x, float *min_y, int32_t *arg_y, float *scratch, void *stream);
 
 /* Backward of hitadv_nn_min through the saved arg-mins (what autograd does through
@@ -67,11 +72,12 @@ int hitadv_nn_min_bwd(const float *x, const float *y, const int32_t *arg_x, cons
                       const float *g_min_x, const float *g_min_y, int B, int N, int M, int D,
                       float *grad_x, float *grad_y, void *stream);
 
-/* K nearest neighbours, direct form, ascending, ties -> lower index.  q[B,N,3], p[B,M,3] ->
+/* K nearest neighbours, ascending, ties -> lower index.  q[B,N,3], p[B,M,3] ->
  * dists[B,N,K], idx[B,N,K] (int64 when idx_is_i64 != 0, else int32).  1 <= K <= min(M, 64).
+ * `form` = HITADV_FORM_DIRECT (pytorch3d's rule) or HITADV_FORM_GRAM_KNN (KNNDist's own distance matrix).
  * Replaces pytorch3d.ops.knn_points as called at ShapeAttack/HiT_ADV.py:78,320,329 and
  * util/dist_utils.py:482, and the Gram+topk of KNNDist (util/dist_utils.py:148-158). */
-int hitadv_knn_points(const float *q, const float *p, int B, int N, int M, int K, float *dists,
+int hitadv_knn_points(const float *q, const float *p, int B, int N, int M, int K, int form, float *dists,
                       void *idx, int idx_is_i64, void *stream);
 
 /* Backward of hitadv_knn_points w.r.t. both point sets, given g_dists[B,N,K]:
@@ -250,6 +256,19 @@ int hitadv_linear_max_fwd(const float *X, const float *Wt, const float *bias, in
                           int relu, float *part_val, int32_t *part_idx, float *out, int64_t *idx, int32_t *tickets,
                           void *stream);
 int64_t hitadv_linear_max_fwd_scratch(int B, int N, int Cout);
+
+/* The same operator on the bf16 matrix cores at fp32 accuracy (csrc/victim_bf3.hip): every fp32 operand is carried as
+ * three bf16 pieces that sum to it EXACTLY (a = a1 + a2 + a3, 8 significant bits each) and the product is evaluated as
+ * the six leading cross terms in an fp32 accumulator -- the dropped terms are below 2^-24 of the product, i.e. below the
+ * rounding of an fp32 GEMM; nothing is rounded to bf16 precision.  2.67x less matrix time than the f32 MFMA form.
+ * W3 [3][Cout][Cin] bf16 = the pieces of the layer's weight W [Cout,Cin] (row-major, one row per output channel), made
+ * once per attack by hitadv_split_weights_bf16x3; 16-byte aligned.  Scratch / tickets as for hitadv_linear_max_fwd
+ * (tickets must not be NULL). */
+int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream);
+int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin, int Cout,
+                                 int relu, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
+                                 int32_t *tickets, void *stream);
+int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout);
 
 /* ------------------------------------------------------------------ PointNet victim, attack-time view
  * The eval.py victim (model/feature_models.py:71-230: PointNetFeatureModel = PointNetEncoder + STN3d + STNkd) in

@@ -139,27 +139,41 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
-def knn_points(p1, p2, K):
-    """Canonical kNN -> (dists f32[B,N,K], idx i64[B,N,K])"""
+FORM_DIRECT, FORM_GRAM, FORM_GRAM_KNN = 0, 1, 2  # pair_value() in pointnet2_oracle.c
+
+
+def pairwise(x, y, form=FORM_DIRECT):
+    """P[B,N,M] with every entry evaluated in the given form (form 1 / 2 = the reference's own fp32 arithmetic)."""
+    a, ap = _f(x)
+    b, bp = _f(y)
+    B, N, _ = a.shape
+    M = b.shape[1]
+    P = torch.zeros(B, N, M)
+    lib().oracle_pairwise_form(B, N, M, form, ap, bp, _p(P))
+    return P
+
+
+def knn_points(p1, p2, K, form=FORM_DIRECT):
+    """Canonical kNN -> (dists f32[B,N,K], idx i64[B,N,K]); ascending, ties -> lower index."""
     q, qp = _f(p1)
     p, pp = _f(p2)
     B, N, _ = q.shape
     M = p.shape[1]
     d = torch.zeros(B, N, K)
     ix = torch.zeros(B, N, K, dtype=torch.int64)
-    lib().oracle_knn_points(B, N, M, K, qp, pp, _p(d), _p(ix))
+    lib().oracle_knn_points_form(B, N, M, K, form, qp, pp, _p(d), _p(ix))
     return d, ix
 
 
-def nn_min(x, y):
-    """-> (min_j |x_i-y_j|^2 f32[B,N], argmin i32[B,N])"""
+def nn_min(x, y, form=FORM_DIRECT):
+    """-> (min_j |x_i-y_j|^2 f32[B,N], argmin i32[B,N], lowest j on ties)"""
     a, ap = _f(x)
     b, bp = _f(y)
     B, N, _ = a.shape
     M = b.shape[1]
     d = torch.zeros(B, N)
     ix = torch.zeros(B, N, dtype=torch.int32)
-    lib().oracle_nn_min(B, N, M, ap, bp, _p(d), _p(ix))
+    lib().oracle_nn_min_form(B, N, M, form, ap, bp, _p(d), _p(ix))
     return d, ix
 
 

@@ -27,6 +27,37 @@ static inline float sqdist3(const float *a, const float *b) {
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+/*
+ * The reference's OWN fp32 arithmetic for a squared distance, as executed by torch on an x86 CPU (the GEMM behind
+ * torch.bmm / torch.matmul accumulates a K = 3 dot product as one FMA chain in k order; checked bit for bit against
+ * torch in tests/test_oracle_gram.py):
+ *   form 1  util/set_distance.py:15-32   P = (rx_i + ry_j) - 2 zz_ij, rx / ry = diagonal of bmm(x, x^T) (an FMA chain)
+ *   form 2  util/dist_utils.py:148-150   dist = (xx_j + (-2 zz_ij)) + xx_i, xx = sum(pc ** 2, dim=1) (plain adds)
+ * form 0 is the project's direct form.  q = the row / query point (i), p = the column / reference point (j).
+ */
+static inline float dot3_fma(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+
+static inline float pair_value(int form, const float *q, const float *p) {
+  if (form == 1) {
+    float rq = dot3_fma(q, q), rp = dot3_fma(p, p), zz = dot3_fma(q, p);
+    return (rq + rp) - 2.0f * zz;
+  }
+  if (form == 2) {
+    float xq = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2], xp = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+    float inner = -2.0f * dot3_fma(q, p);
+    return (xp + inner) + xq;
+  }
+  return sqdist3(q, p);
+}
+
+/* P[b,i,j] in the given form (x [b,n,3] rows, y [b,m,3] columns). */
+void oracle_pairwise_form(int b, int n, int m, int form, const float *x, const float *y, float *P) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < m; ++j)
+        P[((size_t)bi * n + i) * m + j] = pair_value(form, x + ((size_t)bi * n + i) * 3, y + ((size_t)bi * m + j) * 3);
+}
+
 /* include/cuda_utils.h:15-18: clamp(2^floor(log2 n), 1, 512) */
 static int opt_n_threads(int work) {
   int p = (int)(log((double)work) / log(2.0));
@@ -228,15 +259,15 @@ void oracle_three_interpolate_grad(int b, int c, int n, int m, const float *grad
  * called at ShapeAttack/HiT_ADV.py:78,320,329): K smallest direct-difference
  * squared distances, ascending, ties -> lower index.  Insertion list per query.
  */
-void oracle_knn_points(int b, int n, int m, int K, const float *q, const float *p, float *dists,
-                       int64_t *idx) {
+void oracle_knn_points_form(int b, int n, int m, int K, int form, const float *q, const float *p, float *dists,
+                            int64_t *idx) {
   for (int bi = 0; bi < b; ++bi)
     for (int i = 0; i < n; ++i) {
       float *bd = dists + ((size_t)bi * n + i) * K;
       int64_t *bix = idx + ((size_t)bi * n + i) * K;
       int cnt = 0;
       for (int j = 0; j < m; ++j) {
-        float d = sqdist3(q + ((size_t)bi * n + i) * 3, p + ((size_t)bi * m + j) * 3);
+        float d = pair_value(form, q + ((size_t)bi * n + i) * 3, p + ((size_t)bi * m + j) * 3);
         if (cnt == K && !(d < bd[K - 1])) continue;
         int pos = cnt < K ? cnt : K - 1;
         while (pos > 0 && d < bd[pos - 1]) {
@@ -251,20 +282,29 @@ void oracle_knn_points(int b, int n, int m, int K, const float *q, const float *
     }
 }
 
-/* Nearest neighbour of every x_i in y (direct form, lowest index on ties). */
-void oracle_nn_min(int b, int n, int m, const float *x, const float *y, float *mind,
-                   int32_t *argm) {
+void oracle_knn_points(int b, int n, int m, int K, const float *q, const float *p, float *dists,
+                       int64_t *idx) {
+  oracle_knn_points_form(b, n, m, K, 0, q, p, dists, idx);
+}
+
+/* Nearest neighbour of every x_i in y (lowest index on ties), distances in the given form. */
+void oracle_nn_min_form(int b, int n, int m, int form, const float *x, const float *y, float *mind,
+                        int32_t *argm) {
   for (int bi = 0; bi < b; ++bi)
     for (int i = 0; i < n; ++i) {
       float best = INFINITY;
       int bj = 0;
       for (int j = 0; j < m; ++j) {
-        float d = sqdist3(x + ((size_t)bi * n + i) * 3, y + ((size_t)bi * m + j) * 3);
+        float d = pair_value(form, x + ((size_t)bi * n + i) * 3, y + ((size_t)bi * m + j) * 3);
         if (d < best) { best = d; bj = j; }
       }
       mind[(size_t)bi * n + i] = best;
       argm[(size_t)bi * n + i] = bj;
     }
+}
+
+void oracle_nn_min(int b, int n, int m, const float *x, const float *y, float *mind, int32_t *argm) {
+  oracle_nn_min_form(b, n, m, 0, x, y, mind, argm);
 }
 
 /*

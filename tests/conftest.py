@@ -11,6 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    try:  # the CPU oracle's op sizes stop scaling (and start contending) beyond ~32 intra-op threads; the GPU box has 256
+        torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    except AttributeError:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

@@ -30,7 +30,7 @@ def test_invalid_arguments_return_error_codes_not_crashes():
     lib = _lib.load()
     null = ctypes.c_void_p(0)
     assert lib.hitadv_pairwise_sqdist(null, null, null, 1, 1, 1, 3, 0, null) == -1
-    assert lib.hitadv_knn_points(null, null, 1, 1, 1, 1, null, null, 1, null) == -1
+    assert lib.hitadv_knn_points(null, null, 1, 1, 1, 1, 0, null, null, 1, null) == -1
     assert lib.hitadv_deform_fwd(null, null, null, null, 1, 1, 1, null, null, null) == -1
     assert lib.hitadv_furthest_point_sampling(0, 0, 0, null, null, null, null) == -1
 

@@ -192,7 +192,7 @@ def test_hit_adv_batch32_follows_the_cpu_oracle(victim):
     best, succ = att.attack(data, label)
     ws = next(iter(att._ws.values()))
     assert torch.equal(ws.central.cpu(), oracle.state['central'])  # same 192 centres in all 32 clouds
-    tol = dict(rtol=1e-4, atol=2e-5)
+    tol = dict(rtol=1e-4, atol=1e-5)  # achieved on MI355X: <= 5.7e-6 absolute on clouds of unit scale
     for i, row in enumerate(rec.rows):
         close(row['adv'], trace[i]['adv'], what='iterate %d' % i, **tol)
         close(row['adv_loss'], trace[i]['adv_loss'], rtol=1e-4, atol=1e-5, what='adv_loss %d' % i)
@@ -654,7 +654,8 @@ def test_pointnet2_victim_on_gpu():
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         best, succ = att.attack(data, label)
-    assert best.shape == (2, 1024, 3) and np.isfinite(best).all() and not att.last_graph_used
+    # the victim's per-forward FPS starts come from the attack's pre-drawn feed (model/_sampling.py): the loop is captured
+    assert best.shape == (2, 1024, 3) and np.isfinite(best).all() and att.last_graph_used
 
 
 def test_pct_victim_on_gpu():

@@ -48,17 +48,19 @@ def test_pairwise_direct_bit_exact(A, n, m):
     assert torch.equal(P, O.pairwise_sqdist_direct(x, y))
 
 
-@pytest.mark.parametrize("n,m", [(1024, 1024), (100, 1001)])
-def test_pairwise_gram_within_gram_noise(A, n, m):
+@pytest.mark.parametrize("n,m", [(1024, 1024), (100, 1001), (7, 3)])
+@pytest.mark.parametrize("form", ["gram", "gram_knn"])
+def test_pairwise_gram_forms_bit_exact(A, n, m, form):
+    """Both Gram forms reproduce the oracle's restatement of the reference's arithmetic bit for bit -- which in turn is
+    checked bit for bit against torch itself in tests/test_oracle_gram.py (set_distance.py:15-32, dist_utils.py:148-150)."""
     x, _ = clouds(2, n, 100)
     y, _ = clouds(2, m, 110)
-    P = A.pairwise_sqdist(cu(x), cu(y), A.FORM_GRAM).cpu()
-    ref = O.pairwise_sqdist_gram(x, y)
-    # both sides evaluate |x|^2+|y|^2-2x.y in fp32; they differ by the rounding of 3-term dot products
-    scale = float((x ** 2).sum(-1).max() + (y ** 2).sum(-1).max())
-    assert (P - ref).abs().max().item() <= 8 * EPS * scale
+    f_hip, f_c = (A.FORM_GRAM, N.FORM_GRAM) if form == "gram" else (A.FORM_GRAM_KNN, N.FORM_GRAM_KNN)
+    P = A.pairwise_sqdist(cu(x), cu(y), f_hip).cpu()
+    assert torch.equal(P, N.pairwise(x, y, f_c))
     truth = ((x.double()[:, :, None] - y.double()[:, None]) ** 2).sum(-1)
-    assert (P - truth).abs().max().item() <= 8 * EPS * scale
+    scale = float((x ** 2).sum(-1).max() + (y ** 2).sum(-1).max())
+    assert (P - truth).abs().max().item() <= 8 * EPS * scale  # the Gram form's own cancellation noise
 
 
 def test_pairwise_generic_dim(A):
@@ -80,6 +82,22 @@ def test_nn_min_bit_exact_both_directions(A, n, m):
     ry, ray = N.nn_min(y, x)
     assert torch.equal(mx, rx) and torch.equal(ax, rax)
     assert torch.equal(my, ry) and torch.equal(ay, ray)
+
+
+@pytest.mark.parametrize("n,m", [(1024, 1024), (256, 1024), (1000, 37), (130, 2049)])
+def test_nn_min_reference_arithmetic_bit_exact(A, n, m):
+    """Gram-form minima (the reference's own values, set_distance.py:45-49) in both directions, bit for bit."""
+    x, _ = clouds(3, n, 120)
+    y = clouds(3, m, 130)[0] if n != m else x + 0.01 * torch.randn(x.shape, generator=torch.Generator().manual_seed(2))
+    mx, ax, my, ay = (t.cpu() for t in A.nn_min(cu(x), cu(y), reference=True))
+    rx, rax = N.nn_min(x, y, N.FORM_GRAM)
+    ry, ray = N.nn_min(y, x, N.FORM_GRAM)
+    assert torch.equal(mx, rx) and torch.equal(ax, rax)
+    assert torch.equal(my, ry) and torch.equal(ay, ray)
+    with A.reference_arithmetic(True):  # the package-wide switch selects the same kernels
+        mx2, _, my2, _ = A.nn_min(cu(x), cu(y))
+    assert torch.equal(mx2.cpu(), rx) and torch.equal(my2.cpu(), ry)
+    assert not A.reference_arithmetic.get()
 
 
 def test_nn_min_ties_take_lowest_index(A):
@@ -132,6 +150,39 @@ def test_set_distance_modules_vs_reference_vectors(A):
     close(a.grad, fx['HausdorffDist_both_grad'], rtol=1e-5, atol=1e-7)
 
 
+def test_set_distance_modules_reference_arithmetic_equal_reference_vectors(A):
+    """north_star's bar -- Chamfer / Hausdorff within 1e-5 relative of the reference -- WITHOUT an absolute floor: with
+    ``reference_arithmetic`` on, the minima are the reference's bit for bit, so Hausdorff values are EQUAL and Chamfer
+    values differ by the summation order of a 1024-term mean."""
+    from hit_adv_amd.util import dist_utils, set_distance
+    fx = golden('g1_set_distance.npz')
+    adv, ori, small, w = (cu(T(fx[k])) for k in ('adv', 'ori', 'small', 'weights'))
+    cham, haus = set_distance.ChamferDistance(True), set_distance.HausdorffDistance(True)
+    for name, mod, a, b in (('chamfer', cham, adv, ori), ('chamfer_small', cham, small, ori)):
+        l1, l2 = mod(a, b)
+        close(l1, fx[name + '_l1'], rtol=1e-6, atol=0, what=name + ' l1 (reference arithmetic)')
+        close(l2, fx[name + '_l2'], rtol=1e-6, atol=0, what=name + ' l2 (reference arithmetic)')
+    for name, a in (('hausdorff', adv), ('hausdorff_small', small)):
+        l1, l2 = haus(a, ori)
+        assert np.array_equal(l1.cpu().numpy(), fx[name + '_l1']) and np.array_equal(l2.cpu().numpy(), fx[name + '_l2'])
+    for m in ('adv2ori', 'ori2adv', 'both'):
+        close(dist_utils.ChamferDist(m, reference_arithmetic=True)(adv, ori, w, batch_avg=False),
+              fx['ChamferDist_%s' % m], rtol=1e-6, atol=0, what='ChamferDist %s (reference arithmetic)' % m)
+        close(dist_utils.HausdorffDist(m, reference_arithmetic=True)(adv, ori, w, batch_avg=False),
+              fx['HausdorffDist_%s' % m], rtol=1e-6, atol=0, what='HausdorffDist %s (reference arithmetic)' % m)
+    fx2 = golden('g2_knn_dist.npz')
+    adv2, ori2 = cu(T(fx2['adv'])), cu(T(fx2['ori']))
+    for k in (4, 5):
+        close(dist_utils.KNNDist(k=k, reference_arithmetic=True)(adv2, batch_avg=False), fx2['KNNDist_k%d' % k],
+              rtol=1e-5, atol=0, what='KNNDist k=%d (reference arithmetic)' % k)
+    close(dist_utils.ChamferkNNDist(reference_arithmetic=True)(adv2, ori2, batch_avg=False), fx2['ChamferkNNDist'],
+          rtol=1e-5, atol=0, what='ChamferkNNDist (reference arithmetic)')
+    # gradients still flow (through the same arg-minima), evaluated as 2 g (x - y)
+    a = adv.clone().requires_grad_()
+    dist_utils.ChamferDist('both', reference_arithmetic=True)(a, ori, w).backward()
+    close(a.grad, fx['ChamferDist_both_grad'], rtol=1e-4, atol=1e-7, what='ChamferDist grad (reference arithmetic)')
+
+
 def test_nn_min_backward_matches_autograd_of_direct_matrix(A):
     x, _ = clouds(2, 300, 160)
     y, _ = clouds(2, 257, 170)
@@ -148,7 +199,7 @@ def test_nn_min_backward_matches_autograd_of_direct_matrix(A):
 
 
 # ------------------------------------------------------------------ K4 kNN
-@pytest.mark.parametrize("K", [1, 5, 6, 17, 33, 64])
+@pytest.mark.parametrize("K", [1, 4, 5, 6, 8, 16, 17, 20, 30, 32, 33, 64])
 def test_knn_points_bit_exact(A, K):
     from hit_adv_amd.pytorch3d_ops import knn_points
     x, _ = clouds(2, 1024, 180)
@@ -157,6 +208,48 @@ def test_knn_points_bit_exact(A, K):
     d, ix = N.knn_points(q, x, K)
     assert r.idx.dtype == torch.int64
     assert torch.equal(r.idx.cpu(), ix) and torch.equal(r.dists.cpu(), d)
+
+
+@pytest.mark.parametrize("m", [2048, 1500, 51, 7, 3000])
+@pytest.mark.parametrize("K", [3, 6, 17, 32])
+def test_knn_points_sizes_and_both_selection_kernels(A, m, K):
+    """Reference counts on both sides of the select kernel's range (M <= 2048; beyond it the insertion-list kernel runs),
+    fewer references than a lane's list (M = 7, 51), queries != references."""
+    if K > m:
+        pytest.skip("K > M")
+    x, _ = clouds(2, m, 181)
+    q, _ = clouds(2, 130, 182)
+    d, ix = A.KnnPoints.apply(cu(q), cu(x), K)
+    rd, rix = N.knn_points(q, x, K)
+    assert torch.equal(ix.cpu(), rix) and torch.equal(d.cpu(), rd)
+
+
+@pytest.mark.parametrize("K", [5, 6, 17, 33])
+def test_knn_points_gram_knn_form_bit_exact(A, K):
+    """KNNDist's own distance matrix (dist_utils.py:148-150) inside the fused selection: the k+1 smallest values the
+    reference's topk(-dist) returns, bit for bit (rank 0 need not be the point itself in this form)."""
+    x, _ = clouds(2, 1024, 183)
+    d, ix = A.KnnPoints.apply(cu(x), cu(x), K, A.FORM_GRAM_KNN)
+    rd, rix = N.knn_points(x, x, K, N.FORM_GRAM_KNN)
+    assert torch.equal(d.cpu(), rd) and torch.equal(ix.cpu(), rix)
+
+
+def test_knn_points_heavy_ties_and_log_compaction(A):
+    """Adversarial orders for the select kernel: distances that fall monotonically along the scan (every reference is
+    accepted: the per-lane log overflows and is compacted again and again) and clouds made of a few distinct points
+    (many exact ties at the threshold)."""
+    g = torch.Generator().manual_seed(9)
+    q = torch.zeros(1, 64, 3)
+    q[0, :, 0] = torch.linspace(-0.01, 0.01, 64)
+    far_to_near = torch.zeros(1, 1024, 3)
+    far_to_near[0, :, 0] = torch.linspace(5.0, 0.5, 1024)   # reference j+1 is closer than reference j for every query
+    far_to_near[0, :, 1] = 0.001 * torch.randn(1024, generator=g)
+    few = torch.randn(1, 6, 3, generator=g)[:, torch.randint(0, 6, (1024,), generator=g)]
+    for refs in (far_to_near, few, torch.cat([few[:, :500], far_to_near[:, :524]], 1)):
+        for K in (6, 17, 32):
+            d, ix = A.KnnPoints.apply(cu(q), cu(refs), K)
+            rd, rix = N.knn_points(q, refs, K)
+            assert torch.equal(ix.cpu(), rix) and torch.equal(d.cpu(), rd), K
 
 
 def test_knn_points_duplicates_ragged_and_gather(A):
@@ -575,6 +668,46 @@ def test_linear_max_fwd_mfma(A, B, Np, Cin, Cout):
     assert torch.equal(v3, val) and torch.equal(i3, idx)
     _, iu = A.max_over_points(cu(x) @ cu(Wt), B, Np)
     assert torch.equal(iu.cpu()[clear], idx.cpu()[clear])
+
+
+@pytest.mark.parametrize("B,Np,Cin,Cout", [(32, 1024, 128, 1024), (3, 1000, 128, 1024), (2, 130, 64, 256), (5, 64, 128, 320)])
+def test_linear_max_fwd_bf16x3_is_fp32_accurate(A, B, Np, Cin, Cout):
+    """The same operator on the bf16 matrix cores with both operands split into three bf16 pieces (csrc/victim_bf3.hip):
+    the pieces sum to the fp32 value EXACTLY, and the result is as close to float64 as the f32-MFMA kernel's -- nothing is
+    rounded to bf16 precision.  Achieved errors of both forms are recorded side by side."""
+    g = torch.Generator().manual_seed(B * 1000 + Np)
+    x = torch.randn(B * Np, Cin, generator=g).relu()  # the layer's input is a ReLU output
+    Wt = torch.randn(Cin, Cout, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g)
+    W3 = A.split_weights_bf16x3(cu(Wt.t().contiguous()))
+    pieces = (W3.cpu().view(torch.bfloat16) if W3.dtype != torch.bfloat16 else W3.cpu()).float()
+    assert torch.equal(pieces[0] + pieces[1] + pieces[2], Wt.t())  # exact three-way split
+    y = (x.double() @ Wt.double()).view(B, Np, Cout)
+    ref_val, ref_idx = y.max(dim=1)
+    val, idx = A.linear_max_fwd_bf16x3(cu(x), W3, B, Np)
+    f32_val, f32_idx = A.linear_max_fwd(cu(x), cu(Wt), B, Np)
+    close(val, ref_val.float(), rtol=2e-6, atol=2e-5, what='bf16x3 max vs float64')
+    close(f32_val, ref_val.float(), rtol=2e-6, atol=2e-5, what='f32 MFMA max vs float64')
+    e3, e1 = (val.cpu().double() - ref_val).abs().max().item(), (f32_val.cpu().double() - ref_val).abs().max().item()
+    assert e3 <= 2 * e1 + 1e-6, (e3, e1)  # no worse than the exact-f32 kernel (both are bounded by the fp32 accumulation)
+    top2 = y.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert torch.equal(idx.cpu()[clear], ref_idx[clear]) and torch.equal(idx.cpu()[clear], f32_idx.cpu()[clear])
+    close(y.gather(1, idx.cpu().unsqueeze(1)).squeeze(1).float(), val, rtol=2e-6, atol=2e-5, what='bf16x3 arg-max row')
+    val2, idx2 = A.linear_max_fwd_bf16x3(cu(x), W3, B, Np, bias=cu(bias), relu=True)
+    assert torch.equal(idx2, idx) and torch.equal(val2, (val + cu(bias)).clamp_min(0.))
+    v3, i3 = A.linear_max_fwd_bf16x3(cu(x), W3, B, Np)
+    assert torch.equal(v3, val) and torch.equal(i3, idx)  # bitwise reproducible
+
+
+def test_linear_max_fwd_bf16x3_ties_keep_the_first_point(A):
+    g = torch.Generator().manual_seed(3)
+    B, Np, Cin, Cout = 2, 1024, 128, 256
+    base = torch.randn(B, 8, Cin, generator=g)
+    x = base.repeat_interleave(Np // 8, dim=1).reshape(B * Np, Cin)
+    W3 = A.split_weights_bf16x3(cu(torch.randn(Cout, Cin, generator=g)))
+    _, idx = A.linear_max_fwd_bf16x3(cu(x), W3, B, Np)
+    assert (idx.cpu() % (Np // 8) == 0).all()
 
 
 def test_linear_max_fwd_ties_and_errors(A):

@@ -68,7 +68,7 @@ def main():
         out['pairwise_' + name] = dict(us=round(us, 2), GBps=round(by / us / 1e3, 1), frac_of_8TBps=round(by / us / 1e3 / 8000, 4))
     mx, my = torch.empty(B, N, device='cuda'), torch.empty(B, N, device='cuda')
     ax, ay = torch.empty(B, N, device='cuda', dtype=torch.int32), torch.empty(B, N, device='cuda', dtype=torch.int32)
-    us = timed(lambda s=s0: lib.hitadv_nn_min(p(x), p(y), B, N, N, 3, p(mx), p(ax), p(my), p(ay), None, s), a.reps)
+    us = timed(lambda s=s0: lib.hitadv_nn_min(p(x), p(y), B, N, N, 3, 0, p(mx), p(ax), p(my), p(ay), None, s), a.reps)
     pairs = 2 * B * N * N  # both directions evaluated independently
     out['nn_min'] = dict(us=round(us, 2), Gpairs_per_s=round(pairs / us / 1e3, 1),
                          valu_TFLOPs_at_11_ops=round(pairs * 11 / us / 1e6, 2))
@@ -80,7 +80,7 @@ def main():
     for K in (1, 6, 17):
         d = torch.empty(B, N, K, device='cuda')
         ix = torch.empty(B, N, K, device='cuda', dtype=torch.int64)
-        us = timed(lambda s=s0: lib.hitadv_knn_points(p(x), p(x), B, N, N, K, p(d), p(ix), 1, s), max(20, a.reps // 4))
+        us = timed(lambda s=s0: lib.hitadv_knn_points(p(x), p(x), B, N, N, K, 0, p(d), p(ix), 1, s), max(20, a.reps // 4))
         out['knn_K%d' % K] = dict(us=round(us, 2), Gpairs_per_s=round(B * N * N / us / 1e3, 1))
     ori = x.transpose(1, 2).contiguous()
     central = ori[:, :, :C].contiguous()
