@@ -439,6 +439,9 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="cfg2: skip the extra one-attack-in-flight measurement")
+    ap.add_argument("--matrix-mode", choices=["bf16x3", "f32"], default=None,
+                    help="cfg2: how the PointNet engine runs its 128->1024 layers (default: the engine's own default)")
+    ap.add_argument("--iters-per-graph", type=int, default=None, help="HiT-ADV iterations recorded per hipGraph")
     ap.add_argument("--concurrent", type=int, default=None,
                     help="independent attack() batches in flight per GPU (separate HIP streams; 1 = strictly serial)")
     args = ap.parse_args()
@@ -462,6 +465,12 @@ def main():
     _lib.load()  # fail loudly if the HIP library is missing
 
     model = build_victim(cfg).to(dev)
+    if args.matrix_mode is not None:
+        from hit_adv_amd.model.pointnet import FoldedPointNet
+        FoldedPointNet.matrix_mode = args.matrix_mode
+    if args.iters_per_graph is not None:
+        from hit_adv_amd.ShapeAttack import HiT_ADV as _H
+        _H.HiT_ADV._chunk = lambda self, n=args.iters_per_graph: max(1, min(n, self.num_iter))
     run, prewarm, info, iters_per_step = make_runner(cfg, model, dev, concurrent)
     nbatch = warmup + steps
     extra = 2 if (args.config == 'cfg2' and not args.no_single and world == 1) else 0

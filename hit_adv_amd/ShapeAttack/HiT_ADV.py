@@ -74,7 +74,8 @@ class _Workspace:
         self.gp_reg, self.gs_reg = torch.empty(B, C, 3, **f), torch.empty(B, C, **f)
         self.g_adv = torch.empty(B, 3, N, **f)
         self.deform_part = torch.empty(ops.deform_bwd_scratch(B, N, C), **f)
-        self.reg_scratch = torch.empty(ops.regulariser_scratch(B), **f)
+        self.reg_scratch = torch.zeros(ops.regulariser_scratch(B), **f)  # zeroed: its last float is a ticket
+        self.head_scratch = ops.iteration_head_scratch(B, dev)
         self.scaled = torch.zeros((), **f)
 
     def reset_step(self):
@@ -255,7 +256,8 @@ class HiT_ADV:
         """The same iteration with the chain rule written out instead of recorded: autograd is used for the victim
         only (any nn.Module), every other forward / backward is an explicit kernel call on workspace buffers, and
         gradient sums ride inside the consuming kernels (victim + regulariser into deform_bwd's upstream; deformation +
-        regulariser into Adam).  9 launches around the victim instead of ~37.  The projection of (perturb, sigma)
+        regulariser into Adam).  6 launches around the victim instead of ~37 (deform_fwd, iteration_head, regulariser
+        forward, regulariser backward, deform_bwd, Adam).  The projection of (perturb, sigma)
         (:157-158) is applied by the Adam kernel right after the update -- the parameters every forward pass sees
         are the same (the initial draws already lie inside the box)."""
         regs = (self.cd_weight, self.ker_weight, self.hide_weight)
@@ -264,20 +266,27 @@ class HiT_ADV:
         ops.deform_fwd_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den)
         x = ws.adv.detach().requires_grad_()
         logits = self._logits(x, ws.feed)
-        ops.best_update(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, counter=ws.step)
-        _, dlogits = self.adv_func.fused(logits, ws.target, loss_out=ws.adv_loss)
+        if hasattr(self.adv_func, 'fused_kind'):  # best-result tracking + adversarial loss: one launch
+            kind, kappa = self.adv_func.fused_kind()
+            dlogits = torch.empty_like(logits)
+            ops.iteration_head(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, ws.step, kind, kappa, ws.adv_loss,
+                               dlogits, ws.head_scratch)
+        else:
+            ops.best_update(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, counter=ws.step)
+            _, dlogits = self.adv_func.fused(logits, ws.target, loss_out=ws.adv_loss)
         g_victim, = torch.autograd.grad(logits, x, grad_outputs=dlogits)
         if any(w != 0 for w in regs):
-            ops.regulariser_fwd_into(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.scale_const, regs, rng, ws.reg_scratch,
-                                     ws.dist_loss, ws.scaled)
+            ops.regulariser_fwd_fused_into(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.scale_const, regs, rng,
+                                           ws.reg_scratch, ws.dist_loss, ws.scaled)
             ops.regulariser_bwd_add(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.reg_scratch, g_victim.contiguous(), regs,
                                     rng, ws.gp_reg, ws.gs_reg, ws.g_adv)
             g_adv, gp2, gs2 = ws.g_adv, ws.gp_reg, ws.gs_reg
         else:
             g_adv, gp2, gs2 = g_victim.contiguous(), None, None
-        ops.deform_bwd_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den, g_adv, ws.deform_part, ws.gp, ws.gs)
-        ops.adam_step_sum(P, sigma, ws.gp, gp2, ws.gs, gs2, ws.m_p, ws.v_p, ws.m_s, ws.v_s, ws.step,
-                          self.attack_lr * 5, self.attack_lr * 3, (-self.budget, self.budget), rng)
+        # the deformation's gradient stays in its per-slab partials; the Adam kernel sums them (in the reduce order)
+        ops.deform_bwd_partials_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den, g_adv, ws.deform_part)
+        ops.adam_step_partials(P, sigma, ws.deform_part, ws.N, gp2, gs2, ws.m_p, ws.v_p, ws.m_s, ws.v_s, ws.step,
+                               self.attack_lr * 5, self.attack_lr * 3, (-self.budget, self.budget), rng)
 
     def _warm_up(self, ws):
         """Two eager passes of the iteration on ``ws.stream``; the second under PyTorch's sync-debug mode set

@@ -43,6 +43,12 @@ PROTOTYPES = {
     "hitadv_regulariser_bwd_add": [_P] * 8 + [_I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hitadv_adam_step_sum": [_P, _P, _P, _P, _P, _c.c_int64, _F, _F, _F, _P, _P, _P, _P, _P, _c.c_int64, _F, _F, _F, _P, _P],
     "hitadv_adv_loss": [_I, _P, _P, _I, _I, _F, _P, _P, _P],
+    "hitadv_iteration_head": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P],
+    "hitadv_iteration_head_scratch_floats": [_I],
+    "hitadv_regulariser_fwd_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "hitadv_deform_bwd_partials": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "hitadv_deform_bwd_slabs": [_I],
+    "hitadv_adam_step_partials": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P],
     "hitadv_linear_max_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "hitadv_max_over_points": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hitadv_max_over_points_scratch": [_I, _I],
@@ -69,7 +75,7 @@ PROTOTYPES = {
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,
             "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_linear_max_fwd_scratch": _c.c_int64, "hitadv_linear_max_fwd_bf16x3_scratch": _c.c_int64, "hitadv_pointnet_rowmlp_tiles": _c.c_int64, "hitadv_fc_layer_scratch_floats": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64,
-            "hitadv_edge_max_bwd_scratch_ints": _c.c_int64, "hitadv_group_add_relu_bwd_scratch_ints": _c.c_int64}
+            "hitadv_edge_max_bwd_scratch_ints": _c.c_int64, "hitadv_iteration_head_scratch_floats": _c.c_int64, "hitadv_deform_bwd_slabs": _c.c_int64, "hitadv_group_add_relu_bwd_scratch_ints": _c.c_int64}
 
 _lib = None
 

@@ -187,6 +187,22 @@ extern "C" int64_t hitadv_deform_bwd_scratch_floats(int B, int N, int C) {
   return (int64_t)B * nslab * 4 * C;
 }
 
+extern "C" int64_t hitadv_deform_bwd_slabs(int N) { return N > 0 ? (N + DB_PTS - 1) / DB_PTS : 0; }
+
+// The first launch of hitadv_deform_bwd alone: per-slab partials [B,nslab,4,C] for a consumer that sums them itself
+// (hitadv_adam_step_partials, in the reduce kernel's order).
+extern "C" int hitadv_deform_bwd_partials(const float *ori, const float *central, const float *perturb,
+                                          const float *sigma, const float *adv, const float *inv_den,
+                                          const float *g_adv, int B, int N, int C, float *partials, void *stream) {
+  if (!ori || !central || !perturb || !sigma || !adv || !inv_den || !g_adv || !partials || B <= 0 || N <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  const int nslab = (N + DB_PTS - 1) / DB_PTS;
+  dim3 grid((C + 255) / 256, nslab, B);
+  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int hitadv_deform_bwd(const float *ori, const float *central, const float *perturb,
                                  const float *sigma, const float *adv, const float *inv_den,
                                  const float *g_adv, int B, int N, int C, float *partials,

@@ -1,0 +1,209 @@
+// Fewer, fatter launches around the victim inside one HiT-ADV iteration (ShapeAttack/HiT_ADV.py:156-246).  At one attack in
+// flight the iteration is a chain of dependent launches of ~4-7 us each; these entry points merge neighbours of that chain
+// whose data dependence allows it, without changing a single result bit:
+//   hitadv_iteration_head       best-result tracking (hitadv_best_update) + adversarial loss and d loss / d logits
+//                               (hitadv_adv_loss): both consume only the logits; one block per cloud, the batch mean of
+//                               the loss is taken in cloud order by the last block to arrive
+//   hitadv_deform_bwd_partials  the deformation backward WITHOUT its reduce launch ...
+//   hitadv_adam_step_partials   ... whose fixed-order slab sum happens inside the Adam kernel that consumes it
+#include "common.hpp"
+#include "hitadv.h"
+
+namespace hitadv {
+
+__device__ __forceinline__ uint32_t ordered_bits_i(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// One block (256 threads) per cloud.  Waves 0..3 share the transformation-loss sums; wave 0 finds the prediction, wave 1
+// the adversarial loss row.  scratch: per[B] floats, then one int ticket (zeroed once by the caller).
+__global__ __launch_bounds__(256) void iteration_head_k(
+    const float *__restrict__ logits, const int64_t *__restrict__ label, const float *__restrict__ perturb,
+    const float *__restrict__ sigma, const float *__restrict__ adv, int B, int num_class, int N, int C,
+    float *__restrict__ bestdist, int64_t *__restrict__ bestscore, float *__restrict__ o_bestdist,
+    int64_t *__restrict__ o_bestscore, float *__restrict__ o_bestattack, int64_t *__restrict__ pred_out,
+    float *__restrict__ dist_val_out, int32_t *__restrict__ iter_counter, int kind, float kappa,
+    float *__restrict__ loss, float *__restrict__ dlogits, float *per, int *ticket) {
+  __shared__ float s1[4], s2[4];
+  __shared__ int s_copy, s_last;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // transformation_loss(batch_avg=False): (|P_b|_F + |1 - sigma_b|_2) / C   -- as best_update_k
+  float a1 = 0.f, a2 = 0.f;
+  const float *pp = perturb + (size_t)b * C * 3;
+  for (int e = threadIdx.x; e < C * 3; e += 256) a1 = fmaf(pp[e], pp[e], a1);
+  const float *sp = sigma + (size_t)b * C;
+  for (int e = threadIdx.x; e < C; e += 256) {
+    const float t = 1.0f - sp[e];
+    a2 = fmaf(t, t, a2);
+  }
+  a1 = wave_sum(a1);
+  a2 = wave_sum(a2);
+  if (lane == 0) {
+    s1[wave] = a1;
+    s2[wave] = a2;
+  }
+  const float *z = logits + (size_t)b * num_class;
+  unsigned long long key = 0ull;
+  if (wave == 0) {  // argmax over the logits, lowest index on ties
+    for (int c = lane; c < num_class; c += 64) {
+      const unsigned long long k = ((unsigned long long)ordered_bits_i(z[c]) << 32) | (0xFFFFFFFFu - (uint32_t)c);
+      key = k > key ? k : key;
+    }
+    key = wave_max_u64(key);
+  } else if (wave == 1) {  // adversarial loss row of this cloud -- as adv_loss_k
+    float *d = dlogits + (size_t)b * num_class;
+    const int t = (int)label[b];
+    const float invB = 1.0f / (float)B;
+    float mine;
+    if (kind == 2) {
+      float mx = -__builtin_inff();
+      for (int j = lane; j < num_class; j += 64) mx = fmaxf(mx, z[j]);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, HITADV_WAVE));
+      float se = 0.f;
+      for (int j = lane; j < num_class; j += 64) se += __expf(z[j] - mx);
+      se = wave_sum(se);
+      const float lse = mx + __logf(se);
+      for (int j = lane; j < num_class; j += 64) d[j] = (__expf(z[j] - lse) - (j == t ? 1.0f : 0.f)) * invB;
+      mine = lse - z[t];
+    } else {
+      unsigned long long k2 = 0ull;
+      for (int j = lane; j < num_class; j += 64) {
+        const float v = j == t ? -10000.f : z[j];
+        const unsigned long long k = ((unsigned long long)ordered_bits_i(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
+        k2 = k > k2 ? k : k2;
+      }
+      k2 = wave_max_u64(k2);
+      const int o = (int)(0xFFFFFFFFu - (uint32_t)(k2 & 0xffffffffu));
+      const float other = o == t ? -10000.f : z[o];
+      const float margin = kind == 0 ? (z[t] - other) + kappa : (other - z[t]) + kappa;
+      const bool on = margin >= 0.f;  // torch's clamp(min=0) passes the gradient at the boundary
+      const float s = on ? (kind == 0 ? invB : -invB) : 0.f;
+      for (int j = lane; j < num_class; j += 64) d[j] = (j == t ? s : 0.f) - ((j == o && o != t) ? s : 0.f);
+      mine = margin > 0.f ? margin : 0.f;
+    }
+    if (lane == 0) __hip_atomic_store(&per[b], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float dv = (__builtin_sqrtf((s1[0] + s1[1]) + (s1[2] + s1[3])) +
+                      __builtin_sqrtf((s2[0] + s2[1]) + (s2[2] + s2[3]))) / (float)C;
+    const int64_t pred = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xffffffffu));
+    pred_out[b] = pred;
+    dist_val_out[b] = dv;
+    int copy = 0;
+    if (pred != label[b]) {
+      if (dv < bestdist[b]) {
+        bestdist[b] = dv;
+        bestscore[b] = pred;
+      }
+      if (dv < o_bestdist[b]) {
+        o_bestdist[b] = dv;
+        o_bestscore[b] = pred;
+        copy = 1;
+      }
+    }
+    s_copy = copy;
+    if (b == 0 && iter_counter != nullptr) *iter_counter += 1;
+  }
+  __syncthreads();
+  if (s_copy) {
+    const float *src = adv + (size_t)b * 3 * N;
+    float *dst = o_bestattack + (size_t)b * 3 * N;
+    for (int e = threadIdx.x; e < 3 * N; e += 256) dst[e] = src[e];
+  }
+  // batch mean of the loss, in cloud order, by the last block to arrive (hand-off protocol: common.hpp)
+  if (!handoff_last_arriver(ticket, 0, B, &s_last)) return;
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int q = 0; q < B; ++q) a += __hip_atomic_load(&per[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    loss[0] = a / (float)B;
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// Adam on (perturb [B,C,3], sigma [B,C]) with the deformation's gradient still in its per-slab partials
+// [B,nslab,4,C] (summed here in ascending slab order = deform_bwd_reduce's order) plus an optional second term, then the
+// projection of adam2_k.  One thread per (cloud, centre).
+__global__ __launch_bounds__(256) void adam_partials_k(float *__restrict__ P, float *__restrict__ S,
+                                                       const float *__restrict__ partials, int nslab,
+                                                       const float *__restrict__ hP, const float *__restrict__ hS,
+                                                       float *__restrict__ mP, float *__restrict__ vP,
+                                                       float *__restrict__ mS, float *__restrict__ vS, int B, int C,
+                                                       float lrP, float loP, float hiP, float lrS, float loS, float hiS,
+                                                       const int32_t *__restrict__ step) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * C) return;
+  const int b = e / C, j = e % C;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nslab; ++s) {
+    const float *p = partials + (((size_t)b * nslab + s) * 4) * C + j;
+    g[0] += p[0];
+    g[1] += p[C];
+    g[2] += p[2 * C];
+    g[3] += p[3 * C];
+  }
+  const int t = *step;
+  const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
+  const double bc1 = 1.0 - pow(beta1, (double)t);
+  const double bc2 = 1.0 - pow(beta2, (double)t);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  auto upd = [&](float *p, float *m, float *v, size_t i, float gi, double lr, float lo, float hi) {
+    const float step_size = (float)(lr / bc1);
+    const float mi = m[i] + (gi - m[i]) * (float)(1.0 - beta1);
+    const float vi = v[i] * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = __builtin_sqrtf(vi) / bc2_sqrt + (float)eps;
+    float q = p[i] - (step_size * mi) / denom;
+    if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);
+    p[i] = q;
+  };
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t i = (size_t)e * 3 + c;
+    upd(P, mP, vP, i, hP ? g[c] + hP[i] : g[c], (double)lrP, loP, hiP);
+  }
+  upd(S, mS, vS, (size_t)e, hS ? g[3] + hS[e] : g[3], (double)lrS, loS, hiS);
+}
+
+}  // namespace hitadv
+
+using namespace hitadv;
+
+extern "C" int64_t hitadv_iteration_head_scratch_floats(int B) { return B > 0 ? (int64_t)B + 4 : 0; }
+
+extern "C" int hitadv_iteration_head(const float *logits, const int64_t *label, const float *perturb, const float *sigma,
+                                     const float *adv, int B, int num_class, int N, int C, float *bestdist,
+                                     int64_t *bestscore, float *o_bestdist, int64_t *o_bestscore, float *o_bestattack,
+                                     int64_t *pred_out, float *dist_val_out, int32_t *iter_counter, int kind, float kappa,
+                                     float *loss, float *dlogits, float *scratch, void *stream) {
+  if (!logits || !label || !perturb || !sigma || !adv || !bestdist || !bestscore || !o_bestdist || !o_bestscore ||
+      !o_bestattack || !pred_out || !dist_val_out || !loss || !dlogits || !scratch || kind < 0 || kind > 2 || B <= 0 ||
+      num_class <= 0 || N <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  iteration_head_k<<<B, 256, 0, (hipStream_t)stream>>>(logits, label, perturb, sigma, adv, B, num_class, N, C, bestdist,
+                                                       bestscore, o_bestdist, o_bestscore, o_bestattack, pred_out,
+                                                       dist_val_out, iter_counter, kind, kappa, loss, dlogits, scratch,
+                                                       reinterpret_cast<int *>(scratch + B));
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_adam_step_partials(float *perturb, float *sigma, const float *partials, int nslab,
+                                         const float *g_perturb2, const float *g_sigma2, float *m_perturb,
+                                         float *v_perturb, float *m_sigma, float *v_sigma, int B, int C, float lr_perturb,
+                                         float lo_perturb, float hi_perturb, float lr_sigma, float lo_sigma,
+                                         float hi_sigma, const int32_t *step, void *stream) {
+  if (!perturb || !sigma || !partials || !m_perturb || !v_perturb || !m_sigma || !v_sigma || !step || nslab <= 0 ||
+      B <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  adam_partials_k<<<(B * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(perturb, sigma, partials, nslab, g_perturb2,
+                                                                        g_sigma2, m_perturb, v_perturb, m_sigma, v_sigma, B,
+                                                                        C, lr_perturb, lo_perturb, hi_perturb, lr_sigma,
+                                                                        lo_sigma, hi_sigma, step);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}

@@ -165,22 +165,27 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
 //   * at the end the surviving entries are matched to the slots of the sorted distance list (equal distances: in log =
 //     index order), distances re-evaluated from the LDS-resident references with the same expression, bit for bit;
 //   * the four waves' lists meet in LDS and wave 0 merges them (K steps, index compare on equal distances).
-__host__ __device__ constexpr int ks_cap(int KB) { return KB <= 8 ? 32 : (KB <= 16 ? 64 : 96); }
-__host__ __device__ constexpr size_t ks_union_bytes(int KB) {
-  return (size_t)4 * 64 * (ks_cap(KB) * 2 > KB * 8 ? ks_cap(KB) * 2 : KB * 8);
+// NW waves of a block split the reference range for the same 64 queries (NW = 8 from 512 references on: 4096 short waves
+// instead of 2048 give every SIMD four waves to switch between -- the scan is a chain of dependent VALU instructions).
+__host__ __device__ constexpr int ks_cap(int KB, int NW) {  // >= 2 KB - 1 survivors of a compaction + one group of 4
+  return NW == 8 ? (KB <= 8 ? 24 : (KB <= 12 ? 32 : (KB <= 20 ? 44 : 72))) : (KB <= 8 ? 32 : (KB <= 16 ? 64 : 96));
+}
+__host__ __device__ constexpr size_t ks_union_bytes(int KB, int NW) {
+  return (size_t)NW * 64 * (ks_cap(KB, NW) * 2 > KB * 8 ? ks_cap(KB, NW) * 2 : KB * 8);
 }
 
-template <int KB, int FORM>
-__global__ __launch_bounds__(256) void knn_select(const float *__restrict__ q, const float *__restrict__ p, int N, int M,
-                                                  int K, float *__restrict__ dists, void *__restrict__ idx_out,
-                                                  int idx_is_i64) {
-  constexpr int CAP = ks_cap(KB);
+template <int KB, int FORM, int NW>
+__global__ __launch_bounds__(NW * 64) void knn_select(const float *__restrict__ q, const float *__restrict__ p, int N,
+                                                      int M, int K, float *__restrict__ dists,
+                                                      void *__restrict__ idx_out, int idx_is_i64) {
+  constexpr int CAP = ks_cap(KB, NW);
+  static_assert(CAP >= 2 * KB + 3, "a compaction must leave room for one group of four candidates");
   extern __shared__ __attribute__((aligned(16))) char ks_smem[];
   const int Mpad = (M + 3) & ~3;
-  float4 *sref = reinterpret_cast<float4 *>(ks_smem);                                  // [Mpad]
-  unsigned short *slog = reinterpret_cast<unsigned short *>(ks_smem + (size_t)Mpad * 16);  // [4][CAP][64]
-  float *md = reinterpret_cast<float *>(ks_smem + (size_t)Mpad * 16);                  // after the scan: [4][KB][64]
-  int *mi = reinterpret_cast<int *>(md + 4 * KB * 64);
+  float4 *sref = reinterpret_cast<float4 *>(ks_smem);                                       // [Mpad]
+  unsigned short *slog = reinterpret_cast<unsigned short *>(ks_smem + (size_t)Mpad * 16);   // [NW][CAP][64]
+  float *md = reinterpret_cast<float *>(ks_smem + (size_t)Mpad * 16);                       // after the scan: [NW][KB][64]
+  int *mi = reinterpret_cast<int *>(md + NW * KB * 64);
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = blockIdx.x * 64 + lane;
@@ -189,78 +194,93 @@ __global__ __launch_bounds__(256) void knn_select(const float *__restrict__ q, c
   const float qx = qp[0], qy = qp[1], qz = qp[2];
   const float rq = sq_norm<FORM>(qx, qy, qz);
   p += (size_t)b * M * 3;
-  for (int r = threadIdx.x; r < M; r += 256) {
+  for (int r = threadIdx.x; r < M; r += NW * 64) {
     const float *s = p + (size_t)r * 3;
     sref[r] = make_float4(s[0], s[1], s[2], sq_norm<FORM>(s[0], s[1], s[2]));
   }
   __syncthreads();
   float L[KB];
+  int I[KB];
 #pragma unroll
-  for (int t = 0; t < KB; ++t) L[t] = __builtin_inff();
-  unsigned short *mylog = slog + (size_t)wave * CAP * 64 + lane;
-  int cnt = 0;
+  for (int t = 0; t < KB; ++t) {
+    L[t] = __builtin_inff();
+    I[t] = 0x7fffffff;
+  }
+  const int per = (M + NW - 1) / NW;
+  const int lo = wave * per, hi = min(lo + per, M);
   auto dist_of = [&](int j) {
     const float4 v = sref[j];
     return pair_dist<FORM>(qx, qy, qz, rq, v.x, v.y, v.z, v.w);
   };
-  auto compact = [&]() {  // keep the logged candidates that can still be among the K best, in order
-    const float tau = L[KB - 1];
-    int w = 0;
-    for (int e = 0; e < CAP; ++e) {
-      if (e < cnt) {
-        const int j = mylog[e * 64];
-        if (dist_of(j) <= tau) {
-          mylog[w * 64] = (unsigned short)j;
-          ++w;
-        }
+  if (KB == 1) {  // nearest neighbour: the index rides along (strict <, ascending scan: lowest index on ties)
+    for (int r0 = lo; r0 < hi; r0 += 4) {
+      float c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = dist_of(min(r0 + u, hi - 1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool acc = r0 + u < hi && c[u] < L[0];
+        L[0] = acc ? c[u] : L[0];
+        I[0] = acc ? r0 + u : I[0];
       }
     }
-    cnt = w;
-  };
-  const int per = (M + 3) >> 2;
-  const int lo = wave * per, hi = min(lo + per, M);
-  for (int r0 = lo; r0 < hi; r0 += 4) {
-    float4 v[4];
+  } else {
+    unsigned short *mylog = slog + (size_t)wave * CAP * 64 + lane;
+    int cnt = 0;
+    auto compact = [&]() {  // keep the logged candidates that can still be among the K best, in order
+      const float tau = L[KB - 1];
+      int w = 0;
+      for (int e = 0; e < CAP; ++e) {
+        if (e < cnt) {
+          const int j = mylog[e * 64];
+          if (dist_of(j) <= tau) {
+            mylog[w * 64] = (unsigned short)j;
+            ++w;
+          }
+        }
+      }
+      cnt = w;
+    };
+    for (int r0 = lo; r0 < hi; r0 += 4) {
+      // four independent distance chains first (their LDS reads are in flight before the first log store) ...
+      float c[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = sref[min(r0 + u, hi - 1)];  // four LDS reads in flight before the first log store
+      for (int u = 0; u < 4; ++u) c[u] = dist_of(min(r0 + u, hi - 1));
+      if (__builtin_amdgcn_ballot_w64(cnt > CAP - 4)) compact();  // room for this group in every lane's log
+      // ... then the four insertions: a branch-free median chain on the distances, a masked 2-byte store of the index
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (r0 + u < hi) {  // wave-uniform
-        const float c = pair_dist<FORM>(qx, qy, qz, rq, v[u].x, v[u].y, v[u].z, v[u].w);
-        const bool acc = c < L[KB - 1];
+      for (int u = 0; u < 4; ++u) {
+        const bool acc = r0 + u < hi && c[u] < L[KB - 1];
+        const float cu = r0 + u < hi ? c[u] : __builtin_inff();
 #pragma unroll
-        for (int t = KB - 1; t > 0; --t) L[t] = __builtin_amdgcn_fmed3f(L[t - 1], c, L[t]);
-        L[0] = __builtin_amdgcn_fmed3f(-__builtin_inff(), c, L[0]);  // = min(c, L[0]) in one instruction
+        for (int t = KB - 1; t > 0; --t) L[t] = __builtin_amdgcn_fmed3f(L[t - 1], cu, L[t]);
+        L[0] = __builtin_amdgcn_fmed3f(-__builtin_inff(), cu, L[0]);  // = min(c, L[0]) in one instruction
         if (acc) {
           mylog[cnt * 64] = (unsigned short)(r0 + u);
           ++cnt;
         }
-        if (__builtin_amdgcn_ballot_w64(cnt >= CAP)) compact();
       }
     }
-  }
-  // the survivors, matched to their slots (entries of equal distance fill equal slots in log = index order)
-  compact();
-  int I[KB];
+    // the survivors, matched to their slots (entries of equal distance fill equal slots in log = index order)
+    compact();
+    int most = cnt;  // wave-uniform trip count: the longest surviving log (<= 2 KB - 1)
 #pragma unroll
-  for (int t = 0; t < KB; ++t) I[t] = 0x7fffffff;
-  int most = cnt;  // wave-uniform trip count: the longest surviving log (<= 2 KB - 1)
+    for (int m = 32; m >= 1; m >>= 1) most = max(most, __shfl_xor(most, m, 64));
+    most = __builtin_amdgcn_readfirstlane(most);
+    for (int e = 0; e < most; ++e) {
+      const bool on = e < cnt;
+      const int j = on ? (int)mylog[e * 64] : 0;
+      const float c = dist_of(j);
+      bool placed = !on;
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) most = max(most, __shfl_xor(most, m, 64));
-  most = __builtin_amdgcn_readfirstlane(most);
-  for (int e = 0; e < most; ++e) {
-    const bool on = e < cnt;
-    const int j = on ? (int)mylog[e * 64] : 0;
-    const float c = dist_of(j);
-    bool placed = !on;
-#pragma unroll
-    for (int t = 0; t < KB; ++t) {
-      const bool hit = !placed && c == L[t] && I[t] == 0x7fffffff;
-      I[t] = hit ? j : I[t];
-      placed = placed || hit;
+      for (int t = 0; t < KB; ++t) {
+        const bool hit = !placed && c == L[t] && I[t] == 0x7fffffff;
+        I[t] = hit ? j : I[t];
+        placed = placed || hit;
+      }
     }
+    __syncthreads();  // every wave is done with its log: the area becomes the merge buffers
   }
-  __syncthreads();  // every wave is done with its log: the area becomes the merge buffers
 #pragma unroll
   for (int t = 0; t < KB; ++t) {
     md[(wave * KB + t) * 64 + lane] = L[t];
@@ -268,11 +288,12 @@ __global__ __launch_bounds__(256) void knn_select(const float *__restrict__ q, c
   }
   __syncthreads();
   if (wave != 0 || !live) return;
-  int pos[4] = {0, 0, 0, 0};
-  float hd[4];
-  int hi4[4];
+  int pos[NW];
+  float hd[NW];
+  int hi4[NW];
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NW; ++w) {
+    pos[w] = 0;
     hd[w] = md[(w * KB) * 64 + lane];
     hi4[w] = mi[(w * KB) * 64 + lane];
   }
@@ -281,23 +302,20 @@ __global__ __launch_bounds__(256) void knn_select(const float *__restrict__ q, c
   int32_t *o32 = reinterpret_cast<int32_t *>(idx_out) + ((size_t)b * N + i) * K;
   for (int t = 0; t < K; ++t) {
     int bw = 0;
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const bool take = hd[w] < hd[bw] || (hd[w] == hd[bw] && hi4[w] < hi4[bw]);
-      bw = take ? w : bw;
-    }
     float bd = hd[0];
     int bi = hi4[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      bd = bw == w ? hd[w] : bd;
-      bi = bw == w ? hi4[w] : bi;
+    for (int w = 1; w < NW; ++w) {
+      const bool take = hd[w] < bd || (hd[w] == bd && hi4[w] < bi);
+      bw = take ? w : bw;
+      bd = take ? hd[w] : bd;
+      bi = take ? hi4[w] : bi;
     }
     od[t] = bd;
     if (idx_is_i64) o64[t] = bi;
     else o32[t] = bi;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       if (bw == w) {
         pos[w] += 1;
         const bool more = pos[w] < KB;
@@ -463,18 +481,19 @@ static int launch_knn_topk(const float *q, const float *p, int B, int N, int M, 
   return HITADV_E_ARG;
 }
 
-template <int FORM>
+template <int FORM, int NW>
 static int launch_knn_select(const float *q, const float *p, int B, int N, int M, int K, float *dists, void *idx,
                              int idx_is_i64, hipStream_t s) {
   dim3 grid((N + 63) / 64, B);
   const size_t refs = (size_t)((M + 3) & ~3) * 16;
 #define HITADV_KS_CASE(KB)                                                                                     \
   if (K <= KB) {                                                                                               \
-    const size_t shm = refs + ks_union_bytes(KB);                                                              \
-    static int raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_select<KB, FORM>),             \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + (int)ks_union_bytes(KB)); \
+    const size_t shm = refs + ks_union_bytes(KB, NW);                                                          \
+    static int raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_select<KB, FORM, NW>),         \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,                        \
+                                            32768 + (int)ks_union_bytes(KB, NW));                              \
     (void)raised;                                                                                              \
-    knn_select<KB, FORM><<<grid, 256, shm, s>>>(q, p, N, M, K, dists, idx, idx_is_i64);                        \
+    knn_select<KB, FORM, NW><<<grid, NW * 64, shm, s>>>(q, p, N, M, K, dists, idx, idx_is_i64);                \
     return 0;                                                                                                  \
   }
   if (FORM == 0) {
@@ -510,8 +529,12 @@ extern "C" int hitadv_knn_points(const float *q, const float *p, int B, int N, i
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (K <= 32 && M <= 2048) {
-    rc = form == HITADV_FORM_DIRECT ? launch_knn_select<0>(q, p, B, N, M, K, dists, idx, idx_is_i64, s)
-                                    : launch_knn_select<2>(q, p, B, N, M, K, dists, idx, idx_is_i64, s);
+    if (M >= 512)
+      rc = form == HITADV_FORM_DIRECT ? launch_knn_select<0, 8>(q, p, B, N, M, K, dists, idx, idx_is_i64, s)
+                                      : launch_knn_select<2, 8>(q, p, B, N, M, K, dists, idx, idx_is_i64, s);
+    else
+      rc = form == HITADV_FORM_DIRECT ? launch_knn_select<0, 4>(q, p, B, N, M, K, dists, idx, idx_is_i64, s)
+                                      : launch_knn_select<2, 4>(q, p, B, N, M, K, dists, idx, idx_is_i64, s);
   } else if (form == HITADV_FORM_DIRECT) {
     rc = idx_is_i64 ? launch_knn_topk<0, int64_t>(q, p, B, N, M, K, dists, (int64_t *)idx, s)
                     : launch_knn_topk<0, int32_t>(q, p, B, N, M, K, dists, (int32_t *)idx, s);

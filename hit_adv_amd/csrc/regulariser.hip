@@ -24,11 +24,25 @@ __device__ __forceinline__ float block_sum(float v, float *sm) {
   return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
+__device__ void reg_finalise_body(const float *part, const float *__restrict__ scale_const, int B, int C, float cd_w,
+                                  float ker_w, float hide_w, float *__restrict__ per_cloud, float *__restrict__ scal,
+                                  float *__restrict__ dist_out, float *__restrict__ scaled_out, float *sm);
+
+// `fin` != nullptr: the last block to arrive (ticket = scal[7], zeroed once by the caller) combines the clouds in the same
+// launch -- what reg_finalise does as a second launch otherwise.
+struct RegFin {
+  const float *scale_const;
+  int B;
+  float cd_w, ker_w, hide_w;
+  float *per_cloud, *scal, *dist_out, *scaled_out;
+};
+
 __global__ __launch_bounds__(256) void reg_partials(const float *__restrict__ P, const float *__restrict__ sigma,
                                                     const float *__restrict__ adv, const float *__restrict__ ori,
                                                     const float *__restrict__ hide_ref, int N, int C, float min_s,
-                                                    float inv_range, float *__restrict__ part) {
+                                                    float inv_range, float *part, RegFin fin, int fused) {
   __shared__ float sm[4];
+  __shared__ int s_last;
   const int b = blockIdx.x;
   float a = 0.f;
   for (int e = threadIdx.x; e < C * 3; e += 256) {
@@ -75,19 +89,26 @@ __global__ __launch_bounds__(256) void reg_partials(const float *__restrict__ P,
   if (threadIdx.x == 0) {
     float *o = part + (size_t)b * RG_NPART;
 #pragma unroll
-    for (int k = 0; k < 14; ++k) o[k] = out[k];
+    for (int k = 0; k < 14; ++k) __hip_atomic_store(&o[k], out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (!fused) return;
+  int *ticket = reinterpret_cast<int *>(fin.scal + 7);
+  if (!handoff_last_arriver(ticket, 0, fin.B, &s_last)) return;
+  reg_finalise_body(part, fin.scale_const, fin.B, C, fin.cd_w, fin.ker_w, fin.hide_w, fin.per_cloud, fin.scal, fin.dist_out,
+                    fin.scaled_out, sm);
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One block: combine the clouds.  per_cloud[b] = {cos_b, inv(|r||n|), inv(|n|^2), arg0, arg1, arg2}
-__global__ __launch_bounds__(256) void reg_finalise(const float *__restrict__ part, const float *__restrict__ scale_const,
-                                                    int B, int C, float cd_w, float ker_w, float hide_w,
-                                                    float *__restrict__ per_cloud, float *__restrict__ scal,
-                                                    float *__restrict__ dist_out, float *__restrict__ scaled_out) {
-  __shared__ float sm[4];
+__device__ void reg_finalise_body(const float *part, const float *__restrict__ scale_const, int B, int C, float cd_w,
+                                  float ker_w, float hide_w, float *__restrict__ per_cloud, float *__restrict__ scal,
+                                  float *__restrict__ dist_out, float *__restrict__ scaled_out, float *sm) {
   float sp = 0.f, ss = 0.f, sq = 0.f, sc = 0.f, sk = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) {
-    const float *p = part + (size_t)b * RG_NPART;
+    float p[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k)  // written by other blocks of this launch in the fused form: read past the L1
+      p[k] = __hip_atomic_load(&part[(size_t)b * RG_NPART + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sp += p[0];
     ss += p[1];
     const float nr = fmaxf(__builtin_sqrtf(p[3]), 1e-8f), nn = fmaxf(__builtin_sqrtf(p[4]), 1e-8f);
@@ -130,6 +151,15 @@ __global__ __launch_bounds__(256) void reg_finalise(const float *__restrict__ pa
     *dist_out = dist;
     *scaled_out = coef * dist;
   }
+}
+
+// One block: combine the clouds.  per_cloud[b] = {cos_b, inv(|r||n|), inv(|n|^2), arg0, arg1, arg2}
+__global__ __launch_bounds__(256) void reg_finalise(const float *__restrict__ part, const float *__restrict__ scale_const,
+                                                    int B, int C, float cd_w, float ker_w, float hide_w,
+                                                    float *__restrict__ per_cloud, float *__restrict__ scal,
+                                                    float *__restrict__ dist_out, float *__restrict__ scaled_out) {
+  __shared__ float sm[4];
+  reg_finalise_body(part, scale_const, B, C, cd_w, ker_w, hide_w, per_cloud, scal, dist_out, scaled_out, sm);
 }
 
 __global__ __launch_bounds__(256) void reg_backward(const float *__restrict__ P, const float *__restrict__ sigma,
@@ -187,8 +217,25 @@ extern "C" int hitadv_regulariser_fwd(const float *perturb, const float *sigma, 
   hipStream_t s = (hipStream_t)stream;
   float *part = scratch, *per_cloud = scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
   const float inv_range = 1.0f / (max_sigm - min_sigm + 1e-7f);
-  reg_partials<<<B, 256, 0, s>>>(perturb, sigma, adv, ori, hide_ref, N, C, min_sigm, inv_range, part);
+  reg_partials<<<B, 256, 0, s>>>(perturb, sigma, adv, ori, hide_ref, N, C, min_sigm, inv_range, part, RegFin{}, 0);
   reg_finalise<<<1, 256, 0, s>>>(part, scale_const, B, C, cd_w, ker_w, hide_w, per_cloud, scal, dist_loss, scaled_loss);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same forward in ONE launch: the last block of the per-cloud pass combines the clouds.  The scratch's last float
+// (the ticket) must be ZERO when this is first called on a scratch buffer; every call leaves it at zero.
+extern "C" int hitadv_regulariser_fwd_fused(const float *perturb, const float *sigma, const float *adv, const float *ori,
+                                            const float *hide_ref, const float *scale_const, int B, int N, int C,
+                                            float cd_w, float ker_w, float hide_w, float min_sigm, float max_sigm,
+                                            float *scratch, float *dist_loss, float *scaled_loss, void *stream) {
+  if (!perturb || !sigma || !adv || !ori || !hide_ref || !scale_const || !scratch || !dist_loss || !scaled_loss ||
+      B <= 0 || N <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  float *part = scratch, *per_cloud = scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
+  const float inv_range = 1.0f / (max_sigm - min_sigm + 1e-7f);
+  RegFin fin{scale_const, B, cd_w, ker_w, hide_w, per_cloud, scal, dist_loss, scaled_loss};
+  reg_partials<<<B, 256, 0, (hipStream_t)stream>>>(perturb, sigma, adv, ori, hide_ref, N, C, min_sigm, inv_range, part, fin, 1);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

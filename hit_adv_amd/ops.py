@@ -308,6 +308,46 @@ def adam_step_sum(perturb, sigma, gp, gp2, gs, gs2, m_p, v_p, m_s, v_s, step, lr
 ADV_UNTARGETED, ADV_TARGETED, ADV_CROSS_ENTROPY = 0, 1, 2
 
 
+def iteration_head_scratch(B, device):
+    """Zeroed scratch of ``iteration_head`` (per-cloud loss terms + a ticket that every call leaves at zero)."""
+    return torch.zeros(int(_lib.load().hitadv_iteration_head_scratch_floats(B)), device=device)
+
+
+def iteration_head(logits, label, perturb, sigma, adv, state, counter, kind, kappa, loss_out, dlogits, scratch):
+    """``best_update`` and ``adv_loss`` in one launch (same results): the best-so-far buffers of ``state`` are updated in
+    place, ``loss_out`` (0-d) and ``dlogits`` [B,K] receive the adversarial loss and its gradient."""
+    B, K = logits.shape
+    _lib.call("hitadv_iteration_head", _p(logits), _p(label), _p(perturb), _p(sigma), _p(adv), B, K, adv.shape[2],
+              sigma.shape[1], _p(state["bestdist"]), _p(state["bestscore"]), _p(state["o_bestdist"]),
+              _p(state["o_bestscore"]), _p(state["o_bestattack"]), _p(state["pred"]), _p(state["dist_val"]), _p(counter),
+              kind, ctypes.c_float(float(kappa)), _p(loss_out), _p(dlogits), _p(scratch), _stream())
+
+
+def regulariser_fwd_fused_into(perturb, sigma, adv, ori, hide_ref, scale_const, weights, sig_range, scratch, dist_out,
+                               scaled_out):
+    """``regulariser_fwd_into`` in one launch; ``scratch`` must have been ZEROED when it was allocated."""
+    B, _, N = adv.shape
+    cd, ker, hide = (ctypes.c_float(float(w)) for w in weights)
+    lo, hi = (ctypes.c_float(float(v)) for v in sig_range)
+    _lib.call("hitadv_regulariser_fwd_fused", _p(perturb), _p(sigma), _p(adv), _p(ori), _p(hide_ref), _p(scale_const), B,
+              N, sigma.shape[1], cd, ker, hide, lo, hi, _p(scratch), _p(dist_out), _p(scaled_out), _stream())
+
+
+def deform_bwd_partials_into(ori, central, perturb, sigma, adv, inv_den, g_adv, partials):
+    B, _, N = ori.shape
+    _lib.call("hitadv_deform_bwd_partials", _p(ori), _p(central), _p(perturb), _p(sigma), _p(adv), _p(inv_den), _p(g_adv),
+              B, N, central.shape[2], _p(partials), _stream())
+
+
+def adam_step_partials(perturb, sigma, partials, N, gp2, gs2, m_p, v_p, m_s, v_s, step, lr_p, lr_s, clamp_p, clamp_s):
+    """``adam_step_sum`` with the deformation's gradient still in its per-slab partials (summed inside, reduce order)."""
+    B, C = sigma.shape
+    _lib.call("hitadv_adam_step_partials", _p(perturb), _p(sigma), _p(partials), int(_lib.load().hitadv_deform_bwd_slabs(N)),
+              _p(gp2), _p(gs2), _p(m_p), _p(v_p), _p(m_s), _p(v_s), B, C, ctypes.c_float(lr_p),
+              ctypes.c_float(clamp_p[0]), ctypes.c_float(clamp_p[1]), ctypes.c_float(lr_s), ctypes.c_float(clamp_s[0]),
+              ctypes.c_float(clamp_s[1]), _p(step), _stream())
+
+
 def adv_loss(kind, logits, target, kappa=0., loss_out=None):
     """(loss, d loss / d logits) of the util/adv_utils.py losses in one launch; ``loss_out`` (0-d) is written if given."""
     logits = _dev(logits.detach(), "logits")

@@ -31,6 +31,10 @@ class LogitsAdvLoss(nn.Module):
         from .. import ops
         return ops.adv_loss(ops.ADV_TARGETED, logits, targets, self.kappa, loss_out)
 
+    def fused_kind(self):
+        """(kind, kappa) for kernels that evaluate this loss inside a larger launch (hitadv_iteration_head)."""
+        return 1, self.kappa
+
 
 class UntargetedLogitsAdvLoss(nn.Module):
     """Untargeted margin loss, util/adv_utils.py:38-67 (the one eval.py:84 hands to HiT-ADV)."""
@@ -48,6 +52,9 @@ class UntargetedLogitsAdvLoss(nn.Module):
         from .. import ops
         return ops.adv_loss(ops.ADV_UNTARGETED, logits, targets, self.kappa, loss_out)
 
+    def fused_kind(self):
+        return 0, self.kappa
+
 
 class CrossEntropyAdvLoss(nn.Module):
     """util/adv_utils.py:70-85."""
@@ -58,3 +65,6 @@ class CrossEntropyAdvLoss(nn.Module):
     def fused(self, logits, targets, loss_out=None):
         from .. import ops
         return ops.adv_loss(ops.ADV_CROSS_ENTROPY, logits, targets, 0., loss_out)
+
+    def fused_kind(self):
+        return 2, 0.

@@ -362,6 +362,37 @@ int hitadv_group_add_relu_bwd(const float *dH, const float *U, const float *V, c
                               int ns, int C, float *dU, float *dV, int32_t *scratch, void *stream);
 int64_t hitadv_group_add_relu_bwd_scratch_ints(int B, int N, int S, int ns);
 
+/* ------------------------------------------------------------------ merged launches of one HiT-ADV iteration
+ * (csrc/iteration.hip, csrc/regulariser.hip, csrc/deform.hip).  Results are those of the entry points they merge, bit for
+ * bit; they exist because at one attack in flight an iteration is a chain of ~40 dependent launches of 4-7 us each.
+ *
+ * hitadv_iteration_head = hitadv_best_update + hitadv_adv_loss (both read only the logits, ShapeAttack/HiT_ADV.py:
+ *   186-217 and util/adv_utils.py:18-85).  scratch: hitadv_iteration_head_scratch_floats(B) floats, ZEROED ONCE by the
+ *   caller (it holds a ticket that every call leaves at zero).
+ * hitadv_regulariser_fwd_fused = hitadv_regulariser_fwd in one launch; the LAST float of its scratch is a ticket and
+ *   must be zero on first use.
+ * hitadv_deform_bwd_partials = the deformation backward without its reduce launch: partials [B,nslab,4,C],
+ *   nslab = hitadv_deform_bwd_slabs(N);  hitadv_adam_step_partials = hitadv_adam_step_sum that sums those partials itself
+ *   (ascending slab = the reduce launch's order) before the Adam update and the projection. */
+int hitadv_iteration_head(const float *logits, const int64_t *label, const float *perturb, const float *sigma,
+                          const float *adv, int B, int num_class, int N, int C, float *bestdist, int64_t *bestscore,
+                          float *o_bestdist, int64_t *o_bestscore, float *o_bestattack, int64_t *pred_out,
+                          float *dist_val_out, int32_t *iter_counter, int kind, float kappa, float *loss, float *dlogits,
+                          float *scratch, void *stream);
+int64_t hitadv_iteration_head_scratch_floats(int B);
+int hitadv_regulariser_fwd_fused(const float *perturb, const float *sigma, const float *adv, const float *ori,
+                                 const float *hide_ref, const float *scale_const, int B, int N, int C, float cd_w,
+                                 float ker_w, float hide_w, float min_sigm, float max_sigm, float *scratch,
+                                 float *dist_loss, float *scaled_loss, void *stream);
+int hitadv_deform_bwd_partials(const float *ori, const float *central, const float *perturb, const float *sigma,
+                               const float *adv, const float *inv_den, const float *g_adv, int B, int N, int C,
+                               float *partials, void *stream);
+int64_t hitadv_deform_bwd_slabs(int N);
+int hitadv_adam_step_partials(float *perturb, float *sigma, const float *partials, int nslab, const float *g_perturb2,
+                              const float *g_sigma2, float *m_perturb, float *v_perturb, float *m_sigma, float *v_sigma,
+                              int B, int C, float lr_perturb, float lo_perturb, float hi_perturb, float lr_sigma,
+                              float lo_sigma, float hi_sigma, const int32_t *step, void *stream);
+
 /* k nearest neighbours in feature space for DGCNN's dynamic graph (model/dgcnn_cls.py:7-13: topk of
  * -|x_i|^2 + 2 x_i.x_j - |x_j|^2), fused: the scores come off the f32 matrix cores tile by tile and go straight into
  * per-lane sorted lists -- no [B,N,N] matrix.  X [B,N,D] points-major (D in {64,128}, 16-byte aligned), xx [B,N] = |x|^2,

@@ -951,3 +951,66 @@ def test_topk_rows_bit_exact(A, K, largest):
     order = torch.sort(-P if largest else P, dim=-1, stable=True)
     assert torch.equal(idx.cpu(), order.indices[..., :K])
     assert torch.equal(vals.cpu(), P.gather(-1, order.indices[..., :K]))
+
+
+# ------------------------------------------------------------------ merged launches of the iteration (csrc/iteration.hip)
+@pytest.mark.parametrize("B,K,Np,C", [(32, 40, 1024, 192), (5, 16, 130, 12), (1, 40, 64, 3)])
+def test_merged_iteration_launches_equal_the_launches_they_merge(A, B, K, Np, C):
+    """iteration_head == best_update + adv_loss, regulariser_fwd_fused == regulariser_fwd, deform_bwd_partials +
+    adam_step_partials == deform_bwd + adam_step_sum: same bits, over several calls on the same state (the tickets the
+    merged forms keep in their scratch must come back to zero every time)."""
+    g = torch.Generator().manual_seed(B * 7 + C)
+    dev = 'cuda'
+
+    def state():
+        return dict(bestdist=torch.full((B,), 1e10, device=dev), bestscore=torch.full((B,), -1, dtype=torch.int64, device=dev),
+                    o_bestdist=torch.full((B,), 1e10, device=dev), o_bestscore=torch.full((B,), -1, dtype=torch.int64, device=dev),
+                    o_bestattack=torch.zeros(B, 3, Np, device=dev), pred=torch.zeros(B, dtype=torch.int64, device=dev),
+                    dist_val=torch.zeros(B, device=dev))
+    label = torch.randint(0, K, (B,), generator=g).cuda()
+    ori = cu(torch.randn(B, 3, Np, generator=g) * 0.4)
+    central = ori[:, :, :C].contiguous()
+    hide_ref = cu(torch.rand(B, C, generator=g))
+    scale = cu(10. + 70. * torch.rand(B, generator=g))
+    regs, rng = (1e-4, 1.0, 1.0), (0.1, 1.2)
+    for kind in (A.ADV_UNTARGETED, A.ADV_TARGETED, A.ADV_CROSS_ENTROPY):
+        sa, sb = state(), state()
+        ca, cb = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        head = A.iteration_head_scratch(B, dev)
+        reg_a = torch.zeros(A.regulariser_scratch(B), device=dev)
+        reg_b = torch.zeros(A.regulariser_scratch(B), device=dev)
+        Pa = cu((torch.rand(B, C, 3, generator=g) - 0.5) * 0.5)
+        Sa = cu(0.1 + 1.1 * torch.rand(B, C, generator=g))
+        Pb, Sb = Pa.clone(), Sa.clone()
+        ma = [torch.zeros_like(Pa), torch.zeros_like(Pa), torch.zeros_like(Sa), torch.zeros_like(Sa)]
+        mb = [t.clone() for t in ma]
+        part_a = torch.empty(A.deform_bwd_scratch(B, Np, C), device=dev)
+        part_b = torch.empty_like(part_a)
+        for it in range(4):
+            logits = cu(torch.randn(B, K, generator=g) * 3)
+            adv, inv = torch.empty_like(ori), torch.empty(B, Np, device=dev)
+            A.deform_fwd_into(ori, central, Pa, Sa, adv, inv)
+            # reference: the separate launches
+            A.best_update(logits, label, Pa, Sa, adv, sa, counter=ca)
+            loss_a, d_a = A.adv_loss(kind, logits, label, 30.)
+            la, lb = torch.zeros((), device=dev), torch.zeros((), device=dev)
+            d_b, da_l, db_l = torch.empty_like(logits), torch.zeros((), device=dev), torch.zeros((), device=dev)
+            A.iteration_head(logits, label, Pb, Sb, adv, sb, cb, kind, 30., lb, d_b, head)
+            assert torch.equal(d_a, d_b) and torch.equal(loss_a, lb) and int(ca) == int(cb) == it + 1
+            for k in sa:
+                assert torch.equal(sa[k], sb[k]), k
+            A.regulariser_fwd_into(Pa, Sa, adv, ori, hide_ref, scale, regs, rng, reg_a, da_l, la)
+            A.regulariser_fwd_fused_into(Pb, Sb, adv, ori, hide_ref, scale, regs, rng, reg_b, db_l, lb)
+            assert torch.equal(da_l, db_l) and torch.equal(la, lb)
+            assert torch.equal(reg_a[:-1], reg_b[:-1]) and float(reg_b[-1]) == 0.
+            up = cu(torch.randn(B, 3, Np, generator=g))
+            gp, gs = torch.empty_like(Pa), torch.empty_like(Sa)
+            gp2, gs2, ga = torch.empty_like(Pa), torch.empty_like(Sa), torch.empty_like(adv)
+            A.regulariser_bwd_add(Pa, Sa, adv, ori, hide_ref, reg_a, up, regs, rng, gp2, gs2, ga)
+            A.deform_bwd_into(ori, central, Pa, Sa, adv, inv, ga, part_a, gp, gs)
+            A.adam_step_sum(Pa, Sa, gp, gp2, gs, gs2, *ma, ca, 0.05, 0.03, (-0.55, 0.55), rng)
+            A.deform_bwd_partials_into(ori, central, Pb, Sb, adv, inv, ga, part_b)
+            A.adam_step_partials(Pb, Sb, part_b, Np, gp2, gs2, *mb, cb, 0.05, 0.03, (-0.55, 0.55), rng)
+            assert torch.equal(Pa, Pb) and torch.equal(Sa, Sb)
+            for x, y in zip(ma, mb):
+                assert torch.equal(x, y)
