@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
 // NW waves of a block split the reference range for the same 64 queries (NW = 8 from 512 references on: 4096 short waves
 // instead of 2048 give every SIMD four waves to switch between -- the scan is a chain of dependent VALU instructions).
 __host__ __device__ constexpr int ks_cap(int KB, int NW) {  // >= 2 KB - 1 survivors of a compaction + one group of 4
-  return NW == 8 ? (KB <= 8 ? 24 : (KB <= 12 ? 32 : (KB <= 20 ? 44 : 72))) : (KB <= 8 ? 32 : (KB <= 16 ? 64 : 96));
+  return NW == 8 ? (KB <= 8 ? 24 : (KB <= 12 ? 32 : (KB <= 20 ? 56 : 72))) : (KB <= 8 ? 32 : (KB <= 16 ? 64 : 96));
 }
 __host__ __device__ constexpr size_t ks_union_bytes(int KB, int NW) {
   return (size_t)NW * 64 * (ks_cap(KB, NW) * 2 > KB * 8 ? ks_cap(KB, NW) * 2 : KB * 8);
@@ -227,14 +227,26 @@ __global__ __launch_bounds__(NW * 64) void knn_select(const float *__restrict__ 
   } else {
     unsigned short *mylog = slog + (size_t)wave * CAP * 64 + lane;
     int cnt = 0;
-    auto compact = [&]() {  // keep the logged candidates that can still be among the K best, in order
+    // keep the logged candidates that can still be among the K best, in order.  Eight entries at a time: their indices, then
+    // their references, are read as independent LDS loads (one round trip each for the group, not per entry)
+    auto compact = [&]() {
       const float tau = L[KB - 1];
       int w = 0;
-      for (int e = 0; e < CAP; ++e) {
-        if (e < cnt) {
-          const int j = mylog[e * 64];
-          if (dist_of(j) <= tau) {
-            mylog[w * 64] = (unsigned short)j;
+      int most = cnt;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) most = max(most, __shfl_xor(most, m, 64));
+      most = __builtin_amdgcn_readfirstlane(most);
+      for (int e0 = 0; e0 < most; e0 += 8) {
+        int jj[8];
+        float cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) jj[u] = e0 + u < cnt ? (int)mylog[min(e0 + u, CAP - 1) * 64] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cc[u] = dist_of(jj[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (e0 + u < cnt && cc[u] <= tau) {
+            mylog[w * 64] = (unsigned short)jj[u];  // w <= e0 + u: never ahead of the entries still to be read
             ++w;
           }
         }
@@ -267,16 +279,22 @@ __global__ __launch_bounds__(NW * 64) void knn_select(const float *__restrict__ 
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) most = max(most, __shfl_xor(most, m, 64));
     most = __builtin_amdgcn_readfirstlane(most);
-    for (int e = 0; e < most; ++e) {
-      const bool on = e < cnt;
-      const int j = on ? (int)mylog[e * 64] : 0;
-      const float c = dist_of(j);
-      bool placed = !on;
+    for (int e0 = 0; e0 < most; e0 += 4) {
+      int jj[4];
+      float cc[4];
 #pragma unroll
-      for (int t = 0; t < KB; ++t) {
-        const bool hit = !placed && c == L[t] && I[t] == 0x7fffffff;
-        I[t] = hit ? j : I[t];
-        placed = placed || hit;
+      for (int u = 0; u < 4; ++u) jj[u] = e0 + u < cnt ? (int)mylog[min(e0 + u, CAP - 1) * 64] : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cc[u] = dist_of(jj[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bool placed = !(e0 + u < cnt);
+#pragma unroll
+        for (int t = 0; t < KB; ++t) {
+          const bool hit = !placed && cc[u] == L[t] && I[t] == 0x7fffffff;
+          I[t] = hit ? jj[u] : I[t];
+          placed = placed || hit;
+        }
       }
     }
     __syncthreads();  // every wave is done with its log: the area becomes the merge buffers

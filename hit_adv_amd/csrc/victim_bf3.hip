@@ -12,8 +12,8 @@
 // This is NOT bf16 precision: nothing is rounded to 8 bits.
 //
 //   block   = 8 waves (two per SIMD); one cloud, one split of its points, 256 output channels (32 per wave)
-//   W       : host-side split once per attack (weights are constants), [3][Cout][CIN] bf16; the wave's 32 columns x CIN
-//             rows x 3 pieces live in VGPRs for the whole kernel (96 registers at CIN = 128)
+//   W       : split once per attack (weights are constants) into three bf16 images in fragment order; the wave's 32
+//             columns x CIN rows x 3 pieces live in VGPRs for the whole kernel (96 registers at CIN = 128)
 //   x       : 64-point tiles, global fp32 -> registers -> split (4 VALU per value) -> three bf16 LDS images (row stride
 //             2 CIN + 16 bytes: conflict-free ds_read_b128), double buffered, one barrier per tile
 //   compute : per tile and wave 2 row blocks x (CIN/16 slices) x 6 MFMAs; the next slice's A fragments are read while
@@ -79,19 +79,23 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   const int ntiles = (n1 - n0 + B3_TM - 1) / B3_TM;
   X += (size_t)b * N * CIN;
 
-  // B operand of slice j, piece p: the lane's column, k = 16 j + 8 h .. + 7 (8 consecutive bf16 = one 16-byte load)
+  // B operand of slice j, piece p: the lane's column, k = 16 j + 8 h .. + 7.  W3 is stored in fragment order
+  // [piece][32-column block][slice][lane] x 16 bytes, so every load instruction of a wave reads 1 KB contiguous.
   uint4 w[3][NSL];
   {
-    const uint16_t *wp = W3 + (size_t)((active ? col0 : 0) + r) * CIN + 8 * h;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(W3) + (size_t)((active ? col0 : 0) / 32) * NSL * 64 + lane;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int j = 0; j < NSL; ++j)
-        w[p][j] = *reinterpret_cast<const uint4 *>(wp + (size_t)p * Cout * CIN + 16 * j);
+      for (int j = 0; j < NSL; ++j) w[p][j] = wp[((size_t)p * (Cout / 32) * NSL + j) * 64];
   }
 
-  float4 st[ST][2];
-  auto fetch = [&](int tile) {
+  // x tiles travel global -> registers -> (split) -> LDS.  Two register sets: the loads of tile t+2 are issued at the top
+  // of tile t and written to LDS one tile later, so no wave ever waits on HBM.  The two waves of a SIMD are staggered
+  // (waves 4-7 convert and store tile t+1 BEFORE their MFMAs of tile t, waves 0-3 after): while one of them is in its
+  // vector phase (split + scan) the other owns the matrix pipe (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+  float4 stA[ST][2], stB[ST][2];
+  auto fetch = [&](float4 (&st)[ST][2], int tile) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
       st[u][1] = make_float4(in ? v1.x : 0.f, in ? v1.y : 0.f, in ? v1.z : 0.f, in ? v1.w : 0.f);
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](const float4 (&st)[ST][2], int buf) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
@@ -127,66 +131,81 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   float bv = -__builtin_inff();
   int bi = -1;
   f32x16b acc0, acc1;  // row blocks 0 and 1: element e = row 32*rb + (e&3) + 8*(e>>2) + 4*h, column r (the f32 kernel's layout)
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const bool more = tile + 1 < ntiles;
-    if (more) fetch(tile + 1);
-    if (active) {
-      const char *base = sB3 + (size_t)(tile & 1) * 3 * PIECE + r * RS + 16 * h;
+  const bool late = wave >= 4;  // wave-uniform
+  // one tile: MFMAs (the A fragments of slice j+1 are read from LDS while the twelve MFMAs of slice j run), then the scan
+  auto compute = [&](int tile) {
+    const char *base = sB3 + (size_t)(tile & 1) * 3 * PIECE + r * RS + 16 * h;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
+    uint4 fa[2][6];
 #pragma unroll
-      for (int j = 0; j < NSL; ++j) {
-        const bf16x8 w0 = as_bf16x8(w[0][j]), w1 = as_bf16x8(w[1][j]), w2 = as_bf16x8(w[2][j]);
-        const bf16x8 f0 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + 32 * j));
-        const bf16x8 f1 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + PIECE + 32 * j));
-        const bf16x8 f2 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + 2 * PIECE + 32 * j));
-        const bf16x8 g0 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + 32 * RS + 32 * j));
-        const bf16x8 g1 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + PIECE + 32 * RS + 32 * j));
-        const bf16x8 g2 = as_bf16x8(*reinterpret_cast<const uint4 *>(base + 2 * PIECE + 32 * RS + 32 * j));
-        // smallest terms first; the two row blocks alternate so that consecutive MFMAs are independent
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w2, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w2, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, w0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2, w0, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w1, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, w1, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w1, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w1, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, w0, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w0, acc1, 0, 0, 0);
+    for (int q = 0; q < 6; ++q) fa[0][q] = *reinterpret_cast<const uint4 *>(base + (q % 3) * PIECE + (q / 3) * 32 * RS);
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+      if (j + 1 < NSL) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          fa[(j + 1) & 1][q] = *reinterpret_cast<const uint4 *>(base + (q % 3) * PIECE + (q / 3) * 32 * RS + 32 * (j + 1));
       }
-      // running (max, first arg-max): a tile-local best with an inline-constant code, joined with the tile number once
-      const bool ragged = n0 + (tile + 1) * B3_TM > n1;  // wave-uniform: only a split's last tile can be ragged
-      const int row0 = n0 + tile * B3_TM + 4 * h;
-      float tv = -__builtin_inff();
-      int tc = 0;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float v = acc0[e];
-        if (ragged) v = row0 + (e & 3) + 8 * (e >> 2) < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
-        const bool g = v > tv;
-        tv = g ? v : tv;
-        tc = g ? e : tc;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float v = acc1[e];
-        if (ragged) v = row0 + 32 + (e & 3) + 8 * (e >> 2) < n1 ? v : -__builtin_inff();
-        const bool g = v > tv;
-        tv = g ? v : tv;
-        tc = g ? 16 + e : tc;
-      }
-      const bool g = tv > bv;  // earlier tiles hold earlier points: they keep ties
-      bv = g ? tv : bv;
-      bi = g ? tile * 32 + tc : bi;
+      __builtin_amdgcn_sched_barrier(0);  // the reads stay above this slice's MFMAs
+      const bf16x8 w0 = as_bf16x8(w[0][j]), w1 = as_bf16x8(w[1][j]), w2 = as_bf16x8(w[2][j]);
+      const bf16x8 f0 = as_bf16x8(fa[j & 1][0]), f1 = as_bf16x8(fa[j & 1][1]), f2 = as_bf16x8(fa[j & 1][2]);
+      const bf16x8 g0 = as_bf16x8(fa[j & 1][3]), g1 = as_bf16x8(fa[j & 1][4]), g2 = as_bf16x8(fa[j & 1][5]);
+      // smallest terms first; the two row blocks alternate so that consecutive MFMAs are independent
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w2, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w2, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, w0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2, w0, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w1, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, w1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w1, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, w0, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w0, acc1, 0, 0, 0);
     }
-    if (more) stash((tile + 1) & 1);
+    // running (max, first arg-max): a tile-local best with an inline-constant code, joined with the tile number once
+    const bool ragged = n0 + (tile + 1) * B3_TM > n1;  // wave-uniform: only a split's last tile can be ragged
+    const int row0 = n0 + tile * B3_TM + 4 * h;
+    float tv = -__builtin_inff();
+    int tc = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = acc0[e];
+      if (ragged) v = row0 + (e & 3) + 8 * (e >> 2) < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
+      const bool g = v > tv;
+      tv = g ? v : tv;
+      tc = g ? e : tc;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = acc1[e];
+      if (ragged) v = row0 + 32 + (e & 3) + 8 * (e >> 2) < n1 ? v : -__builtin_inff();
+      const bool g = v > tv;
+      tv = g ? v : tv;
+      tc = g ? 16 + e : tc;
+    }
+    const bool g = tv > bv;  // earlier tiles hold earlier points: they keep ties
+    bv = g ? tv : bv;
+    bi = g ? tile * 32 + tc : bi;
+  };
+  // tile t: stA holds tile t+1 (loaded during tile t-1), tile t+2 is requested into stB; the sets swap every tile
+  auto step = [&](int tile, float4 (&have)[ST][2], float4 (&next)[ST][2]) {
+    const bool more = tile + 1 < ntiles;
+    if (tile + 2 < ntiles) fetch(next, tile + 2);
+    if (more && late) stash(have, (tile + 1) & 1);
+    if (active) compute(tile);
+    if (more && !late) stash(have, (tile + 1) & 1);
     __syncthreads();
+  };
+  fetch(stA, 0);
+  stash(stA, 0);
+  if (ntiles > 1) fetch(stA, 1);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    step(tile, stA, stB);
+    if (tile + 1 < ntiles) step(tile + 1, stB, stA);
   }
   // code -> point index; nothing won (all rows -inf): the split's first point
   bi = bi < 0 ? n0 : n0 + (bi >> 5) * B3_TM + 4 * h + 32 * ((bi >> 4) & 1) + (bi & 3) + 8 * ((bi & 15) >> 2);
@@ -229,15 +248,20 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   if (threadIdx.x == 0) __hip_atomic_store(&tickets[b * ncg + cg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// W[Cout,CIN] fp32 (row-major, one row per output channel) -> W3[3][Cout][CIN] bf16 pieces
-__global__ __launch_bounds__(256) void split_weights_k(const float *__restrict__ W, uint16_t *__restrict__ W3, long long total) {
+// W[Cout,Cin] fp32 (row-major, one row per output channel) -> its three bf16 pieces in FRAGMENT ORDER:
+// W3[piece][c / 32][k / 16][(k % 16) / 8][c % 32][k % 8]  (16 bytes per (piece, 32-column block, slice, lane)).
+__global__ __launch_bounds__(256) void split_weights_k(const float *__restrict__ W, uint16_t *__restrict__ W3, int Cout,
+                                                       int Cin) {
+  const long long total = (long long)Cout * Cin;
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
-  uint32_t a, bb, c;
-  split3(W[e], a, bb, c);
-  W3[e] = (uint16_t)(a >> 16);
-  W3[total + e] = (uint16_t)(bb >> 16);
-  W3[2 * total + e] = (uint16_t)(c >> 16);
+  const int c = (int)(e / Cin), k = (int)(e % Cin);
+  uint32_t a, bb, cc;
+  split3(W[e], a, bb, cc);
+  const long long o = ((((long long)(c / 32) * (Cin / 16) + k / 16) * 2 + (k % 16) / 8) * 32 + c % 32) * 8 + k % 8;
+  W3[o] = (uint16_t)(a >> 16);
+  W3[total + o] = (uint16_t)(bb >> 16);
+  W3[2 * total + o] = (uint16_t)(cc >> 16);
 }
 
 static void bf3_split(int B, int N, int Cout, int *S, int *rows) {  // as linear_max_split (csrc/victim.hip): one block per CU
@@ -256,9 +280,9 @@ static void bf3_split(int B, int N, int Cout, int *S, int *rows) {  // as linear
 using namespace hitadv;
 
 extern "C" int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream) {
-  if (!W || !W3 || Cout <= 0 || Cin <= 0) return HITADV_E_ARG;
+  if (!W || !W3 || Cout <= 0 || Cin <= 0 || (Cout & 31) || (Cin & 15)) return HITADV_E_ARG;
   const long long total = (long long)Cout * Cin;
-  split_weights_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, W3, total);
+  split_weights_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, W3, Cout, Cin);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

@@ -261,8 +261,9 @@ int64_t hitadv_linear_max_fwd_scratch(int B, int N, int Cout);
  * three bf16 pieces that sum to it EXACTLY (a = a1 + a2 + a3, 8 significant bits each) and the product is evaluated as
  * the six leading cross terms in an fp32 accumulator -- the dropped terms are below 2^-24 of the product, i.e. below the
  * rounding of an fp32 GEMM; nothing is rounded to bf16 precision.  2.67x less matrix time than the f32 MFMA form.
- * W3 [3][Cout][Cin] bf16 = the pieces of the layer's weight W [Cout,Cin] (row-major, one row per output channel), made
- * once per attack by hitadv_split_weights_bf16x3; 16-byte aligned.  Scratch / tickets as for hitadv_linear_max_fwd
+ * W3 = the three bf16 pieces of the layer's weight W [Cout,Cin] (row-major, one row per output channel; Cout % 32 == 0,
+ * Cin % 16 == 0), 3*Cout*Cin uint16 in the kernel's fragment order [piece][c/32][k/16][(k%16)/8][c%32][k%8], made once
+ * per attack by hitadv_split_weights_bf16x3; 16-byte aligned.  Scratch / tickets as for hitadv_linear_max_fwd
  * (tickets must not be NULL). */
 int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream);
 int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin, int Cout,

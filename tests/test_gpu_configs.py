@@ -173,15 +173,20 @@ def test_cfg4_pointnet2_batch64_2048_points_tables_and_float64_module():
     _gradient_vs_float64(xg.grad[:nb], xd.grad, 'cfg4 input gradient')
 
 
-def _gradient_vs_float64(g, gd, what):
+def _gradient_vs_float64(g, gd, what, frac_bound=2e-3, l2_bound=3e-2):
     """The input gradient is piecewise: where fp32 and float64 disagree on a ReLU sign or on the winner of a max whose two
     best candidates are an fp32 rounding apart, a whole path's contribution moves.  So: all but a few elements agree to
     1e-3, and what the few that do not carry is small against the gradient as a whole."""
     g, gd = g.detach().cpu().double(), gd.detach().double()
     scale = float(gd.abs().max())
-    bad = (g - gd).abs() > 1e-3 * gd.abs() + 1e-5 * scale
-    close(bad.double().mean(), 0., rtol=0, atol=2e-3, what=what + ': fraction of elements off by > 1e-3')
-    close((g - gd).norm() / gd.norm(), 0., rtol=0, atol=3e-2, what=what + ': relative L2 error vs float64')
+    bad = float(((g - gd).abs() > 1e-3 * gd.abs() + 1e-5 * scale).double().mean())
+    l2 = float((g - gd).norm() / gd.norm())
+    from helpers import PARITY
+    import os
+    PARITY.setdefault(os.environ.get('PYTEST_CURRENT_TEST', 'unknown').split(' ')[0], []).append(
+        dict(what=what + ' (fraction of elements off by > 1e-3, relative L2 error)', max_abs=bad, max_rel=l2,
+             max_abs_over_scale=l2, rtol=l2_bound, atol=frac_bound, n=int(g.numel())))
+    assert bad <= frac_bound and l2 <= l2_bound, (what, bad, l2)
 
 
 def test_dgcnn_gradient_vs_float64_module_on_the_same_graphs():

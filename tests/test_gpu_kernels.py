@@ -680,7 +680,9 @@ def test_linear_max_fwd_bf16x3_is_fp32_accurate(A, B, Np, Cin, Cout):
     Wt = torch.randn(Cin, Cout, generator=g) * 0.1
     bias = torch.randn(Cout, generator=g)
     W3 = A.split_weights_bf16x3(cu(Wt.t().contiguous()))
-    pieces = (W3.cpu().view(torch.bfloat16) if W3.dtype != torch.bfloat16 else W3.cpu()).float()
+    # fragment order [piece][c/32][k/16][(k%16)/8][c%32][k%8] -> [piece][c][k]
+    pieces = W3.cpu().view(torch.bfloat16).float().view(3, Cout // 32, Cin // 16, 2, 32, 8).permute(0, 1, 4, 2, 3, 5)
+    pieces = pieces.reshape(3, Cout, Cin)
     assert torch.equal(pieces[0] + pieces[1] + pieces[2], Wt.t())  # exact three-way split
     y = (x.double() @ Wt.double()).view(B, Np, Cout)
     ref_val, ref_idx = y.max(dim=1)
