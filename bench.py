@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md, HBM3E spec peak
 F32_MFMA_PEAK = 157.3   # TFLOP/s, dense f32-input MFMA (= the f32 vector peak), same guide
 
 CONFIGS = {
-    'cfg2': dict(victim='pointnet', B=32, N=1024, classes=40, attack='hit_adv', steps=3, warmup=1, concurrent=3,
+    'cfg2': dict(victim='pointnet', B=32, N=1024, classes=40, attack='hit_adv', steps=4, warmup=2, concurrent=2,
                  metric="attacked point-clouds/sec (HiT-ADV, PointNet, N=1024, 500 iters)",
                  workload="cfg2: synthetic ModelNet40-shaped clouds, 1024 pts, batch 32 per GPU, PointNet victim (random "
                           "init, eval mode), HiT-ADV eval.py hyper-parameters, num_iter=500 x binary_step=10 = 5000 inner "

@@ -547,7 +547,10 @@ extern "C" int hitadv_knn_points(const float *q, const float *p, int B, int N, i
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (K <= 32 && M <= 2048) {
-    if (M >= 512)
+    // measured at B = 32, 1024 x 1024 (profiles/r02_kbench.json): 8 waves per block win for short lists (K = 1: 14 vs 29 us,
+    // K = 6: 37 vs 43), 4 waves for long ones (K = 17: 74 vs 107 -- the 8-way merge and the doubled log area cost more
+    // than the extra waves hide)
+    if (M >= 512 && K <= 8)
       rc = form == HITADV_FORM_DIRECT ? launch_knn_select<0, 8>(q, p, B, N, M, K, dists, idx, idx_is_i64, s)
                                       : launch_knn_select<2, 8>(q, p, B, N, M, K, dists, idx, idx_is_i64, s);
     else

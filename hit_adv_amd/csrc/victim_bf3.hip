@@ -20,6 +20,8 @@
 //             the current slice's MFMAs run
 //   epilogue: the accumulator layout is that of the f32 kernel (column on the lane, 16 rows in registers): same running
 //             (max, first arg-max) scan, same split merge by the last block to arrive.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "hitadv.h"
 
@@ -264,9 +266,23 @@ __global__ __launch_bounds__(256) void split_weights_k(const float *__restrict__
   W3[2 * total + o] = (uint16_t)(cc >> 16);
 }
 
-static void bf3_split(int B, int N, int Cout, int *S, int *rows) {  // as linear_max_split (csrc/victim.hip): one block per CU
+// Point splits per cloud so that the grid has about `cus` blocks (as linear_max_split, csrc/victim.hip: one block per CU;
+// every block first loads its 24 KB / wave of W).  HITADV_V1_CUS (environment, read once) lowers the target: with several
+// attacks in flight a V1 grid that leaves part of the chip to the other streams' latency-bound kernels can be the better
+// trade (tools/README.md); results do not depend on it (the split merge is in point order).
+static int bf3_cus() {
+  static int cus = [] {
+    const char *e = getenv("HITADV_V1_CUS");
+    const int v = e ? atoi(e) : 256;
+    return v >= 8 && v <= 256 ? v : 256;
+  }();
+  return cus;
+}
+
+static void bf3_split(int B, int N, int Cout, int *S, int *rows) {
   const int colgroups = (Cout + 255) / 256;
-  int want = (256 + B * colgroups - 1) / (B * colgroups);
+  const int cus = bf3_cus();
+  int want = (cus + B * colgroups - 1) / (B * colgroups);
   const int maxs = (N + B3_TM - 1) / B3_TM;
   want = want < 1 ? 1 : (want > maxs ? maxs : want);
   int per = (N + want - 1) / want;
