@@ -234,6 +234,22 @@ def test_knn_points_gram_knn_form_bit_exact(A, K):
     assert torch.equal(d.cpu(), rd) and torch.equal(ix.cpu(), rix)
 
 
+@pytest.mark.parametrize("K,m,form", [(2, 1024, 0), (5, 1024, 2), (6, 1024, 0), (6, 2048, 2), (8, 512, 0), (12, 1024, 0),
+                                      (17, 1024, 0), (17, 2048, 0), (18, 1000, 2)])
+def test_knn_points_two_queries_per_lane_kernel(A, K, m, form):
+    """Enough queries (B * N >= 16384) select knn_select2: two queries per lane, 128-query blocks.  Same canonical result
+    bit for bit, including clouds with many exact ties and a monotonically approaching reference order in part of the batch."""
+    B, n = 16, 1024 + 37  # ragged last block
+    x, _ = clouds(B, m, 184)
+    q, _ = clouds(B, n, 185)
+    g = torch.Generator().manual_seed(K)
+    x[1] = torch.randn(1, 6, 3, generator=g)[:, torch.randint(0, 6, (m,), generator=g)]  # six distinct points: ties
+    x[2, :, 0] = torch.linspace(5.0, 0.5, m)  # every next reference is closer: the logs overflow and compact
+    d, ix = A.KnnPoints.apply(cu(q), cu(x), K, A.FORM_GRAM_KNN if form else A.FORM_DIRECT)
+    rd, rix = N.knn_points(q, x, K, N.FORM_GRAM_KNN if form else N.FORM_DIRECT)
+    assert torch.equal(ix.cpu(), rix) and torch.equal(d.cpu(), rd)
+
+
 def test_knn_points_heavy_ties_and_log_compaction(A):
     """Adversarial orders for the select kernel: distances that fall monotonically along the scan (every reference is
     accepted: the per-lane log overflows and is compacted again and again) and clouds made of a few distinct points
