@@ -345,195 +345,6 @@ __global__ __launch_bounds__(NW * 64) void knn_select(const float *__restrict__ 
   }
 }
 
-// The same selection with TWO queries per lane (queries i and i + 64 of a 128-query block): every reference read from LDS
-// serves two independent distance / median chains, which is what lets the scan approach the VALU issue rate (the
-// fused minima kernel K2 does the same with four queries per lane).  Used when there are enough queries to fill the chip.
-__host__ __device__ constexpr int ks2_cap(int KB) { return KB <= 8 ? 24 : (KB <= 12 ? 32 : (KB <= 18 ? 40 : 72)); }
-__host__ __device__ constexpr size_t ks2_union_bytes(int KB, int NW) {
-  return (size_t)NW * 64 * (2 * ks2_cap(KB) * 2 > KB * 8 ? 2 * ks2_cap(KB) * 2 : KB * 8);
-}
-
-template <int KB, int FORM, int NW>
-__global__ __launch_bounds__(NW * 64) void knn_select2(const float *__restrict__ q, const float *__restrict__ p, int N,
-                                                       int M, int K, float *__restrict__ dists,
-                                                       void *__restrict__ idx_out, int idx_is_i64) {
-  constexpr int CAP = ks2_cap(KB);
-  static_assert(CAP >= 2 * KB + 3, "a compaction must leave room for one group of four candidates");
-  extern __shared__ __attribute__((aligned(16))) char ks_smem[];
-  const int Mpad = (M + 3) & ~3;
-  float4 *sref = reinterpret_cast<float4 *>(ks_smem);                                       // [Mpad]
-  unsigned short *slog = reinterpret_cast<unsigned short *>(ks_smem + (size_t)Mpad * 16);   // [NW][2][CAP][64]
-  float *md = reinterpret_cast<float *>(ks_smem + (size_t)Mpad * 16);                       // after the scan: [NW][KB][64]
-  int *mi = reinterpret_cast<int *>(md + NW * KB * 64);
-  const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i0 = blockIdx.x * 128 + lane;
-  float qx[2], qy[2], qz[2], rq[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int i = min(i0 + 64 * u, N - 1);
-    const float *qp = q + ((size_t)b * N + i) * 3;
-    qx[u] = qp[0];
-    qy[u] = qp[1];
-    qz[u] = qp[2];
-    rq[u] = sq_norm<FORM>(qx[u], qy[u], qz[u]);
-  }
-  p += (size_t)b * M * 3;
-  for (int r = threadIdx.x; r < M; r += NW * 64) {
-    const float *s = p + (size_t)r * 3;
-    sref[r] = make_float4(s[0], s[1], s[2], sq_norm<FORM>(s[0], s[1], s[2]));
-  }
-  __syncthreads();
-  float L[2][KB];
-  int I[2][KB];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int t = 0; t < KB; ++t) {
-      L[u][t] = __builtin_inff();
-      I[u][t] = 0x7fffffff;
-    }
-  const int per = (M + NW - 1) / NW;
-  const int lo = wave * per, hi = min(lo + per, M);
-  unsigned short *mylog[2] = {slog + ((size_t)wave * 2 + 0) * CAP * 64 + lane, slog + ((size_t)wave * 2 + 1) * CAP * 64 + lane};
-  int cnt[2] = {0, 0};
-  auto dist_of = [&](int u, int j) {
-    const float4 v = sref[j];
-    return pair_dist<FORM>(qx[u], qy[u], qz[u], rq[u], v.x, v.y, v.z, v.w);
-  };
-  auto compact = [&]() {  // see knn_select; both queries of the lane
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const float tau = L[u][KB - 1];
-      int w = 0;
-      int most = cnt[u];
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) most = max(most, __shfl_xor(most, m, 64));
-      most = __builtin_amdgcn_readfirstlane(most);
-      for (int e0 = 0; e0 < most; e0 += 8) {
-        int jj[8];
-        float cc[8];
-#pragma unroll
-        for (int v = 0; v < 8; ++v) jj[v] = e0 + v < cnt[u] ? (int)mylog[u][min(e0 + v, CAP - 1) * 64] : 0;
-#pragma unroll
-        for (int v = 0; v < 8; ++v) cc[v] = dist_of(u, jj[v]);
-#pragma unroll
-        for (int v = 0; v < 8; ++v) {
-          if (e0 + v < cnt[u] && cc[v] <= tau) {
-            mylog[u][w * 64] = (unsigned short)jj[v];
-            ++w;
-          }
-        }
-      }
-      cnt[u] = w;
-    }
-  };
-  for (int r0 = lo; r0 < hi; r0 += 4) {
-    float4 v[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) v[g] = sref[min(r0 + g, hi - 1)];
-    float c[2][4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) c[u][g] = pair_dist<FORM>(qx[u], qy[u], qz[u], rq[u], v[g].x, v[g].y, v[g].z, v[g].w);
-    if (__builtin_amdgcn_ballot_w64(max(cnt[0], cnt[1]) > CAP - 4)) compact();
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const bool in = r0 + g < hi;  // wave-uniform
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const float cu = in ? c[u][g] : __builtin_inff();
-        const bool acc = cu < L[u][KB - 1];
-#pragma unroll
-        for (int t = KB - 1; t > 0; --t) L[u][t] = __builtin_amdgcn_fmed3f(L[u][t - 1], cu, L[u][t]);
-        L[u][0] = __builtin_amdgcn_fmed3f(-__builtin_inff(), cu, L[u][0]);
-        if (acc) {
-          mylog[u][cnt[u] * 64] = (unsigned short)(r0 + g);
-          ++cnt[u];
-        }
-      }
-    }
-  }
-  compact();
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    int most = cnt[u];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) most = max(most, __shfl_xor(most, m, 64));
-    most = __builtin_amdgcn_readfirstlane(most);
-    for (int e0 = 0; e0 < most; e0 += 4) {
-      int jj[4];
-      float cc[4];
-#pragma unroll
-      for (int v2 = 0; v2 < 4; ++v2) jj[v2] = e0 + v2 < cnt[u] ? (int)mylog[u][min(e0 + v2, CAP - 1) * 64] : 0;
-#pragma unroll
-      for (int v2 = 0; v2 < 4; ++v2) cc[v2] = dist_of(u, jj[v2]);
-#pragma unroll
-      for (int v2 = 0; v2 < 4; ++v2) {
-        bool placed = !(e0 + v2 < cnt[u]);
-#pragma unroll
-        for (int t = 0; t < KB; ++t) {
-          const bool hit = !placed && cc[v2] == L[u][t] && I[u][t] == 0x7fffffff;
-          I[u][t] = hit ? jj[v2] : I[u][t];
-          placed = placed || hit;
-        }
-      }
-    }
-  }
-  // the NW lists of every query meet in LDS (the log area is dead), one query of the lane at a time; wave u merges pass u
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < KB; ++t) {
-      md[(wave * KB + t) * 64 + lane] = L[u][t];
-      mi[(wave * KB + t) * 64 + lane] = I[u][t];
-    }
-    __syncthreads();
-    const int i = i0 + 64 * u;
-    if (wave == 0 && i < N) {
-      int pos[NW];
-      float hd[NW];
-      int hi4[NW];
-#pragma unroll
-      for (int w = 0; w < NW; ++w) {
-        pos[w] = 0;
-        hd[w] = md[(w * KB) * 64 + lane];
-        hi4[w] = mi[(w * KB) * 64 + lane];
-      }
-      float *od = dists + ((size_t)b * N + i) * K;
-      int64_t *o64 = reinterpret_cast<int64_t *>(idx_out) + ((size_t)b * N + i) * K;
-      int32_t *o32 = reinterpret_cast<int32_t *>(idx_out) + ((size_t)b * N + i) * K;
-      for (int t = 0; t < K; ++t) {
-        int bw = 0;
-        float bd = hd[0];
-        int bi = hi4[0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) {
-          const bool take = hd[w] < bd || (hd[w] == bd && hi4[w] < bi);
-          bw = take ? w : bw;
-          bd = take ? hd[w] : bd;
-          bi = take ? hi4[w] : bi;
-        }
-        od[t] = bd;
-        if (idx_is_i64) o64[t] = bi;
-        else o32[t] = bi;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          if (bw == w) {
-            pos[w] += 1;
-            const bool more = pos[w] < KB;
-            const int a2 = (w * KB + (more ? pos[w] : KB - 1)) * 64 + lane;
-            hd[w] = more ? md[a2] : __builtin_inff();
-            hi4[w] = more ? mi[a2] : 0x7fffffff;
-          }
-        }
-      }
-    }
-  }
-}
-
 // K smallest (or largest) entries of every row of a materialised matrix P[B*N, M], ascending
 // (descending) with ties -> lower column index: the selection half of DGCNN's feature-space kNN
 // (model/dgcnn_cls.py:7-13: Gram matrix by GEMM, then topk).  One lane per row; a 64-row x 64-column tile is
@@ -724,34 +535,6 @@ static int launch_knn_select(const float *q, const float *p, int B, int N, int M
   return HITADV_E_ARG;
 }
 
-template <int FORM>
-static int launch_knn_select2(const float *q, const float *p, int B, int N, int M, int K, float *dists, void *idx,
-                              int idx_is_i64, hipStream_t s) {
-  constexpr int NW = 8;
-  dim3 grid((N + 127) / 128, B);
-  const size_t refs = (size_t)((M + 3) & ~3) * 16;
-#define HITADV_KS2_CASE(KB)                                                                                    \
-  if (K <= KB) {                                                                                               \
-    const size_t shm = refs + ks2_union_bytes(KB, NW);                                                         \
-    static int raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_select2<KB, FORM, NW>),        \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,                        \
-                                            32768 + (int)ks2_union_bytes(KB, NW));                             \
-    (void)raised;                                                                                              \
-    knn_select2<KB, FORM, NW><<<grid, NW * 64, shm, s>>>(q, p, N, M, K, dists, idx, idx_is_i64);               \
-    return 0;                                                                                                  \
-  }
-  HITADV_KS2_CASE(5)
-  HITADV_KS2_CASE(6)
-  HITADV_KS2_CASE(8)
-  if (FORM == 0) {
-    HITADV_KS2_CASE(12)
-    HITADV_KS2_CASE(17)
-  }
-  HITADV_KS2_CASE(18)
-#undef HITADV_KS2_CASE
-  return HITADV_E_ARG;
-}
-
 }  // namespace hitadv
 
 using namespace hitadv;
@@ -763,14 +546,11 @@ extern "C" int hitadv_knn_points(const float *q, const float *p, int B, int N, i
   if (form != HITADV_FORM_DIRECT && form != HITADV_FORM_GRAM_KNN) return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (K >= 2 && K <= 18 && M >= 512 && M <= 2048 && (long long)B * N >= 16384) {
-    // enough queries to fill the chip with 128-query blocks: two queries per lane
-    rc = form == HITADV_FORM_DIRECT ? launch_knn_select2<0>(q, p, B, N, M, K, dists, idx, idx_is_i64, s)
-                                    : launch_knn_select2<2>(q, p, B, N, M, K, dists, idx, idx_is_i64, s);
-  } else if (K <= 32 && M <= 2048) {
+  if (K <= 32 && M <= 2048) {
     // measured at B = 32, 1024 x 1024 (profiles/r02_kbench.json): 8 waves per block win for short lists (K = 1: 14 vs 29 us,
     // K = 6: 37 vs 43), 4 waves for long ones (K = 17: 74 vs 107 -- the 8-way merge and the doubled log area cost more
-    // than the extra waves hide)
+    // than the extra waves hide).  Two queries per lane (128-query blocks, as K2 does with four) was also measured: it
+    // halves the number of waves and lost -- K = 6: 50 us, K = 17: 107 us -- thread-level parallelism is what this scan needs.
     if (M >= 512 && K <= 8)
       rc = form == HITADV_FORM_DIRECT ? launch_knn_select<0, 8>(q, p, B, N, M, K, dists, idx, idx_is_i64, s)
                                       : launch_knn_select<2, 8>(q, p, B, N, M, K, dists, idx, idx_is_i64, s);

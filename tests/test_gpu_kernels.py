@@ -236,9 +236,9 @@ def test_knn_points_gram_knn_form_bit_exact(A, K):
 
 @pytest.mark.parametrize("K,m,form", [(2, 1024, 0), (5, 1024, 2), (6, 1024, 0), (6, 2048, 2), (8, 512, 0), (12, 1024, 0),
                                       (17, 1024, 0), (17, 2048, 0), (18, 1000, 2)])
-def test_knn_points_two_queries_per_lane_kernel(A, K, m, form):
-    """Enough queries (B * N >= 16384) select knn_select2: two queries per lane, 128-query blocks.  Same canonical result
-    bit for bit, including clouds with many exact ties and a monotonically approaching reference order in part of the batch."""
+def test_knn_points_full_batch_with_ties_and_falling_distances(A, K, m, form):
+    """A batch as large as the attack's own calls (16 clouds x 1061 queries, ragged last block), with one cloud made of six
+    distinct points (exact ties everywhere) and one whose references come ever closer (the logs overflow and compact)."""
     B, n = 16, 1024 + 37  # ragged last block
     x, _ = clouds(B, m, 184)
     q, _ = clouds(B, n, 185)
