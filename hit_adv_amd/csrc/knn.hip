@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
 // NW waves of a block split the reference range for the same 64 queries (NW = 8 from 512 references on: 4096 short waves
 // instead of 2048 give every SIMD four waves to switch between -- the scan is a chain of dependent VALU instructions).
 __host__ __device__ constexpr int ks_cap(int KB, int NW) {  // >= 2 KB - 1 survivors of a compaction + one group of 4
-  return NW == 8 ? (KB <= 8 ? 24 : (KB <= 12 ? 32 : (KB <= 20 ? 56 : 72))) : (KB <= 8 ? 32 : (KB <= 16 ? 64 : 96));
+  return NW == 8 ? (KB <= 8 ? 36 : (KB <= 12 ? 48 : (KB <= 20 ? 56 : 72))) : (KB <= 8 ? 32 : (KB <= 16 ? 64 : 96));
 }
 __host__ __device__ constexpr size_t ks_union_bytes(int KB, int NW) {
   return (size_t)NW * 64 * (ks_cap(KB, NW) * 2 > KB * 8 ? ks_cap(KB, NW) * 2 : KB * 8);
