@@ -3,7 +3,7 @@
 // fp32 operand carried as THREE bf16 pieces.
 //
 // Why: gfx950 has no reduced-precision f32 MFMA; v_mfma_f32_32x32x2_f32 runs at the f32 vector rate (64 flop / cycle /
-// SIMD, csrc/victim.hip reaches 82 % of it).  v_mfma_f32_32x32x16_bf16 runs 16x faster.  An fp32 value splits EXACTLY into
+// SIMD, csrc/victim.hip reaches 82 % of it).  The bf16 MFMAs run 16x faster.  An fp32 value splits EXACTLY into
 // three bf16 numbers, a = a1 + a2 + a3 (8 + 8 + 8 significant bits, each piece the truncation of what the previous ones
 // left), so   a.b = a1.b1 + (a1.b2 + a2.b1) + (a1.b3 + a3.b1 + a2.b2) + [terms below 2^-24 |a.b|],
 // six bf16 MFMAs (every bf16 x bf16 product is exact in fp32, the accumulator is fp32) instead of eight f32 MFMAs per 16
@@ -15,11 +15,16 @@
 //   W       : split once per attack (weights are constants) into three bf16 images in fragment order; the wave's 32
 //             columns x CIN rows x 3 pieces live in VGPRs for the whole kernel (96 registers at CIN = 128)
 //   x       : 64-point tiles, global fp32 -> registers -> split (4 VALU per value) -> three bf16 LDS images (row stride
-//             2 CIN + 16 bytes: conflict-free ds_read_b128), double buffered, one barrier per tile
-//   compute : per tile and wave 2 row blocks x (CIN/16 slices) x 6 MFMAs; the next slice's A fragments are read while
-//             the current slice's MFMAs run
-//   epilogue: the accumulator layout is that of the f32 kernel (column on the lane, 16 rows in registers): same running
-//             (max, first arg-max) scan, same split merge by the last block to arrive.
+//             2 CIN + 32 bytes: conflict-free ds_read_b128 for the fragment pattern below), double buffered, one barrier
+//             per tile
+//   compute : v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock under it than under the 32x32x16 form, and four
+//             accumulators rotate): per tile and wave 4 row tiles x 2 column tiles x (CIN/32 slices) x 6 MFMAs; the next
+//             unit's A fragments are read while the current unit's 24 MFMAs run
+//   epilogue: a lane scans its two channels' 16 points per tile into a running (max, first arg-max); four lane groups and
+//             the splits merge at the end (the last block to arrive, as in the f32 kernel).
+// Where the time goes (tools/tune/v1bf3: variants of this file with one cost removed, in-kernel clock stamped): the
+// MFMAs alone (no split, no scan, A fragments read once) take 36 us of the 40; 192 MFMAs per tile and wave at 16 cycles
+// and 1.9 GHz under this load are 26 us, the rest of that is the W load, the first tile and the tail.
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -27,7 +32,7 @@
 
 namespace hitadv {
 
-typedef float f32x16b __attribute__((ext_vector_type(16)));
+typedef float f32x4b __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int B3_TM = 64;
 
@@ -52,8 +57,9 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
                                                             float *pval, int32_t *pidx, const float *__restrict__ bias,
                                                             int relu, float *__restrict__ out, int64_t *__restrict__ idx,
                                                             int *tickets) {
-  constexpr int NSL = CIN / 16;          // 16-deep MFMA slices
-  constexpr int RS = 2 * CIN + 16;       // bytes per LDS row of one piece
+  constexpr int NSL = CIN / 32;          // 32-deep MFMA slices
+  constexpr int RS = 2 * CIN + 32;       // bytes per LDS row of one piece: rows 2 x 16 bytes apart mod 256 make the
+                                         // 16x16x32 A-fragment reads (lane -> row lane % 16, chunk lane / 16) conflict-free
   constexpr int PIECE = B3_TM * RS;      // bytes per piece image
   constexpr int G8 = CIN / 8;            // groups of 8 consecutive k per row
   constexpr int ST = B3_TM * G8 / 512;   // 8-value groups staged per thread per tile
@@ -74,22 +80,24 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
     }
   }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = lane & 31, h = lane >> 5;
   const int col0 = cg * 256 + wave * 32;
   const bool active = col0 < Cout;  // wave-uniform
   const int n0 = s * rows_per_split, n1 = min(N, n0 + rows_per_split);
   const int ntiles = (n1 - n0 + B3_TM - 1) / B3_TM;
   X += (size_t)b * N * CIN;
 
-  // B operand of slice j, piece p: the lane's column, k = 16 j + 8 h .. + 7.  W3 is stored in fragment order
-  // [piece][32-column block][slice][lane] x 16 bytes, so every load instruction of a wave reads 1 KB contiguous.
-  uint4 w[3][NSL];
+  // B operand of slice j (32 values of k), column tile ct (16 columns), piece p: the lane's column 16 ct + lane % 16,
+  // k = 32 j + 8 (lane / 16) .. + 7.  W3 is stored in fragment order [piece][16-column block][slice][lane] x 16 bytes, so
+  // every load instruction of a wave reads 1 KB contiguous.
+  uint4 w[3][2][NSL];
   {
-    const uint4 *wp = reinterpret_cast<const uint4 *>(W3) + (size_t)((active ? col0 : 0) / 32) * NSL * 64 + lane;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(W3) + (size_t)((active ? col0 : 0) / 16) * NSL * 64 + lane;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int j = 0; j < NSL; ++j) w[p][j] = wp[((size_t)p * (Cout / 32) * NSL + j) * 64];
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) w[p][ct][j] = wp[((size_t)p * (Cout / 16) * NSL + ct * NSL + j) * 64];
   }
 
   // x tiles travel global -> registers -> (split) -> LDS.  Two register sets: the loads of tile t+2 are issued at the top
@@ -97,26 +105,27 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   // (waves 4-7 convert and store tile t+1 BEFORE their MFMAs of tile t, waves 0-3 after): while one of them is in its
   // vector phase (split + scan) the other owns the matrix pipe (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
   float4 stA[ST][2], stB[ST][2];
+  // fetch() only issues the loads (rows past the split read a valid address); the first instruction that touches the
+  // loaded registers is in stash(), a whole tile later -- a select here would make the wave wait for HBM among its MFMAs.
   auto fetch = [&](float4 (&st)[ST][2], int tile) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
       const int n = n0 + tile * B3_TM + e / G8;
-      const float *src = X + (size_t)n * CIN + 8 * (e % G8);
-      // rows past the split read a valid address and are zeroed by selects (an if / else around the two loads sends
-      // ROCm 7.2's Machine Copy Propagation pass into a segmentation fault in this kernel)
-      const bool in = n < n1;
-      const float *sp = in ? src : X;
-      const float4 v0 = *reinterpret_cast<const float4 *>(sp), v1 = *reinterpret_cast<const float4 *>(sp + 4);
-      st[u][0] = make_float4(in ? v0.x : 0.f, in ? v0.y : 0.f, in ? v0.z : 0.f, in ? v0.w : 0.f);
-      st[u][1] = make_float4(in ? v1.x : 0.f, in ? v1.y : 0.f, in ? v1.z : 0.f, in ? v1.w : 0.f);
+      const float *sp = n < n1 ? X + (size_t)n * CIN + 8 * (e % G8) : X;
+      st[u][0] = *reinterpret_cast<const float4 *>(sp);
+      st[u][1] = *reinterpret_cast<const float4 *>(sp + 4);
     }
   };
-  auto stash = [&](const float4 (&st)[ST][2], int buf) {
+  auto stash = [&](const float4 (&st)[ST][2], int tile) {
+    const int buf = tile & 1;
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
-      const float a[8] = {st[u][0].x, st[u][0].y, st[u][0].z, st[u][0].w, st[u][1].x, st[u][1].y, st[u][1].z, st[u][1].w};
+      const bool in = n0 + tile * B3_TM + e / G8 < n1;  // rows past the split are zero in LDS (and masked in the scan)
+      float a[8] = {st[u][0].x, st[u][0].y, st[u][0].z, st[u][0].w, st[u][1].x, st[u][1].y, st[u][1].z, st[u][1].w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = in ? a[i] : 0.f;
       uint32_t p1[8], p2[8], p3[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) split3(a[i], p1[i], p2[i], p3[i]);
@@ -130,78 +139,92 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
     }
   };
 
-  float bv = -__builtin_inff();
-  int bi = -1;
-  f32x16b acc0, acc1;  // row blocks 0 and 1: element e = row 32*rb + (e&3) + 8*(e>>2) + 4*h, column r (the f32 kernel's layout)
+  // v_mfma_f32_16x16x32_bf16: the same flops per cycle as the 32x32x16 form on paper, but the chip holds a higher clock
+  // under it (MI355X_MICROARCH.md, DVFS item 7: ~1.13x the rate on random data) -- measured here: tools/tune/v1bf3.
+  // Accumulators: acc[rt][ct], row tile rt (16 points) x column tile ct (16 channels); element i of a lane = point
+  // 16 rt + 4 (lane / 16) + i, channel 16 ct + lane % 16.  A lane therefore scans TWO channels.
+  float bv[2] = {-__builtin_inff(), -__builtin_inff()};
+  int bi[2] = {-1, -1};
+  const int l16 = lane & 15, g4 = lane >> 4;
   const bool late = wave >= 4;  // wave-uniform
-  // one tile: MFMAs (the A fragments of slice j+1 are read from LDS while the twelve MFMAs of slice j run), then the scan
+  // one tile: 8 units of (slice j, row-tile pair rp): 6 A fragments (2 row tiles x 3 pieces) feed 24 MFMAs; the next
+  // unit's fragments are read from LDS while this unit's MFMAs run.  Then the scan.
   auto compute = [&](int tile) {
-    const char *base = sB3 + (size_t)(tile & 1) * 3 * PIECE + r * RS + 16 * h;
+    const char *base = sB3 + (size_t)(tile & 1) * 3 * PIECE + l16 * RS + 16 * g4;
+    f32x4b acc[4][2];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc0[e] = acc1[e] = 0.f;
-    uint4 fa[2][6];
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int q = 0; q < 6; ++q) fa[0][q] = *reinterpret_cast<const uint4 *>(base + (q % 3) * PIECE + (q / 3) * 32 * RS);
+      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4b{0.f, 0.f, 0.f, 0.f};
+    uint4 fa[2][6];  // [buffer][3 * (row tile within the pair) + piece]
+    auto frag = [&](int u, int q) {  // unit u = 2 j + rp
+      return *reinterpret_cast<const uint4 *>(base + (q % 3) * PIECE + (2 * (u & 1) + q / 3) * 16 * RS + 64 * (u >> 1));
+    };
 #pragma unroll
-    for (int j = 0; j < NSL; ++j) {
-      if (j + 1 < NSL) {
+    for (int q = 0; q < 6; ++q) fa[0][q] = frag(0, q);
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
-          fa[(j + 1) & 1][q] = *reinterpret_cast<const uint4 *>(base + (q % 3) * PIECE + (q / 3) * 32 * RS + 32 * (j + 1));
+    for (int u = 0; u < 2 * NSL; ++u) {
+      if (u + 1 < 2 * NSL) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) fa[(u + 1) & 1][q] = frag(u + 1, q);
       }
-      __builtin_amdgcn_sched_barrier(0);  // the reads stay above this slice's MFMAs
-      const bf16x8 w0 = as_bf16x8(w[0][j]), w1 = as_bf16x8(w[1][j]), w2 = as_bf16x8(w[2][j]);
-      const bf16x8 f0 = as_bf16x8(fa[j & 1][0]), f1 = as_bf16x8(fa[j & 1][1]), f2 = as_bf16x8(fa[j & 1][2]);
-      const bf16x8 g0 = as_bf16x8(fa[j & 1][3]), g1 = as_bf16x8(fa[j & 1][4]), g2 = as_bf16x8(fa[j & 1][5]);
-      // smallest terms first; the two row blocks alternate so that consecutive MFMAs are independent
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w2, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w2, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, w0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g2, w0, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w1, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, w1, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w1, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w1, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, w0, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, w0, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // the reads stay above this unit's MFMAs
+      const int j = u >> 1, rp = u & 1;
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[x][p] = as_bf16x8(fa[u & 1][3 * x + p]);
+          b[x][p] = as_bf16x8(w[p][x][j]);
+        }
+      // smallest terms first; the four accumulators of the unit take turns, so consecutive MFMAs are independent
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            acc[2 * rp + x][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[x][PA[t]], b[ct][PB[t]], acc[2 * rp + x][ct], 0, 0, 0);
     }
-    // running (max, first arg-max): a tile-local best with an inline-constant code, joined with the tile number once
+    // running (max, first arg-max) per channel: a tile-local best with an inline-constant code (4 rt + i: ascending points),
+    // joined with the tile number once
     const bool ragged = n0 + (tile + 1) * B3_TM > n1;  // wave-uniform: only a split's last tile can be ragged
-    const int row0 = n0 + tile * B3_TM + 4 * h;
-    float tv = -__builtin_inff();
-    int tc = 0;
+    const int row0 = n0 + tile * B3_TM + 4 * g4;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float v = acc0[e];
-      if (ragged) v = row0 + (e & 3) + 8 * (e >> 2) < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
-      const bool g = v > tv;
-      tv = g ? v : tv;
-      tc = g ? e : tc;
-    }
+    for (int ct = 0; ct < 2; ++ct) {
+      float tv = -__builtin_inff();
+      int tc = 0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float v = acc1[e];
-      if (ragged) v = row0 + 32 + (e & 3) + 8 * (e >> 2) < n1 ? v : -__builtin_inff();
-      const bool g = v > tv;
-      tv = g ? v : tv;
-      tc = g ? 16 + e : tc;
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[rt][ct][i];
+          if (ragged) v = row0 + 16 * rt + i < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
+          const bool g = v > tv;
+          tv = g ? v : tv;
+          tc = g ? 4 * rt + i : tc;
+        }
+      const bool g = tv > bv[ct];  // earlier tiles hold earlier points: they keep ties
+      bv[ct] = g ? tv : bv[ct];
+      bi[ct] = g ? tile * 16 + tc : bi[ct];
     }
-    const bool g = tv > bv;  // earlier tiles hold earlier points: they keep ties
-    bv = g ? tv : bv;
-    bi = g ? tile * 32 + tc : bi;
   };
   // tile t: stA holds tile t+1 (loaded during tile t-1), tile t+2 is requested into stB; the sets swap every tile
   auto step = [&](int tile, float4 (&have)[ST][2], float4 (&next)[ST][2]) {
     const bool more = tile + 1 < ntiles;
     if (tile + 2 < ntiles) fetch(next, tile + 2);
-    if (more && late) stash(have, (tile + 1) & 1);
+    if (more && late) stash(have, tile + 1);
     if (active) compute(tile);
-    if (more && !late) stash(have, (tile + 1) & 1);
+    if (more && !late) stash(have, tile + 1);
     __syncthreads();
   };
   fetch(stA, 0);
+  // every load issued so far (W, tile 0) completes HERE, explicitly: the first use of W is inside the loop, and a load that
+  // may still be pending at the loop entry makes the compiler's wait-count pass guard every in-loop use of W with a
+  // vmcnt wait that, on the iterations that did issue new loads, waits for THOSE (measured: tools/tune/v1bf3)
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   stash(stA, 0);
   if (ntiles > 1) fetch(stA, 1);
   __syncthreads();
@@ -209,23 +232,31 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
     step(tile, stA, stB);
     if (tile + 1 < ntiles) step(tile + 1, stB, stA);
   }
-  // code -> point index; nothing won (all rows -inf): the split's first point
-  bi = bi < 0 ? n0 : n0 + (bi >> 5) * B3_TM + 4 * h + 32 * ((bi >> 4) & 1) + (bi & 3) + 8 * ((bi & 15) >> 2);
-  {  // the other half of the wave holds the same column, other rows
-    const float ov = __shfl_xor(bv, 32, HITADV_WAVE);
-    const int oi = __shfl_xor(bi, 32, HITADV_WAVE);
-    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  // code -> point index; nothing won (all rows -inf): the split's first point.  The four 16-lane groups of the wave hold
+  // the same channels, other points: two exchanges, the lower point keeps a tie.
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    bi[ct] = bi[ct] < 0 ? n0 : n0 + (bi[ct] >> 4) * B3_TM + 16 * ((bi[ct] >> 2) & 3) + 4 * g4 + (bi[ct] & 3);
+#pragma unroll
+    for (int m = 16; m <= 32; m <<= 1) {
+      const float ov = __shfl_xor(bv[ct], m, HITADV_WAVE);
+      const int oi = __shfl_xor(bi[ct], m, HITADV_WAVE);
+      if (ov > bv[ct] || (ov == bv[ct] && oi < bi[ct])) { bv[ct] = ov; bi[ct] = oi; }
+    }
   }
-  if (active && h == 0) {
-    const int c = col0 + r;
-    if (S == 1) {  // nothing to merge: finish here
-      float v = bv + (bias ? bias[c] : 0.f);  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
-      out[(size_t)b * Cout + c] = relu ? (v > 0.f ? v : 0.f) : v;  // max and ReLU commute
-      idx[(size_t)b * Cout + c] = bi;
-    } else {
-      const size_t o = ((size_t)b * S + s) * Cout + c;
-      __hip_atomic_store(&pval[o], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&pidx[o], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (active && g4 == 0) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int c = col0 + 16 * ct + l16;
+      if (S == 1) {  // nothing to merge: finish here
+        float v = bv[ct] + (bias ? bias[c] : 0.f);  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
+        out[(size_t)b * Cout + c] = relu ? (v > 0.f ? v : 0.f) : v;  // max and ReLU commute
+        idx[(size_t)b * Cout + c] = bi[ct];
+      } else {
+        const size_t o = ((size_t)b * S + s) * Cout + c;
+        __hip_atomic_store(&pval[o], bv[ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pidx[o], bi[ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   if (S == 1) return;
@@ -251,7 +282,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
 }
 
 // W[Cout,Cin] fp32 (row-major, one row per output channel) -> its three bf16 pieces in FRAGMENT ORDER:
-// W3[piece][c / 32][k / 16][(k % 16) / 8][c % 32][k % 8]  (16 bytes per (piece, 32-column block, slice, lane)).
+// W3[piece][c / 16][k / 32][(k % 32) / 8][c % 16][k % 8]  (16 bytes per (piece, 16-column block, slice, lane)).
 __global__ __launch_bounds__(256) void split_weights_k(const float *__restrict__ W, uint16_t *__restrict__ W3, int Cout,
                                                        int Cin) {
   const long long total = (long long)Cout * Cin;
@@ -260,7 +291,7 @@ __global__ __launch_bounds__(256) void split_weights_k(const float *__restrict__
   const int c = (int)(e / Cin), k = (int)(e % Cin);
   uint32_t a, bb, cc;
   split3(W[e], a, bb, cc);
-  const long long o = ((((long long)(c / 32) * (Cin / 16) + k / 16) * 2 + (k % 16) / 8) * 32 + c % 32) * 8 + k % 8;
+  const long long o = ((((long long)(c / 16) * (Cin / 32) + k / 32) * 4 + (k % 32) / 8) * 16 + c % 16) * 8 + k % 8;
   W3[o] = (uint16_t)(a >> 16);
   W3[total + o] = (uint16_t)(bb >> 16);
   W3[2 * total + o] = (uint16_t)(cc >> 16);
@@ -296,7 +327,7 @@ static void bf3_split(int B, int N, int Cout, int *S, int *rows) {
 using namespace hitadv;
 
 extern "C" int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream) {
-  if (!W || !W3 || Cout <= 0 || Cin <= 0 || (Cout & 31) || (Cin & 15)) return HITADV_E_ARG;
+  if (!W || !W3 || Cout <= 0 || Cin <= 0 || (Cout & 15) || (Cin & 31)) return HITADV_E_ARG;
   const long long total = (long long)Cout * Cin;
   split_weights_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, W3, Cout, Cin);
   HITADV_LAUNCH_CHECK();
@@ -321,16 +352,16 @@ extern "C" int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, 
   bf3_split(B, N, Cout, &S, &rows);
   const int ncg = (Cout + 255) / 256;
   dim3 grid((unsigned)(ncg * S * B));
-  const size_t shm = (size_t)2 * 3 * B3_TM * (2 * Cin + 16);
+  const size_t shm = (size_t)2 * 3 * B3_TM * (2 * Cin + 32);
   if (Cin == 128) {
     static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<128>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 128 + 16));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 128 + 32));
     (void)once;
     linear_max_fwd_bf3_k<128><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
                                                      tickets);
   } else {
     static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<64>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 64 + 16));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 64 + 32));
     (void)once;
     linear_max_fwd_bf3_k<64><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
                                                     tickets);

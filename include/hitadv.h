@@ -262,7 +262,7 @@ int64_t hitadv_linear_max_fwd_scratch(int B, int N, int Cout);
  * the six leading cross terms in an fp32 accumulator -- the dropped terms are below 2^-24 of the product, i.e. below the
  * rounding of an fp32 GEMM; nothing is rounded to bf16 precision.  2.67x less matrix time than the f32 MFMA form.
  * W3 = the three bf16 pieces of the layer's weight W [Cout,Cin] (row-major, one row per output channel; Cout % 32 == 0,
- * Cin % 16 == 0), 3*Cout*Cin uint16 in the kernel's fragment order [piece][c/32][k/16][(k%16)/8][c%32][k%8], made once
+ * Cin % 32 == 0), 3*Cout*Cin uint16 in the kernel's fragment order [piece][c/16][k/32][(k%32)/8][c%16][k%8], made once
  * per attack by hitadv_split_weights_bf16x3; 16-byte aligned.  Scratch / tickets as for hitadv_linear_max_fwd
  * (tickets must not be NULL). */
 int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream);

@@ -13,6 +13,11 @@ replaced by stand-ins in ``sys.modules``:
   used throughout this project: fp32 direct difference, evaluated as
   ``((dx*dx + dy*dy) + dz*dz)`` with one rounding per operation (no FMA),
   K smallest in ascending order, ties -> lower index (stable sort).
+  Fixtures whose values passed through this stand-in (everything that calls ``knn_points`` in the reference):
+  g2 (kNN tables, kappa, kappa-std, CurvStdDist), g4 (centre selection), g5 / g5b (HiT-ADV trajectories: scoring and
+  centre selection), g22 (CurvDist).  g1, g3, g6-g21, g23, g24 never reach it.  The rule is stated independently in
+  tests/test_gpu_kernels.py::test_knn_points_vs_independent_float64_top_k (float64 brute force on well-separated
+  neighbours + the explicit tie policy).
 * ``mayavi``, ``open3d``, ``torchvision``, ``seaborn``: GUI / unused imports.
 * ``pointnet2_ops_lib...pointnet2_utils``: the CUDA extension (cannot be built
   without nvcc / run without a GPU) -- placeholder only so ``util.other_utils``

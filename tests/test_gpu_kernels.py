@@ -250,6 +250,28 @@ def test_knn_points_full_batch_with_ties_and_falling_distances(A, K, m, form):
     assert torch.equal(ix.cpu(), rix) and torch.equal(d.cpu(), rd)
 
 
+def test_knn_points_vs_independent_float64_top_k(A):
+    """An independent statement of the selection rule: brute force in float64 -- squared differences summed in
+    float64, ``torch.topk`` -- on clouds whose neighbour distances are well separated, so that fp32 rounding cannot change
+    the ranking: same indices.  And the explicit tie policy on exact duplicates: equal distances rank by ascending index."""
+    x, _ = clouds(2, 777, 186)
+    q, _ = clouds(2, 200, 187)
+    d64 = ((q.double()[:, :, None, :] - x.double()[:, None, :, :]) ** 2).sum(-1)
+    K = 17
+    ref = d64.topk(K + 1, dim=-1, largest=False, sorted=True)
+    gaps = (ref.values[..., 1:] - ref.values[..., :-1]) / ref.values[..., 1:].clamp_min(1e-30)
+    clear = (gaps > 1e-5).all(-1)  # every one of the K+1 nearest is separated from the next by more than fp32 noise
+    assert clear.float().mean() > 0.8
+    d, ix = A.KnnPoints.apply(cu(q), cu(x), K)
+    assert torch.equal(ix.cpu()[clear], ref.indices[..., :K][clear])
+    close(d.cpu()[clear], ref.values[..., :K][clear].float(), rtol=2e-6, atol=1e-9, what='kNN distances vs float64 brute force')
+    dup = torch.cat([x[:, :50], x[:, :50].flip(1), x[:, :50]], 1)  # every point three times, at indices i, 99-i, 100+i
+    d, ix = A.KnnPoints.apply(cu(x[:, :50].contiguous()), cu(dup), 3)
+    i = torch.arange(50)
+    want = torch.stack([torch.minimum(i, 99 - i), torch.maximum(i, 99 - i), 100 + i], -1)
+    assert (d == 0).all() and torch.equal(ix.cpu(), want.expand(2, 50, 3))
+
+
 def test_knn_points_heavy_ties_and_log_compaction(A):
     """Adversarial orders for the select kernel: distances that fall monotonically along the scan (every reference is
     accepted: the per-lane log overflows and is compacted again and again) and clouds made of a few distinct points
@@ -696,8 +718,8 @@ def test_linear_max_fwd_bf16x3_is_fp32_accurate(A, B, Np, Cin, Cout):
     Wt = torch.randn(Cin, Cout, generator=g) * 0.1
     bias = torch.randn(Cout, generator=g)
     W3 = A.split_weights_bf16x3(cu(Wt.t().contiguous()))
-    # fragment order [piece][c/32][k/16][(k%16)/8][c%32][k%8] -> [piece][c][k]
-    pieces = W3.cpu().view(torch.bfloat16).float().view(3, Cout // 32, Cin // 16, 2, 32, 8).permute(0, 1, 4, 2, 3, 5)
+    # fragment order [piece][c/16][k/32][(k%32)/8][c%16][k%8] -> [piece][c][k]
+    pieces = W3.cpu().view(torch.bfloat16).float().view(3, Cout // 16, Cin // 32, 4, 16, 8).permute(0, 1, 4, 2, 3, 5)
     pieces = pieces.reshape(3, Cout, Cin)
     assert torch.equal(pieces[0] + pieces[1] + pieces[2], Wt.t())  # exact three-way split
     y = (x.double() @ Wt.double()).view(B, Np, Cout)
