@@ -97,6 +97,10 @@ struct RowMlpFwd {
   float *o1;         // [B*N,64]  relu(t1)                   (stage 1)
   float *o2;         // [B*N,128] relu(last layer)
   int N;
+  // stage 1, optional: the input transform itself, T3[b] = F5[b,:256] @ W6[256,9] + b6 (STN3d's fc3, :186-190, identity
+  // folded into b6), evaluated by every block of the cloud instead of by a launch of its own; tile 0 writes it to Tout
+  const float *F5, *W6, *b6;
+  float *Tout;
 };
 
 template <int STAGE>
@@ -129,12 +133,38 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
       const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
       sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
     }
+    __shared__ float sTp[4][9], sT[9];
+    const bool ownT = STAGE == 1 && a.F5 != nullptr;  // block-uniform
+    if (ownT) {  // 256 threads = the 256 inputs of fc3: a fixed butterfly per wave, then the four waves in order
+      const float f = a.F5[(size_t)b * 256 + threadIdx.x];
+      float p[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) p[q] = f * a.W6[threadIdx.x * 9 + q];
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) p[q] += __shfl_xor(p[q], m, HITADV_WAVE);
+      if (lane < 9) {
+        float v = p[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) v = lane == q ? p[q] : v;
+        sTp[wave][lane] = v;
+      }
+    }
     __syncthreads();
+    if (ownT) {
+      if (threadIdx.x < 9) {
+        const float v = ((sTp[0][threadIdx.x] + sTp[1][threadIdx.x]) + sTp[2][threadIdx.x]) + sTp[3][threadIdx.x] + a.b6[threadIdx.x];
+        sT[threadIdx.x] = v;
+        if (blockIdx.x == 0) a.Tout[(size_t)b * 9 + threadIdx.x] = v;
+      }
+      __syncthreads();
+    }
     const float *xin = sX;
     if (STAGE == 1) {  // x' = x @ T3   (torch.bmm(x, trans), :124)
       if (threadIdx.x < 192) {
         const int n = threadIdx.x / 3, j = threadIdx.x % 3;
-        const float *T = a.T + (size_t)b * 9;
+        const float *T = ownT ? sT : a.T + (size_t)b * 9;
         const float v = fmaf(sX[n * 3 + 2], T[6 + j], fmaf(sX[n * 3 + 1], T[3 + j], sX[n * 3] * T[j]));
         sXp[threadIdx.x] = v;
         if (a.xp != nullptr && n < rows) a.xp[row0 * 3 + threadIdx.x] = v;
@@ -607,10 +637,22 @@ constexpr int FC_CH = 128;
 constexpr int FC_LD = FC_CH + 4;
 constexpr int FC_TICKETS = 16384;  // fixed-size ticket area at the head of the scratch (one per output tile)
 
+// PRE: the input is itself a small product that is evaluated on the way in instead of by a launch of its own,
+//   in[b,k] = sum_j (sum_t pre[b,t,j]) * Wpre[j,k]      (J <= 64; t ascending; j ascending within a lane half),
+// the first layer of a backward stack (its K is the 9 or 40 outputs of the forward stack's last layer) together with the
+// sum over the tiles' partials that produced its input.  The block sums the partials of its 32 rows into LDS once; every
+// wave then computes the 32 x 32 slice of the chunk that it consumes itself (J/2 MFMAs).
+struct FcPre {
+  const float *pre;   // [B,T,J]
+  const float *Wpre;  // [J,K]
+  int T, J;
+};
+
+template <int PRE>  // 0: plain; otherwise the number of MFMA steps of the product in front (8: J <= 16, 32: J <= 64)
 __global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, const float *__restrict__ mask,
                                                   const float *__restrict__ Wt, const float *__restrict__ bias, int B,
                                                   int K, int NOUT, int relu, int chunk, float *__restrict__ out,
-                                                  float *part, int *ticket) {
+                                                  float *part, int *ticket, FcPre pp) {
   __shared__ float4 sA4[32 * FC_LD / 4];
   __shared__ float red[4 * 1024];
   __shared__ int s_last;
@@ -624,15 +666,75 @@ __global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, 
   const bool cok = col < NOUT;
   f32x16 acc;
   zero(acc);
-  for (int kc = kb0; kc < kb1; kc += FC_CH) {
-    float wv[16];
+  // every global operand of a chunk is requested in one go (addresses clamped into range, out-of-range values dropped
+  // where they are used): this wave's 32 rows of Wt and, PRE, its column of Wpre and the mask values of its output slots
+  constexpr int PS = PRE > 0 ? PRE : 1;
+  float wv[16], bq[PS], mk[16], av[PS];
+  auto issue = [&](int kc) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {  // this wave's 32 rows of Wt, in flight while the input chunk is staged
+    for (int t = 0; t < 16; ++t) {
       const int k = kc + 32 * wave + kmap(t, h);
       wv[t] = (k < kb1 && cok) ? Wt[(size_t)k * NOUT + col] : 0.f;
     }
-    if (kc != kb0) __syncthreads();
-    if ((K & 3) == 0) {
+    if (PRE) {
+      const int kk = min(kc + 32 * wave + r, K - 1);
+#pragma unroll
+      for (int t = 0; t < PS; ++t) bq[t] = pp.Wpre[(size_t)min(2 * t + h, pp.J - 1) * K + kk];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        mk[e] = mask != nullptr ? mask[(size_t)min(row0 + acc_row(e, h), B - 1) * K + kk] : 1.f;
+    }
+  };
+  issue(kb0);
+  if (PRE) {  // P[32,J] = the summed partials of this block's rows, into the (still unused) reduction array
+    if (pp.T == 1) {  // nothing to sum: a thread's (up to eight) values in one batch of loads
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = min((int)threadIdx.x + 256 * u, 32 * pp.J - 1);
+        v[u] = pp.pre[(size_t)min(row0 + e / pp.J, B - 1) * pp.J + e % pp.J];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < 32 * pp.J) red[(e / pp.J) * 65 + e % pp.J] = row0 + e / pp.J < B ? v[u] : 0.f;
+      }
+    } else {
+      for (int e = threadIdx.x; e < 32 * pp.J; e += 256) {
+        const int rr = e / pp.J, j = e - rr * pp.J;
+        const float *p = pp.pre + ((size_t)min(row0 + rr, B - 1) * pp.T) * pp.J + j;
+        float v = 0.f;
+        for (int t0 = 0; t0 < pp.T; t0 += 16) {  // sixteen partials in flight, added in ascending t
+          float q[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) q[t] = p[(size_t)min(t0 + t, pp.T - 1) * pp.J];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) v += t0 + t < pp.T ? q[t] : 0.f;
+        }
+        red[rr * 65 + j] = row0 + rr < B ? v : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < PS; ++t) av[t] = 2 * t + h < pp.J ? red[r * 65 + min(2 * t + h, 63)] : 0.f;
+    __syncthreads();  // every wave holds its operands: the array is free for the accumulators
+  }
+  for (int kc = kb0; kc < kb1; kc += FC_CH) {
+    if (kc != kb0) {
+      issue(kc);
+      __syncthreads();
+    }
+    if (PRE) {
+      f32x16 pa;
+      zero(pa);
+#pragma unroll
+      for (int t = 0; t < PS; ++t)
+        if (2 * t < pp.J) pa = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bq[t], pa, 0, 0, 0);  // wave-uniform guard
+      const bool kok = kc + 32 * wave + r < kb1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        sA[acc_row(e, h) * FC_LD + 32 * wave + r] = (kok && mk[e] > 0.f) ? pa[e] : 0.f;  // rows past B are zeros of P
+    } else if ((K & 3) == 0) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int e = threadIdx.x + 256 * u, rr = e >> 5, k = kc + 4 * (e & 31);
@@ -736,12 +838,25 @@ extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float
   if (stage < 2 && (!x || !W0 || !b0 || !o0)) return HITADV_E_ARG;
   if (stage == 1 && (!T || !W1 || !b1 || !o1)) return HITADV_E_ARG;
   if (stage == 2 && (!T || !hin)) return HITADV_E_ARG;
-  RowMlpFwd a{x, T, hin, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N};
+  RowMlpFwd a{x, T, hin, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, nullptr, nullptr, nullptr, nullptr};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   hipStream_t s = (hipStream_t)stream;
   if (stage == 0) rowmlp_fwd_k<0><<<grid, 256, 0, s>>>(a);
   else if (stage == 1) rowmlp_fwd_k<1><<<grid, 256, 0, s>>>(a);
   else rowmlp_fwd_k<2><<<grid, 256, 0, s>>>(a);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, const float *W6, const float *b6,
+                                              float *Tout, const float *W0, const float *b0, const float *W1,
+                                              const float *b1, const float *W2, const float *b2, float *xp, float *o0,
+                                              float *o1, float *o2, int B, int N, void *stream) {
+  if (B <= 0 || N <= 0 || !x || !F5 || !W6 || !b6 || !Tout || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !o0 || !o1 || !o2)
+    return HITADV_E_ARG;
+  RowMlpFwd a{x, nullptr, nullptr, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, F5, W6, b6, Tout};
+  dim3 grid((N + PM_TM - 1) / PM_TM, B);
+  rowmlp_fwd_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -796,8 +911,29 @@ extern "C" int hitadv_fc_layer(const float *in, const float *mask, const float *
   fc_split(B, K, NOUT, &chunk, &KS, &tiles);
   if (tiles > FC_TICKETS) return HITADV_E_ARG;
   dim3 grid((NOUT + 31) / 32, (B + 31) / 32, KS);
-  fc_layer_k<<<grid, 256, 0, (hipStream_t)stream>>>(in, mask, Wt, bias, B, K, NOUT, relu, chunk, out, scratch + FC_TICKETS,
-                                                    reinterpret_cast<int *>(scratch));
+  fc_layer_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(in, mask, Wt, bias, B, K, NOUT, relu, chunk, out,
+                                                           scratch + FC_TICKETS, reinterpret_cast<int *>(scratch), FcPre{});
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_fc_layer_pre(const float *pre, int T, int J, const float *Wpre, const float *mask, const float *Wt,
+                                   const float *bias, int B, int K, int NOUT, int relu, float *out, float *scratch,
+                                   void *stream) {
+  if (!pre || !Wpre || !Wt || !out || !scratch || B <= 0 || K <= 0 || NOUT <= 0 || T <= 0 || J <= 0 || J > 64)
+    return HITADV_E_ARG;
+  int chunk, KS, tiles;
+  fc_split(B, K, NOUT, &chunk, &KS, &tiles);
+  if (tiles > FC_TICKETS) return HITADV_E_ARG;
+  dim3 grid((NOUT + 31) / 32, (B + 31) / 32, KS);
+  const FcPre pp{pre, Wpre, T, J};
+  int *tk = reinterpret_cast<int *>(scratch);
+  if (J <= 16)
+    fc_layer_k<8><<<grid, 256, 0, (hipStream_t)stream>>>(nullptr, mask, Wt, bias, B, K, NOUT, relu, chunk, out,
+                                                         scratch + FC_TICKETS, tk, pp);
+  else
+    fc_layer_k<32><<<grid, 256, 0, (hipStream_t)stream>>>(nullptr, mask, Wt, bias, B, K, NOUT, relu, chunk, out,
+                                                          scratch + FC_TICKETS, tk, pp);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

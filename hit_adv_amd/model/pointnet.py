@@ -202,11 +202,16 @@ class _PointNetHip(torch.autograd.Function):
         gs, js = lin_max(a2s, 's3', True)
         f4s = ops.fc_layer(gs, v.s4_w, v.s4_b, relu=True)
         f5s = ops.fc_layer(f4s, v.s5_w, v.s5_b, relu=True)
-        T3 = ops.fc_layer(f5s, v.s6_w, v.s6_b)
-        # input transform, first encoder layer, STNkd
+        # input transform (STN3d's last layer is evaluated inside the stage-1 kernel), first encoder layer, STNkd
         h1, a1t, a2t = E(R, 64), E(R, 64), E(R, 128)
-        ops.pointnet_rowmlp_fwd(1, B, N, v.t2_w, v.t2_b, a2t, x=x, T=T3, W0=v.e1_w, b0=v.e1_b, W1=v.t1_w, b1=v.t1_b,
-                                o0=h1, o1=a1t)
+        if v.fold_small_layers:
+            T3 = E(B, 9)
+            ops.pointnet_rowmlp_fwd_stn(B, N, x, f5s, v.s6_w, v.s6_b, T3, v.e1_w, v.e1_b, v.t1_w, v.t1_b, v.t2_w, v.t2_b,
+                                        h1, a1t, a2t)
+        else:
+            T3 = ops.fc_layer(f5s, v.s6_w, v.s6_b)
+            ops.pointnet_rowmlp_fwd(1, B, N, v.t2_w, v.t2_b, a2t, x=x, T=T3, W0=v.e1_w, b0=v.e1_b, W1=v.t1_w, b1=v.t1_b,
+                                    o0=h1, o1=a1t)
         gt, jt = lin_max(a2t, 't3', True)
         f4t = ops.fc_layer(gt, v.t4_w, v.t4_b, relu=True)
         f5t = ops.fc_layer(f4t, v.t5_w, v.t5_b, relu=True)
@@ -235,8 +240,10 @@ class _PointNetHip(torch.autograd.Function):
         if dlogits is None:
             dlogits = torch.zeros(B, v.h3_w.shape[1], device=x.device)
         # head and encoder tail
-        d = ops.fc_layer(dlogits.contiguous(), v.h3_wr)
-        d = ops.fc_layer(d, v.h2_wr, mask=f2)
+        if v.fold_small_layers:  # fc3 and fc2 backwards: one launch
+            d = ops.fc_layer_pre(dlogits.contiguous().unsqueeze(1), v.h3_wr, v.h2_wr, mask=f2)
+        else:
+            d = ops.fc_layer(ops.fc_layer(dlogits.contiguous(), v.h3_wr), v.h2_wr, mask=f2)
         dg = ops.fc_layer(d, v.h1_wr, mask=f1)
         dTp, dH1 = E(B, tiles, 4096), E(R, 64)
         # which points of a tile receive any gradient: handed from stage to stage, each stage works on those rows only
@@ -251,10 +258,11 @@ class _PointNetHip(torch.autograd.Function):
         dTp, dPts = E(B, tiles, 9), E(B, 3, N)
         ops.pointnet_rowmlp_bwd(1, B, N, dgt, jt, v.t3_wr, a2t, v.t2_wr, dPts, gmask=gt, A1=a1t, W1r=v.t1_wr, H1=h1,
                                 dH1in=dH1, W0r=v.e1_wr, T=T3, x=x, dTpart=dTp, pres_in=pres2, pres_out=pres1)
-        dT3 = ops.sum_partials(dTp)
-        # STN3d
-        d = ops.fc_layer(dT3, v.s6_wr)
-        d = ops.fc_layer(d, v.s5_wr, mask=f5s)
+        # STN3d: the sum of the tiles' dT3 partials, fc3 and fc2 backwards in one launch
+        if v.fold_small_layers:
+            d = ops.fc_layer_pre(dTp, v.s6_wr, v.s5_wr, mask=f5s)
+        else:
+            d = ops.fc_layer(ops.fc_layer(ops.sum_partials(dTp), v.s6_wr), v.s5_wr, mask=f5s)
         dgs = ops.fc_layer(d, v.s4_wr, mask=f4s)
         dX = E(B, 3, N)
         ops.pointnet_rowmlp_bwd(0, B, N, dgs, js, v.s3_wr, a2s, v.s2_wr, dX, gmask=gs, A1=a1s, W0r=v.s1_wr, dPin=dPts,
@@ -332,6 +340,8 @@ class FoldedPointNet(nn.Module):
         return self
 
     matrix_mode = 'bf16x3'  # the three 128 -> 1024 layers: 'bf16x3' (three-piece bf16 split, fp32-accurate) or 'f32'
+    fold_small_layers = True  # the 256 -> 9 layer inside the stage-1 kernel, the 9 / 40 -> 256 backward layers inside the
+    #                           next layer's launch (False: one launch per layer, kept for A/B timing and as a cross-check)
 
     def pieces(self, name):
         """bf16 pieces [3,Cout,Cin] of a 128 -> 1024 layer's folded weight, split on first use (weights are constants

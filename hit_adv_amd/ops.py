@@ -487,6 +487,22 @@ def fc_layer(x, Wt, bias=None, relu=False, mask=None):
     return out
 
 
+def fc_layer_pre(pre, Wpre, Wt, bias=None, relu=False, mask=None):
+    """``fc_layer`` whose input is evaluated on the way in: x = (sum_t pre[:, t, :]) @ Wpre  (pre [B,T,J], Wpre [J,K], J <= 64),
+    gated by mask > 0, then @ Wt [K,NOUT] -- the sum over the tiles' partials, the first (tiny) layer of a backward stack and
+    its second layer in one launch."""
+    pre, Wpre, Wt = _dev(pre, "pre"), _dev(Wpre, "Wpre"), _dev(Wt, "Wt")
+    B, T, J = pre.shape
+    K, NOUT = Wt.shape
+    if tuple(Wpre.shape) != (J, K):
+        raise ValueError("Wpre must be [%d,%d]" % (J, K))
+    out = torch.empty(B, NOUT, device=pre.device)
+    scratch = _fc_scratch_for(pre, _lib.load().hitadv_fc_layer_scratch_floats(B, K, NOUT))
+    _lib.call("hitadv_fc_layer_pre", _p(pre), T, J, _p(Wpre), _p(mask), _p(Wt), _p(bias), B, K, NOUT, 1 if relu else 0,
+              _p(out), _p(scratch), _stream())
+    return out
+
+
 def sum_partials(part, extra=None):
     """part [B,T,M] (+ extra [B,M]) -> [B,M], summed in ascending T."""
     B, T, M = part.shape
@@ -499,6 +515,14 @@ def pointnet_rowmlp_fwd(stage, B, N, W2, b2, o2, x=None, T=None, hin=None, W0=No
                         xp=None, o0=None, o1=None):
     _lib.call("hitadv_pointnet_rowmlp_fwd", stage, _p(x), _p(T), _p(hin), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2),
               _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, _stream())
+
+
+def pointnet_rowmlp_fwd_stn(B, N, x, F5, W6, b6, Tout, W0, b0, W1, b1, W2, b2, o0, o1, o2, xp=None):
+    """Stage 1 of the forward chain with STN3d's last layer (F5 [B,256] @ W6 [256,9] + b6 -> Tout [B,9]) evaluated inside."""
+    if F5.shape[1] != 256 or tuple(W6.shape) != (256, 9):
+        raise ValueError("the fused input transform is the 256 -> 9 layer")
+    _lib.call("hitadv_pointnet_rowmlp_fwd_stn", _p(x), _p(F5), _p(W6), _p(b6), _p(Tout), _p(W0), _p(b0), _p(W1), _p(b1),
+              _p(W2), _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, _stream())
 
 
 def pointnet_rowmlp_bwd(stage, B, N, dg, idx, W3r, A2, W2r, out, gmask=None, A1=None, W1r=None, H1=None, dH1in=None,

@@ -289,6 +289,12 @@ int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const 
                                const float *b0, const float *W1, const float *b1, const float *W2, const float *b2,
                                float *xp, float *o0, float *o1, float *o2, int B, int N, void *stream);
 /* Number of 64-point tiles per cloud = leading dimension of the dTpart scratch below. */
+/* Stage 1 with the input transform evaluated inside: T3[b] = F5[b,:256] @ W6[256,9] + b6 (STN3d's last layer, :186-190,
+ * the identity folded into b6) is computed by every block of the cloud (2304 multiply-adds, fixed order) and written to
+ * Tout [B,9] for the backward pass; everything else as hitadv_pointnet_rowmlp_fwd(stage = 1, T = Tout). */
+int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, const float *W6, const float *b6, float *Tout,
+                                   const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
+                                   const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N, void *stream);
 int64_t hitadv_pointnet_rowmlp_tiles(int N);
 /* Input-gradient chain of the same stages, starting at the max-pooled output of the stage's 128->Cout layer:
  * dg [B,Cout] is the gradient there, idx [B,Cout] the arg-max point of every channel (hitadv_linear_max_fwd),
@@ -321,6 +327,12 @@ int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int
 int hitadv_fc_layer(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K, int NOUT,
                     int relu, float *out, float *scratch, void *stream);
 int64_t hitadv_fc_layer_scratch_floats(int B, int K, int NOUT);
+/* The same layer with its input produced on the way in:  in[b,k] = sum_j (sum_t pre[b,t,j]) * Wpre[j,k]  (pre [B,T,J]
+ * partials summed in ascending t, Wpre [J,K], J <= 64), then gated by mask as above.  One launch for what would be three
+ * in the backward stacks: the sum over the tiles' dT partials, the stack's first layer (K = 9 or 40: fc3 of :186 / :91
+ * backwards) and its second.  Scratch as for hitadv_fc_layer(B,K,NOUT). */
+int hitadv_fc_layer_pre(const float *pre, int T, int J, const float *Wpre, const float *mask, const float *Wt,
+                        const float *bias, int B, int K, int NOUT, int relu, float *out, float *scratch, void *stream);
 
 /* ------------------------------------------------------------------ DGCNN victim: EdgeConv neighbour reduction
  * get_graph_feature + Conv2d(1x1) + BatchNorm2d + LeakyReLU + max over the k neighbours (model/dgcnn_cls.py:16-43,

@@ -740,6 +740,27 @@ def test_linear_max_fwd_bf16x3_is_fp32_accurate(A, B, Np, Cin, Cout):
     assert torch.equal(v3, val) and torch.equal(i3, idx)  # bitwise reproducible
 
 
+@pytest.mark.parametrize("B,T,J,K,NOUT", [(32, 1, 40, 256, 512), (32, 16, 9, 256, 512), (5, 3, 64, 200, 70), (33, 2, 7, 130, 33)])
+def test_fc_layer_with_its_input_evaluated_on_the_way_in(A, B, T, J, K, NOUT):
+    """hitadv_fc_layer_pre == sum_partials -> fc_layer -> fc_layer(mask) to fp32 rounding (the small product is summed in a
+    different order), against float64; bitwise reproducible."""
+    g = torch.Generator().manual_seed(B * 100 + J)
+    pre = torch.randn(B, T, J, generator=g)
+    Wpre = torch.randn(J, K, generator=g) * 0.3
+    Wt = torch.randn(K, NOUT, generator=g) * 0.1
+    mask = torch.randn(B, K, generator=g)
+    bias = torch.randn(NOUT, generator=g)
+    x64 = (pre.double().sum(1) @ Wpre.double()) * (mask > 0)
+    ref = (x64 @ Wt.double() + bias.double()).clamp_min(0.)
+    out = A.fc_layer_pre(cu(pre), cu(Wpre), cu(Wt), bias=cu(bias), relu=True, mask=cu(mask))
+    close(out, ref.float(), rtol=2e-5, atol=2e-5, what='fc_layer_pre vs float64')
+    three = A.fc_layer(A.fc_layer(A.sum_partials(cu(pre)), cu(Wpre)), cu(Wt), bias=cu(bias), relu=True, mask=cu(mask))
+    close(out, three, rtol=2e-5, atol=2e-5, what='fc_layer_pre vs the three launches')
+    assert torch.equal(out, A.fc_layer_pre(cu(pre), cu(Wpre), cu(Wt), bias=cu(bias), relu=True, mask=cu(mask)))
+    nomask = A.fc_layer_pre(cu(pre), cu(Wpre), cu(Wt))
+    close(nomask, (pre.double().sum(1) @ Wpre.double() @ Wt.double()).float(), rtol=2e-5, atol=2e-5)
+
+
 def test_linear_max_fwd_bf16x3_ties_keep_the_first_point(A):
     g = torch.Generator().manual_seed(3)
     B, Np, Cin, Cout = 2, 1024, 128, 256
