@@ -15,6 +15,8 @@
 //                       gated by (mask > 0): the same kernel is the backward of a ReLU'd FC layer.
 //
 // Weights: Wt = [Cin][Cout] (forward operand), Wr = [Cout][Cin] (backward operand); both are kept by the caller.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "hitadv.h"
 
@@ -820,7 +822,14 @@ __global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, 
 }
 
 static void fc_split(int B, int K, int NOUT, int *chunk, int *KS, int *tiles) {
-  int c = FC_CH * ((K + FC_CH * 32 - 1) / (FC_CH * 32));  // at most 32 K chunks per tile
+  // 128-deep chunks per block, measured at B = 32 (tools/fc_split_probe.py): K <= 256 runs without a split (no hand-off:
+  // 6.5 instead of 7.0 us), 512 and 1024 one chunk per block (two chunks: +1.0 .. +1.6 us), 4096 two (10.8 instead of
+  // 12.6 us: half the partials for the last block to add); never more than 32 splits per tile
+  int n = K <= 2 * FC_CH ? 2 : (K >= 16 * FC_CH ? 2 : 1);
+  while ((K + FC_CH * n - 1) / (FC_CH * n) > 32) ++n;
+  static const int force = [] { const char *e = getenv("HITADV_FC_CHUNKS"); return e ? atoi(e) : 0; }();  // tuning only
+  if (force > 0) n = force > n ? force : n;
+  int c = FC_CH * n;
   *chunk = c;
   *KS = (K + c - 1) / c;
   *tiles = ((NOUT + 31) / 32) * ((B + 31) / 32);
