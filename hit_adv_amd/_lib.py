@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhitadv_hip.so")
+# HITADV_LIBRARY: another build of the same library (diagnostic builds of tools/: stamped kernels, -DHITADV_PORTABLE_HANDOFF)
+LIB_PATH = os.environ.get("HITADV_LIBRARY") or os.path.join(_HERE, "libhitadv_hip.so")
 
 _c = ctypes
 _P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64

@@ -245,23 +245,21 @@ template <bool TWO>
 __device__ __forceinline__ void gather_rows(const int2 *list, int M, const float *__restrict__ Wc, int r, int h,
                                             f32x16 (&acc)[2]) {
   if (M <= 0) return;
-  int2 en[16];
-  float bv[16];
+  // Two register sets that swap roles every batch of 32 list entries: while one batch's 16 MFMAs run, the W3r rows of
+  // the next are in flight into the other set.  Batches go in PAIRS and every batch requests its successor
+  // unconditionally (the list carries 128 zero-gradient padding entries: they add exact zeros): a request under a
+  // condition, or a register copy from a "next" set into a "current" one, makes the compiler wait for the rows it has
+  // just requested before the MFMAs that do not need them.
+  int2 enA[16], enB[16];
+  float bvA[16], bvB[16];
+  auto request = [&](int2 (&en)[16], float (&bv)[16], int q) {
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    en[t] = list[2 * t + h];
-    bv[t] = Wc[(size_t)(en[t].x & 0xffff) * 128];
-  }
-  for (int q = 0; q < M; q += 32) {
-    int2 en2[16];
-    float bv2[16];
-    if (q + 32 < M) {  // the next 32 rows of W3r are requested before this batch's MFMAs start
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        en2[t] = list[q + 32 + 2 * t + h];
-        bv2[t] = Wc[(size_t)(en2[t].x & 0xffff) * 128];
-      }
+    for (int t = 0; t < 16; ++t) {
+      en[t] = list[q + 2 * t + h];
+      bv[t] = Wc[(size_t)(en[t].x & 0xffff) * 128];
     }
+  };
+  auto multiply = [&](const int2 (&en)[16], const float (&bv)[16]) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int i = en[t].x >> 16;
@@ -269,11 +267,13 @@ __device__ __forceinline__ void gather_rows(const int2 *list, int M, const float
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(i == r ? g : 0.f, bv[t], acc[0], 0, 0, 0);
       if (TWO) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(i == 32 + r ? g : 0.f, bv[t], acc[1], 0, 0, 0);
     }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      en[t] = en2[t];
-      bv[t] = bv2[t];
-    }
+  };
+  request(enA, bvA, 0);
+  for (int q = 0; q < M; q += 64) {
+    request(enB, bvB, q + 32);
+    multiply(enA, bvA);
+    request(enA, bvA, q + 64);
+    multiply(enB, bvB);
   }
 }
 
@@ -310,6 +310,25 @@ constexpr int BW_CH = 4;  // Cout <= 256 * BW_CH
 #endif
 constexpr bool BW_MFMA_GATHER = BW_MFMA_GATHER_DEFAULT;  // see the gather step of rowmlp_bwd_k
 
+// Diagnostic build only (-DHITADV_STAMPS, tools/v3_phases.py): wall-clock stamps (s_memrealtime, 10 ns) of the phases of
+// every block, read back through hitadv_debug_v3_stamps.  The product build has no stamp and no such symbol.
+#ifdef HITADV_STAMPS
+__device__ unsigned long long g_v3_stamp[3 * 1024 * 8];
+// stamps stay in registers until the block is done: a global store in front of a barrier would make the barrier wait for
+// every load in flight (release semantics) and change what is being measured
+#define V3_STAMP_DECL unsigned long long v3_st[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define V3_STAMP(i) v3_st[i] = __builtin_amdgcn_s_memrealtime()
+#define V3_STAMP_FLUSH()                                                                                      \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1024)                                       \
+      for (int i_ = 0; i_ < 8; ++i_) g_v3_stamp[(STAGE * 1024 + blockIdx.y * gridDim.x + blockIdx.x) * 8 + i_] = v3_st[i_]; \
+  } while (0)
+#else
+#define V3_STAMP_DECL
+#define V3_STAMP(i)
+#define V3_STAMP_FLUSH()
+#endif
+
 template <int STAGE>
 __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   // LDS footprint kept at 51 KB (sD + sE) so that blocks of other kernels fit beside two of these on a CU: the second
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   __shared__ unsigned long long s_present;  // points of this tile that receive any gradient
   __shared__ int s_rowmap[PM_TM];           // compact index -> point
   float *sD = reinterpret_cast<float *>(sD4), *sE = reinterpret_cast<float *>(sEF4), *sF = sD;
-  int2 *list = reinterpret_cast<int2 *>(sEF4);  // [256 * BW_CH + 32] (channel | point << 16, gradient bits); dead before sE is written
+  int2 *list = reinterpret_cast<int2 *>(sEF4);  // [256 * BW_CH + 128] (channel | point << 16, gradient bits); dead before sE is written
   const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, n0 = tile * PM_TM, N = a.N, Cout = a.Cout;
   const int rows = min(PM_TM, N - n0);
   const size_t row0 = (size_t)b * N + n0;
@@ -337,6 +356,8 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   const unsigned long long rowmask = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
   const unsigned long long incoming =
       (STAGE == 2 ? 0ull : (a.pres_in != nullptr ? a.pres_in[(size_t)b * ntiles + tile] : ~0ull)) & rowmask;
+  V3_STAMP_DECL;
+  V3_STAMP(0);
   if (threadIdx.x == 0) s_present = incoming;
   __syncthreads();
   // ---- the arg-max table of the cloud
@@ -370,6 +391,7 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
     rank[ch] = __popcll(m & ((1ull << lane) - 1ull));
   }
   __syncthreads();
+  V3_STAMP(1);
   const unsigned long long present = s_present;
   const int D = __popcll(present);
   const int R = (D + 31) >> 5;  // 32-row blocks of compacted points: 0, 1 or 2
@@ -402,8 +424,9 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
                                        __float_as_int(mg[ch]));
       M += s_cnt[ch][w];
     }
-  if (threadIdx.x < 32) list[M + threadIdx.x] = make_int2(0, 0);  // zero-gradient padding to a multiple of 32
+  if (threadIdx.x < 128) list[M + threadIdx.x] = make_int2(0, 0);  // zero-gradient padding: batches go in pairs and look one ahead
   __syncthreads();
+  V3_STAMP(2);
   // ---- gather on the matrix cores:  dA2[D,128] = S[D,M] @ W3r[list,:]  with S[i,k] = g_k if channel k routes to
   //      the i-th compacted point (one non-zero per column, built on the fly from the list).  Wave w owns columns
   //      32w..32w+31; K runs over the list in order -> a fixed fmaf chain per output, and a point that wins hundreds
@@ -445,6 +468,7 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
       }
     }
   }
+  V3_STAMP(3);
   // ---- everything the chain will need from global memory, requested while the gather's last MFMAs run (the gather
   //      itself wants the registers: 32 rows of W3r in flight per lane, double buffered).  Rows are the compacted ones.
   const bool act = rb < R;  // wave-uniform: this wave's 32-row block holds compacted points
@@ -485,6 +509,7 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
       }
   }
   __syncthreads();
+  V3_STAMP(4);
 #pragma unroll
   for (int u = 0; u < 8; ++u) {  // ReLU of the 64->128 layer
     const int e = threadIdx.x + 256 * u;
@@ -524,6 +549,7 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
     }
   }
   __syncthreads();
+  V3_STAMP(5);
   if (STAGE == 2) {  // sD is dead: it now takes the h1 rows (left operand of the transform gradient)
     stash_tile<64>(h1t, sF, PM_L64);
     __syncthreads();
@@ -553,6 +579,8 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
         if (i < D) a.out[(row0 + s_rowmap[i]) * 64 + 32 * cb + r] = acc[0][e];
       }
     }
+    V3_STAMP(7);
+    V3_STAMP_FLUSH();
     return;
   }
 
@@ -585,6 +613,7 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
     sG[i * 3 + c] = v;  // compacted row i
   }
   __syncthreads();
+  V3_STAMP(6);
   if (STAGE == 0) {
     if (wave < 3) {
       const int c = wave, n = lane;
@@ -613,6 +642,8 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
       a.dTpart[((size_t)b * ntiles + tile) * 9 + q] = v;
     }
   }
+  V3_STAMP(7);
+  V3_STAMP_FLUSH();
 }
 
 // out[b,m] = sum_t part[b,t,m] (+ extra[b,m]), ascending t.
@@ -895,6 +926,12 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
   HITADV_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef HITADV_STAMPS
+extern "C" int hitadv_debug_v3_stamps(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_v3_stamp), sizeof(unsigned long long) * (n < 3 * 1024 * 8 ? n : 3 * 1024 * 8));
+}
+#endif
 
 extern "C" int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out,
                                    void *stream) {
