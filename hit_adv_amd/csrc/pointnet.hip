@@ -363,15 +363,24 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   // ---- the arg-max table of the cloud
   int mn[BW_CH];
   float mg[BW_CH];
+  // (all loads of this kernel are unconditional, from addresses clamped into range, and what is out of range is dropped by
+  // a select afterwards: a load under a condition is compiled as a branch with its own wait, and a handful of such
+  // loads become as many dependent global round trips -- tools/v3_phases.py: 2.6 -> 1.x us for this table)
+  {
+    int64_t ti[BW_CH];
+    float tg[BW_CH], tm[BW_CH];
 #pragma unroll
-  for (int ch = 0; ch < BW_CH; ++ch) {
-    const int j = ch * 256 + threadIdx.x;
-    mn[ch] = -1;
-    mg[ch] = 0.f;
-    if (j < Cout) {
-      mn[ch] = (int)a.idx[(size_t)b * Cout + j] - n0;
-      mg[ch] = a.dg[(size_t)b * Cout + j];
-      if (a.gmask != nullptr) mg[ch] = a.gmask[(size_t)b * Cout + j] > 0.f ? mg[ch] : 0.f;
+    for (int ch = 0; ch < BW_CH; ++ch) {
+      const size_t o = (size_t)b * Cout + min(ch * 256 + (int)threadIdx.x, Cout - 1);
+      ti[ch] = a.idx[o];
+      tg[ch] = a.dg[o];
+      tm[ch] = a.gmask != nullptr ? a.gmask[o] : 1.f;  // block-uniform condition
+    }
+#pragma unroll
+    for (int ch = 0; ch < BW_CH; ++ch) {
+      const bool in = ch * 256 + (int)threadIdx.x < Cout;
+      mn[ch] = in ? (int)ti[ch] - n0 : -1;
+      mg[ch] = (in && tm[ch] > 0.f) ? tg[ch] : 0.f;
     }
   }
   if (STAGE == 1 && threadIdx.x < 192) {
@@ -479,15 +488,20 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   for (int e = 0; e < 16; ++e) {
     const int i = 32 * rb + acc_row(e, h);
     const bool in = act && i < D;
-    m1v[e] = (STAGE != 2 && in) ? a.A1[(row0 + s_rowmap[i]) * 64 + 32 * cb + r] : 0.f;
+    if (STAGE != 2) {
+      const float v = a.A1[(row0 + s_rowmap[min(i, D - 1)]) * 64 + 32 * cb + r];
+      m1v[e] = in ? v : 0.f;
+    } else {
+      m1v[e] = 0.f;
+    }
   }
   float4 a2[8];  // ReLU mask of the 64->128 layer, compacted rows
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int e = threadIdx.x + 256 * u;
     const int i = e >> 5;
-    a2[u] = i < D ? *reinterpret_cast<const float4 *>(a.A2 + (row0 + s_rowmap[i]) * 128 + 4 * (e & 31))
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = *reinterpret_cast<const float4 *>(a.A2 + (row0 + s_rowmap[min(i, D - 1)]) * 128 + 4 * (e & 31));
+    a2[u] = i < D ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float4 h1t[4];
   if (STAGE == 2) {
@@ -495,8 +509,8 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
     for (int u = 0; u < 4; ++u) {
       const int e = threadIdx.x + 256 * u;
       const int i = e >> 4;
-      h1t[u] = i < D ? *reinterpret_cast<const float4 *>(a.H1 + (row0 + s_rowmap[i]) * 64 + 4 * (e & 15))
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = *reinterpret_cast<const float4 *>(a.H1 + (row0 + s_rowmap[min(i, D - 1)]) * 64 + 4 * (e & 15));
+      h1t[u] = i < D ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   if (BW_MFMA_GATHER) {
@@ -532,10 +546,11 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
       for (int e = 0; e < 16; ++e) {
         const int i = 32 * rb + acc_row(e, h);
         const bool in = i < D;
-        const int p = in ? s_rowmap[i] : 0;
+        const int p = s_rowmap[min(i, D - 1)];
         const size_t o = (row0 + p) * 64 + 32 * cb + r;
-        mhv[e] = in ? a.H1[o] : 0.f;
-        dhv[e] = (in && ((incoming >> p) & 1ull)) ? a.dH1in[o] : 0.f;  // rows outside pres_in were never written
+        const float hv = a.H1[o], dv = a.dH1in[o];  // rows outside pres_in were never written: read, then dropped
+        mhv[e] = in ? hv : 0.f;
+        dhv[e] = (in && ((incoming >> p) & 1ull)) ? dv : 0.f;
       }
     }
     f32x16 acc[1];
