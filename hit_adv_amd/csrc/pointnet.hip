@@ -329,8 +329,11 @@ __device__ unsigned long long g_v3_stamp[3 * 1024 * 8];
 #define V3_STAMP_FLUSH()
 #endif
 
+// Registers: stage 1 holds the most masks and incoming gradients at once; at three blocks per CU (168 registers) it spills,
+// and a spill is a scratch access behind the same counter as the loads it was meant to overlap.  Two blocks per CU is what
+// a 16-tile x 32-cloud grid puts on a CU anyway.
 template <int STAGE>
-__global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
+__global__ __launch_bounds__(256, STAGE == 1 ? 2 : 3) void rowmlp_bwd_k(RowMlpBwd a) {
   // LDS footprint kept at 51 KB (sD + sE) so that blocks of other kernels fit beside two of these on a CU: the second
   // 64-wide tile (sF) reuses sD, which is dead once every wave has finished the 128-deep product
   __shared__ float4 sD4[PM_TM * PM_L128 / 4], sEF4[PM_TM * PM_L64 / 4];
@@ -363,9 +366,10 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
   // ---- the arg-max table of the cloud
   int mn[BW_CH];
   float mg[BW_CH];
-  // (all loads of this kernel are unconditional, from addresses clamped into range, and what is out of range is dropped by
-  // a select afterwards: a load under a condition is compiled as a branch with its own wait, and a handful of such
-  // loads become as many dependent global round trips -- tools/v3_phases.py: 2.6 -> 1.x us for this table)
+  // (all loads of this kernel are unconditional, from addresses clamped into range: a load under a condition -- or one
+  // whose only use is a select, which the optimiser turns back into a load under a condition -- is compiled as a branch
+  // with its own wait, and a handful of them become as many dependent global round trips (tools/v3_phases.py).  Compacted
+  // rows D..32R-1 therefore carry the masks of row D-1: they multiply rows of the gradient tile that are exact zeros.)
   {
     int64_t ti[BW_CH];
     float tg[BW_CH], tm[BW_CH];
@@ -374,13 +378,14 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
       const size_t o = (size_t)b * Cout + min(ch * 256 + (int)threadIdx.x, Cout - 1);
       ti[ch] = a.idx[o];
       tg[ch] = a.dg[o];
-      tm[ch] = a.gmask != nullptr ? a.gmask[o] : 1.f;  // block-uniform condition
+      tm[ch] = (a.gmask != nullptr ? a.gmask : a.dg)[o];  // a pointer select, not a load under a condition
     }
+    const bool gated = a.gmask != nullptr;
 #pragma unroll
     for (int ch = 0; ch < BW_CH; ++ch) {
       const bool in = ch * 256 + (int)threadIdx.x < Cout;
       mn[ch] = in ? (int)ti[ch] - n0 : -1;
-      mg[ch] = (in && tm[ch] > 0.f) ? tg[ch] : 0.f;
+      mg[ch] = (in && (!gated || tm[ch] > 0.f)) ? tg[ch] : 0.f;
     }
   }
   if (STAGE == 1 && threadIdx.x < 192) {
@@ -487,21 +492,14 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int i = 32 * rb + acc_row(e, h);
-    const bool in = act && i < D;
-    if (STAGE != 2) {
-      const float v = a.A1[(row0 + s_rowmap[min(i, D - 1)]) * 64 + 32 * cb + r];
-      m1v[e] = in ? v : 0.f;
-    } else {
-      m1v[e] = 0.f;
-    }
+    m1v[e] = STAGE != 2 ? a.A1[(row0 + s_rowmap[min(i, D - 1)]) * 64 + 32 * cb + r] : 0.f;
   }
   float4 a2[8];  // ReLU mask of the 64->128 layer, compacted rows
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int e = threadIdx.x + 256 * u;
     const int i = e >> 5;
-    const float4 v = *reinterpret_cast<const float4 *>(a.A2 + (row0 + s_rowmap[min(i, D - 1)]) * 128 + 4 * (e & 31));
-    a2[u] = i < D ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    a2[u] = *reinterpret_cast<const float4 *>(a.A2 + (row0 + s_rowmap[min(i, D - 1)]) * 128 + 4 * (e & 31));
   }
   float4 h1t[4];
   if (STAGE == 2) {
@@ -509,8 +507,7 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
     for (int u = 0; u < 4; ++u) {
       const int e = threadIdx.x + 256 * u;
       const int i = e >> 4;
-      const float4 v = *reinterpret_cast<const float4 *>(a.H1 + (row0 + s_rowmap[min(i, D - 1)]) * 64 + 4 * (e & 15));
-      h1t[u] = i < D ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      h1t[u] = *reinterpret_cast<const float4 *>(a.H1 + (row0 + s_rowmap[min(i, D - 1)]) * 64 + 4 * (e & 15));
     }
   }
   if (BW_MFMA_GATHER) {
@@ -545,6 +542,8 @@ __global__ __launch_bounds__(256, 3) void rowmlp_bwd_k(RowMlpBwd a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = 32 * rb + acc_row(e, h);
+        // (these two stay loads under a condition on purpose: only the D compacted rows are fetched, and fetching all 32
+        // measured slower -- tools/v3_phases.py, stage 1: 6.3 instead of 3.9 us for this phase)
         const bool in = i < D;
         const int p = s_rowmap[min(i, D - 1)];
         const size_t o = (row0 + p) * 64 + 32 * cb + r;
@@ -718,7 +717,19 @@ __global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, 
   // where they are used): this wave's 32 rows of Wt and, PRE, its column of Wpre and the mask values of its output slots
   constexpr int PS = PRE > 0 ? PRE : 1;
   float wv[16], bq[PS], mk[16], av[PS];
+  float4 si[4], sm[4];  // plain form, K % 4 == 0: the thread's four float4 of the input chunk and of its mask
+  const bool vec = !PRE && (K & 3) == 0;
+  const float *mp = mask != nullptr ? mask : in;  // a pointer select, so that the mask load is not under a condition
   auto issue = [&](int kc) {
+    if (vec) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const size_t o = (size_t)min(row0 + (e >> 5), B - 1) * K + min(kc + 4 * (e & 31), K - 4);
+        si[u] = *reinterpret_cast<const float4 *>(in + o);
+        sm[u] = *reinterpret_cast<const float4 *>(mp + o);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int k = kc + 32 * wave + kmap(t, h);
@@ -786,16 +797,13 @@ __global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, 
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int e = threadIdx.x + 256 * u, rr = e >> 5, k = kc + 4 * (e & 31);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + rr < B && k < kb1) {
-          const size_t o = (size_t)(row0 + rr) * K + k;
-          v = *reinterpret_cast<const float4 *>(in + o);
-          if (mask != nullptr) {
-            const float4 g = *reinterpret_cast<const float4 *>(mask + o);
-            v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
-            v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
-          }
-        }
+        const bool ok = row0 + rr < B && k < kb1, gated = mask != nullptr;
+        const float4 x = si[u], g = sm[u];
+        float4 v;
+        v.x = (ok && (!gated || g.x > 0.f)) ? x.x : 0.f;
+        v.y = (ok && (!gated || g.y > 0.f)) ? x.y : 0.f;
+        v.z = (ok && (!gated || g.z > 0.f)) ? x.z : 0.f;
+        v.w = (ok && (!gated || g.w > 0.f)) ? x.w : 0.f;
         *reinterpret_cast<float4 *>(sA + rr * FC_LD + 4 * (e & 31)) = v;
       }
     } else {
