@@ -30,13 +30,36 @@ __global__ __launch_bounds__(256) void iteration_head_k(
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // transformation_loss(batch_avg=False): (|P_b|_F + |1 - sigma_b|_2) / C   -- as best_update_k
+  // Everything the block reads is requested before anything is used: a load inside a loop whose trip count the compiler
+  // does not know, or under a condition, is a dependent global round trip of its own (this kernel had about ten of them
+  // in a row).  Out-of-range slots read a clamped address and enter the sums multiplied by an exact 0.
   float a1 = 0.f, a2 = 0.f;
   const float *pp = perturb + (size_t)b * C * 3;
-  for (int e = threadIdx.x; e < C * 3; e += 256) a1 = fmaf(pp[e], pp[e], a1);
   const float *sp = sigma + (size_t)b * C;
-  for (int e = threadIdx.x; e < C; e += 256) {
-    const float t = 1.0f - sp[e];
-    a2 = fmaf(t, t, a2);
+  const float *z = logits + (size_t)b * num_class;
+  const float z_lane = z[min(lane, num_class - 1)];            // waves 0 and 1: the row, when it fits a wave
+  const int64_t lab = label[b];
+  const float bd0 = bestdist[b], obd0 = o_bestdist[b];
+  for (int e0 = 0; e0 < C * 3; e0 += 1024) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = pp[min(e0 + (int)threadIdx.x + 256 * u, C * 3 - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float w = e0 + (int)threadIdx.x + 256 * u < C * 3 ? 1.0f : 0.0f;
+      a1 = fmaf(v[u] * w, v[u], a1);  // the same fmaf chain in the same order as a plain strided loop
+    }
+  }
+  for (int e0 = 0; e0 < C; e0 += 1024) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = sp[min(e0 + (int)threadIdx.x + 256 * u, C - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float w = e0 + (int)threadIdx.x + 256 * u < C ? 1.0f : 0.0f;
+      const float t = (1.0f - v[u]) * w;
+      a2 = fmaf(t, t, a2);
+    }
   }
   a1 = wave_sum(a1);
   a2 = wave_sum(a2);
@@ -44,41 +67,46 @@ __global__ __launch_bounds__(256) void iteration_head_k(
     s1[wave] = a1;
     s2[wave] = a2;
   }
-  const float *z = logits + (size_t)b * num_class;
+  const bool row_in_wave = num_class <= 64;  // block-uniform
   unsigned long long key = 0ull;
   if (wave == 0) {  // argmax over the logits, lowest index on ties
     for (int c = lane; c < num_class; c += 64) {
-      const unsigned long long k = ((unsigned long long)ordered_bits_i(z[c]) << 32) | (0xFFFFFFFFu - (uint32_t)c);
+      const float zc = row_in_wave ? z_lane : z[c];
+      const unsigned long long k = ((unsigned long long)ordered_bits_i(zc) << 32) | (0xFFFFFFFFu - (uint32_t)c);
       key = k > key ? k : key;
     }
     key = wave_max_u64(key);
   } else if (wave == 1) {  // adversarial loss row of this cloud -- as adv_loss_k
     float *d = dlogits + (size_t)b * num_class;
-    const int t = (int)label[b];
+    const int t = (int)lab;
     const float invB = 1.0f / (float)B;
+    // z[j] for the lane's own j comes from the register; z[o] / z[t] by a lane read of it
+    auto zat = [&](int j) { return row_in_wave ? __shfl(z_lane, j, HITADV_WAVE) : z[j]; };
+    auto zown = [&](int j) { return row_in_wave ? z_lane : z[j]; };
     float mine;
     if (kind == 2) {
       float mx = -__builtin_inff();
-      for (int j = lane; j < num_class; j += 64) mx = fmaxf(mx, z[j]);
+      for (int j = lane; j < num_class; j += 64) mx = fmaxf(mx, zown(j));
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, HITADV_WAVE));
       float se = 0.f;
-      for (int j = lane; j < num_class; j += 64) se += __expf(z[j] - mx);
+      for (int j = lane; j < num_class; j += 64) se += __expf(zown(j) - mx);
       se = wave_sum(se);
       const float lse = mx + __logf(se);
-      for (int j = lane; j < num_class; j += 64) d[j] = (__expf(z[j] - lse) - (j == t ? 1.0f : 0.f)) * invB;
-      mine = lse - z[t];
+      for (int j = lane; j < num_class; j += 64) d[j] = (__expf(zown(j) - lse) - (j == t ? 1.0f : 0.f)) * invB;
+      mine = lse - zat(t);
     } else {
       unsigned long long k2 = 0ull;
       for (int j = lane; j < num_class; j += 64) {
-        const float v = j == t ? -10000.f : z[j];
+        const float v = j == t ? -10000.f : zown(j);
         const unsigned long long k = ((unsigned long long)ordered_bits_i(v) << 32) | (0xFFFFFFFFu - (uint32_t)j);
         k2 = k > k2 ? k : k2;
       }
       k2 = wave_max_u64(k2);
       const int o = (int)(0xFFFFFFFFu - (uint32_t)(k2 & 0xffffffffu));
-      const float other = o == t ? -10000.f : z[o];
-      const float margin = kind == 0 ? (z[t] - other) + kappa : (other - z[t]) + kappa;
+      const float zo = zat(o), zt = zat(t);
+      const float other = o == t ? -10000.f : zo;
+      const float margin = kind == 0 ? (zt - other) + kappa : (other - zt) + kappa;
       const bool on = margin >= 0.f;  // torch's clamp(min=0) passes the gradient at the boundary
       const float s = on ? (kind == 0 ? invB : -invB) : 0.f;
       for (int j = lane; j < num_class; j += 64) d[j] = (j == t ? s : 0.f) - ((j == o && o != t) ? s : 0.f);
@@ -94,12 +122,12 @@ __global__ __launch_bounds__(256) void iteration_head_k(
     pred_out[b] = pred;
     dist_val_out[b] = dv;
     int copy = 0;
-    if (pred != label[b]) {
-      if (dv < bestdist[b]) {
+    if (pred != lab) {
+      if (dv < bd0) {
         bestdist[b] = dv;
         bestscore[b] = pred;
       }
-      if (dv < o_bestdist[b]) {
+      if (dv < obd0) {
         o_bestdist[b] = dv;
         o_bestscore[b] = pred;
         copy = 1;
@@ -137,36 +165,50 @@ __global__ __launch_bounds__(256) void adam_partials_k(float *__restrict__ P, fl
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= B * C) return;
   const int b = e / C, j = e % C;
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < nslab; ++s) {
-    const float *p = partials + (((size_t)b * nslab + s) * 4) * C + j;
-    g[0] += p[0];
-    g[1] += p[C];
-    g[2] += p[2 * C];
-    g[3] += p[3 * C];
-  }
+  // the state the update needs is requested first, then the slab partials eight slabs at a time (32 loads in flight,
+  // added in ascending slab order): one round trip each instead of one per slab and per state word
   const int t = *step;
+  float m0[4], v0[4], p0[4], h0[4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t i = (size_t)e * 3 + c;
+    m0[c] = mP[i]; v0[c] = vP[i]; p0[c] = P[i];
+    h0[c] = (hP ? hP : P)[i];  // a pointer select: no load under a condition
+  }
+  m0[3] = mS[e]; v0[3] = vS[e]; p0[3] = S[e];
+  h0[3] = (hS ? hS : S)[e];
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < nslab; s0 += 8) {
+    float q[8][4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float *p = partials + (((size_t)b * nslab + min(s0 + s, nslab - 1)) * 4) * C + j;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) q[s][c] = p[c * C];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g[c] += s0 + s < nslab ? q[s][c] : 0.f;
+  }
   const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
   const double bc1 = 1.0 - pow(beta1, (double)t);
   const double bc2 = 1.0 - pow(beta2, (double)t);
   const float bc2_sqrt = (float)sqrt(bc2);
-  auto upd = [&](float *p, float *m, float *v, size_t i, float gi, double lr, float lo, float hi) {
+  auto upd = [&](float *p, float *m, float *v, size_t i, int c, float gi, double lr, float lo, float hi) {
     const float step_size = (float)(lr / bc1);
-    const float mi = m[i] + (gi - m[i]) * (float)(1.0 - beta1);
-    const float vi = v[i] * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
+    const float mi = m0[c] + (gi - m0[c]) * (float)(1.0 - beta1);
+    const float vi = v0[c] * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
     m[i] = mi;
     v[i] = vi;
     const float denom = __builtin_sqrtf(vi) / bc2_sqrt + (float)eps;
-    float q = p[i] - (step_size * mi) / denom;
+    float q = p0[c] - (step_size * mi) / denom;
     if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);
     p[i] = q;
   };
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const size_t i = (size_t)e * 3 + c;
-    upd(P, mP, vP, i, hP ? g[c] + hP[i] : g[c], (double)lrP, loP, hiP);
-  }
-  upd(S, mS, vS, (size_t)e, hS ? g[3] + hS[e] : g[3], (double)lrS, loS, hiS);
+  for (int c = 0; c < 3; ++c) upd(P, mP, vP, (size_t)e * 3 + c, c, hP ? g[c] + h0[c] : g[c], (double)lrP, loP, hiP);
+  upd(S, mS, vS, (size_t)e, 3, hS ? g[3] + h0[3] : g[3], (double)lrS, loS, hiS);
 }
 
 }  // namespace hitadv
