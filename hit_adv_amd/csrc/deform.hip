@@ -100,6 +100,15 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
   const int b = blockIdx.z, slab = blockIdx.y;
   const int n0 = slab * DB_PTS;
   const int cnt = min(DB_PTS, N - n0);
+  // the thread's centre is requested together with the slab's points, not after the barrier behind them (one global round
+  // trip instead of two); threads past C read centre C-1 and leave before they would write
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int jc = min(j, C - 1);
+  const float *cp = central + (size_t)b * 3 * C + jc;
+  const float cx = cp[0], cy = cp[C], cz = cp[2 * C];
+  const float *pp = perturb + ((size_t)b * C + jc) * 3;
+  const float px = pp[0], py = pp[1], pz = pp[2];
+  const float s = sigma[(size_t)b * C + jc];
   if (threadIdx.x < DB_PTS) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), g = a;
     if (threadIdx.x < cnt) {
@@ -118,13 +127,7 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
     sg[threadIdx.x] = g;
   }
   __syncthreads();
-  const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= C) return;
-  const float *cp = central + (size_t)b * 3 * C + j;
-  const float cx = cp[0], cy = cp[C], cz = cp[2 * C];
-  const float *pp = perturb + ((size_t)b * C + j) * 3;
-  const float px = pp[0], py = pp[1], pz = pp[2];
-  const float s = sigma[(size_t)b * C + j];
   const float a2 = -LOG2E / (2.0f * s * s);
   float apx = 0.f, apy = 0.f, apz = 0.f, asg = 0.f;
 #pragma unroll 4

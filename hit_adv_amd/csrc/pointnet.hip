@@ -668,8 +668,15 @@ __global__ __launch_bounds__(256) void sum_partials_k(const float *__restrict__ 
   const long long b = e / M;
   const int m = (int)(e % M);
   const float *p = part + (size_t)b * T * M + m;
-  float v = extra ? extra[e] : 0.f;
-  for (int t = 0; t < T; ++t) v += p[(size_t)t * M];
+  const float x = (extra ? extra : part)[extra ? e : 0];  // requested with the partials, not before them
+  float v = extra ? x : 0.f;
+  for (int t0 = 0; t0 < T; t0 += 16) {  // sixteen partials in flight, added in ascending t
+    float q[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) q[t] = p[(size_t)min(t0 + t, T - 1) * M];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v += t0 + t < T ? q[t] : 0.f;
+  }
   out[e] = v;
 }
 

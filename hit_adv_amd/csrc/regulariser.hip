@@ -42,54 +42,83 @@ __global__ __launch_bounds__(256) void reg_partials(const float *__restrict__ P,
                                                     const float *__restrict__ hide_ref, int N, int C, float min_s,
                                                     float inv_range, float *part, RegFin fin, int fused) {
   __shared__ float sm[4];
+  __shared__ float sw[4][14];
   __shared__ int s_last;
   const int b = blockIdx.x;
+  // Loads are requested in batches ahead of their use (up to four strided slots per thread at a time; a slot past the end
+  // reads a clamped address and enters the sums multiplied by an exact 0): a load inside a loop of unknown trip count is a
+  // global round trip per trip.  The sums themselves keep the order of the plain strided loops.
   float a = 0.f;
-  for (int e = threadIdx.x; e < C * 3; e += 256) {
-    const float p = P[(size_t)b * C * 3 + e];
-    a = fmaf(p, p, a);
+  for (int e0 = 0; e0 < C * 3; e0 += 1024) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = P[(size_t)b * C * 3 + min(e0 + (int)threadIdx.x + 256 * u, C * 3 - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a = fmaf(v[u] * (e0 + (int)threadIdx.x + 256 * u < C * 3 ? 1.0f : 0.0f), v[u], a);
   }
   float s2 = 0.f, dot = 0.f, rr = 0.f, nn = 0.f;
-  for (int e = threadIdx.x; e < C; e += 256) {
-    const float s = sigma[(size_t)b * C + e];
-    const float t = 1.0f - s;
-    s2 = fmaf(t, t, s2);
-    const float n = (s - min_s) * inv_range;
-    const float r = hide_ref[(size_t)b * C + e];
-    dot = fmaf(r, n, dot);
-    rr = fmaf(r, r, rr);
-    nn = fmaf(n, n, nn);
+  for (int e0 = 0; e0 < C; e0 += 1024) {
+    float sv[4], rv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t o = (size_t)b * C + min(e0 + (int)threadIdx.x + 256 * u, C - 1);
+      sv[u] = sigma[o];
+      rv[u] = hide_ref[o];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float w = e0 + (int)threadIdx.x + 256 * u < C ? 1.0f : 0.0f;
+      const float t = (1.0f - sv[u]) * w;
+      s2 = fmaf(t, t, s2);
+      const float n = ((sv[u] - min_s) * inv_range) * w;
+      const float r = rv[u] * w;
+      dot = fmaf(r, n, dot);
+      rr = fmaf(r, r, rr);
+      nn = fmaf(n, n, nn);
+    }
   }
   float d[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) d[k] = 0.f;
   const float *ap = adv + (size_t)b * 3 * N, *op = ori + (size_t)b * 3 * N;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float a0 = ap[n], a1 = ap[N + n], a2 = ap[2 * N + n];
-    const float o0 = op[n], o1 = op[N + n], o2 = op[2 * N + n];
-    float t;
-    t = a0 - o0; d[0] = fmaf(t, t, d[0]);
-    t = a0 - o1; d[1] = fmaf(t, t, d[1]);
-    t = a0 - o2; d[2] = fmaf(t, t, d[2]);
-    t = a1 - o0; d[3] = fmaf(t, t, d[3]);
-    t = a1 - o1; d[4] = fmaf(t, t, d[4]);
-    t = a1 - o2; d[5] = fmaf(t, t, d[5]);
-    t = a2 - o0; d[6] = fmaf(t, t, d[6]);
-    t = a2 - o1; d[7] = fmaf(t, t, d[7]);
-    t = a2 - o2; d[8] = fmaf(t, t, d[8]);
+  for (int n0 = 0; n0 < N; n0 += 1024) {
+    float av[4][3], ov[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = min(n0 + (int)threadIdx.x + 256 * u, N - 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        av[u][c] = ap[c * N + n];
+        ov[u][c] = op[c * N + n];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float w = n0 + (int)threadIdx.x + 256 * u < N ? 1.0f : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float t = (av[u][i] - ov[u][j]) * w;
+          d[3 * i + j] = fmaf(t, t, d[3 * i + j]);
+        }
+    }
   }
-  float out[14];
-  out[0] = block_sum(a, sm);
-  out[1] = block_sum(s2, sm);
-  out[2] = block_sum(dot, sm);
-  out[3] = block_sum(rr, sm);
-  out[4] = block_sum(nn, sm);
+  // the fourteen block sums in one pass: a wave sum each, one barrier, then the four waves in block_sum's order
+  float out[14] = {a, s2, dot, rr, nn, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8]};
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) out[5 + k] = block_sum(d[k], sm);
-  if (threadIdx.x == 0) {
-    float *o = part + (size_t)b * RG_NPART;
-#pragma unroll
-    for (int k = 0; k < 14; ++k) __hip_atomic_store(&o[k], out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < 14; ++k) {
+      const float v = wave_sum(out[k]);
+      if (lane == 0) sw[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 14) {
+      const int k = threadIdx.x;
+      __hip_atomic_store(&part[(size_t)b * RG_NPART + k], (sw[0][k] + sw[1][k]) + (sw[2][k] + sw[3][k]), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (!fused) return;
   int *ticket = reinterpret_cast<int *>(fin.scal + 7);
@@ -131,11 +160,23 @@ __device__ void reg_finalise_body(const float *part, const float *__restrict__ s
     pc[2] = 1.0f / (nn * nn);
     sk += scale_const[b];
   }
-  sp = block_sum(sp, sm);
-  ss = block_sum(ss, sm);
-  sq = block_sum(sq, sm);
-  sc = block_sum(sc, sm);
-  sk = block_sum(sk, sm);
+  {  // the five block sums in one pass (block_sum's order: a wave sum each, then (w0 + w1) + (w2 + w3))
+    __shared__ float sw5[4][5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float v5[5] = {sp, ss, sq, sc, sk};
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float v = wave_sum(v5[k]);
+      if (lane == 0) sw5[wave][k] = v;
+    }
+    __syncthreads();
+    sp = (sw5[0][0] + sw5[1][0]) + (sw5[2][0] + sw5[3][0]);
+    ss = (sw5[0][1] + sw5[1][1]) + (sw5[2][1] + sw5[3][1]);
+    sq = (sw5[0][2] + sw5[1][2]) + (sw5[2][2] + sw5[3][2]);
+    sc = (sw5[0][3] + sw5[1][3]) + (sw5[2][3] + sw5[3][3]);
+    sk = (sw5[0][4] + sw5[1][4]) + (sw5[2][4] + sw5[3][4]);
+  }
   if (threadIdx.x == 0) {
     const float np = __builtin_sqrtf(sp), ns = __builtin_sqrtf(ss);
     float dist = 0.f;
