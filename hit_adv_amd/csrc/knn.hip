@@ -152,6 +152,22 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
   }
 }
 
+// Two references at a time on the packed-f32 VALU (v_pk_add / v_pk_mul / v_pk_fma: two IEEE fp32 results per instruction,
+// each rounded exactly as the scalar instruction would): the expression and its rounding points are those of pair_dist.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int FORM>
+__device__ __forceinline__ f32x2 pair_dist2(float qx, float qy, float qz, float rq, f32x2 px, f32x2 py, f32x2 pz, f32x2 rp) {
+  const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+  if (FORM == 0) {
+    const f32x2 dx = qx2 - px, dy = qy2 - py, dz = qz2 - pz;
+    return (dx * dx + dy * dy) + dz * dz;
+  }
+  const f32x2 zz = __builtin_elementwise_fma(qz2, pz, __builtin_elementwise_fma(qy2, py, qx2 * px));
+  const f32x2 m2 = {-2.0f, -2.0f}, rq2 = {rq, rq};
+  if (FORM == 1) return __builtin_elementwise_fma(m2, zz, rq2 + rp);
+  return __builtin_elementwise_fma(m2, zz, rp) + rq2;
+}
+
 // ------------------------------------------------------------------------------------ K4 (K <= 32, M <= 2048)
 // Why not a sorted (distance, index) insertion list: its body (4 VALU instructions per slot) is executed by the whole wave
 // whenever ANY of the 64 lanes accepts a candidate, which for K >= 5 is at almost every reference -- the r01 kernel spent
@@ -181,7 +197,11 @@ __global__ __launch_bounds__(NW * 64) void knn_select(const float *__restrict__ 
   constexpr int CAP = ks_cap(KB, NW);
   static_assert(CAP >= 2 * KB + 3, "a compaction must leave room for one group of four candidates");
   extern __shared__ __attribute__((aligned(16))) char ks_smem[];
-  const int Mpad = (M + 3) & ~3;
+  // references live in LDS as PAIRS: sref[2 m] = (x0, x1, y0, y1), sref[2 m + 1] = (z0, z1, n0, n1) of references 2 m, 2 m + 1
+  // (n = |p|^2 in the kernel's form).  Every wave's range is a multiple of 4 references; the slots past M hold a sentinel
+  // whose distance to anything is +inf, so the scan needs no bounds test: +inf is never below a threshold.
+  const int per = (((M + NW - 1) / NW) + 3) & ~3;
+  const int Mpad = per * NW;
   float4 *sref = reinterpret_cast<float4 *>(ks_smem);                                       // [Mpad]
   unsigned short *slog = reinterpret_cast<unsigned short *>(ks_smem + (size_t)Mpad * 16);   // [NW][CAP][64]
   float *md = reinterpret_cast<float *>(ks_smem + (size_t)Mpad * 16);                       // after the scan: [NW][KB][64]
@@ -194,9 +214,20 @@ __global__ __launch_bounds__(NW * 64) void knn_select(const float *__restrict__ 
   const float qx = qp[0], qy = qp[1], qz = qp[2];
   const float rq = sq_norm<FORM>(qx, qy, qz);
   p += (size_t)b * M * 3;
-  for (int r = threadIdx.x; r < M; r += NW * 64) {
-    const float *s = p + (size_t)r * 3;
-    sref[r] = make_float4(s[0], s[1], s[2], sq_norm<FORM>(s[0], s[1], s[2]));
+  {
+    float *sf = reinterpret_cast<float *>(sref);
+    for (int r = threadIdx.x; r < Mpad; r += NW * 64) {
+      const float *s = p + (size_t)min(r, M - 1) * 3;
+      const bool in = r < M;
+      // sentinel: direct form x = +inf (dx * dx = +inf); Gram forms p = 0, |p|^2 = +inf
+      const float x = in ? s[0] : (FORM == 0 ? __builtin_inff() : 0.f), y = in ? s[1] : 0.f, z = in ? s[2] : 0.f;
+      const float n = in ? sq_norm<FORM>(x, y, z) : __builtin_inff();
+      float *o = sf + (size_t)(r >> 1) * 8 + (r & 1);
+      o[0] = x;
+      o[2] = y;
+      o[4] = z;
+      o[6] = n;
+    }
   }
   __syncthreads();
   float L[KB];
@@ -206,20 +237,27 @@ __global__ __launch_bounds__(NW * 64) void knn_select(const float *__restrict__ 
     L[t] = __builtin_inff();
     I[t] = 0x7fffffff;
   }
-  const int per = (M + NW - 1) / NW;
-  const int lo = wave * per, hi = min(lo + per, M);
-  auto dist_of = [&](int j) {
-    const float4 v = sref[j];
-    return pair_dist<FORM>(qx, qy, qz, rq, v.x, v.y, v.z, v.w);
+  const int lo = wave * per, hi = lo + per;  // a multiple of 4 references, sentinels included
+  auto dist_of = [&](int j) {  // one reference (compaction, slot matching): the same expression, scalar
+    const float *o = reinterpret_cast<const float *>(sref) + (size_t)(j >> 1) * 8 + (j & 1);
+    return pair_dist<FORM>(qx, qy, qz, rq, o[0], o[2], o[4], o[6]);
+  };
+  auto dist4 = [&](int r0, float (&c)[4]) {  // references r0 .. r0 + 3 (r0 % 4 == 0)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float4 a = sref[r0 + 2 * u], bq = sref[r0 + 2 * u + 1];
+      const f32x2 d = pair_dist2<FORM>(qx, qy, qz, rq, f32x2{a.x, a.y}, f32x2{a.z, a.w}, f32x2{bq.x, bq.y}, f32x2{bq.z, bq.w});
+      c[2 * u] = d.x;
+      c[2 * u + 1] = d.y;
+    }
   };
   if (KB == 1) {  // nearest neighbour: the index rides along (strict <, ascending scan: lowest index on ties)
     for (int r0 = lo; r0 < hi; r0 += 4) {
       float c[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) c[u] = dist_of(min(r0 + u, hi - 1));
+      dist4(r0, c);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const bool acc = r0 + u < hi && c[u] < L[0];
+        const bool acc = c[u] < L[0];
         L[0] = acc ? c[u] : L[0];
         I[0] = acc ? r0 + u : I[0];
       }
@@ -256,21 +294,19 @@ __global__ __launch_bounds__(NW * 64) void knn_select(const float *__restrict__ 
     for (int r0 = lo; r0 < hi; r0 += 4) {
       // four independent distance chains first (their LDS reads are in flight before the first log store) ...
       float c[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) c[u] = dist_of(min(r0 + u, hi - 1));
+      dist4(r0, c);
       if (__builtin_amdgcn_ballot_w64(cnt > CAP - 4)) compact();  // room for this group in every lane's log
       // ... then the four insertions: a branch-free median chain on the distances, a masked 2-byte store of the index
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const bool acc = r0 + u < hi && c[u] < L[KB - 1];
-        const float cu = r0 + u < hi ? c[u] : __builtin_inff();
+        const bool acc = c[u] < L[KB - 1];
+        const float cu = c[u];
 #pragma unroll
         for (int t = KB - 1; t > 0; --t) L[t] = __builtin_amdgcn_fmed3f(L[t - 1], cu, L[t]);
         L[0] = __builtin_amdgcn_fmed3f(-__builtin_inff(), cu, L[0]);  // = min(c, L[0]) in one instruction
-        if (acc) {
-          mylog[cnt * 64] = (unsigned short)(r0 + u);
-          ++cnt;
-        }
+        // the index goes to the log's next slot whatever happens (no exec-mask juggling); an acceptance claims the slot
+        mylog[cnt * 64] = (unsigned short)(r0 + u);
+        cnt += acc ? 1 : 0;
       }
     }
     // the survivors, matched to their slots (entries of equal distance fill equal slots in log = index order)
@@ -503,13 +539,13 @@ template <int FORM, int NW>
 static int launch_knn_select(const float *q, const float *p, int B, int N, int M, int K, float *dists, void *idx,
                              int idx_is_i64, hipStream_t s) {
   dim3 grid((N + 63) / 64, B);
-  const size_t refs = (size_t)((M + 3) & ~3) * 16;
+  const size_t refs = (size_t)((((M + NW - 1) / NW + 3) & ~3) * NW) * 16;  // every wave's range padded to a multiple of 4
 #define HITADV_KS_CASE(KB)                                                                                     \
   if (K <= KB) {                                                                                               \
     const size_t shm = refs + ks_union_bytes(KB, NW);                                                          \
     static int raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_select<KB, FORM, NW>),         \
                                             hipFuncAttributeMaxDynamicSharedMemorySize,                        \
-                                            32768 + (int)ks_union_bytes(KB, NW));                              \
+                                            32768 + 512 + (int)ks_union_bytes(KB, NW));                              \
     (void)raised;                                                                                              \
     knn_select<KB, FORM, NW><<<grid, NW * 64, shm, s>>>(q, p, N, M, K, dists, idx, idx_is_i64);                \
     return 0;                                                                                                  \
