@@ -144,11 +144,17 @@ __global__ __launch_bounds__(256) void iteration_head_k(
   }
   // batch mean of the loss, in cloud order, by the last block to arrive (hand-off protocol: common.hpp)
   if (!handoff_last_arriver(ticket, 0, B, &s_last)) return;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {  // wave 0: sixty-four clouds' values per round trip, added by lane 0 in cloud order
     float a = 0.f;
-    for (int q = 0; q < B; ++q) a += __hip_atomic_load(&per[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    loss[0] = a / (float)B;
-    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q0 = 0; q0 < B; q0 += 64) {
+      const float v = __hip_atomic_load(&per[min(q0 + lane, B - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int n = min(64, B - q0);
+      for (int q = 0; q < n; ++q) a += __shfl(v, q, HITADV_WAVE);
+    }
+    if (threadIdx.x == 0) {
+      loss[0] = a / (float)B;
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

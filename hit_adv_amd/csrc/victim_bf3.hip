@@ -268,11 +268,18 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   if (threadIdx.x < 256 && c < Cout) {
     float best = 0.f;
     int bidx = 0;
-    for (int q = 0; q < S; ++q) {
-      const size_t o = ((size_t)b * S + q) * Cout + c;
-      const float v = __hip_atomic_load(&pval[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int vi = __hip_atomic_load(&pidx[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (q == 0 || v > best) { best = v; bidx = vi; }
+    for (int q0 = 0; q0 < S; q0 += 4) {  // four splits' partials per round trip, compared in split order
+      float v[4];
+      int vi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t o = ((size_t)b * S + min(q0 + u, S - 1)) * Cout + c;
+        v[u] = __hip_atomic_load(&pval[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vi[u] = __hip_atomic_load(&pidx[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u < S && (q0 + u == 0 || v[u] > best)) { best = v[u]; bidx = vi[u]; }
     }
     best += bias ? bias[c] : 0.f;
     out[(size_t)b * Cout + c] = relu ? (best > 0.f ? best : 0.f) : best;
