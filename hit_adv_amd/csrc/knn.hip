@@ -6,6 +6,8 @@
 //                       every accepted candidate is appended to a per-lane log in LDS, and the few logged candidates
 //                       that survive are matched to their slots once, at the end.  fp32-VALU-bound.
 //       knn_topk<KB>    every other size: sorted (distance, index) insertion list per lane in VGPRs.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "hitadv.h"
 
@@ -184,7 +186,7 @@ __device__ __forceinline__ f32x2 pair_dist2(float qx, float qy, float qz, float 
 // NW waves of a block split the reference range for the same 64 queries (NW = 8 from 512 references on: 4096 short waves
 // instead of 2048 give every SIMD four waves to switch between -- the scan is a chain of dependent VALU instructions).
 __host__ __device__ constexpr int ks_cap(int KB, int NW) {  // >= 2 KB - 1 survivors of a compaction + one group of 4
-  return NW == 8 ? (KB <= 8 ? 36 : (KB <= 12 ? 48 : (KB <= 20 ? 56 : 72))) : (KB <= 8 ? 32 : (KB <= 16 ? 64 : 96));
+  return NW == 8 ? (KB <= 8 ? 48 : (KB <= 12 ? 56 : (KB <= 20 ? 64 : 72))) : (KB <= 8 ? 48 : (KB <= 16 ? 80 : 96));
 }
 __host__ __device__ constexpr size_t ks_union_bytes(int KB, int NW) {
   return (size_t)NW * 64 * (ks_cap(KB, NW) * 2 > KB * 8 ? ks_cap(KB, NW) * 2 : KB * 8);
@@ -587,7 +589,8 @@ extern "C" int hitadv_knn_points(const float *q, const float *p, int B, int N, i
     // K = 6: 37 vs 43), 4 waves for long ones (K = 17: 74 vs 107 -- the 8-way merge and the doubled log area cost more
     // than the extra waves hide).  Two queries per lane (128-query blocks, as K2 does with four) was also measured: it
     // halves the number of waves and lost -- K = 6: 50 us, K = 17: 107 us -- thread-level parallelism is what this scan needs.
-    if (M >= 512 && K <= 8)
+    static const int force_nw = [] { const char *e = getenv("HITADV_KNN_NW"); return e ? atoi(e) : 0; }();  // tuning only
+    if (force_nw == 8 || (force_nw != 4 && M >= 512 && K <= 8))
       rc = form == HITADV_FORM_DIRECT ? launch_knn_select<0, 8>(q, p, B, N, M, K, dists, idx, idx_is_i64, s)
                                       : launch_knn_select<2, 8>(q, p, B, N, M, K, dists, idx, idx_is_i64, s);
     else
