@@ -882,6 +882,89 @@ __global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, 
   }
 }
 
+// The same layer for K = 64 NWV (used at K = 512) WITHOUT a split over blocks: one block of NWV waves per 32 x 32 output tile, wave
+// w takes the 64-deep slice k = 64 w .. 64 w + 63 -- its own staging area for its slice of the input rows (coalesced
+// float4 loads, gated by the mask on the way in, no block barrier: only this wave reads it), 32 MFMAs -- and the NWV
+// partial tiles meet in LDS, added in wave order.  No global partials, no ticket, no second pass by a last block: two
+// dependent global round trips less than the split form; the price is that the tile's 64 NWV x 32 weights are read by
+// one CU.
+constexpr int FCW_LD = 68;  // floats per staged input row (64 + 4: conflict-free ds_read_b128)
+
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void fc_wide_k(const float *__restrict__ in, const float *__restrict__ mask,
+                                                      const float *__restrict__ Wt, const float *__restrict__ bias, int B,
+                                                      int K, int NOUT, int relu, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float fcw_sm[];  // NWV x 32 x FCW_LD staging, then NWV x 1024 partials
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int col = blockIdx.x * 32 + r, row0 = blockIdx.y * 32;
+  const int cc = min(col, NOUT - 1);
+  const int k0 = 64 * wave;
+  // every operand is requested before anything is used; out-of-range columns read column NOUT - 1 and are never stored
+  float wv[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) wv[t] = Wt[(size_t)(k0 + kmap(t, h)) * NOUT + cc];
+  const float *mp = mask != nullptr ? mask : in;
+  const bool gated = mask != nullptr;
+  float4 x[8], g[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = lane + 64 * u;
+    const size_t o = (size_t)min(row0 + (e >> 4), B - 1) * K + k0 + 4 * (e & 15);
+    x[u] = *reinterpret_cast<const float4 *>(in + o);
+    g[u] = *reinterpret_cast<const float4 *>(mp + o);
+  }
+  float *sW = fcw_sm + (size_t)wave * 32 * FCW_LD;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = lane + 64 * u;
+    const bool ok = row0 + (e >> 4) < B;
+    float4 v;
+    v.x = (ok && (!gated || g[u].x > 0.f)) ? x[u].x : 0.f;
+    v.y = (ok && (!gated || g[u].y > 0.f)) ? x[u].y : 0.f;
+    v.z = (ok && (!gated || g[u].z > 0.f)) ? x[u].z : 0.f;
+    v.w = (ok && (!gated || g[u].w > 0.f)) ? x[u].w : 0.f;
+    *reinterpret_cast<float4 *>(sW + (e >> 4) * FCW_LD + 4 * (e & 15)) = v;
+  }
+  f32x16 acc;
+  zero(acc);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 a = *reinterpret_cast<const float4 *>(sW + r * FCW_LD + 8 * j + 4 * h);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wv[4 * j], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wv[4 * j + 1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wv[4 * j + 2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wv[4 * j + 3], acc, 0, 0, 0);
+  }
+  __syncthreads();  // every wave is done with its staging area: the memory becomes the partial tiles
+#pragma unroll
+  for (int e = 0; e < 16; ++e) fcw_sm[(size_t)wave * 1024 + e * 64 + lane] = acc[e];
+  __syncthreads();
+  for (int o = threadIdx.x; o < 1024; o += NWV * 64) {
+    float v = fcw_sm[o];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) v += fcw_sm[(size_t)w * 1024 + o];
+    const int e = o >> 6, l = o & 63;
+    const int orow = row0 + acc_row(e, l >> 5), ocol = blockIdx.x * 32 + (l & 31);
+    if (orow < B && ocol < NOUT) {
+      float y = v + (bias ? bias[ocol] : 0.f);
+      if (relu) y = y > 0.f ? y : 0.f;
+      out[(size_t)orow * NOUT + ocol] = y;
+    }
+  }
+}
+
+template <int NWV>
+static void launch_fc_wide(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K, int NOUT,
+                           int relu, float *out, hipStream_t s) {
+  constexpr int shm = NWV * 32 * FCW_LD * 4;  // >= NWV * 4096 bytes of partials
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc_wide_k<NWV>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+  (void)once;
+  dim3 grid((NOUT + 31) / 32, (B + 31) / 32);
+  fc_wide_k<NWV><<<grid, NWV * 64, shm, s>>>(in, mask, Wt, bias, B, K, NOUT, relu, out);
+}
+
 static void fc_split(int B, int K, int NOUT, int *chunk, int *KS, int *tiles) {
   // 128-deep chunks per block, measured at B = 32 (tools/fc_split_probe.py): K <= 256 runs without a split (no hand-off:
   // 6.5 instead of 7.0 us), 512 and 1024 one chunk per block (two chunks: +1.0 .. +1.6 us), 4096 two (10.8 instead of
@@ -983,6 +1066,14 @@ extern "C" int hitadv_fc_layer(const float *in, const float *mask, const float *
                                int NOUT, int relu, float *out, float *scratch, void *stream) {
   if (!in || !Wt || !out || !scratch || B <= 0 || K <= 0 || NOUT <= 0) return HITADV_E_ARG;
   if ((K & 3) == 0 && (((uintptr_t)in | (uintptr_t)mask) & 15)) return HITADV_E_ARG;
+  static const int wide = [] { const char *e = getenv("HITADV_FC_WIDE"); return e ? atoi(e) : 1; }();  // 0: tuning / A-B only
+  // K = 512 only: at K = 1024 a block of sixteen waves is left with 64 registers per lane, its weight loads end up between
+  // the MFMAs, and the split form wins (9.0 vs 7.4 us; K = 512: 5.6 vs 6.3 / 6.7 us -- tools/fc_split_probe.py)
+  if (wide && K == 512) {
+    launch_fc_wide<8>(in, mask, Wt, bias, B, K, NOUT, relu, out, (hipStream_t)stream);
+    HITADV_LAUNCH_CHECK();
+    return 0;
+  }
   int chunk, KS, tiles;
   fc_split(B, K, NOUT, &chunk, &KS, &tiles);
   if (tiles > FC_TICKETS) return HITADV_E_ARG;
