@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, 
   }
 }
 
-// The same layer for K = 64 NWV (used at K = 512) WITHOUT a split over blocks: one block of NWV waves per 32 x 32 output tile, wave
+// The same layer for K = 64 NWV (used at K = 256 and 512) WITHOUT a split over blocks or a chunk loop: one block of NWV waves per 32 x 32 output tile, wave
 // w takes the 64-deep slice k = 64 w .. 64 w + 63 -- its own staging area for its slice of the input rows (coalesced
 // float4 loads, gated by the mask on the way in, no block barrier: only this wave reads it), 32 MFMAs -- and the NWV
 // partial tiles meet in LDS, added in wave order.  No global partials, no ticket, no second pass by a last block: two
@@ -890,10 +890,12 @@ __global__ __launch_bounds__(256) void fc_layer_k(const float *__restrict__ in, 
 // one CU.
 constexpr int FCW_LD = 68;  // floats per staged input row (64 + 4: conflict-free ds_read_b128)
 
-template <int NWV>
+// PRE > 0 (the number of MFMA steps of the product in front, as in fc_layer_k): the wave's 32 x 64 slice of the input is
+// itself computed, P[32,J] @ Wpre[J, its 64 columns], from the block's summed partials P (behind the staging areas in LDS).
+template <int NWV, int PRE>
 __global__ __launch_bounds__(NWV * 64) void fc_wide_k(const float *__restrict__ in, const float *__restrict__ mask,
                                                       const float *__restrict__ Wt, const float *__restrict__ bias, int B,
-                                                      int K, int NOUT, int relu, float *__restrict__ out) {
+                                                      int K, int NOUT, int relu, float *__restrict__ out, FcPre pp) {
   extern __shared__ __attribute__((aligned(16))) float fcw_sm[];  // NWV x 32 x FCW_LD staging, then NWV x 1024 partials
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -904,27 +906,86 @@ __global__ __launch_bounds__(NWV * 64) void fc_wide_k(const float *__restrict__ 
   float wv[32];
 #pragma unroll
   for (int t = 0; t < 32; ++t) wv[t] = Wt[(size_t)(k0 + kmap(t, h)) * NOUT + cc];
-  const float *mp = mask != nullptr ? mask : in;
   const bool gated = mask != nullptr;
-  float4 x[8], g[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = lane + 64 * u;
-    const size_t o = (size_t)min(row0 + (e >> 4), B - 1) * K + k0 + 4 * (e & 15);
-    x[u] = *reinterpret_cast<const float4 *>(in + o);
-    g[u] = *reinterpret_cast<const float4 *>(mp + o);
-  }
   float *sW = fcw_sm + (size_t)wave * 32 * FCW_LD;
+  if (PRE == 0) {
+    const float *mp = mask != nullptr ? mask : in;
+    float4 x[8], g[8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = lane + 64 * u;
-    const bool ok = row0 + (e >> 4) < B;
-    float4 v;
-    v.x = (ok && (!gated || g[u].x > 0.f)) ? x[u].x : 0.f;
-    v.y = (ok && (!gated || g[u].y > 0.f)) ? x[u].y : 0.f;
-    v.z = (ok && (!gated || g[u].z > 0.f)) ? x[u].z : 0.f;
-    v.w = (ok && (!gated || g[u].w > 0.f)) ? x[u].w : 0.f;
-    *reinterpret_cast<float4 *>(sW + (e >> 4) * FCW_LD + 4 * (e & 15)) = v;
+    for (int u = 0; u < 8; ++u) {
+      const int e = lane + 64 * u;
+      const size_t o = (size_t)min(row0 + (e >> 4), B - 1) * K + k0 + 4 * (e & 15);
+      x[u] = *reinterpret_cast<const float4 *>(in + o);
+      g[u] = *reinterpret_cast<const float4 *>(mp + o);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = lane + 64 * u;
+      const bool ok = row0 + (e >> 4) < B;
+      float4 v;
+      v.x = (ok && (!gated || g[u].x > 0.f)) ? x[u].x : 0.f;
+      v.y = (ok && (!gated || g[u].y > 0.f)) ? x[u].y : 0.f;
+      v.z = (ok && (!gated || g[u].z > 0.f)) ? x[u].z : 0.f;
+      v.w = (ok && (!gated || g[u].w > 0.f)) ? x[u].w : 0.f;
+      *reinterpret_cast<float4 *>(sW + (e >> 4) * FCW_LD + 4 * (e & 15)) = v;
+    }
+  } else {
+    constexpr int PS = PRE > 0 ? PRE : 1;
+    float *sP = fcw_sm + (size_t)NWV * 32 * FCW_LD;  // [32][65]
+    // this wave's columns of Wpre and the mask values of its output slots: requested with the weights
+    float bq[2][PS], mk[2][16];
+    const float *mp = mask != nullptr ? mask : Wt;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int kk = k0 + 32 * ct + r;
+#pragma unroll
+      for (int t = 0; t < PS; ++t) bq[ct][t] = pp.Wpre[(size_t)min(2 * t + h, pp.J - 1) * K + kk];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mk[ct][e] = mp[gated ? (size_t)min(row0 + acc_row(e, h), B - 1) * K + kk : 0];
+    }
+    // P[32,J]: the block sums its rows' partials once (ascending t), as fc_layer_k does
+    if (pp.T == 1) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = min((int)threadIdx.x + NWV * 64 * u, 32 * pp.J - 1);
+        v[u] = pp.pre[(size_t)min(row0 + e / pp.J, B - 1) * pp.J + e % pp.J];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + NWV * 64 * u;
+        if (e < 32 * pp.J) sP[(e / pp.J) * 65 + e % pp.J] = row0 + e / pp.J < B ? v[u] : 0.f;
+      }
+    } else {
+      for (int e = threadIdx.x; e < 32 * pp.J; e += NWV * 64) {
+        const int rr = e / pp.J, j = e - rr * pp.J;
+        const float *p = pp.pre + ((size_t)min(row0 + rr, B - 1) * pp.T) * pp.J + j;
+        float v = 0.f;
+        for (int t0 = 0; t0 < pp.T; t0 += 16) {
+          float q[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) q[t] = p[(size_t)min(t0 + t, pp.T - 1) * pp.J];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) v += t0 + t < pp.T ? q[t] : 0.f;
+        }
+        sP[rr * 65 + j] = row0 + rr < B ? v : 0.f;
+      }
+    }
+    __syncthreads();
+    float av[PS];
+#pragma unroll
+    for (int t = 0; t < PS; ++t) av[t] = 2 * t + h < pp.J ? sP[r * 65 + min(2 * t + h, 63)] : 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      f32x16 pa;
+      zero(pa);
+#pragma unroll
+      for (int t = 0; t < PS; ++t)
+        if (2 * t < pp.J) pa = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bq[ct][t], pa, 0, 0, 0);  // wave-uniform guard
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        sW[acc_row(e, h) * FCW_LD + 32 * ct + r] = (!gated || mk[ct][e] > 0.f) ? pa[e] : 0.f;  // rows past B are zeros of P
+    }
   }
   f32x16 acc;
   zero(acc);
@@ -954,15 +1015,15 @@ __global__ __launch_bounds__(NWV * 64) void fc_wide_k(const float *__restrict__ 
   }
 }
 
-template <int NWV>
+template <int NWV, int PRE>
 static void launch_fc_wide(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K, int NOUT,
-                           int relu, float *out, hipStream_t s) {
-  constexpr int shm = NWV * 32 * FCW_LD * 4;  // >= NWV * 4096 bytes of partials
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc_wide_k<NWV>),
+                           int relu, float *out, FcPre pp, hipStream_t s) {
+  constexpr int shm = NWV * 32 * FCW_LD * 4 + (PRE ? 32 * 65 * 4 : 0);  // staging (>= NWV * 4096 bytes of partials) + P
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc_wide_k<NWV, PRE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, shm);
   (void)once;
   dim3 grid((NOUT + 31) / 32, (B + 31) / 32);
-  fc_wide_k<NWV><<<grid, NWV * 64, shm, s>>>(in, mask, Wt, bias, B, K, NOUT, relu, out);
+  fc_wide_k<NWV, PRE><<<grid, NWV * 64, shm, s>>>(in, mask, Wt, bias, B, K, NOUT, relu, out, pp);
 }
 
 static void fc_split(int B, int K, int NOUT, int *chunk, int *KS, int *tiles) {
@@ -1067,10 +1128,12 @@ extern "C" int hitadv_fc_layer(const float *in, const float *mask, const float *
   if (!in || !Wt || !out || !scratch || B <= 0 || K <= 0 || NOUT <= 0) return HITADV_E_ARG;
   if ((K & 3) == 0 && (((uintptr_t)in | (uintptr_t)mask) & 15)) return HITADV_E_ARG;
   static const int wide = [] { const char *e = getenv("HITADV_FC_WIDE"); return e ? atoi(e) : 1; }();  // 0: tuning / A-B only
-  // K = 512 only: at K = 1024 a block of sixteen waves is left with 64 registers per lane, its weight loads end up between
-  // the MFMAs, and the split form wins (9.0 vs 7.4 us; K = 512: 5.6 vs 6.3 / 6.7 us -- tools/fc_split_probe.py)
-  if (wide && K == 512) {
-    launch_fc_wide<8>(in, mask, Wt, bias, B, K, NOUT, relu, out, (hipStream_t)stream);
+  // K = 256 and 512 (tools/fc_split_probe.py, B = 32: 4.3-4.6 instead of 5.7-5.9 us, 5.6 instead of 6.3-6.7 us); at K = 1024 a
+  // block of sixteen waves is left with 64 registers per lane, its weight loads end up between the MFMAs, and the split
+  // form wins (9.0 vs 7.4 us)
+  if (wide && (K == 512 || K == 256)) {
+    if (K == 512) launch_fc_wide<8, 0>(in, mask, Wt, bias, B, K, NOUT, relu, out, FcPre{}, (hipStream_t)stream);
+    else launch_fc_wide<4, 0>(in, mask, Wt, bias, B, K, NOUT, relu, out, FcPre{}, (hipStream_t)stream);
     HITADV_LAUNCH_CHECK();
     return 0;
   }
@@ -1094,6 +1157,13 @@ extern "C" int hitadv_fc_layer_pre(const float *pre, int T, int J, const float *
   if (tiles > FC_TICKETS) return HITADV_E_ARG;
   dim3 grid((NOUT + 31) / 32, (B + 31) / 32, KS);
   const FcPre pp{pre, Wpre, T, J};
+  static const int wide = [] { const char *e = getenv("HITADV_FC_WIDE"); return e ? atoi(e) : 1; }();  // 0: tuning / A-B only
+  if (wide && K == 256) {  // the stacks' case: four waves, one 64-deep slice each, no chunk loop
+    if (J <= 16) launch_fc_wide<4, 8>(nullptr, mask, Wt, bias, B, K, NOUT, relu, out, pp, (hipStream_t)stream);
+    else launch_fc_wide<4, 32>(nullptr, mask, Wt, bias, B, K, NOUT, relu, out, pp, (hipStream_t)stream);
+    HITADV_LAUNCH_CHECK();
+    return 0;
+  }
   int *tk = reinterpret_cast<int *>(scratch);
   if (J <= 16)
     fc_layer_k<8><<<grid, 256, 0, (hipStream_t)stream>>>(nullptr, mask, Wt, bias, B, K, NOUT, relu, chunk, out,
