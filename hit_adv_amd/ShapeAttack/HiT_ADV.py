@@ -256,8 +256,8 @@ class HiT_ADV:
         """The same iteration with the chain rule written out instead of recorded: autograd is used for the victim
         only (any nn.Module), every other forward / backward is an explicit kernel call on workspace buffers, and
         gradient sums ride inside the consuming kernels (victim + regulariser into deform_bwd's upstream; deformation +
-        regulariser into Adam).  6 launches around the victim instead of ~37 (deform_fwd, iteration_head, regulariser
-        forward, regulariser backward, deform_bwd, Adam).  The projection of (perturb, sigma)
+        regulariser into Adam).  5 launches around the victim instead of ~37 (deform_fwd, iteration_head with the
+        regularisers' forward pass, regulariser backward, deform_bwd, Adam).  The projection of (perturb, sigma)
         (:157-158) is applied by the Adam kernel right after the update -- the parameters every forward pass sees
         are the same (the initial draws already lie inside the box)."""
         regs = (self.cd_weight, self.ker_weight, self.hide_weight)
@@ -266,18 +266,26 @@ class HiT_ADV:
         ops.deform_fwd_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den)
         x = ws.adv.detach().requires_grad_()
         logits = self._logits(x, ws.feed)
+        reg_done = False
         if hasattr(self.adv_func, 'fused_kind'):  # best-result tracking + adversarial loss: one launch
             kind, kappa = self.adv_func.fused_kind()
             dlogits = torch.empty_like(logits)
-            ops.iteration_head(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, ws.step, kind, kappa, ws.adv_loss,
-                               dlogits, ws.head_scratch)
+            if any(w != 0 for w in regs):  # ... which also takes the regularisers' forward pass (they need no victim output)
+                ops.iteration_head_reg(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, ws.step, kind, kappa,
+                                       ws.adv_loss, dlogits, ws.head_scratch, ws.ori, ws.hide_ref, ws.scale_const, regs, rng,
+                                       ws.reg_scratch, ws.dist_loss, ws.scaled)
+                reg_done = True
+            else:
+                ops.iteration_head(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, ws.step, kind, kappa,
+                                   ws.adv_loss, dlogits, ws.head_scratch)
         else:
             ops.best_update(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, counter=ws.step)
             _, dlogits = self.adv_func.fused(logits, ws.target, loss_out=ws.adv_loss)
         g_victim, = torch.autograd.grad(logits, x, grad_outputs=dlogits)
         if any(w != 0 for w in regs):
-            ops.regulariser_fwd_fused_into(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.scale_const, regs, rng,
-                                           ws.reg_scratch, ws.dist_loss, ws.scaled)
+            if not reg_done:
+                ops.regulariser_fwd_fused_into(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.scale_const, regs, rng,
+                                               ws.reg_scratch, ws.dist_loss, ws.scaled)
             ops.regulariser_bwd_add(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.reg_scratch, g_victim.contiguous(), regs,
                                     rng, ws.gp_reg, ws.gs_reg, ws.g_adv)
             g_adv, gp2, gs2 = ws.g_adv, ws.gp_reg, ws.gs_reg

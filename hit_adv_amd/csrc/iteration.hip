@@ -8,6 +8,7 @@
 //   hitadv_adam_step_partials   ... whose fixed-order slab sum happens inside the Adam kernel that consumes it
 #include "common.hpp"
 #include "hitadv.h"
+#include "regulariser_body.hpp"
 
 namespace hitadv {
 
@@ -18,16 +19,39 @@ __device__ __forceinline__ uint32_t ordered_bits_i(float v) {
 
 // One block (256 threads) per cloud.  Waves 0..3 share the transformation-loss sums; wave 0 finds the prediction, wave 1
 // the adversarial loss row.  scratch: per[B] floats, then one int ticket (zeroed once by the caller).
-__global__ __launch_bounds__(256) void iteration_head_k(
-    const float *__restrict__ logits, const int64_t *__restrict__ label, const float *__restrict__ perturb,
-    const float *__restrict__ sigma, const float *__restrict__ adv, int B, int num_class, int N, int C,
-    float *__restrict__ bestdist, int64_t *__restrict__ bestscore, float *__restrict__ o_bestdist,
-    int64_t *__restrict__ o_bestscore, float *__restrict__ o_bestattack, int64_t *__restrict__ pred_out,
-    float *__restrict__ dist_val_out, int32_t *__restrict__ iter_counter, int kind, float kappa,
-    float *__restrict__ loss, float *__restrict__ dlogits, float *per, int *ticket) {
+struct HeadArgs {
+  const float *logits;
+  const int64_t *label;
+  const float *perturb, *sigma, *adv;
+  int B, num_class, N, C;
+  float *bestdist;
+  int64_t *bestscore;
+  float *o_bestdist;
+  int64_t *o_bestscore;
+  float *o_bestattack;
+  int64_t *pred_out;
+  float *dist_val_out;
+  int32_t *iter_counter;
+  int kind;
+  float kappa;
+  float *loss, *dlogits, *per;
+  int *ticket;
+};
+
+__device__ __forceinline__ void iteration_head_body(const HeadArgs &a, const int b) {
+  const float *__restrict__ logits = a.logits, *__restrict__ perturb = a.perturb, *__restrict__ sigma = a.sigma,
+                           *__restrict__ adv = a.adv;
+  const int64_t *__restrict__ label = a.label;
+  const int B = a.B, num_class = a.num_class, N = a.N, C = a.C, kind = a.kind;
+  const float kappa = a.kappa;
+  float *__restrict__ bestdist = a.bestdist, *__restrict__ o_bestdist = a.o_bestdist, *__restrict__ o_bestattack = a.o_bestattack,
+                      *__restrict__ dist_val_out = a.dist_val_out, *__restrict__ loss = a.loss, *__restrict__ dlogits = a.dlogits;
+  int64_t *__restrict__ bestscore = a.bestscore, *__restrict__ o_bestscore = a.o_bestscore, *__restrict__ pred_out = a.pred_out;
+  int32_t *__restrict__ iter_counter = a.iter_counter;
+  float *per = a.per;
+  int *ticket = a.ticket;
   __shared__ float s1[4], s2[4];
   __shared__ int s_copy, s_last;
-  const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // transformation_loss(batch_avg=False): (|P_b|_F + |1 - sigma_b|_2) / C   -- as best_update_k
   // Everything the block reads is requested before anything is used: a load inside a loop whose trip count the compiler
@@ -158,6 +182,25 @@ __global__ __launch_bounds__(256) void iteration_head_k(
   }
 }
 
+__global__ __launch_bounds__(256) void iteration_head_k(HeadArgs a) { iteration_head_body(a, blockIdx.x); }
+
+// iteration_head and the regularisers' forward pass in ONE launch: both are one block per cloud with a last-arriver
+// reduction, and the regularisers need nothing the victim produces (perturb, sigma and the deformed cloud only) -- blocks
+// 0 .. B-1 run the head, blocks B .. 2B-1 the regularisers' per-cloud pass.  Same code, same bits, one launch less.
+struct RegArgs {
+  const float *ori, *hide_ref;
+  float min_s, inv_range;
+  float *part;
+  RegFin fin;
+};
+__global__ __launch_bounds__(256) void iteration_head_reg_k(HeadArgs a, RegArgs g) {
+  if ((int)blockIdx.x < a.B)
+    iteration_head_body(a, blockIdx.x);
+  else
+    reg_partials_body(a.perturb, a.sigma, a.adv, g.ori, g.hide_ref, a.N, a.C, g.min_s, g.inv_range, g.part, g.fin, 1,
+                      (int)blockIdx.x - a.B);
+}
+
 // Adam on (perturb [B,C,3], sigma [B,C]) with the deformation's gradient still in its per-slab partials
 // [B,nslab,4,C] (summed here in ascending slab order = deform_bwd_reduce's order) plus an optional second term, then the
 // projection of adam2_k.  One thread per (cloud, centre).
@@ -232,10 +275,33 @@ extern "C" int hitadv_iteration_head(const float *logits, const int64_t *label, 
       !o_bestattack || !pred_out || !dist_val_out || !loss || !dlogits || !scratch || kind < 0 || kind > 2 || B <= 0 ||
       num_class <= 0 || N <= 0 || C <= 0)
     return HITADV_E_ARG;
-  iteration_head_k<<<B, 256, 0, (hipStream_t)stream>>>(logits, label, perturb, sigma, adv, B, num_class, N, C, bestdist,
-                                                       bestscore, o_bestdist, o_bestscore, o_bestattack, pred_out,
-                                                       dist_val_out, iter_counter, kind, kappa, loss, dlogits, scratch,
-                                                       reinterpret_cast<int *>(scratch + B));
+  const HeadArgs a{logits, label, perturb, sigma, adv, B, num_class, N, C, bestdist, bestscore, o_bestdist, o_bestscore,
+                   o_bestattack, pred_out, dist_val_out, iter_counter, kind, kappa, loss, dlogits, scratch,
+                   reinterpret_cast<int *>(scratch + B)};
+  iteration_head_k<<<B, 256, 0, (hipStream_t)stream>>>(a);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_iteration_head_reg(const float *logits, const int64_t *label, const float *perturb, const float *sigma,
+                                         const float *adv, int B, int num_class, int N, int C, float *bestdist,
+                                         int64_t *bestscore, float *o_bestdist, int64_t *o_bestscore, float *o_bestattack,
+                                         int64_t *pred_out, float *dist_val_out, int32_t *iter_counter, int kind,
+                                         float kappa, float *loss, float *dlogits, float *scratch, const float *ori,
+                                         const float *hide_ref, const float *scale_const, float cd_w, float ker_w,
+                                         float hide_w, float min_sigm, float max_sigm, float *reg_scratch, float *dist_loss,
+                                         float *scaled_loss, void *stream) {
+  if (!logits || !label || !perturb || !sigma || !adv || !bestdist || !bestscore || !o_bestdist || !o_bestscore ||
+      !o_bestattack || !pred_out || !dist_val_out || !loss || !dlogits || !scratch || kind < 0 || kind > 2 || B <= 0 ||
+      num_class <= 0 || N <= 0 || C <= 0 || !ori || !hide_ref || !scale_const || !reg_scratch || !dist_loss || !scaled_loss)
+    return HITADV_E_ARG;
+  const HeadArgs a{logits, label, perturb, sigma, adv, B, num_class, N, C, bestdist, bestscore, o_bestdist, o_bestscore,
+                   o_bestattack, pred_out, dist_val_out, iter_counter, kind, kappa, loss, dlogits, scratch,
+                   reinterpret_cast<int *>(scratch + B)};
+  float *part = reg_scratch, *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
+  const RegArgs g{ori, hide_ref, min_sigm, 1.0f / (max_sigm - min_sigm + 1e-7f), part,
+                  RegFin{scale_const, B, cd_w, ker_w, hide_w, per_cloud, scal, dist_loss, scaled_loss}};
+  iteration_head_reg_k<<<2 * B, 256, 0, (hipStream_t)stream>>>(a, g);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

@@ -323,6 +323,19 @@ def iteration_head(logits, label, perturb, sigma, adv, state, counter, kind, kap
               kind, ctypes.c_float(float(kappa)), _p(loss_out), _p(dlogits), _p(scratch), _stream())
 
 
+def iteration_head_reg(logits, label, perturb, sigma, adv, state, counter, kind, kappa, loss_out, dlogits, scratch, ori,
+                       hide_ref, scale_const, weights, sig_range, reg_scratch, dist_out, scaled_out):
+    """``iteration_head`` and ``regulariser_fwd_fused_into`` in one launch (same results, bit for bit)."""
+    B, K = logits.shape
+    cd, ker, hide = (ctypes.c_float(float(w)) for w in weights)
+    lo, hi = (ctypes.c_float(float(v)) for v in sig_range)
+    _lib.call("hitadv_iteration_head_reg", _p(logits), _p(label), _p(perturb), _p(sigma), _p(adv), B, K, adv.shape[2],
+              sigma.shape[1], _p(state["bestdist"]), _p(state["bestscore"]), _p(state["o_bestdist"]),
+              _p(state["o_bestscore"]), _p(state["o_bestattack"]), _p(state["pred"]), _p(state["dist_val"]), _p(counter),
+              kind, ctypes.c_float(float(kappa)), _p(loss_out), _p(dlogits), _p(scratch), _p(ori), _p(hide_ref),
+              _p(scale_const), cd, ker, hide, lo, hi, _p(reg_scratch), _p(dist_out), _p(scaled_out), _stream())
+
+
 def regulariser_fwd_fused_into(perturb, sigma, adv, ori, hide_ref, scale_const, weights, sig_range, scratch, dist_out,
                                scaled_out):
     """``regulariser_fwd_into`` in one launch; ``scratch`` must have been ZEROED when it was allocated."""

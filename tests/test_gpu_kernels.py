@@ -1035,9 +1035,11 @@ def test_merged_iteration_launches_equal_the_launches_they_merge(A, B, K, Np, C)
     scale = cu(10. + 70. * torch.rand(B, generator=g))
     regs, rng = (1e-4, 1.0, 1.0), (0.1, 1.2)
     for kind in (A.ADV_UNTARGETED, A.ADV_TARGETED, A.ADV_CROSS_ENTROPY):
-        sa, sb = state(), state()
+        sa, sb, sc = state(), state(), state()
         ca, cb = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
-        head = A.iteration_head_scratch(B, dev)
+        cc = torch.zeros(1, dtype=torch.int32, device=dev)
+        head, head_c = A.iteration_head_scratch(B, dev), A.iteration_head_scratch(B, dev)
+        reg_c = torch.zeros(A.regulariser_scratch(B), device=dev)
         reg_a = torch.zeros(A.regulariser_scratch(B), device=dev)
         reg_b = torch.zeros(A.regulariser_scratch(B), device=dev)
         Pa = cu((torch.rand(B, C, 3, generator=g) - 0.5) * 0.5)
@@ -1064,6 +1066,15 @@ def test_merged_iteration_launches_equal_the_launches_they_merge(A, B, K, Np, C)
             A.regulariser_fwd_fused_into(Pb, Sb, adv, ori, hide_ref, scale, regs, rng, reg_b, db_l, lb)
             assert torch.equal(da_l, db_l) and torch.equal(la, lb)
             assert torch.equal(reg_a[:-1], reg_b[:-1]) and float(reg_b[-1]) == 0.
+            # iteration_head + the regularisers' forward pass in ONE launch (a third copy of the state)
+            d_c, lc, dc_l, sc_l = torch.empty_like(logits), torch.zeros((), device=dev), torch.zeros((), device=dev), torch.zeros((), device=dev)
+            A.iteration_head_reg(logits, label, Pb, Sb, adv, sc, cc, kind, 30., lc, d_c, head_c, ori, hide_ref, scale, regs, rng,
+                                 reg_c, dc_l, sc_l)
+            assert torch.equal(d_c, d_b) and torch.equal(lc, loss_a) and int(cc) == it + 1
+            for k in sa:
+                assert torch.equal(sa[k], sc[k]), k
+            assert torch.equal(dc_l, da_l) and torch.equal(sc_l, la)
+            assert torch.equal(reg_c[:-1], reg_a[:-1]) and float(reg_c[-1]) == 0.
             up = cu(torch.randn(B, 3, Np, generator=g))
             gp, gs = torch.empty_like(Pa), torch.empty_like(Sa)
             gp2, gs2, ga = torch.empty_like(Pa), torch.empty_like(Sa), torch.empty_like(adv)
