@@ -256,8 +256,8 @@ class HiT_ADV:
         """The same iteration with the chain rule written out instead of recorded: autograd is used for the victim
         only (any nn.Module), every other forward / backward is an explicit kernel call on workspace buffers, and
         gradient sums ride inside the consuming kernels (victim + regulariser into deform_bwd's upstream; deformation +
-        regulariser into Adam).  5 launches around the victim instead of ~37 (deform_fwd, iteration_head with the
-        regularisers' forward pass, regulariser backward, deform_bwd, Adam).  The projection of (perturb, sigma)
+        regulariser into Adam).  4 launches around the victim instead of ~37 (deform_fwd, iteration_head with the
+        regularisers' forward pass, deform_bwd and Adam with the regularisers' backward terms).  The projection of (perturb, sigma)
         (:157-158) is applied by the Adam kernel right after the update -- the parameters every forward pass sees
         are the same (the initial draws already lie inside the box)."""
         regs = (self.cd_weight, self.ker_weight, self.hide_weight)
@@ -282,19 +282,23 @@ class HiT_ADV:
             ops.best_update(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, counter=ws.step)
             _, dlogits = self.adv_func.fused(logits, ws.target, loss_out=ws.adv_loss)
         g_victim, = torch.autograd.grad(logits, x, grad_outputs=dlogits)
+        clamp_p = (-self.budget, self.budget)
         if any(w != 0 for w in regs):
             if not reg_done:
                 ops.regulariser_fwd_fused_into(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.scale_const, regs, rng,
                                                ws.reg_scratch, ws.dist_loss, ws.scaled)
-            ops.regulariser_bwd_add(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.reg_scratch, g_victim.contiguous(), regs,
-                                    rng, ws.gp_reg, ws.gs_reg, ws.g_adv)
-            g_adv, gp2, gs2 = ws.g_adv, ws.gp_reg, ws.gs_reg
+            # the regularisers' backward terms are closed-form in what the next two kernels read anyway: evaluated inside
+            # them (same bits as regulariser_bwd_add), no launch of their own
+            ops.deform_bwd_partials_reg_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den, g_victim.contiguous(),
+                                             ws.reg_scratch, regs, ws.deform_part)
+            ops.adam_step_partials_reg(P, sigma, ws.deform_part, ws.N, ws.hide_ref, ws.reg_scratch, regs, rng, ws.m_p, ws.v_p,
+                                       ws.m_s, ws.v_s, ws.step, self.attack_lr * 5, self.attack_lr * 3, clamp_p, rng)
         else:
-            g_adv, gp2, gs2 = g_victim.contiguous(), None, None
-        # the deformation's gradient stays in its per-slab partials; the Adam kernel sums them (in the reduce order)
-        ops.deform_bwd_partials_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den, g_adv, ws.deform_part)
-        ops.adam_step_partials(P, sigma, ws.deform_part, ws.N, gp2, gs2, ws.m_p, ws.v_p, ws.m_s, ws.v_s, ws.step,
-                               self.attack_lr * 5, self.attack_lr * 3, (-self.budget, self.budget), rng)
+            # the deformation's gradient stays in its per-slab partials; the Adam kernel sums them (in the reduce order)
+            ops.deform_bwd_partials_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den, g_victim.contiguous(),
+                                         ws.deform_part)
+            ops.adam_step_partials(P, sigma, ws.deform_part, ws.N, None, None, ws.m_p, ws.v_p, ws.m_s, ws.v_s, ws.step,
+                                   self.attack_lr * 5, self.attack_lr * 3, clamp_p, rng)
 
     def _warm_up(self, ws):
         """Two eager passes of the iteration on ``ws.stream``; the second under PyTorch's sync-debug mode set

@@ -52,6 +52,9 @@ PROTOTYPES = {
     "hitadv_deform_bwd_partials": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "hitadv_deform_bwd_slabs": [_I],
     "hitadv_adam_step_partials": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P],
+    "hitadv_deform_bwd_partials_reg": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P],
+    "hitadv_adam_step_partials_reg": [_P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F,
+                                      _F, _F, _P, _P],
     "hitadv_linear_max_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "hitadv_max_over_points": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "hitadv_max_over_points_scratch": [_I, _I],

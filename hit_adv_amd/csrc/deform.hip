@@ -12,6 +12,7 @@
 //                    deform_bwd_reduce -> bitwise reproducible gradients, no atomics.
 #include "common.hpp"
 #include "hitadv.h"
+#include "regulariser_body.hpp"
 
 namespace hitadv {
 
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
                                                   const float *__restrict__ adv,
                                                   const float *__restrict__ inv_den,
                                                   const float *__restrict__ g_adv, int N, int C,
-                                                  int nslab, float *__restrict__ partials) {
+                                                  int nslab, float *__restrict__ partials, RegGrad rg) {
   __shared__ float4 sxyz[DB_PTS];  // x y z cn
   __shared__ float4 sg[DB_PTS];    // gDx gDy gDz -
   const int b = blockIdx.z, slab = blockIdx.y;
@@ -118,8 +119,17 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
       const float *gp = g_adv + (size_t)b * 3 * N;
       const float inv = inv_den[(size_t)b * N + n];
       const float x = op[n], y = op[N + n], z = op[2 * N + n];
-      const float gx = gp[n] * inv, gy = gp[N + n] * inv, gz = gp[2 * N + n] * inv;
-      const float cn = gx * (ap[n] - x) + gy * (ap[N + n] - y) + gz * (ap[2 * N + n] - z);
+      const float ax = ap[n], ay = ap[N + n], az = ap[2 * N + n];
+      float g0 = gp[n], g1 = gp[N + n], g2 = gp[2 * N + n];
+      if (rg.per_cloud != nullptr) {  // block-uniform: the regularisers' gradient at the deformed cloud, added on the way in
+        const float *pc = rg.per_cloud + (size_t)b * 8;
+        const int a0 = (int)pc[3], a1 = (int)pc[4], a2 = (int)pc[5];
+        g0 = reg_grad_adv(rg, ax, a0 == 0 ? x : (a0 == 1 ? y : z)) + g0;
+        g1 = reg_grad_adv(rg, ay, a1 == 0 ? x : (a1 == 1 ? y : z)) + g1;
+        g2 = reg_grad_adv(rg, az, a2 == 0 ? x : (a2 == 1 ? y : z)) + g2;
+      }
+      const float gx = g0 * inv, gy = g1 * inv, gz = g2 * inv;
+      const float cn = gx * (ax - x) + gy * (ay - y) + gz * (az - z);
       a = make_float4(x, y, z, cn);
       g = make_float4(gx, gy, gz, 0.f);
     }
@@ -201,7 +211,23 @@ extern "C" int hitadv_deform_bwd_partials(const float *ori, const float *central
     return HITADV_E_ARG;
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
   dim3 grid((C + 255) / 256, nslab, B);
-  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials);
+  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{});
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_deform_bwd_partials_reg(const float *ori, const float *central, const float *perturb,
+                                              const float *sigma, const float *adv, const float *inv_den,
+                                              const float *g_victim, const float *reg_scratch, float cd_w, int B, int N,
+                                              int C, float *partials, void *stream) {
+  if (!ori || !central || !perturb || !sigma || !adv || !inv_den || !g_victim || !reg_scratch || !partials || B <= 0 ||
+      N <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  const float *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
+  const RegGrad rg{per_cloud, scal, nullptr, cd_w, 0.f, 0.f, 0.f, 0.f, B};
+  const int nslab = (N + DB_PTS - 1) / DB_PTS;
+  dim3 grid((C + 255) / 256, nslab, B);
+  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials, rg);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -216,7 +242,7 @@ extern "C" int hitadv_deform_bwd(const float *ori, const float *central, const f
   hipStream_t s = (hipStream_t)stream;
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
   dim3 grid((C + 255) / 256, nslab, B);
-  deform_bwd<<<grid, 256, 0, s>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials);
+  deform_bwd<<<grid, 256, 0, s>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{});
   dim3 grid2((C + 255) / 256, B);
   deform_bwd_reduce<<<grid2, 256, 0, s>>>(partials, C, nslab, grad_perturb, grad_sigma);
   HITADV_LAUNCH_CHECK();

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void adam_partials_k(float *__restrict__ P, fl
                                                        float *__restrict__ mP, float *__restrict__ vP,
                                                        float *__restrict__ mS, float *__restrict__ vS, int B, int C,
                                                        float lrP, float loP, float hiP, float lrS, float loS, float hiS,
-                                                       const int32_t *__restrict__ step) {
+                                                       const int32_t *__restrict__ step, RegGrad rg) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= B * C) return;
   const int b = e / C, j = e % C;
@@ -226,6 +226,8 @@ __global__ __launch_bounds__(256) void adam_partials_k(float *__restrict__ P, fl
   }
   m0[3] = mS[e]; v0[3] = vS[e]; p0[3] = S[e];
   h0[3] = (hS ? hS : S)[e];
+  const bool reg = rg.per_cloud != nullptr;  // the regularisers' gradients evaluated here instead of read (hP = hS = nullptr then)
+  const float href = reg ? rg.hide_ref[e] : 0.f;
   float g[4] = {0.f, 0.f, 0.f, 0.f};
   for (int s0 = 0; s0 < nslab; s0 += 8) {
     float q[8][4];
@@ -255,9 +257,14 @@ __global__ __launch_bounds__(256) void adam_partials_k(float *__restrict__ P, fl
     if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);
     p[i] = q;
   };
+  if (reg) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) upd(P, mP, vP, (size_t)e * 3 + c, c, hP ? g[c] + h0[c] : g[c], (double)lrP, loP, hiP);
-  upd(S, mS, vS, (size_t)e, 3, hS ? g[3] + h0[3] : g[3], (double)lrS, loS, hiS);
+    for (int c = 0; c < 3; ++c) h0[c] = reg_grad_perturb(rg, C, p0[c]);
+    h0[3] = reg_grad_sigma(rg, C, b, p0[3], href);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) upd(P, mP, vP, (size_t)e * 3 + c, c, (hP || reg) ? g[c] + h0[c] : g[c], (double)lrP, loP, hiP);
+  upd(S, mS, vS, (size_t)e, 3, (hS || reg) ? g[3] + h0[3] : g[3], (double)lrS, loS, hiS);
 }
 
 }  // namespace hitadv
@@ -317,7 +324,26 @@ extern "C" int hitadv_adam_step_partials(float *perturb, float *sigma, const flo
   adam_partials_k<<<(B * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(perturb, sigma, partials, nslab, g_perturb2,
                                                                         g_sigma2, m_perturb, v_perturb, m_sigma, v_sigma, B,
                                                                         C, lr_perturb, lo_perturb, hi_perturb, lr_sigma,
-                                                                        lo_sigma, hi_sigma, step);
+                                                                        lo_sigma, hi_sigma, step, RegGrad{});
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_adam_step_partials_reg(float *perturb, float *sigma, const float *partials, int nslab,
+                                             const float *hide_ref, const float *reg_scratch, float cd_w, float ker_w,
+                                             float hide_w, float min_sigm, float max_sigm, float *m_perturb,
+                                             float *v_perturb, float *m_sigma, float *v_sigma, int B, int C,
+                                             float lr_perturb, float lo_perturb, float hi_perturb, float lr_sigma,
+                                             float lo_sigma, float hi_sigma, const int32_t *step, void *stream) {
+  if (!perturb || !sigma || !partials || !hide_ref || !reg_scratch || !m_perturb || !v_perturb || !m_sigma || !v_sigma ||
+      !step || nslab <= 0 || B <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  const float *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
+  const RegGrad rg{per_cloud, scal, hide_ref, cd_w, ker_w, hide_w, min_sigm, 1.0f / (max_sigm - min_sigm + 1e-7f), B};
+  adam_partials_k<<<(B * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(perturb, sigma, partials, nslab, nullptr, nullptr,
+                                                                        m_perturb, v_perturb, m_sigma, v_sigma, B, C,
+                                                                        lr_perturb, lo_perturb, hi_perturb, lr_sigma,
+                                                                        lo_sigma, hi_sigma, step, rg);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

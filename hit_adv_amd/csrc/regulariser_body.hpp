@@ -187,4 +187,34 @@ __device__ inline void reg_finalise_body(const float *part, const float *__restr
   }
 }
 
+// The backward pass's three terms (reg_backward, regulariser.hip), for the kernels that evaluate them on the fly instead
+// of reading them from a launch of their own: the same expressions in the same order, so the same bits.
+struct RegGrad {
+  const float *per_cloud;  // [B,8] of the forward pass; nullptr = no regulariser
+  const float *scal;       // [8]
+  const float *hide_ref;   // [B,C]
+  float cd_w, ker_w, hide_w, min_s, inv_range;
+  int B;
+};
+// d loss / d adv[b,row,n]: a = adv[b,row,n], o = ori[b,arg(row),n] with arg = the nearest ori row of the forward pass
+__device__ __forceinline__ float reg_grad_adv(const RegGrad &g, float a, float o) {
+  const float k = 1.0f * g.scal[0];
+  return g.cd_w != 0.f ? k * (g.cd_w / (3.0f * (float)g.B)) * 2.0f * (a - o) : 0.f;
+}
+__device__ __forceinline__ float reg_grad_perturb(const RegGrad &g, int C, float p) {
+  const float k = 1.0f * g.scal[0];
+  return g.ker_w != 0.f ? k * (g.ker_w / (float)C) * g.scal[1] * p : 0.f;
+}
+__device__ __forceinline__ float reg_grad_sigma(const RegGrad &g, int C, int b, float s, float href) {
+  const float k = 1.0f * g.scal[0];
+  float v = 0.f;
+  if (g.ker_w != 0.f) v += (g.ker_w / (float)C) * g.scal[2] * (s - 1.0f);
+  if (g.hide_w != 0.f) {
+    const float *pc = g.per_cloud + (size_t)b * 8;
+    const float n = (s - g.min_s) * g.inv_range;
+    v += (g.hide_w / (float)g.B) * g.inv_range * (href * pc[1] - pc[0] * n * pc[2]);
+  }
+  return k * v;
+}
+
 }  // namespace hitadv

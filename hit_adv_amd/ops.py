@@ -352,6 +352,28 @@ def deform_bwd_partials_into(ori, central, perturb, sigma, adv, inv_den, g_adv, 
               B, N, central.shape[2], _p(partials), _stream())
 
 
+def deform_bwd_partials_reg_into(ori, central, perturb, sigma, adv, inv_den, g_victim, reg_scratch, weights, partials):
+    """``deform_bwd_partials_into`` whose upstream gradient is ``g_victim`` plus the regularisers' term, evaluated inside
+    from the forward pass's ``reg_scratch`` (what ``regulariser_bwd_add`` would have written to ``ga``)."""
+    B, _, N = ori.shape
+    _lib.call("hitadv_deform_bwd_partials_reg", _p(ori), _p(central), _p(perturb), _p(sigma), _p(adv), _p(inv_den),
+              _p(g_victim), _p(reg_scratch), ctypes.c_float(float(weights[0])), B, N, central.shape[2], _p(partials),
+              _stream())
+
+
+def adam_step_partials_reg(perturb, sigma, partials, N, hide_ref, reg_scratch, weights, sig_range, m_p, v_p, m_s, v_s, step,
+                           lr_p, lr_s, clamp_p, clamp_s):
+    """``adam_step_partials`` that evaluates the regularisers' gradients at (perturb, sigma) itself (``regulariser_bwd_add``'s
+    ``gp`` / ``gs``) instead of reading them."""
+    B, C = sigma.shape
+    cd, ker, hide = (ctypes.c_float(float(w)) for w in weights)
+    lo, hi = (ctypes.c_float(float(v)) for v in sig_range)
+    _lib.call("hitadv_adam_step_partials_reg", _p(perturb), _p(sigma), _p(partials),
+              int(_lib.load().hitadv_deform_bwd_slabs(N)), _p(hide_ref), _p(reg_scratch), cd, ker, hide, lo, hi, _p(m_p),
+              _p(v_p), _p(m_s), _p(v_s), B, C, ctypes.c_float(lr_p), ctypes.c_float(clamp_p[0]), ctypes.c_float(clamp_p[1]),
+              ctypes.c_float(lr_s), ctypes.c_float(clamp_s[0]), ctypes.c_float(clamp_s[1]), _p(step), _stream())
+
+
 def adam_step_partials(perturb, sigma, partials, N, gp2, gs2, m_p, v_p, m_s, v_s, step, lr_p, lr_s, clamp_p, clamp_s):
     """``adam_step_sum`` with the deformation's gradient still in its per-slab partials (summed inside, reduce order)."""
     B, C = sigma.shape

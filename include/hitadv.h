@@ -415,6 +415,18 @@ int hitadv_adam_step_partials(float *perturb, float *sigma, const float *partial
                               const float *g_sigma2, float *m_perturb, float *v_perturb, float *m_sigma, float *v_sigma,
                               int B, int C, float lr_perturb, float lo_perturb, float hi_perturb, float lr_sigma,
                               float lo_sigma, float hi_sigma, const int32_t *step, void *stream);
+/* The same two launches WITHOUT hitadv_regulariser_bwd_add between the victim and them: the regularisers' backward terms are
+ * closed-form in what these kernels read anyway, so they evaluate them on the fly (same expressions, same order, same
+ * bits).  _reg forms: g_victim = the victim's gradient at the deformed cloud (the regularisers' term is added inside);
+ * reg_scratch = the scratch of the forward pass (hitadv_regulariser_fwd_fused / hitadv_iteration_head_reg). */
+int hitadv_deform_bwd_partials_reg(const float *ori, const float *central, const float *perturb, const float *sigma,
+                                   const float *adv, const float *inv_den, const float *g_victim,
+                                   const float *reg_scratch, float cd_w, int B, int N, int C, float *partials, void *stream);
+int hitadv_adam_step_partials_reg(float *perturb, float *sigma, const float *partials, int nslab, const float *hide_ref,
+                                  const float *reg_scratch, float cd_w, float ker_w, float hide_w, float min_sigm,
+                                  float max_sigm, float *m_perturb, float *v_perturb, float *m_sigma, float *v_sigma, int B,
+                                  int C, float lr_perturb, float lo_perturb, float hi_perturb, float lr_sigma,
+                                  float lo_sigma, float hi_sigma, const int32_t *step, void *stream);
 
 /* k nearest neighbours in feature space for DGCNN's dynamic graph (model/dgcnn_cls.py:7-13: topk of
  * -|x_i|^2 + 2 x_i.x_j - |x_j|^2), fused: the scores come off the f32 matrix cores tile by tile and go straight into

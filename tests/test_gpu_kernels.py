@@ -1045,10 +1045,13 @@ def test_merged_iteration_launches_equal_the_launches_they_merge(A, B, K, Np, C)
         Pa = cu((torch.rand(B, C, 3, generator=g) - 0.5) * 0.5)
         Sa = cu(0.1 + 1.1 * torch.rand(B, C, generator=g))
         Pb, Sb = Pa.clone(), Sa.clone()
+        Pc, Sc = Pa.clone(), Sa.clone()
         ma = [torch.zeros_like(Pa), torch.zeros_like(Pa), torch.zeros_like(Sa), torch.zeros_like(Sa)]
         mb = [t.clone() for t in ma]
+        mc = [t.clone() for t in ma]
         part_a = torch.empty(A.deform_bwd_scratch(B, Np, C), device=dev)
         part_b = torch.empty_like(part_a)
+        part_c = torch.empty_like(part_a)
         for it in range(4):
             logits = cu(torch.randn(B, K, generator=g) * 3)
             adv, inv = torch.empty_like(ori), torch.empty(B, Np, device=dev)
@@ -1083,6 +1086,10 @@ def test_merged_iteration_launches_equal_the_launches_they_merge(A, B, K, Np, C)
             A.adam_step_sum(Pa, Sa, gp, gp2, gs, gs2, *ma, ca, 0.05, 0.03, (-0.55, 0.55), rng)
             A.deform_bwd_partials_into(ori, central, Pb, Sb, adv, inv, ga, part_b)
             A.adam_step_partials(Pb, Sb, part_b, Np, gp2, gs2, *mb, cb, 0.05, 0.03, (-0.55, 0.55), rng)
-            assert torch.equal(Pa, Pb) and torch.equal(Sa, Sb)
-            for x, y in zip(ma, mb):
-                assert torch.equal(x, y)
+            # ... and the _reg forms, which evaluate regulariser_bwd_add's three outputs themselves (state copy c)
+            A.deform_bwd_partials_reg_into(ori, central, Pc, Sc, adv, inv, up, reg_a, regs, part_c)
+            A.adam_step_partials_reg(Pc, Sc, part_c, Np, hide_ref, reg_a, regs, rng, *mc, cb, 0.05, 0.03, (-0.55, 0.55), rng)
+            assert torch.equal(part_c, part_b)
+            assert torch.equal(Pa, Pb) and torch.equal(Sa, Sb) and torch.equal(Pa, Pc) and torch.equal(Sa, Sc)
+            for x, y, z in zip(ma, mb, mc):
+                assert torch.equal(x, y) and torch.equal(x, z)
