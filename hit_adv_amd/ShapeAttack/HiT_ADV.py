@@ -265,7 +265,21 @@ class HiT_ADV:
         P, sigma = ws.P.detach(), ws.sigma.detach()
         ops.deform_fwd_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den)
         x = ws.adv.detach().requires_grad_()
-        logits = self._logits(x, ws.feed)
+        fused = hasattr(self.adv_func, 'fused_kind')
+        # the PointNet engine can leave its last layer (256 -> classes) to the loss kernel below: one launch less
+        view = self._view
+        defer = (fused and any(w != 0 for w in regs) and getattr(view, 'hip_engine', False) and hasattr(view, 'defer_logits')
+                 and view.h3_w.shape[0] <= 256 and view.h3_w.shape[1] <= 64)
+        head = None
+        if defer:
+            view.defer_logits = True
+            try:
+                logits = self._logits(x, ws.feed)
+                head = view.pending_head
+            finally:
+                view.defer_logits, view.pending_head = False, None
+        else:
+            logits = self._logits(x, ws.feed)
         reg_done = False
         if hasattr(self.adv_func, 'fused_kind'):  # best-result tracking + adversarial loss: one launch
             kind, kappa = self.adv_func.fused_kind()
@@ -273,7 +287,7 @@ class HiT_ADV:
             if any(w != 0 for w in regs):  # ... which also takes the regularisers' forward pass (they need no victim output)
                 ops.iteration_head_reg(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, ws.step, kind, kappa,
                                        ws.adv_loss, dlogits, ws.head_scratch, ws.ori, ws.hide_ref, ws.scale_const, regs, rng,
-                                       ws.reg_scratch, ws.dist_loss, ws.scaled)
+                                       ws.reg_scratch, ws.dist_loss, ws.scaled, head=head)
                 reg_done = True
             else:
                 ops.iteration_head(logits.detach(), ws.target, P, sigma, ws.adv, ws.state, ws.step, kind, kappa,

@@ -36,6 +36,11 @@ struct HeadArgs {
   float kappa;
   float *loss, *dlogits, *per;
   int *ticket;
+  // optional: the logits themselves, logits[b,:] = feat[b,:feat_dim] @ Wlog[feat_dim,num_class] + blog, evaluated here (the
+  // classifier's last layer, model/feature_models.py:91) instead of by a launch of its own; written to logits_out
+  const float *feat, *Wlog, *blog;
+  int feat_dim;
+  float *logits_out;
 };
 
 __device__ __forceinline__ void iteration_head_body(const HeadArgs &a, const int b) {
@@ -61,7 +66,28 @@ __device__ __forceinline__ void iteration_head_body(const HeadArgs &a, const int
   const float *pp = perturb + (size_t)b * C * 3;
   const float *sp = sigma + (size_t)b * C;
   const float *z = logits + (size_t)b * num_class;
-  const float z_lane = z[min(lane, num_class - 1)];            // waves 0 and 1: the row, when it fits a wave
+  float z_lane;                                                // waves 0 and 1: the row, when it fits a wave
+  if (a.feat != nullptr) {  // block-uniform; requires num_class <= 64 and feat_dim <= 256 (checked by the host)
+    // wave w takes features 64 w .. 64 w + 63, lane c accumulates class c over them in ascending order (the feature is
+    // broadcast from the lane that loaded it), then the four waves are added in order and the bias last
+    __shared__ float s_z[4][64];
+    const int k = 64 * wave + lane;
+    const float f = k < a.feat_dim ? a.feat[(size_t)b * a.feat_dim + k] : 0.f;
+    const int cc = min(lane, num_class - 1);
+    float wcol[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) wcol[t] = a.Wlog[(size_t)min(64 * wave + t, a.feat_dim - 1) * num_class + cc];
+    const float bl = a.blog[cc];
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 64; ++t) acc = fmaf(__shfl(f, t, HITADV_WAVE), wcol[t], acc);  // f is 0 past feat_dim
+    s_z[wave][lane] = acc;
+    __syncthreads();
+    z_lane = ((s_z[0][lane] + s_z[1][lane]) + (s_z[2][lane] + s_z[3][lane])) + bl;
+    if (wave == 0 && lane < num_class) a.logits_out[(size_t)b * num_class + lane] = z_lane;
+  } else {
+    z_lane = z[min(lane, num_class - 1)];
+  }
   const int64_t lab = label[b];
   const float bd0 = bestdist[b], obd0 = o_bestdist[b];
   for (int e0 = 0; e0 < C * 3; e0 += 1024) {
@@ -284,7 +310,7 @@ extern "C" int hitadv_iteration_head(const float *logits, const int64_t *label, 
     return HITADV_E_ARG;
   const HeadArgs a{logits, label, perturb, sigma, adv, B, num_class, N, C, bestdist, bestscore, o_bestdist, o_bestscore,
                    o_bestattack, pred_out, dist_val_out, iter_counter, kind, kappa, loss, dlogits, scratch,
-                   reinterpret_cast<int *>(scratch + B)};
+                   reinterpret_cast<int *>(scratch + B), nullptr, nullptr, nullptr, 0, nullptr};
   iteration_head_k<<<B, 256, 0, (hipStream_t)stream>>>(a);
   HITADV_LAUNCH_CHECK();
   return 0;
@@ -297,14 +323,16 @@ extern "C" int hitadv_iteration_head_reg(const float *logits, const int64_t *lab
                                          float kappa, float *loss, float *dlogits, float *scratch, const float *ori,
                                          const float *hide_ref, const float *scale_const, float cd_w, float ker_w,
                                          float hide_w, float min_sigm, float max_sigm, float *reg_scratch, float *dist_loss,
-                                         float *scaled_loss, void *stream) {
+                                         float *scaled_loss, const float *feat, const float *Wlog, const float *blog,
+                                         int feat_dim, void *stream) {
+  if (feat != nullptr && (!Wlog || !blog || feat_dim <= 0 || feat_dim > 256 || num_class > 64)) return HITADV_E_ARG;
   if (!logits || !label || !perturb || !sigma || !adv || !bestdist || !bestscore || !o_bestdist || !o_bestscore ||
       !o_bestattack || !pred_out || !dist_val_out || !loss || !dlogits || !scratch || kind < 0 || kind > 2 || B <= 0 ||
       num_class <= 0 || N <= 0 || C <= 0 || !ori || !hide_ref || !scale_const || !reg_scratch || !dist_loss || !scaled_loss)
     return HITADV_E_ARG;
   const HeadArgs a{logits, label, perturb, sigma, adv, B, num_class, N, C, bestdist, bestscore, o_bestdist, o_bestscore,
                    o_bestattack, pred_out, dist_val_out, iter_counter, kind, kappa, loss, dlogits, scratch,
-                   reinterpret_cast<int *>(scratch + B)};
+                   reinterpret_cast<int *>(scratch + B), feat, Wlog, blog, feat_dim, const_cast<float *>(logits)};
   float *part = reg_scratch, *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
   const RegArgs g{ori, hide_ref, min_sigm, 1.0f / (max_sigm - min_sigm + 1e-7f), part,
                   RegFin{scale_const, B, cd_w, ker_w, hide_w, per_cloud, scal, dist_loss, scaled_loss}};

@@ -222,7 +222,11 @@ class _PointNetHip(torch.autograd.Function):
         g, je = lin_max(a2e, 'e3', False)
         f1 = ops.fc_layer(g, v.h1_w, v.h1_b, relu=True)
         f2 = ops.fc_layer(f1, v.h2_w, v.h2_b, relu=True)
-        logits = ops.fc_layer(f2, v.h3_w, v.h3_b)
+        if v.defer_logits:  # the caller's loss kernel evaluates the last layer itself (hitadv_iteration_head_reg) and
+            logits = E(B, v.h3_w.shape[1])  # fills this buffer; nothing else may read it before that
+            v.pending_head = (f2, v.h3_w, v.h3_b)
+        else:
+            logits = ops.fc_layer(f2, v.h3_w, v.h3_b)
         ctx.save_for_backward(x, a1s, a2s, gs, js, f4s, f5s, T3, h1, a1t, a2t, gt, jt, f4t, f5t, T64, a2e, je, f1, f2)
         ctx.view = v
         ctx.set_materialize_grads(False)
@@ -340,6 +344,8 @@ class FoldedPointNet(nn.Module):
         return self
 
     matrix_mode = 'bf16x3'  # the three 128 -> 1024 layers: 'bf16x3' (three-piece bf16 split, fp32-accurate) or 'f32'
+    defer_logits = False      # set by a caller whose loss kernel takes (features, last layer) instead of logits: see forward
+    pending_head = None
     fold_small_layers = True  # the 256 -> 9 layer inside the stage-1 kernel, the 9 / 40 -> 256 backward layers inside the
     #                           next layer's launch (False: one launch per layer, kept for A/B timing and as a cross-check)
 

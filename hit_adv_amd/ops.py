@@ -324,8 +324,9 @@ def iteration_head(logits, label, perturb, sigma, adv, state, counter, kind, kap
 
 
 def iteration_head_reg(logits, label, perturb, sigma, adv, state, counter, kind, kappa, loss_out, dlogits, scratch, ori,
-                       hide_ref, scale_const, weights, sig_range, reg_scratch, dist_out, scaled_out):
-    """``iteration_head`` and ``regulariser_fwd_fused_into`` in one launch (same results, bit for bit)."""
+                       hide_ref, scale_const, weights, sig_range, reg_scratch, dist_out, scaled_out, head=None):
+    """``iteration_head`` and ``regulariser_fwd_fused_into`` in one launch (same results, bit for bit).  ``head`` =
+    (feat [B,F], Wt [F,K], bias [K]): ``logits`` is then an OUTPUT, the classifier's last layer is evaluated inside."""
     B, K = logits.shape
     cd, ker, hide = (ctypes.c_float(float(w)) for w in weights)
     lo, hi = (ctypes.c_float(float(v)) for v in sig_range)
@@ -333,7 +334,9 @@ def iteration_head_reg(logits, label, perturb, sigma, adv, state, counter, kind,
               sigma.shape[1], _p(state["bestdist"]), _p(state["bestscore"]), _p(state["o_bestdist"]),
               _p(state["o_bestscore"]), _p(state["o_bestattack"]), _p(state["pred"]), _p(state["dist_val"]), _p(counter),
               kind, ctypes.c_float(float(kappa)), _p(loss_out), _p(dlogits), _p(scratch), _p(ori), _p(hide_ref),
-              _p(scale_const), cd, ker, hide, lo, hi, _p(reg_scratch), _p(dist_out), _p(scaled_out), _stream())
+              _p(scale_const), cd, ker, hide, lo, hi, _p(reg_scratch), _p(dist_out), _p(scaled_out),
+              _p(head[0]) if head else None, _p(head[1]) if head else None, _p(head[2]) if head else None,
+              int(head[0].shape[1]) if head else 0, _stream())
 
 
 def regulariser_fwd_fused_into(perturb, sigma, adv, ori, hide_ref, scale_const, weights, sig_range, scratch, dist_out,

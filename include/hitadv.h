@@ -394,14 +394,18 @@ int hitadv_iteration_head(const float *logits, const int64_t *label, const float
                           float *scratch, void *stream);
 /* hitadv_iteration_head and hitadv_regulariser_fwd_fused in ONE launch (blocks 0..B-1 / B..2B-1): the regularisers' forward
  * pass needs perturb, sigma and the deformed cloud only, nothing the victim produces.  Arguments: those of the two entry
- * points (scratch = the head's, reg_scratch = the regularisers'; both zeroed once by the caller); same results, bit for bit. */
+ * points (scratch = the head's, reg_scratch = the regularisers'; both zeroed once by the caller); same results, bit for bit.
+ * feat != NULL: `logits` is an OUTPUT -- the classifier's last layer (feature_models.py:91) is evaluated by the head blocks,
+ * logits[b,:] = feat[b,:feat_dim] @ Wlog[feat_dim,num_class] + blog (feat_dim <= 256, num_class <= 64; fixed summation
+ * order: 64 features per wave in ascending order, the four waves in order, the bias last), and written there. */
 int hitadv_iteration_head_reg(const float *logits, const int64_t *label, const float *perturb, const float *sigma,
                               const float *adv, int B, int num_class, int N, int C, float *bestdist, int64_t *bestscore,
                               float *o_bestdist, int64_t *o_bestscore, float *o_bestattack, int64_t *pred_out,
                               float *dist_val_out, int32_t *iter_counter, int kind, float kappa, float *loss,
                               float *dlogits, float *scratch, const float *ori, const float *hide_ref,
                               const float *scale_const, float cd_w, float ker_w, float hide_w, float min_sigm,
-                              float max_sigm, float *reg_scratch, float *dist_loss, float *scaled_loss, void *stream);
+                              float max_sigm, float *reg_scratch, float *dist_loss, float *scaled_loss, const float *feat,
+                              const float *Wlog, const float *blog, int feat_dim, void *stream);
 int64_t hitadv_iteration_head_scratch_floats(int B);
 int hitadv_regulariser_fwd_fused(const float *perturb, const float *sigma, const float *adv, const float *ori,
                                  const float *hide_ref, const float *scale_const, int B, int N, int C, float cd_w,

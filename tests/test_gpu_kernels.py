@@ -1014,6 +1014,42 @@ def test_topk_rows_bit_exact(A, K, largest):
     assert torch.equal(vals.cpu(), P.gather(-1, order.indices[..., :K]))
 
 
+def test_iteration_head_evaluates_the_classifiers_last_layer(A):
+    """hitadv_iteration_head_reg with (features, last layer) instead of logits: the logits it writes are the layer's output
+    (float64 reference), and every other output equals, bit for bit, a call that is handed those logits."""
+    g = torch.Generator().manual_seed(77)
+    B, K, F_, Np, C, dev = 32, 40, 256, 256, 24, 'cuda'
+
+    def state():
+        return dict(bestdist=torch.full((B,), 1e10, device=dev), bestscore=torch.full((B,), -1, dtype=torch.int64, device=dev),
+                    o_bestdist=torch.full((B,), 1e10, device=dev), o_bestscore=torch.full((B,), -1, dtype=torch.int64, device=dev),
+                    o_bestattack=torch.zeros(B, 3, Np, device=dev), pred=torch.zeros(B, dtype=torch.int64, device=dev),
+                    dist_val=torch.zeros(B, device=dev))
+    feat = torch.randn(B, F_, generator=g).relu()
+    W = torch.randn(F_, K, generator=g) * 0.2
+    bias = torch.randn(K, generator=g)
+    label = torch.randint(0, K, (B,), generator=g).cuda()
+    ori = cu(torch.randn(B, 3, Np, generator=g) * 0.4)
+    adv = cu(torch.randn(B, 3, Np, generator=g) * 0.4)
+    P, S = cu((torch.rand(B, C, 3, generator=g) - 0.5) * 0.5), cu(0.1 + 1.1 * torch.rand(B, C, generator=g))
+    hide_ref, scale = cu(torch.rand(B, C, generator=g)), cu(10. + 70. * torch.rand(B, generator=g))
+    regs, rng = (1e-4, 1.0, 1.0), (0.1, 1.2)
+    for kind in (A.ADV_UNTARGETED, A.ADV_TARGETED, A.ADV_CROSS_ENTROPY):
+        out = []
+        logits = torch.empty(B, K, device=dev)
+        for head in ((cu(feat), cu(W), cu(bias)), None):
+            st, cnt = state(), torch.zeros(1, dtype=torch.int32, device=dev)
+            d, loss, dl, sl = torch.empty(B, K, device=dev), torch.zeros((), device=dev), torch.zeros((), device=dev), torch.zeros((), device=dev)
+            A.iteration_head_reg(logits, label, P, S, adv, st, cnt, kind, 30., loss, d, A.iteration_head_scratch(B, dev), ori, hide_ref,
+                                 scale, regs, rng, torch.zeros(A.regulariser_scratch(B), device=dev), dl, sl, head=head)
+            out.append((d, loss, dl, sl, st))
+        close(logits, (feat.double() @ W.double() + bias.double()).float(), rtol=2e-6, atol=2e-6, what='logits evaluated in the head kernel')
+        (d0, l0, a0, b0, s0), (d1, l1, a1, b1, s1) = out
+        assert torch.equal(d0, d1) and torch.equal(l0, l1) and torch.equal(a0, a1) and torch.equal(b0, b1)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k
+
+
 # ------------------------------------------------------------------ merged launches of the iteration (csrc/iteration.hip)
 @pytest.mark.parametrize("B,K,Np,C", [(32, 40, 1024, 192), (5, 16, 130, 12), (1, 40, 64, 3)])
 def test_merged_iteration_launches_equal_the_launches_they_merge(A, B, K, Np, C):
