@@ -263,23 +263,30 @@ class HiT_ADV:
         regs = (self.cd_weight, self.ker_weight, self.hide_weight)
         rng = (self.min_sigm, self.max_sigm)
         P, sigma = ws.P.detach(), ws.sigma.detach()
-        ops.deform_fwd_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den)
+        view = self._view
+        # the PointNet engine can deform the cloud in its own first kernel (same bits as deform_fwd): one launch less
+        own_deform = (getattr(view, 'hip_engine', False) and hasattr(view, 'deform_inputs') and ws.C <= 256
+                      and getattr(view, 'fold_small_layers', False))
+        if not own_deform:
+            ops.deform_fwd_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den)
         x = ws.adv.detach().requires_grad_()
         fused = hasattr(self.adv_func, 'fused_kind')
-        # the PointNet engine can leave its last layer (256 -> classes) to the loss kernel below: one launch less
-        view = self._view
+        # ... and leave its last layer (256 -> classes) to the loss kernel below: another one
         defer = (fused and any(w != 0 for w in regs) and getattr(view, 'hip_engine', False) and hasattr(view, 'defer_logits')
                  and view.h3_w.shape[0] <= 256 and view.h3_w.shape[1] <= 64)
         head = None
+        if own_deform:
+            view.deform_inputs = (ws.ori, ws.central, P, sigma, ws.inv_den)
         if defer:
             view.defer_logits = True
-            try:
-                logits = self._logits(x, ws.feed)
-                head = view.pending_head
-            finally:
-                view.defer_logits, view.pending_head = False, None
-        else:
+        try:
             logits = self._logits(x, ws.feed)
+            head = view.pending_head if defer else None
+        finally:
+            if own_deform:
+                view.deform_inputs = None
+            if defer:
+                view.defer_logits, view.pending_head = False, None
         reg_done = False
         if hasattr(self.adv_func, 'fused_kind'):  # best-result tracking + adversarial loss: one launch
             kind, kappa = self.adv_func.fused_kind()

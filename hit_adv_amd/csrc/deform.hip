@@ -13,72 +13,18 @@
 #include "common.hpp"
 #include "hitadv.h"
 #include "regulariser_body.hpp"
+#include "deform_body.hpp"
 
 namespace hitadv {
 
-constexpr int DF_PTS = 64;    // points per block (forward)
 constexpr int DF_CMAX = 1024; // centres staged per LDS pass
-constexpr float LOG2E = 1.4426950408889634f;
 
 __global__ __launch_bounds__(256) void deform_fwd(const float *__restrict__ ori,
                                                   const float *__restrict__ central,
                                                   const float *__restrict__ perturb,
                                                   const float *__restrict__ sigma, int N, int C,
                                                   float *__restrict__ adv, float *__restrict__ inv_den) {
-  __shared__ float4 sc[DF_CMAX];  // cx cy cz a
-  __shared__ float4 sp[DF_CMAX];  // px py pz -
-  __shared__ float4 part[4][DF_PTS];
-  const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = blockIdx.x * DF_PTS + lane;
-  const int nn = n < N ? n : N - 1;
-  const float *op = ori + (size_t)b * 3 * N;
-  const float x = op[nn], y = op[N + nn], z = op[2 * N + nn];
-  float sx = 0.f, sy = 0.f, sz = 0.f, den = 0.f;
-  for (int c0 = 0; c0 < C; c0 += DF_CMAX) {
-    const int cnt = min(DF_CMAX, C - c0);
-    __syncthreads();
-    for (int j = threadIdx.x; j < cnt; j += 256) {
-      const float *cp = central + (size_t)b * 3 * C + c0 + j;
-      const float *pp = perturb + ((size_t)b * C + c0 + j) * 3;
-      const float s = sigma[(size_t)b * C + c0 + j];
-      sc[j] = make_float4(cp[0], cp[C], cp[2 * C], -LOG2E / (2.0f * s * s));
-      sp[j] = make_float4(pp[0], pp[1], pp[2], 0.f);
-    }
-    __syncthreads();
-    const int per = (cnt + 3) >> 2;
-    const int lo = wave * per, hi = min(lo + per, cnt);
-#pragma unroll 4
-    for (int j = lo; j < hi; ++j) {
-      const float4 c = sc[j];
-      const float4 p = sp[j];
-      const float r = __builtin_sqrtf(sqdist3(x, y, z, c.x, c.y, c.z));
-      const float k = exp2f(r * c.w);
-      sx = fmaf(k, p.x, sx);
-      sy = fmaf(k, p.y, sy);
-      sz = fmaf(k, p.z, sz);
-      den = den + k;
-    }
-  }
-  part[wave][lane] = make_float4(sx, sy, sz, den);
-  __syncthreads();
-  if (wave == 0 && n < N) {
-    float4 a = part[0][lane];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const float4 o = part[w][lane];
-      a.x += o.x;
-      a.y += o.y;
-      a.z += o.z;
-      a.w += o.w;
-    }
-    const float inv = 1.0f / a.w;
-    float *ap = adv + (size_t)b * 3 * N;
-    ap[n] = x + a.x * inv;
-    ap[N + n] = y + a.y * inv;
-    ap[2 * N + n] = z + a.z * inv;
-    inv_den[(size_t)b * N + n] = inv;
-  }
+  deform_fwd_body<DF_CMAX>(ori, central, perturb, sigma, N, C, adv, inv_den, blockIdx.y, blockIdx.x, nullptr);
 }
 
 // ---------------------------------------------------------------------------------- backward

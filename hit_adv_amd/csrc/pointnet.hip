@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "deform_body.hpp"
 #include "hitadv.h"
 
 namespace hitadv {
@@ -103,6 +104,12 @@ struct RowMlpFwd {
   // folded into b6), evaluated by every block of the cloud instead of by a launch of its own; tile 0 writes it to Tout
   const float *F5, *W6, *b6;
   float *Tout;
+  // stage 0, optional: the input itself is HiT-ADV's deformation of d_ori (csrc/deform_body.hpp), evaluated by this block
+  // for its 64 points instead of by a launch of its own; the deformed points go to d_adv [B,3,N] (what `x` would have held)
+  // and 1 / sum_j k to d_inv, for the backward pass
+  const float *d_ori, *d_central, *d_perturb, *d_sigma;
+  float *d_adv, *d_inv;
+  int d_C;
 };
 
 template <int STAGE>
@@ -131,7 +138,9 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
   if (STAGE < 2) {
     const int c0 = threadIdx.x & 63;
     const float w00 = a.W0[c0], w01 = a.W0[64 + c0], w02 = a.W0[128 + c0], bb = a.b0[c0];
-    if (threadIdx.x < 192) {
+    if (STAGE == 0 && a.d_ori != nullptr) {  // block-uniform
+      deform_fwd_body<256>(a.d_ori, a.d_central, a.d_perturb, a.d_sigma, N, a.d_C, a.d_adv, a.d_inv, b, blockIdx.x, sX);
+    } else if (threadIdx.x < 192) {
       const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
       sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
     }
@@ -1052,7 +1061,8 @@ extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float
   if (stage < 2 && (!x || !W0 || !b0 || !o0)) return HITADV_E_ARG;
   if (stage == 1 && (!T || !W1 || !b1 || !o1)) return HITADV_E_ARG;
   if (stage == 2 && (!T || !hin)) return HITADV_E_ARG;
-  RowMlpFwd a{x, T, hin, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, nullptr, nullptr, nullptr, nullptr};
+  RowMlpFwd a{x, T, hin, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, nullptr, nullptr, nullptr, nullptr,
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   hipStream_t s = (hipStream_t)stream;
   if (stage == 0) rowmlp_fwd_k<0><<<grid, 256, 0, s>>>(a);
@@ -1068,9 +1078,25 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, c
                                               float *o1, float *o2, int B, int N, void *stream) {
   if (B <= 0 || N <= 0 || !x || !F5 || !W6 || !b6 || !Tout || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !o0 || !o1 || !o2)
     return HITADV_E_ARG;
-  RowMlpFwd a{x, nullptr, nullptr, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, F5, W6, b6, Tout};
+  RowMlpFwd a{x, nullptr, nullptr, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, F5, W6, b6, Tout,
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   rowmlp_fwd_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *central, const float *perturb,
+                                                 const float *sigma, int C, float *adv, float *inv_den, const float *W0,
+                                                 const float *b0, const float *W2, const float *b2, float *o0, float *o2,
+                                                 int B, int N, void *stream) {
+  if (B <= 0 || N <= 0 || C <= 0 || C > 256 || !ori || !central || !perturb || !sigma || !adv || !inv_den || !W0 || !b0 ||
+      !W2 || !b2 || !o0 || !o2)
+    return HITADV_E_ARG;
+  RowMlpFwd a{adv, nullptr, nullptr, W0, b0, nullptr, nullptr, W2, b2, nullptr, o0, nullptr, o2, N, nullptr, nullptr, nullptr,
+              nullptr, ori, central, perturb, sigma, adv, inv_den, C};
+  dim3 grid((N + PM_TM - 1) / PM_TM, B);
+  rowmlp_fwd_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

@@ -198,7 +198,11 @@ class _PointNetHip(torch.autograd.Function):
                 return ops.linear_max_fwd_bf16x3(a, v.pieces(name), B, N, bias=getattr(v, name + '_b'), relu=relu)
             return ops.linear_max_fwd(a, getattr(v, name + '_w'), B, N, bias=getattr(v, name + '_b'), relu=relu)
 
-        ops.pointnet_rowmlp_fwd(0, B, N, v.s2_w, v.s2_b, a2s, x=x, W0=v.s1_w, b0=v.s1_b, o0=a1s)
+        if v.deform_inputs is not None:  # x is an OUTPUT of the first kernel: the caller's deformation, evaluated inside
+            ori, central, P, sigma, inv_den = v.deform_inputs
+            ops.pointnet_rowmlp_fwd_deform(B, N, ori, central, P, sigma, x, inv_den, v.s1_w, v.s1_b, v.s2_w, v.s2_b, a1s, a2s)
+        else:
+            ops.pointnet_rowmlp_fwd(0, B, N, v.s2_w, v.s2_b, a2s, x=x, W0=v.s1_w, b0=v.s1_b, o0=a1s)
         gs, js = lin_max(a2s, 's3', True)
         f4s = ops.fc_layer(gs, v.s4_w, v.s4_b, relu=True)
         f5s = ops.fc_layer(f4s, v.s5_w, v.s5_b, relu=True)
@@ -344,6 +348,8 @@ class FoldedPointNet(nn.Module):
         return self
 
     matrix_mode = 'bf16x3'  # the three 128 -> 1024 layers: 'bf16x3' (three-piece bf16 split, fp32-accurate) or 'f32'
+    deform_inputs = None      # (ori, central, perturb, sigma, inv_den) set by HiT-ADV's loop for ONE forward call: the input
+    #                           tensor is then produced by the engine's first kernel (hitadv_pointnet_rowmlp_fwd_deform)
     defer_logits = False      # set by a caller whose loss kernel takes (features, last layer) instead of logits: see forward
     pending_head = None
     fold_small_layers = True  # the 256 -> 9 layer inside the stage-1 kernel, the 9 / 40 -> 256 backward layers inside the

@@ -563,6 +563,16 @@ def pointnet_rowmlp_fwd_stn(B, N, x, F5, W6, b6, Tout, W0, b0, W1, b1, W2, b2, o
               _p(W2), _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, _stream())
 
 
+def pointnet_rowmlp_fwd_deform(B, N, ori, central, perturb, sigma, adv, inv_den, W0, b0, W2, b2, o0, o2):
+    """Stage 0 of the forward chain on HiT-ADV's deformation of ``ori``, evaluated inside (``adv`` and ``inv_den`` are
+    OUTPUTS: what ``deform_fwd_into`` writes)."""
+    C = sigma.shape[1]
+    if C > 256:
+        raise ValueError("the fused deformation holds at most 256 centres")
+    _lib.call("hitadv_pointnet_rowmlp_fwd_deform", _p(ori), _p(central), _p(perturb), _p(sigma), C, _p(adv), _p(inv_den),
+              _p(W0), _p(b0), _p(W2), _p(b2), _p(o0), _p(o2), B, N, _stream())
+
+
 def pointnet_rowmlp_bwd(stage, B, N, dg, idx, W3r, A2, W2r, out, gmask=None, A1=None, W1r=None, H1=None, dH1in=None,
                         W0r=None, T=None, x=None, dPin=None, dTpart=None, pres_in=None, pres_out=None):
     """``pres_in`` / ``pres_out``: int64 [B, tiles] row-presence bit sets handed from stage to stage (see hitadv.h)."""

@@ -289,6 +289,12 @@ int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const 
                                const float *b0, const float *W1, const float *b1, const float *W2, const float *b2,
                                float *xp, float *o0, float *o1, float *o2, int B, int N, void *stream);
 /* Number of 64-point tiles per cloud = leading dimension of the dTpart scratch below. */
+/* Stage 0 whose input IS HiT-ADV's deformation (hitadv_deform_fwd, ShapeAttack/HiT_ADV.py:160-175) of `ori`: every block
+ * deforms its 64 points itself (C <= 256 centres), writes them to adv [B,3,N] and 1 / sum_j k to inv_den [B,N] -- what
+ * hitadv_deform_fwd writes, bit for bit -- and goes on with them as hitadv_pointnet_rowmlp_fwd(stage = 0, x = adv). */
+int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *central, const float *perturb, const float *sigma,
+                                      int C, float *adv, float *inv_den, const float *W0, const float *b0, const float *W2,
+                                      const float *b2, float *o0, float *o2, int B, int N, void *stream);
 /* Stage 1 with the input transform evaluated inside: T3[b] = F5[b,:256] @ W6[256,9] + b6 (STN3d's last layer, :186-190,
  * the identity folded into b6) is computed by every block of the cloud (2304 multiply-adds, fixed order) and written to
  * Tout [B,9] for the backward pass; everything else as hitadv_pointnet_rowmlp_fwd(stage = 1, T = Tout). */

@@ -1014,6 +1014,26 @@ def test_topk_rows_bit_exact(A, K, largest):
     assert torch.equal(vals.cpu(), P.gather(-1, order.indices[..., :K]))
 
 
+@pytest.mark.parametrize("B,Np,C", [(32, 1024, 192), (3, 130, 7), (2, 300, 256)])
+def test_engine_first_kernel_with_the_deformation_inside(A, B, Np, C):
+    """hitadv_pointnet_rowmlp_fwd_deform == hitadv_deform_fwd followed by stage 0 of the forward chain: the deformed cloud,
+    1 / sum k and both activation tensors, bit for bit (ragged last tile included)."""
+    g = torch.Generator().manual_seed(B + Np + C)
+    ori = cu(torch.randn(B, 3, Np, generator=g) * 0.4)
+    central = ori[:, :, :C].contiguous()
+    P, S = cu((torch.rand(B, C, 3, generator=g) - 0.5) * 0.5), cu(0.1 + 1.1 * torch.rand(B, C, generator=g))
+    W0, b0, W2, b2 = cu(torch.randn(3, 64, generator=g)), cu(torch.randn(64, generator=g)), cu(torch.randn(64, 128, generator=g) * 0.2), cu(torch.randn(128, generator=g))
+    adv_a, inv_a = torch.empty_like(ori), torch.empty(B, Np, device='cuda')
+    A.deform_fwd_into(ori, central, P, S, adv_a, inv_a)
+    o0a, o2a = torch.empty(B * Np, 64, device='cuda'), torch.empty(B * Np, 128, device='cuda')
+    A.pointnet_rowmlp_fwd(0, B, Np, W2, b2, o2a, x=adv_a, W0=W0, b0=b0, o0=o0a)
+    adv_b, inv_b = torch.zeros_like(ori), torch.zeros(B, Np, device='cuda')
+    o0b, o2b = torch.empty_like(o0a), torch.empty_like(o2a)
+    A.pointnet_rowmlp_fwd_deform(B, Np, ori, central, P, S, adv_b, inv_b, W0, b0, W2, b2, o0b, o2b)
+    assert torch.equal(adv_a, adv_b) and torch.equal(inv_a, inv_b)
+    assert torch.equal(o0a, o0b) and torch.equal(o2a, o2b)
+
+
 def test_iteration_head_evaluates_the_classifiers_last_layer(A):
     """hitadv_iteration_head_reg with (features, last layer) instead of logits: the logits it writes are the layer's output
     (float64 reference), and every other output equals, bit for bit, a call that is handed those logits."""
