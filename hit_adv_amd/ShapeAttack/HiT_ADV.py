@@ -309,7 +309,9 @@ class HiT_ADV:
                 ops.regulariser_fwd_fused_into(P, sigma, ws.adv, ws.ori, ws.hide_ref, ws.scale_const, regs, rng,
                                                ws.reg_scratch, ws.dist_loss, ws.scaled)
             # the regularisers' backward terms are closed-form in what the next two kernels read anyway: evaluated inside
-            # them (same bits as regulariser_bwd_add), no launch of their own
+            # them (same bits as regulariser_bwd_add), no launch of their own.  (ops.deform_bwd_adam_reg runs the Adam step
+            # as the tail of the deformation's backward kernel, one launch for both: measured 4 us SLOWER per iteration --
+            # the hand-off and the last block's serial tail cost more than the kernel boundary -- so two launches stay.)
             ops.deform_bwd_partials_reg_into(ws.ori, ws.central, P, sigma, ws.adv, ws.inv_den, g_victim.contiguous(),
                                              ws.reg_scratch, regs, ws.deform_part)
             ops.adam_step_partials_reg(P, sigma, ws.deform_part, ws.N, ws.hide_ref, ws.reg_scratch, regs, rng, ws.m_p, ws.v_p,

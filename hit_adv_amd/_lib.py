@@ -53,6 +53,8 @@ PROTOTYPES = {
     "hitadv_deform_bwd_slabs": [_I],
     "hitadv_adam_step_partials": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _P, _P],
     "hitadv_deform_bwd_partials_reg": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P],
+    "hitadv_deform_bwd_adam_reg": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _I, _I, _F, _F,
+                                   _F, _F, _F, _F, _P, _P, _P, _P],
     "hitadv_adam_step_partials_reg": [_P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F,
                                       _F, _F, _P, _P],
     "hitadv_linear_max_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],

@@ -14,6 +14,7 @@
 #include "hitadv.h"
 #include "regulariser_body.hpp"
 #include "deform_body.hpp"
+#include "adam_body.hpp"
 
 namespace hitadv {
 
@@ -34,16 +35,22 @@ __global__ __launch_bounds__(256) void deform_fwd(const float *__restrict__ ori,
 //   dL/dsig_j   = sum_n dL/dk[n,j] * k[n,j] * r[n,j] / sig_j^3
 constexpr int DB_PTS = 64;  // points per slab
 
+struct AdamTail {
+  int *tickets;  // [B], zeroed once by the caller; nullptr = no tail
+  AdamArgs adam;
+};
+
 __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
                                                   const float *__restrict__ central,
-                                                  const float *__restrict__ perturb,
-                                                  const float *__restrict__ sigma,
+                                                  const float *perturb,  // (no __restrict__: the Adam tail writes them)
+                                                  const float *sigma,
                                                   const float *__restrict__ adv,
                                                   const float *__restrict__ inv_den,
                                                   const float *__restrict__ g_adv, int N, int C,
-                                                  int nslab, float *__restrict__ partials, RegGrad rg) {
+                                                  int nslab, float *partials, RegGrad rg, AdamTail tail) {
   __shared__ float4 sxyz[DB_PTS];  // x y z cn
   __shared__ float4 sg[DB_PTS];    // gDx gDy gDz -
+  __shared__ int s_last;
   const int b = blockIdx.z, slab = blockIdx.y;
   const int n0 = slab * DB_PTS;
   const int cnt = min(DB_PTS, N - n0);
@@ -83,11 +90,11 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
     sg[threadIdx.x] = g;
   }
   __syncthreads();
-  if (j >= C) return;
+  if (j >= C && tail.tickets == nullptr) return;
   const float a2 = -LOG2E / (2.0f * s * s);
   float apx = 0.f, apy = 0.f, apz = 0.f, asg = 0.f;
 #pragma unroll 4
-  for (int t = 0; t < cnt; ++t) {
+  for (int t = 0; t < (j < C ? cnt : 0); ++t) {
     const float4 pt = sxyz[t];
     const float4 g = sg[t];
     const float r = __builtin_sqrtf(sqdist3(pt.x, pt.y, pt.z, cx, cy, cz));
@@ -99,10 +106,25 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
     asg = fmaf(dk * k, r, asg);
   }
   float *out = partials + (((size_t)b * nslab + slab) * 4) * C + j;
-  out[0] = apx;
-  out[C] = apy;
-  out[2 * C] = apz;
-  out[3 * C] = asg / (s * s * s);
+  if (tail.tickets == nullptr) {
+    out[0] = apx;
+    out[C] = apy;
+    out[2 * C] = apz;
+    out[3 * C] = asg / (s * s * s);
+    return;
+  }
+  // With an Adam tail: the partials are written through, the blocks of the cloud (all slabs, all centre groups) draw a
+  // ticket, and the last one to arrive runs the update for the cloud's centres -- every block of the cloud has read
+  // perturb / sigma long before (hand-off protocol: common.hpp).  The ticket goes back to zero.
+  if (j < C) {
+    __hip_atomic_store(out, apx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + C, apy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 2 * C, apz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(out + 3 * C, asg / (s * s * s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!handoff_last_arriver(tail.tickets, b, nslab * (int)gridDim.x, &s_last)) return;
+  for (int jj = threadIdx.x; jj < C; jj += 256) adam_partials_body<true>(tail.adam, b, jj);
+  if (threadIdx.x == 0) __hip_atomic_store(&tail.tickets[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void deform_bwd_reduce(const float *__restrict__ partials, int C,
@@ -157,7 +179,7 @@ extern "C" int hitadv_deform_bwd_partials(const float *ori, const float *central
     return HITADV_E_ARG;
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
   dim3 grid((C + 255) / 256, nslab, B);
-  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{});
+  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{}, AdamTail{});
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -173,7 +195,31 @@ extern "C" int hitadv_deform_bwd_partials_reg(const float *ori, const float *cen
   const RegGrad rg{per_cloud, scal, nullptr, cd_w, 0.f, 0.f, 0.f, 0.f, B};
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
   dim3 grid((C + 255) / 256, nslab, B);
-  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials, rg);
+  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials, rg, AdamTail{});
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_deform_bwd_adam_reg(const float *ori, const float *central, float *perturb, float *sigma,
+                                          const float *adv, const float *inv_den, const float *g_victim,
+                                          const float *hide_ref, const float *reg_scratch, float cd_w, float ker_w,
+                                          float hide_w, float min_sigm, float max_sigm, float *m_perturb, float *v_perturb,
+                                          float *m_sigma, float *v_sigma, int B, int N, int C, float lr_perturb,
+                                          float lo_perturb, float hi_perturb, float lr_sigma, float lo_sigma, float hi_sigma,
+                                          const int32_t *step, float *partials, int32_t *tickets, void *stream) {
+  if (!ori || !central || !perturb || !sigma || !adv || !inv_den || !g_victim || !hide_ref || !reg_scratch || !m_perturb ||
+      !v_perturb || !m_sigma || !v_sigma || !step || !partials || !tickets || B <= 0 || N <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  const float *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
+  const RegGrad rg_adv{per_cloud, scal, nullptr, cd_w, 0.f, 0.f, 0.f, 0.f, B};
+  const RegGrad rg{per_cloud, scal, hide_ref, cd_w, ker_w, hide_w, min_sigm, 1.0f / (max_sigm - min_sigm + 1e-7f), B};
+  const int nslab = (N + DB_PTS - 1) / DB_PTS;
+  const AdamTail tail{tickets, AdamArgs{perturb, sigma, partials, nslab, nullptr, nullptr, m_perturb, v_perturb, m_sigma,
+                                        v_sigma, B, C, lr_perturb, lo_perturb, hi_perturb, lr_sigma, lo_sigma, hi_sigma, step,
+                                        rg}};
+  dim3 grid((C + 255) / 256, nslab, B);
+  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials,
+                                                    rg_adv, tail);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -188,7 +234,7 @@ extern "C" int hitadv_deform_bwd(const float *ori, const float *central, const f
   hipStream_t s = (hipStream_t)stream;
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
   dim3 grid((C + 255) / 256, nslab, B);
-  deform_bwd<<<grid, 256, 0, s>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{});
+  deform_bwd<<<grid, 256, 0, s>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{}, AdamTail{});
   dim3 grid2((C + 255) / 256, B);
   deform_bwd_reduce<<<grid2, 256, 0, s>>>(partials, C, nslab, grad_perturb, grad_sigma);
   HITADV_LAUNCH_CHECK();

@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "hitadv.h"
 #include "regulariser_body.hpp"
+#include "adam_body.hpp"
 
 namespace hitadv {
 
@@ -227,70 +228,12 @@ __global__ __launch_bounds__(256) void iteration_head_reg_k(HeadArgs a, RegArgs 
                       (int)blockIdx.x - a.B);
 }
 
-// Adam on (perturb [B,C,3], sigma [B,C]) with the deformation's gradient still in its per-slab partials
-// [B,nslab,4,C] (summed here in ascending slab order = deform_bwd_reduce's order) plus an optional second term, then the
-// projection of adam2_k.  One thread per (cloud, centre).
-__global__ __launch_bounds__(256) void adam_partials_k(float *__restrict__ P, float *__restrict__ S,
-                                                       const float *__restrict__ partials, int nslab,
-                                                       const float *__restrict__ hP, const float *__restrict__ hS,
-                                                       float *__restrict__ mP, float *__restrict__ vP,
-                                                       float *__restrict__ mS, float *__restrict__ vS, int B, int C,
-                                                       float lrP, float loP, float hiP, float lrS, float loS, float hiS,
-                                                       const int32_t *__restrict__ step, RegGrad rg) {
+// Adam on (perturb [B,C,3], sigma [B,C]) with the deformation's gradient still in its per-slab partials: adam_body.hpp.
+// One thread per (cloud, centre).
+__global__ __launch_bounds__(256) void adam_partials_k(AdamArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= B * C) return;
-  const int b = e / C, j = e % C;
-  // the state the update needs is requested first, then the slab partials eight slabs at a time (32 loads in flight,
-  // added in ascending slab order): one round trip each instead of one per slab and per state word
-  const int t = *step;
-  float m0[4], v0[4], p0[4], h0[4];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const size_t i = (size_t)e * 3 + c;
-    m0[c] = mP[i]; v0[c] = vP[i]; p0[c] = P[i];
-    h0[c] = (hP ? hP : P)[i];  // a pointer select: no load under a condition
-  }
-  m0[3] = mS[e]; v0[3] = vS[e]; p0[3] = S[e];
-  h0[3] = (hS ? hS : S)[e];
-  const bool reg = rg.per_cloud != nullptr;  // the regularisers' gradients evaluated here instead of read (hP = hS = nullptr then)
-  const float href = reg ? rg.hide_ref[e] : 0.f;
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; s0 < nslab; s0 += 8) {
-    float q[8][4];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const float *p = partials + (((size_t)b * nslab + min(s0 + s, nslab - 1)) * 4) * C + j;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) q[s][c] = p[c * C];
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) g[c] += s0 + s < nslab ? q[s][c] : 0.f;
-  }
-  const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
-  const double bc1 = 1.0 - pow(beta1, (double)t);
-  const double bc2 = 1.0 - pow(beta2, (double)t);
-  const float bc2_sqrt = (float)sqrt(bc2);
-  auto upd = [&](float *p, float *m, float *v, size_t i, int c, float gi, double lr, float lo, float hi) {
-    const float step_size = (float)(lr / bc1);
-    const float mi = m0[c] + (gi - m0[c]) * (float)(1.0 - beta1);
-    const float vi = v0[c] * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = __builtin_sqrtf(vi) / bc2_sqrt + (float)eps;
-    float q = p0[c] - (step_size * mi) / denom;
-    if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);
-    p[i] = q;
-  };
-  if (reg) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) h0[c] = reg_grad_perturb(rg, C, p0[c]);
-    h0[3] = reg_grad_sigma(rg, C, b, p0[3], href);
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) upd(P, mP, vP, (size_t)e * 3 + c, c, (hP || reg) ? g[c] + h0[c] : g[c], (double)lrP, loP, hiP);
-  upd(S, mS, vS, (size_t)e, 3, (hS || reg) ? g[3] + h0[3] : g[3], (double)lrS, loS, hiS);
+  if (e >= a.B * a.C) return;
+  adam_partials_body<false>(a, e / a.C, e % a.C);
 }
 
 }  // namespace hitadv
@@ -349,10 +292,7 @@ extern "C" int hitadv_adam_step_partials(float *perturb, float *sigma, const flo
   if (!perturb || !sigma || !partials || !m_perturb || !v_perturb || !m_sigma || !v_sigma || !step || nslab <= 0 ||
       B <= 0 || C <= 0)
     return HITADV_E_ARG;
-  adam_partials_k<<<(B * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(perturb, sigma, partials, nslab, g_perturb2,
-                                                                        g_sigma2, m_perturb, v_perturb, m_sigma, v_sigma, B,
-                                                                        C, lr_perturb, lo_perturb, hi_perturb, lr_sigma,
-                                                                        lo_sigma, hi_sigma, step, RegGrad{});
+  adam_partials_k<<<(B * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(AdamArgs{perturb, sigma, partials, nslab, g_perturb2, g_sigma2, m_perturb, v_perturb, m_sigma, v_sigma, B, C, lr_perturb, lo_perturb, hi_perturb, lr_sigma, lo_sigma, hi_sigma, step, RegGrad{}});
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -368,10 +308,7 @@ extern "C" int hitadv_adam_step_partials_reg(float *perturb, float *sigma, const
     return HITADV_E_ARG;
   const float *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
   const RegGrad rg{per_cloud, scal, hide_ref, cd_w, ker_w, hide_w, min_sigm, 1.0f / (max_sigm - min_sigm + 1e-7f), B};
-  adam_partials_k<<<(B * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(perturb, sigma, partials, nslab, nullptr, nullptr,
-                                                                        m_perturb, v_perturb, m_sigma, v_sigma, B, C,
-                                                                        lr_perturb, lo_perturb, hi_perturb, lr_sigma,
-                                                                        lo_sigma, hi_sigma, step, rg);
+  adam_partials_k<<<(B * C + 255) / 256, 256, 0, (hipStream_t)stream>>>(AdamArgs{perturb, sigma, partials, nslab, nullptr, nullptr, m_perturb, v_perturb, m_sigma, v_sigma, B, C, lr_perturb, lo_perturb, hi_perturb, lr_sigma, lo_sigma, hi_sigma, step, rg});
   HITADV_LAUNCH_CHECK();
   return 0;
 }

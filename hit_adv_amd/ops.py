@@ -364,6 +364,20 @@ def deform_bwd_partials_reg_into(ori, central, perturb, sigma, adv, inv_den, g_v
               _stream())
 
 
+def deform_bwd_adam_reg(ori, central, perturb, sigma, adv, inv_den, g_victim, hide_ref, reg_scratch, weights, sig_range, m_p,
+                        v_p, m_s, v_s, step, lr_p, lr_s, clamp_p, clamp_s, partials, tickets):
+    """``deform_bwd_partials_reg_into`` and ``adam_step_partials_reg`` in one launch (same bits); ``tickets``: int32 [B],
+    zeroed once."""
+    B, _, N = ori.shape
+    cd, ker, hide = (ctypes.c_float(float(w)) for w in weights)
+    lo, hi = (ctypes.c_float(float(v)) for v in sig_range)
+    _lib.call("hitadv_deform_bwd_adam_reg", _p(ori), _p(central), _p(perturb), _p(sigma), _p(adv), _p(inv_den), _p(g_victim),
+              _p(hide_ref), _p(reg_scratch), cd, ker, hide, lo, hi, _p(m_p), _p(v_p), _p(m_s), _p(v_s), B, N,
+              central.shape[2], ctypes.c_float(lr_p), ctypes.c_float(clamp_p[0]), ctypes.c_float(clamp_p[1]),
+              ctypes.c_float(lr_s), ctypes.c_float(clamp_s[0]), ctypes.c_float(clamp_s[1]), _p(step), _p(partials),
+              _p(tickets), _stream())
+
+
 def adam_step_partials_reg(perturb, sigma, partials, N, hide_ref, reg_scratch, weights, sig_range, m_p, v_p, m_s, v_s, step,
                            lr_p, lr_s, clamp_p, clamp_s):
     """``adam_step_partials`` that evaluates the regularisers' gradients at (perturb, sigma) itself (``regulariser_bwd_add``'s

@@ -432,6 +432,15 @@ int hitadv_adam_step_partials(float *perturb, float *sigma, const float *partial
 int hitadv_deform_bwd_partials_reg(const float *ori, const float *central, const float *perturb, const float *sigma,
                                    const float *adv, const float *inv_den, const float *g_victim,
                                    const float *reg_scratch, float cd_w, int B, int N, int C, float *partials, void *stream);
+/* Both of them in ONE launch: the blocks of a cloud draw a ticket after publishing their partials and the last one to
+ * arrive runs the Adam step for the cloud's centres (tickets: int32 [B], zeroed once by the caller, left at zero). */
+int hitadv_deform_bwd_adam_reg(const float *ori, const float *central, float *perturb, float *sigma, const float *adv,
+                               const float *inv_den, const float *g_victim, const float *hide_ref,
+                               const float *reg_scratch, float cd_w, float ker_w, float hide_w, float min_sigm,
+                               float max_sigm, float *m_perturb, float *v_perturb, float *m_sigma, float *v_sigma, int B,
+                               int N, int C, float lr_perturb, float lo_perturb, float hi_perturb, float lr_sigma,
+                               float lo_sigma, float hi_sigma, const int32_t *step, float *partials, int32_t *tickets,
+                               void *stream);
 int hitadv_adam_step_partials_reg(float *perturb, float *sigma, const float *partials, int nslab, const float *hide_ref,
                                   const float *reg_scratch, float cd_w, float ker_w, float hide_w, float min_sigm,
                                   float max_sigm, float *m_perturb, float *v_perturb, float *m_sigma, float *v_sigma, int B,

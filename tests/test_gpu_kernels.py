@@ -1102,6 +1102,10 @@ def test_merged_iteration_launches_equal_the_launches_they_merge(A, B, K, Np, C)
         Sa = cu(0.1 + 1.1 * torch.rand(B, C, generator=g))
         Pb, Sb = Pa.clone(), Sa.clone()
         Pc, Sc = Pa.clone(), Sa.clone()
+        Pd, Sd = Pa.clone(), Sa.clone()
+        md = [torch.zeros_like(Pa), torch.zeros_like(Pa), torch.zeros_like(Sa), torch.zeros_like(Sa)]
+        part_d = torch.empty(A.deform_bwd_scratch(B, Np, C), device=dev)
+        tickets_d = torch.zeros(B, dtype=torch.int32, device=dev)
         ma = [torch.zeros_like(Pa), torch.zeros_like(Pa), torch.zeros_like(Sa), torch.zeros_like(Sa)]
         mb = [t.clone() for t in ma]
         mc = [t.clone() for t in ma]
@@ -1146,6 +1150,12 @@ def test_merged_iteration_launches_equal_the_launches_they_merge(A, B, K, Np, C)
             A.deform_bwd_partials_reg_into(ori, central, Pc, Sc, adv, inv, up, reg_a, regs, part_c)
             A.adam_step_partials_reg(Pc, Sc, part_c, Np, hide_ref, reg_a, regs, rng, *mc, cb, 0.05, 0.03, (-0.55, 0.55), rng)
             assert torch.equal(part_c, part_b)
+            # ... and both of them as ONE launch (the Adam step as the tail of the deformation's backward; state copy d)
+            A.deform_bwd_adam_reg(ori, central, Pd, Sd, adv, inv, up, hide_ref, reg_a, regs, rng, *md, cb, 0.05, 0.03, (-0.55, 0.55), rng,
+                                  part_d, tickets_d)
+            assert torch.equal(part_d, part_b) and torch.equal(Pd, Pc) and torch.equal(Sd, Sc) and int(tickets_d.abs().sum()) == 0
+            for x, y in zip(mc, md):
+                assert torch.equal(x, y)
             assert torch.equal(Pa, Pb) and torch.equal(Sa, Sb) and torch.equal(Pa, Pc) and torch.equal(Sa, Sc)
             for x, y, z in zip(ma, mb, mc):
                 assert torch.equal(x, y) and torch.equal(x, z)
