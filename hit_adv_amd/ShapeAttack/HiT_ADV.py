@@ -282,6 +282,8 @@ class HiT_ADV:
         try:
             logits = self._logits(x, ws.feed)
             head = view.pending_head if defer else None
+            if own_deform and view.deform_inputs is not None:  # the forward pass did not go through the engine's kernel
+                raise RuntimeError("the victim was asked to deform the cloud in its first kernel and did not")
         finally:
             if own_deform:
                 view.deform_inputs = None

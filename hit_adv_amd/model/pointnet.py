@@ -200,6 +200,7 @@ class _PointNetHip(torch.autograd.Function):
 
         if v.deform_inputs is not None:  # x is an OUTPUT of the first kernel: the caller's deformation, evaluated inside
             ori, central, P, sigma, inv_den = v.deform_inputs
+            v.deform_inputs = None  # consumed: the caller checks this
             ops.pointnet_rowmlp_fwd_deform(B, N, ori, central, P, sigma, x, inv_den, v.s1_w, v.s1_b, v.s2_w, v.s2_b, a1s, a2s)
         else:
             ops.pointnet_rowmlp_fwd(0, B, N, v.s2_w, v.s2_b, a2s, x=x, W0=v.s1_w, b0=v.s1_b, o0=a1s)
