@@ -153,8 +153,11 @@ def roofline_pairwise(dev, B=32, N=1024):
 
 
 def roofline_knn_features(dev, B=32, N=1024, D=64, k=5):
-    """cfg3's dominant own kernel: DGCNN's feature-space kNN graph (scores on the f32 matrix cores, selection in the
-    same launch); 2*B*N*N*D flop per launch, three launches per forward (D = 64, 64, 128)."""
+    """cfg3's dominant own kernel: DGCNN's feature-space kNN graph (scores on the bf16 matrix cores at fp32 accuracy --
+    both operands as three bf16 pieces, six MFMAs per 16 values of k, fp32 accumulator -- selection in the same launch);
+    2*B*N*N*D useful flop per launch (6x that executed), three launches per forward (D = 64, 64, 128).  `achieved` /
+    `peak` / `frac` price the USEFUL flops against the f32 matrix peak, the yardstick of an fp32-accurate product; the
+    executed bf16 rate is given beside it."""
     from hit_adv_amd import _lib
     lib = _lib.load()
     f = torch.randn(B, N, D, device=dev)
@@ -165,7 +168,8 @@ def roofline_knn_features(dev, B=32, N=1024, D=64, k=5):
     ach = flops / us / 1e6
     return dict(kernel="knn_feat_k<%d,%d> (hitadv_knn_features, B=%d, N=%d)" % (D, k, B, N), bound="mfma",
                 achieved=round(ach, 1), peak=F32_MFMA_PEAK, unit="TFLOP/s", frac=round(ach / F32_MFMA_PEAK, 4), traffic=None,
-                us_per_launch=round(us, 2), flops_per_launch=flops, dtype="f32")
+                us_per_launch=round(us, 2), flops_per_launch=flops, dtype="3 x bf16 -> f32",
+                executed_bf16_tflops=round(6 * ach, 1), peak_bf16=2500.0, frac_of_bf16_peak=round(6 * ach / 2500.0, 4))
 
 
 def roofline_group_add_relu(dev, B, N, S, ns, C, what):

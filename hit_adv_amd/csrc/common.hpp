@@ -53,6 +53,34 @@ __device__ __forceinline__ bool handoff_last_arriver(int *tickets, int slot, int
   return last;
 }
 
+// ---- an fp32 value as three bf16 pieces (csrc/victim_bf3.hip, csrc/knn.hip: fp32-accurate products on the bf16 MFMAs)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast(bf16x8, u); }
+
+// a = hi + mid + lo exactly, each the bf16 truncation of what is left (upper 16 bits of an fp32 = a bf16)
+__device__ __forceinline__ void split3(float a, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+  hi = __float_as_uint(a) & 0xffff0000u;
+  const float r1 = a - __uint_as_float(hi);
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mid);
+  lo = __float_as_uint(r2);  // at most 8 significant bits are left: its lower 16 bits are zero
+}
+
+__device__ __forceinline__ uint32_t pack_hi(uint32_t even, uint32_t odd) {  // two bf16 (upper halves) -> one dword
+  return (even >> 16) | (odd & 0xffff0000u);
+}
+
+// eight consecutive floats -> their three pieces, eight bf16 (one uint4) each
+__device__ __forceinline__ void split3x8(const float4 &lo4, const float4 &hi4, uint4 &p1, uint4 &p2, uint4 &p3) {
+  const float a[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+  uint32_t h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split3(a[i], h[i], m[i], l[i]);
+  p1 = make_uint4(pack_hi(h[0], h[1]), pack_hi(h[2], h[3]), pack_hi(h[4], h[5]), pack_hi(h[6], h[7]));
+  p2 = make_uint4(pack_hi(m[0], m[1]), pack_hi(m[2], m[3]), pack_hi(m[4], m[5]), pack_hi(m[6], m[7]));
+  p3 = make_uint4(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]), pack_hi(l[4], l[5]), pack_hi(l[6], l[7]));
+}
+
 // Canonical squared distance: ((dx*dx + dy*dy) + dz*dz), one fp32 rounding per operation.
 // The translation unit is built with -ffp-contract=off so nothing here fuses into an FMA.
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {

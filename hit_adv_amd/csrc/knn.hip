@@ -660,39 +660,46 @@ extern "C" int hitadv_knn_points_bwd(const float *q, const float *p, const void 
 // ---------------------------------------------------------------------------------------------------
 // k nearest neighbours in FEATURE space (DGCNN's dynamic graph, model/dgcnn_cls.py:7-13) without the [B,N,N] score
 // matrix: scores  s_ij = (-|x_i|^2 + 2 x_i.x_j) - |x_j|^2  (the reference's expression, larger = closer) come out of the
-// f32 matrix cores tile by tile and go straight into per-lane sorted lists.
-//   block = 8 waves = 128 queries of one cloud; reference points stream through LDS 64 at a time (two 32-point tiles,
-//   double buffered, shared by the waves); waves w and w+4 hold the same 32 queries' features in registers as the MFMA
+// matrix cores tile by tile and go straight into per-lane sorted lists.
+//   block = 8 waves = 128 queries of one cloud; reference points stream through LDS 128 (D = 64) or 64 (D = 128) at a time
+//   (32-point tiles, double buffered, shared by the waves); waves w and w+4 hold the same 32 queries' features in registers as the MFMA
 //   B operand and take the even / odd tile, so the accumulator has the QUERY on the lane and 16 reference points in
 //   registers: a lane scans its 16 scores against its own list (KB entries, compile-time indices, no scratch).  Each
 //   query is served by four lanes (two waves x the halves of a wave, disjoint reference rows), so a list sees a quarter
 //   of the candidates; the four lists are merged at the end.  Ties -> lower index.
-//   Measured at B=32, N=1024, K=5 (tools/tune/knnfeat_tune.hip): D=64 74 us, of which 47 is the bare MFMA + staging loop
-//   and 27 the selection (VALU time adds to f32-MFMA time on this chip, see below); D=128 111 us (87 + 24).
+//   Measured at B=32, N=1024, K=5 with f32 MFMAs (tools/tune/knnfeat_tune.hip): D=64 74 us, of which 47 the bare MFMA +
+//   staging loop and 27 the selection (VALU time adds to MFMA time on this chip, see below); D=128 111 us (87 + 24).  The
+//   scores now come from the bf16 matrix cores at fp32 accuracy (three-piece split, below).
 namespace hitadv {
 
 typedef float f32x16_k __attribute__((ext_vector_type(16)));
 
-#ifndef KF_SUB
-#define KF_SUB 2  // 32-point tiles per wave per step: a step stages KF_STEP = 64 * KF_SUB reference points
-#endif
-#define KF_STEP (64 * KF_SUB)
-// LDS floats of knn_feat_k: the double-buffered reference tiles (2 x KF_STEP points) or, after the scan, the 4 x 128 lists
-__host__ __device__ constexpr int knn_feat_main_floats(int D, int KB) {
-  return 2 * KF_STEP * (D + 4) > 128 * 4 * KB * 2 ? 2 * KF_STEP * (D + 4) : 128 * 4 * KB * 2;
+// Scores on the bf16 matrix cores at fp32 accuracy (the three-piece split of csrc/victim_bf3.hip: both operands carried as
+// three bf16 numbers that sum to the fp32 value exactly, six MFMAs per 16 values of k in an fp32 accumulator): 2.7x less
+// matrix time than v_mfma_f32_32x32x2_f32.  The 32x32 output shape is kept, so the scan below is unchanged.
+//   references: fp32 -> registers -> split -> three bf16 LDS images per buffer (row stride 2 D + 16 bytes: conflict-free
+//               ds_read_b128), KF_STEP(D) = 128 (D = 64) or 64 (D = 128) points per step, double buffered;
+//   queries   : the lane's query row as the B operand, three pieces x D/16 slices in registers for the whole kernel.
+__host__ __device__ constexpr int kf_step(int D) { return D <= 64 ? 128 : 64; }
+__host__ __device__ constexpr int kf_row_bytes(int D) { return 2 * D + 16; }
+// LDS bytes of knn_feat_k: the double-buffered reference images (2 x 3 x KF_STEP rows) or, after the scan, the 4 x 128 lists
+__host__ __device__ constexpr int knn_feat_main_bytes(int D, int KB) {
+  return 2 * 3 * kf_step(D) * kf_row_bytes(D) > 128 * 4 * KB * 2 * 4 ? 2 * 3 * kf_step(D) * kf_row_bytes(D) : 128 * 4 * KB * 2 * 4;
 }
 __host__ __device__ constexpr int knn_feat_lds_bytes(int D, int KB) {
-  return (knn_feat_main_floats(D, KB) + 2 * KF_STEP) * 4;
+  return knn_feat_main_bytes(D, KB) + 2 * kf_step(D) * 4;
 }
 
 template <int D, int KB>
 __global__ __launch_bounds__(512) void knn_feat_k(const float *__restrict__ X, const float *__restrict__ xx, int N, int K,
                                                   int64_t *__restrict__ idx) {
-  constexpr int LD = D + 4;
-  constexpr int ST = KF_STEP * (D / 4) / 512;  // float4 staged per thread per step
-  extern __shared__ float4 knn_feat_sm[];  // knn_feat_lds_bytes<D,KB>(): max(reference tiles, final merge) + |x|^2
-  float *sR = reinterpret_cast<float *>(knn_feat_sm);
-  float(*sXX)[KF_STEP] = reinterpret_cast<float(*)[KF_STEP]>(sR + knn_feat_main_floats(D, KB));
+  constexpr int STEP = kf_step(D), SUB = STEP / 64;  // reference points per step; 32-point tiles per wave per step
+  constexpr int RS = kf_row_bytes(D), PIECE = STEP * RS, NSL = D / 16;
+  constexpr int ST = STEP * (D / 8) / 512;  // groups of 8 values staged per thread per step
+  extern __shared__ float4 knn_feat_sm[];  // knn_feat_lds_bytes<D,KB>(): max(reference images, final merge) + |x|^2
+  char *sB = reinterpret_cast<char *>(knn_feat_sm);
+  float *sR = reinterpret_cast<float *>(knn_feat_sm);  // the merge buffers alias the images once the scan is over
+  float(*sXX)[STEP] = reinterpret_cast<float(*)[STEP]>(sB + knn_feat_main_bytes(D, KB));
   const int b = blockIdx.y, q0 = blockIdx.x * 128;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int qg = wave & 3, half = wave >> 2;  // query group; which tile of a step
@@ -701,9 +708,12 @@ __global__ __launch_bounds__(512) void knn_feat_k(const float *__restrict__ X, c
   xx += (size_t)b * N;
   const int q = q0 + 32 * qg + r;         // this lane's query
   const int qc = q < N ? q : N - 1;       // clamp for loads
-  float qreg[D / 2];
+  uint4 qw[3][NSL];  // B operand: column = the query, k = 16 j + 8 h .. + 7, three pieces
 #pragma unroll
-  for (int t = 0; t < D / 2; ++t) qreg[t] = X[(size_t)qc * D + 8 * (t >> 2) + 4 * h + (t & 3)];
+  for (int j = 0; j < NSL; ++j) {
+    const float *src = X + (size_t)qc * D + 16 * j + 8 * h;
+    split3x8(*reinterpret_cast<const float4 *>(src), *reinterpret_cast<const float4 *>(src + 4), qw[0][j], qw[1][j], qw[2][j]);
+  }
   const float qxx = xx[qc];
   float lv[KB];
   int li[KB];
@@ -747,51 +757,63 @@ __global__ __launch_bounds__(512) void knn_feat_k(const float *__restrict__ X, c
       if (np > t) insert(pv[t], pj[t]);
     np = 0;
   };
-  const int ntiles = (N + 31) / 32, nsteps = (N + KF_STEP - 1) / KF_STEP;
-  float4 st[ST];
+  const int ntiles = (N + 31) / 32, nsteps = (N + STEP - 1) / STEP;
+  float4 st[ST][2];
   float stx = 0.f;
   auto fetch = [&](int step) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
-      const int n = step * KF_STEP + e / (D / 4);
-      st[u] = n < N ? *reinterpret_cast<const float4 *>(X + (size_t)n * D + 4 * (e % (D / 4))) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int n = min(step * STEP + e / (D / 8), N - 1);  // rows past N read row N - 1: their |x|^2 of +inf keeps them out
+      const float *src = X + (size_t)n * D + 8 * (e % (D / 8));
+      st[u][0] = *reinterpret_cast<const float4 *>(src);
+      st[u][1] = *reinterpret_cast<const float4 *>(src + 4);
     }
-    if (threadIdx.x < KF_STEP) stx = step * KF_STEP + threadIdx.x < N ? xx[step * KF_STEP + threadIdx.x] : __builtin_inff();
+    if (threadIdx.x < STEP) stx = step * STEP + threadIdx.x < N ? xx[step * STEP + threadIdx.x] : __builtin_inff();
   };
   auto stash = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
-      *reinterpret_cast<float4 *>(sR + buf * KF_STEP * LD + (e / (D / 4)) * LD + 4 * (e % (D / 4))) = st[u];
+      uint4 p1, p2, p3;
+      split3x8(st[u][0], st[u][1], p1, p2, p3);
+      char *dst = sB + (size_t)buf * 3 * PIECE + (e / (D / 8)) * RS + 16 * (e % (D / 8));
+      *reinterpret_cast<uint4 *>(dst) = p1;
+      *reinterpret_cast<uint4 *>(dst + PIECE) = p2;
+      *reinterpret_cast<uint4 *>(dst + 2 * PIECE) = p3;
     }
-    if (threadIdx.x < KF_STEP) sXX[buf][threadIdx.x] = stx;
+    if (threadIdx.x < STEP) sXX[buf][threadIdx.x] = stx;
   };
   fetch(0);
   stash(0);
   __syncthreads();
-  // f32 MFMAs and VALU instructions do not overlap on gfx950 (tools/tune/mfma_valu_overlap.hip: V fmas between two
-  // dependent MFMAs add their full 4 cycles each, at one and at two waves per SIMD), so the selection's VALU work is
-  // paid on top of the matrix time whatever the schedule; it simply follows the tile's products.
+  // MFMA and VALU instructions of one wave do not overlap on gfx950 (tools/tune/mfma_valu_overlap.hip), so the selection's
+  // VALU work is paid on top of the matrix time whatever the schedule; it simply follows the tile's products.
   for (int step = 0; step < nsteps; ++step) {
     const bool more = step + 1 < nsteps;
     if (more) fetch(step + 1);
 #pragma unroll
-    for (int sub = 0; sub < KF_SUB; ++sub) {
+    for (int sub = 0; sub < SUB; ++sub) {
       const int trow = 32 * (2 * sub + half);  // this wave's tile inside the step: waves w / w+4 alternate
-      const int tile = (KF_STEP / 32) * step + 2 * sub + half;
+      const int tile = (STEP / 32) * step + 2 * sub + half;
       if (tile < ntiles) {
-        const float *a = sR + (step & 1) * KF_STEP * LD + (trow + r) * LD + 4 * h;
+        const char *a = sB + (size_t)(step & 1) * 3 * PIECE + (trow + r) * RS + 16 * h;
         f32x16_k acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int j = 0; j < D / 8; ++j) {
-          const float4 av = *reinterpret_cast<const float4 *>(a + 8 * j);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, qreg[4 * j], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, qreg[4 * j + 1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, qreg[4 * j + 2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qreg[4 * j + 3], acc, 0, 0, 0);
+        for (int j = 0; j < NSL; ++j) {
+          const bf16x8 f0 = as_bf16x8(*reinterpret_cast<const uint4 *>(a + 32 * j));
+          const bf16x8 f1 = as_bf16x8(*reinterpret_cast<const uint4 *>(a + PIECE + 32 * j));
+          const bf16x8 f2 = as_bf16x8(*reinterpret_cast<const uint4 *>(a + 2 * PIECE + 32 * j));
+          const bf16x8 w0 = as_bf16x8(qw[0][j]), w1 = as_bf16x8(qw[1][j]), w2 = as_bf16x8(qw[2][j]);
+          // smallest terms first
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, w0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, w0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, w0, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {  // reference row of element e: (e&3) + 8*(e>>2) + 4*h, ascending in e
@@ -824,7 +846,7 @@ __global__ __launch_bounds__(512) void knn_feat_k(const float *__restrict__ X, c
     __syncthreads();
   }
   flush();
-  // merge the four lists of every query (LDS: the reference tiles are dead)
+  // merge the four lists of every query (LDS: the reference images are dead)
   float *mv = sR;                                  // [128 queries][4 lists][KB]
   int *mi = reinterpret_cast<int *>(sR + 128 * 4 * KB);
   const int slot = ((qg * 32 + r) * 4 + 2 * half + h) * KB;

@@ -33,23 +33,7 @@
 namespace hitadv {
 
 typedef float f32x4b __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int B3_TM = 64;
-
-__device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast(bf16x8, u); }
-
-// a = hi + mid + lo exactly, each the bf16 truncation of what is left (upper 16 bits of an fp32 = a bf16)
-__device__ __forceinline__ void split3(float a, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
-  hi = __float_as_uint(a) & 0xffff0000u;
-  const float r1 = a - __uint_as_float(hi);
-  mid = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mid);
-  lo = __float_as_uint(r2);  // at most 8 significant bits are left: its lower 16 bits are zero
-}
-
-__device__ __forceinline__ uint32_t pack_hi(uint32_t even, uint32_t odd) {  // two bf16 (upper halves) -> one dword
-  return (even >> 16) | (odd & 0xffff0000u);
-}
 
 template <int CIN>
 __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restrict__ X, const uint16_t *__restrict__ W3,
