@@ -9,4 +9,10 @@ Module names mirror the reference tree so that its callers switch with an import
     from hit_adv_amd.pointnet2_ops import pointnet2_utils
 All compute runs in libhitadv_hip.so (hand-written HIP for gfx950); there is no CPU path.
 """
+import os as _os
+
+# attack_many() runs independent attacks on their own HIP streams; with the runtime's default of 4 hardware queues four of
+# them serialise again (bench.py: 23.9 vs 27.0 clouds/s).  Only effective if the HIP runtime has not started yet.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __version__ = "0.1.0"
