@@ -82,6 +82,7 @@ PROTOTYPES = {
     "hitadv_lrelu_pool_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "hitadv_fc_layer": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "hitadv_fc_layer_scratch_floats": [_I, _I, _I],
+    "hitadv_linear_max_bf16x3_set_blocks": [_I],
     "hitadv_fc_layer_pre": [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,

@@ -292,7 +292,10 @@ __global__ __launch_bounds__(256) void split_weights_k(const float *__restrict__
 // every block first loads its 24 KB / wave of W).  HITADV_V1_CUS (environment, read once) lowers the target: with several
 // attacks in flight a V1 grid that leaves part of the chip to the other streams' latency-bound kernels can be the better
 // trade (tools/README.md); results do not depend on it (the split merge is in point order).
+static int g_bf3_cus_override = 0;  // hitadv_linear_max_bf16x3_set_blocks: 0 = the environment's / default choice
+
 static int bf3_cus() {
+  if (g_bf3_cus_override > 0) return g_bf3_cus_override;
   static int cus = [] {
     const char *e = getenv("HITADV_V1_CUS");
     const int v = e ? atoi(e) : 256;
@@ -316,6 +319,12 @@ static void bf3_split(int B, int N, int Cout, int *S, int *rows) {
 }  // namespace hitadv
 
 using namespace hitadv;
+
+extern "C" int hitadv_linear_max_bf16x3_set_blocks(int cus) {
+  if (cus != 0 && (cus < 8 || cus > 256)) return HITADV_E_ARG;
+  g_bf3_cus_override = cus;
+  return 0;
+}
 
 extern "C" int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream) {
   if (!W || !W3 || Cout <= 0 || Cin <= 0 || (Cout & 15) || (Cin & 31)) return HITADV_E_ARG;

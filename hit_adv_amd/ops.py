@@ -522,6 +522,11 @@ def linear_max_fwd_bf16x3(x, W3, B, N, bias=None, relu=False):
     return out, idx
 
 
+def set_linear_max_blocks(cus):
+    """Workgroups the bf16x3 ``linear_max_fwd`` spreads over from now on (0 = default); results do not depend on it."""
+    _lib.call("hitadv_linear_max_bf16x3_set_blocks", int(cus))
+
+
 def linear_max_fwd_supported(Cin, Cout):
     return Cin in (64, 128) and Cout % 64 == 0
 
