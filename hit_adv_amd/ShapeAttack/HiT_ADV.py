@@ -24,6 +24,8 @@ ZeroDivisionError (quirk Q4); the per-100-iteration stopwatch lines are not prin
 """
 import warnings
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -548,7 +550,7 @@ class HiT_ADV:
             self._view.refresh(self.model)
         # with three or more attacks in flight the victim's 128 -> 1024 layers run on half the chip each (twice as long):
         # the other half stays free for the other streams' short kernels (bench.py: 28.1 instead of 27.0 clouds/s at four)
-        ops.set_linear_max_blocks(128 if len(batches) >= 3 else 0)
+        ops.set_linear_max_blocks(128 if len(batches) >= 3 else 0)  # 64 (two clouds per block): 27.3, 32: 22.0 clouds/s
         try:
             wss = [self._setup(d, t, slot=i) for i, (d, t) in enumerate(batches)]
             self._prepare_graphs(wss)

@@ -37,7 +37,7 @@ constexpr int B3_TM = 64;
 
 template <int CIN>
 __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restrict__ X, const uint16_t *__restrict__ W3,
-                                                            int B_, int N, int Cout, int rows_per_split, int S, int ncg,
+                                                            int B_, int N, int Cout, int rows_per_split, int S, int ncg, int cpb,
                                                             float *pval, int32_t *pidx, const float *__restrict__ bias,
                                                             int relu, float *__restrict__ out, int64_t *__restrict__ idx,
                                                             int *tickets) {
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   extern __shared__ __attribute__((aligned(16))) char sB3[];  // 2 buffers x 3 pieces x PIECE
   int cg, s, b;
   {  // XCD-aware block order (see linear_max_fwd_k): the column-group blocks that stream the same x tiles share an XCD
-    const int NCG = ncg, id = blockIdx.x, nrg = S * B_;
+    const int NCG = ncg, id = blockIdx.x, nrg = S * ((B_ + cpb - 1) / cpb);  // cpb > 1 (clouds per block) only with S == 1
     if ((nrg & 7) == 0) {
       const int xcd = id & 7, slot = id >> 3;
       cg = slot % NCG;
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   const bool active = col0 < Cout;  // wave-uniform
   const int n0 = s * rows_per_split, n1 = min(N, n0 + rows_per_split);
   const int ntiles = (n1 - n0 + B3_TM - 1) / B3_TM;
-  X += (size_t)b * N * CIN;
+  const float *const X0 = X;
+  const int b0 = b * cpb;  // this block's first cloud: it takes cpb of them one after the other with the same W in registers
 
   // B operand of slice j (32 values of k), column tile ct (16 columns), piece p: the lane's column 16 ct + lane % 16,
   // k = 32 j + 8 (lane / 16) .. + 7.  W3 is stored in fragment order [piece][16-column block][slice][lane] x 16 bytes, so
@@ -204,6 +205,12 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
     if (more && !late) stash(have, tile + 1);
     __syncthreads();
   };
+  for (int bb = 0; bb < cpb && b0 + bb < B_; ++bb) {
+  b = b0 + bb;
+  X = X0 + (size_t)b * N * CIN;
+  bv[0] = bv[1] = -__builtin_inff();
+  bi[0] = bi[1] = -1;
+  if (bb > 0) __syncthreads();  // the previous cloud's last tile is no longer being read
   fetch(stA, 0);
   // every load issued so far (W, tile 0) completes HERE, explicitly: the first use of W is inside the loop, and a load that
   // may still be pending at the loop entry makes the compiler's wait-count pass guard every in-loop use of W with a
@@ -243,6 +250,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
       }
     }
   }
+  }  // clouds of this block
   if (S == 1) return;
   // The S splits of a (cloud, column group) meet here: the last block to draw the group's ticket merges the partials in
   // split order (= ascending points, so ties keep the first point).  Hand-off protocol of fc_layer_k (csrc/pointnet.hip).
@@ -304,9 +312,11 @@ static int bf3_cus() {
   return cus;
 }
 
-static void bf3_split(int B, int N, int Cout, int *S, int *rows) {
+static void bf3_split(int B, int N, int Cout, int *S, int *rows, int *cpb) {
   const int colgroups = (Cout + 255) / 256;
   const int cus = bf3_cus();
+  // fewer workgroups than (clouds x column groups): a block takes several clouds in turn (W stays in its registers)
+  *cpb = cus < B * colgroups ? (B * colgroups + cus - 1) / cus : 1;
   int want = (cus + B * colgroups - 1) / (B * colgroups);
   const int maxs = (N + B3_TM - 1) / B3_TM;
   want = want < 1 ? 1 : (want > maxs ? maxs : want);
@@ -336,8 +346,8 @@ extern "C" int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, ui
 
 extern "C" int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout) {
   if (B <= 0 || N <= 0 || Cout <= 0) return 0;
-  int S, rows;
-  bf3_split(B, N, Cout, &S, &rows);
+  int S, rows, cpb;
+  bf3_split(B, N, Cout, &S, &rows, &cpb);
   return (int64_t)B * S * Cout;
 }
 
@@ -348,22 +358,22 @@ extern "C" int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, 
       (Cin != 64 && Cin != 128) || ((uintptr_t)X & 15) || ((uintptr_t)W3 & 15))
     return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
-  int S, rows;
-  bf3_split(B, N, Cout, &S, &rows);
+  int S, rows, cpb;
+  bf3_split(B, N, Cout, &S, &rows, &cpb);
   const int ncg = (Cout + 255) / 256;
-  dim3 grid((unsigned)(ncg * S * B));
+  dim3 grid((unsigned)(ncg * S * ((B + cpb - 1) / cpb)));
   const size_t shm = (size_t)2 * 3 * B3_TM * (2 * Cin + 32);
   if (Cin == 128) {
     static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<128>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 128 + 32));
     (void)once;
-    linear_max_fwd_bf3_k<128><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
+    linear_max_fwd_bf3_k<128><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out, idx,
                                                      tickets);
   } else {
     static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<64>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 64 + 32));
     (void)once;
-    linear_max_fwd_bf3_k<64><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, part_val, part_idx, bias, relu, out, idx,
+    linear_max_fwd_bf3_k<64><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out, idx,
                                                     tickets);
   }
   HITADV_LAUNCH_CHECK();
