@@ -15,10 +15,11 @@ from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss  # noqa: E402
 
 def main():
     dev = torch.device('cuda', 0)
-    model = bench.victim().to(dev)
+    cfg = bench.CONFIGS['cfg2']
+    model = bench.build_victim(cfg).to(dev)
     att = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=bench.BINARY_STEP,
                   num_iter=bench.NUM_ITER, verbose=False, **bench.HP)
-    data, _ = bench.synth(0, bench.B_PER_GPU)
+    data, _ = bench.synth(0, cfg['B'], cfg['N'])
     data = data.to(dev)
     with torch.no_grad():
         label = model(data[:, :, :3].transpose(1, 2).contiguous())[0].argmax(1)
