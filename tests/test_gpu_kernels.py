@@ -761,6 +761,27 @@ def test_fc_layer_with_its_input_evaluated_on_the_way_in(A, B, T, J, K, NOUT):
     close(nomask, (pre.double().sum(1) @ Wpre.double() @ Wt.double()).float(), rtol=2e-5, atol=2e-5)
 
 
+def test_linear_max_fwd_bf16x3_same_bits_for_every_grid(A):
+    """hitadv_linear_max_bf16x3_set_blocks only changes how the work is spread (point splits merged in point order, or
+    several clouds per block): values and arg-max are the same bits, ties included."""
+    g = torch.Generator().manual_seed(5)
+    B, Np, Cin, Cout = 32, 1000, 128, 1024
+    x = torch.randn(B * Np, Cin, generator=g).relu()
+    x[Np + 7] = x[Np + 3]  # a duplicate point: equal activations, the lower index must win everywhere
+    W3 = A.split_weights_bf16x3(cu(torch.randn(Cout, Cin, generator=g) * 0.1))
+    bias = cu(torch.randn(Cout, generator=g))
+    ref = None
+    try:
+        for blocks in (0, 256, 128, 64, 40, 8):
+            A.set_linear_max_blocks(blocks)
+            out = A.linear_max_fwd_bf16x3(cu(x), W3, B, Np, bias=bias, relu=True)
+            if ref is None:
+                ref = out
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), blocks
+    finally:
+        A.set_linear_max_blocks(0)
+
+
 def test_linear_max_fwd_bf16x3_ties_keep_the_first_point(A):
     g = torch.Generator().manual_seed(3)
     B, Np, Cin, Cout = 2, 1024, 128, 256
