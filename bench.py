@@ -436,7 +436,8 @@ def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg['workload'], "batch_per_gpu": B, "num_point": N,
                    "parallelism": "independent batch shards, 1 process per GPU",
-                   "attacks_in_flight_per_gpu": in_flight, **info},
+                   "attacks_in_flight_per_gpu": in_flight,
+                   "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), **info},
         "cloud_iterations_per_s": clouds * iters_per_step / elapsed,
         "attack_success": {"succeeded": succeeded, "attacked": attacked},
         # what RCCL saw: the calls each rank made in this run (all zero in a single-process run)
