@@ -28,11 +28,12 @@ PROTOTYPES = {
     "hitadv_best_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hitadv_adam_step": [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _L, _F, _P, _P],
     "hitadv_fps_from_start": [_P, _P, _I, _I, _I, _P, _P],
+    "hitadv_fps_pct": [_P, _P, _I, _I, _I, _P, _P],
     "hitadv_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
     "hitadv_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_query_ball_point": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
-    "hitadv_query_ball_point_inclusive": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "hitadv_query_ball_point_victim": [_I, _I, _I, _F, _I, _I, _P, _P, _P, _P],
     "hitadv_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],

@@ -95,10 +95,23 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 //                   torch.bmm executes for a K = 3 inner dimension
 //   2  Gram (kNN)   (|p|^2 + (-2 q.p)) + |q|^2, q.p an FMA chain, |.|^2 a     KNNDist (util/dist_utils.py:148-150)
 //                   plain sum of squares ((a0*a0 + a1*a1) + a2*a2)
-// q = the row / query point, p = the column / reference point.  Forms 1 and 2 reproduce the reference's values bit for
+//   3  square_distance  ((-2 q.p) + |q|^2) + |p|^2, q.p an FMA chain, |.|^2 a    the victims' square_distance(src = q, dst = p)
+//                   plain sum of squares                                      (model/pointnet2_utils.py:19-41,
+//                                                                              model/pct_utils.py:40-58)
+//   4  PCT get_dists  sqrt(d < 0 ? 1e-7 : d), d = (|q|^2 + |p|^2) - 2 q.p     util/other_utils.py:237-251 as PCT's sampler
+//                   with q.p = fma(q1, p1, q0 p0) + q2 p2: the product of a   calls it (:254-272); only pct_dist() below
+//                   ONE-row matrix does not take the GEMM kernel's chain
+// q = the row / query point, p = the column / reference point.  Forms 1 to 4 reproduce the reference's values bit for
 // bit (oracle/pointnet2_oracle.c::pair_value is checked against torch itself, tests/test_oracle_gram.py).
 __device__ __forceinline__ float dot3_fma(float ax, float ay, float az, float bx, float by, float bz) {
   return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+
+// form 4 (rq, rp = plain sums of squares); sqrtf is the correctly rounded one (hipcc's default for fp32 sqrt)
+__device__ __forceinline__ float pct_dist(float qx, float qy, float qz, float rq, float px, float py, float pz, float rp) {
+  const float zz = fmaf(qy, py, qx * px) + qz * pz;
+  const float d = fmaf(-2.0f, zz, rq + rp);  // 2*zz is exact: (rq + rp) - 2*zz rounded once
+  return __builtin_sqrtf(d < 0.f ? 1e-7f : d);
 }
 
 template <int FORM>
@@ -112,6 +125,7 @@ __device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float r
   if (FORM == 0) return sqdist3(qx, qy, qz, px, py, pz);
   const float zz = dot3_fma(qx, qy, qz, px, py, pz);
   if (FORM == 1) return fmaf(-2.0f, zz, rq + rp);  // 2*zz is exact, so this is (rq + rp) - 2*zz rounded once
+  if (FORM == 3) return fmaf(-2.0f, zz, rq) + rp;  // ((-2*zz) + rq) + rp
   return fmaf(-2.0f, zz, rp) + rq;                 // (rp + (-2*zz)) + rq
 }
 

@@ -9,7 +9,9 @@ namespace hitadv {
 // ballot + prefix popcount, so the "first nsample hits in index order" rule of
 // ball_query_gpu.cu:9-44 is kept without a serial scan.  Empty ball -> zeros, short ball -> padded
 // with the first hit.
-template <bool INCLUSIVE, typename IdxT>
+// FORM: how the squared distance is evaluated (common.hpp::pair_dist): 0 = direct (the CUDA extension), 3 = the victims'
+// Gram-form square_distance(new_xyz, xyz) in torch's fp32 arithmetic (model/pointnet2_utils.py:19-41, :87-107).
+template <bool INCLUSIVE, typename IdxT, int FORM = 0>
 __global__ __launch_bounds__(256) void ball_query_k(int n, int m, float radius2, int nsample,
                                                     const float *__restrict__ new_xyz,
                                                     const float *__restrict__ xyz, IdxT *__restrict__ idx,
@@ -20,6 +22,7 @@ __global__ __launch_bounds__(256) void ball_query_k(int n, int m, float radius2,
   const int b = (int)(qid / m);
   const float *q = new_xyz + qid * 3;
   const float qx = q[0], qy = q[1], qz = q[2];
+  const float rq = sq_norm<FORM>(qx, qy, qz);
   const float *P = xyz + (size_t)b * n * 3;
   IdxT *out = idx + qid * nsample;
   int cnt = 0, first = empty_value;
@@ -27,8 +30,9 @@ __global__ __launch_bounds__(256) void ball_query_k(int n, int m, float radius2,
     const int k = k0 + lane;
     bool hit = false;
     if (k < n) {
-      const float d2 = sqdist3(qx, qy, qz, P[k * 3], P[k * 3 + 1], P[k * 3 + 2]);
-      hit = INCLUSIVE ? (d2 <= radius2) : (d2 < radius2);
+      const float x = P[k * 3], y = P[k * 3 + 1], z = P[k * 3 + 2];
+      const float d2 = pair_dist<FORM>(qx, qy, qz, rq, x, y, z, sq_norm<FORM>(x, y, z));
+      hit = INCLUSIVE ? !(d2 > radius2) : (d2 < radius2);
     }
     const unsigned long long mask = __ballot(hit);
     if (mask) {
@@ -166,12 +170,16 @@ extern "C" int hitadv_query_ball_point(int b, int n, int m, float radius, int ns
   return 0;
 }
 
-extern "C" int hitadv_query_ball_point_inclusive(int b, int n, int m, float radius, int nsample,
-                                                 const float *new_xyz, const float *xyz, int64_t *idx, void *stream) {
+extern "C" int hitadv_query_ball_point_victim(int b, int n, int m, float radius2, int nsample, int form,
+                                              const float *new_xyz, const float *xyz, int64_t *idx, void *stream) {
   if (!new_xyz || !xyz || !idx || b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return HITADV_E_ARG;
+  if (form != HITADV_FORM_DIRECT && form != HITADV_FORM_SQUARE_DISTANCE) return HITADV_E_ARG;
   const long long nq = (long long)b * m;
-  ball_query_k<true, int64_t><<<(unsigned)((nq + 3) / 4), 256, 0, (hipStream_t)stream>>>(
-      n, m, radius * radius, nsample, new_xyz, xyz, idx, nq, n);
+  const unsigned grid = (unsigned)((nq + 3) / 4);
+  if (form == HITADV_FORM_DIRECT)
+    ball_query_k<true, int64_t, 0><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, radius2, nsample, new_xyz, xyz, idx, nq, n);
+  else
+    ball_query_k<true, int64_t, 3><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, radius2, nsample, new_xyz, xyz, idx, nq, n);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

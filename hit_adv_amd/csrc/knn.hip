@@ -167,6 +167,7 @@ __device__ __forceinline__ f32x2 pair_dist2(float qx, float qy, float qz, float 
   const f32x2 zz = __builtin_elementwise_fma(qz2, pz, __builtin_elementwise_fma(qy2, py, qx2 * px));
   const f32x2 m2 = {-2.0f, -2.0f}, rq2 = {rq, rq};
   if (FORM == 1) return __builtin_elementwise_fma(m2, zz, rq2 + rp);
+  if (FORM == 3) return __builtin_elementwise_fma(m2, zz, rq2) + rp;
   return __builtin_elementwise_fma(m2, zz, rp) + rq2;
 }
 
@@ -563,10 +564,12 @@ static int launch_knn_select(const float *q, const float *p, int B, int N, int M
     HITADV_KS_CASE(17)
     HITADV_KS_CASE(20)
     HITADV_KS_CASE(24)
-  } else {  // KNNDist calls with K = k + 1 = 5 or 6 (util/dist_utils.py:156)
+  } else if (FORM == 2) {  // KNNDist calls with K = k + 1 = 5 or 6 (util/dist_utils.py:156)
     HITADV_KS_CASE(5)
     HITADV_KS_CASE(6)
     HITADV_KS_CASE(16)
+  } else {
+    HITADV_KS_CASE(8)
   }
   HITADV_KS_CASE(32)
 #undef HITADV_KS_CASE
@@ -581,10 +584,16 @@ extern "C" int hitadv_knn_points(const float *q, const float *p, int B, int N, i
                                  void *idx, int idx_is_i64, void *stream) {
   if (!q || !p || !dists || !idx || B <= 0 || N <= 0 || M <= 0 || K <= 0 || K > 64 || K > M)
     return HITADV_E_ARG;
-  if (form != HITADV_FORM_DIRECT && form != HITADV_FORM_GRAM_KNN) return HITADV_E_ARG;
+  if (form != HITADV_FORM_DIRECT && form != HITADV_FORM_GRAM_KNN && form != HITADV_FORM_SQUARE_DISTANCE) return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (K <= 32 && M <= 2048) {
+  if (form == HITADV_FORM_SQUARE_DISTANCE) {  // PCT's knn_point: K = 32 over 1024 / 512 points (model/pct_cls.py:48-53)
+    if (K <= 32 && M <= 2048)
+      rc = launch_knn_select<3, 4>(q, p, B, N, M, K, dists, idx, idx_is_i64, s);
+    else
+      rc = idx_is_i64 ? launch_knn_topk<3, int64_t>(q, p, B, N, M, K, dists, (int64_t *)idx, s)
+                      : launch_knn_topk<3, int32_t>(q, p, B, N, M, K, dists, (int32_t *)idx, s);
+  } else if (K <= 32 && M <= 2048) {
     // measured at B = 32, 1024 x 1024 (profiles/r02_kbench.json): 8 waves per block win for short lists (K = 1: 14 vs 29 us,
     // K = 6: 37 vs 43), 4 waves for long ones (K = 17: 74 vs 107 -- the 8-way merge and the doubled log area cost more
     // than the extra waves hide).  Two queries per lane (128-query blocks, as K2 does with four) was also measured: it

@@ -5,9 +5,12 @@
 //                      coordinates.  Per step: PT distance updates, a 64-bit (distance-bits,
 //                      tie-key) max via two DPP reductions, one barrier, 4-slot merge.  Latency-bound
 //                      serial chain of m steps.
-//        EXT = false : ShapeAttack/HiT_ADV.py:489-510 semantics (given start, lowest index on ties)
-//        EXT = true  : sampling_gpu.cu:69-173 semantics (start 0, |p|^2 <= 1e-3 skipped, the
-//                      thread-slot tie order of the reference's shared-memory tree)
+//        MODE 0 : ShapeAttack/HiT_ADV.py:489-510 = model/pointnet2_utils.py:63-84 semantics (given start, direct-form
+//                 squared distances, running distance 1e10, lowest index on ties)
+//        MODE 1 : sampling_gpu.cu:69-173 semantics (start 0, |p|^2 <= 1e-3 skipped, the
+//                 thread-slot tie order of the reference's shared-memory tree)
+//        MODE 2 : PCT's sampler, util/other_utils.py:254-272: given start, distances by get_dists (:237-251: sqrt of
+//                 the clamped Gram form in torch's own fp32 arithmetic, common.hpp::pct_dist), running distance 1e5
 #include "common.hpp"
 #include "hitadv.h"
 
@@ -15,7 +18,7 @@ namespace hitadv {
 
 __device__ __forceinline__ uint32_t bitrev_n(uint32_t v, int bits) { return __brev(v) >> (32 - bits); }
 
-template <int PT, bool EXT, typename IdxT>
+template <int PT, int MODE, typename IdxT>
 __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const int64_t *__restrict__ start,
                                            int N, int m, int ref_bs, int ref_bits, int use_lds,
                                            IdxT *__restrict__ idx) {
@@ -25,7 +28,8 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   xyz += (size_t)b * N * 3;
   idx += (size_t)b * m;
-  float px[PT], py[PT], pz[PT], run[PT];
+  constexpr bool EXT = MODE == 1, PCT = MODE == 2;
+  float px[PT], py[PT], pz[PT], run[PT], rp[PT];
   uint32_t tb[PT];
 #pragma unroll
   for (int u = 0; u < PT; ++u) {
@@ -35,7 +39,8 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
     px[u] = xyz[kk * 3];
     py[u] = xyz[kk * 3 + 1];
     pz[u] = xyz[kk * 3 + 2];
-    run[u] = 1e10f;
+    run[u] = PCT ? 1e5f : 1e10f;
+    rp[u] = (px[u] * px[u] + py[u] * py[u]) + pz[u] * pz[u];
     bool ok = in;
     uint32_t tie = (uint32_t)k;
     if (EXT) {
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
       tie = (ref_bits ? (bitrev_n(s, ref_bits) << 16) : 0u) | ((uint32_t)k >> ref_bits);
     }
     tb[u] = ok ? 0xFFFFFFFFu - tie : 0u;  // 0 marks "never a candidate"
-    if (use_lds && in) spts[k] = make_float4(px[u], py[u], pz[u], 0.f);
+    if (use_lds && in) spts[k] = make_float4(px[u], py[u], pz[u], rp[u]);
   }
   int far = EXT ? 0 : (int)start[b];
   __syncthreads();
@@ -53,17 +58,18 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
   if (EXT && threadIdx.x == 0) idx[0] = 0;
   for (int j = 0; j < steps; ++j) {
     if (!EXT && threadIdx.x == 0) idx[j] = (IdxT)far;
-    float cx, cy, cz;
+    float cx, cy, cz, rc;
     if (use_lds) {
       const float4 c = spts[far];
-      cx = c.x; cy = c.y; cz = c.z;
+      cx = c.x; cy = c.y; cz = c.z; rc = c.w;
     } else {
       cx = xyz[far * 3]; cy = xyz[far * 3 + 1]; cz = xyz[far * 3 + 2];
+      rc = (cx * cx + cy * cy) + cz * cz;
     }
     unsigned long long best = 0ull;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
-      const float d = sqdist3(px[u], py[u], pz[u], cx, cy, cz);
+      const float d = PCT ? pct_dist(cx, cy, cz, rc, px[u], py[u], pz[u], rp[u]) : sqdist3(px[u], py[u], pz[u], cx, cy, cz);
       if (EXT) {
         if (tb[u] != 0u) run[u] = d < run[u] ? d : run[u];
       } else {
@@ -125,10 +131,10 @@ __global__ __launch_bounds__(256) void gather_points_grad_k(int c, int n, int np
       for (int l = 0; l < c; ++l) gp[(size_t)l * n] += go[(size_t)l * npoints + j];
 }
 
-template <bool EXT, typename IdxT>
+template <int MODE, typename IdxT>
 static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int m, IdxT *idx, hipStream_t s) {
   int ref_bs = 1, ref_bits = 0;
-  if (EXT) {  // include/cuda_utils.h:15-18 opt_n_threads: clamp(2^floor(log2 n), 1, 512)
+  if (MODE == 1) {  // include/cuda_utils.h:15-18 opt_n_threads: clamp(2^floor(log2 n), 1, 512)
     while (ref_bs * 2 <= N && ref_bs < 512) {
       ref_bs *= 2;
       ++ref_bits;
@@ -138,7 +144,7 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
   const size_t shm = use_lds ? (size_t)N * sizeof(float4) : 0;
 #define HITADV_FPS_CASE(PT)                                                                       \
   if (N <= 256 * PT) {                                                                            \
-    fps<PT, EXT, IdxT><<<B, 256, shm, s>>>(xyz, start, N, m, ref_bs, ref_bits, use_lds, idx);     \
+    fps<PT, MODE, IdxT><<<B, 256, shm, s>>>(xyz, start, N, m, ref_bs, ref_bits, use_lds, idx);     \
     return 0;                                                                                     \
   }
   HITADV_FPS_CASE(1)
@@ -159,7 +165,15 @@ using namespace hitadv;
 extern "C" int hitadv_fps_from_start(const float *xyz, const int64_t *start, int B, int N, int m,
                                      int64_t *idx, void *stream) {
   if (!xyz || !start || !idx || B <= 0 || N <= 0 || m <= 0) return HITADV_E_ARG;
-  int rc = launch_fps<false, int64_t>(xyz, start, B, N, m, idx, (hipStream_t)stream);
+  int rc = launch_fps<0, int64_t>(xyz, start, B, N, m, idx, (hipStream_t)stream);
+  if (rc) return rc;
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_fps_pct(const float *xyz, const int64_t *start, int B, int N, int m, int64_t *idx, void *stream) {
+  if (!xyz || !start || !idx || B <= 0 || N <= 0 || m <= 0) return HITADV_E_ARG;
+  int rc = launch_fps<2, int64_t>(xyz, start, B, N, m, idx, (hipStream_t)stream);
   if (rc) return rc;
   HITADV_LAUNCH_CHECK();
   return 0;
@@ -170,7 +184,7 @@ extern "C" int hitadv_furthest_point_sampling(int b, int n, int m, const float *
   (void)temp;  // running distances live in registers; the scratch tensor of the reference is unused
   if (!dataset || !idxs || b <= 0 || n <= 0) return HITADV_E_ARG;
   if (m <= 0) return 0;  // sampling_gpu.cu:73
-  int rc = launch_fps<true, int32_t>(dataset, nullptr, b, n, m, idxs, (hipStream_t)stream);
+  int rc = launch_fps<1, int32_t>(dataset, nullptr, b, n, m, idxs, (hipStream_t)stream);
   if (rc) return rc;
   HITADV_LAUNCH_CHECK();
   return 0;

@@ -5,18 +5,18 @@ BatchNorm folded in eval mode, see _pointwise.py); the neighbourhood constructio
 ``sample_and_group`` (model/pct_utils.py:111-140) runs in HIP:
 
 * ``fps`` (util/other_utils.py:254-272): random first index from the CPU generator (:264) or from an attack's
-  pre-drawn feed (_sampling.py), then
-  ``hitadv_fps_from_start``.  The reference maximises sqrt of a clamped Gram-form distance; sqrt is monotone, so
-  the selected indices are those of the squared direct-form distance except for fp32 near-ties;
-* ``knn_point`` (pct_utils.py:98-109, ``topk(..., sorted=False)``): ``hitadv_knn_points`` (sorted; the consumer
-  max-pools over the neighbours, so order is irrelevant).
+  pre-drawn feed (_sampling.py), then ``hitadv_fps_pct``: running distances = sqrt of the clamped Gram-form distance
+  in torch's own fp32 arithmetic (``get_dists``, :237-251), so the table is the reference's bit for bit (fixture g12);
+* ``knn_point`` (pct_utils.py:98-109, ``topk(..., sorted=False)``): ``hitadv_knn_points`` on the reference's Gram-form
+  ``square_distance`` values (sorted; the consumer max-pools over the neighbours, so order is irrelevant -- the SET is
+  the reference's).
+``ops.victim_reference_arithmetic(False)`` selects direct-form distances for both.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..pytorch3d_ops import knn_points
 from . import _sampling
 from ._pointwise import conv1x1, fast_pm, linear_pm, linear_relu_pm, split_first_layer
 from .pointnet2 import index_points
@@ -24,11 +24,12 @@ from .pointnet2 import index_points
 
 def fps(xyz, M):
     B, N, _ = xyz.shape
-    return ops.fps_from_start(xyz, M, _sampling.next_start(B, N, xyz.device))
+    return ops.fps_pct(xyz, M, _sampling.next_start(B, N, xyz.device))
 
 
 def knn_point(nsample, xyz, new_xyz):
-    return knn_points(new_xyz.detach(), xyz.detach(), K=nsample).idx
+    form = ops.FORM_SQUARE_DISTANCE if ops.victim_reference_arithmetic.get() else ops.FORM_DIRECT
+    return ops.KnnPoints.apply(new_xyz.detach(), xyz.detach(), int(nsample), form)[1]
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points):

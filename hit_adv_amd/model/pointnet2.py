@@ -5,8 +5,9 @@ model/pointnet2_cls_ssg.py::get_model (:6-42) and model/pointnet2_utils.py::Poin
 * ``farthest_point_sample`` (pointnet2_utils.py:63-84): the random first index is drawn from the CPU generator
   exactly as the reference does (:75) -- or read from an attack's pre-drawn feed (_sampling.py), which makes the
   forward pass capturable --, the 512/128 sequential arg-max steps run in ``hitadv_fps_from_start``;
-* ``query_ball_point`` (:87-107): ``hitadv_query_ball_point_inclusive`` (d^2 <= r^2, first nsample in index order,
-  padded with the first hit) instead of a [B,S,N] distance matrix + full sort.
+* ``query_ball_point`` (:87-107): ``hitadv_query_ball_point_victim`` (not ``d^2 > r^2`` on the reference's Gram-form
+  ``square_distance`` values, first nsample in index order, padded with the first hit) instead of a [B,S,N] distance
+  matrix + full sort; the table is the reference's bit for bit (fixture g11).
 """
 import torch
 import torch.nn as nn

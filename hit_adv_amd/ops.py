@@ -5,12 +5,13 @@ tape; every computation below happens in libhitadv_hip.so.  All functions requir
 (ROCm) tensors and raise otherwise -- there is no CPU path.
 """
 import ctypes
+import struct
 
 import torch
 
 from . import _lib
 
-FORM_DIRECT, FORM_GRAM, FORM_GRAM_KNN = 0, 1, 2  # include/hitadv.h HITADV_FORM_*
+FORM_DIRECT, FORM_GRAM, FORM_GRAM_KNN, FORM_SQUARE_DISTANCE = 0, 1, 2, 3  # include/hitadv.h HITADV_FORM_*
 
 _reference_arithmetic = False
 
@@ -43,6 +44,33 @@ class reference_arithmetic:
     @staticmethod
     def get():
         return _reference_arithmetic
+
+
+class victim_reference_arithmetic(reference_arithmetic):
+    """The same kind of switch for the samplers INSIDE the victims (PointNet++'s ball query, PCT's farthest point
+    sampling and kNN grouping): on (the default), their distances are evaluated in the reference's own fp32 arithmetic
+    (Gram-form ``square_distance``, model/pointnet2_utils.py:19-41; ``get_dists``, util/other_utils.py:237-251), so the
+    index tables -- which DEFINE the victim's function -- are the reference's bit for bit; off, in the direct form."""
+    _on = True
+
+    def __enter__(self):
+        self.prev, victim_reference_arithmetic._on = victim_reference_arithmetic._on, self.on
+        return self
+
+    def __exit__(self, *exc):
+        victim_reference_arithmetic._on = self.prev
+
+    @staticmethod
+    def set(on):
+        victim_reference_arithmetic._on = bool(on)
+
+    @staticmethod
+    def get():
+        return victim_reference_arithmetic._on
+
+
+def _victim_form(explicit):
+    return victim_reference_arithmetic._on if explicit is None else bool(explicit)
 
 
 def _form(explicit, reference_form):
@@ -452,6 +480,21 @@ def fps_from_start(xyz, npoint, start):
     return idx
 
 
+def fps_pct(xyz, npoint, start, reference=None):
+    """PCT's sampler (util/other_utils.py:254-272) from given first indices: xyz[B,N,3], start[B] int64 -> idx[B,npoint]
+    int64.  With ``reference`` on (None: the ``victim_reference_arithmetic`` switch) the running distances are the
+    reference's sqrt(clamped Gram form) values bit for bit; off, squared direct-form distances (sqrt is monotone: the
+    tables differ only where two candidates are within fp32 rounding of each other)."""
+    if not _victim_form(reference):
+        return fps_from_start(xyz, npoint, start)
+    xyz = _dev(xyz.detach(), "xyz")
+    start = _dev(start, "start", torch.int64)
+    B, N, _ = xyz.shape
+    idx = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
+    _lib.call("hitadv_fps_pct", _p(xyz), _p(start), B, N, npoint, _p(idx), _stream())
+    return idx
+
+
 # --------------------------------------------------------------------------- victim-side helper
 def linear_max_bwd(dg, W, idx, N, act_out=None):
     """dX[b*N+n,:] = sum_{j: idx[b,j]==n} dg[b,j] * W[j,:]   (dg[B,Cout], W[Cout,Cin], idx[B,Cout] int64);
@@ -740,12 +783,21 @@ def topk_rows(P, K, largest=True):
     return vals, idx
 
 
-def query_ball_point(radius, nsample, xyz, new_xyz):
-    """torch-semantics ball query (model/pointnet2_utils.py:87-107): xyz[B,N,3], new_xyz[B,S,3] -> idx[B,S,nsample] int64."""
+def radius_squared(radius):
+    """The threshold of ``sqrdists > radius ** 2`` (model/pointnet2_utils.py:102): torch compares an fp32 tensor with a
+    Python double in fp32, i.e. with the fp32 value of the DOUBLE square -- not with the fp32 product."""
+    return struct.unpack('f', struct.pack('f', float(radius) ** 2))[0]
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz, reference=None):
+    """torch-semantics ball query (model/pointnet2_utils.py:87-107): xyz[B,N,3], new_xyz[B,S,3] -> idx[B,S,nsample] int64.
+    ``reference`` (None: the ``victim_reference_arithmetic`` switch, on by default) evaluates the distances as the
+    reference's Gram-form ``square_distance`` does, bit for bit: the table is then the reference's."""
     xyz, new_xyz = _dev(xyz.detach(), "xyz"), _dev(new_xyz.detach(), "new_xyz")
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
     idx = torch.empty(B, S, nsample, device=xyz.device, dtype=torch.int64)
-    _lib.call("hitadv_query_ball_point_inclusive", B, N, S, ctypes.c_float(radius), nsample, _p(new_xyz), _p(xyz),
-              _p(idx), _stream())
+    form = FORM_SQUARE_DISTANCE if _victim_form(reference) else FORM_DIRECT
+    _lib.call("hitadv_query_ball_point_victim", B, N, S, ctypes.c_float(radius_squared(radius)), nsample, form,
+              _p(new_xyz), _p(xyz), _p(idx), _stream())
     return idx

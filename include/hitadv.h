@@ -41,6 +41,9 @@ extern "C" {
                               * an x86 CPU -- the reference's values bit for bit (tests/test_oracle_gram.py)          */
 #define HITADV_FORM_GRAM_KNN 2 /* (|y_j|^2 + (-2 x_i.y_j)) + |x_i|^2, dot product an FMA chain, |.|^2 = (a*a+b*b)+c*c:
                                 * the distance matrix of KNNDist (util/dist_utils.py:148-150), bit for bit             */
+#define HITADV_FORM_SQUARE_DISTANCE 3 /* ((-2 q_i.p_j) + |q_i|^2) + |p_j|^2, dot product an FMA chain, |.|^2 plain:
+                                       * square_distance(src = q, dst = p) of the victims (model/pointnet2_utils.py:19-41,
+                                       * model/pct_utils.py:40-58; also ShapeAttack/HiT_ADV.py:447-468), bit for bit   */
 
 /* Library / build identification (static string). */
 const char *hitadv_version(void);
@@ -74,7 +77,9 @@ int hitadv_nn_min_bwd(const float *x, const float *y, const int32_t *arg_x, cons
 
 /* K nearest neighbours, ascending, ties -> lower index.  q[B,N,3], p[B,M,3] ->
  * dists[B,N,K], idx[B,N,K] (int64 when idx_is_i64 != 0, else int32).  1 <= K <= min(M, 64).
- * `form` = HITADV_FORM_DIRECT (pytorch3d's rule) or HITADV_FORM_GRAM_KNN (KNNDist's own distance matrix).
+ * `form` = HITADV_FORM_DIRECT (pytorch3d's rule), HITADV_FORM_GRAM_KNN (KNNDist's own distance matrix) or
+ * HITADV_FORM_SQUARE_DISTANCE (the k smallest entries of the victims' square_distance(q, p): PCT's knn_point,
+ * model/pct_utils.py:98-109).
  * Replaces pytorch3d.ops.knn_points as called at ShapeAttack/HiT_ADV.py:78,320,329 and
  * util/dist_utils.py:482, and the Gram+topk of KNNDist (util/dist_utils.py:148-158). */
 int hitadv_knn_points(const float *q, const float *p, int B, int N, int M, int K, int form, float *dists,
@@ -184,6 +189,12 @@ int64_t hitadv_regulariser_scratch_floats(int B);
 int hitadv_fps_from_start(const float *xyz, const int64_t *start, int B, int N, int m,
                           int64_t *idx, void *stream);
 
+/* PCT's sampler (util/other_utils.py:254-272) with a given first index per cloud: running distance 1e5, distances by
+ * get_dists (:237-251) = sqrt(d < 0 ? 1e-7 : d), d = (|c|^2 + |p|^2) - 2 c.p in torch's own fp32 arithmetic for a
+ * one-row matrix product (c.p = fma(c1, p1, c0 p0) + c2 p2), update where smaller, arg-max with the lowest index on
+ * ties: idx[B,m] (int64) equals the reference's table. */
+int hitadv_fps_pct(const float *xyz, const int64_t *start, int B, int N, int m, int64_t *idx, void *stream);
+
 /* ------------------------------------------------------------------ pointnet2_ops natives
  * One for one with the reference's kernel wrappers; same argument order.               */
 
@@ -202,12 +213,14 @@ int hitadv_gather_points_grad(int b, int c, int n, int npoints, const float *gra
 int hitadv_query_ball_point(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                             const float *xyz, int32_t *idx, void *stream);
 /* The pure-torch ball query of the PointNet++ victim and of HiT_ADV.query_ball_point
- * (model/pointnet2_utils.py:87-107, ShapeAttack/HiT_ADV.py:512-532): first nsample indices (ascending) with
- * d^2 <= r^2 (INCLUSIVE), short rows padded with the first hit, an empty ball filled with n (the reference's
- * out-of-range marker), int64 indices.  Direct-form distances (the reference uses the Gram form: only points
- * within fp32 noise of the sphere can differ). */
-int hitadv_query_ball_point_inclusive(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                                      const float *xyz, int64_t *idx, void *stream);
+ * (model/pointnet2_utils.py:87-107, ShapeAttack/HiT_ADV.py:512-532): first nsample indices (ascending) that are NOT
+ * `d^2 > radius2`, short rows padded with the first hit, an empty ball filled with n (the reference's out-of-range
+ * marker), int64 indices.  `radius2` is the threshold itself: the reference compares an fp32 tensor with the Python
+ * double `radius ** 2`, which torch rounds to fp32 -- NOT the fp32 product radius * radius (0.2f * 0.2f is one ulp
+ * above (float)0.04).  `form` = HITADV_FORM_SQUARE_DISTANCE (the reference's Gram-form square_distance(new_xyz, xyz),
+ * bit for bit: the table equals the reference's) or HITADV_FORM_DIRECT. */
+int hitadv_query_ball_point_victim(int b, int n, int m, float radius2, int nsample, int form, const float *new_xyz,
+                                   const float *xyz, int64_t *idx, void *stream);
 /* src/group_points.cpp:4-6 */
 int hitadv_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
                         const int32_t *idx, float *out, void *stream);

@@ -139,7 +139,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
-FORM_DIRECT, FORM_GRAM, FORM_GRAM_KNN = 0, 1, 2  # pair_value() in pointnet2_oracle.c
+FORM_DIRECT, FORM_GRAM, FORM_GRAM_KNN, FORM_SQUARE_DISTANCE, FORM_PCT_DISTS = 0, 1, 2, 3, 4  # pair_value() in pointnet2_oracle.c
 
 
 def pairwise(x, y, form=FORM_DIRECT):
@@ -183,4 +183,30 @@ def fps_from_start(xyz, npoint, start):
     B, N, _ = p.shape
     out = torch.zeros(B, npoint, dtype=torch.int64)
     lib().oracle_fps_from_start(B, N, npoint, pp, _p(s), _p(out))
+    return out
+
+
+def fps_pct(xyz, npoint, start):
+    """PCT's sampler (util/other_utils.py:254-272) from given first indices -> i64[B,npoint]."""
+    p, pp = _f(xyz)
+    s = start.detach().contiguous().to(torch.int64)
+    B, N, _ = p.shape
+    out = torch.zeros(B, npoint, dtype=torch.int64)
+    lib().oracle_fps_pct(B, N, npoint, pp, _p(s), _p(out))
+    return out
+
+
+def radius_squared(radius):
+    """``sqrdists > radius ** 2`` compares an fp32 tensor with a Python double: torch rounds the scalar to fp32."""
+    return float(np.float32(float(radius) ** 2))
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz, form=FORM_SQUARE_DISTANCE):
+    """The victims' query_ball_point (model/pointnet2_utils.py:87-107), argument order as there -> i64[B,S,nsample]."""
+    q, qp = _f(new_xyz)
+    p, pp = _f(xyz)
+    B, m, _ = q.shape
+    n = p.shape[1]
+    out = torch.zeros(B, m, nsample, dtype=torch.int64)
+    lib().oracle_query_ball_form(B, n, m, ctypes.c_float(radius_squared(radius)), nsample, form, qp, pp, _p(out))
     return out

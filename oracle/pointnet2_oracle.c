@@ -33,9 +33,16 @@ static inline float sqdist3(const float *a, const float *b) {
  * torch in tests/test_oracle_gram.py):
  *   form 1  util/set_distance.py:15-32   P = (rx_i + ry_j) - 2 zz_ij, rx / ry = diagonal of bmm(x, x^T) (an FMA chain)
  *   form 2  util/dist_utils.py:148-150   dist = (xx_j + (-2 zz_ij)) + xx_i, xx = sum(pc ** 2, dim=1) (plain adds)
+ *   form 3  model/pointnet2_utils.py:19-41 (= model/pct_utils.py:40-58, ShapeAttack/HiT_ADV.py:447-468) square_distance(src = q, dst = p):
+ *           dist = -2 zz; dist += sum(src ** 2, -1); dist += sum(dst ** 2, -1)  =>  ((-2 zz_ij) + r_i) + r_j, r = (x*x + y*y) + z*z
+ *   form 4  util/other_utils.py:237-251 get_dists(points1 = ONE point per cloud [B,1,3], points2) as PCT's sampler calls it:
+ *           sqrt(where(d < 0, 1e-7, d)), d = (r_q + r_p) - 2 zz.  The product of a ONE-row matrix does not go through the GEMM
+ *           kernel: MKL evaluates it as fma(q1, p1, q0 p0) + q2 p2 (checked bit for bit, tests/test_oracle_gram.py).
  * form 0 is the project's direct form.  q = the row / query point (i), p = the column / reference point (j).
  */
 static inline float dot3_fma(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+static inline float dot3_row(const float *a, const float *b) { return fmaf(a[1], b[1], a[0] * b[0]) + a[2] * b[2]; }
+static inline float sumsq3(const float *a) { return (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]; }
 
 static inline float pair_value(int form, const float *q, const float *p) {
   if (form == 1) {
@@ -46,6 +53,12 @@ static inline float pair_value(int form, const float *q, const float *p) {
     float xq = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2], xp = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
     float inner = -2.0f * dot3_fma(q, p);
     return (xp + inner) + xq;
+  }
+  if (form == 3) return ((-2.0f * dot3_fma(q, p)) + sumsq3(q)) + sumsq3(p);
+  if (form == 4) {
+    float d = (sumsq3(q) + sumsq3(p)) - 2.0f * dot3_row(q, p);
+    if (d < 0) d = 1e-7f;
+    return sqrtf(d);
   }
   return sqdist3(q, p);
 }
@@ -331,4 +344,52 @@ void oracle_fps_from_start(int b, int n, int m, const float *xyz, const int64_t 
     }
   }
   free(run);
+}
+
+/*
+ * PCT's sampler, util/other_utils.py:254-272: running distance 1e5, distances by get_dists (form 4: sqrt of the clamped
+ * Gram form, the current point as a one-row matrix), update where cur < running, arg-max of the running distances with
+ * the lowest index on ties (torch.max over a CPU tensor).
+ */
+void oracle_fps_pct(int b, int n, int m, const float *xyz, const int64_t *start, int64_t *idxs) {
+  float *run = (float *)malloc(sizeof(float) * n);
+  for (int bi = 0; bi < b; ++bi) {
+    const float *P = xyz + (size_t)bi * n * 3;
+    for (int k = 0; k < n; ++k) run[k] = 1e5f;
+    int64_t far = start[bi];
+    for (int j = 0; j < m; ++j) {
+      idxs[(size_t)bi * m + j] = far;
+      float best = -INFINITY;
+      int64_t bk = 0;
+      for (int k = 0; k < n; ++k) {
+        float d = pair_value(4, P + far * 3, P + k * 3);
+        if (d < run[k]) run[k] = d;
+        if (run[k] > best) { best = run[k]; bk = k; }
+      }
+      far = bk;
+    }
+  }
+  free(run);
+}
+
+/*
+ * query_ball_point of the victims, model/pointnet2_utils.py:87-107 (= model/pct_utils.py:77-96,
+ * ShapeAttack/HiT_ADV.py:512-532): square_distance in the given form, entries with d > r2 dropped (r2 = the fp32 value
+ * of the Python double radius ** 2: a float tensor compared with a Python scalar is compared in fp32), the first nsample
+ * survivors in index order, padded with the first survivor; an empty ball is nsample times n.
+ */
+void oracle_query_ball_form(int b, int n, int m, float r2, int nsample, int form, const float *new_xyz, const float *xyz,
+                            int64_t *idx) {
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < m; ++j) {
+      const float *q = new_xyz + ((size_t)bi * m + j) * 3;
+      int64_t *out = idx + ((size_t)bi * m + j) * nsample;
+      int cnt = 0;
+      for (int k = 0; k < n && cnt < nsample; ++k) {
+        float d = pair_value(form, q, xyz + ((size_t)bi * n + k) * 3);
+        if (!(d > r2)) out[cnt++] = k;
+      }
+      int64_t first = cnt ? out[0] : n;
+      for (int l = cnt; l < nsample; ++l) out[l] = first;
+    }
 }

@@ -60,3 +60,19 @@ def hp_from_fixture(fx):
             hp[k[3:]] = int(v) if float(v).is_integer() and k[3:] in (
                 'central_num', 'total_central_num', 'binary_step', 'num_iter', 'curv_loss_knn') else float(v)
     return hp
+
+
+def gradient_close(g, gd, what, frac_bound=2e-3, l2_bound=3e-2):
+    """An input gradient of a deep victim against a reference evaluation (float64 module, or the reference's own fp32
+    gradient in a fixture).  The gradient is piecewise: where two evaluations disagree on a ReLU sign or on the winner of a
+    max whose two best candidates are an fp32 rounding apart, a whole path's contribution moves.  So: all but a few elements
+    agree to 1e-3, and what the few that do not carry is small against the gradient as a whole.  Records what was achieved."""
+    g = torch.as_tensor(np.asarray(g.detach().cpu() if torch.is_tensor(g) else g)).double()
+    gd = torch.as_tensor(np.asarray(gd.detach().cpu() if torch.is_tensor(gd) else gd)).double()
+    scale = float(gd.abs().max())
+    bad = float(((g - gd).abs() > 1e-3 * gd.abs() + 1e-5 * scale).double().mean())
+    l2 = float((g - gd).norm() / gd.norm())
+    PARITY.setdefault(os.environ.get('PYTEST_CURRENT_TEST', 'unknown').split(' ')[0], []).append(
+        dict(what=what + ' (fraction of elements off by > 1e-3, relative L2 error)', max_abs=bad, max_rel=l2,
+             max_abs_over_scale=l2, rtol=l2_bound, atol=frac_bound, n=int(g.numel())))
+    assert bad <= frac_bound and l2 <= l2_bound, (what, bad, l2)

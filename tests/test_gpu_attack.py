@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from helpers import close as _close
-from helpers import T, golden, hp_from_fixture, synth_batch, toy_from_fixture
+from helpers import T, golden, gradient_close, hp_from_fixture, synth_batch, toy_from_fixture
 from oracle import hitadv_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -621,10 +621,9 @@ def test_dgcnn_attack_view_and_edge_max_kernels():
 
 
 def test_pointnet2_victim_on_gpu():
-    """PointNet++ SSG with HIP FPS / ball query against the reference (fixture g11): same FPS table bit for bit,
-    same ball-query table (up to points within fp32 noise of the sphere: the reference thresholds Gram-form
-    distances), logits and input gradient to tolerance; and HiT-ADV runs on it (eager: the per-forward CPU
-    randint of the victim cannot be captured, the attack falls back by itself)."""
+    """PointNet++ SSG with HIP FPS / ball query against the reference (fixture g11): the FPS table AND the ball-query
+    table bit for bit (the ball query thresholds the reference's own Gram-form distances), logits and input gradient to
+    tolerance; and HiT-ADV runs on it, its loop captured (the victim's FPS starts come from the attack's pre-drawn feed)."""
     import warnings
     from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
     from hit_adv_amd.model import pointnet2 as P2
@@ -637,14 +636,13 @@ def test_pointnet2_victim_on_gpu():
     torch.manual_seed(int(fx['fwd_seed']))
     fps1 = P2.farthest_point_sample(pts, 512)
     assert torch.equal(fps1.cpu(), T(fx['fps1']))
-    ball1 = P2.query_ball_point(0.2, 32, pts, P2.index_points(pts, fps1)).cpu()
-    assert (ball1 != T(fx['ball1'])).float().mean().item() < 1e-3
+    assert torch.equal(P2.query_ball_point(0.2, 32, pts, P2.index_points(pts, fps1)).cpu(), T(fx['ball1']))
     torch.manual_seed(int(fx['fwd_seed']))
     logits, l3 = m(x)
     assert l3.shape == (2, 1024, 1)
-    close(logits, fx['logits'], rtol=2e-3, atol=2e-4)
+    close(logits, fx['logits'], rtol=1e-4, atol=1e-5, what='PointNet++ logits vs the reference (g11)')
     (logits * T(fx['grad_w']).cuda()).sum().backward()
-    assert np.abs(x.grad.cpu().numpy() - fx['grad_x']).max() <= 0.05 * np.abs(fx['grad_x']).max()
+    gradient_close(x.grad, fx['grad_x'], 'PointNet++ input gradient vs the reference (g11)')
     data, _ = synth_batch(2, 1024, first=1300)
     with torch.no_grad():
         label = m(data[:, :, :3].transpose(1, 2).contiguous().cuda())[0].argmax(1)
@@ -659,7 +657,10 @@ def test_pointnet2_victim_on_gpu():
 
 
 def test_pct_victim_on_gpu():
-    """PCT with HIP FPS / kNN grouping against the reference (fixture g12)."""
+    """PCT with HIP FPS / kNN grouping against the reference (fixture g12): the FPS table bit for bit (the sampler
+    maximises the reference's own sqrt(clamped Gram) distances), logits and input gradient to tolerance.  PCT's input
+    gradient is ill-conditioned in fp32 (tests/test_gpu_configs.py: the plain fp32 module is itself a few per cent (L2)
+    from float64), so two fp32 evaluations are held to that, not to 1e-3."""
     import argparse
     from hit_adv_amd.model import pct as PCT
     fx = golden('g12_pct.npz')
@@ -668,13 +669,12 @@ def test_pct_victim_on_gpu():
     x = T(fx['x']).cuda().requires_grad_()
     torch.manual_seed(int(fx['fwd_seed']))
     fps1 = PCT.fps(x.detach().transpose(1, 2).contiguous(), 512)
-    # the reference maximises sqrt(clamped Gram distance): same arg-max except for fp32 near-ties
-    assert (fps1.cpu() != T(fx['fps1'])).float().mean().item() < 0.02
+    assert torch.equal(fps1.cpu(), T(fx['fps1']))
     torch.manual_seed(int(fx['fwd_seed']))
     logits = m(x)
-    close(logits, fx['logits'], rtol=5e-3, atol=5e-4)
+    close(logits, fx['logits'], rtol=1e-4, atol=1e-5, what='PCT logits vs the reference (g12)')
     (logits * T(fx['grad_w']).cuda()).sum().backward()
-    assert np.isfinite(x.grad.cpu().numpy()).all()
+    gradient_close(x.grad, fx['grad_x'], 'PCT input gradient vs the reference (g12)', frac_bound=1., l2_bound=0.15)
 
 
 def test_hit_adv_pointnet_gpu_vs_cpu_oracle_short_run():

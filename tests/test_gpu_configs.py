@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import close, synth_batch
+from helpers import close, gradient_close, synth_batch
 from oracle import c_oracle as N
 from oracle import hitadv_oracle as O
 from oracle import victim_geometry as VG
@@ -128,9 +128,9 @@ def _restore(mod, saved):
 
 
 def test_cfg4_pointnet2_batch64_2048_points_tables_and_float64_module():
-    """cfg4's forward / input gradient at B = 64, N = 2048: FPS tables bit-exact against the C oracle on the same
-    start indices, ball-query tables against the reference's Gram-form rule (boundary points within fp32 noise of the
-    sphere may differ), logits and input gradient against the float64 module evaluated on the SAME tables."""
+    """cfg4's forward / input gradient at B = 64, N = 2048: FPS tables and ball-query tables bit-exact against the C oracle
+    (the reference's Gram-form rule, pinned to torch and fixture g11 on the CPU) on the same start indices, logits and input
+    gradient against the float64 module evaluated on the SAME tables."""
     from hit_adv_amd.model import _sampling
     from hit_adv_amd.model import pointnet2 as P2
     torch.manual_seed(13)
@@ -156,9 +156,8 @@ def test_cfg4_pointnet2_batch64_2048_points_tables_and_float64_module():
     assert torch.equal(fps1, N.fps_from_start(pts, 512, starts[0]))
     l1_xyz = VG.index_points(pts, fps1)
     assert torch.equal(fps2, N.fps_from_start(l1_xyz, 128, starts[1]))
-    ref1 = VG.query_ball_point(0.2, 32, pts, l1_xyz)
-    ref2 = VG.query_ball_point(0.4, 64, l1_xyz, VG.index_points(l1_xyz, fps2))
-    assert (ball1 != ref1).float().mean().item() < 1e-3 and (ball2 != ref2).float().mean().item() < 1e-3
+    assert torch.equal(ball1, VG.c_query_ball_point(0.2, 32, pts, l1_xyz))
+    assert torch.equal(ball2, VG.c_query_ball_point(0.4, 64, l1_xyz, VG.index_points(l1_xyz, fps2)))
     # float64 module on the SAME tables (clouds are independent: the first 8 of the 64 keep the CPU time in seconds)
     nb = 8
     md = copy.deepcopy(m).double()
@@ -174,19 +173,7 @@ def test_cfg4_pointnet2_batch64_2048_points_tables_and_float64_module():
 
 
 def _gradient_vs_float64(g, gd, what, frac_bound=2e-3, l2_bound=3e-2):
-    """The input gradient is piecewise: where fp32 and float64 disagree on a ReLU sign or on the winner of a max whose two
-    best candidates are an fp32 rounding apart, a whole path's contribution moves.  So: all but a few elements agree to
-    1e-3, and what the few that do not carry is small against the gradient as a whole."""
-    g, gd = g.detach().cpu().double(), gd.detach().double()
-    scale = float(gd.abs().max())
-    bad = float(((g - gd).abs() > 1e-3 * gd.abs() + 1e-5 * scale).double().mean())
-    l2 = float((g - gd).norm() / gd.norm())
-    from helpers import PARITY
-    import os
-    PARITY.setdefault(os.environ.get('PYTEST_CURRENT_TEST', 'unknown').split(' ')[0], []).append(
-        dict(what=what + ' (fraction of elements off by > 1e-3, relative L2 error)', max_abs=bad, max_rel=l2,
-             max_abs_over_scale=l2, rtol=l2_bound, atol=frac_bound, n=int(g.numel())))
-    assert bad <= frac_bound and l2 <= l2_bound, (what, bad, l2)
+    gradient_close(g, gd, what, frac_bound, l2_bound)
 
 
 def test_dgcnn_gradient_vs_float64_module_on_the_same_graphs():
@@ -362,9 +349,6 @@ def test_cfg5_pct_batch32_cw_sweep_vs_cpu_oracle(which):
 
     gpu_model = copy.deepcopy(cpu_model)
     iters = 3
-    # PCT's sampler: the reference maximises sqrt(clamped Gram distance), the HIP FPS the direct-form squared distance --
-    # the same arg-max except for fp32 near-ties, after which the two sample different subsets (fixture g12: < 2 % of the
-    # table); plus Adam's sign-like first steps.  Hence an envelope of the step size, and a tight bound on the MEDIAN.
     if which == "knn":
         att = CW.CWKNN(gpu_model, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), recording_clip, attack_lr=1e-2,
                        num_iter=iters, verbose=False)
@@ -402,18 +386,16 @@ def test_cfg5_pct_batch32_cw_sweep_vs_cpu_oracle(which):
     rows = trace[:iters]
     assert len(rows) == iters and len(orows) >= iters
     ori = xyz.transpose(1, 2).numpy()
-    # AdvPC and AOF have no distance term: a point's only gradient is the adversarial loss through the victim, tiny for
-    # most points, and Adam divides it by its own magnitude -- from the second step on, rounding-level differences in
-    # that gradient (and PCT's sampler near-ties) move a point by a sizeable fraction of the step.  So: the FIRST iterate
-    # is compared tightly (same start, same first step), later iterates against Adam's reach.  CWKNN's distance term
-    # conditions every point and all iterates stay on the oracle's.
-    tight = iters if which == "knn" else 1
+    # The victim's sampling / grouping tables are the oracle's bit for bit (PCT's sampler and kNN grouping run in the
+    # reference's own arithmetic), so every iterate is compared.  AdvPC and AOF have no distance term: a point's only
+    # gradient is the adversarial loss through the victim, and Adam divides it by its own magnitude -- a rounding-level
+    # difference in a tiny gradient moves that point by a sizeable fraction of the step, which is what the 99th percentile
+    # (not the maximum) bounds.
     for i in range(iters):
         err = np.abs(rows[i] - orows[i])
         assert np.abs(rows[i] - ori).max() <= 0.18 + 1e-6
         assert err.max() <= 2 * lr * (i + 1) + 1e-6, (i, err.max())        # Adam's reach
-        if i < tight:
-            close(np.median(err), 0., rtol=0, atol=1e-6, what='cfg5 %s iterate %d: median |gpu - oracle|' % (which, i))
-            close(np.quantile(err, 0.99), 0., rtol=0, atol=5e-3 if which != "knn" else 1e-3,
-                  what='cfg5 %s iterate %d: 99th percentile |gpu - oracle|' % (which, i))
-    assert final.shape == ofinal.shape and abs(int(succ) - int(osucc)) <= 2
+        close(np.median(err), 0., rtol=0, atol=1e-6, what='cfg5 %s iterate %d: median |gpu - oracle|' % (which, i))
+        close(np.quantile(err, 0.99), 0., rtol=0, atol=1e-4 if which != "knn" else 1e-3,
+              what='cfg5 %s iterate %d: 99th percentile |gpu - oracle|' % (which, i))
+    assert final.shape == ofinal.shape and int(succ) == int(osucc)

@@ -401,6 +401,61 @@ def test_fps_from_start_bit_exact_sizes(A, n, m):
     assert torch.equal(A.fps_from_start(cu(x), m, cu(start)).cpu(), N.fps_from_start(x, m, start))
 
 
+@pytest.mark.parametrize("n,m", [(1024, 512), (512, 256), (2048, 512), (300, 300), (64, 5), (5000, 64)])
+def test_fps_pct_bit_exact_sizes(A, n, m):
+    """PCT's sampler (util/other_utils.py:254-272): running distances = sqrt of the clamped Gram form in torch's own fp32
+    arithmetic (oracle form 4, pinned against torch and fixture g12 in tests/test_oracle_gram.py, test_victims_cpu.py)."""
+    x, _ = clouds(4, n, 245)
+    x[3, 7] = x[3, 3]  # a duplicate: the clamped branch (d < 0 -> 1e-7) and exact ties
+    start = torch.tensor([0, n - 1, n // 2, 3])
+    got = A.fps_pct(cu(x), m, cu(start), reference=True).cpu()
+    assert torch.equal(got, N.fps_pct(x, m, start))
+    assert torch.equal(A.fps_pct(cu(x), m, cu(start), reference=False).cpu(), N.fps_from_start(x, m, start))
+
+
+def test_fps_pct_reproduces_the_reference_table(A):
+    fx = golden('g12_pct.npz')
+    pts = T(fx['x']).transpose(1, 2).contiguous()
+    ref = T(fx['fps1'])
+    assert torch.equal(A.fps_pct(cu(pts), 512, cu(ref[:, 0].contiguous())).cpu(), ref)
+
+
+@pytest.mark.parametrize("n,s,radius,nsample", [(1024, 512, 0.2, 32), (512, 128, 0.4, 64), (2048, 512, 0.2, 32), (300, 77, 0.3, 16),
+                                                (64, 48, 0.05, 8)])
+def test_query_ball_point_victim_bit_exact(A, n, s, radius, nsample):
+    """The victims' ball query (model/pointnet2_utils.py:87-107) on the reference's Gram-form square_distance (oracle form
+    3): threshold = the fp32 value of the double radius ** 2, ``>`` excluded, index order, padded with the first hit, an
+    empty ball = n."""
+    x, _ = clouds(3, n, 246)
+    q = x[:, :s].contiguous().clone()
+    q[0, 1] = 50.  # an empty ball
+    for k in range(2, min(s, 40)):  # points ON the sphere up to rounding: where the two forms and the two thresholds part
+        d = torch.nn.functional.normalize(torch.randn(3, generator=torch.Generator().manual_seed(k)), dim=0)
+        x[1, k + 100 if k + 100 < n else k] = q[1, k] + d * radius
+    for reference, form in ((True, N.FORM_SQUARE_DISTANCE), (False, N.FORM_DIRECT)):
+        got = A.query_ball_point(radius, nsample, cu(x), cu(q), reference=reference).cpu()
+        assert got.dtype == torch.int64 and torch.equal(got, N.query_ball_point(radius, nsample, x, q, form))
+    assert int(got[0, 1, 0]) == n
+
+
+def test_query_ball_point_victim_reproduces_the_reference_table(A):
+    fx = golden('g11_pointnet2.npz')
+    pts = T(fx['x']).transpose(1, 2).contiguous()
+    new = torch.gather(pts, 1, T(fx['fps1']).unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(A.query_ball_point(0.2, 32, cu(pts), cu(new)).cpu(), T(fx['ball1']))
+
+
+@pytest.mark.parametrize("n,s,K", [(1024, 512, 32), (512, 256, 32), (2048, 300, 32), (3000, 64, 32), (300, 77, 8), (64, 48, 33)])
+def test_knn_points_square_distance_form_bit_exact(A, n, s, K):
+    """PCT's knn_point (model/pct_utils.py:98-109): the K smallest entries of square_distance(new_xyz, xyz), oracle form 3."""
+    x, _ = clouds(3, n, 247)
+    q = x[:, :s].contiguous() + 0.
+    x[2, 11] = x[2, 5]
+    d, ix = A.KnnPoints.apply(cu(q), cu(x), K, A.FORM_SQUARE_DISTANCE)
+    rd, rix = N.knn_points(q, x, K, N.FORM_SQUARE_DISTANCE)
+    assert torch.equal(d.cpu(), rd) and torch.equal(ix.cpu(), rix)
+
+
 @pytest.mark.parametrize("n,m", [(1024, 51), (2048, 102), (300, 64), (700, 700), (5000, 33)])
 def test_fps_ext_bit_exact(A, n, m):
     from hit_adv_amd.pointnet2_ops import _ext

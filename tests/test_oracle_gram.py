@@ -10,6 +10,7 @@ import torch
 from helpers import T, golden, synth_batch
 from oracle import c_oracle as N
 from oracle import hitadv_oracle as O
+from oracle import victim_geometry as VG
 
 
 def _clouds(b, n, first):
@@ -56,3 +57,52 @@ def test_gram_forms_reproduce_the_reference_vectors():
     np.testing.assert_allclose(to_pred.mean(1), fx['chamfer_l2'], rtol=2e-7)
     assert np.array_equal(to_gt.max(1).values.numpy(), fx['hausdorff_l1'])
     assert np.array_equal(to_pred.max(1).values.numpy(), fx['hausdorff_l2'])
+
+
+# (N, S) of every sampling / grouping call inside the victims: PointNet++ SSG at 1024 and 2048 points (cfg4), its second
+# set-abstraction level, PCT's two Local_op levels, and two odd sizes
+VICTIM_SHAPES = [(1024, 512), (2048, 512), (512, 128), (512, 256), (300, 77), (64, 48)]
+
+
+@pytest.mark.parametrize("n,s", VICTIM_SHAPES)
+def test_victim_square_distance_and_its_consumers_bit_for_bit(n, s):
+    """form 3 = the victims' ``square_distance`` (model/pointnet2_utils.py:19-41) as torch evaluates it, and on it the
+    ball query (:87-107) and PCT's kNN grouping (model/pct_utils.py:98-109)."""
+    xyz = _clouds(3, n, 400)
+    new_xyz = xyz[:, :s].contiguous() + 0.001
+    assert torch.equal(N.pairwise(new_xyz, xyz, N.FORM_SQUARE_DISTANCE), VG.square_distance(new_xyz, xyz))
+    for radius, nsample in ((0.2, 32), (0.4, 64)):
+        if nsample <= n:
+            assert torch.equal(VG.c_query_ball_point(radius, nsample, xyz, new_xyz), VG.query_ball_point(radius, nsample, xyz, new_xyz))
+    k = 32
+    assert torch.equal(VG.c_pct_knn_point(k, xyz, new_xyz).sort(-1)[0], VG.pct_knn_point(k, xyz, new_xyz).sort(-1)[0])
+
+
+@pytest.mark.parametrize("n,s", [v for v in VICTIM_SHAPES if v[0] >= 200])
+def test_pct_sampler_bit_for_bit(n, s):
+    """form 4 = ``get_dists`` of ONE point against the cloud (util/other_utils.py:237-251; a one-row matrix product takes a
+    different code path in torch's BLAS than the GEMM of forms 1-3) and PCT's sampler on it (:254-272).  Clouds of fewer than
+    134 points would take a third path (torch multiplies matrices with fewer than 400 multiply-adds itself, without
+    BLAS); the reference's PCT samples from 1024 and 512 points (model/pct_cls.py:48-53)."""
+    xyz = _clouds(3, n, 410)
+    cur = xyz[:, 5:6].contiguous()
+    got = N.pairwise(cur, xyz, N.FORM_PCT_DISTS)
+    squared = VG.get_dists_squared(cur, xyz)  # everything in front of the reference's torch.sqrt: bit for bit
+    assert torch.equal(got, torch.from_numpy(np.sqrt(squared.numpy())))  # numpy's fp32 sqrt is the correctly rounded one
+    # torch.sqrt itself is MKL VML's vsSqrt (< 1 ulp, not correctly rounded): at most one ulp off, in a few values per thousand
+    ref = VG.get_dists(cur, xyz)
+    off = got != ref
+    assert off.float().mean().item() < 0.02
+    assert torch.equal(torch.where(off, torch.nextafter(ref, got), ref), got)
+    torch.manual_seed(n + s)
+    want = VG.pct_fps(xyz, s)
+    torch.manual_seed(n + s)
+    assert torch.equal(VG.c_pct_fps(xyz, s), want)
+
+
+def test_ball_query_threshold_is_the_fp32_value_of_the_double_square():
+    """``sqrdists > radius ** 2``: the Python double is rounded to fp32 for the comparison; 0.2f * 0.2f is one ulp above."""
+    r2 = N.radius_squared(0.2)
+    assert r2 == float(np.float32(0.2 ** 2)) and r2 != float(np.float32(0.2) * np.float32(0.2))
+    d = torch.tensor([np.float32(0.2) * np.float32(0.2)], dtype=torch.float32)
+    assert bool((d > 0.2 ** 2).item())  # torch agrees: the fp32 product lies outside the ball

@@ -5,23 +5,26 @@ the module definitions (same parameters, same function) and the oracle geometry 
 import argparse
 
 import numpy as np
+import pytest
 import torch
 
 from helpers import T, golden
 from oracle import victim_geometry as VG
 
 
-def test_pointnet2_cpu_equals_reference_vectors():
+@pytest.mark.parametrize("torch_ops", [False, True], ids=["c", "torch"])
+def test_pointnet2_cpu_equals_reference_vectors(torch_ops):
     from hit_adv_amd.model import pointnet2 as P2
     fx = golden('g11_pointnet2.npz')
     torch.manual_seed(int(fx['init_seed']))
-    m = VG.CpuVictim(P2.get_model(40, normal_channel=False).eval())
+    m = VG.CpuVictim(P2.get_model(40, normal_channel=False).eval(), torch_ops)
     x = T(fx['x']).clone().requires_grad_()
     pts = x.detach().transpose(1, 2).contiguous()
     torch.manual_seed(int(fx['fwd_seed']))
-    fps1 = VG.farthest_point_sample(pts, 512)
+    fps1 = (VG.farthest_point_sample if torch_ops else VG.c_farthest_point_sample)(pts, 512)
     assert torch.equal(fps1, T(fx['fps1']))
-    assert torch.equal(VG.query_ball_point(0.2, 32, pts, VG.index_points(pts, fps1)), T(fx['ball1']))
+    ball = VG.query_ball_point if torch_ops else VG.c_query_ball_point
+    assert torch.equal(ball(0.2, 32, pts, VG.index_points(pts, fps1)), T(fx['ball1']))
     torch.manual_seed(int(fx['fwd_seed']))
     logits, l3 = m(x)
     assert l3.shape == (2, 1024, 1)
@@ -30,14 +33,15 @@ def test_pointnet2_cpu_equals_reference_vectors():
     np.testing.assert_allclose(x.grad, fx['grad_x'], rtol=1e-4, atol=1e-7)
 
 
-def test_pct_cpu_equals_reference_vectors():
+@pytest.mark.parametrize("torch_ops", [False, True], ids=["c", "torch"])
+def test_pct_cpu_equals_reference_vectors(torch_ops):
     from hit_adv_amd.model import pct as PCT
     fx = golden('g12_pct.npz')
     torch.manual_seed(int(fx['init_seed']))
-    m = VG.CpuVictim(PCT.Pct(argparse.Namespace(dropout=0.2), output_channels=40).eval())
+    m = VG.CpuVictim(PCT.Pct(argparse.Namespace(dropout=0.2), output_channels=40).eval(), torch_ops)
     x = T(fx['x']).clone().requires_grad_()
     torch.manual_seed(int(fx['fwd_seed']))
-    assert torch.equal(VG.pct_fps(x.detach().transpose(1, 2).contiguous(), 512), T(fx['fps1']))
+    assert torch.equal((VG.pct_fps if torch_ops else VG.c_pct_fps)(x.detach().transpose(1, 2).contiguous(), 512), T(fx['fps1']))
     torch.manual_seed(int(fx['fwd_seed']))
     logits = m(x)
     np.testing.assert_allclose(logits.detach(), fx['logits'], rtol=1e-5, atol=1e-6)
