@@ -26,6 +26,7 @@ import warnings
 # Independent attacks run on their own HIP streams; the runtime multiplexes streams onto 4 hardware queues by default, and
 # four attacks on four queues shared with everything else serialise again (measured: 23.9 clouds/s at four in flight with 4
 # queues, 27.0 with 8; two in flight: 24.0 either way).  Must be set before the HIP runtime starts.
+_QUEUES_PRESET = os.environ.get("GPU_MAX_HW_QUEUES")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
@@ -33,6 +34,16 @@ import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# What the line reports as `hip_hardware_queues`: the variable's value only if the runtime cannot have started before it was
+# in the environment -- i.e. it was exported by the caller, or nothing had initialised the GPU when this file set it (a
+# profiler's preloaded library does: under rocprofv3 export GPU_MAX_HW_QUEUES=8 in the shell, tools/r03_measure.sh).
+if _QUEUES_PRESET is not None:
+    HW_QUEUES = int(_QUEUES_PRESET)
+elif torch.cuda.is_initialized() or os.environ.get("ROCPROFILER_LIBRARY_CTOR") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+    HW_QUEUES = "unknown (the HIP runtime may have started before GPU_MAX_HW_QUEUES was set: 4 unless exported earlier)"
+else:
+    HW_QUEUES = 8
 
 NUM_ITER, BINARY_STEP = 500, 10
 HP = dict(attack_lr=1e-2, central_num=192, total_central_num=256, init_weight=10., max_weight=80.,
@@ -232,9 +243,9 @@ def hot_loop_kernels(dev, B=32, N=1024):
     # matrix cores execute 6/8 x 16 = 12x fewer cycles per useful flop than the f32 MFMA form would
     W3 = torch.empty(3, 1024, 128, device=dev, dtype=torch.int16)
     lib.hitadv_split_weights_bf16x3(_p(Wt.t().contiguous()), 1024, 128, _p(W3), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    n3 = lib.hitadv_linear_max_fwd_bf16x3_scratch(B, N, 1024)
+    n3 = lib.hitadv_linear_max_fwd_bf16x3_scratch(B, N, 1024, 0)
     pv3, pi3 = torch.empty(n3, device=dev), torch.empty(n3, device=dev, dtype=torch.int32)
-    us3 = round(graph_timed(lambda st: lib.hitadv_linear_max_fwd_bf16x3(_p(h2), _p(W3), _p(bias), B, N, 128, 1024, 1, _p(pv3),
+    us3 = round(graph_timed(lambda st: lib.hitadv_linear_max_fwd_bf16x3(_p(h2), _p(W3), _p(bias), B, N, 128, 1024, 1, 0, _p(pv3),
                                                                         _p(pi3), _p(mo), _p(mi), _p(tk), st)), 2)
     out["linear_max_fwd_bf16x3"] = {"bound": "mfma", "us_per_launch": us3, "useful_tflops": round(flops / us3 / 1e6, 1),
                                     "executed_bf16_tflops": round(6 * flops / us3 / 1e6, 1), "peak_bf16": 2500.0,
@@ -347,11 +358,9 @@ def make_runner(cfg, model, dev, concurrent):
                       verbose=False, **HP)
 
         def run(todo):
+            from hit_adv_amd import groups_in_flight
             ok, i = 0, 0
-            while i < len(todo):
-                n = min(concurrent, len(todo) - i)
-                if n == 3 and concurrent != 3:
-                    n = 2  # a tail of three goes as two and one: three in flight measured slower than two
+            for n in groups_in_flight(len(todo), concurrent):  # a tail of three goes as two and one (shared with eval_ASR)
                 group = todo[i:i + n]
                 res = att.attack_many(group) if len(group) > 1 else [att.attack(*group[0])]
                 ok += sum(int(k) for _, k in res)
@@ -437,7 +446,7 @@ def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_
         "config": {"workload": cfg['workload'], "batch_per_gpu": B, "num_point": N,
                    "parallelism": "independent batch shards, 1 process per GPU",
                    "attacks_in_flight_per_gpu": in_flight,
-                   "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), **info},
+                   "hip_hardware_queues": HW_QUEUES, **info},
         "cloud_iterations_per_s": clouds * iters_per_step / elapsed,
         "attack_success": {"succeeded": succeeded, "attacked": attacked},
         # what RCCL saw: the calls each rank made in this run (all zero in a single-process run)

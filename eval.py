@@ -18,8 +18,12 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# --in_flight 4 needs eight HIP hardware queues; the runtime reads this ONCE, when it starts (torch.cuda.is_available()
+# below already starts it), so it has to be in the environment before anything touches the GPU -- as bench.py does.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
@@ -192,7 +196,9 @@ def main(argv=None):
                          % (args.k + 1, int(args.num_point * 0.016)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    eval_ASR(model, loader, args, attacker, logger=logger, in_flight=args.in_flight)
+    import hit_adv_amd
+    in_flight = hit_adv_amd.attacks_in_flight(args.in_flight)  # 2 at most on the runtime's default four hardware queues
+    eval_ASR(model, loader, args, attacker, logger=logger, in_flight=in_flight)
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
     if rank == 0:
@@ -200,6 +206,7 @@ def main(argv=None):
         print(json.dumps(dict(ASR=r['ASR'], knn=r['knn'], uniform=r['uniform'], curv_std=r['curv_std'],
                               clean_correct=r['at_denom'], batches=r['batches'], batch_size=args.batch_size,
                               world=world, model=args.model, weights=weights, seconds=round(seconds, 3),
+                              attacks_in_flight=in_flight, hip_hardware_queues=hit_adv_amd.hardware_queues(),
                               attack_seconds=round(eval_ASR.last_seconds['attack'], 3),
                               metric_seconds=round(eval_ASR.last_seconds['metrics'], 3),
                               clouds_per_s=round(r['batches'] * args.batch_size / seconds, 3))))

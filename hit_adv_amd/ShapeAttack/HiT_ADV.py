@@ -550,8 +550,10 @@ class HiT_ADV:
             self._view.refresh(self.model)
         # with three or more attacks in flight the victim's 128 -> 1024 layers run on half the chip each (twice as long):
         # the other half stays free for the other streams' short kernels (bench.py: 28.1 instead of 27.0 clouds/s at four)
-        ops.set_linear_max_blocks(128 if len(batches) >= 3 else 0)  # 64 (two clouds per block): 27.3, 32: 22.0 clouds/s
-        try:
+        view = self._view if hasattr(self._view, 'linear_max_blocks') else None
+        if view is not None:
+            before, view.linear_max_blocks = view.linear_max_blocks, (128 if len(batches) >= 3 else view.linear_max_blocks)
+        try:  # 64 workgroups (two clouds per block): 27.3, 32: 22.0 clouds/s
             wss = [self._setup(d, t, slot=i) for i, (d, t) in enumerate(batches)]
             self._prepare_graphs(wss)
             self.last_graph_used = all(ws.graph is not None for ws in wss)
@@ -566,4 +568,5 @@ class HiT_ADV:
                 torch.cuda.current_stream().wait_stream(ws.stream)
             return [self._finish(ws, False) for ws in wss]
         finally:
-            ops.set_linear_max_blocks(0)
+            if view is not None:
+                view.linear_max_blocks = before

@@ -10,9 +10,64 @@ Module names mirror the reference tree so that its callers switch with an import
 All compute runs in libhitadv_hip.so (hand-written HIP for gfx950); there is no CPU path.
 """
 import os as _os
+import sys as _sys
+import warnings as _warnings
 
 # attack_many() runs independent attacks on their own HIP streams; with the runtime's default of 4 hardware queues four of
-# them serialise again (bench.py: 23.9 vs 27.0 clouds/s).  Only effective if the HIP runtime has not started yet.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# them serialise again (bench.py: 23.9 vs 27.0 clouds/s).  The variable is read ONCE, when the HIP runtime starts: setting
+# it here only helps if nothing has touched the GPU yet (importing torch is fine; torch.cuda.is_available(), set_device(),
+# init_process_group('nccl') and a profiler's preloaded library are not).
+_HW_QUEUES_WANTED = 8
+
+
+def _runtime_started():
+    t = _sys.modules.get("torch")
+    return bool(t is not None and t.cuda.is_initialized())
+
+
+_preset = _os.environ.get("GPU_MAX_HW_QUEUES")
+if _preset is None:
+    _os.environ["GPU_MAX_HW_QUEUES"] = str(_HW_QUEUES_WANTED)
+    _QUEUES_IN_TIME = not _runtime_started()
+    if not _QUEUES_IN_TIME:
+        _warnings.warn("hit_adv_amd: the HIP runtime was already initialised when the package was imported, so "
+                       "GPU_MAX_HW_QUEUES=8 cannot take effect in this process (4 hardware queues): attacks in flight are "
+                       "capped at 2.  Export GPU_MAX_HW_QUEUES=8, or import hit_adv_amd, before the first torch.cuda call.",
+                       RuntimeWarning, stacklevel=2)
+else:
+    _QUEUES_IN_TIME = True  # the environment carried it into the process: whatever started the runtime saw it
+
+
+def hardware_queues():
+    """HIP hardware queues this process's streams are multiplexed onto, as far as the package can know: the value of
+    GPU_MAX_HW_QUEUES if it was in the environment before the runtime started, else the runtime's default of 4."""
+    if not _QUEUES_IN_TIME:
+        return 4
+    try:
+        return int(_os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4
+
+
+def attacks_in_flight(requested):
+    """How many independent attacks to run at a time: ``requested``, capped at 2 when the process has only the runtime's
+    4 hardware queues (four attacks on four shared queues serialise again and measure no better than two)."""
+    requested = max(1, int(requested))
+    return requested if hardware_queues() >= 8 else min(requested, 2)
+
+
+def groups_in_flight(pending, in_flight):
+    """Split ``pending`` batches into the group sizes attacked together: ``in_flight`` at a time, and a remainder of three
+    as two and one (three in flight measured slower than two: DESIGN.md section 5).  bench.py and eval_ASR share this."""
+    in_flight = max(1, int(in_flight))
+    sizes = []
+    while pending > 0:
+        n = min(in_flight, pending)
+        if n == 3 and in_flight != 3:
+            n = 2
+        sizes.append(n)
+        pending -= n
+    return sizes
+
 
 __version__ = "0.1.0"

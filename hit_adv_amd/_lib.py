@@ -64,8 +64,8 @@ PROTOTYPES = {
     "hitadv_linear_max_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hitadv_linear_max_fwd_scratch": [_I, _I, _I],
     "hitadv_split_weights_bf16x3": [_P, _I, _I, _P, _P],
-    "hitadv_linear_max_fwd_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "hitadv_linear_max_fwd_bf16x3_scratch": [_I, _I, _I],
+    "hitadv_linear_max_fwd_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "hitadv_linear_max_fwd_bf16x3_scratch": [_I, _I, _I, _I],
     "hitadv_pointnet_rowmlp_fwd": [_I] + [_P] * 13 + [_I, _I, _P],
     "hitadv_pointnet_rowmlp_fwd_stn": [_P] * 15 + [_I, _I, _P],
     "hitadv_pointnet_rowmlp_fwd_deform": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
@@ -83,7 +83,6 @@ PROTOTYPES = {
     "hitadv_lrelu_pool_bwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
     "hitadv_fc_layer": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "hitadv_fc_layer_scratch_floats": [_I, _I, _I],
-    "hitadv_linear_max_bf16x3_set_blocks": [_I],
     "hitadv_fc_layer_pre": [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,

@@ -297,13 +297,12 @@ __global__ __launch_bounds__(256) void split_weights_k(const float *__restrict__
 }
 
 // Point splits per cloud so that the grid has about `cus` blocks (as linear_max_split, csrc/victim.hip: one block per CU;
-// every block first loads its 24 KB / wave of W).  HITADV_V1_CUS (environment, read once) lowers the target: with several
-// attacks in flight a V1 grid that leaves part of the chip to the other streams' latency-bound kernels can be the better
-// trade (tools/README.md); results do not depend on it (the split merge is in point order).
-static int g_bf3_cus_override = 0;  // hitadv_linear_max_bf16x3_set_blocks: 0 = the environment's / default choice
-
-static int bf3_cus() {
-  if (g_bf3_cus_override > 0) return g_bf3_cus_override;
+// every block first loads its 24 KB / wave of W).  `blocks` (a per-call argument; 0 = HITADV_V1_CUS from the environment,
+// read once, or 256) lowers the target: with several attacks in flight a V1 grid that leaves part of the chip to the other
+// streams' latency-bound kernels is the better trade (tools/README.md); results do not depend on it (the split merge is
+// in point order).  The scratch query and the launch derive S / rows / cpb from the SAME function of (B, N, Cout, blocks).
+static int bf3_cus(int blocks) {
+  if (blocks > 0) return blocks;
   static int cus = [] {
     const char *e = getenv("HITADV_V1_CUS");
     const int v = e ? atoi(e) : 256;
@@ -312,9 +311,9 @@ static int bf3_cus() {
   return cus;
 }
 
-static void bf3_split(int B, int N, int Cout, int *S, int *rows, int *cpb) {
+static void bf3_split(int B, int N, int Cout, int blocks, int *S, int *rows, int *cpb) {
   const int colgroups = (Cout + 255) / 256;
-  const int cus = bf3_cus();
+  const int cus = bf3_cus(blocks);
   // fewer workgroups than (clouds x column groups): a block takes several clouds in turn (W stays in its registers)
   *cpb = cus < B * colgroups ? (B * colgroups + cus - 1) / cus : 1;
   int want = (cus + B * colgroups - 1) / (B * colgroups);
@@ -330,12 +329,6 @@ static void bf3_split(int B, int N, int Cout, int *S, int *rows, int *cpb) {
 
 using namespace hitadv;
 
-extern "C" int hitadv_linear_max_bf16x3_set_blocks(int cus) {
-  if (cus != 0 && (cus < 8 || cus > 256)) return HITADV_E_ARG;
-  g_bf3_cus_override = cus;
-  return 0;
-}
-
 extern "C" int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream) {
   if (!W || !W3 || Cout <= 0 || Cin <= 0 || (Cout & 15) || (Cin & 31)) return HITADV_E_ARG;
   const long long total = (long long)Cout * Cin;
@@ -344,22 +337,22 @@ extern "C" int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, ui
   return 0;
 }
 
-extern "C" int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout) {
-  if (B <= 0 || N <= 0 || Cout <= 0) return 0;
+extern "C" int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout, int blocks) {
+  if (B <= 0 || N <= 0 || Cout <= 0 || blocks < 0 || (blocks != 0 && (blocks < 8 || blocks > 256))) return 0;
   int S, rows, cpb;
-  bf3_split(B, N, Cout, &S, &rows, &cpb);
+  bf3_split(B, N, Cout, blocks, &S, &rows, &cpb);
   return (int64_t)B * S * Cout;
 }
 
 extern "C" int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin,
-                                            int Cout, int relu, float *part_val, int32_t *part_idx, float *out,
+                                            int Cout, int relu, int blocks, float *part_val, int32_t *part_idx, float *out,
                                             int64_t *idx, int32_t *tickets, void *stream) {
   if (!X || !W3 || !part_val || !part_idx || !out || !idx || !tickets || B <= 0 || N <= 0 || Cout <= 0 || (Cout & 63) ||
-      (Cin != 64 && Cin != 128) || ((uintptr_t)X & 15) || ((uintptr_t)W3 & 15))
+      (Cin != 64 && Cin != 128) || ((uintptr_t)X & 15) || ((uintptr_t)W3 & 15) || (blocks != 0 && (blocks < 8 || blocks > 256)))
     return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   int S, rows, cpb;
-  bf3_split(B, N, Cout, &S, &rows, &cpb);
+  bf3_split(B, N, Cout, blocks, &S, &rows, &cpb);
   const int ncg = (Cout + 255) / 256;
   dim3 grid((unsigned)(ncg * S * ((B + cpb - 1) / cpb)));
   const size_t shm = (size_t)2 * 3 * B3_TM * (2 * Cin + 32);

@@ -195,7 +195,8 @@ class _PointNetHip(torch.autograd.Function):
             """128 -> 1024 shared layer + max over the points: bf16x3 split (fp32-accurate, 2.7x less matrix time) or the
             f32 MFMA form (``view.matrix_mode = 'f32'``)."""
             if v.matrix_mode == 'bf16x3':
-                return ops.linear_max_fwd_bf16x3(a, v.pieces(name), B, N, bias=getattr(v, name + '_b'), relu=relu)
+                return ops.linear_max_fwd_bf16x3(a, v.pieces(name), B, N, bias=getattr(v, name + '_b'), relu=relu,
+                                                 blocks=v.linear_max_blocks)
             return ops.linear_max_fwd(a, getattr(v, name + '_w'), B, N, bias=getattr(v, name + '_b'), relu=relu)
 
         if v.deform_inputs is not None:  # x is an OUTPUT of the first kernel: the caller's deformation, evaluated inside
@@ -296,16 +297,20 @@ class FoldedPointNet(nn.Module):
     with ``PointNetFeatureModel.attack_view()``; it snapshots the weights at that moment.
     """
 
+    PIECED = ('s3', 't3', 'e3')  # the 128 -> 1024 layers whose weights are also kept as three bf16 pieces
+
     def __init__(self, m):
         super().__init__()
-        self._pieces = {}
         for k, (w, b) in self._folded(m).items():
             self.register_buffer(k + '_w', w.detach().clone())
             self.register_buffer(k + '_b', b.detach().clone())
             self.register_buffer(k + '_wr', w.detach().t().contiguous())  # row-major [Cout,Cin] for dX
+        for name in self.PIECED:  # registered (non-persistent) buffers: .to() / .cuda() move them with the weights
+            wr = getattr(self, name + '_wr')
+            self.register_buffer(name + '_w3', torch.zeros(3, *wr.shape, dtype=torch.int16, device=wr.device), persistent=False)
+        self._split_on = None  # the device the pieces were last split on (the split itself is a HIP kernel)
         if self.s3_wr.is_cuda:
-            for name in ('s3', 't3', 'e3'):
-                self.pieces(name)
+            self._resplit()
 
     @staticmethod
     def _folded(m):
@@ -343,10 +348,18 @@ class FoldedPointNet(nn.Module):
             getattr(self, k + '_w').copy_(w)
             getattr(self, k + '_b').copy_(b)
             getattr(self, k + '_wr').copy_(w.t())
-        for name, buf in self._pieces.items():  # re-split in place
-            from .. import ops
-            ops.split_weights_bf16x3(getattr(self, name + '_wr'), out=buf)
+        if self.s3_wr.is_cuda:
+            self._resplit()  # in place: the addresses a captured graph holds stay valid
         return self
+
+    def _resplit(self):
+        from .. import ops
+        for name in self.PIECED:
+            ops.split_weights_bf16x3(getattr(self, name + '_wr'), out=getattr(self, name + '_w3'))
+        self._split_on = self.s3_wr.device
+
+    linear_max_blocks = 0     # workgroups of the bf16x3 128 -> 1024 kernel (0 = one per CU); HiT_ADV.attack_many sets 128 on
+    #                           ITS view while three or more attacks are in flight.  Per view, not per process.
 
     matrix_mode = 'bf16x3'  # the three 128 -> 1024 layers: 'bf16x3' (three-piece bf16 split, fp32-accurate) or 'f32'
     deform_inputs = None      # (ori, central, perturb, sigma, inv_den) set by HiT-ADV's loop for ONE forward call: the input
@@ -357,12 +370,15 @@ class FoldedPointNet(nn.Module):
     #                           next layer's launch (False: one launch per layer, kept for A/B timing and as a cross-check)
 
     def pieces(self, name):
-        """bf16 pieces [3,Cout,Cin] of a 128 -> 1024 layer's folded weight, split on first use (weights are constants
-        of an attack; ``refresh`` re-splits them in place)."""
-        if name not in self._pieces:
-            from .. import ops
-            self._pieces[name] = ops.split_weights_bf16x3(getattr(self, name + '_wr'))
-        return self._pieces[name]
+        """bf16 pieces [3,Cout,Cin] of a 128 -> 1024 layer's folded weight (weights are constants of an attack; ``refresh``
+        re-splits them in place).  A view that was built on the CPU, or moved to another device since, is split here --
+        eagerly at the first forward pass on the new device, never lazily inside someone's graph capture of a later one."""
+        if self._split_on != self.s3_wr.device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FoldedPointNet: the bf16 weight pieces are stale (the view moved to %s); run one forward "
+                                   "pass or call refresh() before capturing" % self.s3_wr.device)
+            self._resplit()
+        return getattr(self, name + '_w3')
 
     def _lin(self, x, name, relu=True):
         w, b = getattr(self, name + '_w'), getattr(self, name + '_b')

@@ -549,25 +549,25 @@ def split_weights_bf16x3(Wr, out=None):
     return out
 
 
-def linear_max_fwd_bf16x3(x, W3, B, N, bias=None, relu=False):
+def linear_max_fwd_bf16x3(x, W3, B, N, bias=None, relu=False, blocks=0):
     """``linear_max_fwd`` on the bf16 matrix cores at fp32 accuracy (three-piece split of both operands, six cross terms
-    in an fp32 accumulator; csrc/victim_bf3.hip).  W3 = split_weights_bf16x3(Wt.t())."""
+    in an fp32 accumulator; csrc/victim_bf3.hip).  W3 = split_weights_bf16x3(Wt.t()).  ``blocks``: workgroups the launch
+    spreads over (0 = one per CU); results do not depend on it."""
     x = _dev(x, "x")
+    if W3.device != x.device:
+        raise RuntimeError("linear_max_fwd_bf16x3: weight pieces live on %s, the activations on %s" % (W3.device, x.device))
     _, Cout, Cin = W3.shape
-    n = _lib.load().hitadv_linear_max_fwd_bf16x3_scratch(B, N, Cout)
+    n = _lib.load().hitadv_linear_max_fwd_bf16x3_scratch(B, N, Cout, int(blocks))
+    if n <= 0:
+        raise RuntimeError("linear_max_fwd_bf16x3: bad sizes (B=%d, N=%d, Cout=%d, blocks=%d)" % (B, N, Cout, blocks))
     pv = torch.empty(n, device=x.device)
     pi = torch.empty(n, device=x.device, dtype=torch.int32)
     out = torch.empty(B, Cout, device=x.device)
     idx = torch.empty(B, Cout, device=x.device, dtype=torch.int64)
     tickets = _fc_scratch_for(x, 1 << 14)
-    _lib.call("hitadv_linear_max_fwd_bf16x3", _p(x), _p(W3), _p(bias), B, N, Cin, Cout, 1 if relu else 0, _p(pv), _p(pi),
-              _p(out), _p(idx), _p(tickets), _stream())
+    _lib.call("hitadv_linear_max_fwd_bf16x3", _p(x), _p(W3), _p(bias), B, N, Cin, Cout, 1 if relu else 0, int(blocks), _p(pv),
+              _p(pi), _p(out), _p(idx), _p(tickets), _stream())
     return out, idx
-
-
-def set_linear_max_blocks(cus):
-    """Workgroups the bf16x3 ``linear_max_fwd`` spreads over from now on (0 = default); results do not depend on it."""
-    _lib.call("hitadv_linear_max_bf16x3_set_blocks", int(cus))
 
 
 def linear_max_fwd_supported(Cin, Cout):
@@ -737,10 +737,11 @@ class LReluPool(torch.autograd.Function):
         _lib.call("hitadv_lrelu_pool_fwd", _p(Z), B, N, C, ctypes.c_float(slope), _p(out), _p(arg), _stream())
         ctx.save_for_backward(Z, arg)
         ctx.slope = slope
-        return out
+        ctx.mark_non_differentiable(arg)
+        return out, arg
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _garg):
         Z, arg = ctx.saved_tensors
         B, N, C = Z.shape
         g = g.contiguous()
@@ -749,8 +750,10 @@ class LReluPool(torch.autograd.Function):
         return dZ, None
 
 
-def lrelu_pool(Z, slope=0.2):
-    return LReluPool.apply(Z, slope)
+def lrelu_pool(Z, slope=0.2, return_arg=False):
+    """``return_arg``: also the int32 [B,C] table of the points the maxima were taken at (the kernel's own tie rule)."""
+    out, arg = LReluPool.apply(Z, slope)
+    return (out, arg) if return_arg else out
 
 
 def lrelu_pool_supported(C):

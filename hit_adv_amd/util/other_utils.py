@@ -113,7 +113,8 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
     ``in_flight`` > 1 hands that many of this rank's batches at a time to ``val_attack.attack_many`` (HiT_ADV: the
     batches are attacked concurrently on separate HIP streams, with the results and RNG draws of back-to-back
     ``attack`` calls; 4 gives 1.6x the throughput of 1 on one MI355X -- with the eight hardware queues the package asks the HIP
-    runtime for; even counts only: 3 and 5 measured worse than 2 -- and no per-iteration progress lines)."""
+    runtime for (``hit_adv_amd.attacks_in_flight`` caps the count at 2 when they cannot be had); even counts only: 3 and
+    5 measured worse than 2, a tail of three goes as two and one -- and no per-iteration progress lines)."""
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     metrics = metrics or _default_metrics()
     distributed = dist.is_available() and dist.is_initialized()
@@ -162,6 +163,7 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
         seconds['attack'] += t1 - t0
         seconds['metrics'] += time.perf_counter() - t1
 
+    from .. import groups_in_flight
     group = max(1, int(in_flight)) if hasattr(val_attack, 'attack_many') else 1
     pending = []
     presharded = getattr(test_loader, 'rank_sharded', False)  # rank_loader(): only this rank's batches arrive
@@ -173,8 +175,9 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
         if len(pending) == group:
             flush(pending)
             pending = []
-    if pending:
-        flush(pending)
+    for n in groups_in_flight(len(pending), group):  # the tail: three go as two and one, as bench.py's runner does
+        flush(pending[:n])
+        pending = pending[n:]
 
     at_num, at_denom, knn_sum, uni_sum, curv_sum, total_batches = all_reduce_sums(
         [at_num, at_denom, knn_sum, uni_sum, curv_sum, float(n_batches)], device)

@@ -279,14 +279,13 @@ int64_t hitadv_linear_max_fwd_scratch(int B, int N, int Cout);
  * per attack by hitadv_split_weights_bf16x3; 16-byte aligned.  Scratch / tickets as for hitadv_linear_max_fwd
  * (tickets must not be NULL). */
 int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream);
-/* How many workgroups the bf16x3 kernel spreads over (process-wide; 0 = default: one per CU, or HITADV_V1_CUS): with four
- * attacks in flight, 128 -- half the chip, for twice as long -- leaves the other half to the other streams' short kernels
- * (28.1 instead of 27.0 clouds/s).  Results do not depend on it; scratch sizes do: set it before asking for them. */
-int hitadv_linear_max_bf16x3_set_blocks(int cus);
+/* `blocks`: how many workgroups the kernel spreads over (0 = default: one per CU, or HITADV_V1_CUS; else 8..256): with
+ * four attacks in flight, 128 -- half the chip, for twice as long -- leaves the other half to the other streams' short
+ * kernels (28.1 instead of 27.0 clouds/s).  Results do not depend on it; the scratch size does: ask with the same value. */
 int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin, int Cout,
-                                 int relu, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
+                                 int relu, int blocks, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
                                  int32_t *tickets, void *stream);
-int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout);
+int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout, int blocks);
 
 /* ------------------------------------------------------------------ PointNet victim, attack-time view
  * The eval.py victim (model/feature_models.py:71-230: PointNetFeatureModel = PointNetEncoder + STN3d + STNkd) in

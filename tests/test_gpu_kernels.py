@@ -817,8 +817,8 @@ def test_fc_layer_with_its_input_evaluated_on_the_way_in(A, B, T, J, K, NOUT):
 
 
 def test_linear_max_fwd_bf16x3_same_bits_for_every_grid(A):
-    """hitadv_linear_max_bf16x3_set_blocks only changes how the work is spread (point splits merged in point order, or
-    several clouds per block): values and arg-max are the same bits, ties included."""
+    """The ``blocks`` argument only changes how the work is spread (point splits merged in point order, or several clouds
+    per block): values and arg-max are the same bits, ties included."""
     g = torch.Generator().manual_seed(5)
     B, Np, Cin, Cout = 32, 1000, 128, 1024
     x = torch.randn(B * Np, Cin, generator=g).relu()
@@ -826,15 +826,28 @@ def test_linear_max_fwd_bf16x3_same_bits_for_every_grid(A):
     W3 = A.split_weights_bf16x3(cu(torch.randn(Cout, Cin, generator=g) * 0.1))
     bias = cu(torch.randn(Cout, generator=g))
     ref = None
-    try:
-        for blocks in (0, 256, 128, 64, 40, 8):
-            A.set_linear_max_blocks(blocks)
-            out = A.linear_max_fwd_bf16x3(cu(x), W3, B, Np, bias=bias, relu=True)
-            if ref is None:
-                ref = out
-            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), blocks
-    finally:
-        A.set_linear_max_blocks(0)
+    for blocks in (0, 256, 128, 64, 40, 8):
+        out = A.linear_max_fwd_bf16x3(cu(x), W3, B, Np, bias=bias, relu=True, blocks=blocks)
+        if ref is None:
+            ref = out
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), blocks
+    with pytest.raises(RuntimeError):
+        A.linear_max_fwd_bf16x3(cu(x), W3, B, Np, blocks=5)
+
+
+def test_folded_pointnet_pieces_follow_the_view(A):
+    """The bf16 weight pieces are registered buffers: a view built on the CPU and moved afterwards is split on its new
+    device before the first forward pass, and gives the bits of a view built on the GPU."""
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    torch.manual_seed(3)
+    m = PointNetFeatureModel(40, normal_channel=False).eval()
+    late = m.attack_view().cuda()          # folded on the CPU, moved afterwards
+    early = m.cuda().attack_view()
+    assert late.s3_w3.is_cuda and late._split_on is None
+    x = cu(clouds(2, 256, 77)[0].transpose(1, 2).contiguous())
+    a, b = late(x)[0], early(x)[0]
+    assert torch.equal(a, b) and torch.equal(late.e3_w3, early.e3_w3)
+    assert 's3_w3' not in late.state_dict()
 
 
 def test_linear_max_fwd_bf16x3_ties_keep_the_first_point(A):
