@@ -251,6 +251,34 @@ def hot_loop_kernels(dev, B=32, N=1024):
                                     "executed_bf16_tflops": round(6 * flops / us3 / 1e6, 1), "peak_bf16": 2500.0,
                                     "frac_of_bf16_peak": round(6 * flops / us3 / 1e6 / 2500.0, 4), "dtype": "3 x bf16 -> f32",
                                     "flops_per_launch": flops}
+    # what each form of the layer delivers against float64 on this input (max and rms error of the [B,1024] maxima over the
+    # largest of them): the precision claim behind `dtype`
+    ref = (h2.double() @ Wt.double()).view(B, N, 1024).max(dim=1).values + bias.double()
+    ref = ref.clamp_min(0.)
+    top = float(ref.abs().max())
+
+    def err(v):
+        e = (v.double() - ref).abs()
+        return {"max_over_scale": float(e.max()) / top, "rms_over_scale": float(e.pow(2).mean().sqrt()) / top}
+    acc = {"f32_mfma": err(mo.clone())}
+    lib.hitadv_linear_max_fwd(_p(h2), _p(Wt), _p(bias), B, N, 128, 1024, 1, _p(pv), _p(pi), _p(mo), _p(mi), _p(tk),
+                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    acc["f32_mfma"] = err(mo.clone())
+    lib.hitadv_linear_max_fwd_bf16x3(_p(h2), _p(W3), _p(bias), B, N, 128, 1024, 1, 0, _p(pv3), _p(pi3), _p(mo), _p(mi), _p(tk),
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    acc["bf16x3"] = err(mo.clone())
+    W2 = torch.empty(2, 1024, 128, device=dev, dtype=torch.int16)
+    lib.hitadv_split_weights_f16x2(_p(Wt.t().contiguous()), 1024, 128, _p(W2), None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    us2 = round(graph_timed(lambda st: lib.hitadv_linear_max_fwd_f16x2(_p(h2), _p(W2), _p(bias), B, N, 128, 1024, 1, 0, _p(pv3),
+                                                                       _p(pi3), _p(mo), _p(mi), _p(tk), None, st)), 2)
+    lib.hitadv_linear_max_fwd_f16x2(_p(h2), _p(W2), _p(bias), B, N, 128, 1024, 1, 0, _p(pv3), _p(pi3), _p(mo), _p(mi), _p(tk), None,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    acc["fp16x2"] = err(mo.clone())
+    out["accuracy_vs_float64"] = acc
+    out["linear_max_fwd_f16x2"] = {"bound": "mfma", "us_per_launch": us2, "useful_tflops": round(flops / us2 / 1e6, 1),
+                                   "executed_f16_tflops": round(3 * flops / us2 / 1e6, 1), "peak_f16": 2500.0,
+                                   "frac_of_f16_peak": round(3 * flops / us2 / 1e6 / 2500.0, 4), "dtype": "2 x fp16 -> f32",
+                                   "flops_per_launch": flops}
     return out
 
 
@@ -263,6 +291,37 @@ def pointnet_forward_flops(B, N, classes=40):
     per_point += 2 * (64 * 64 + 64 * 128 + 128 * 1024)         # feature transform, encoder tail
     per_cloud = 2 * (1024 * 512 + 512 * 256) * 3 + 2 * 256 * (9 + 4096 + classes)
     return float(B) * (N * per_point + per_cloud)
+
+
+BF16_MFMA_PEAK = 2500.0  # TFLOP/s, dense bf16 MFMA (MI355X_MICROARCH.md; the headline 5 PF figure includes 2:1 sparsity)
+
+
+def loop_floor(B, N, classes=40, matrix_mode='bf16x3', C=192):
+    """What ONE HiT-ADV iteration on the PointNet engine costs at the chip's three ceilings, counted from what the kernels
+    EXECUTE (not from the dense model): the three 128 -> 1024 layers as six bf16 products per useful one (or on the f32
+    matrix cores in `f32` mode), the shared-layer chains, the nine FC layers and their nine backward layers on the f32
+    matrix cores, and the activations / weights that cross HBM once per iteration.  The input-gradient pass behind the
+    max-pools touches ~10 of 64 points per tile: its chain is counted on 32-row blocks (one per tile), its gather as one
+    128-wide row per (cloud, channel).  floor = the three times ADDED (no overlap assumed): a bound from below on the
+    iteration's duration that no schedule of these kernels can beat by more than the overlap it leaves out."""
+    R, tiles = B * N, B * ((N + 63) // 64)
+    v1_useful = 3 * 2.0 * R * 128 * 1024
+    fwd_chain = 2.0 * R * (64 * 128 + (64 * 64 + 64 * 128) + (64 * 64 + 64 * 128))        # V2: s2 | t1, t2 | h1 @ T64, e2
+    fc = 2.0 * B * (3 * (1024 * 512 + 512 * 256) + 256 * (9 + 4096 + classes))             # V4 forward
+    bwd_gather = 3 * 2.0 * B * 1024 * 128                                                  # V3: one W3r row per (cloud, channel)
+    bwd_chain = 2.0 * tiles * 32 * ((128 * 64) + (128 * 64 + 64 * 64) + (128 * 64 + 64 * 64 + 64 * 64))  # V3 on 32-row blocks
+    f32_flop = fwd_chain + 2 * fc + bwd_gather + bwd_chain
+    bf16_flop = {'bf16x3': 6, 'fp16x2': 3}.get(matrix_mode, 0) * v1_useful  # 16-bit MFMA flop (bf16 and fp16 share the peak)
+    if matrix_mode not in ('bf16x3', 'fp16x2'):
+        f32_flop += v1_useful
+    act = 4.0 * R * (64 + 128 + 64 + 64 + 128 + 128)          # a1s a2s h1 a1t a2t a2e: written once by V2 ...
+    hbm = act + 4.0 * R * 3 * 128                               # ... and the three 128-wide ones read once by V1
+    hbm += 2 * 4.0 * (3 * (1024 * 512 + 512 * 256) + 256 * (9 + 4096 + classes))   # FC weights, forward and backward
+    hbm += 3 * 2 * 4.0 * 1024 * 128 + 4.0 * B * N * 3 * 4      # 128 -> 1024 weights (as pieces: the same bytes), clouds in / out
+    hbm += 4.0 * B * (C * 4 * 4 + tiles // B * 4096 * 2)        # attack parameters + Adam moments, transform-gradient partials
+    us = dict(bf16_mfma=bf16_flop / BF16_MFMA_PEAK / 1e6, f32_mfma=f32_flop / F32_MFMA_PEAK / 1e6, hbm=hbm / HBM_PEAK_GBS / 1e3)
+    return dict(executed_bf16_flop=bf16_flop, executed_f32_mfma_flop=f32_flop, hbm_bytes=hbm,
+                us=dict({k: round(v, 2) for k, v in us.items()}), loop_floor_us=round(sum(us.values()), 2))
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline
@@ -408,6 +467,7 @@ def make_runner(cfg, model, dev, concurrent):
         t.append(time.perf_counter())
         if not short:
             made['graph'] = k.last_graph_used
+            made['graph_advpc'], made['graph_aof'] = a.last_graph_used, f.last_graph_used
             made.setdefault('seconds', []).append([round(t[i + 1] - t[i], 3) for i in range(3)])
         return int(s1) + int(s2) + int(s3)
 
@@ -416,7 +476,8 @@ def make_runner(cfg, model, dev, concurrent):
 
     def info():
         sec = made.get('seconds', [[0, 0, 0]])[-1]
-        return dict(hip_graph_knn=made.get('graph'), attacks=["CWAdvPC 2x200", "CWKNN 2500", "CWAOF 2x200"],
+        return dict(hip_graph_knn=made.get('graph'), hip_graph_advpc=made.get('graph_advpc'), hip_graph_aof=made.get('graph_aof'),
+                    attacks=["CWAdvPC 2x200", "CWKNN 2500", "CWAOF 2x200"],
                     seconds_per_attack_last_step=dict(advpc=sec[0], knn=sec[1], aof=sec[2]))
 
     return run, (lambda batch: sweep(batch, short=True)), info, 2 * 200 + 2500 + 2 * 200
@@ -435,15 +496,21 @@ def reduce_over_ranks(elapsed_s, succeeded, attacked, dev, world, collectives):
     return elapsed.item(), counters[0].item(), counters[1].item()
 
 
-def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_step, in_flight, info, collectives):
+def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_step, in_flight, info, collectives,
+             matrix_mode=None, host=None):
     """The fields every configuration's line carries (throughput is whole-job: clouds of all ranks / max-over-ranks time)."""
     B, N = cfg['B'], cfg['N']
     clouds = steps * B * world
     return {
         "metric": cfg['metric'], "value": clouds / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": {"bf16x3": "f32 (128->1024 layers: 3 bf16 pieces per operand, six exact products, f32 accumulate -- f32-accurate)",
+                  "fp16x2": "f32 (128->1024 layers: 2 fp16 pieces per operand, three exact products, f32 accumulate -- error vs "
+                            "float64 no larger than the f32-MFMA kernel's: hot_loop_kernels.accuracy_vs_float64)"}.get(matrix_mode, "f32"),
+        "data": "synthetic",
         "config": {"workload": cfg['workload'], "batch_per_gpu": B, "num_point": N,
+                   **({"matrix_mode": matrix_mode} if matrix_mode else {}), **(host or {}),
                    "parallelism": "independent batch shards, 1 process per GPU",
                    "attacks_in_flight_per_gpu": in_flight,
                    "hip_hardware_queues": HW_QUEUES, **info},
@@ -462,7 +529,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="cfg2: skip the extra one-attack-in-flight measurement")
-    ap.add_argument("--matrix-mode", choices=["bf16x3", "f32"], default=None,
+    ap.add_argument("--no-f32", action="store_true", help="cfg2: skip the extra f32-matrix-mode measurement")
+    ap.add_argument("--matrix-mode", choices=["bf16x3", "fp16x2", "f32"], default=None,
                     help="cfg2: how the PointNet engine runs its 128->1024 layers (default: the engine's own default)")
     ap.add_argument("--iters-per-graph", type=int, default=None, help="HiT-ADV iterations recorded per hipGraph")
     ap.add_argument("--concurrent", type=int, default=None,
@@ -487,19 +555,34 @@ def main():
     from hit_adv_amd import _lib
     _lib.load()  # fail loudly if the HIP library is missing
 
+    # N ranks x (attacks in flight) Python-driven graph replays share one host: every rank keeps to its share of the cores
+    # (intra-op threads only matter for the CPU baseline leg, which runs at N = 1)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    threads = max(1, min(32, avail // max(1, local_world)))
+    torch.set_num_threads(threads)
+    host = {"host_threads_per_rank": threads, "host_cpus_visible": avail}
+
     model = build_victim(cfg).to(dev)
-    if args.matrix_mode is not None:
+    matrix_mode = None
+    if cfg['victim'] == 'pointnet':
         from hit_adv_amd.model.pointnet import FoldedPointNet
-        FoldedPointNet.matrix_mode = args.matrix_mode
+        if args.matrix_mode is not None:
+            FoldedPointNet.matrix_mode = args.matrix_mode
+        matrix_mode = FoldedPointNet.matrix_mode
     if args.iters_per_graph is not None:
         from hit_adv_amd.ShapeAttack import HiT_ADV as _H
         _H.HiT_ADV._chunk = lambda self, n=args.iters_per_graph: max(1, min(n, self.num_iter))
     run, prewarm, info, iters_per_step = make_runner(cfg, model, dev, concurrent)
     nbatch = warmup + steps
     extra = 2 if (args.config == 'cfg2' and not args.no_single and world == 1) else 0
+    extra_f32 = concurrent if (extra and matrix_mode in ('bf16x3', 'fp16x2') and not args.no_f32) else 0
     batches = []
-    for s in range(nbatch + extra + 1):  # every (rank, step) attacks distinct clouds; all resident in HBM up front
-        data, _ = synth((rank * (nbatch + extra + 1) + s) * B, B, N)
+    for s in range(nbatch + extra + extra_f32 + 1):  # every (rank, step) attacks distinct clouds; all resident in HBM up front
+        data, _ = synth((rank * (nbatch + extra + extra_f32 + 1) + s) * B, B, N)
         data = data.to(dev)
         with torch.no_grad():  # labels = clean predictions, so every cloud starts correctly classified
             label = logits_of(model, data[:, :, :3].transpose(1, 2).contiguous()).argmax(1)
@@ -513,7 +596,7 @@ def main():
         torch.cuda.synchronize()
 
     torch.manual_seed(1234 + rank)
-    single = None
+    single, other_modes = None, {}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         prewarm(batches[-1])
@@ -530,28 +613,48 @@ def main():
                 run([b])
             torch.cuda.synchronize()
             single = (time.perf_counter() - t1) / extra
+        other_modes = {}
+        if extra_f32:  # informational: one group of attacks with the 128 -> 1024 layers in each of the other forms
+            for mode in ('f32', 'bf16x3'):
+                if mode == matrix_mode:
+                    continue
+                FoldedPointNet.matrix_mode = mode
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                run(batches[nbatch + extra:nbatch + extra + extra_f32])
+                torch.cuda.synchronize()
+                other_modes[mode] = time.perf_counter() - t1
+            FoldedPointNet.matrix_mode = matrix_mode
     per_attack = 3 if cfg['attack'] == 'cw_sweep' else 1
     elapsed, succeeded, attacked = reduce_over_ranks(elapsed, succ, steps * B * per_attack, dev, world, collectives)
 
     if rank == 0:
         in_flight = min(concurrent, max(1, steps)) if cfg['attack'] == 'hit_adv' else 1
         line = headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_step, in_flight, info(),
-                        collectives)
+                        collectives, matrix_mode, host)
         if args.config == 'cfg2':
             line["roofline"] = roofline_pairwise(dev)
             line["hot_loop_kernels"] = hot_loop_kernels(dev)
-            flops = pointnet_forward_flops(B, N)
+            floor = loop_floor(B, N, cfg['classes'], matrix_mode, HP['central_num'])
             eff = elapsed / steps / iters_per_step * 1e6  # wall time per B=32 iteration, all attacks in flight counted
-            line["end_to_end"] = {
-                "flops_per_iteration": flops, "us_per_iteration": round(eff, 2), "attacks_in_flight": in_flight,
-                "achieved_tflops": round(flops / eff / 1e6, 1),
-                "frac_of_f32_mfma_peak": round(flops / eff / 1e6 / F32_MFMA_PEAK, 4),
-                "note": "dense flops of the victim's forward pass per B=32 iteration (the input-gradient pass is sparse "
-                        "behind the max-pool and not counted) over wall time per iteration = ms_per_step / 5000"}
+            line["end_to_end"] = dict(
+                floor, us_per_iteration=round(eff, 2), attacks_in_flight=in_flight,
+                frac=round(floor['loop_floor_us'] / eff, 4), dense_forward_flops=pointnet_forward_flops(B, N),
+                note="loop_floor_us = executed bf16 flop / 2.5 PF + executed f32-MFMA flop / 157.3 TF + HBM bytes / 8 TB/s of "
+                     "ONE B=32 iteration (bench.py::loop_floor); us_per_iteration = ms_per_step / 5000 with "
+                     "`attacks_in_flight` attacks sharing the GPU; frac = floor / measured")
             if single is not None:
+                us1 = single / iters_per_step * 1e6
                 line["single_attack"] = {"value": B / single, "unit": "clouds/s", "ms_per_step": single * 1e3, "steps": extra,
-                                         "attacks_in_flight_per_gpu": 1,
-                                         "us_per_iteration": round(single / iters_per_step * 1e6, 2)}
+                                         "attacks_in_flight_per_gpu": 1, "us_per_iteration": round(us1, 2),
+                                         "frac_of_loop_floor": round(floor['loop_floor_us'] / us1, 4)}
+            for mode, secs in other_modes.items():
+                us_f = secs / extra_f32 / iters_per_step * 1e6
+                line[mode + "_mode"] = {"value": extra_f32 * B / secs, "unit": "clouds/s", "steps": 1,
+                                        "attacks_in_flight_per_gpu": extra_f32, "us_per_iteration": round(us_f, 2),
+                                        "loop_floor_us": loop_floor(B, N, cfg['classes'], mode, HP['central_num'])['loop_floor_us'],
+                                        "note": "the same job with view.matrix_mode = %r for the three 128 -> 1024 layers: one "
+                                                "group of attacks, informational" % mode}
         elif args.config == 'cfg3':
             line["roofline"] = roofline_knn_features(dev)
         elif args.config == 'cfg4':

@@ -4,12 +4,12 @@ most salient points of the cloud and optimised with Adam under a Chamfer / Hausd
 (``dist_func`` on [B,num_add,3] vs [B,K,3]: the ragged-size case of the HIP nearest-neighbour reductions), with the
 usual per-sample bisection of the constraint weight.  Targeted: success means ``pred == target``.
 
-Best-result tracking and the bisection are device-resident (float64 bounds as in the reference).
+Best-result tracking and the bisection are device-resident (float64 bounds as in the reference); one iteration -- victim
+forward / backward, both losses, Adam, best tracking -- is captured into a hipGraph and replayed (util/graph_loop.py).
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
-import torch.optim as optim
 
 from .. import ops
 
@@ -39,10 +39,12 @@ class CWAdd:
     """Class for CW attack (adding points)."""
 
     def __init__(self, model, adv_func, dist_func, attack_lr=1e-2, init_weight=5e3, max_weight=4e4, binary_step=10,
-                 num_iter=500, num_add=512, verbose=True, fast_victim=True):
+                 num_iter=500, num_add=512, verbose=True, fast_victim=True, use_graph='auto'):
         self.model = model.cuda()
         self.model.eval()
         self._victim = Victim(self.model, fast_victim)
+        self.use_graph = use_graph  # 'auto': replay one captured iteration when the victim and the losses allow it
+        self.last_graph_used = False
         self.adv_func = adv_func
         self.dist_func = dist_func
         self.attack_lr = attack_lr
@@ -66,6 +68,7 @@ class CWAdd:
 
     def attack(self, data, target):
         """data [B,num_points,3], target [B] -> (o_bestdist float64 [B], float64 [B,num_points+n_add,3], successes)."""
+        from ..util.graph_loop import IterationGraph
         self._victim.prepare()
         B, K = data.shape[:2]
         ori = data.float().cuda().detach().transpose(1, 2).contiguous()
@@ -74,48 +77,96 @@ class CWAdd:
         f64 = dict(device=dev, dtype=torch.float64)
         lower = torch.zeros(B, **f64)
         upper = torch.full((B,), float(self.max_weight), **f64)
+        init = self._init_points(ori, target)
+        n_add = init.shape[2]
+        # state of the loop at fixed addresses (updated in place), so that one iteration can be captured and replayed
         weight = torch.full((B,), float(self.init_weight), **f64)
         o_bestdist = torch.full((B,), 1e10, **f64)
         o_bestscore = torch.full((B,), -1, device=dev, dtype=torch.int64)
-        init = self._init_points(ori, target)
-        n_add = init.shape[2]
         o_bestattack = torch.zeros(B, 3, n_add, device=dev)
+        bestdist = torch.full((B,), 1e10, **f64)
+        bestscore = torch.full((B,), -1, device=dev, dtype=torch.int64)
+        last_input = init.clone()
+        adv = init.clone().requires_grad_()
+        m, v = torch.zeros_like(init), torch.zeros_like(init)
+        step = torch.zeros(1, device=dev, dtype=torch.int32)
+        adv_loss, dist_loss = torch.zeros((), device=dev), torch.zeros((), device=dev)
+        shown_adv, shown_dist = torch.zeros((), device=dev), torch.zeros((), device=dev)
+        hits = torch.zeros((), device=dev, dtype=torch.int64)
+
+        def iteration():
+            logits = self._logits(torch.cat([ori, adv], dim=-1))
+            pred = logits.argmax(dim=-1)
+            with torch.no_grad():
+                shown_adv.copy_(adv_loss)    # the progress line shows the losses of the PREVIOUS iteration (:113-116)
+                shown_dist.copy_(dist_loss)
+                hits.copy_((pred == target).sum())
+                last_input.copy_(adv)
+                dist_val = self._dist(adv, ori, batch_avg=False).detach().double()
+                hit = pred == target
+                better = hit & (dist_val < bestdist)
+                bestdist.copy_(torch.where(better, dist_val, bestdist))
+                bestscore.copy_(torch.where(better, pred, bestscore))
+                o_better = hit & (dist_val < o_bestdist)
+                o_bestdist.copy_(torch.where(o_better, dist_val, o_bestdist))
+                o_bestscore.copy_(torch.where(o_better, pred, o_bestscore))
+                o_bestattack.copy_(torch.where(o_better[:, None, None], adv.detach(), o_bestattack))
+            a = self.adv_func(logits, target).mean()
+            d = self._dist(adv, ori, weights=weight).mean()
+            g, = torch.autograd.grad(a + d, adv)
+            with torch.no_grad():
+                adv_loss.copy_(a)
+                dist_loss.copy_(d)
+                ops.adam_single(adv, g, m, v, step, self.attack_lr)  # torch.optim.Adam's update (defaults)
+
+        def start_step(first):
+            with torch.no_grad():
+                adv.copy_(first)
+                m.zero_()
+                v.zero_()
+                step.zero_()
+                bestdist.fill_(1e10)
+                bestscore.fill_(-1)
+                adv_loss.zero_()
+                dist_loss.zero_()
+
+        def start_search():
+            with torch.no_grad():
+                weight.fill_(float(self.init_weight))
+                o_bestdist.fill_(1e10)
+                o_bestscore.fill_(-1)
+                o_bestattack.zero_()
+                last_input.copy_(init)
+
+        total = self.binary_step * self.num_iter
+        graph = self.use_graph if total >= 16 else False
+        loop = IterationGraph(iteration, graph, 'the point-adding iteration')
+        if graph not in (False, 'never'):
+            self._victim.open_feed(B, K + n_add, total, dev)  # a sampling victim's draws, device-resident
+        if loop.probe():
+            start_search()
+            start_step(init)
+            loop.capture()
+        start_search()
         report_every = max(1, self.num_iter // 5)
-        last_input = init
         for binary_step in range(self.binary_step):
-            adv = (init + torch.randn((B, 3, n_add)).cuda() * 1e-7).requires_grad_()
-            bestdist = torch.full((B,), 1e10, **f64)
-            bestscore = torch.full((B,), -1, device=dev, dtype=torch.int64)
-            opt = optim.Adam([adv], lr=self.attack_lr, weight_decay=0.)
-            adv_loss = torch.zeros((), device=dev)
-            dist_loss = torch.zeros((), device=dev)
-            for iteration in range(self.num_iter):
-                logits = self._logits(torch.cat([ori, adv], dim=-1))
-                pred = logits.argmax(dim=-1)
-                if self.verbose and iteration % report_every == 0:
+            start_step(init + torch.randn((B, 3, n_add)).cuda() * 1e-7)
+            self._victim.load(binary_step * self.num_iter, self.num_iter)
+            loop.enter()
+            for it in range(self.num_iter):
+                loop.step()
+                if self.verbose and it % report_every == 0:
                     print('Step {}, iteration {}, success {}/{}\nadv_loss: {:.4f}, dist_loss: {:.4f}'.format(
-                        binary_step, iteration, (pred == target).sum().item(), B, adv_loss.item(), dist_loss.item()))
-                with torch.no_grad():
-                    last_input = adv.detach().clone()
-                    dist_val = self._dist(adv, ori, batch_avg=False).detach().double()
-                    hit = pred == target
-                    better = hit & (dist_val < bestdist)
-                    bestdist = torch.where(better, dist_val, bestdist)
-                    bestscore = torch.where(better, pred, bestscore)
-                    o_better = hit & (dist_val < o_bestdist)
-                    o_bestdist = torch.where(o_better, dist_val, o_bestdist)
-                    o_bestscore = torch.where(o_better, pred, o_bestscore)
-                    o_bestattack = torch.where(o_better[:, None, None], adv.detach(), o_bestattack)
-                adv_loss = self.adv_func(logits, target).mean()
-                dist_loss = self._dist(adv, ori, weights=weight).mean()
-                opt.zero_grad()
-                (adv_loss + dist_loss).backward()
-                opt.step()
+                        binary_step, it, hits.item(), B, shown_adv.item(), shown_dist.item()))
+            loop.leave_step()
             with torch.no_grad():  # bisection (:196-206)
                 ok = (bestscore == target) & (bestscore != -1) & (bestdist <= o_bestdist)
                 lower = torch.where(ok, torch.maximum(lower, weight), lower)
                 upper = torch.where(ok, upper, torch.minimum(upper, weight))
-                weight = (lower + upper) / 2.
+                weight.copy_((lower + upper) / 2.)
+        loop.leave()
+        self._victim.close_feed()
+        self.last_graph_used = loop.reason is None
         with torch.no_grad():
             best = torch.where((lower == 0.)[:, None, None], last_input, o_bestattack)
         success_num = int((lower > 0.).sum().item())

@@ -12,7 +12,8 @@ class CWTAOF(_CWFamily):
     freeze_model = True  # :105-106
 
     def __init__(self, model, adv_func, dist_func, attack_lr=1e-2, binary_step=2, num_iter=200, GAMMA=0.5,
-                 low_pass=100, clip_func=None, verbose=True):
+                 low_pass=100, clip_func=None, verbose=True, fast_victim=True, use_graph='auto'):
+        self.fast_victim, self.use_graph = fast_victim, use_graph
         self._setup(model, adv_func, dist_func, attack_lr, binary_step, num_iter, GAMMA, clip_func, verbose,
                     low_pass=low_pass)
 

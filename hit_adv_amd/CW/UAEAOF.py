@@ -9,7 +9,8 @@ class CWUAEAOF(_CWFamily):
     fresh = False  # :180-183
 
     def __init__(self, model, ae_model, adv_func, dist_func, attack_lr=1e-2, binary_step=2, num_iter=200, GAMMA=0.25,
-                 low_pass=100, clip_func=None, verbose=True):
+                 low_pass=100, clip_func=None, verbose=True, fast_victim=True, use_graph='auto'):
+        self.fast_victim, self.use_graph = fast_victim, use_graph
         self._setup(model, adv_func, dist_func, attack_lr, binary_step, num_iter, GAMMA, clip_func, verbose,
                     ae_model=ae_model, low_pass=low_pass)
 

@@ -7,7 +7,8 @@ class CWUAdvPC(_CWFamily):
     fresh = False  # best-tracking uses the predictions of the logits the loss was computed on (:109-111)
 
     def __init__(self, model, ae_model, adv_func, dist_func, attack_lr=1e-2, binary_step=2, num_iter=200, GAMMA=0.5,
-                 clip_func=None, verbose=True):
+                 clip_func=None, verbose=True, fast_victim=True, use_graph='auto'):
+        self.fast_victim, self.use_graph = fast_victim, use_graph
         self._setup(model, adv_func, dist_func, attack_lr, binary_step, num_iter, GAMMA, clip_func, verbose,
                     ae_model=ae_model)
 

@@ -8,15 +8,15 @@
              from the logits the loss was computed on, before the step (UAdvPC, UAEAOF)
 
 The per-iteration ``.cpu().numpy()`` copies and the Python loop over samples of the reference become [B]-sized device
-ops; the spectral split uses ``CW/AOF.py``'s HIP-kNN Laplacian.  The auto-encoder is any module mapping [B,3,K] ->
+ops on fixed buffers, the iteration is replayed as a hipGraph (``use_graph=`` in the constructors, ``last_graph_used``
+afterwards); the spectral split uses the HIP-kNN Laplacian of ``CW/_spectral.py``.  The auto-encoder is any module mapping [B,3,K] ->
 [B,3,K'] (the reference ships none).
 """
 import torch
-import torch.optim as optim
 
-from .AOF import get_Laplace_from_pc
-
+from ._spectral import get_Laplace_from_pc
 from ._victim import Victim
+
 
 class _CWFamily:
     spectral = False
@@ -30,6 +30,7 @@ class _CWFamily:
         self.model = model.cuda()
         self.model.eval()
         self._victim = Victim(self.model, getattr(self, 'fast_victim', True))
+        self.last_graph_used = False
         self.ae_model = None
         if ae_model is not None:
             self.ae_model = ae_model.cuda()
@@ -74,9 +75,17 @@ class _CWFamily:
         return ok & ((other != target) | (self.GAMMA < 0.001))
 
     def _run(self, data, target, y_truth=None):
+        """The loop of CW/AdvPC.py:63-79 / CW/AOF.py:106-134 on fixed buffers: one iteration -- up to three victim passes with
+        their input gradients (summed in the reference's order of ``backward`` calls), Adam, clip, the spectral re-split,
+        the fresh predictions and the best-so-far bookkeeping -- is one body that is captured into a hipGraph and replayed
+        ``num_iter`` times per binary step when nothing in it needs the host (util/graph_loop.py)."""
+        from .. import ops
+        from ..util.graph_loop import IterationGraph
         self._victim.prepare()
         B, K = data.shape[:2]
         ori = data.float().cuda().detach().transpose(1, 2).contiguous()
+        if ori.shape[1] == 6:
+            ori = ori[:, :3, :].contiguous()
         target = target.long().cuda().detach()
         if y_truth is not None:
             y_truth = y_truth.long().cuda().detach()
@@ -84,66 +93,111 @@ class _CWFamily:
             for p in self.model.parameters():
                 p.requires_grad = False
         dev = ori.device
+        spectral, ae = self.spectral, self.ae_model
         o_bestdist = torch.full((B,), 1e10, device=dev)
         o_bestscore = torch.full((B,), -1, device=dev, dtype=torch.int64)
         o_bestattack = torch.zeros(B, 3, K, device=dev)
         w_full, w_lfc, w_ae = self._weights()
         report_every = max(1, self.num_iter // 5)
-        adv = ori
-        for binary_step in range(self.binary_step):
-            adv = ori.clone() + torch.randn((B, 3, K)).cuda() * 1e-7
-            if self.spectral:
-                _, V = get_Laplace_from_pc(adv)
-                lfc, hfc = self._split(adv, V)
-                var = lfc.detach().clone().requires_grad_()
-                hfc = hfc.detach().clone()
-            else:
-                var = adv.requires_grad_()
-                hfc = None
-            opt = optim.Adam([var], lr=self.attack_lr, weight_decay=0.)
-            for iteration in range(self.num_iter):
-                full = var + hfc if self.spectral else var
-                logits = self._logits(full)
-                adv_loss = w_full * self.adv_func(logits, target).mean()
-                opt.zero_grad()
-                adv_loss.backward()
-                shown = adv_loss.item() if self.verbose and iteration % report_every == 0 else 0.
-                lfc_logits = ae_logits = None
-                if self.ae_model is not None:  # the reference's order of backward calls: full cloud, AE view, low-pass view
-                    ae_logits = self._logits(self.ae_model(full))
-                    ae_loss = w_ae * self.adv_func(ae_logits, target).mean()
-                    ae_loss.backward()
-                    if not self.spectral:
-                        shown += ae_loss.item() if self.verbose and iteration % report_every == 0 else 0.
-                if self.spectral:
-                    lfc_logits = self._logits(var)
-                    lfc_loss = w_lfc * self.adv_func(lfc_logits, target).mean()
-                    lfc_loss.backward()
-                    shown += lfc_loss.item() if self.verbose and iteration % report_every == 0 else 0.
-                opt.step()
+        # state of the loop at fixed addresses
+        var = ori.clone().requires_grad_()            # the optimised tensor: the cloud, or its low-frequency part
+        hfc = torch.zeros_like(ori) if spectral else None
+        V = torch.zeros(B, K, K, device=dev) if spectral else None
+        adv = ori.clone()                             # the clipped iterate
+        m, v = torch.zeros_like(ori), torch.zeros_like(ori)
+        step = torch.zeros(1, device=dev, dtype=torch.int32)
+        shown = torch.zeros((), device=dev)
+        n_ok = torch.zeros((), device=dev, dtype=torch.int64)
+
+        def iteration():
+            full = var + hfc if spectral else var
+            logits = self._logits(full)
+            adv_loss = w_full * self.adv_func(logits, target).mean()
+            g, = torch.autograd.grad(adv_loss, var)
+            total = adv_loss.detach()
+            lfc_logits = ae_logits = None
+            if ae is not None:  # the reference's order of backward calls: full cloud, AE view, low-pass view
+                ae_logits = self._logits(ae(full))
+                ae_loss = w_ae * self.adv_func(ae_logits, target).mean()
+                g = g + torch.autograd.grad(ae_loss, var)[0]
+                if not spectral:
+                    total = total + ae_loss.detach()
+            if spectral:
+                lfc_logits = self._logits(var)
+                lfc_loss = w_lfc * self.adv_func(lfc_logits, target).mean()
+                g = g + torch.autograd.grad(lfc_loss, var)[0]
+                total = total + lfc_loss.detach()
+            with torch.no_grad():
+                shown.copy_(total)
+                ops.adam_single(var, g, m, v, step, self.attack_lr)  # torch.optim.Adam's update (defaults, no weight decay)
+                adv.copy_(self.clip_func((var + hfc if spectral else var).clone(), ori))
+                if spectral:
+                    new_l, new_h = self._split(adv, V)
+                    var.copy_(new_l)
+                    hfc.copy_(new_h)
+                else:
+                    var.copy_(adv)
+                if self.fresh:
+                    pred = self._logits(adv).argmax(dim=1)
+                    lfc_pred = self._logits(var).argmax(dim=1) if spectral else None
+                    ae_pred = self._logits(ae(adv)).argmax(dim=1) if ae is not None else None
+                else:
+                    pred = logits.argmax(dim=1)
+                    lfc_pred = lfc_logits.argmax(dim=1) if lfc_logits is not None else None
+                    ae_pred = ae_logits.argmax(dim=1) if ae_logits is not None else None
+                dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2]))
+                ok = self._better(pred, lfc_pred, ae_pred, target, y_truth) & (dist_val < o_bestdist)
+                o_bestdist.copy_(torch.where(ok, dist_val, o_bestdist))
+                o_bestscore.copy_(torch.where(ok, pred, o_bestscore))
+                o_bestattack.copy_(torch.where(ok[:, None, None], adv, o_bestattack))
+                n_ok.copy_(self._progress(pred, lfc_pred, ae_pred, target))
+
+        def start_step(init):
+            with torch.no_grad():
+                adv.copy_(init)
+                if spectral:
+                    V.copy_(get_Laplace_from_pc(init)[1])
+                    lfc0, hfc0 = self._split(init, V)
+                    var.copy_(lfc0)
+                    hfc.copy_(hfc0)
+                else:
+                    var.copy_(init)
+                m.zero_()
+                v.zero_()
+                step.zero_()
+
+        def start_search():
+            with torch.no_grad():
+                o_bestdist.fill_(1e10)
+                o_bestscore.fill_(-1)
+                o_bestattack.zero_()
+
+        passes = (1 + (ae is not None) + spectral) * (2 if self.fresh else 1)  # victim forward passes per iteration
+        total_iters = self.binary_step * self.num_iter
+        graph = getattr(self, 'use_graph', 'auto') if total_iters >= 16 else False
+        loop = IterationGraph(iteration, graph, 'the %s iteration' % type(self).__name__)
+        if graph not in (False, 'never'):
+            self._victim.open_feed(B, K, total_iters * passes, dev)  # a sampling victim's draws, device-resident
+        if loop.probe():
+            start_search()
+            if spectral:
                 with torch.no_grad():
-                    adv = self.clip_func((var + hfc if self.spectral else var).detach().clone(), ori)
-                    if self.spectral:
-                        var.data, hfc.data = self._split(adv, V)
-                    else:
-                        var.data = adv
-                    if self.fresh:
-                        pred = self._logits(adv).argmax(dim=1)
-                        lfc_pred = self._logits(var).argmax(dim=1) if self.spectral else None
-                        ae_pred = self._logits(self.ae_model(adv)).argmax(dim=1) if self.ae_model is not None else None
-                    else:
-                        pred = logits.argmax(dim=1)
-                        lfc_pred = lfc_logits.argmax(dim=1) if lfc_logits is not None else None
-                        ae_pred = ae_logits.argmax(dim=1) if ae_logits is not None else None
-                    dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2]))
-                    ok = self._better(pred, lfc_pred, ae_pred, target, y_truth) & (dist_val < o_bestdist)
-                    o_bestdist = torch.where(ok, dist_val, o_bestdist)
-                    o_bestscore = torch.where(ok, pred, o_bestscore)
-                    o_bestattack = torch.where(ok[:, None, None], adv, o_bestattack)
-                if self.verbose and iteration % report_every == 0:
-                    n_ok = self._progress(pred, lfc_pred, ae_pred, target)
+                    V.zero_()  # the probing passes only need SOME basis; the first binary step computes the real one
+            loop.capture()
+        start_search()
+        for binary_step in range(self.binary_step):
+            start_step(ori.clone() + torch.randn((B, 3, K)).cuda() * 1e-7)
+            self._victim.load(binary_step * self.num_iter * passes, self.num_iter * passes)  # this step's passes, drawn now
+            loop.enter()
+            for it in range(self.num_iter):
+                loop.step()
+                if self.verbose and it % report_every == 0:
                     print('Step {}, iteration {}, success {}/{}\nadv_loss: {:.4f}, dist_loss: {:.4f}'.format(
-                        binary_step, iteration, n_ok, B, shown, 0.))
+                        binary_step, it, n_ok.item(), B, shown.item(), 0.))
+            loop.leave_step()
+        loop.leave()
+        self._victim.close_feed()
+        self.last_graph_used = loop.reason is None
         with torch.no_grad():
             best = torch.where((o_bestscore < 0)[:, None, None], adv, o_bestattack)  # failures: the last iterate
             adv_pc = self.clip_func(best, ori) if self.final_clip else best
@@ -154,11 +208,12 @@ class _CWFamily:
         return (o_bestdist.double().cpu().numpy(), adv_pc.detach().cpu().numpy().transpose((0, 2, 1)), success_num)
 
     def _progress(self, pred, lfc_pred, ae_pred, target):
+        """Number of samples the progress line counts as attacked (a 0-d device tensor: read only when a line is printed)."""
         if self.targeted:
-            return (pred == target).sum().item()
+            return (pred == target).sum()
         ok = pred != target
         if lfc_pred is not None:
             ok = ok & (lfc_pred != target)
         if ae_pred is not None:
             ok = ok & (ae_pred != target)
-        return ok.sum().item()
+        return ok.sum()

@@ -508,6 +508,8 @@ class HiT_ADV:
             best = torch.where(fail[:, None, None], ws.adv, st["o_bestattack"])
             st["o_bestdist"].copy_(torch.where(fail, st["dist_val"], st["o_bestdist"]))
         lower_cpu = ws.lower.cpu()
+        if hasattr(self._view, 'check_range'):
+            self._view.check_range()  # fp16x2 victim layers: loud if an operand left fp16's range
         self.last_lower_bound = lower_cpu
         self.last_bestdist = st["o_bestdist"].cpu()
         success_num = (lower_cpu > 0.).sum()
@@ -550,6 +552,7 @@ class HiT_ADV:
             self._view.refresh(self.model)
         # with three or more attacks in flight the victim's 128 -> 1024 layers run on half the chip each (twice as long):
         # the other half stays free for the other streams' short kernels (bench.py: 28.1 instead of 27.0 clouds/s at four)
+        self._victim()  # the view is created on first use: it has to exist before its grid is chosen
         view = self._view if hasattr(self._view, 'linear_max_blocks') else None
         if view is not None:
             before, view.linear_max_blocks = view.linear_max_blocks, (128 if len(batches) >= 3 else view.linear_max_blocks)

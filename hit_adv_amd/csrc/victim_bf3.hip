@@ -33,21 +33,33 @@
 namespace hitadv {
 
 typedef float f32x4b __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8 as_f16x8(uint4 u) { return __builtin_bit_cast(f16x8, u); }
 constexpr int B3_TM = 64;
 
-template <int CIN>
+// MODE 1 -- the same kernel on the fp16 matrix cores with TWO pieces per operand (csrc header of hitadv_linear_max_fwd_f16x2):
+//   a = a1 + 2^-11 a2 + ra,  a1 = fp16(a) (round to nearest: |a - a1| <= 2^-12 |a|, and a - a1 is exact in fp32),
+//   a2 = fp16(2^11 (a - a1)) (the residual scaled back into fp16's normal range), |ra| <= 2^-24 |a|,
+// so  a.b = a1.b1 + 2^-11 (a1.b2 + a2.b1) + [a2.b2 2^-22 + ra.b + a.rb: each <= 2^-24 |a.b|, fp32's own unit roundoff]:
+// THREE fp16 MFMAs (every fp16 x fp16 product is exact in fp32) into two fp32 accumulator sets (one per power of two),
+// joined once per tile -- half the matrix time of the six-product bf16 form.  fp16 tops out at 65504: an operand beyond
+// that raises the caller's range flag (the engine then refuses the result; `matrix_mode = 'bf16x3'` has fp32's range).
+constexpr float F16X2_SCALE = 2048.f;  // 2^11
+
+template <int CIN, int MODE>
 __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restrict__ X, const uint16_t *__restrict__ W3,
                                                             int B_, int N, int Cout, int rows_per_split, int S, int ncg, int cpb,
                                                             float *pval, int32_t *pidx, const float *__restrict__ bias,
                                                             int relu, float *__restrict__ out, int64_t *__restrict__ idx,
-                                                            int *tickets) {
+                                                            int *tickets, int *range_flag) {
+  constexpr int NP = MODE == 1 ? 2 : 3;  // pieces per operand
   constexpr int NSL = CIN / 32;          // 32-deep MFMA slices
   constexpr int RS = 2 * CIN + 32;       // bytes per LDS row of one piece: rows 2 x 16 bytes apart mod 256 make the
                                          // 16x16x32 A-fragment reads (lane -> row lane % 16, chunk lane / 16) conflict-free
   constexpr int PIECE = B3_TM * RS;      // bytes per piece image
   constexpr int G8 = CIN / 8;            // groups of 8 consecutive k per row
   constexpr int ST = B3_TM * G8 / 512;   // 8-value groups staged per thread per tile
-  extern __shared__ __attribute__((aligned(16))) char sB3[];  // 2 buffers x 3 pieces x PIECE
+  extern __shared__ __attribute__((aligned(16))) char sB3[];  // 2 buffers x NP pieces x PIECE
   int cg, s, b;
   {  // XCD-aware block order (see linear_max_fwd_k): the column-group blocks that stream the same x tiles share an XCD
     const int NCG = ncg, id = blockIdx.x, nrg = S * ((B_ + cpb - 1) / cpb);  // cpb > 1 (clouds per block) only with S == 1
@@ -74,11 +86,11 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   // B operand of slice j (32 values of k), column tile ct (16 columns), piece p: the lane's column 16 ct + lane % 16,
   // k = 32 j + 8 (lane / 16) .. + 7.  W3 is stored in fragment order [piece][16-column block][slice][lane] x 16 bytes, so
   // every load instruction of a wave reads 1 KB contiguous.
-  uint4 w[3][2][NSL];
+  uint4 w[NP][2][NSL];
   {
     const uint4 *wp = reinterpret_cast<const uint4 *>(W3) + (size_t)((active ? col0 : 0) / 16) * NSL * 64 + lane;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -111,16 +123,30 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
       float a[8] = {st[u][0].x, st[u][0].y, st[u][0].z, st[u][0].w, st[u][1].x, st[u][1].y, st[u][1].z, st[u][1].w};
 #pragma unroll
       for (int i = 0; i < 8; ++i) a[i] = in ? a[i] : 0.f;
-      uint32_t p1[8], p2[8], p3[8];
+      char *dst = sB3 + (size_t)buf * NP * PIECE + (e / G8) * RS + 16 * (e % G8);
+      if constexpr (MODE == 1) {
+        f16x8 h1, h2;
+        float big = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) split3(a[i], p1[i], p2[i], p3[i]);
-      char *dst = sB3 + (size_t)buf * 3 * PIECE + (e / G8) * RS + 16 * (e % G8);
-      *reinterpret_cast<uint4 *>(dst) = make_uint4(pack_hi(p1[0], p1[1]), pack_hi(p1[2], p1[3]), pack_hi(p1[4], p1[5]),
-                                                   pack_hi(p1[6], p1[7]));
-      *reinterpret_cast<uint4 *>(dst + PIECE) = make_uint4(pack_hi(p2[0], p2[1]), pack_hi(p2[2], p2[3]),
-                                                           pack_hi(p2[4], p2[5]), pack_hi(p2[6], p2[7]));
-      *reinterpret_cast<uint4 *>(dst + 2 * PIECE) = make_uint4(pack_hi(p3[0], p3[1]), pack_hi(p3[2], p3[3]),
-                                                               pack_hi(p3[4], p3[5]), pack_hi(p3[6], p3[7]));
+        for (int i = 0; i < 8; ++i) {
+          h1[i] = (_Float16)a[i];  // round to nearest even
+          h2[i] = (_Float16)((a[i] - (float)h1[i]) * F16X2_SCALE);
+          big = fmaxf(big, fabsf(a[i]));
+        }
+        if (!(big < 65504.f) && range_flag != nullptr) *range_flag = 1;  // beyond fp16 (or NaN): the caller refuses the result
+        *reinterpret_cast<uint4 *>(dst) = __builtin_bit_cast(uint4, h1);
+        *reinterpret_cast<uint4 *>(dst + PIECE) = __builtin_bit_cast(uint4, h2);
+      } else {
+        uint32_t p1[8], p2[8], p3[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split3(a[i], p1[i], p2[i], p3[i]);
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(pack_hi(p1[0], p1[1]), pack_hi(p1[2], p1[3]), pack_hi(p1[4], p1[5]),
+                                                     pack_hi(p1[6], p1[7]));
+        *reinterpret_cast<uint4 *>(dst + PIECE) = make_uint4(pack_hi(p2[0], p2[1]), pack_hi(p2[2], p2[3]),
+                                                             pack_hi(p2[4], p2[5]), pack_hi(p2[6], p2[7]));
+        *reinterpret_cast<uint4 *>(dst + (NP - 1) * PIECE) = make_uint4(pack_hi(p3[0], p3[1]), pack_hi(p3[2], p3[3]),
+                                                                        pack_hi(p3[4], p3[5]), pack_hi(p3[6], p3[7]));
+      }
     }
   };
 
@@ -135,43 +161,68 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   // one tile: 8 units of (slice j, row-tile pair rp): 6 A fragments (2 row tiles x 3 pieces) feed 24 MFMAs; the next
   // unit's fragments are read from LDS while this unit's MFMAs run.  Then the scan.
   auto compute = [&](int tile) {
-    const char *base = sB3 + (size_t)(tile & 1) * 3 * PIECE + l16 * RS + 16 * g4;
-    f32x4b acc[4][2];
+    const char *base = sB3 + (size_t)(tile & 1) * NP * PIECE + l16 * RS + 16 * g4;
+    f32x4b acc[4][2], accl[MODE == 1 ? 4 : 1][2];  // MODE 1: accl collects the 2^-11 terms
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4b{0.f, 0.f, 0.f, 0.f};
-    uint4 fa[2][6];  // [buffer][3 * (row tile within the pair) + piece]
+      for (int ct = 0; ct < 2; ++ct) {
+        acc[rt][ct] = f32x4b{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == 1) accl[rt][ct] = f32x4b{0.f, 0.f, 0.f, 0.f};
+      }
+    uint4 fa[2][2 * NP];  // [buffer][NP * (row tile within the pair) + piece]
     auto frag = [&](int u, int q) {  // unit u = 2 j + rp
-      return *reinterpret_cast<const uint4 *>(base + (q % 3) * PIECE + (2 * (u & 1) + q / 3) * 16 * RS + 64 * (u >> 1));
+      return *reinterpret_cast<const uint4 *>(base + (q % NP) * PIECE + (2 * (u & 1) + q / NP) * 16 * RS + 64 * (u >> 1));
     };
 #pragma unroll
-    for (int q = 0; q < 6; ++q) fa[0][q] = frag(0, q);
+    for (int q = 0; q < 2 * NP; ++q) fa[0][q] = frag(0, q);
 #pragma unroll
     for (int u = 0; u < 2 * NSL; ++u) {
       if (u + 1 < 2 * NSL) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) fa[(u + 1) & 1][q] = frag(u + 1, q);
+        for (int q = 0; q < 2 * NP; ++q) fa[(u + 1) & 1][q] = frag(u + 1, q);
       }
       __builtin_amdgcn_sched_barrier(0);  // the reads stay above this unit's MFMAs
       const int j = u >> 1, rp = u & 1;
-      bf16x8 a[2][3], b[2][3];
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          a[x][p] = as_bf16x8(fa[u & 1][3 * x + p]);
-          b[x][p] = as_bf16x8(w[p][x][j]);
-        }
-      // smallest terms first; the four accumulators of the unit take turns, so consecutive MFMAs are independent
-      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
+      if constexpr (MODE == 1) {
+        f16x8 a[2][2], b[2][2];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
-            acc[2 * rp + x][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[x][PA[t]], b[ct][PB[t]], acc[2 * rp + x][ct], 0, 0, 0);
+          for (int p = 0; p < 2; ++p) {
+            a[x][p] = as_f16x8(fa[u & 1][2 * x + p]);
+            b[x][p] = as_f16x8(w[p][x][j]);
+          }
+        // the eight accumulators of the unit take turns, so consecutive MFMAs are independent
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              if (t == 0) accl[2 * rp + x][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[x][1], b[ct][0], accl[2 * rp + x][ct], 0, 0, 0);
+              if (t == 1) accl[2 * rp + x][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[x][0], b[ct][1], accl[2 * rp + x][ct], 0, 0, 0);
+              if (t == 2) acc[2 * rp + x][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[x][0], b[ct][0], acc[2 * rp + x][ct], 0, 0, 0);
+            }
+      } else {
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            a[x][p] = as_bf16x8(fa[u & 1][NP * x + p]);
+            b[x][p] = as_bf16x8(w[p][x][j]);
+          }
+        // smallest terms first; the four accumulators of the unit take turns, so consecutive MFMAs are independent
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+              acc[2 * rp + x][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[x][PA[t]], b[ct][PB[t]], acc[2 * rp + x][ct], 0, 0, 0);
+      }
     }
     // running (max, first arg-max) per channel: a tile-local best with an inline-constant code (4 rt + i: ascending points),
     // joined with the tile number once
@@ -186,6 +237,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v = acc[rt][ct][i];
+          if constexpr (MODE == 1) v = fmaf(accl[rt][ct][i], 1.f / F16X2_SCALE, v);  // the two powers of two meet
           if (ragged) v = row0 + 16 * rt + i < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
           const bool g = v > tv;
           tv = g ? v : tv;
@@ -280,17 +332,28 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   if (threadIdx.x == 0) __hip_atomic_store(&tickets[b * ncg + cg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// W[Cout,Cin] fp32 (row-major, one row per output channel) -> its three bf16 pieces in FRAGMENT ORDER:
+// W[Cout,Cin] fp32 (row-major, one row per output channel) -> its pieces in FRAGMENT ORDER:
 // W3[piece][c / 16][k / 32][(k % 32) / 8][c % 16][k % 8]  (16 bytes per (piece, 16-column block, slice, lane)).
+// MODE 0: three bf16 pieces (exact); MODE 1: two fp16 pieces, the second scaled by 2^11 (see the kernel's header).
+template <int MODE>
 __global__ __launch_bounds__(256) void split_weights_k(const float *__restrict__ W, uint16_t *__restrict__ W3, int Cout,
-                                                       int Cin) {
+                                                       int Cin, int *range_flag) {
   const long long total = (long long)Cout * Cin;
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int c = (int)(e / Cin), k = (int)(e % Cin);
+  const long long o = ((((long long)(c / 16) * (Cin / 32) + k / 32) * 4 + (k % 32) / 8) * 16 + c % 16) * 8 + k % 8;
+  if (MODE == 1) {
+    const float a = W[e];
+    const _Float16 h1 = (_Float16)a;
+    const _Float16 h2 = (_Float16)((a - (float)h1) * F16X2_SCALE);
+    if (!(fabsf(a) < 65504.f) && range_flag != nullptr) *range_flag = 1;
+    W3[o] = __builtin_bit_cast(uint16_t, h1);
+    W3[total + o] = __builtin_bit_cast(uint16_t, h2);
+    return;
+  }
   uint32_t a, bb, cc;
   split3(W[e], a, bb, cc);
-  const long long o = ((((long long)(c / 16) * (Cin / 32) + k / 32) * 4 + (k % 32) / 8) * 16 + c % 16) * 8 + k % 8;
   W3[o] = (uint16_t)(a >> 16);
   W3[total + o] = (uint16_t)(bb >> 16);
   W3[2 * total + o] = (uint16_t)(cc >> 16);
@@ -332,7 +395,15 @@ using namespace hitadv;
 extern "C" int hitadv_split_weights_bf16x3(const float *W, int Cout, int Cin, uint16_t *W3, void *stream) {
   if (!W || !W3 || Cout <= 0 || Cin <= 0 || (Cout & 15) || (Cin & 31)) return HITADV_E_ARG;
   const long long total = (long long)Cout * Cin;
-  split_weights_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, W3, Cout, Cin);
+  split_weights_k<0><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, W3, Cout, Cin, nullptr);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_split_weights_f16x2(const float *W, int Cout, int Cin, uint16_t *W2, int32_t *range_flag, void *stream) {
+  if (!W || !W2 || Cout <= 0 || Cin <= 0 || (Cout & 15) || (Cin & 31)) return HITADV_E_ARG;
+  const long long total = (long long)Cout * Cin;
+  split_weights_k<1><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, W2, Cout, Cin, range_flag);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -344,9 +415,10 @@ extern "C" int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout, 
   return (int64_t)B * S * Cout;
 }
 
-extern "C" int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin,
-                                            int Cout, int relu, int blocks, float *part_val, int32_t *part_idx, float *out,
-                                            int64_t *idx, int32_t *tickets, void *stream) {
+template <int MODE>
+static int launch_linear_max_pieces(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin, int Cout,
+                                    int relu, int blocks, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
+                                    int32_t *tickets, int32_t *range_flag, void *stream) {
   if (!X || !W3 || !part_val || !part_idx || !out || !idx || !tickets || B <= 0 || N <= 0 || Cout <= 0 || (Cout & 63) ||
       (Cin != 64 && Cin != 128) || ((uintptr_t)X & 15) || ((uintptr_t)W3 & 15) || (blocks != 0 && (blocks < 8 || blocks > 256)))
     return HITADV_E_ARG;
@@ -355,20 +427,35 @@ extern "C" int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, 
   bf3_split(B, N, Cout, blocks, &S, &rows, &cpb);
   const int ncg = (Cout + 255) / 256;
   dim3 grid((unsigned)(ncg * S * ((B + cpb - 1) / cpb)));
-  const size_t shm = (size_t)2 * 3 * B3_TM * (2 * Cin + 32);
+  constexpr int NP = MODE == 1 ? 2 : 3;
+  const size_t shm = (size_t)2 * NP * B3_TM * (2 * Cin + 32);
   if (Cin == 128) {
-    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<128>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 128 + 32));
+    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<128, MODE>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NP * B3_TM * (2 * 128 + 32));
     (void)once;
-    linear_max_fwd_bf3_k<128><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out, idx,
-                                                     tickets);
+    linear_max_fwd_bf3_k<128, MODE><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out,
+                                                           idx, tickets, range_flag);
   } else {
-    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<64>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * B3_TM * (2 * 64 + 32));
+    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<64, MODE>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NP * B3_TM * (2 * 64 + 32));
     (void)once;
-    linear_max_fwd_bf3_k<64><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out, idx,
-                                                    tickets);
+    linear_max_fwd_bf3_k<64, MODE><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out,
+                                                          idx, tickets, range_flag);
   }
   HITADV_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin,
+                                            int Cout, int relu, int blocks, float *part_val, int32_t *part_idx, float *out,
+                                            int64_t *idx, int32_t *tickets, void *stream) {
+  return launch_linear_max_pieces<0>(X, W3, bias, B, N, Cin, Cout, relu, blocks, part_val, part_idx, out, idx, tickets, nullptr,
+                                     stream);
+}
+
+extern "C" int hitadv_linear_max_fwd_f16x2(const float *X, const uint16_t *W2, const float *bias, int B, int N, int Cin,
+                                           int Cout, int relu, int blocks, float *part_val, int32_t *part_idx, float *out,
+                                           int64_t *idx, int32_t *tickets, int32_t *range_flag, void *stream) {
+  return launch_linear_max_pieces<1>(X, W2, bias, B, N, Cin, Cout, relu, blocks, part_val, part_idx, out, idx, tickets, range_flag,
+                                     stream);
 }

@@ -197,6 +197,9 @@ class _PointNetHip(torch.autograd.Function):
             if v.matrix_mode == 'bf16x3':
                 return ops.linear_max_fwd_bf16x3(a, v.pieces(name), B, N, bias=getattr(v, name + '_b'), relu=relu,
                                                  blocks=v.linear_max_blocks)
+            if v.matrix_mode == 'fp16x2':
+                return ops.linear_max_fwd_f16x2(a, v.pieces(name, 2), B, N, bias=getattr(v, name + '_b'), relu=relu,
+                                                blocks=v.linear_max_blocks, range_flag=v.range_flag)
             return ops.linear_max_fwd(a, getattr(v, name + '_w'), B, N, bias=getattr(v, name + '_b'), relu=relu)
 
         if v.deform_inputs is not None:  # x is an OUTPUT of the first kernel: the caller's deformation, evaluated inside
@@ -308,6 +311,9 @@ class FoldedPointNet(nn.Module):
         for name in self.PIECED:  # registered (non-persistent) buffers: .to() / .cuda() move them with the weights
             wr = getattr(self, name + '_wr')
             self.register_buffer(name + '_w3', torch.zeros(3, *wr.shape, dtype=torch.int16, device=wr.device), persistent=False)
+            self.register_buffer(name + '_w2', torch.zeros(2, *wr.shape, dtype=torch.int16, device=wr.device), persistent=False)
+        # raised by the fp16x2 kernels when a weight or an activation lies beyond fp16's range (65504)
+        self.register_buffer('range_flag', torch.zeros(1, dtype=torch.int32, device=self.s3_wr.device), persistent=False)
         self._split_on = None  # the device the pieces were last split on (the split itself is a HIP kernel)
         if self.s3_wr.is_cuda:
             self._resplit()
@@ -354,14 +360,24 @@ class FoldedPointNet(nn.Module):
 
     def _resplit(self):
         from .. import ops
+        self.range_flag.zero_()
         for name in self.PIECED:
             ops.split_weights_bf16x3(getattr(self, name + '_wr'), out=getattr(self, name + '_w3'))
+            ops.split_weights_f16x2(getattr(self, name + '_wr'), out=getattr(self, name + '_w2'), range_flag=self.range_flag)
         self._split_on = self.s3_wr.device
+
+    def check_range(self):
+        """fp16x2 mode: raise if any operand of the 128 -> 1024 layers left fp16's range since the last refresh (one small
+        device-to-host read; the attacks call it where they read their results back anyway)."""
+        if self.matrix_mode == 'fp16x2' and self.range_flag.is_cuda and int(self.range_flag.item()) != 0:
+            raise RuntimeError("FoldedPointNet(matrix_mode='fp16x2'): an activation or weight of a 128 -> 1024 layer exceeds "
+                               "fp16's range (65504); the results are invalid -- use matrix_mode='bf16x3' or 'f32'")
 
     linear_max_blocks = 0     # workgroups of the bf16x3 128 -> 1024 kernel (0 = one per CU); HiT_ADV.attack_many sets 128 on
     #                           ITS view while three or more attacks are in flight.  Per view, not per process.
 
-    matrix_mode = 'bf16x3'  # the three 128 -> 1024 layers: 'bf16x3' (three-piece bf16 split, fp32-accurate) or 'f32'
+    matrix_mode = 'fp16x2'  # the three 128 -> 1024 layers: 'bf16x3' (three bf16 pieces, six products: fp32-accurate), 'fp16x2' (two
+    #                         fp16 pieces, three products: errors at fp32's unit roundoff, half the matrix time) or 'f32'
     deform_inputs = None      # (ori, central, perturb, sigma, inv_den) set by HiT-ADV's loop for ONE forward call: the input
     #                           tensor is then produced by the engine's first kernel (hitadv_pointnet_rowmlp_fwd_deform)
     defer_logits = False      # set by a caller whose loss kernel takes (features, last layer) instead of logits: see forward
@@ -369,8 +385,8 @@ class FoldedPointNet(nn.Module):
     fold_small_layers = True  # the 256 -> 9 layer inside the stage-1 kernel, the 9 / 40 -> 256 backward layers inside the
     #                           next layer's launch (False: one launch per layer, kept for A/B timing and as a cross-check)
 
-    def pieces(self, name):
-        """bf16 pieces [3,Cout,Cin] of a 128 -> 1024 layer's folded weight (weights are constants of an attack; ``refresh``
+    def pieces(self, name, n=3):
+        """bf16 pieces [3,Cout,Cin] (n = 3) or fp16 pieces [2,Cout,Cin] (n = 2) of a 128 -> 1024 layer's folded weight (weights are constants of an attack; ``refresh``
         re-splits them in place).  A view that was built on the CPU, or moved to another device since, is split here --
         eagerly at the first forward pass on the new device, never lazily inside someone's graph capture of a later one."""
         if self._split_on != self.s3_wr.device:
@@ -378,7 +394,7 @@ class FoldedPointNet(nn.Module):
                 raise RuntimeError("FoldedPointNet: the bf16 weight pieces are stale (the view moved to %s); run one forward "
                                    "pass or call refresh() before capturing" % self.s3_wr.device)
             self._resplit()
-        return getattr(self, name + '_w3')
+        return getattr(self, name + ('_w3' if n == 3 else '_w2'))
 
     def _lin(self, x, name, relu=True):
         w, b = getattr(self, name + '_w'), getattr(self, name + '_b')

@@ -570,6 +570,39 @@ def linear_max_fwd_bf16x3(x, W3, B, N, bias=None, relu=False, blocks=0):
     return out, idx
 
 
+def split_weights_f16x2(Wr, out=None, range_flag=None):
+    """Wr [Cout,Cin] fp32 -> its two fp16 pieces [2,Cout,Cin] (int16 storage; the second scaled by 2^11), fragment order of
+    ``split_weights_bf16x3``.  ``range_flag`` (int32[1] on the device) is raised by a weight beyond fp16's range."""
+    Wr = _dev(Wr, "Wr")
+    Cout, Cin = Wr.shape
+    if out is None:
+        out = torch.empty(2, Cout, Cin, device=Wr.device, dtype=torch.int16)
+    _lib.call("hitadv_split_weights_f16x2", _p(Wr), Cout, Cin, _p(out), _p(range_flag), _stream())
+    return out
+
+
+def linear_max_fwd_f16x2(x, W2, B, N, bias=None, relu=False, blocks=0, range_flag=None):
+    """``linear_max_fwd`` on the fp16 matrix cores: two pieces per operand, three exact products per useful one, fp32
+    accumulators (csrc/victim_bf3.hip, MODE 1) -- half the matrix time of the bf16x3 form, errors at fp32's own roundoff
+    level.  W2 = split_weights_f16x2(Wt.t()).  ``range_flag``: int32[1] on the device, raised (never cleared) when an
+    activation lies beyond fp16's range."""
+    x = _dev(x, "x")
+    if W2.device != x.device:
+        raise RuntimeError("linear_max_fwd_f16x2: weight pieces live on %s, the activations on %s" % (W2.device, x.device))
+    _, Cout, Cin = W2.shape
+    n = _lib.load().hitadv_linear_max_fwd_bf16x3_scratch(B, N, Cout, int(blocks))
+    if n <= 0:
+        raise RuntimeError("linear_max_fwd_f16x2: bad sizes (B=%d, N=%d, Cout=%d, blocks=%d)" % (B, N, Cout, blocks))
+    pv = torch.empty(n, device=x.device)
+    pi = torch.empty(n, device=x.device, dtype=torch.int32)
+    out = torch.empty(B, Cout, device=x.device)
+    idx = torch.empty(B, Cout, device=x.device, dtype=torch.int64)
+    tickets = _fc_scratch_for(x, 1 << 14)
+    _lib.call("hitadv_linear_max_fwd_f16x2", _p(x), _p(W2), _p(bias), B, N, Cin, Cout, 1 if relu else 0, int(blocks), _p(pv),
+              _p(pi), _p(out), _p(idx), _p(tickets), _p(range_flag), _stream())
+    return out, idx
+
+
 def linear_max_fwd_supported(Cin, Cout):
     return Cin in (64, 128) and Cout % 64 == 0
 

@@ -287,6 +287,20 @@ int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, const float
                                  int32_t *tickets, void *stream);
 int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout, int blocks);
 
+/* The same operator on the fp16 matrix cores with TWO pieces per operand and THREE products per useful one (half the matrix
+ * time of the bf16 form): a = a1 + 2^-11 a2 + ra with a1 = fp16(a), a2 = fp16(2^11 (a - a1)) (round to nearest; a - a1 is exact
+ * in fp32) and |ra| <= 2^-24 |a|;  a.b = a1.b1 + 2^-11 (a1.b2 + a2.b1) + terms <= 2^-24 |a.b| each -- fp32's own unit roundoff --
+ * with every fp16 x fp16 product exact in the fp32 accumulators (one accumulator set per power of two, joined per tile).
+ * Error against float64 measured next to the f32-MFMA kernel's: tests/test_gpu_kernels.py::test_linear_max_fwd_f16x2_*.
+ * W2 = hitadv_split_weights_f16x2(Wr): 2*Cout*Cin uint16 (fp16 bits) in the fragment order of the bf16 form.
+ * fp16 ends at 65504: `range_flag` (device int32, may be NULL; zero it before the first call) is set to 1 by either entry
+ * point when an operand lies beyond that (or is NaN); results are then meaningless and the caller must fall back to the
+ * bf16x3 / f32 form.  Scratch: hitadv_linear_max_fwd_bf16x3_scratch with the same `blocks`. */
+int hitadv_split_weights_f16x2(const float *W, int Cout, int Cin, uint16_t *W2, int32_t *range_flag, void *stream);
+int hitadv_linear_max_fwd_f16x2(const float *X, const uint16_t *W2, const float *bias, int B, int N, int Cin, int Cout,
+                                int relu, int blocks, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
+                                int32_t *tickets, int32_t *range_flag, void *stream);
+
 /* ------------------------------------------------------------------ PointNet victim, attack-time view
  * The eval.py victim (model/feature_models.py:71-230: PointNetFeatureModel = PointNetEncoder + STN3d + STNkd) in
  * eval mode with every BatchNorm folded into the layer in front of it, as four building blocks that together

@@ -41,6 +41,7 @@ def pytest_sessionfinish(session, exitstatus):
                              worst_max_abs=max(r['max_abs'] for r in rows),
                              worst_abs_over_scale=max(r['max_abs_over_scale'] for r in rows),
                              asserted_rtol=max(r['rtol'] for r in rows), asserted_atol=max(r['atol'] for r in rows),
+                             pinned_comparisons=sum(1 for r in rows if 'pinned_max_abs' in r),
                              rows=rows if len(rows) <= 12 else sorted(rows, key=lambda r: -r['max_rel'])[:12])
     out = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
@@ -48,3 +49,6 @@ def pytest_sessionfinish(session, exitstatus):
     name = 'parity_report_gpu.json' if torch.cuda.is_available() else 'parity_report_cpu.json'
     with open(os.path.join(out, name), 'w') as f:
         json.dump(summary, f, indent=1, sort_keys=True)
+    # every row, in execution order (what tools/make_parity_pins.py reads)
+    with open(os.path.join(out, name.replace('report', 'rows')), 'w') as f:
+        json.dump({t: dict(comparisons=len(r), rows=r) for t, r in PARITY.items()}, f, sort_keys=True)

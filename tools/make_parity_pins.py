@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Turn a GPU parity report (gpurun_out/parity_report_gpu.json, written by tests/conftest.py) into tests/golden/parity_pins.json.
+
+Every float comparison of the GPU suite goes through tests/helpers.py::close(), which records what was ACHIEVED next to what the
+test wrote as its tolerance.  Wherever the written tolerance is more than 10x what was achieved on MI355X, the achieved figure is
+pinned here and close() additionally asserts  max |a - b| <= 4 x pinned  on GPU runs -- so no comparison of the suite is held to
+less than 4x what the hardware actually delivers, without hand-editing a hundred call sites after every kernel change.
+Comparisons whose outcome depends on fp32 near-ties inside the victim (PCT's max-pool winners, tests/test_gpu_configs.py) keep
+their written bounds: those are already set from measurement and vary with the host's BLAS threading.
+
+    python tools/make_parity_pins.py gpurun_out/parity_report_gpu.json [more reports ...] > tests/golden/parity_pins.json
+
+Several reports (different boxes / runs) are merged by taking the LARGEST achieved error per comparison."""
+import json
+import sys
+
+SLACK = 10.0
+SKIP = ('cfg5', 'raw relative L2', 'fraction of elements')
+
+
+def main(paths):
+    pins = {}
+    for path in paths:
+        with open(path) as f:
+            report = json.load(f)
+        for test, v in report.items():
+            rows = v['rows']
+            if v['comparisons'] != len(rows):
+                continue  # the report keeps only the 12 worst rows of a long test: order is lost, nothing is pinned
+            for i, r in enumerate(rows):
+                what = r['what']
+                if any(s in what for s in SKIP) or r['max_abs'] <= 0.0:
+                    continue
+                if r['rtol'] == 0:
+                    ratio = r['atol'] / r['max_abs']
+                else:
+                    ra = r['rtol'] / r['max_rel'] if r['max_rel'] > 0 else float('inf')
+                    ratio = min(ra, r['atol'] / r['max_abs'] if r['atol'] > 0 else float('inf'))
+                    if ratio == float('inf'):
+                        ratio = r['rtol'] * 1.0 / max(r['max_abs_over_scale'], 1e-300)
+                if ratio <= SLACK:
+                    continue
+                slot = pins.setdefault(test, {}).setdefault(what, dict(max_abs=0.0, written_rtol=r['rtol'], written_atol=r['atol']))
+                slot['max_abs'] = max(slot['max_abs'], r['max_abs'])
+    json.dump(pins, sys.stdout, indent=1, sort_keys=True)
+    sys.stdout.write("\n")
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])
