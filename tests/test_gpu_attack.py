@@ -1025,7 +1025,8 @@ def test_cw_family_follows_reference_trajectories(name, cls, ae, targeted, spect
     trace = []
     adv_f = LogitsAdvLoss(kappa=0.) if targeted else UntargetedLogitsAdvLoss(kappa=30.)
     kw = dict(attack_lr=float(fx['lr']), binary_step=2, num_iter=int(fx['num_iter']), GAMMA=float(fx['gamma']),
-              clip_func=_recording(0.3, trace), verbose=False)
+              clip_func=_recording(0.3, trace), verbose=False,
+              use_graph=False)  # the recording hook reads every iterate back: a host round trip per iteration
     if spectral:
         kw['low_pass'] = 40
     model = toy_from_fixture(fx)
