@@ -87,6 +87,10 @@ class _Workspace:
         self.state["bestscore"].fill_(-1)
 
 
+# workgroups of the PointNet engine's 128 -> 1024 kernel while three or more attacks share the GPU (tuning knob; see attack_many)
+_V1_BLOCKS_IN_FLIGHT = int(os.environ.get("HITADV_V1_BLOCKS_IN_FLIGHT", "128"))
+
+
 class HiT_ADV:
     """Class for the HiT-ADV attack (constructor signature of the reference, :18-22)."""
 
@@ -555,7 +559,7 @@ class HiT_ADV:
         self._victim()  # the view is created on first use: it has to exist before its grid is chosen
         view = self._view if hasattr(self._view, 'linear_max_blocks') else None
         if view is not None:
-            before, view.linear_max_blocks = view.linear_max_blocks, (128 if len(batches) >= 3 else view.linear_max_blocks)
+            before, view.linear_max_blocks = view.linear_max_blocks, (_V1_BLOCKS_IN_FLIGHT if len(batches) >= 3 else view.linear_max_blocks)
         try:  # 64 workgroups (two clouds per block): 27.3, 32: 22.0 clouds/s
             wss = [self._setup(d, t, slot=i) for i, (d, t) in enumerate(batches)]
             self._prepare_graphs(wss)

@@ -4,8 +4,9 @@ checkpoints load unchanged.  The network itself stays PyTorch-ROCm; what changes
 
 * ``knn`` (:7-13) keeps the reference's Gram-form score ``-|xi|^2 + 2 xi.xj - |xj|^2`` (one GEMM) but the
   top-k selection runs in ``hitadv_topk_rows`` (sorted, ties -> lower index) instead of ``torch.topk``;
-  for the first EdgeConv (3-D coordinates) the fused ``hitadv_knn_points`` kernel is used and no
-  [B,N,N] matrix exists at all;
+  for the first EdgeConv (3-D coordinates) the fused ``hitadv_knn_points`` kernel is used -- on the reference's own
+  Gram-form values (``ops.victim_reference_arithmetic``), so that table is the reference's -- and no [B,N,N] matrix
+  exists at all;
 * ``get_graph_feature`` (:16-43) builds the edge features on the input's own device (the reference
   hard-codes ``torch.device('cuda')``, :25) with one batched gather.
 """
@@ -14,14 +15,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..pytorch3d_ops import knn_points
 
 
 def knn(x, k):
     """x [B,D,N] -> idx [B,N,k] int64: the k nearest points of every point in feature space, itself included."""
     if x.shape[1] == 3 and x.is_cuda:
-        pts = x.transpose(2, 1).contiguous()
-        return knn_points(pts.detach(), pts.detach(), K=k).idx
+        # the reference's score is -((|x_j|^2 + (-2 x_i.x_j)) + |x_i|^2) in this order of operations (:8-10): the k largest
+        # scores are the k smallest values of the library's GRAM_KNN form, evaluated in torch's own fp32 arithmetic
+        pts = x.transpose(2, 1).contiguous().detach()
+        form = ops.FORM_GRAM_KNN if ops.victim_reference_arithmetic.get() else ops.FORM_DIRECT
+        return ops.KnnPoints.apply(pts, pts, int(k), form)[1]
     inner = -2 * torch.matmul(x.transpose(2, 1), x)
     xx = torch.sum(x ** 2, dim=1, keepdim=True)
     score = -xx - inner - xx.transpose(2, 1)  # [B,N,N], larger = closer

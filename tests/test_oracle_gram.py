@@ -106,3 +106,16 @@ def test_ball_query_threshold_is_the_fp32_value_of_the_double_square():
     assert r2 == float(np.float32(0.2 ** 2)) and r2 != float(np.float32(0.2) * np.float32(0.2))
     d = torch.tensor([np.float32(0.2) * np.float32(0.2)], dtype=torch.float32)
     assert bool((d > 0.2 ** 2).item())  # torch agrees: the fp32 product lies outside the ball
+
+
+def test_dgcnn_first_layer_score_is_the_negated_knn_form():
+    """model/dgcnn_cls.py:7-13 on 3-D coordinates: score = (-|x_j|^2 - (-2 x_i.x_j)) - |x_i|^2 is, operation for operation, the
+    negation of form 2 (negation and a - b = a + (-b) are exact), so its k largest entries are the k smallest form-2 values."""
+    x = _clouds(2, 1024, 330).transpose(1, 2).contiguous()  # [B,3,N]
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    score = -xx - inner - xx.transpose(2, 1)
+    pts = x.transpose(1, 2).contiguous()
+    assert torch.equal(-N.pairwise(pts, pts, N.FORM_GRAM_KNN), score)
+    d, idx = N.knn_points(pts, pts, 5, N.FORM_GRAM_KNN)
+    assert torch.equal(-d, score.topk(k=5, dim=-1).values)
