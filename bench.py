@@ -23,9 +23,9 @@ import sys
 import time
 import warnings
 
-# Independent attacks run on their own HIP streams; the runtime multiplexes streams onto 4 hardware queues by default, and
-# four attacks on four queues shared with everything else serialise again (measured: 23.9 clouds/s at four in flight with 4
-# queues, 27.0 with 8; two in flight: 24.0 either way).  Must be set before the HIP runtime starts.
+# Independent stacks of attacks run on their own HIP streams; the runtime multiplexes streams onto 4 hardware queues by
+# default, and three or four streams on four queues shared with everything else serialise again (measured, 12 attacks in
+# three stacks: 30.3 clouds/s with 4 queues, 37.4 with 8).  Must be set before the HIP runtime starts.
 _QUEUES_PRESET = os.environ.get("GPU_MAX_HW_QUEUES")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md, HBM3E spec peak
 F32_MFMA_PEAK = 157.3   # TFLOP/s, dense f32-input MFMA (= the f32 vector peak), same guide
 
 CONFIGS = {
-    'cfg2': dict(victim='pointnet', B=32, N=1024, classes=40, attack='hit_adv', steps=8, warmup=4, concurrent=4,
+    'cfg2': dict(victim='pointnet', B=32, N=1024, classes=40, attack='hit_adv', steps=24, warmup=12, concurrent=12,
                  metric="attacked point-clouds/sec (HiT-ADV, PointNet, N=1024, 500 iters)",
                  workload="cfg2: synthetic ModelNet40-shaped clouds, 1024 pts, batch 32 per GPU, PointNet victim (random "
                           "init, eval mode), HiT-ADV eval.py hyper-parameters, num_iter=500 x binary_step=10 = 5000 inner "
@@ -419,7 +419,7 @@ def make_runner(cfg, model, dev, concurrent):
         def run(todo):
             from hit_adv_amd import groups_in_flight
             ok, i = 0, 0
-            for n in groups_in_flight(len(todo), concurrent):  # a tail of three goes as two and one (shared with eval_ASR)
+            for n in groups_in_flight(len(todo), concurrent, stacked=att.attacks_per_stack > 1):  # shared with eval_ASR
                 group = todo[i:i + n]
                 res = att.attack_many(group) if len(group) > 1 else [att.attack(*group[0])]
                 ok += sum(int(k) for _, k in res)
@@ -430,8 +430,11 @@ def make_runner(cfg, model, dev, concurrent):
             short = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=1, num_iter=4, verbose=False, **HP)
             short.attack(*batch)
 
-        return run, prewarm, lambda: dict(hip_graph=att.last_graph_used, num_iter=NUM_ITER, binary_step=BINARY_STEP,
-                                          central_num=HP["central_num"]), NUM_ITER * BINARY_STEP
+        def hit_info():
+            stacked = any(isinstance(k[3], str) for k in att._ws)  # attack_many merged the victim passes of its attacks
+            return dict(hip_graph=att.last_graph_used, num_iter=NUM_ITER, binary_step=BINARY_STEP, central_num=HP["central_num"],
+                        attacks_per_stack=att.attacks_per_stack if stacked else 1)
+        return run, prewarm, hit_info, NUM_ITER * BINARY_STEP
 
     from hit_adv_amd import CW
     from hit_adv_amd.util.clip_utils import ClipPointsLinf

@@ -18,7 +18,7 @@ import os
 import sys
 import time
 
-# --in_flight 4 needs eight HIP hardware queues; the runtime reads this ONCE, when it starts (torch.cuda.is_available()
+# --in_flight 12 (three stacks on three streams) needs eight HIP hardware queues; the runtime reads this ONCE, when it starts (torch.cuda.is_available()
 # below already starts it), so it has to be in the environment before anything touches the GPU -- as bench.py does.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -76,8 +76,9 @@ def parse_args(argv=None):
                    help='attack this many batches of synthetic clouds instead of a dataset; a missing checkpoint then '
                         'means a seeded random-init victim')
     p.add_argument('--synthetic_kind', type=str, default='gaussian', choices=['gaussian', 'sphere'])
-    p.add_argument('--in_flight', type=int, default=4,
-                   help='attack() calls kept in flight per GPU (1 = one at a time; 4 on 8 hardware queues measured best, odd counts worst)')
+    p.add_argument('--in_flight', type=int, default=12,
+                   help='attack() calls kept in flight per GPU (1 = one at a time; 12 = three stacks of four merged victim '
+                        'passes on 8 hardware queues measured best on the PointNet engine)')
     p.add_argument('--metric_k', type=int, default=None,
                    help="neighbour count of the Uniform metric when it should differ from --k (the reference uses --k for "
                         "both, other_utils.py:74; the metric's smallest ball holds 1.6 %% of the points, so k+1 <= 16 at 1024)")
@@ -197,7 +198,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     import hit_adv_amd
-    in_flight = hit_adv_amd.attacks_in_flight(args.in_flight)  # 2 at most on the runtime's default four hardware queues
+    in_flight = hit_adv_amd.attacks_in_flight(args.in_flight)  # 8 at most on the runtime's default four hardware queues
     eval_ASR(model, loader, args, attacker, logger=logger, in_flight=in_flight)
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0

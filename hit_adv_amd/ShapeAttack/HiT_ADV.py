@@ -43,23 +43,28 @@ def _take(points, idx):
 class _Workspace:
     """Static device buffers + the captured iteration graph for one (B, N) problem shape."""
 
-    def __init__(self, B, N, C, dev):
+    def __init__(self, B, N, C, dev, shared=None):
         f = dict(device=dev, dtype=torch.float32)
         i64 = dict(device=dev, dtype=torch.int64)
         self.B, self.N, self.C = B, N, C
-        self.ori = torch.empty(B, 3, N, **f)
-        self.central = torch.empty(B, 3, C, **f)
+        if shared is None:
+            self.ori = torch.empty(B, 3, N, **f)
+            self.central = torch.empty(B, 3, C, **f)
+            self.P = torch.zeros(B, C, 3, **f).requires_grad_()
+            self.sigma = torch.ones(B, C, **f).requires_grad_()
+        else:  # slot g of a _Stack: what the victim's kernels read and write are rows of the stack's [G*B, ...] tensors
+            stack, g = shared
+            rows = slice(g * B, (g + 1) * B)
+            self.ori, self.central, self.P, self.sigma = stack.ori[rows], stack.central[rows], stack.P[rows], stack.sigma[rows]
         self.hide_ref = torch.empty(B, C, **f)  # min-max normalised central kappa-std (constant)
         self.target = torch.empty(B, **i64)
-        self.P = torch.zeros(B, C, 3, **f).requires_grad_()
-        self.sigma = torch.ones(B, C, **f).requires_grad_()
         self.m_p, self.v_p = torch.zeros(B, C, 3, **f), torch.zeros(B, C, 3, **f)
         self.m_s, self.v_s = torch.zeros(B, C, **f), torch.zeros(B, C, **f)
         self.step = torch.zeros(1, device=dev, dtype=torch.int32)
         self.scale_const = torch.empty(B, **f)
         self.lower = torch.empty(B, **f)
         self.upper = torch.empty(B, **f)
-        self.adv = torch.zeros(B, 3, N, **f)  # last iterate
+        self.adv = torch.zeros(B, 3, N, **f) if shared is None else shared[0].adv[rows]  # last iterate
         self.state = dict(bestdist=torch.empty(B, **f), bestscore=torch.empty(B, **i64),
                           o_bestdist=torch.empty(B, **f), o_bestscore=torch.empty(B, **i64),
                           o_bestattack=torch.zeros(B, 3, N, **f), pred=torch.zeros(B, **i64),
@@ -71,7 +76,7 @@ class _Workspace:
         self.chunk = 1
         self.feed = None  # pre-drawn FPS starts of a sampling victim (set per attack by _setup)
         # buffers of the autograd-free iteration (_iteration_fused)
-        self.inv_den = torch.empty(B, N, **f)
+        self.inv_den = torch.empty(B, N, **f) if shared is None else shared[0].inv_den[rows]
         self.gp, self.gs = torch.empty(B, C, 3, **f), torch.empty(B, C, **f)
         self.gp_reg, self.gs_reg = torch.empty(B, C, 3, **f), torch.empty(B, C, **f)
         self.g_adv = torch.empty(B, 3, N, **f)
@@ -87,6 +92,33 @@ class _Workspace:
         self.state["bestscore"].fill_(-1)
 
 
+class _Stack:
+    """G independent attacks whose victim passes run as ONE pass over G*B clouds (HiT_ADV.attack_many on the PointNet engine).
+
+    The victim treats clouds independently, and most of its kernels at B = 32 are bound by latency, not by throughput (the
+    shared-layer chains put two 4-wave blocks on a CU, the FC stacks compute 32 rows): G = 4 attacks stacked cost little more
+    there than one, where four streams of B = 32 kernels each pay the full latency chain and serialise on the chip-filling
+    ones.  Everything the reference couples inside a batch -- the normalisations of the setup phase, the batch-mean losses, the
+    mean(scale_const) weighting, best tracking, bisection -- stays per attack: those kernels run once per group on its rows.
+    A group's results are the bits of an ``attack()`` call of its own (tests/test_gpu_attack.py)."""
+
+    def __init__(self, G, B, N, C, dev):
+        f = dict(device=dev, dtype=torch.float32)
+        self.G, self.B, self.N, self.C = G, B, N, C
+        self.ori = torch.empty(G * B, 3, N, **f)
+        self.central = torch.empty(G * B, 3, C, **f)
+        self.P = torch.zeros(G * B, C, 3, **f)
+        self.sigma = torch.ones(G * B, C, **f)
+        self.adv = torch.zeros(G * B, 3, N, **f)
+        self.inv_den = torch.empty(G * B, N, **f)
+        self.groups = [_Workspace(B, N, C, dev, shared=(self, g)) for g in range(G)]
+        self.stream = torch.cuda.Stream()
+        self.graph = self.graph_many = None
+        self.chunk = 1
+
+
+# attacks per stack in attack_many (0 / 1: no stacking, one stream per attack as before); tuning knob
+_STACK = int(os.environ.get("HITADV_STACK", "4"))
 # workgroups of the PointNet engine's 128 -> 1024 kernel while three or more attacks share the GPU (tuning knob; see attack_many)
 _V1_BLOCKS_IN_FLIGHT = int(os.environ.get("HITADV_V1_BLOCKS_IN_FLIGHT", "128"))
 
@@ -125,6 +157,7 @@ class HiT_ADV:
         self.fused_regulariser = fused_regulariser
         self.iterations_per_graph = iterations_per_graph  # 'auto': what the victim's view asks for (PointNet engine: 10)
         self._view = None
+        self.attacks_per_stack = _STACK  # attack_many: victim passes of this many attacks merged into one (PointNet engine)
         self._chamfer = ChamferDist()
         self._ws = {}
         self.last_graph_used = False
@@ -410,7 +443,7 @@ class HiT_ADV:
         warnings.warn("the HiT-ADV iteration is not hipGraph-capturable (%r); running the eager loop" % (reason,))
 
     # ------------------------------------------------------------------ attack phases
-    def _setup(self, data, target, slot=0):
+    def _setup(self, data, target, slot=0, into=None):
         """Everything before the binary search (:51-123): scoring, centre selection, state initialisation, and
         ALL random draws of this attack, taken from the global CPU generator in the reference's order (randint for
         the FPS start :501, then per binary step rand(B,C,3) :130 and rand(B,C) :133) and uploaded once."""
@@ -423,11 +456,17 @@ class HiT_ADV:
         grad, _ = self.get_gradient(ori, target)
         central, central_kappa, _ = self._select_centres(ori, normal, grad)
 
-        key = (B, K, C, slot)
-        ws = self._ws.get(key)
-        if ws is None:
-            ws = self._ws[key] = _Workspace(B, K, C, dev)
-            ws.stream = torch.cuda.Stream()
+        if into is not None:
+            ws = into
+            if (ws.B, ws.N, ws.C) != (B, K, C):
+                raise RuntimeError("stacked attacks need batches of one shape: got (%d, %d), the stack holds (%d, %d)"
+                                   % (B, K, ws.B, ws.N))
+        else:
+            key = (B, K, C, slot)
+            ws = self._ws.get(key)
+            if ws is None:
+                ws = self._ws[key] = _Workspace(B, K, C, dev)
+                ws.stream = torch.cuda.Stream()
         ws.ori.copy_(ori)
         ws.central.copy_(central)
         ws.target.copy_(target)
@@ -466,16 +505,8 @@ class HiT_ADV:
         """One binary-search step (:125-273) enqueued on the current stream: fresh parameters, num_iter replays
         (or eager iterations), per-sample bisection of the distance weight -- no host synchronisation unless
         ``verbose`` asks for the reference's progress lines."""
-        B, C, st = ws.B, ws.C, ws.state
-        if ws.feed is not None:
-            ws.feed.seek(binary_step * self.num_iter)  # this step's rows (the warm-up passes moved the cursor)
-        with torch.no_grad():
-            ws.P.copy_(ws.rand_P[binary_step])
-            ws.sigma.copy_(torch.ones((B, C), device=ws.P.device) * self.min_sigm
-                           + ws.rand_S[binary_step] * (self.max_sigm - self.min_sigm))
-        ws.reset_step()
-        ws.adv_loss.zero_()
-        ws.dist_loss.zero_()
+        B, st = ws.B, ws.state
+        self._begin_step(ws, binary_step)
         report_every = max(1, self.num_iter // 5)
         iteration = 0
         while iteration < self.num_iter:
@@ -497,12 +528,149 @@ class HiT_ADV:
                       'adv_loss: {:.4f}, dist_loss: {:.4f}'.format(binary_step, iteration, success_num, B,
                                                                    prev[0], prev[1]))
             iteration += ws.chunk if many else 1
-        with torch.no_grad():  # (:264-273), on device
+        self._end_step(ws)
+
+    def _begin_step(self, ws, binary_step):
+        """Fresh parameters of a binary-search step from the draws taken at setup (:128-141), Adam and per-step best state reset."""
+        B, C = ws.B, ws.C
+        if ws.feed is not None:
+            ws.feed.seek(binary_step * self.num_iter)  # this step's rows (the warm-up passes moved the cursor)
+        with torch.no_grad():
+            ws.P.copy_(ws.rand_P[binary_step])
+            ws.sigma.copy_(torch.ones((B, C), device=ws.P.device) * self.min_sigm
+                           + ws.rand_S[binary_step] * (self.max_sigm - self.min_sigm))
+        ws.reset_step()
+        ws.adv_loss.zero_()
+        ws.dist_loss.zero_()
+
+    def _end_step(self, ws):
+        """Per-sample bisection of the distance weight (:264-273), on the device."""
+        st = ws.state
+        with torch.no_grad():
             ok = ((st["bestscore"] != ws.target) & (st["bestscore"] != -1)
                   & (st["bestdist"] <= st["o_bestdist"]))
             ws.lower.copy_(torch.where(ok, torch.maximum(ws.lower, ws.scale_const), ws.lower))
             ws.upper.copy_(torch.where(ok, ws.upper, torch.minimum(ws.upper, ws.scale_const)))
             ws.scale_const.copy_((ws.lower + ws.upper) / 2.)
+
+    # ------------------------------------------------------------------ stacked attacks (attack_many on the PointNet engine)
+    def _can_stack(self):
+        """Stacking needs the iteration whose victim pass is ONE call that takes the deformation and hands back the classifier
+        head's input: the PointNet engine under the fused adversarial loss with at least one regulariser on."""
+        view = self._victim()
+        return (view is self._view and getattr(view, 'hip_engine', False) and hasattr(view, 'deform_inputs')
+                and getattr(view, 'fold_small_layers', False) and hasattr(view, 'defer_logits')
+                and self.fused_regulariser and hasattr(self.adv_func, 'fused_kind') and self.central_num <= 256
+                and any(w != 0 for w in (self.cd_weight, self.ker_weight, self.hide_weight))
+                and view.h3_w.shape[0] <= 256 and view.h3_w.shape[1] <= 64 and self.use_graph not in (False, 'never'))
+
+    def _iteration_stacked(self, stack):
+        """``_iteration_fused`` for G attacks at once: one victim forward pass over the G*B clouds (its first kernel deforms
+        them, its last layer is left to the loss kernels), per group the loss / best-tracking / regulariser kernel on its
+        rows, one victim backward pass, per group the deformation's backward and the Adam step."""
+        regs = (self.cd_weight, self.ker_weight, self.hide_weight)
+        rng = (self.min_sigm, self.max_sigm)
+        view, B = self._view, stack.B
+        kind, kappa = self.adv_func.fused_kind()
+        x = stack.adv.detach().requires_grad_()
+        view.deform_inputs = (stack.ori, stack.central, stack.P, stack.sigma, stack.inv_den)
+        view.defer_logits = True
+        try:
+            logits = self._logits(x)
+            f2, h3_w, h3_b = view.pending_head
+            if view.deform_inputs is not None:
+                raise RuntimeError("the victim was asked to deform the cloud in its first kernel and did not")
+        finally:
+            view.deform_inputs = None
+            view.defer_logits, view.pending_head = False, None
+        dlogits = torch.empty_like(logits)
+        flat = logits.detach()
+        for g, ws in enumerate(stack.groups):
+            rows = slice(g * B, (g + 1) * B)
+            ops.iteration_head_reg(flat[rows], ws.target, ws.P, ws.sigma, ws.adv, ws.state, ws.step, kind, kappa, ws.adv_loss,
+                                   dlogits[rows], ws.head_scratch, ws.ori, ws.hide_ref, ws.scale_const, regs, rng,
+                                   ws.reg_scratch, ws.dist_loss, ws.scaled, head=(f2[rows], h3_w, h3_b))
+        g_victim, = torch.autograd.grad(logits, x, grad_outputs=dlogits)
+        g_victim = g_victim.contiguous()
+        clamp_p = (-self.budget, self.budget)
+        for g, ws in enumerate(stack.groups):
+            rows = slice(g * B, (g + 1) * B)
+            ops.deform_bwd_partials_reg_into(ws.ori, ws.central, ws.P, ws.sigma, ws.adv, ws.inv_den, g_victim[rows],
+                                             ws.reg_scratch, regs, ws.deform_part)
+            ops.adam_step_partials_reg(ws.P, ws.sigma, ws.deform_part, ws.N, ws.hide_ref, ws.reg_scratch, regs, rng, ws.m_p,
+                                       ws.v_p, ws.m_s, ws.v_s, ws.step, self.attack_lr * 5, self.attack_lr * 3, clamp_p, rng)
+
+    def _prepare_stack_graphs(self, stacks):
+        """Two warm-up passes per stack (the second under sync-debug "error"), then one- and many-iteration graphs."""
+        prev_mode = torch.cuda.get_sync_debug_mode()
+        for st in stacks:
+            st.graph = st.graph_many = None
+            try:
+                st.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st.stream):
+                    self._iteration_stacked(st)
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        torch.cuda.set_sync_debug_mode("error")
+                    self._iteration_stacked(st)
+            finally:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    torch.cuda.set_sync_debug_mode(prev_mode)
+                torch.cuda.current_stream().wait_stream(st.stream)
+                torch.cuda.synchronize()
+        chunk = self._chunk()
+        for st in stacks:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st.stream):
+                self._iteration_stacked(st)
+            st.graph, st.graph_many, st.chunk = g, None, 1
+            if chunk > 1:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st.stream):
+                    for _ in range(chunk):
+                        self._iteration_stacked(st)
+                st.graph_many, st.chunk = g, chunk
+
+    def _attack_stacked(self, batches, per_stack):
+        """attack_many through stacks of ``per_stack`` attacks: every stack on its own stream, its victim passes merged."""
+        B, K = batches[0][0].shape[:2]
+        dev = torch.device('cuda', torch.cuda.current_device())
+        sizes = [min(per_stack, len(batches) - i) for i in range(0, len(batches), per_stack)]
+        stacks, i = [], 0
+        for n, G in enumerate(sizes):
+            key = (B, K, self.central_num, 'stack', n, G)
+            st = self._ws.get(key)
+            if st is None:
+                st = self._ws[key] = _Stack(G, B, K, self.central_num, dev)
+            for ws, (d, t) in zip(st.groups, batches[i:i + G]):  # setup in batch order: the reference's order of random draws
+                self._setup(d, t, into=ws)
+            stacks.append(st)
+            i += G
+        self._prepare_stack_graphs(stacks)
+        self.last_graph_used = True
+        for st in stacks:
+            for ws in st.groups:
+                self._reset_search(ws)
+            st.stream.wait_stream(torch.cuda.current_stream())
+        for binary_step in range(self.binary_step):
+            for st in stacks:
+                with torch.cuda.stream(st.stream):
+                    for ws in st.groups:
+                        self._begin_step(ws, binary_step)
+                    it = 0
+                    while it < self.num_iter:
+                        if st.graph_many is not None and self.num_iter - it >= st.chunk:
+                            st.graph_many.replay()
+                            it += st.chunk
+                        else:
+                            st.graph.replay()
+                            it += 1
+                    for ws in st.groups:
+                        self._end_step(ws)
+        for st in stacks:
+            torch.cuda.current_stream().wait_stream(st.stream)
+        return [self._finish(ws, False) for st in stacks for ws in st.groups]
 
     def _finish(self, ws, verbose):
         """Failure fill and return value (:277-287)."""
@@ -557,6 +725,16 @@ class HiT_ADV:
         # with three or more attacks in flight the victim's 128 -> 1024 layers run on half the chip each (twice as long):
         # the other half stays free for the other streams' short kernels (bench.py: 28.1 instead of 27.0 clouds/s at four)
         self._victim()  # the view is created on first use: it has to exist before its grid is chosen
+        per_stack = self.attacks_per_stack
+        if (per_stack > 1 and len(batches) > 1 and self._can_stack()
+                and len({tuple(d.shape[:2]) for d, _ in batches}) == 1):
+            view = self._view
+            before, view.linear_max_blocks = view.linear_max_blocks, (
+                _V1_BLOCKS_IN_FLIGHT if len(batches) > per_stack else view.linear_max_blocks)  # two stacks or more in flight
+            try:
+                return self._attack_stacked(batches, per_stack)
+            finally:
+                view.linear_max_blocks = before
         view = self._view if hasattr(self._view, 'linear_max_blocks') else None
         if view is not None:
             before, view.linear_max_blocks = view.linear_max_blocks, (_V1_BLOCKS_IN_FLIGHT if len(batches) >= 3 else view.linear_max_blocks)

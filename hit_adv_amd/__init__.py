@@ -13,8 +13,8 @@ import os as _os
 import sys as _sys
 import warnings as _warnings
 
-# attack_many() runs independent attacks on their own HIP streams; with the runtime's default of 4 hardware queues four of
-# them serialise again (bench.py: 23.9 vs 27.0 clouds/s).  The variable is read ONCE, when the HIP runtime starts: setting
+# attack_many() runs stacks of independent attacks on their own HIP streams; with the runtime's default of 4 hardware queues
+# three or more of them serialise again (bench.py: 30.3 vs 37.4 clouds/s at twelve attacks in three stacks).  The variable is read ONCE, when the HIP runtime starts: setting
 # it here only helps if nothing has touched the GPU yet (importing torch is fine; torch.cuda.is_available(), set_device(),
 # init_process_group('nccl') and a profiler's preloaded library are not).
 _HW_QUEUES_WANTED = 8
@@ -32,7 +32,7 @@ if _preset is None:
     if not _QUEUES_IN_TIME:
         _warnings.warn("hit_adv_amd: the HIP runtime was already initialised when the package was imported, so "
                        "GPU_MAX_HW_QUEUES=8 cannot take effect in this process (4 hardware queues): attacks in flight are "
-                       "capped at 2.  Export GPU_MAX_HW_QUEUES=8, or import hit_adv_amd, before the first torch.cuda call.",
+                       "capped at 8.  Export GPU_MAX_HW_QUEUES=8, or import hit_adv_amd, before the first torch.cuda call.",
                        RuntimeWarning, stacklevel=2)
 else:
     _QUEUES_IN_TIME = True  # the environment carried it into the process: whatever started the runtime saw it
@@ -50,20 +50,22 @@ def hardware_queues():
 
 
 def attacks_in_flight(requested):
-    """How many independent attacks to run at a time: ``requested``, capped at 2 when the process has only the runtime's
-    4 hardware queues (four attacks on four shared queues serialise again and measure no better than two)."""
+    """How many independent attacks to hand to ``attack_many`` at a time: ``requested``, capped at 8 (two stacks of four on
+    two streams) when the process has only the runtime's 4 hardware queues -- three streams on four shared queues serialise
+    again (12 in flight: 30.3 clouds/s on 4 queues, 37.4 on 8; 8 in flight on 4 queues: 35.5)."""
     requested = max(1, int(requested))
-    return requested if hardware_queues() >= 8 else min(requested, 2)
+    return requested if hardware_queues() >= 8 else min(requested, 8)
 
 
-def groups_in_flight(pending, in_flight):
-    """Split ``pending`` batches into the group sizes attacked together: ``in_flight`` at a time, and a remainder of three
-    as two and one (three in flight measured slower than two: DESIGN.md section 5).  bench.py and eval_ASR share this."""
+def groups_in_flight(pending, in_flight, stacked=True):
+    """Split ``pending`` batches into the group sizes attacked together: ``in_flight`` at a time.  Without stacking (one
+    stream per attack) a remainder of three goes as two and one: three streams measured slower than two.  bench.py and
+    eval_ASR share this."""
     in_flight = max(1, int(in_flight))
     sizes = []
     while pending > 0:
         n = min(in_flight, pending)
-        if n == 3 and in_flight != 3:
+        if n == 3 and in_flight != 3 and not stacked:
             n = 2
         sizes.append(n)
         pending -= n

@@ -110,11 +110,11 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
     clean-correct, and the batch means of KNN / Uniform / CurvStd distances of the adversarial clouds.
     Returns the (global) ASR as a float; every rank returns the same value.
 
-    ``in_flight`` > 1 hands that many of this rank's batches at a time to ``val_attack.attack_many`` (HiT_ADV: the
-    batches are attacked concurrently on separate HIP streams, with the results and RNG draws of back-to-back
-    ``attack`` calls; 4 gives 1.6x the throughput of 1 on one MI355X -- with the eight hardware queues the package asks the HIP
-    runtime for (``hit_adv_amd.attacks_in_flight`` caps the count at 2 when they cannot be had); even counts only: 3 and
-    5 measured worse than 2, a tail of three goes as two and one -- and no per-iteration progress lines)."""
+    ``in_flight`` > 1 hands that many of this rank's batches at a time to ``val_attack.attack_many`` (HiT_ADV: results and
+    RNG draws of back-to-back ``attack`` calls; on the PointNet engine the victim passes of four attacks at a time are merged
+    into one pass over 128 clouds and the stacks run on separate HIP streams -- 12 in flight give 2.1x the throughput of 1
+    on one MI355X with the eight hardware queues the package asks the HIP runtime for, ``hit_adv_amd.attacks_in_flight``
+    caps the count at 8 when they cannot be had -- and no per-iteration progress lines)."""
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     metrics = metrics or _default_metrics()
     distributed = dist.is_available() and dist.is_initialized()
@@ -175,7 +175,7 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
         if len(pending) == group:
             flush(pending)
             pending = []
-    for n in groups_in_flight(len(pending), group):  # the tail: three go as two and one, as bench.py's runner does
+    for n in groups_in_flight(len(pending), group, stacked=getattr(val_attack, 'attacks_per_stack', 1) > 1):  # the tail, as bench.py's runner
         flush(pending[:n])
         pending = pending[n:]
 

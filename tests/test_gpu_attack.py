@@ -809,9 +809,12 @@ def test_cwaof_follows_reference_trajectory():
     assert succ == int(fx['success_num']) and final.dtype == np.float32
 
 
-def test_attack_many_equals_sequential_attacks():
-    """Concurrent multi-stream attacks return exactly what back-to-back attack() calls return (PointNet view: every
-    kernel in the loop is deterministic), including the RNG draw order."""
+@pytest.mark.parametrize("per_stack", [4, 2, 1])
+def test_attack_many_equals_sequential_attacks(per_stack):
+    """Concurrent attacks return exactly what back-to-back attack() calls return (PointNet view: every kernel in the loop is
+    deterministic), including the RNG draw order -- whether their victim passes are merged into one pass over all the clouds
+    (``attacks_per_stack`` = 4: one stack of three; 2: a stack of two and one of one, on two streams) or every attack runs its
+    own B-cloud kernels on its own stream (1)."""
     from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
     from hit_adv_amd.model.pointnet import PointNetFeatureModel
     from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
@@ -829,9 +832,11 @@ def test_attack_many_equals_sequential_attacks():
     torch.manual_seed(77)
     seq = [att.attack(d, l) for d, l in batches]
     att2 = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), **hp)
+    att2.attacks_per_stack = per_stack
     torch.manual_seed(77)
     par = att2.attack_many(batches)
     assert att2.last_graph_used
+    assert any(isinstance(k[3], str) for k in att2._ws) == (per_stack > 1)  # the stacked path really ran (or really did not)
     for (a, na), (b, nb) in zip(seq, par):
         assert np.array_equal(a, b) and int(na) == int(nb)
     # and the same attacker can go on with single attacks afterwards
