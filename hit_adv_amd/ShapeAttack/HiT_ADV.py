@@ -40,50 +40,54 @@ def _take(points, idx):
     return points.gather(1, idx.unsqueeze(-1).expand(-1, -1, points.shape[2]))
 
 
+def _buffers(G, B, N, C, dev):
+    """Every device buffer of one attack, with a leading group dimension G (1 for a plain workspace): name -> tensor."""
+    f = dict(device=dev, dtype=torch.float32)
+    i64 = dict(device=dev, dtype=torch.int64)
+    return dict(
+        ori=torch.empty(G, B, 3, N, **f), central=torch.empty(G, B, 3, C, **f),
+        hide_ref=torch.empty(G, B, C, **f),  # min-max normalised central kappa-std (constant)
+        target=torch.empty(G, B, **i64),
+        P=torch.zeros(G, B, C, 3, **f), sigma=torch.ones(G, B, C, **f),
+        m_p=torch.zeros(G, B, C, 3, **f), v_p=torch.zeros(G, B, C, 3, **f),
+        m_s=torch.zeros(G, B, C, **f), v_s=torch.zeros(G, B, C, **f),
+        step=torch.zeros(G, 1, device=dev, dtype=torch.int32),
+        scale_const=torch.empty(G, B, **f), lower=torch.empty(G, B, **f), upper=torch.empty(G, B, **f),
+        adv=torch.zeros(G, B, 3, N, **f),  # last iterate
+        bestdist=torch.empty(G, B, **f), bestscore=torch.empty(G, B, **i64),
+        o_bestdist=torch.empty(G, B, **f), o_bestscore=torch.empty(G, B, **i64),
+        o_bestattack=torch.zeros(G, B, 3, N, **f), pred=torch.zeros(G, B, **i64), dist_val=torch.zeros(G, B, **f),
+        adv_loss=torch.zeros(G, **f), dist_loss=torch.zeros(G, **f), scaled=torch.zeros(G, **f),
+        # buffers of the autograd-free iteration (_iteration_fused)
+        inv_den=torch.empty(G, B, N, **f),
+        gp=torch.empty(G, B, C, 3, **f), gs=torch.empty(G, B, C, **f),
+        gp_reg=torch.empty(G, B, C, 3, **f), gs_reg=torch.empty(G, B, C, **f), g_adv=torch.empty(G, B, 3, N, **f),
+        deform_part=torch.empty(G, ops.deform_bwd_scratch(B, N, C), **f),
+        reg_scratch=torch.zeros(G, ops.regulariser_scratch(B), **f),       # zeroed: its last float is a ticket
+        head_scratch=torch.zeros(G, ops.iteration_head_scratch(B, dev).numel(), **f))  # zeroed: per-cloud terms + a ticket
+
+
+_STATE = ('bestdist', 'bestscore', 'o_bestdist', 'o_bestscore', 'o_bestattack', 'pred', 'dist_val')
+
+
 class _Workspace:
-    """Static device buffers + the captured iteration graph for one (B, N) problem shape."""
+    """Static device buffers + the captured iteration graph for one (B, N) problem shape.  ``shared`` = (stack, g): the
+    buffers are group g's rows of a _Stack's (attack_many on the PointNet engine)."""
 
     def __init__(self, B, N, C, dev, shared=None):
-        f = dict(device=dev, dtype=torch.float32)
-        i64 = dict(device=dev, dtype=torch.int64)
         self.B, self.N, self.C = B, N, C
-        if shared is None:
-            self.ori = torch.empty(B, 3, N, **f)
-            self.central = torch.empty(B, 3, C, **f)
-            self.P = torch.zeros(B, C, 3, **f).requires_grad_()
-            self.sigma = torch.ones(B, C, **f).requires_grad_()
-        else:  # slot g of a _Stack: what the victim's kernels read and write are rows of the stack's [G*B, ...] tensors
-            stack, g = shared
-            rows = slice(g * B, (g + 1) * B)
-            self.ori, self.central, self.P, self.sigma = stack.ori[rows], stack.central[rows], stack.P[rows], stack.sigma[rows]
-        self.hide_ref = torch.empty(B, C, **f)  # min-max normalised central kappa-std (constant)
-        self.target = torch.empty(B, **i64)
-        self.m_p, self.v_p = torch.zeros(B, C, 3, **f), torch.zeros(B, C, 3, **f)
-        self.m_s, self.v_s = torch.zeros(B, C, **f), torch.zeros(B, C, **f)
-        self.step = torch.zeros(1, device=dev, dtype=torch.int32)
-        self.scale_const = torch.empty(B, **f)
-        self.lower = torch.empty(B, **f)
-        self.upper = torch.empty(B, **f)
-        self.adv = torch.zeros(B, 3, N, **f) if shared is None else shared[0].adv[rows]  # last iterate
-        self.state = dict(bestdist=torch.empty(B, **f), bestscore=torch.empty(B, **i64),
-                          o_bestdist=torch.empty(B, **f), o_bestscore=torch.empty(B, **i64),
-                          o_bestattack=torch.zeros(B, 3, N, **f), pred=torch.zeros(B, **i64),
-                          dist_val=torch.zeros(B, **f))
-        self.adv_loss = torch.zeros((), **f)
-        self.dist_loss = torch.zeros((), **f)
+        bufs, g = (_buffers(1, B, N, C, dev), 0) if shared is None else (shared[0].bufs, shared[1])
+        for name, t in bufs.items():
+            if name not in _STATE:
+                setattr(self, name, t[g])
+        self.state = {name: bufs[name][g] for name in _STATE}
+        if shared is None:  # the op-by-op iteration differentiates through these two
+            self.P.requires_grad_()
+            self.sigma.requires_grad_()
         self.graph = None       # one inner iteration
         self.graph_many = None  # `chunk` inner iterations (see HiT_ADV._chunk)
         self.chunk = 1
         self.feed = None  # pre-drawn FPS starts of a sampling victim (set per attack by _setup)
-        # buffers of the autograd-free iteration (_iteration_fused)
-        self.inv_den = torch.empty(B, N, **f) if shared is None else shared[0].inv_den[rows]
-        self.gp, self.gs = torch.empty(B, C, 3, **f), torch.empty(B, C, **f)
-        self.gp_reg, self.gs_reg = torch.empty(B, C, 3, **f), torch.empty(B, C, **f)
-        self.g_adv = torch.empty(B, 3, N, **f)
-        self.deform_part = torch.empty(ops.deform_bwd_scratch(B, N, C), **f)
-        self.reg_scratch = torch.zeros(ops.regulariser_scratch(B), **f)  # zeroed: its last float is a ticket
-        self.head_scratch = ops.iteration_head_scratch(B, dev)
-        self.scaled = torch.zeros((), **f)
 
     def reset_step(self):
         for t in (self.m_p, self.v_p, self.m_s, self.v_s, self.step):
@@ -95,26 +99,27 @@ class _Workspace:
 class _Stack:
     """G independent attacks whose victim passes run as ONE pass over G*B clouds (HiT_ADV.attack_many on the PointNet engine).
 
-    The victim treats clouds independently, and most of its kernels at B = 32 are bound by latency, not by throughput (the
-    shared-layer chains put two 4-wave blocks on a CU, the FC stacks compute 32 rows): G = 4 attacks stacked cost little more
-    there than one, where four streams of B = 32 kernels each pay the full latency chain and serialise on the chip-filling
-    ones.  Everything the reference couples inside a batch -- the normalisations of the setup phase, the batch-mean losses, the
-    mean(scale_const) weighting, best tracking, bisection -- stays per attack: those kernels run once per group on its rows.
-    A group's results are the bits of an ``attack()`` call of its own (tests/test_gpu_attack.py)."""
+    The victim treats clouds independently, and at B = 32 its kernels pay latency rather than throughput (the shared-layer
+    chains put two 4-wave blocks on a CU, the FC stacks compute 32 rows): the pass over four stacked attacks costs 2.4x the
+    pass over one (tools/victim_batch_probe.py: 301 us at B = 32, 716 us at B = 128), where four streams of B = 32 kernels
+    each pay the full latency chain and serialise on the chip-filling ones.  Everything the reference couples inside a batch
+    -- the normalisations of the setup phase, the batch-mean losses, the mean(scale_const) weighting, best tracking, bisection
+    -- stays per attack: the three launches around the victim take a group dimension and run the per-group code on each
+    group's rows (include/hitadv.h, ``*_stack``).  A group's results are the bits of an ``attack()`` call of its own
+    (tests/test_gpu_attack.py::test_attack_many_equals_sequential_attacks)."""
 
     def __init__(self, G, B, N, C, dev):
-        f = dict(device=dev, dtype=torch.float32)
         self.G, self.B, self.N, self.C = G, B, N, C
-        self.ori = torch.empty(G * B, 3, N, **f)
-        self.central = torch.empty(G * B, 3, C, **f)
-        self.P = torch.zeros(G * B, C, 3, **f)
-        self.sigma = torch.ones(G * B, C, **f)
-        self.adv = torch.zeros(G * B, 3, N, **f)
-        self.inv_den = torch.empty(G * B, N, **f)
+        self.bufs = _buffers(G, B, N, C, dev)
         self.groups = [_Workspace(B, N, C, dev, shared=(self, g)) for g in range(G)]
         self.stream = torch.cuda.Stream()
         self.graph = self.graph_many = None
         self.chunk = 1
+
+    def all(self, name):
+        """Buffer ``name`` of all groups as the kernels see it: the group dimension merged into the leading one."""
+        t = self.bufs[name]
+        return t.reshape(t.shape[0] * t.shape[1], *t.shape[2:]) if t.dim() > 1 else t
 
 
 # attacks per stack in attack_many (0 / 1: no stacking, one stream per attack as before); tuning knob
@@ -566,39 +571,35 @@ class HiT_ADV:
 
     def _iteration_stacked(self, stack):
         """``_iteration_fused`` for G attacks at once: one victim forward pass over the G*B clouds (its first kernel deforms
-        them, its last layer is left to the loss kernels), per group the loss / best-tracking / regulariser kernel on its
-        rows, one victim backward pass, per group the deformation's backward and the Adam step."""
+        them, its last layer is left to the loss kernel), the loss / best-tracking / regulariser launch for all groups, one
+        victim backward pass, the deformation's backward and the Adam step for all groups -- 32 launches for G attacks."""
         regs = (self.cd_weight, self.ker_weight, self.hide_weight)
         rng = (self.min_sigm, self.max_sigm)
-        view, B = self._view, stack.B
+        view, G, A = self._view, stack.G, stack.all
         kind, kappa = self.adv_func.fused_kind()
-        x = stack.adv.detach().requires_grad_()
-        view.deform_inputs = (stack.ori, stack.central, stack.P, stack.sigma, stack.inv_den)
+        x = A('adv').detach().requires_grad_()
+        view.deform_inputs = (A('ori'), A('central'), A('P'), A('sigma'), A('inv_den'))
         view.defer_logits = True
         try:
             logits = self._logits(x)
-            f2, h3_w, h3_b = view.pending_head
+            head = view.pending_head
             if view.deform_inputs is not None:
                 raise RuntimeError("the victim was asked to deform the cloud in its first kernel and did not")
         finally:
             view.deform_inputs = None
             view.defer_logits, view.pending_head = False, None
         dlogits = torch.empty_like(logits)
-        flat = logits.detach()
-        for g, ws in enumerate(stack.groups):
-            rows = slice(g * B, (g + 1) * B)
-            ops.iteration_head_reg(flat[rows], ws.target, ws.P, ws.sigma, ws.adv, ws.state, ws.step, kind, kappa, ws.adv_loss,
-                                   dlogits[rows], ws.head_scratch, ws.ori, ws.hide_ref, ws.scale_const, regs, rng,
-                                   ws.reg_scratch, ws.dist_loss, ws.scaled, head=(f2[rows], h3_w, h3_b))
+        state = {name: A(name) for name in _STATE}
+        ops.iteration_head_reg(logits.detach(), A('target'), A('P'), A('sigma'), A('adv'), state, A('step'), kind, kappa,
+                               A('adv_loss'), dlogits, A('head_scratch'), A('ori'), A('hide_ref'), A('scale_const'), regs, rng,
+                               A('reg_scratch'), A('dist_loss'), A('scaled'), head=head, groups=G)
         g_victim, = torch.autograd.grad(logits, x, grad_outputs=dlogits)
-        g_victim = g_victim.contiguous()
         clamp_p = (-self.budget, self.budget)
-        for g, ws in enumerate(stack.groups):
-            rows = slice(g * B, (g + 1) * B)
-            ops.deform_bwd_partials_reg_into(ws.ori, ws.central, ws.P, ws.sigma, ws.adv, ws.inv_den, g_victim[rows],
-                                             ws.reg_scratch, regs, ws.deform_part)
-            ops.adam_step_partials_reg(ws.P, ws.sigma, ws.deform_part, ws.N, ws.hide_ref, ws.reg_scratch, regs, rng, ws.m_p,
-                                       ws.v_p, ws.m_s, ws.v_s, ws.step, self.attack_lr * 5, self.attack_lr * 3, clamp_p, rng)
+        ops.deform_bwd_partials_reg_into(A('ori'), A('central'), A('P'), A('sigma'), A('adv'), A('inv_den'),
+                                         g_victim.contiguous(), A('reg_scratch'), regs, A('deform_part'), groups=G)
+        ops.adam_step_partials_reg(A('P'), A('sigma'), A('deform_part'), stack.N, A('hide_ref'), A('reg_scratch'), regs, rng,
+                                   A('m_p'), A('v_p'), A('m_s'), A('v_s'), A('step'), self.attack_lr * 5, self.attack_lr * 3,
+                                   clamp_p, rng, groups=G)
 
     def _prepare_stack_graphs(self, stacks):
         """Two warm-up passes per stack (the second under sync-debug "error"), then one- and many-iteration graphs."""

@@ -48,6 +48,11 @@ PROTOTYPES = {
     "hitadv_iteration_head": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P],
     "hitadv_iteration_head_reg": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P,
                                   _P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
+    "hitadv_iteration_head_reg_stack": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P,
+                                        _P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
+    "hitadv_deform_bwd_partials_reg_stack": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P],
+    "hitadv_adam_step_partials_reg_stack": [_I, _P, _P, _P, _I, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F,
+                                            _F, _F, _P, _P],
     "hitadv_iteration_head_scratch_floats": [_I],
     "hitadv_regulariser_fwd_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P],
     "hitadv_deform_bwd_partials": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],

@@ -52,6 +52,13 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
   __shared__ float4 sg[DB_PTS];    // gDx gDy gDz -
   __shared__ int s_last;
   const int b = blockIdx.z, slab = blockIdx.y;
+  // stacked groups (csrc/iteration.hip::shift_group): the per-cloud arrays are dense over all groups' clouds, so b indexes
+  // them as it is; only the regularisers' per-group scratch (rg.B clouds per group) moves with the group
+  if (rg.per_cloud != nullptr && b >= rg.B) {
+    const size_t rs = (size_t)(b / rg.B) * ((size_t)rg.B * (RG_NPART + 8) + RG_NSCAL) - (size_t)(b / rg.B) * rg.B * 8;
+    rg.per_cloud += rs;  // per_cloud is indexed by the GLOBAL b below: take the group's base back by its clouds' rows
+    rg.scal += (size_t)(b / rg.B) * ((size_t)rg.B * (RG_NPART + 8) + RG_NSCAL);
+  }
   const int n0 = slab * DB_PTS;
   const int cnt = min(DB_PTS, N - n0);
   // the thread's centre is requested together with the slab's points, not after the barrier behind them (one global round
@@ -195,6 +202,22 @@ extern "C" int hitadv_deform_bwd_partials_reg(const float *ori, const float *cen
   const RegGrad rg{per_cloud, scal, nullptr, cd_w, 0.f, 0.f, 0.f, 0.f, B};
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
   dim3 grid((C + 255) / 256, nslab, B);
+  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials, rg, AdamTail{});
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_deform_bwd_partials_reg_stack(int G, const float *ori, const float *central, const float *perturb,
+                                                    const float *sigma, const float *adv, const float *inv_den,
+                                                    const float *g_victim, const float *reg_scratch, float cd_w, int B, int N,
+                                                    int C, float *partials, void *stream) {
+  if (G <= 0 || !ori || !central || !perturb || !sigma || !adv || !inv_den || !g_victim || !reg_scratch || !partials ||
+      B <= 0 || N <= 0 || C <= 0 || (long long)G * B > 65535)
+    return HITADV_E_ARG;
+  const float *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
+  const RegGrad rg{per_cloud, scal, nullptr, cd_w, 0.f, 0.f, 0.f, 0.f, B};
+  const int nslab = (N + DB_PTS - 1) / DB_PTS;
+  dim3 grid((C + 255) / 256, nslab, G * B);
   deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials, rg, AdamTail{});
   HITADV_LAUNCH_CHECK();
   return 0;

@@ -220,7 +220,47 @@ struct RegArgs {
   float *part;
   RegFin fin;
 };
+// G attacks stacked: every per-cloud argument is the group-0 pointer of a buffer that holds the G groups one after the other
+// (B clouds each), every per-group scalar / scratch likewise with its own stride.  blockIdx.y = the group: the arguments are
+// moved to that group's rows and the unchanged per-group bodies run on them -- the bits of G separate launches.
+constexpr int RG_NSCAL_I = RG_NSCAL;
+__device__ __forceinline__ void shift_group(HeadArgs &a, RegArgs &g, const int grp) {
+  if (grp == 0) return;
+  const size_t cl = (size_t)grp * a.B;  // clouds in front of this group
+  a.logits += cl * a.num_class;
+  a.label += cl;
+  a.perturb += cl * a.C * 3;
+  a.sigma += cl * a.C;
+  a.adv += cl * 3 * a.N;
+  a.bestdist += cl;
+  a.bestscore += cl;
+  a.o_bestdist += cl;
+  a.o_bestscore += cl;
+  a.o_bestattack += cl * 3 * a.N;
+  a.pred_out += cl;
+  a.dist_val_out += cl;
+  if (a.iter_counter != nullptr) a.iter_counter += grp;
+  a.loss += grp;
+  a.dlogits += cl * a.num_class;
+  a.per += (size_t)grp * (a.B + 4);  // hitadv_iteration_head_scratch_floats
+  a.ticket = reinterpret_cast<int *>(a.per + a.B);
+  if (a.feat != nullptr) {
+    a.feat += cl * a.feat_dim;
+    a.logits_out += cl * a.num_class;
+  }
+  const size_t rs = (size_t)grp * ((size_t)a.B * (RG_NPART + 8) + RG_NSCAL_I);  // hitadv_regulariser_scratch_floats
+  g.ori += cl * 3 * a.N;
+  g.hide_ref += cl * a.C;
+  g.part += rs;
+  g.fin.scale_const += cl;
+  g.fin.per_cloud += rs;
+  g.fin.scal += rs;
+  g.fin.dist_out += grp;
+  g.fin.scaled_out += grp;
+}
+
 __global__ __launch_bounds__(256) void iteration_head_reg_k(HeadArgs a, RegArgs g) {
+  shift_group(a, g, blockIdx.y);
   if ((int)blockIdx.x < a.B)
     iteration_head_body(a, blockIdx.x);
   else
@@ -233,6 +273,20 @@ __global__ __launch_bounds__(256) void iteration_head_reg_k(HeadArgs a, RegArgs 
 __global__ __launch_bounds__(256) void adam_partials_k(AdamArgs a) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= a.B * a.C) return;
+  if (blockIdx.y != 0) {  // stacked groups (see shift_group): this group's rows of every buffer
+    const int grp = blockIdx.y;
+    const size_t cl = (size_t)grp * a.B, cc = cl * a.C;
+    a.P += cc * 3; a.S += cc;
+    a.partials += cl * a.nslab * 4 * a.C;
+    a.mP += cc * 3; a.vP += cc * 3; a.mS += cc; a.vS += cc;
+    a.step += grp;
+    if (a.rg.per_cloud != nullptr) {
+      const size_t rs = (size_t)grp * ((size_t)a.B * (RG_NPART + 8) + RG_NSCAL_I);
+      a.rg.per_cloud += rs;
+      a.rg.scal += rs;
+      a.rg.hide_ref += cc;
+    }
+  }
   adam_partials_body<false>(a, e / a.C, e % a.C);
 }
 
@@ -280,6 +334,49 @@ extern "C" int hitadv_iteration_head_reg(const float *logits, const int64_t *lab
   const RegArgs g{ori, hide_ref, min_sigm, 1.0f / (max_sigm - min_sigm + 1e-7f), part,
                   RegFin{scale_const, B, cd_w, ker_w, hide_w, per_cloud, scal, dist_loss, scaled_loss}};
   iteration_head_reg_k<<<2 * B, 256, 0, (hipStream_t)stream>>>(a, g);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_iteration_head_reg_stack(int G, const float *logits, const int64_t *label, const float *perturb,
+                                               const float *sigma, const float *adv, int B, int num_class, int N, int C,
+                                               float *bestdist, int64_t *bestscore, float *o_bestdist, int64_t *o_bestscore,
+                                               float *o_bestattack, int64_t *pred_out, float *dist_val_out,
+                                               int32_t *iter_counter, int kind, float kappa, float *loss, float *dlogits,
+                                               float *scratch, const float *ori, const float *hide_ref,
+                                               const float *scale_const, float cd_w, float ker_w, float hide_w,
+                                               float min_sigm, float max_sigm, float *reg_scratch, float *dist_loss,
+                                               float *scaled_loss, const float *feat, const float *Wlog, const float *blog,
+                                               int feat_dim, void *stream) {
+  if (G <= 0 || G > 65535) return HITADV_E_ARG;
+  if (feat != nullptr && (!Wlog || !blog || feat_dim <= 0 || feat_dim > 256 || num_class > 64)) return HITADV_E_ARG;
+  if (!logits || !label || !perturb || !sigma || !adv || !bestdist || !bestscore || !o_bestdist || !o_bestscore ||
+      !o_bestattack || !pred_out || !dist_val_out || !loss || !dlogits || !scratch || kind < 0 || kind > 2 || B <= 0 ||
+      num_class <= 0 || N <= 0 || C <= 0 || !ori || !hide_ref || !scale_const || !reg_scratch || !dist_loss || !scaled_loss)
+    return HITADV_E_ARG;
+  const HeadArgs a{logits, label, perturb, sigma, adv, B, num_class, N, C, bestdist, bestscore, o_bestdist, o_bestscore,
+                   o_bestattack, pred_out, dist_val_out, iter_counter, kind, kappa, loss, dlogits, scratch,
+                   reinterpret_cast<int *>(scratch + B), feat, Wlog, blog, feat_dim, const_cast<float *>(logits)};
+  float *part = reg_scratch, *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
+  const RegArgs g{ori, hide_ref, min_sigm, 1.0f / (max_sigm - min_sigm + 1e-7f), part,
+                  RegFin{scale_const, B, cd_w, ker_w, hide_w, per_cloud, scal, dist_loss, scaled_loss}};
+  iteration_head_reg_k<<<dim3(2 * B, G), 256, 0, (hipStream_t)stream>>>(a, g);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_adam_step_partials_reg_stack(int G, float *perturb, float *sigma, const float *partials, int nslab,
+                                                   const float *hide_ref, const float *reg_scratch, float cd_w, float ker_w,
+                                                   float hide_w, float min_sigm, float max_sigm, float *m_perturb,
+                                                   float *v_perturb, float *m_sigma, float *v_sigma, int B, int C,
+                                                   float lr_perturb, float lo_perturb, float hi_perturb, float lr_sigma,
+                                                   float lo_sigma, float hi_sigma, const int32_t *step, void *stream) {
+  if (G <= 0 || G > 65535 || !perturb || !sigma || !partials || !hide_ref || !reg_scratch || !m_perturb || !v_perturb ||
+      !m_sigma || !v_sigma || !step || nslab <= 0 || B <= 0 || C <= 0)
+    return HITADV_E_ARG;
+  const float *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
+  const RegGrad rg{per_cloud, scal, hide_ref, cd_w, ker_w, hide_w, min_sigm, 1.0f / (max_sigm - min_sigm + 1e-7f), B};
+  adam_partials_k<<<dim3((B * C + 255) / 256, G), 256, 0, (hipStream_t)stream>>>(AdamArgs{perturb, sigma, partials, nslab, nullptr, nullptr, m_perturb, v_perturb, m_sigma, v_sigma, B, C, lr_perturb, lo_perturb, hi_perturb, lr_sigma, lo_sigma, hi_sigma, step, rg});
   HITADV_LAUNCH_CHECK();
   return 0;
 }

@@ -352,13 +352,16 @@ def iteration_head(logits, label, perturb, sigma, adv, state, counter, kind, kap
 
 
 def iteration_head_reg(logits, label, perturb, sigma, adv, state, counter, kind, kappa, loss_out, dlogits, scratch, ori,
-                       hide_ref, scale_const, weights, sig_range, reg_scratch, dist_out, scaled_out, head=None):
+                       hide_ref, scale_const, weights, sig_range, reg_scratch, dist_out, scaled_out, head=None, groups=1):
     """``iteration_head`` and ``regulariser_fwd_fused_into`` in one launch (same results, bit for bit).  ``head`` =
-    (feat [B,F], Wt [F,K], bias [K]): ``logits`` is then an OUTPUT, the classifier's last layer is evaluated inside."""
-    B, K = logits.shape
+    (feat [B,F], Wt [F,K], bias [K]): ``logits`` is then an OUTPUT, the classifier's last layer is evaluated inside.
+    ``groups`` = G > 1: every argument holds G stacked attacks (include/hitadv.h, ``*_stack``): per-cloud tensors [G*B, ...],
+    per-group scalars [G], scratches [G, size]; each group gets the bits of a call of its own."""
+    B, K = logits.shape[0] // groups, logits.shape[1]
     cd, ker, hide = (ctypes.c_float(float(w)) for w in weights)
     lo, hi = (ctypes.c_float(float(v)) for v in sig_range)
-    _lib.call("hitadv_iteration_head_reg", _p(logits), _p(label), _p(perturb), _p(sigma), _p(adv), B, K, adv.shape[2],
+    _lib.call(*(("hitadv_iteration_head_reg_stack", groups) if groups > 1 else ("hitadv_iteration_head_reg",)),
+              _p(logits), _p(label), _p(perturb), _p(sigma), _p(adv), B, K, adv.shape[2],
               sigma.shape[1], _p(state["bestdist"]), _p(state["bestscore"]), _p(state["o_bestdist"]),
               _p(state["o_bestscore"]), _p(state["o_bestattack"]), _p(state["pred"]), _p(state["dist_val"]), _p(counter),
               kind, ctypes.c_float(float(kappa)), _p(loss_out), _p(dlogits), _p(scratch), _p(ori), _p(hide_ref),
@@ -383,11 +386,13 @@ def deform_bwd_partials_into(ori, central, perturb, sigma, adv, inv_den, g_adv, 
               B, N, central.shape[2], _p(partials), _stream())
 
 
-def deform_bwd_partials_reg_into(ori, central, perturb, sigma, adv, inv_den, g_victim, reg_scratch, weights, partials):
+def deform_bwd_partials_reg_into(ori, central, perturb, sigma, adv, inv_den, g_victim, reg_scratch, weights, partials, groups=1):
     """``deform_bwd_partials_into`` whose upstream gradient is ``g_victim`` plus the regularisers' term, evaluated inside
-    from the forward pass's ``reg_scratch`` (what ``regulariser_bwd_add`` would have written to ``ga``)."""
-    B, _, N = ori.shape
-    _lib.call("hitadv_deform_bwd_partials_reg", _p(ori), _p(central), _p(perturb), _p(sigma), _p(adv), _p(inv_den),
+    from the forward pass's ``reg_scratch`` (what ``regulariser_bwd_add`` would have written to ``ga``).  ``groups``: see
+    ``iteration_head_reg``."""
+    B, N = ori.shape[0] // groups, ori.shape[2]
+    _lib.call(*(("hitadv_deform_bwd_partials_reg_stack", groups) if groups > 1 else ("hitadv_deform_bwd_partials_reg",)),
+              _p(ori), _p(central), _p(perturb), _p(sigma), _p(adv), _p(inv_den),
               _p(g_victim), _p(reg_scratch), ctypes.c_float(float(weights[0])), B, N, central.shape[2], _p(partials),
               _stream())
 
@@ -407,13 +412,14 @@ def deform_bwd_adam_reg(ori, central, perturb, sigma, adv, inv_den, g_victim, hi
 
 
 def adam_step_partials_reg(perturb, sigma, partials, N, hide_ref, reg_scratch, weights, sig_range, m_p, v_p, m_s, v_s, step,
-                           lr_p, lr_s, clamp_p, clamp_s):
+                           lr_p, lr_s, clamp_p, clamp_s, groups=1):
     """``adam_step_partials`` that evaluates the regularisers' gradients at (perturb, sigma) itself (``regulariser_bwd_add``'s
-    ``gp`` / ``gs``) instead of reading them."""
-    B, C = sigma.shape
+    ``gp`` / ``gs``) instead of reading them.  ``groups``: see ``iteration_head_reg``."""
+    B, C = sigma.shape[0] // groups, sigma.shape[1]
     cd, ker, hide = (ctypes.c_float(float(w)) for w in weights)
     lo, hi = (ctypes.c_float(float(v)) for v in sig_range)
-    _lib.call("hitadv_adam_step_partials_reg", _p(perturb), _p(sigma), _p(partials),
+    _lib.call(*(("hitadv_adam_step_partials_reg_stack", groups) if groups > 1 else ("hitadv_adam_step_partials_reg",)),
+              _p(perturb), _p(sigma), _p(partials),
               int(_lib.load().hitadv_deform_bwd_slabs(N)), _p(hide_ref), _p(reg_scratch), cd, ker, hide, lo, hi, _p(m_p),
               _p(v_p), _p(m_s), _p(v_s), B, C, ctypes.c_float(lr_p), ctypes.c_float(clamp_p[0]), ctypes.c_float(clamp_p[1]),
               ctypes.c_float(lr_s), ctypes.c_float(clamp_s[0]), ctypes.c_float(clamp_s[1]), _p(step), _stream())

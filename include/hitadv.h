@@ -477,6 +477,32 @@ int hitadv_adam_step_partials_reg(float *perturb, float *sigma, const float *par
                                   int C, float lr_perturb, float lo_perturb, float hi_perturb, float lr_sigma,
                                   float lo_sigma, float hi_sigma, const int32_t *step, void *stream);
 
+/* G independent attacks STACKED (HiT_ADV.attack_many on the PointNet engine: one victim pass over the G*B clouds): the three
+ * launches around that pass for all G groups at once.  Every per-cloud argument is the group-0 pointer of a buffer that
+ * holds the G groups' rows one after the other (B clouds each); every per-group scalar or scratch likewise, with the stride
+ * of its size query: loss / dist_loss / scaled_loss / iter_counter / step 1 element, scratch
+ * hitadv_iteration_head_scratch_floats(B), reg_scratch hitadv_regulariser_scratch_floats(B), partials
+ * hitadv_deform_bwd_scratch_floats(B, N, C).  Wlog / blog are shared.  Group g's results are the bits of the un-stacked
+ * entry point called on its rows (the kernels move their arguments to the group's rows and run the same per-group code). */
+int hitadv_iteration_head_reg_stack(int G, const float *logits, const int64_t *label, const float *perturb,
+                                    const float *sigma, const float *adv, int B, int num_class, int N, int C, float *bestdist,
+                                    int64_t *bestscore, float *o_bestdist, int64_t *o_bestscore, float *o_bestattack,
+                                    int64_t *pred_out, float *dist_val_out, int32_t *iter_counter, int kind, float kappa,
+                                    float *loss, float *dlogits, float *scratch, const float *ori, const float *hide_ref,
+                                    const float *scale_const, float cd_w, float ker_w, float hide_w, float min_sigm,
+                                    float max_sigm, float *reg_scratch, float *dist_loss, float *scaled_loss,
+                                    const float *feat, const float *Wlog, const float *blog, int feat_dim, void *stream);
+int hitadv_deform_bwd_partials_reg_stack(int G, const float *ori, const float *central, const float *perturb,
+                                         const float *sigma, const float *adv, const float *inv_den, const float *g_victim,
+                                         const float *reg_scratch, float cd_w, int B, int N, int C, float *partials,
+                                         void *stream);
+int hitadv_adam_step_partials_reg_stack(int G, float *perturb, float *sigma, const float *partials, int nslab,
+                                        const float *hide_ref, const float *reg_scratch, float cd_w, float ker_w,
+                                        float hide_w, float min_sigm, float max_sigm, float *m_perturb, float *v_perturb,
+                                        float *m_sigma, float *v_sigma, int B, int C, float lr_perturb, float lo_perturb,
+                                        float hi_perturb, float lr_sigma, float lo_sigma, float hi_sigma,
+                                        const int32_t *step, void *stream);
+
 /* k nearest neighbours in feature space for DGCNN's dynamic graph (model/dgcnn_cls.py:7-13: topk of
  * -|x_i|^2 + 2 x_i.x_j - |x_j|^2), fused: the scores come off the f32 matrix cores tile by tile and go straight into
  * per-lane sorted lists -- no [B,N,N] matrix.  X [B,N,D] points-major (D in {64,128}, 16-byte aligned), xx [B,N] = |x|^2,
