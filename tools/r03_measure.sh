@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 OUT=gpurun_out/r03
 mkdir -p $OUT /tmp/prof
-WHAT=${*:-bench_cfg2 prof_c4 prof_c1}
+WHAT=${*:-bench_cfg2 prof_headline prof_c1}
 for w in $WHAT; do
   case $w in
     bench_cfg2)
@@ -16,9 +16,15 @@ for w in $WHAT; do
     bench_cfg3|bench_cfg4|bench_cfg5)
       c=${w#bench_}
       timeout 1200 python bench.py --config $c > $OUT/bench_$c.log 2>&1; tail -1 $OUT/bench_$c.log > $OUT/bench_line_$c.json ;;
-    prof_c4)  # the configuration the headline runs: four attacks in flight, eight hardware queues, V1 on 128 workgroups
+    prof_headline)  # the configuration the headline runs: twelve attacks in flight as three stacks of four, eight hardware queues
+      rm -rf /tmp/prof/hl
+      GPU_MAX_HW_QUEUES=8 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/hl -- \
+        python3 bench.py --steps 12 --warmup 0 --no-cpu-baseline --no-single --no-f32 > $OUT/prof_headline.log 2>&1
+      f=$(find /tmp/prof/hl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/cfg2_headline_kernel_stats.csv
+      tail -1 $OUT/prof_headline.log > $OUT/prof_line_headline.json ;;
+    prof_c4)  # four attacks in flight, one stream each (round 2's headline configuration; HITADV_STACK=1 switches the stacking off)
       rm -rf /tmp/prof/c4
-      GPU_MAX_HW_QUEUES=8 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/c4 -- \
+      GPU_MAX_HW_QUEUES=8 HITADV_STACK=1 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/c4 -- \
         python3 bench.py --steps 4 --warmup 0 --concurrent 4 --no-cpu-baseline --no-single --no-f32 > $OUT/prof_c4.log 2>&1
       f=$(find /tmp/prof/c4 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/cfg2_c4_kernel_stats.csv
       tail -1 $OUT/prof_c4.log > $OUT/prof_line_c4.json ;;
