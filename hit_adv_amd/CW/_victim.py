@@ -24,7 +24,14 @@ class Victim:
             self.feed.load(offset, forwards)
 
     def close_feed(self):
+        """End of an attack's loop: drop the feed; loud if a fused fp16x2 layer of the victim left fp16's range meanwhile."""
         self.feed = None
+        from ..model import _pointwise
+        p = next(self.model.parameters(), None)
+        if p is not None:
+            _pointwise.check_range(p.device)
+        if hasattr(self.view, 'check_range'):
+            self.view.check_range()
 
     def prepare(self):
         if not (self.fast and hasattr(self.model, 'attack_view')):

@@ -683,6 +683,8 @@ class HiT_ADV:
         lower_cpu = ws.lower.cpu()
         if hasattr(self._view, 'check_range'):
             self._view.check_range()  # fp16x2 victim layers: loud if an operand left fp16's range
+        from ..model import _pointwise
+        _pointwise.check_range(ws.adv.device)
         self.last_lower_bound = lower_cpu
         self.last_bestdist = st["o_bestdist"].cpu()
         success_num = (lower_cpu > 0.).sum()

@@ -82,6 +82,41 @@ def linear_relu_pm(conv, bn, x):
     return y.view(*x.shape[:-1], W.shape[0])
 
 
+_RANGE_FLAGS = {}
+
+
+def range_flag(device):
+    """One device-resident int32 per GPU that the fp16x2 kernels raise when an operand leaves fp16's range (65504)."""
+    key = str(device)
+    if key not in _RANGE_FLAGS:
+        _RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _RANGE_FLAGS[key]
+
+
+def check_range(device):
+    """Raise if any fp16x2 layer of a victim has seen an operand beyond fp16's range since the flag was last cleared."""
+    flag = _RANGE_FLAGS.get(str(device))
+    if flag is not None and int(flag.item()) != 0:
+        flag.zero_()
+        raise RuntimeError("a fused linear + max layer (fp16x2 matrix form) met an activation or weight beyond fp16's range "
+                           "(65504): the results are invalid; set hit_adv_amd.model._pointwise.FUSED_GROUP_MAX = False")
+
+
+FUSED_GROUP_MAX = True  # last shared layer of a sample-and-group block + max over the neighbours as one fp16x2 MFMA kernel
+
+
+def linear_relu_max_pm(conv, bn, x):
+    """relu(bn(conv(.))) applied to points-major x [..., ns, Cin] followed by the max over the ns neighbours -> [..., Cout]:
+    ``hitadv_group_linear_max`` where the shape is supported (no [.., ns, Cout] activation, no ReLU / max passes, a sparse
+    backward), the GEMM + max otherwise."""
+    from .. import ops
+    W, b = _folded(conv, bn)
+    if (FUSED_GROUP_MAX and x.is_cuda and b is not None and not WEIGHT_GRADS
+            and ops.group_linear_max_supported(W.shape[1], W.shape[0], x.shape[-2])):
+        return ops.group_linear_max(x.contiguous(), W.detach(), b.detach(), range_flag(x.device))
+    return linear_relu_pm(conv, bn, x).max(dim=-2)[0]
+
+
 def split_first_layer(conv, bn, n_rel):
     """The first shared layer of a sample-and-group block, W [rel ; rest] + t with rel = (neighbour - centre)[:n_rel],
     as the pair (W, t) of the folded layer: the caller forms U = [x_j ; rest_j] W^T per POINT and V = -c_i W[:, :n_rel]^T

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from . import _sampling
-from ._pointwise import conv1x1, fast_pm, linear_pm, linear_relu_pm, split_first_layer
+from ._pointwise import conv1x1, fast_pm, linear_pm, linear_relu_max_pm, linear_relu_pm, split_first_layer
 from .pointnet2 import index_points
 
 
@@ -66,8 +66,7 @@ class Local_op(nn.Module):
         W, t = split_first_layer(self.conv1, self.bn1, D)
         U = torch.matmul(points, W[:, :D].t())
         V = torch.addmm(t, index_points(points, fps_idx).reshape(-1, D), (W[:, D:] - W[:, :D]).t()).view(-1, npoint, W.shape[0])
-        h = linear_relu_pm(self.conv2, self.bn2, ops.group_add_relu(U, V, idx))
-        return new_xyz, h.max(dim=2)[0]
+        return new_xyz, linear_relu_max_pm(self.conv2, self.bn2, ops.group_add_relu(U, V, idx))
 
     def fast(self, points, nsample):
         return (fast_pm(self.conv1, self.bn1, points) and self.conv1.in_channels == 2 * points.shape[-1] and

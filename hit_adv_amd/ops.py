@@ -789,6 +789,52 @@ class LReluPool(torch.autograd.Function):
         return dZ, None
 
 
+def group_linear_max_supported(Cin, Cout, ns):
+    return bool(_lib.load().hitadv_group_linear_max_supported(int(Cin), int(Cout), int(ns)))
+
+
+class GroupLinearMax(torch.autograd.Function):
+    """out[g,c] = relu(max_j x[g,j,:] . W[c,:] + b[c]) for x [G, ns, Cin] (the last shared layer of a sample-and-group block
+    and the max over the neighbours, model/pointnet2_utils.py:197-201) without the [G*ns, Cout] activation: fp16x2 MFMA
+    forward with the max / arg-max in its epilogue, and a backward that scatters the G*Cout routed gradient values into a
+    zero A operand in LDS and multiplies by W on the matrix cores (csrc/group_mlp.hip).  ``Wr`` [Cout,Cin], ``bias`` [Cout]
+    are constants (the folded eval-mode layer); the gradient goes to ``x`` only."""
+
+    @staticmethod
+    def forward(ctx, x, Wr, bias, range_flag):
+        x = _dev(x, "x")
+        G, ns, Cin = x.shape
+        Cout = Wr.shape[0]
+        W2 = split_weights_f16x2(Wr.contiguous(), range_flag=range_flag)               # forward operand
+        Wb2 = split_weights_f16x2(Wr.t().contiguous(), range_flag=range_flag)           # backward operand: pieces of Wt [Cin,Cout]
+        out = torch.empty(G, Cout, device=x.device)
+        arg = torch.empty(G, Cout, device=x.device, dtype=torch.int32)
+        _lib.call("hitadv_group_linear_max_fwd", _p(x), _p(W2), _p(bias), G, ns, Cin, Cout, _p(out), _p(arg), _p(range_flag),
+                  _stream())
+        ctx.save_for_backward(out, arg, Wb2)
+        ctx.dims = (G, ns, Cin, Cout)
+        ctx.range_flag = range_flag
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, g, _ga):
+        out, arg, Wb2 = ctx.saved_tensors
+        G, ns, Cin, Cout = ctx.dims
+        dX = torch.empty(G, ns, Cin, device=out.device)
+        _lib.call("hitadv_group_linear_max_bwd", _p(g.contiguous()), _p(out), _p(arg), _p(Wb2), G, ns, Cin, Cout, _p(dX),
+                  _p(ctx.range_flag), _stream())
+        return dX, None, None, None
+
+
+def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False):
+    """x [..., ns, Cin] -> relu(max over the ns rows of (x W^T + bias)) [..., Cout]; see ``GroupLinearMax``."""
+    lead = x.shape[:-2]
+    out, arg = GroupLinearMax.apply(x.reshape(-1, x.shape[-2], x.shape[-1]), Wr, bias, range_flag)
+    out = out.view(*lead, out.shape[-1])
+    return (out, arg.view(*lead, arg.shape[-1])) if return_arg else out
+
+
 def lrelu_pool(Z, slope=0.2, return_arg=False):
     """``return_arg``: also the int32 [B,C] table of the points the maxima were taken at (the kernel's own tie rule)."""
     out, arg = LReluPool.apply(Z, slope)

@@ -477,6 +477,23 @@ int hitadv_adam_step_partials_reg(float *perturb, float *sigma, const float *par
                                   int C, float lr_perturb, float lo_perturb, float hi_perturb, float lr_sigma,
                                   float lo_sigma, float hi_sigma, const int32_t *step, void *stream);
 
+/* ------------------------------------------------------------------ last shared layer of a sample-and-group block + max
+ * PointNet++'s set abstraction (model/pointnet2_utils.py:197-201: conv -> bn -> relu -> torch.max(new_points, 2)) and PCT's
+ * Local_op (model/pct_cls.py:14-24) end in a shared layer over [G = B*npoint groups, ns neighbours] rows followed by a max
+ * over the neighbours.  Fused, for ns in {32, 64} and (Cin, Cout) in {(64,128), (128,128), (128,256)}
+ * (hitadv_group_linear_max_supported):
+ *   fwd: out[g,c] = relu(max_j x[g*ns + j,:] . W[c,:] + bias[c]), arg[g,c] = the lowest such j (int32); X [G*ns, Cin] fp32,
+ *        W2 = hitadv_split_weights_f16x2(Wr [Cout,Cin]) -- V1's fp16x2 scheme (two pieces per operand, three exact products,
+ *        fp32 accumulators), so the [G*ns, Cout] activation, its ReLU pass and its max pass never exist;
+ *   bwd: dX[g*ns + j,:] = sum_{c: arg[g,c] == j, out[g,c] > 0} dOut[g,c] W[c,:]; Wb2 = hitadv_split_weights_f16x2(Wt [Cin,Cout])
+ *        (the same layout with the roles of the two dimensions swapped); every row of dX is written.
+ * range_flag as for hitadv_linear_max_fwd_f16x2 (may be NULL). */
+int hitadv_group_linear_max_supported(int Cin, int Cout, int ns);
+int hitadv_group_linear_max_fwd(const float *X, const uint16_t *W2, const float *bias, int64_t G, int ns, int Cin, int Cout,
+                                float *out, int32_t *arg, int32_t *range_flag, void *stream);
+int hitadv_group_linear_max_bwd(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2, int64_t G, int ns,
+                                int Cin, int Cout, float *dX, int32_t *range_flag, void *stream);
+
 /* G independent attacks STACKED (HiT_ADV.attack_many on the PointNet engine: one victim pass over the G*B clouds): the three
  * launches around that pass for all G groups at once.  Every per-cloud argument is the group-0 pointer of a buffer that
  * holds the G groups' rows one after the other (B clouds each); every per-group scalar or scratch likewise, with the stride

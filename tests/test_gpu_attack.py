@@ -642,7 +642,23 @@ def test_pointnet2_victim_on_gpu():
     assert l3.shape == (2, 1024, 1)
     close(logits, fx['logits'], rtol=1e-4, atol=1e-5, what='PointNet++ logits vs the reference (g11)')
     (logits * T(fx['grad_w']).cuda()).sum().backward()
-    gradient_close(x.grad, fx['grad_x'], 'PointNet++ input gradient vs the reference (g11)')
+    # the last shared layer of both set-abstraction levels runs fused with the max over the neighbours on the fp16 matrix cores
+    # (csrc/group_mlp.hip): a handful of neighbour maxima whose two best candidates are an fp32 rounding apart go to the other
+    # candidate than in the reference's CPU evaluation (achieved: 0.28 % of the elements beyond 1e-3, relative L2 3.4e-4; with
+    # _pointwise.FUSED_GROUP_MAX = False: none, 5.5e-7)
+    gradient_close(x.grad, fx['grad_x'], 'PointNet++ input gradient vs the reference (g11)', frac_bound=1e-2, l2_bound=1.5e-3)
+    from hit_adv_amd.model import _pointwise
+    try:
+        _pointwise.FUSED_GROUP_MAX = False
+        x2 = T(fx['x']).cuda().requires_grad_()
+        torch.manual_seed(int(fx['fwd_seed']))
+        logits2, _ = m(x2)
+        (logits2 * T(fx['grad_w']).cuda()).sum().backward()
+    finally:
+        _pointwise.FUSED_GROUP_MAX = True
+    close(logits2, fx['logits'], rtol=1e-4, atol=1e-5, what='PointNet++ logits vs the reference (g11), GEMM + max form')
+    gradient_close(x2.grad, fx['grad_x'], 'PointNet++ input gradient vs the reference (g11), GEMM + max form', frac_bound=1e-3,
+                   l2_bound=1e-4)
     data, _ = synth_batch(2, 1024, first=1300)
     with torch.no_grad():
         label = m(data[:, :, :3].transpose(1, 2).contiguous().cuda())[0].argmax(1)

@@ -829,6 +829,47 @@ def test_linear_max_fwd_f16x2_error_is_at_fp32_roundoff(A, B, Np, Cin, Cout, sca
     assert int(flag.item()) == 0
 
 
+@pytest.mark.parametrize("G,ns,Cin,Cout", [(70, 32, 64, 128), (33, 64, 128, 256), (5, 32, 128, 128), (1, 32, 64, 128),
+                                          (2049, 32, 64, 128), (300, 64, 128, 128)])
+def test_group_linear_max_forward_and_backward(A, G, ns, Cin, Cout):
+    """The last shared layer of a sample-and-group block fused with the max over the neighbours (csrc/group_mlp.hip) against
+    float64: values at fp32's roundoff (the fp16x2 scheme of V1), arg-max = the float64 winner wherever the runner-up is not
+    within rounding, ties -> the lowest row; the backward (the routed gradient through W on the matrix cores) against the
+    float64 gradient of the same function with the kernel's own winners."""
+    g = torch.Generator().manual_seed(G * 7 + ns)
+    x = torch.randn(G, ns, Cin, generator=g).relu()
+    x[0, 5] = x[0, 2]  # duplicate rows: the lower one must win every channel it wins
+    Wr = torch.randn(Cout, Cin, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g) * 0.3
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    xg = cu(x).requires_grad_()
+    out, arg = A.group_linear_max(xg, cu(Wr), cu(bias), flag, return_arg=True)
+    y = x.double() @ Wr.double().t() + bias.double()          # [G,ns,Cout]
+    ref = y.max(dim=1).values.clamp_min(0.)
+    s = float(ref.abs().max())
+    close(out / s, ref.float() / s, rtol=0, atol=2e-6, what='group_linear_max vs float64 (over the output scale)')
+    top2 = y.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4 * s
+    assert torch.equal(arg.cpu().long()[clear], y.argmax(dim=1)[clear])
+    assert int((arg[0] == 5).sum()) == 0 and arg.dtype == torch.int32 and int(arg.min()) >= 0 and int(arg.max()) < ns
+    # backward: d/dx of sum(out * w) with the kernel's winners
+    wgt = torch.randn(G, Cout, generator=g)
+    (out * cu(wgt)).sum().backward()
+    gd = torch.zeros(G, ns, Cin, dtype=torch.float64)
+    routed = (wgt.double() * (out.detach().cpu().double() > 0))  # [G,Cout]
+    contrib = routed.unsqueeze(-1) * Wr.double().unsqueeze(0)     # [G,Cout,Cin]
+    gd.scatter_add_(1, arg.cpu().long().unsqueeze(-1).expand(-1, -1, Cin), contrib)
+    sg = float(gd.abs().max())
+    close(xg.grad / sg, gd.float() / sg, rtol=0, atol=2e-6, what='group_linear_max backward vs float64 (over the gradient scale)')
+    # the torch composition gives the same function
+    xt = cu(x).requires_grad_()
+    ot = torch.relu(torch.nn.functional.linear(xt, cu(Wr), cu(bias))).max(dim=1)[0]
+    close(out, ot, rtol=0, atol=4e-6 * s, what='group_linear_max vs the fp32 torch composition')
+    assert int(flag.item()) == 0
+    out2, arg2 = A.group_linear_max(cu(x), cu(Wr), cu(bias), flag, return_arg=True)
+    assert torch.equal(out2, out) and torch.equal(arg2, arg)  # bitwise reproducible
+
+
 def test_linear_max_fwd_f16x2_raises_its_range_flag(A):
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2 * 64, 128, generator=g).relu()
