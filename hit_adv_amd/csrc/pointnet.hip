@@ -246,6 +246,226 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same chains on the fp16 matrix cores (mode 1 of the entry points; what `view.matrix_mode = 'fp16x2'` selects).
+// v_mfma_f32_32x32x2_f32 takes 64 cycles for 4096 flop; v_mfma_f32_32x32x16_f16 32 cycles for 32768.  With every operand
+// as TWO fp16 pieces (a = a1 + 2^-11 a2 + r, |r| <= 2^-24 |a|: csrc/victim_bf3.hip) a product costs three of the latter --
+// 5.3x less matrix time -- at an error of fp32's own unit roundoff per term.  At B = 32 these kernels pay latency; in a
+// 128-cloud stack (attack_many) half of their time was the f32 matrix pipe.  The C / D layout of the 32x32x16 form is that
+// of the 32x32x2 form (column on the lane, acc_row(e, h) rows), so the epilogues are the same code; the A operand is read
+// from LDS tiles of fp16 pieces (row strides 144 / 272 bytes: conflict-free ds_read_b128 for lane -> (row r, half h)),
+// the B operand is split in registers once per block.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+constexpr float PM_SC = 2048.f;   // 2^11
+constexpr int PM_LH64 = 144;      // bytes per row of a 64-wide fp16 piece tile
+constexpr int PM_LH128 = 272;
+
+__device__ __forceinline__ void split_pair(float v, _Float16 &hi, _Float16 &lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)((v - (float)hi) * PM_SC);
+}
+__device__ __forceinline__ void split8v(const float (&v)[8], uint4 &hi, uint4 &lo) {
+  h8v a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    _Float16 x, y;
+    split_pair(v[i], x, y);
+    a[i] = x;
+    b[i] = y;
+  }
+  hi = __builtin_bit_cast(uint4, a);
+  lo = __builtin_bit_cast(uint4, b);
+}
+// one value into the two piece tiles (row-major halves, row stride ld bytes)
+__device__ __forceinline__ void put_pieces(char *th, char *tl, int ld, int n, int c, float v) {
+  _Float16 x, y;
+  split_pair(v, x, y);
+  *reinterpret_cast<_Float16 *>(th + n * ld + 2 * c) = x;
+  *reinterpret_cast<_Float16 *>(tl + n * ld + 2 * c) = y;
+}
+
+// B operand of a [.,K] x [K,32] product as pieces: step s, element i of lane (r, h) is W(k = 16 s + 8 h + i, col + r)
+template <int K, bool TRANSB>
+__device__ __forceinline__ void load_w16(const float *__restrict__ W, int ldw, int col, int r, int h, uint4 (&wh)[K / 16],
+                                         uint4 (&wl)[K / 16]) {
+  float v[K / 16][8];
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = 16 * s + 8 * h + i;
+      v[s][i] = TRANSB ? W[(size_t)(col + r) * ldw + k] : W[(size_t)k * ldw + col + r];
+    }
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) split8v(v[s], wh[s], wl[s]);
+}
+
+// acc[rb] += A[row_base + 32 rb .. +32)[0..K) @ B: three MFMAs per 16 values of k (lo x hi and hi x lo into accl, hi x hi into acc)
+template <int K, int NRB>
+__device__ __forceinline__ void mfma_apply16(const char *th, const char *tl, int ld, int row_base, const uint4 (&wh)[K / 16],
+                                             const uint4 (&wl)[K / 16], f32x16 (&acc)[NRB], f32x16 (&accl)[NRB], int r, int h) {
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    const h8v bh = __builtin_bit_cast(h8v, wh[s]), bl = __builtin_bit_cast(h8v, wl[s]);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const int o = (row_base + 32 * rb + r) * ld + 2 * (16 * s + 8 * h);
+      const h8v ah = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(th + o));
+      const h8v al = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(tl + o));
+      accl[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accl[rb], 0, 0, 0);
+      accl[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accl[rb], 0, 0, 0);
+      acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[rb], 0, 0, 0);
+    }
+  }
+}
+__device__ __forceinline__ float joined(const f32x16 &hi, const f32x16 &lo, int e) { return fmaf(lo[e], 1.f / PM_SC, hi[e]); }
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void rowmlp_fwd16_k(RowMlpFwd a) {
+  __shared__ __attribute__((aligned(16))) char tA[2][PM_TM * PM_LH64], tB[2][PM_TM * PM_LH64];  // [piece][row][k]
+  __shared__ float sX[PM_TM * 3], sXp[PM_TM * 3];
+  const int b = blockIdx.y, n0 = blockIdx.x * PM_TM, N = a.N;
+  const int rows = min(PM_TM, N - n0);
+  const size_t row0 = (size_t)b * N + n0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int rb = wave & 1, cb = wave >> 1;
+
+  uint4 w2h[4], w2l[4], w1h[4], w1l[4];
+  load_w16<64, false>(a.W2, 128, 32 * wave, r, h, w2h, w2l);
+  const float bias2 = a.b2[32 * wave + r];
+  float bias1 = 0.f;
+  if (STAGE == 1) {
+    load_w16<64, false>(a.W1, 64, 32 * cb, r, h, w1h, w1l);
+    bias1 = a.b1[32 * cb + r];
+  }
+  if (STAGE == 2) load_w16<64, false>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1h, w1l);
+
+  if (STAGE < 2) {
+    const int c0 = threadIdx.x & 63;
+    const float w00 = a.W0[c0], w01 = a.W0[64 + c0], w02 = a.W0[128 + c0], bb = a.b0[c0];
+    if (STAGE == 0 && a.d_ori != nullptr) {  // block-uniform
+      deform_fwd_body<256>(a.d_ori, a.d_central, a.d_perturb, a.d_sigma, N, a.d_C, a.d_adv, a.d_inv, b, blockIdx.x, sX);
+    } else if (threadIdx.x < 192) {
+      const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+      sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
+    }
+    __shared__ float sTp[4][9], sT[9];
+    const bool ownT = STAGE == 1 && a.F5 != nullptr;  // block-uniform
+    if (ownT) {  // exactly the f32 kernel's evaluation of STN3d's last layer (same bits: T3 is shared with the backward pass)
+      const float f = a.F5[(size_t)b * 256 + threadIdx.x];
+      float p[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) p[q] = f * a.W6[threadIdx.x * 9 + q];
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) p[q] += __shfl_xor(p[q], m, HITADV_WAVE);
+      if (lane < 9) {
+        float v = p[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) v = lane == q ? p[q] : v;
+        sTp[wave][lane] = v;
+      }
+    }
+    __syncthreads();
+    if (ownT) {
+      if (threadIdx.x < 9) {
+        const float v = ((sTp[0][threadIdx.x] + sTp[1][threadIdx.x]) + sTp[2][threadIdx.x]) + sTp[3][threadIdx.x] + a.b6[threadIdx.x];
+        sT[threadIdx.x] = v;
+        if (blockIdx.x == 0) a.Tout[(size_t)b * 9 + threadIdx.x] = v;
+      }
+      __syncthreads();
+    }
+    const float *xin = sX;
+    if (STAGE == 1) {  // x' = x @ T3   (torch.bmm(x, trans), :124)
+      if (threadIdx.x < 192) {
+        const int n = threadIdx.x / 3, j = threadIdx.x % 3;
+        const float *T = ownT ? sT : a.T + (size_t)b * 9;
+        const float v = fmaf(sX[n * 3 + 2], T[6 + j], fmaf(sX[n * 3 + 1], T[3 + j], sX[n * 3] * T[j]));
+        sXp[threadIdx.x] = v;
+        if (a.xp != nullptr && n < rows) a.xp[row0 * 3 + threadIdx.x] = v;
+      }
+      __syncthreads();
+      xin = sXp;
+    }
+    {  // 3 -> 64, ReLU on the VALU (exact f32, as the f32 kernel): one column per lane, 16 rows per thread
+      const int q = threadIdx.x >> 6;
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int n = q * 16 + i;
+        float v = fmaf(xin[n * 3 + 2], w02, fmaf(xin[n * 3 + 1], w01, fmaf(xin[n * 3], w00, bb)));
+        v = v > 0.f ? v : 0.f;
+        put_pieces(tA[0], tA[1], PM_LH64, n, c0, v);
+        if (n < rows) a.o0[(row0 + n) * 64 + c0] = v;
+      }
+    }
+    __syncthreads();
+  } else {  // h1' = h1 @ T64   (torch.bmm(x, trans_feat), :131)
+    float4 t[4];
+    fetch_tile<64>(a.hin + row0 * 64, rows, t);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      const int n = e / 16, c = 4 * (e % 16);
+      put_pieces(tB[0], tB[1], PM_LH64, n, c, t[u].x);
+      put_pieces(tB[0], tB[1], PM_LH64, n, c + 1, t[u].y);
+      put_pieces(tB[0], tB[1], PM_LH64, n, c + 2, t[u].z);
+      put_pieces(tB[0], tB[1], PM_LH64, n, c + 3, t[u].w);
+    }
+    __syncthreads();
+    f32x16 acc[1], accl[1];
+    zero(acc[0]);
+    zero(accl[0]);
+    mfma_apply16<64, 1>(tB[0], tB[1], PM_LH64, 32 * rb, w1h, w1l, acc, accl, r, h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
+      const float v = joined(acc[0], accl[0], e);
+      put_pieces(tA[0], tA[1], PM_LH64, n, c, v);
+      if (a.o0 != nullptr && n < rows) a.o0[(row0 + n) * 64 + c] = v;
+    }
+    __syncthreads();
+  }
+
+  const char *inH = tA[0], *inL = tA[1];
+  if (STAGE == 1) {  // t1: 64 -> 64, ReLU
+    f32x16 acc[1], accl[1];
+    zero(acc[0]);
+    zero(accl[0]);
+    mfma_apply16<64, 1>(tA[0], tA[1], PM_LH64, 32 * rb, w1h, w1l, acc, accl, r, h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
+      float v = joined(acc[0], accl[0], e) + bias1;
+      v = v > 0.f ? v : 0.f;
+      put_pieces(tB[0], tB[1], PM_LH64, n, c, v);
+      if (n < rows) a.o1[(row0 + n) * 64 + c] = v;
+    }
+    __syncthreads();
+    inH = tB[0];
+    inL = tB[1];
+  }
+  {  // 64 -> 128, ReLU: wave w owns columns 32w..32w+31 for all 64 rows, one 32-row block after the other (two accumulator
+     // sets per block: with both blocks in flight the kernel needs 173 registers and loses its third wave per SIMD)
+    const int c = 32 * wave + r;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x16 acc[1], accl[1];
+      zero(acc[0]);
+      zero(accl[0]);
+      mfma_apply16<64, 1>(inH, inL, PM_LH64, 32 * q, w2h, w2l, acc, accl, r, h);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = 32 * q + acc_row(e, h);
+        float v = joined(acc[0], accl[0], e) + bias2;
+        v = v > 0.f ? v : 0.f;
+        if (n < rows) a.o2[(row0 + n) * 128 + c] = v;
+      }
+    }
+  }
+}
+
 // dA2[D,32 columns of this wave] = S[D,M] @ W3r[list,:]: the gather of the max-pool gradient as MFMAs.  S[i,k] = g_k if
 // list entry k routes to the i-th winning point of the tile (one non-zero per column, built on the fly); the list is
 // padded with zero-gradient entries to a multiple of 32, so the loop body is branch-free.  TWO: more than 32 winning
@@ -669,6 +889,352 @@ __global__ __launch_bounds__(256, STAGE == 1 ? 2 : 3) void rowmlp_bwd_k(RowMlpBw
   V3_STAMP_FLUSH();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// rowmlp_bwd_k on the fp16 matrix cores (mode 1): the same compaction, the same lists, the same order of operations per
+// output; every matrix product takes its operands as two fp16 pieces (three MFMAs of 32 cycles per 16 values of k instead of
+// eight of 64).  In a 128-cloud stack the f32 form spent about half of its time in the matrix pipe of two of the four SIMDs
+// (R = 1: only the waves of the first row block compute).  Differences in structure: the gradient values of the list carry
+// their two pieces instead of the fp32 bits; the ReLU mask of the 64 -> 128 layer is applied when the gathered tile leaves
+// the accumulators (masks fetched in the accumulator's layout), so the tile exists in LDS only as pieces and the separate
+// mask pass with its barrier is gone; the 64 -> 3 layer reads its rows back as hi + 2^-11 lo.
+// dA2[D rows, 32 columns of this wave] = S[D,M] @ W3r[list,:] as above, 16 list entries per MFMA step.
+template <bool TWO>
+__device__ __forceinline__ void gather_rows16(const int2 *list, int M, const float *__restrict__ Wc, int r, int h,
+                                              f32x16 (&acc)[2], f32x16 (&accl)[2]) {
+  if (M <= 0) return;
+  int2 enA[16], enB[16];
+  float bvA[16], bvB[16];
+  auto request = [&](int2 (&en)[16], float (&bv)[16], int q) {  // 32 entries: step s (0, 1), element j of half h = entry q + 16 s + 8 h + j
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      en[t] = list[q + 16 * (t >> 3) + 8 * h + (t & 7)];
+      bv[t] = Wc[(size_t)(en[t].x & 0xffff) * 128];
+    }
+  };
+  auto multiply = [&](const int2 (&en)[16], const float (&bv)[16]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float bq[8];
+      h8v ah0, al0, ah1, al1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int2 e = en[8 * s + j];
+        bq[j] = bv[8 * s + j];
+        const int i = e.x >> 16;
+        const uint32_t g2 = (uint32_t)e.y;  // (hi piece, lo piece) of the gradient value
+        const _Float16 gh = __builtin_bit_cast(_Float16, (uint16_t)(g2 & 0xffffu));
+        const _Float16 gl = __builtin_bit_cast(_Float16, (uint16_t)(g2 >> 16));
+        const _Float16 z = (_Float16)0.f;
+        ah0[j] = i == r ? gh : z;
+        al0[j] = i == r ? gl : z;
+        if (TWO) {
+          ah1[j] = i == 32 + r ? gh : z;
+          al1[j] = i == 32 + r ? gl : z;
+        }
+      }
+      uint4 wh, wl;
+      split8v(bq, wh, wl);
+      const h8v bh = __builtin_bit_cast(h8v, wh), bl = __builtin_bit_cast(h8v, wl);
+      accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh, accl[0], 0, 0, 0);
+      accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl, accl[0], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh, acc[0], 0, 0, 0);
+      if (TWO) {
+        accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh, accl[1], 0, 0, 0);
+        accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl, accl[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh, acc[1], 0, 0, 0);
+      }
+    }
+  };
+  request(enA, bvA, 0);
+  for (int q = 0; q < M; q += 64) {
+    request(enB, bvB, q + 32);
+    multiply(enA, bvA);
+    request(enA, bvA, q + 64);
+    multiply(enB, bvB);
+  }
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
+  // piece tiles: tD [2][64 rows][128] (the gathered, masked gradient; later reused as tF [2][64][64]), tE [2][64][64]
+  __shared__ __attribute__((aligned(16))) char tD[2][PM_TM * PM_LH128], tE[2][PM_TM * PM_LH64];
+  __shared__ float sX[PM_TM * 3], sG[PM_TM * 3];
+  __shared__ int s_cnt[BW_CH][4];
+  __shared__ unsigned long long s_present;
+  __shared__ int s_rowmap[PM_TM];
+  char *tF0 = tD[0], *tF1 = tD[0] + PM_TM * PM_LH64;   // two 64-wide piece tiles inside tD[0] (dead by then)
+  int2 *list = reinterpret_cast<int2 *>(tE[0]);         // [256 * BW_CH + 128] entries = 9.2 KB <= 2 x 9.2 KB of tE; dead before tE is written
+  const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, n0 = tile * PM_TM, N = a.N, Cout = a.Cout;
+  const int rows = min(PM_TM, N - n0);
+  const size_t row0 = (size_t)b * N + n0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int rb = wave & 1, cb = wave >> 1;
+  const unsigned long long rowmask = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+  const unsigned long long incoming =
+      (STAGE == 2 ? 0ull : (a.pres_in != nullptr ? a.pres_in[(size_t)b * ntiles + tile] : ~0ull)) & rowmask;
+  if (threadIdx.x == 0) s_present = incoming;
+  __syncthreads();
+  int mn[BW_CH];
+  float mg[BW_CH];
+  {
+    int64_t ti[BW_CH];
+    float tg[BW_CH], tm[BW_CH];
+#pragma unroll
+    for (int ch = 0; ch < BW_CH; ++ch) {
+      const size_t o = (size_t)b * Cout + min(ch * 256 + (int)threadIdx.x, Cout - 1);
+      ti[ch] = a.idx[o];
+      tg[ch] = a.dg[o];
+      tm[ch] = (a.gmask != nullptr ? a.gmask : a.dg)[o];
+    }
+    const bool gated = a.gmask != nullptr;
+#pragma unroll
+    for (int ch = 0; ch < BW_CH; ++ch) {
+      const bool in = ch * 256 + (int)threadIdx.x < Cout;
+      mn[ch] = in ? (int)ti[ch] - n0 : -1;
+      mg[ch] = (in && (!gated || tm[ch] > 0.f)) ? tg[ch] : 0.f;
+    }
+  }
+  if (STAGE == 1 && threadIdx.x < 192) {
+    const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+    sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
+  }
+  unsigned rank[BW_CH];
+#pragma unroll
+  for (int ch = 0; ch < BW_CH; ++ch) {
+    const int n = mn[ch];
+    const bool hit = n >= 0 && n < rows && mg[ch] != 0.f;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_cnt[ch][wave] = __popcll(m);
+    if (hit) atomicOr(&s_present, 1ull << n);
+    mn[ch] = hit ? n : -1;
+    rank[ch] = __popcll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  const unsigned long long present = s_present;
+  const int D = __popcll(present);
+  const int R = (D + 31) >> 5;
+  if (threadIdx.x == 0 && a.pres_out != nullptr) a.pres_out[(size_t)b * ntiles + tile] = present;
+  if (D == 0) {  // block-uniform: nothing arrives in this tile
+    if (STAGE == 2) {
+      float4 *o = reinterpret_cast<float4 *>(a.dTpart + ((size_t)b * ntiles + tile) * 4096);
+      for (int e = threadIdx.x; e < 1024; e += 256) o[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      if (STAGE == 1 && threadIdx.x < 9) a.dTpart[((size_t)b * ntiles + tile) * 9 + threadIdx.x] = 0.f;
+      if (threadIdx.x < 192) {
+        const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+        if (n < rows) {
+          const size_t o = ((size_t)b * 3 + c) * N + n0 + n;
+          a.out[o] = STAGE == 0 ? 0.f + a.dPin[o] : 0.f;
+        }
+      }
+    }
+    return;
+  }
+  if (threadIdx.x < PM_TM && ((present >> threadIdx.x) & 1ull))
+    s_rowmap[__popcll(present & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
+  int M = 0;
+#pragma unroll
+  for (int ch = 0; ch < BW_CH; ++ch)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w == wave && mn[ch] >= 0) {
+        _Float16 gh, gl;
+        split_pair(mg[ch], gh, gl);
+        const uint32_t g2 = (uint32_t)__builtin_bit_cast(uint16_t, gh) | ((uint32_t)__builtin_bit_cast(uint16_t, gl) << 16);
+        list[M + rank[ch]] = make_int2((ch * 256 + (int)threadIdx.x) | (__popcll(present & ((1ull << mn[ch]) - 1ull)) << 16),
+                                       (int)g2);
+      }
+      M += s_cnt[ch][w];
+    }
+  if (threadIdx.x < 128) list[M + threadIdx.x] = make_int2(0, 0);
+  __syncthreads();
+  // ---- gather on the fp16 matrix cores
+  f32x16 gacc[2], gaccl[2];
+  zero(gacc[0]);
+  zero(gacc[1]);
+  zero(gaccl[0]);
+  zero(gaccl[1]);
+  if (D > 32)
+    gather_rows16<true>(list, M, a.W3r + 32 * wave + r, r, h, gacc, gaccl);
+  else
+    gather_rows16<false>(list, M, a.W3r + 32 * wave + r, r, h, gacc, gaccl);
+  // ---- everything the chain will need from global memory
+  const bool act = rb < R;
+  uint4 w2h[8], w2l[8], w1h[4], w1l[4];
+  if (act) load_w16<128, false>(a.W2r, 64, 32 * cb, r, h, w2h, w2l);
+  float m1v[16], mhv[16], dhv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = 32 * rb + acc_row(e, h);
+    m1v[e] = STAGE != 2 ? a.A1[(row0 + s_rowmap[min(i, D - 1)]) * 64 + 32 * cb + r] : 0.f;
+  }
+  // ReLU mask of the 64 -> 128 layer in the gather's accumulator layout: row 32 q + acc_row(e, h), column 32 wave + r
+  float a2m[2][16];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = 32 * q + acc_row(e, h);
+      a2m[q][e] = a.A2[(row0 + s_rowmap[min(i, D - 1)]) * 128 + 32 * wave + r];  // rows past D carry row D-1's mask: they are exact zeros
+    }
+  float4 h1t[4];
+  if (STAGE == 2) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      const int i = e >> 4;
+      h1t[u] = *reinterpret_cast<const float4 *>(a.H1 + (row0 + s_rowmap[min(i, D - 1)]) * 64 + 4 * (e & 15));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = 32 * q + acc_row(e, h);
+      if (q < R) {
+        const float v = joined(gacc[q], gaccl[q], e);
+        put_pieces(tD[0], tD[1], PM_LH128, i, 32 * wave + r, a2m[q][e] > 0.f ? v : 0.f);
+      }
+    }
+  __syncthreads();
+  if (act) {  // through the 64->128 layer: [32R,128] @ W2r[128,64]
+    if (STAGE == 1) load_w16<64, false>(a.W1r, 64, 32 * cb, r, h, w1h, w1l);
+    if (STAGE == 2) load_w16<64, true>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1h, w1l);
+    if (STAGE == 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = 32 * rb + acc_row(e, h);
+        const bool in = i < D;
+        const int p = s_rowmap[min(i, D - 1)];
+        const size_t o = (row0 + p) * 64 + 32 * cb + r;
+        const float hv = a.H1[o], dv = a.dH1in[o];
+        mhv[e] = in ? hv : 0.f;
+        dhv[e] = (in && ((incoming >> p) & 1ull)) ? dv : 0.f;
+      }
+    }
+    f32x16 acc[1], accl[1];
+    zero(acc[0]);
+    zero(accl[0]);
+    mfma_apply16<128, 1>(tD[0], tD[1], PM_LH128, 32 * rb, w2h, w2l, acc, accl, r, h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = joined(acc[0], accl[0], e);
+      if (STAGE != 2) v = m1v[e] > 0.f ? v : 0.f;
+      put_pieces(tE[0], tE[1], PM_LH64, 32 * rb + acc_row(e, h), 32 * cb + r, v);
+    }
+  }
+  __syncthreads();
+  if (STAGE == 2) {  // tD is dead: its first half takes the h1 rows (left operand of the transform gradient) as pieces
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = threadIdx.x + 256 * u;
+      const int n = e / 16, c = 4 * (e % 16);
+      put_pieces(tF0, tF1, PM_LH64, n, c, h1t[u].x);
+      put_pieces(tF0, tF1, PM_LH64, n, c + 1, h1t[u].y);
+      put_pieces(tF0, tF1, PM_LH64, n, c + 2, h1t[u].z);
+      put_pieces(tF0, tF1, PM_LH64, n, c + 3, h1t[u].w);
+    }
+    __syncthreads();
+    // (a) dT64 partial of this tile:  sum_n h1[n,i] * d[n,j]   (A = h1^T, B = d, K = the compacted points, ascending): both
+    //     operands are read down the rows of their tiles, eight 2-byte reads per piece and step
+    {
+      f32x16 acc, accl;
+      zero(acc);
+      zero(accl);
+      for (int s16 = 0; s16 < 2 * R; ++s16) {
+        h8v ah, al, bh, bl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int n = 16 * s16 + 8 * h + j;
+          ah[j] = *reinterpret_cast<const _Float16 *>(tF0 + n * PM_LH64 + 2 * (32 * rb + r));
+          al[j] = *reinterpret_cast<const _Float16 *>(tF1 + n * PM_LH64 + 2 * (32 * rb + r));
+          bh[j] = *reinterpret_cast<const _Float16 *>(tE[0] + n * PM_LH64 + 2 * (32 * cb + r));
+          bl[j] = *reinterpret_cast<const _Float16 *>(tE[1] + n * PM_LH64 + 2 * (32 * cb + r));
+        }
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accl, 0, 0, 0);
+        accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accl, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      }
+      float *o = a.dTpart + ((size_t)b * ntiles + tile) * 4096;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[(32 * rb + acc_row(e, h)) * 64 + 32 * cb + r] = joined(acc, accl, e);
+    }
+    // (b) dH1 = d @ T64^T, written for the compacted points only
+    if (act) {
+      f32x16 acc[1], accl[1];
+      zero(acc[0]);
+      zero(accl[0]);
+      mfma_apply16<64, 1>(tE[0], tE[1], PM_LH64, 32 * rb, w1h, w1l, acc, accl, r, h);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = 32 * rb + acc_row(e, h);
+        if (i < D) a.out[(row0 + s_rowmap[i]) * 64 + 32 * cb + r] = joined(acc[0], accl[0], e);
+      }
+    }
+    return;
+  }
+
+  const char *inH = tE[0], *inL = tE[1];
+  if (STAGE == 1) {  // through t1, add the gradient arriving at h1 from the encoder, through e1's ReLU
+    if (act) {
+      f32x16 acc[1], accl[1];
+      zero(acc[0]);
+      zero(accl[0]);
+      mfma_apply16<64, 1>(tE[0], tE[1], PM_LH64, 32 * rb, w1h, w1l, acc, accl, r, h);
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        put_pieces(tF0, tF1, PM_LH64, 32 * rb + acc_row(e, h), 32 * cb + r, mhv[e] > 0.f ? joined(acc[0], accl[0], e) + dhv[e] : 0.f);
+    }
+    __syncthreads();
+    inH = tF0;
+    inL = tF1;
+  }
+  if (wave < 3) {  // 64 -> 3 backwards on the VALU:  g[i,c] = sum_k d[i,k] * W0r[k,c]; the row comes back as hi + 2^-11 lo
+    const int c = wave, i = lane;
+    float v = 0.f;
+    if (i < D) {
+#pragma unroll
+      for (int k8 = 0; k8 < 8; ++k8) {
+        const h8v dh = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(inH + i * PM_LH64 + 16 * k8));
+        const h8v dl = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(inL + i * PM_LH64 + 16 * k8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v = fmaf(fmaf((float)dl[j], 1.f / PM_SC, (float)dh[j]), a.W0r[(8 * k8 + j) * 3 + c], v);
+      }
+    }
+    sG[i * 3 + c] = v;
+  }
+  __syncthreads();
+  if (STAGE == 0) {
+    if (wave < 3) {
+      const int c = wave, n = lane;
+      if (n < rows) {
+        const size_t o = ((size_t)b * 3 + c) * N + n0 + n;
+        const float v = ((present >> n) & 1ull) ? sG[__popcll(present & ((1ull << n) - 1ull)) * 3 + c] : 0.f;
+        a.out[o] = v + a.dPin[o];
+      }
+    }
+  } else {
+    const float *T = a.T + (size_t)b * 9;
+    if (wave < 3) {
+      const int i = wave, n = lane;
+      if (n < rows) {
+        float v = 0.f;
+        if ((present >> n) & 1ull) {
+          const float *g = sG + __popcll(present & ((1ull << n) - 1ull)) * 3;
+          v = fmaf(g[2], T[i * 3 + 2], fmaf(g[1], T[i * 3 + 1], g[0] * T[i * 3]));
+        }
+        a.out[((size_t)b * 3 + i) * N + n0 + n] = v;
+      }
+    } else if (threadIdx.x < 192 + 9) {
+      const int q = threadIdx.x - 192, i = q / 3, j = q % 3;
+      float v = 0.f;
+      for (int ci = 0; ci < D; ++ci) v = fmaf(sX[s_rowmap[ci] * 3 + i], sG[ci * 3 + j], v);
+      a.dTpart[((size_t)b * ntiles + tile) * 9 + q] = v;
+    }
+  }
+}
+
 // out[b,m] = sum_t part[b,t,m] (+ extra[b,m]), ascending t.
 __global__ __launch_bounds__(256) void sum_partials_k(const float *__restrict__ part, const float *__restrict__ extra,
                                                       int T, int M, float *__restrict__ out, long long total) {
@@ -1056,8 +1622,8 @@ using namespace hitadv;
 extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const float *hin, const float *W0,
                                           const float *b0, const float *W1, const float *b1, const float *W2,
                                           const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N,
-                                          void *stream) {
-  if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || !W2 || !b2 || !o2) return HITADV_E_ARG;
+                                          int mode, void *stream) {
+  if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || !W2 || !b2 || !o2 || mode < 0 || mode > 1) return HITADV_E_ARG;
   if (stage < 2 && (!x || !W0 || !b0 || !o0)) return HITADV_E_ARG;
   if (stage == 1 && (!T || !W1 || !b1 || !o1)) return HITADV_E_ARG;
   if (stage == 2 && (!T || !hin)) return HITADV_E_ARG;
@@ -1065,7 +1631,11 @@ extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float
               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   hipStream_t s = (hipStream_t)stream;
-  if (stage == 0) rowmlp_fwd_k<0><<<grid, 256, 0, s>>>(a);
+  if (mode == 1) {
+    if (stage == 0) rowmlp_fwd16_k<0><<<grid, 256, 0, s>>>(a);
+    else if (stage == 1) rowmlp_fwd16_k<1><<<grid, 256, 0, s>>>(a);
+    else rowmlp_fwd16_k<2><<<grid, 256, 0, s>>>(a);
+  } else if (stage == 0) rowmlp_fwd_k<0><<<grid, 256, 0, s>>>(a);
   else if (stage == 1) rowmlp_fwd_k<1><<<grid, 256, 0, s>>>(a);
   else rowmlp_fwd_k<2><<<grid, 256, 0, s>>>(a);
   HITADV_LAUNCH_CHECK();
@@ -1075,13 +1645,15 @@ extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float
 extern "C" int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, const float *W6, const float *b6,
                                               float *Tout, const float *W0, const float *b0, const float *W1,
                                               const float *b1, const float *W2, const float *b2, float *xp, float *o0,
-                                              float *o1, float *o2, int B, int N, void *stream) {
-  if (B <= 0 || N <= 0 || !x || !F5 || !W6 || !b6 || !Tout || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !o0 || !o1 || !o2)
+                                              float *o1, float *o2, int B, int N, int mode, void *stream) {
+  if (B <= 0 || N <= 0 || !x || !F5 || !W6 || !b6 || !Tout || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !o0 || !o1 || !o2 ||
+      mode < 0 || mode > 1)
     return HITADV_E_ARG;
   RowMlpFwd a{x, nullptr, nullptr, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, F5, W6, b6, Tout,
               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
-  rowmlp_fwd_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  if (mode == 1) rowmlp_fwd16_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  else rowmlp_fwd_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -1089,14 +1661,15 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, c
 extern "C" int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *central, const float *perturb,
                                                  const float *sigma, int C, float *adv, float *inv_den, const float *W0,
                                                  const float *b0, const float *W2, const float *b2, float *o0, float *o2,
-                                                 int B, int N, void *stream) {
+                                                 int B, int N, int mode, void *stream) {
   if (B <= 0 || N <= 0 || C <= 0 || C > 256 || !ori || !central || !perturb || !sigma || !adv || !inv_den || !W0 || !b0 ||
-      !W2 || !b2 || !o0 || !o2)
+      !W2 || !b2 || !o0 || !o2 || mode < 0 || mode > 1)
     return HITADV_E_ARG;
   RowMlpFwd a{adv, nullptr, nullptr, W0, b0, nullptr, nullptr, W2, b2, nullptr, o0, nullptr, o2, N, nullptr, nullptr, nullptr,
               nullptr, ori, central, perturb, sigma, adv, inv_den, C};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
-  rowmlp_fwd_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  if (mode == 1) rowmlp_fwd16_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  else rowmlp_fwd_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -1108,9 +1681,9 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
                                           const float *A1, const float *W1r, const float *H1, const float *dH1in,
                                           const float *W0r, const float *T, const float *x, const float *dPin,
                                           float *dTpart, float *out, const uint64_t *pres_in, uint64_t *pres_out, int B,
-                                          int N, void *stream) {
+                                          int N, int mode, void *stream) {
   if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || N > 65535 || Cout <= 0 || Cout > 256 * BW_CH || !dg || !idx ||
-      !W3r || !A2 || !W2r || !out)
+      !W3r || !A2 || !W2r || !out || mode < 0 || mode > 1)
     return HITADV_E_ARG;
   if (stage == 0 && (!A1 || !W0r || !dPin)) return HITADV_E_ARG;
   if (stage == 1 && (!A1 || !W1r || !H1 || !dH1in || !W0r || !T || !x || !dTpart)) return HITADV_E_ARG;
@@ -1120,7 +1693,11 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
               Cout};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   hipStream_t s = (hipStream_t)stream;
-  if (stage == 0) rowmlp_bwd_k<0><<<grid, 256, 0, s>>>(a);
+  if (mode == 1) {
+    if (stage == 0) rowmlp_bwd16_k<0><<<grid, 256, 0, s>>>(a);
+    else if (stage == 1) rowmlp_bwd16_k<1><<<grid, 256, 0, s>>>(a);
+    else rowmlp_bwd16_k<2><<<grid, 256, 0, s>>>(a);
+  } else if (stage == 0) rowmlp_bwd_k<0><<<grid, 256, 0, s>>>(a);
   else if (stage == 1) rowmlp_bwd_k<1><<<grid, 256, 0, s>>>(a);
   else rowmlp_bwd_k<2><<<grid, 256, 0, s>>>(a);
   HITADV_LAUNCH_CHECK();

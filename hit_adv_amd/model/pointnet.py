@@ -189,6 +189,7 @@ class _PointNetHip(torch.autograd.Function):
         B, _, N = x.shape
         R = B * N
         E = lambda *s: torch.empty(*s, device=x.device)  # noqa: E731
+        cm = 1 if v.matrix_mode == 'fp16x2' else 0  # the shared-layer chains: fp16x2 pieces on the fp16 matrix cores, or f32 MFMA
         # STN3d
         a1s, a2s = E(R, 64), E(R, 128)
         def lin_max(a, name, relu):
@@ -205,9 +206,10 @@ class _PointNetHip(torch.autograd.Function):
         if v.deform_inputs is not None:  # x is an OUTPUT of the first kernel: the caller's deformation, evaluated inside
             ori, central, P, sigma, inv_den = v.deform_inputs
             v.deform_inputs = None  # consumed: the caller checks this
-            ops.pointnet_rowmlp_fwd_deform(B, N, ori, central, P, sigma, x, inv_den, v.s1_w, v.s1_b, v.s2_w, v.s2_b, a1s, a2s)
+            ops.pointnet_rowmlp_fwd_deform(B, N, ori, central, P, sigma, x, inv_den, v.s1_w, v.s1_b, v.s2_w, v.s2_b, a1s, a2s,
+                                           mode=cm)
         else:
-            ops.pointnet_rowmlp_fwd(0, B, N, v.s2_w, v.s2_b, a2s, x=x, W0=v.s1_w, b0=v.s1_b, o0=a1s)
+            ops.pointnet_rowmlp_fwd(0, B, N, v.s2_w, v.s2_b, a2s, x=x, W0=v.s1_w, b0=v.s1_b, o0=a1s, mode=cm)
         gs, js = lin_max(a2s, 's3', True)
         f4s = ops.fc_layer(gs, v.s4_w, v.s4_b, relu=True)
         f5s = ops.fc_layer(f4s, v.s5_w, v.s5_b, relu=True)
@@ -216,18 +218,18 @@ class _PointNetHip(torch.autograd.Function):
         if v.fold_small_layers:
             T3 = E(B, 9)
             ops.pointnet_rowmlp_fwd_stn(B, N, x, f5s, v.s6_w, v.s6_b, T3, v.e1_w, v.e1_b, v.t1_w, v.t1_b, v.t2_w, v.t2_b,
-                                        h1, a1t, a2t)
+                                        h1, a1t, a2t, mode=cm)
         else:
             T3 = ops.fc_layer(f5s, v.s6_w, v.s6_b)
             ops.pointnet_rowmlp_fwd(1, B, N, v.t2_w, v.t2_b, a2t, x=x, T=T3, W0=v.e1_w, b0=v.e1_b, W1=v.t1_w, b1=v.t1_b,
-                                    o0=h1, o1=a1t)
+                                    o0=h1, o1=a1t, mode=cm)
         gt, jt = lin_max(a2t, 't3', True)
         f4t = ops.fc_layer(gt, v.t4_w, v.t4_b, relu=True)
         f5t = ops.fc_layer(f4t, v.t5_w, v.t5_b, relu=True)
         T64 = ops.fc_layer(f5t, v.t6_w, v.t6_b)
         # feature transform, encoder tail, classifier head
         a2e = E(R, 128)
-        ops.pointnet_rowmlp_fwd(2, B, N, v.e2_w, v.e2_b, a2e, T=T64, hin=h1)
+        ops.pointnet_rowmlp_fwd(2, B, N, v.e2_w, v.e2_b, a2e, T=T64, hin=h1, mode=cm)
         g, je = lin_max(a2e, 'e3', False)
         f1 = ops.fc_layer(g, v.h1_w, v.h1_b, relu=True)
         f2 = ops.fc_layer(f1, v.h2_w, v.h2_b, relu=True)
@@ -262,7 +264,8 @@ class _PointNetHip(torch.autograd.Function):
         # which points of a tile receive any gradient: handed from stage to stage, each stage works on those rows only
         pres2 = torch.empty(B, tiles, device=x.device, dtype=torch.int64)
         pres1 = torch.empty(B, tiles, device=x.device, dtype=torch.int64)
-        ops.pointnet_rowmlp_bwd(2, B, N, dg, je, v.e3_wr, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp, pres_out=pres2)
+        cm = 1 if v.matrix_mode == 'fp16x2' else 0
+        ops.pointnet_rowmlp_bwd(2, B, N, dg, je, v.e3_wr, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp, pres_out=pres2, mode=cm)
         dT64 = ops.sum_partials(dTp, None if dT64_ext is None else dT64_ext.reshape(B, 4096).contiguous())
         # STNkd, first encoder layer, input transform
         d = ops.fc_layer(dT64, v.t6_wr)
@@ -270,7 +273,7 @@ class _PointNetHip(torch.autograd.Function):
         dgt = ops.fc_layer(d, v.t4_wr, mask=f4t)
         dTp, dPts = E(B, tiles, 9), E(B, 3, N)
         ops.pointnet_rowmlp_bwd(1, B, N, dgt, jt, v.t3_wr, a2t, v.t2_wr, dPts, gmask=gt, A1=a1t, W1r=v.t1_wr, H1=h1,
-                                dH1in=dH1, W0r=v.e1_wr, T=T3, x=x, dTpart=dTp, pres_in=pres2, pres_out=pres1)
+                                dH1in=dH1, W0r=v.e1_wr, T=T3, x=x, dTpart=dTp, pres_in=pres2, pres_out=pres1, mode=cm)
         # STN3d: the sum of the tiles' dT3 partials, fc3 and fc2 backwards in one launch
         if v.fold_small_layers:
             d = ops.fc_layer_pre(dTp, v.s6_wr, v.s5_wr, mask=f5s)
@@ -279,7 +282,7 @@ class _PointNetHip(torch.autograd.Function):
         dgs = ops.fc_layer(d, v.s4_wr, mask=f4s)
         dX = E(B, 3, N)
         ops.pointnet_rowmlp_bwd(0, B, N, dgs, js, v.s3_wr, a2s, v.s2_wr, dX, gmask=gs, A1=a1s, W0r=v.s1_wr, dPin=dPts,
-                                pres_in=pres1)
+                                pres_in=pres1, mode=cm)
         return dX, None
 
 

@@ -651,35 +651,37 @@ def sum_partials(part, extra=None):
 
 
 def pointnet_rowmlp_fwd(stage, B, N, W2, b2, o2, x=None, T=None, hin=None, W0=None, b0=None, W1=None, b1=None,
-                        xp=None, o0=None, o1=None):
+                        xp=None, o0=None, o1=None, mode=0):
+    """``mode`` 1: the layer products on the fp16 matrix cores, two pieces per operand (include/hitadv.h)."""
     _lib.call("hitadv_pointnet_rowmlp_fwd", stage, _p(x), _p(T), _p(hin), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2),
-              _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, _stream())
+              _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, int(mode), _stream())
 
 
-def pointnet_rowmlp_fwd_stn(B, N, x, F5, W6, b6, Tout, W0, b0, W1, b1, W2, b2, o0, o1, o2, xp=None):
+def pointnet_rowmlp_fwd_stn(B, N, x, F5, W6, b6, Tout, W0, b0, W1, b1, W2, b2, o0, o1, o2, xp=None, mode=0):
     """Stage 1 of the forward chain with STN3d's last layer (F5 [B,256] @ W6 [256,9] + b6 -> Tout [B,9]) evaluated inside."""
     if F5.shape[1] != 256 or tuple(W6.shape) != (256, 9):
         raise ValueError("the fused input transform is the 256 -> 9 layer")
     _lib.call("hitadv_pointnet_rowmlp_fwd_stn", _p(x), _p(F5), _p(W6), _p(b6), _p(Tout), _p(W0), _p(b0), _p(W1), _p(b1),
-              _p(W2), _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, _stream())
+              _p(W2), _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, int(mode), _stream())
 
 
-def pointnet_rowmlp_fwd_deform(B, N, ori, central, perturb, sigma, adv, inv_den, W0, b0, W2, b2, o0, o2):
+def pointnet_rowmlp_fwd_deform(B, N, ori, central, perturb, sigma, adv, inv_den, W0, b0, W2, b2, o0, o2, mode=0):
     """Stage 0 of the forward chain on HiT-ADV's deformation of ``ori``, evaluated inside (``adv`` and ``inv_den`` are
     OUTPUTS: what ``deform_fwd_into`` writes)."""
     C = sigma.shape[1]
     if C > 256:
         raise ValueError("the fused deformation holds at most 256 centres")
     _lib.call("hitadv_pointnet_rowmlp_fwd_deform", _p(ori), _p(central), _p(perturb), _p(sigma), C, _p(adv), _p(inv_den),
-              _p(W0), _p(b0), _p(W2), _p(b2), _p(o0), _p(o2), B, N, _stream())
+              _p(W0), _p(b0), _p(W2), _p(b2), _p(o0), _p(o2), B, N, int(mode), _stream())
 
 
 def pointnet_rowmlp_bwd(stage, B, N, dg, idx, W3r, A2, W2r, out, gmask=None, A1=None, W1r=None, H1=None, dH1in=None,
-                        W0r=None, T=None, x=None, dPin=None, dTpart=None, pres_in=None, pres_out=None):
-    """``pres_in`` / ``pres_out``: int64 [B, tiles] row-presence bit sets handed from stage to stage (see hitadv.h)."""
+                        W0r=None, T=None, x=None, dPin=None, dTpart=None, pres_in=None, pres_out=None, mode=0):
+    """``pres_in`` / ``pres_out``: int64 [B, tiles] row-presence bit sets handed from stage to stage (see hitadv.h);
+    ``mode`` 1: the products on the fp16 matrix cores, two pieces per operand."""
     _lib.call("hitadv_pointnet_rowmlp_bwd", stage, _p(dg), _p(gmask), _p(idx), _p(W3r), W3r.shape[0], _p(A2), _p(W2r),
               _p(A1), _p(W1r), _p(H1), _p(dH1in), _p(W0r), _p(T), _p(x), _p(dPin), _p(dTpart), _p(out), _p(pres_in),
-              _p(pres_out), B, N, _stream())
+              _p(pres_out), B, N, int(mode), _stream())
 
 
 def pointnet_rowmlp_tiles(N):

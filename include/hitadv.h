@@ -314,23 +314,28 @@ int hitadv_linear_max_fwd_f16x2(const float *X, const uint16_t *W2, const float 
  *                                   xp = x @ T[b] (T [B,3,3]) -> o0 = relu(xp W0 + b0) -> o1 = relu(o0 W1 + b1) [.,64]
  *                                   -> o2 = relu(o1 W2 + b2)
  *   stage 2 (encoder, :129-137)     o0 = hin @ T[b] (T [B,64,64]) -> o2 = relu(o0 W2 + b2)
- * Unused pointers of a stage may be NULL; so may xp (stage 1) and o0 (stage 2) when the caller does not need them. */
+ * Unused pointers of a stage may be NULL; so may xp (stage 1) and o0 (stage 2) when the caller does not need them.
+ * `mode` (all three forward entry points and the backward one): 0 = the products on the f32 matrix cores (an exact fp32 FMA
+ * chain per output), 1 = on the fp16 matrix cores with every operand as two fp16 pieces and three exact products per useful
+ * one (the scheme of hitadv_linear_max_fwd_f16x2: 5.3x less matrix time, errors at fp32's unit roundoff; the 3 -> 64 and
+ * 64 -> 3 layers and the transforms' 3x3 products stay exact f32 on the VALU). */
 int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const float *hin, const float *W0,
                                const float *b0, const float *W1, const float *b1, const float *W2, const float *b2,
-                               float *xp, float *o0, float *o1, float *o2, int B, int N, void *stream);
+                               float *xp, float *o0, float *o1, float *o2, int B, int N, int mode, void *stream);
 /* Number of 64-point tiles per cloud = leading dimension of the dTpart scratch below. */
 /* Stage 0 whose input IS HiT-ADV's deformation (hitadv_deform_fwd, ShapeAttack/HiT_ADV.py:160-175) of `ori`: every block
  * deforms its 64 points itself (C <= 256 centres), writes them to adv [B,3,N] and 1 / sum_j k to inv_den [B,N] -- what
  * hitadv_deform_fwd writes, bit for bit -- and goes on with them as hitadv_pointnet_rowmlp_fwd(stage = 0, x = adv). */
 int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *central, const float *perturb, const float *sigma,
                                       int C, float *adv, float *inv_den, const float *W0, const float *b0, const float *W2,
-                                      const float *b2, float *o0, float *o2, int B, int N, void *stream);
+                                      const float *b2, float *o0, float *o2, int B, int N, int mode, void *stream);
 /* Stage 1 with the input transform evaluated inside: T3[b] = F5[b,:256] @ W6[256,9] + b6 (STN3d's last layer, :186-190,
  * the identity folded into b6) is computed by every block of the cloud (2304 multiply-adds, fixed order) and written to
  * Tout [B,9] for the backward pass; everything else as hitadv_pointnet_rowmlp_fwd(stage = 1, T = Tout). */
 int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, const float *W6, const float *b6, float *Tout,
                                    const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
-                                   const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N, void *stream);
+                                   const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N, int mode,
+                                   void *stream);
 int64_t hitadv_pointnet_rowmlp_tiles(int N);
 /* Input-gradient chain of the same stages, starting at the max-pooled output of the stage's 128->Cout layer:
  * dg [B,Cout] is the gradient there, idx [B,Cout] the arg-max point of every channel (hitadv_linear_max_fwd),
@@ -352,7 +357,7 @@ int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const float *gmask, c
                                int Cout, const float *A2, const float *W2r, const float *A1, const float *W1r,
                                const float *H1, const float *dH1in, const float *W0r, const float *T, const float *x,
                                const float *dPin, float *dTpart, float *out, const uint64_t *pres_in,
-                               uint64_t *pres_out, int B, int N, void *stream);
+                               uint64_t *pres_out, int B, int N, int mode, void *stream);
 /* out[b,m] = (extra ? extra[b,m] : 0) + sum_t part[b,t,m], ascending t. */
 int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out, void *stream);
 /* out[B,NOUT] = act(in'[B,K] @ Wt[K,NOUT] + bias), in' = in gated by (mask > 0) when mask != NULL (the backward of a
