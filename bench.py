@@ -310,8 +310,11 @@ def loop_floor(B, N, classes=40, matrix_mode='bf16x3', C=192):
     fc = 2.0 * B * (3 * (1024 * 512 + 512 * 256) + 256 * (9 + 4096 + classes))             # V4 forward
     bwd_gather = 3 * 2.0 * B * 1024 * 128                                                  # V3: one W3r row per (cloud, channel)
     bwd_chain = 2.0 * tiles * 32 * ((128 * 64) + (128 * 64 + 64 * 64) + (128 * 64 + 64 * 64 + 64 * 64))  # V3 on 32-row blocks
-    f32_flop = fwd_chain + 2 * fc + bwd_gather + bwd_chain
+    chains = fwd_chain + bwd_gather + bwd_chain
+    f32_flop = 2 * fc + (0.0 if matrix_mode == 'fp16x2' else chains)  # fp16x2 mode: the chains run on the fp16 cores too
     bf16_flop = {'bf16x3': 6, 'fp16x2': 3}.get(matrix_mode, 0) * v1_useful  # 16-bit MFMA flop (bf16 and fp16 share the peak)
+    if matrix_mode == 'fp16x2':
+        bf16_flop += 3 * chains
     if matrix_mode not in ('bf16x3', 'fp16x2'):
         f32_flop += v1_useful
     act = 4.0 * R * (64 + 128 + 64 + 64 + 128 + 128)          # a1s a2s h1 a1t a2t a2e: written once by V2 ...
