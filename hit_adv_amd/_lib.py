@@ -75,10 +75,11 @@ PROTOTYPES = {
     "hitadv_linear_max_fwd_bf16x3": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hitadv_linear_max_fwd_bf16x3_scratch": [_I, _I, _I, _I],
     "hitadv_split_weights_f16x2": [_P, _I, _I, _P, _P, _P],
+    "hitadv_linear_max_fwd_f16x2_packed": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hitadv_linear_max_fwd_f16x2": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
-    "hitadv_pointnet_rowmlp_fwd": [_I] + [_P] * 13 + [_I, _I, _I, _P],
-    "hitadv_pointnet_rowmlp_fwd_stn": [_P] * 15 + [_I, _I, _I, _P],
-    "hitadv_pointnet_rowmlp_fwd_deform": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "hitadv_pointnet_rowmlp_fwd": [_I] + [_P] * 13 + [_I, _I, _I, _P, _P],
+    "hitadv_pointnet_rowmlp_fwd_stn": [_P] * 15 + [_I, _I, _I, _P, _P],
+    "hitadv_pointnet_rowmlp_fwd_deform": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "hitadv_pointnet_rowmlp_tiles": [_I],
     "hitadv_pointnet_rowmlp_bwd": [_I, _P, _P, _P, _P, _I] + [_P] * 14 + [_I, _I, _I, _P],
     "hitadv_sum_partials": [_P, _P, _I, _I, _I, _P, _P],

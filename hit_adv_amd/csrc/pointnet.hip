@@ -110,6 +110,11 @@ struct RowMlpFwd {
   const float *d_ori, *d_central, *d_perturb, *d_sigma;
   float *d_adv, *d_inv;
   int d_C;
+  // mode 2: o2 is written as PACKED PIECES, one 32-bit word per value = (fp16 hi | fp16 lo << 16) with lo the residual scaled by
+  // 2^11 -- what the fp16x2 128 -> 1024 kernel consumes directly (hitadv_linear_max_fwd_f16x2_packed) and what the backward
+  // chain (mode 2) reads as the layer's ReLU mask (word != 0); range_flag (may be NULL) is raised by a value beyond fp16's range
+  int pack_o2;
+  int *range_flag;
 };
 
 template <int STAGE>
@@ -449,6 +454,7 @@ __global__ __launch_bounds__(256) void rowmlp_fwd16_k(RowMlpFwd a) {
   {  // 64 -> 128, ReLU: wave w owns columns 32w..32w+31 for all 64 rows, one 32-row block after the other (two accumulator
      // sets per block: with both blocks in flight the kernel needs 173 registers and loses its third wave per SIMD)
     const int c = 32 * wave + r;
+    float big = 0.f;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       f32x16 acc[1], accl[1];
@@ -460,9 +466,18 @@ __global__ __launch_bounds__(256) void rowmlp_fwd16_k(RowMlpFwd a) {
         const int n = 32 * q + acc_row(e, h);
         float v = joined(acc[0], accl[0], e) + bias2;
         v = v > 0.f ? v : 0.f;
-        if (n < rows) a.o2[(row0 + n) * 128 + c] = v;
+        if (a.pack_o2) {  // block-uniform
+          _Float16 x, y;
+          split_pair(v, x, y);
+          big = fmaxf(big, v);
+          const uint32_t wd = (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+          if (n < rows) reinterpret_cast<uint32_t *>(a.o2)[(row0 + n) * 128 + c] = wd;
+        } else if (n < rows) {
+          a.o2[(row0 + n) * 128 + c] = v;
+        }
       }
     }
+    if (a.pack_o2 && a.range_flag != nullptr && !(big < 65504.f)) *a.range_flag = 1;
   }
 }
 
@@ -531,6 +546,7 @@ struct RowMlpBwd {
                                       // NULL: every row may be (stage 2 has no incoming gradient: NULL = none)
   unsigned long long *pres_out;       // [B,tiles] rows of this tile that receive any gradient in this stage, or NULL
   int N, Cout;
+  int a2_packed;                      // mode 2: A2 holds packed fp16 pieces (rowmlp_fwd16_k, pack_o2), not fp32 values
 };
 
 constexpr int BW_CH = 4;  // Cout <= 256 * BW_CH
@@ -1076,7 +1092,9 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int i = 32 * q + acc_row(e, h);
-      a2m[q][e] = a.A2[(row0 + s_rowmap[min(i, D - 1)]) * 128 + 32 * wave + r];  // rows past D carry row D-1's mask: they are exact zeros
+      // rows past D carry row D-1's mask: they are exact zeros.  Packed pieces (mode 2): a ReLU output is positive iff its word
+      // (hi | lo << 16) is not zero
+      a2m[q][e] = a.A2[(row0 + s_rowmap[min(i, D - 1)]) * 128 + 32 * wave + r];
     }
   float4 h1t[4];
   if (STAGE == 2) {
@@ -1094,7 +1112,8 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
       const int i = 32 * q + acc_row(e, h);
       if (q < R) {
         const float v = joined(gacc[q], gaccl[q], e);
-        put_pieces(tD[0], tD[1], PM_LH128, i, 32 * wave + r, a2m[q][e] > 0.f ? v : 0.f);
+        const bool pos = a.a2_packed ? __float_as_uint(a2m[q][e]) != 0u : a2m[q][e] > 0.f;
+        put_pieces(tD[0], tD[1], PM_LH128, i, 32 * wave + r, pos ? v : 0.f);
       }
     }
   __syncthreads();
@@ -1622,16 +1641,16 @@ using namespace hitadv;
 extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const float *hin, const float *W0,
                                           const float *b0, const float *W1, const float *b1, const float *W2,
                                           const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N,
-                                          int mode, void *stream) {
-  if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || !W2 || !b2 || !o2 || mode < 0 || mode > 1) return HITADV_E_ARG;
+                                          int mode, int32_t *range_flag, void *stream) {
+  if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || !W2 || !b2 || !o2 || mode < 0 || mode > 2) return HITADV_E_ARG;
   if (stage < 2 && (!x || !W0 || !b0 || !o0)) return HITADV_E_ARG;
   if (stage == 1 && (!T || !W1 || !b1 || !o1)) return HITADV_E_ARG;
   if (stage == 2 && (!T || !hin)) return HITADV_E_ARG;
   RowMlpFwd a{x, T, hin, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, nullptr, nullptr, nullptr, nullptr,
-              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, mode == 2, range_flag};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 1) {
+  if (mode >= 1) {
     if (stage == 0) rowmlp_fwd16_k<0><<<grid, 256, 0, s>>>(a);
     else if (stage == 1) rowmlp_fwd16_k<1><<<grid, 256, 0, s>>>(a);
     else rowmlp_fwd16_k<2><<<grid, 256, 0, s>>>(a);
@@ -1645,14 +1664,15 @@ extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float
 extern "C" int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, const float *W6, const float *b6,
                                               float *Tout, const float *W0, const float *b0, const float *W1,
                                               const float *b1, const float *W2, const float *b2, float *xp, float *o0,
-                                              float *o1, float *o2, int B, int N, int mode, void *stream) {
+                                              float *o1, float *o2, int B, int N, int mode, int32_t *range_flag,
+                                              void *stream) {
   if (B <= 0 || N <= 0 || !x || !F5 || !W6 || !b6 || !Tout || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !o0 || !o1 || !o2 ||
-      mode < 0 || mode > 1)
+      mode < 0 || mode > 2)
     return HITADV_E_ARG;
   RowMlpFwd a{x, nullptr, nullptr, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, F5, W6, b6, Tout,
-              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, mode == 2, range_flag};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
-  if (mode == 1) rowmlp_fwd16_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  if (mode >= 1) rowmlp_fwd16_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   else rowmlp_fwd_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   HITADV_LAUNCH_CHECK();
   return 0;
@@ -1661,14 +1681,14 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, c
 extern "C" int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *central, const float *perturb,
                                                  const float *sigma, int C, float *adv, float *inv_den, const float *W0,
                                                  const float *b0, const float *W2, const float *b2, float *o0, float *o2,
-                                                 int B, int N, int mode, void *stream) {
+                                                 int B, int N, int mode, int32_t *range_flag, void *stream) {
   if (B <= 0 || N <= 0 || C <= 0 || C > 256 || !ori || !central || !perturb || !sigma || !adv || !inv_den || !W0 || !b0 ||
-      !W2 || !b2 || !o0 || !o2 || mode < 0 || mode > 1)
+      !W2 || !b2 || !o0 || !o2 || mode < 0 || mode > 2)
     return HITADV_E_ARG;
   RowMlpFwd a{adv, nullptr, nullptr, W0, b0, nullptr, nullptr, W2, b2, nullptr, o0, nullptr, o2, N, nullptr, nullptr, nullptr,
-              nullptr, ori, central, perturb, sigma, adv, inv_den, C};
+              nullptr, ori, central, perturb, sigma, adv, inv_den, C, mode == 2, range_flag};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
-  if (mode == 1) rowmlp_fwd16_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  if (mode >= 1) rowmlp_fwd16_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   else rowmlp_fwd_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   HITADV_LAUNCH_CHECK();
   return 0;
@@ -1683,17 +1703,17 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
                                           float *dTpart, float *out, const uint64_t *pres_in, uint64_t *pres_out, int B,
                                           int N, int mode, void *stream) {
   if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || N > 65535 || Cout <= 0 || Cout > 256 * BW_CH || !dg || !idx ||
-      !W3r || !A2 || !W2r || !out || mode < 0 || mode > 1)
+      !W3r || !A2 || !W2r || !out || mode < 0 || mode > 2)
     return HITADV_E_ARG;
   if (stage == 0 && (!A1 || !W0r || !dPin)) return HITADV_E_ARG;
   if (stage == 1 && (!A1 || !W1r || !H1 || !dH1in || !W0r || !T || !x || !dTpart)) return HITADV_E_ARG;
   if (stage == 2 && (!H1 || !T || !dTpart)) return HITADV_E_ARG;
   RowMlpBwd a{dg, gmask, idx, W3r, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out,
               reinterpret_cast<const unsigned long long *>(pres_in), reinterpret_cast<unsigned long long *>(pres_out), N,
-              Cout};
+              Cout, mode == 2};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 1) {
+  if (mode >= 1) {
     if (stage == 0) rowmlp_bwd16_k<0><<<grid, 256, 0, s>>>(a);
     else if (stage == 1) rowmlp_bwd16_k<1><<<grid, 256, 0, s>>>(a);
     else rowmlp_bwd16_k<2><<<grid, 256, 0, s>>>(a);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
                                                             float *pval, int32_t *pidx, const float *__restrict__ bias,
                                                             int relu, float *__restrict__ out, int64_t *__restrict__ idx,
                                                             int *tickets, int *range_flag) {
-  constexpr int NP = MODE == 1 ? 2 : 3;  // pieces per operand
+  constexpr int NP = MODE >= 1 ? 2 : 3;  // pieces per operand (MODE 2: fp16x2 whose input arrives as packed pieces)
   constexpr int NSL = CIN / 32;          // 32-deep MFMA slices
   constexpr int RS = 2 * CIN + 32;       // bytes per LDS row of one piece: rows 2 x 16 bytes apart mod 256 make the
                                          // 16x16x32 A-fragment reads (lane -> row lane % 16, chunk lane / 16) conflict-free
@@ -124,7 +124,23 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
 #pragma unroll
       for (int i = 0; i < 8; ++i) a[i] = in ? a[i] : 0.f;
       char *dst = sB3 + (size_t)buf * NP * PIECE + (e / G8) * RS + 16 * (e % G8);
-      if constexpr (MODE == 1) {
+      if constexpr (MODE == 2) {
+        // X holds one word per value, (fp16 hi | fp16 lo << 16), written by the layer in front (csrc/pointnet.hip, pack_o2): two
+        // byte permutes per pair of values put the pieces into the two images; rows past the split are zero words
+        const uint32_t wd[8] = {__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]),
+                                __float_as_uint(a[4]), __float_as_uint(a[5]), __float_as_uint(a[6]), __float_as_uint(a[7])};
+        uint4 hi, lo;
+        hi.x = __builtin_amdgcn_perm(wd[1], wd[0], 0x05040100u);
+        lo.x = __builtin_amdgcn_perm(wd[1], wd[0], 0x07060302u);
+        hi.y = __builtin_amdgcn_perm(wd[3], wd[2], 0x05040100u);
+        lo.y = __builtin_amdgcn_perm(wd[3], wd[2], 0x07060302u);
+        hi.z = __builtin_amdgcn_perm(wd[5], wd[4], 0x05040100u);
+        lo.z = __builtin_amdgcn_perm(wd[5], wd[4], 0x07060302u);
+        hi.w = __builtin_amdgcn_perm(wd[7], wd[6], 0x05040100u);
+        lo.w = __builtin_amdgcn_perm(wd[7], wd[6], 0x07060302u);
+        *reinterpret_cast<uint4 *>(dst) = hi;
+        *reinterpret_cast<uint4 *>(dst + PIECE) = lo;
+      } else if constexpr (MODE == 1) {
         f16x8 h1, h2;
         float big = 0.f;
 #pragma unroll
@@ -162,13 +178,13 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   // unit's fragments are read from LDS while this unit's MFMAs run.  Then the scan.
   auto compute = [&](int tile) {
     const char *base = sB3 + (size_t)(tile & 1) * NP * PIECE + l16 * RS + 16 * g4;
-    f32x4b acc[4][2], accl[MODE == 1 ? 4 : 1][2];  // MODE 1: accl collects the 2^-11 terms
+    f32x4b acc[4][2], accl[MODE >= 1 ? 4 : 1][2];  // fp16x2: accl collects the 2^-11 terms
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         acc[rt][ct] = f32x4b{0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == 1) accl[rt][ct] = f32x4b{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE >= 1) accl[rt][ct] = f32x4b{0.f, 0.f, 0.f, 0.f};
       }
     uint4 fa[2][2 * NP];  // [buffer][NP * (row tile within the pair) + piece]
     auto frag = [&](int u, int q) {  // unit u = 2 j + rp
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
       }
       __builtin_amdgcn_sched_barrier(0);  // the reads stay above this unit's MFMAs
       const int j = u >> 1, rp = u & 1;
-      if constexpr (MODE == 1) {
+      if constexpr (MODE >= 1) {
         f16x8 a[2][2], b[2][2];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v = acc[rt][ct][i];
-          if constexpr (MODE == 1) v = fmaf(accl[rt][ct][i], 1.f / F16X2_SCALE, v);  // the two powers of two meet
+          if constexpr (MODE >= 1) v = fmaf(accl[rt][ct][i], 1.f / F16X2_SCALE, v);  // the two powers of two meet
           if (ragged) v = row0 + 16 * rt + i < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
           const bool g = v > tv;
           tv = g ? v : tv;
@@ -427,7 +443,7 @@ static int launch_linear_max_pieces(const float *X, const uint16_t *W3, const fl
   bf3_split(B, N, Cout, blocks, &S, &rows, &cpb);
   const int ncg = (Cout + 255) / 256;
   dim3 grid((unsigned)(ncg * S * ((B + cpb - 1) / cpb)));
-  constexpr int NP = MODE == 1 ? 2 : 3;
+  constexpr int NP = MODE >= 1 ? 2 : 3;
   const size_t shm = (size_t)2 * NP * B3_TM * (2 * Cin + 32);
   if (Cin == 128) {
     static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<128, MODE>),
@@ -451,6 +467,13 @@ extern "C" int hitadv_linear_max_fwd_bf16x3(const float *X, const uint16_t *W3, 
                                             int64_t *idx, int32_t *tickets, void *stream) {
   return launch_linear_max_pieces<0>(X, W3, bias, B, N, Cin, Cout, relu, blocks, part_val, part_idx, out, idx, tickets, nullptr,
                                      stream);
+}
+
+extern "C" int hitadv_linear_max_fwd_f16x2_packed(const uint32_t *Xp, const uint16_t *W2, const float *bias, int B, int N, int Cin,
+                                                  int Cout, int relu, int blocks, float *part_val, int32_t *part_idx, float *out,
+                                                  int64_t *idx, int32_t *tickets, void *stream) {
+  return launch_linear_max_pieces<2>(reinterpret_cast<const float *>(Xp), W2, bias, B, N, Cin, Cout, relu, blocks, part_val,
+                                     part_idx, out, idx, tickets, nullptr, stream);
 }
 
 extern "C" int hitadv_linear_max_fwd_f16x2(const float *X, const uint16_t *W2, const float *bias, int B, int N, int Cin,

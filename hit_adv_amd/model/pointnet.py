@@ -189,7 +189,8 @@ class _PointNetHip(torch.autograd.Function):
         B, _, N = x.shape
         R = B * N
         E = lambda *s: torch.empty(*s, device=x.device)  # noqa: E731
-        cm = 1 if v.matrix_mode == 'fp16x2' else 0  # the shared-layer chains: fp16x2 pieces on the fp16 matrix cores, or f32 MFMA
+        # the shared-layer chains: on the fp16 matrix cores with the 128-wide activations handed on as packed pieces, or f32 MFMA
+        cm, rf = (2, v.range_flag) if v.matrix_mode == 'fp16x2' else (0, None)
         # STN3d
         a1s, a2s = E(R, 64), E(R, 128)
         def lin_max(a, name, relu):
@@ -200,16 +201,16 @@ class _PointNetHip(torch.autograd.Function):
                                                  blocks=v.linear_max_blocks)
             if v.matrix_mode == 'fp16x2':
                 return ops.linear_max_fwd_f16x2(a, v.pieces(name, 2), B, N, bias=getattr(v, name + '_b'), relu=relu,
-                                                blocks=v.linear_max_blocks, range_flag=v.range_flag)
+                                                blocks=v.linear_max_blocks, range_flag=v.range_flag, packed=True)
             return ops.linear_max_fwd(a, getattr(v, name + '_w'), B, N, bias=getattr(v, name + '_b'), relu=relu)
 
         if v.deform_inputs is not None:  # x is an OUTPUT of the first kernel: the caller's deformation, evaluated inside
             ori, central, P, sigma, inv_den = v.deform_inputs
             v.deform_inputs = None  # consumed: the caller checks this
             ops.pointnet_rowmlp_fwd_deform(B, N, ori, central, P, sigma, x, inv_den, v.s1_w, v.s1_b, v.s2_w, v.s2_b, a1s, a2s,
-                                           mode=cm)
+                                           mode=cm, range_flag=rf)
         else:
-            ops.pointnet_rowmlp_fwd(0, B, N, v.s2_w, v.s2_b, a2s, x=x, W0=v.s1_w, b0=v.s1_b, o0=a1s, mode=cm)
+            ops.pointnet_rowmlp_fwd(0, B, N, v.s2_w, v.s2_b, a2s, x=x, W0=v.s1_w, b0=v.s1_b, o0=a1s, mode=cm, range_flag=rf)
         gs, js = lin_max(a2s, 's3', True)
         f4s = ops.fc_layer(gs, v.s4_w, v.s4_b, relu=True)
         f5s = ops.fc_layer(f4s, v.s5_w, v.s5_b, relu=True)
@@ -218,18 +219,18 @@ class _PointNetHip(torch.autograd.Function):
         if v.fold_small_layers:
             T3 = E(B, 9)
             ops.pointnet_rowmlp_fwd_stn(B, N, x, f5s, v.s6_w, v.s6_b, T3, v.e1_w, v.e1_b, v.t1_w, v.t1_b, v.t2_w, v.t2_b,
-                                        h1, a1t, a2t, mode=cm)
+                                        h1, a1t, a2t, mode=cm, range_flag=rf)
         else:
             T3 = ops.fc_layer(f5s, v.s6_w, v.s6_b)
             ops.pointnet_rowmlp_fwd(1, B, N, v.t2_w, v.t2_b, a2t, x=x, T=T3, W0=v.e1_w, b0=v.e1_b, W1=v.t1_w, b1=v.t1_b,
-                                    o0=h1, o1=a1t, mode=cm)
+                                    o0=h1, o1=a1t, mode=cm, range_flag=rf)
         gt, jt = lin_max(a2t, 't3', True)
         f4t = ops.fc_layer(gt, v.t4_w, v.t4_b, relu=True)
         f5t = ops.fc_layer(f4t, v.t5_w, v.t5_b, relu=True)
         T64 = ops.fc_layer(f5t, v.t6_w, v.t6_b)
         # feature transform, encoder tail, classifier head
         a2e = E(R, 128)
-        ops.pointnet_rowmlp_fwd(2, B, N, v.e2_w, v.e2_b, a2e, T=T64, hin=h1, mode=cm)
+        ops.pointnet_rowmlp_fwd(2, B, N, v.e2_w, v.e2_b, a2e, T=T64, hin=h1, mode=cm, range_flag=rf)
         g, je = lin_max(a2e, 'e3', False)
         f1 = ops.fc_layer(g, v.h1_w, v.h1_b, relu=True)
         f2 = ops.fc_layer(f1, v.h2_w, v.h2_b, relu=True)
@@ -264,7 +265,7 @@ class _PointNetHip(torch.autograd.Function):
         # which points of a tile receive any gradient: handed from stage to stage, each stage works on those rows only
         pres2 = torch.empty(B, tiles, device=x.device, dtype=torch.int64)
         pres1 = torch.empty(B, tiles, device=x.device, dtype=torch.int64)
-        cm = 1 if v.matrix_mode == 'fp16x2' else 0
+        cm = 2 if v.matrix_mode == 'fp16x2' else 0  # the mode the forward pass ran in (2: a2* hold packed pieces)
         ops.pointnet_rowmlp_bwd(2, B, N, dg, je, v.e3_wr, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp, pres_out=pres2, mode=cm)
         dT64 = ops.sum_partials(dTp, None if dT64_ext is None else dT64_ext.reshape(B, 4096).contiguous())
         # STNkd, first encoder layer, input transform

@@ -587,7 +587,7 @@ def split_weights_f16x2(Wr, out=None, range_flag=None):
     return out
 
 
-def linear_max_fwd_f16x2(x, W2, B, N, bias=None, relu=False, blocks=0, range_flag=None):
+def linear_max_fwd_f16x2(x, W2, B, N, bias=None, relu=False, blocks=0, range_flag=None, packed=False):
     """``linear_max_fwd`` on the fp16 matrix cores: two pieces per operand, three exact products per useful one, fp32
     accumulators (csrc/victim_bf3.hip, MODE 1) -- half the matrix time of the bf16x3 form, errors at fp32's own roundoff
     level.  W2 = split_weights_f16x2(Wt.t()).  ``range_flag``: int32[1] on the device, raised (never cleared) when an
@@ -604,6 +604,10 @@ def linear_max_fwd_f16x2(x, W2, B, N, bias=None, relu=False, blocks=0, range_fla
     out = torch.empty(B, Cout, device=x.device)
     idx = torch.empty(B, Cout, device=x.device, dtype=torch.int64)
     tickets = _fc_scratch_for(x, 1 << 14)
+    if packed:  # x holds packed pieces (one 32-bit word per value, written by pointnet_rowmlp_fwd(mode=2)): nothing to split
+        _lib.call("hitadv_linear_max_fwd_f16x2_packed", _p(x), _p(W2), _p(bias), B, N, Cin, Cout, 1 if relu else 0, int(blocks),
+                  _p(pv), _p(pi), _p(out), _p(idx), _p(tickets), _stream())
+        return out, idx
     _lib.call("hitadv_linear_max_fwd_f16x2", _p(x), _p(W2), _p(bias), B, N, Cin, Cout, 1 if relu else 0, int(blocks), _p(pv),
               _p(pi), _p(out), _p(idx), _p(tickets), _p(range_flag), _stream())
     return out, idx
@@ -651,28 +655,29 @@ def sum_partials(part, extra=None):
 
 
 def pointnet_rowmlp_fwd(stage, B, N, W2, b2, o2, x=None, T=None, hin=None, W0=None, b0=None, W1=None, b1=None,
-                        xp=None, o0=None, o1=None, mode=0):
-    """``mode`` 1: the layer products on the fp16 matrix cores, two pieces per operand (include/hitadv.h)."""
+                        xp=None, o0=None, o1=None, mode=0, range_flag=None):
+    """``mode`` 1: the layer products on the fp16 matrix cores, two pieces per operand; 2: the same with ``o2`` written as
+    packed pieces for ``linear_max_fwd_f16x2(..., packed=True)`` (include/hitadv.h)."""
     _lib.call("hitadv_pointnet_rowmlp_fwd", stage, _p(x), _p(T), _p(hin), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2),
-              _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, int(mode), _stream())
+              _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, int(mode), _p(range_flag), _stream())
 
 
-def pointnet_rowmlp_fwd_stn(B, N, x, F5, W6, b6, Tout, W0, b0, W1, b1, W2, b2, o0, o1, o2, xp=None, mode=0):
+def pointnet_rowmlp_fwd_stn(B, N, x, F5, W6, b6, Tout, W0, b0, W1, b1, W2, b2, o0, o1, o2, xp=None, mode=0, range_flag=None):
     """Stage 1 of the forward chain with STN3d's last layer (F5 [B,256] @ W6 [256,9] + b6 -> Tout [B,9]) evaluated inside."""
     if F5.shape[1] != 256 or tuple(W6.shape) != (256, 9):
         raise ValueError("the fused input transform is the 256 -> 9 layer")
     _lib.call("hitadv_pointnet_rowmlp_fwd_stn", _p(x), _p(F5), _p(W6), _p(b6), _p(Tout), _p(W0), _p(b0), _p(W1), _p(b1),
-              _p(W2), _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, int(mode), _stream())
+              _p(W2), _p(b2), _p(xp), _p(o0), _p(o1), _p(o2), B, N, int(mode), _p(range_flag), _stream())
 
 
-def pointnet_rowmlp_fwd_deform(B, N, ori, central, perturb, sigma, adv, inv_den, W0, b0, W2, b2, o0, o2, mode=0):
+def pointnet_rowmlp_fwd_deform(B, N, ori, central, perturb, sigma, adv, inv_den, W0, b0, W2, b2, o0, o2, mode=0, range_flag=None):
     """Stage 0 of the forward chain on HiT-ADV's deformation of ``ori``, evaluated inside (``adv`` and ``inv_den`` are
     OUTPUTS: what ``deform_fwd_into`` writes)."""
     C = sigma.shape[1]
     if C > 256:
         raise ValueError("the fused deformation holds at most 256 centres")
     _lib.call("hitadv_pointnet_rowmlp_fwd_deform", _p(ori), _p(central), _p(perturb), _p(sigma), C, _p(adv), _p(inv_den),
-              _p(W0), _p(b0), _p(W2), _p(b2), _p(o0), _p(o2), B, N, int(mode), _stream())
+              _p(W0), _p(b0), _p(W2), _p(b2), _p(o0), _p(o2), B, N, int(mode), _p(range_flag), _stream())
 
 
 def pointnet_rowmlp_bwd(stage, B, N, dg, idx, W3r, A2, W2r, out, gmask=None, A1=None, W1r=None, H1=None, dH1in=None,

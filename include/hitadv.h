@@ -297,6 +297,10 @@ int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout, int blocks)
  * point when an operand lies beyond that (or is NaN); results are then meaningless and the caller must fall back to the
  * bf16x3 / f32 form.  Scratch: hitadv_linear_max_fwd_bf16x3_scratch with the same `blocks`. */
 int hitadv_split_weights_f16x2(const float *W, int Cout, int Cin, uint16_t *W2, int32_t *range_flag, void *stream);
+/* ... and with X already in packed pieces (Xp [B*N, Cin] uint32, see hitadv_pointnet_rowmlp_fwd mode 2). */
+int hitadv_linear_max_fwd_f16x2_packed(const uint32_t *Xp, const uint16_t *W2, const float *bias, int B, int N, int Cin, int Cout,
+                                       int relu, int blocks, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
+                                       int32_t *tickets, void *stream);
 int hitadv_linear_max_fwd_f16x2(const float *X, const uint16_t *W2, const float *bias, int B, int N, int Cin, int Cout,
                                 int relu, int blocks, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
                                 int32_t *tickets, int32_t *range_flag, void *stream);
@@ -318,24 +322,30 @@ int hitadv_linear_max_fwd_f16x2(const float *X, const uint16_t *W2, const float 
  * `mode` (all three forward entry points and the backward one): 0 = the products on the f32 matrix cores (an exact fp32 FMA
  * chain per output), 1 = on the fp16 matrix cores with every operand as two fp16 pieces and three exact products per useful
  * one (the scheme of hitadv_linear_max_fwd_f16x2: 5.3x less matrix time, errors at fp32's unit roundoff; the 3 -> 64 and
- * 64 -> 3 layers and the transforms' 3x3 products stay exact f32 on the VALU). */
+ * 64 -> 3 layers and the transforms' 3x3 products stay exact f32 on the VALU); 2 = mode 1 with the 128-wide activation o2 / A2
+ * held as PACKED PIECES, one 32-bit word per value (fp16 hi | fp16 lo << 16, lo = the residual scaled by 2^11): what
+ * hitadv_linear_max_fwd_f16x2_packed consumes without splitting anything (the split is otherwise redone by each of its four
+ * column-group blocks) and what the backward chain reads as that layer's ReLU mask (word != 0).  range_flag (forward entry
+ * points, may be NULL) is raised by a value beyond fp16's range in mode 2. */
 int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const float *hin, const float *W0,
                                const float *b0, const float *W1, const float *b1, const float *W2, const float *b2,
-                               float *xp, float *o0, float *o1, float *o2, int B, int N, int mode, void *stream);
+                               float *xp, float *o0, float *o1, float *o2, int B, int N, int mode, int32_t *range_flag,
+                               void *stream);
 /* Number of 64-point tiles per cloud = leading dimension of the dTpart scratch below. */
 /* Stage 0 whose input IS HiT-ADV's deformation (hitadv_deform_fwd, ShapeAttack/HiT_ADV.py:160-175) of `ori`: every block
  * deforms its 64 points itself (C <= 256 centres), writes them to adv [B,3,N] and 1 / sum_j k to inv_den [B,N] -- what
  * hitadv_deform_fwd writes, bit for bit -- and goes on with them as hitadv_pointnet_rowmlp_fwd(stage = 0, x = adv). */
 int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *central, const float *perturb, const float *sigma,
                                       int C, float *adv, float *inv_den, const float *W0, const float *b0, const float *W2,
-                                      const float *b2, float *o0, float *o2, int B, int N, int mode, void *stream);
+                                      const float *b2, float *o0, float *o2, int B, int N, int mode, int32_t *range_flag,
+                                      void *stream);
 /* Stage 1 with the input transform evaluated inside: T3[b] = F5[b,:256] @ W6[256,9] + b6 (STN3d's last layer, :186-190,
  * the identity folded into b6) is computed by every block of the cloud (2304 multiply-adds, fixed order) and written to
  * Tout [B,9] for the backward pass; everything else as hitadv_pointnet_rowmlp_fwd(stage = 1, T = Tout). */
 int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, const float *W6, const float *b6, float *Tout,
                                    const float *W0, const float *b0, const float *W1, const float *b1, const float *W2,
                                    const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N, int mode,
-                                   void *stream);
+                                   int32_t *range_flag, void *stream);
 int64_t hitadv_pointnet_rowmlp_tiles(int N);
 /* Input-gradient chain of the same stages, starting at the max-pooled output of the stage's 128->Cout layer:
  * dg [B,Cout] is the gradient there, idx [B,Cout] the arg-max point of every channel (hitadv_linear_max_fwd),
