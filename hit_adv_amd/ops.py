@@ -808,12 +808,13 @@ class GroupLinearMax(torch.autograd.Function):
     are constants (the folded eval-mode layer); the gradient goes to ``x`` only."""
 
     @staticmethod
-    def forward(ctx, x, Wr, bias, range_flag):
+    def forward(ctx, x, Wr, bias, range_flag, W2=None, Wb2=None):
         x = _dev(x, "x")
         G, ns, Cin = x.shape
         Cout = Wr.shape[0]
-        W2 = split_weights_f16x2(Wr.contiguous(), range_flag=range_flag)               # forward operand
-        Wb2 = split_weights_f16x2(Wr.t().contiguous(), range_flag=range_flag)           # backward operand: pieces of Wt [Cin,Cout]
+        if W2 is None:
+            W2 = split_weights_f16x2(Wr.contiguous(), range_flag=range_flag)            # forward operand
+            Wb2 = split_weights_f16x2(Wr.t().contiguous(), range_flag=range_flag)        # backward operand: pieces of Wt [Cin,Cout]
         out = torch.empty(G, Cout, device=x.device)
         arg = torch.empty(G, Cout, device=x.device, dtype=torch.int32)
         _lib.call("hitadv_group_linear_max_fwd", _p(x), _p(W2), _p(bias), G, ns, Cin, Cout, _p(out), _p(arg), _p(range_flag),
@@ -831,13 +832,14 @@ class GroupLinearMax(torch.autograd.Function):
         dX = torch.empty(G, ns, Cin, device=out.device)
         _lib.call("hitadv_group_linear_max_bwd", _p(g.contiguous()), _p(out), _p(arg), _p(Wb2), G, ns, Cin, Cout, _p(dX),
                   _p(ctx.range_flag), _stream())
-        return dX, None, None, None
+        return dX, None, None, None, None, None
 
 
-def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False):
+def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False, pieces=None):
     """x [..., ns, Cin] -> relu(max over the ns rows of (x W^T + bias)) [..., Cout]; see ``GroupLinearMax``."""
     lead = x.shape[:-2]
-    out, arg = GroupLinearMax.apply(x.reshape(-1, x.shape[-2], x.shape[-1]), Wr, bias, range_flag)
+    W2, Wb2 = pieces if pieces is not None else (None, None)  # ``pieces``: (split_weights_f16x2(Wr), split_weights_f16x2(Wr.t())) kept by the caller
+    out, arg = GroupLinearMax.apply(x.reshape(-1, x.shape[-2], x.shape[-1]), Wr, bias, range_flag, W2, Wb2)
     out = out.view(*lead, out.shape[-1])
     return (out, arg.view(*lead, arg.shape[-1])) if return_arg else out
 

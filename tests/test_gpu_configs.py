@@ -236,8 +236,8 @@ def test_pct_gradient_vs_float64_module_on_the_same_tables():
     winners, pre_pool = [], []
     real_max, real_pool, real_group = torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max
 
-    def spy_group(xx, Wr, bias, flag=None, return_arg=False):  # Local_op's last layer + max over the neighbours, fused
-        out, arg = real_group(xx, Wr, bias, flag, return_arg=True)
+    def spy_group(xx, Wr, bias, flag=None, return_arg=False, **kw):  # Local_op's last layer + max over the neighbours, fused
+        out, arg = real_group(xx, Wr, bias, flag, return_arg=True, **kw)
         winners.append(arg.detach().cpu().long())
         return (out, arg) if return_arg else out
 
