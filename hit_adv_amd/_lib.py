@@ -51,6 +51,12 @@ PROTOTYPES = {
     "hitadv_group_linear_max_supported": [_I, _I, _I],
     "hitadv_group_linear_max_fwd": [_P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_group_linear_max_bwd": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P],
+    "hitadv_gemm_f16x2_supported": [_I, _I],
+    "hitadv_split_rows_f16x2": [_P, _I, _I, _P, _P, _P],
+    "hitadv_gemm_f16x2": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P],
+    "hitadv_linear_lrelu_pool_scratch": [_I, _I, _I],
+    "hitadv_linear_lrelu_pool_fwd": [_P, _P, _P, _I, _I, _I, _I, _c.c_float, _P, _P, _P, _P, _P, _P, _P, _P],
+    "hitadv_linear_lrelu_pool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _P, _P, _P],
     "hitadv_iteration_head_reg_stack": [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P,
                                         _P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "hitadv_deform_bwd_partials_reg_stack": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _P],
@@ -98,7 +104,8 @@ PROTOTYPES = {
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,
             "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_linear_max_fwd_scratch": _c.c_int64, "hitadv_linear_max_fwd_bf16x3_scratch": _c.c_int64, "hitadv_pointnet_rowmlp_tiles": _c.c_int64, "hitadv_fc_layer_scratch_floats": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64,
-            "hitadv_edge_max_bwd_scratch_ints": _c.c_int64, "hitadv_iteration_head_scratch_floats": _c.c_int64, "hitadv_deform_bwd_slabs": _c.c_int64, "hitadv_group_add_relu_bwd_scratch_ints": _c.c_int64}
+            "hitadv_edge_max_bwd_scratch_ints": _c.c_int64, "hitadv_iteration_head_scratch_floats": _c.c_int64, "hitadv_deform_bwd_slabs": _c.c_int64, "hitadv_group_add_relu_bwd_scratch_ints": _c.c_int64,
+            "hitadv_linear_lrelu_pool_scratch": _c.c_int64}
 
 _lib = None
 

@@ -1,0 +1,453 @@
+// fp32-accurate GEMMs on the fp16 matrix cores for the victims' wide 1x1 convolutions, and DGCNN's embedding layer fused
+// with its activation and poolings (model/dgcnn_cls.py:63-64,101-104: conv5 -> bn5 -> LeakyReLU(0.2) -> adaptive_max_pool1d
+// | adaptive_avg_pool1d -> cat) -- forward and input gradient.
+//
+// Arithmetic: V1's fp16x2 scheme (csrc/victim_bf3.hip): every operand is two fp16 pieces, a = a1 + 2^-11 a2 (+ <= 2^-24 |a|),
+// three exact fp16 x fp16 products per useful one accumulate in fp32 (v_mfma_f32_16x16x32_f16) into two accumulator sets
+// (one per power of two), joined once by fmaf.  Error against float64: below the library's f32 GEMM (tools/split_gemm_probe.py:
+// 3.6e-7 against 1.0e-6 of the scale at K = 512), at 2-3x its speed: hipBLASLt's f32 GEMM runs at the f32 MFMA rate (120-140
+// TFLOP/s measured here), this kernel executes three times the flop at ~8x the rate.
+//
+//   gemm_f16x2_k<AProd, Epi>   C-tile 256 x 128 per block of 8 waves (4 x 2, a wave owns 64 x 64 = 16 MFMA tiles x 2 accumulator
+//                              sets = 128 VGPRs), K in steps of 32 (one MFMA slice) through a two-stage LDS ring: the A operand
+//                              is PRODUCED by a functor (plain rows; rows gated by a ReLU mask; DGCNN's pooled gradient rebuilt
+//                              from a sign bit mask and the pooled gradients) and split into pieces on the way into LDS, the B
+//                              operand are weight pieces split once per weight ([2][N][K] fp16).  One barrier per K step.
+//   LDS rows are dense (64 bytes = four 16-byte chunks) with the chunks of row r stored at position c ^ g[(r >> 2) & 3],
+//   g = {0, 2, 3, 1}: a ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md,
+//   LDS) -- i.e. the rows 0-3 and 12-15 of a 16-row fragment at one chunk and the rows 4-11 at the next; with this swizzle each
+//   group touches the sixteen 16-byte slots of the 256-byte bank row once.  Unswizzled 80-byte rows: 2-way conflicts.
+//   Block order is XCD-aware: the column blocks that stream the same A rows are neighbours on one XCD (shared L2).
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "hitadv.h"
+
+namespace hitadv {
+
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8m as_f16x8m(uint4 u) { return __builtin_bit_cast(f16x8m, u); }
+
+constexpr int G16_BM = 256, G16_BN = 128, G16_KS = 32, G16_RS = 64;
+constexpr int G16_APIECE = G16_BM * G16_RS;
+constexpr int G16_BPIECE = G16_BN * G16_RS;
+constexpr int G16_STAGE = 2 * G16_APIECE + 2 * G16_BPIECE;  // 61,440 bytes; two stages
+constexpr float G16_SCALE = 2048.f;
+// byte offset of 16-byte chunk c of LDS row r (see the header)
+__device__ __forceinline__ int g16_off(int r, int c) { return r * G16_RS + 16 * (c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)); }
+#ifndef HITADV_G16_WR
+#define HITADV_G16_WR 4
+#endif
+
+struct G16Tile {
+  int b;          // cloud (plain GEMM: 0)
+  int p0;         // first point of the block within the cloud
+  long long row0; // its global row
+  int rows;       // valid rows in the block (<= 256)
+  int rb;         // row-block index (b * chunks + chunk)
+  int col0;       // first output column
+};
+
+// ---------------------------------------------------------------------------------------------- A producers
+// fetch() only issues global loads (clamped, never conditional); values() turns the registers into the four floats of slot u.
+// Slot u of thread t: row rr = (t >> 3) + 64 u of the block, k = k0 + 4 (t & 7) .. + 3.
+template <bool GATED, int U>
+struct PlainA {
+  static constexpr int RSTEP = G16_BM / U;
+  const float *X, *mask;
+  int K;
+  struct Regs {
+    float4 v[U];
+    float4 m[GATED ? U : 1];
+  };
+  __device__ __forceinline__ void fetch(Regs &r, const G16Tile &t, int k0, int tid) const {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = min((tid >> 3) + RSTEP * u, t.rows - 1);
+      const size_t o = (size_t)(t.row0 + rr) * K + k0 + 4 * (tid & 7);
+      r.v[u] = *reinterpret_cast<const float4 *>(X + o);
+      if constexpr (GATED) r.m[u] = *reinterpret_cast<const float4 *>(mask + o);
+    }
+  }
+  __device__ __forceinline__ void values(const Regs &r, const G16Tile &t, int u, int tid, float (&o)[4]) const {
+    const bool in = (tid >> 3) + RSTEP * u < t.rows;
+    o[0] = r.v[u].x, o[1] = r.v[u].y, o[2] = r.v[u].z, o[3] = r.v[u].w;
+    if constexpr (GATED) {
+      o[0] = r.m[u].x > 0.f ? o[0] : 0.f;
+      o[1] = r.m[u].y > 0.f ? o[1] : 0.f;
+      o[2] = r.m[u].z > 0.f ? o[2] : 0.f;
+      o[3] = r.m[u].w > 0.f ? o[3] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = in ? o[j] : 0.f;
+  }
+};
+
+// d z[p,c] of  out = [max_p h | mean_p h],  h = lrelu(z):  s(z[p,c]) (gmean[b,c] / N + [arg[b,c] == p] gmax[b,c]),
+// s = 1 where the forward pass saw z > 0 (its bit mask), the slope elsewhere.  K = C (the layer's output channels).
+template <int U>
+struct PoolBwdA {
+  static constexpr int RSTEP = G16_BM / U;
+  const uint32_t *bits;  // [rows][C / 32]
+  const float *gout;     // [B][2 C]: d out, max half then mean half
+  const int32_t *arg;    // [B][C]
+  int C;
+  float slope, inv_n;
+  struct Regs {
+    float4 gx, gm;
+    int4 ar;
+    uint32_t w[U];
+  };
+  __device__ __forceinline__ void fetch(Regs &r, const G16Tile &t, int k0, int tid) const {
+    const int c = k0 + 4 * (tid & 7);
+    r.gx = *reinterpret_cast<const float4 *>(gout + (size_t)t.b * 2 * C + c);
+    r.gm = *reinterpret_cast<const float4 *>(gout + (size_t)t.b * 2 * C + C + c);
+    r.ar = *reinterpret_cast<const int4 *>(arg + (size_t)t.b * C + c);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = min((tid >> 3) + RSTEP * u, t.rows - 1);
+      r.w[u] = bits[(size_t)(t.row0 + rr) * (C / 32) + (k0 >> 5)];
+    }
+  }
+  __device__ __forceinline__ void values(const Regs &r, const G16Tile &t, int u, int tid, float (&o)[4]) const {
+    const int rr = (tid >> 3) + RSTEP * u;
+    const bool in = rr < t.rows;
+    const int p = t.p0 + rr;
+    const uint32_t w = r.w[u] >> (4 * (tid & 7));
+    const float gx[4] = {r.gx.x, r.gx.y, r.gx.z, r.gx.w}, gm[4] = {r.gm.x, r.gm.y, r.gm.z, r.gm.w};
+    const int ar[4] = {r.ar.x, r.ar.y, r.ar.z, r.ar.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = gm[j] * inv_n + (ar[j] == p ? gx[j] : 0.f);
+      const float s = ((w >> j) & 1u) ? 1.f : slope;
+      o[j] = in ? s * g : 0.f;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------- epilogues
+// A wave's accumulators: acc[rt][ct][i] = row 16 RT wr + 16 rt + 4 (lane / 16) + i, column 64 wc + 16 ct + lane % 16 of the block
+// (RT row tiles per wave: 4 with eight waves per block, 8 with four).
+struct PlainEpi {
+  float *C;
+  const float *bias;
+  int N, relu;
+  template <int RT>
+  __device__ __forceinline__ void operator()(const G16Tile &t, f32x4m (&acc)[RT][4], int wr, int wc, int lane, char *) const {
+    const int l16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int col = t.col0 + 64 * wc + 16 * ct + l16;
+      const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = 16 * RT * wr + 16 * rt + 4 * g4 + i;
+          float v = acc[rt][ct][i] + bv;
+          v = relu ? fmaxf(v, 0.f) : v;
+          if (rr < t.rows) C[(size_t)(t.row0 + rr) * N + col] = v;
+        }
+    }
+  }
+};
+
+// z = acc + bias;  bits: z > 0;  h = lrelu(z);  per column the block's max (lowest row on ties) and sum of h -> partials.
+struct PoolEpi {
+  const float *bias;
+  uint16_t *bits;   // [rows][C / 16] (= uint32 [rows][C / 32], little endian)
+  float *pmax, *psum;
+  int32_t *parg;    // [row blocks][C]
+  int C;
+  float slope;
+  template <int RT>
+  __device__ __forceinline__ void operator()(const G16Tile &t, f32x4m (&acc)[RT][4], int wr, int wc, int lane, char *lds) const {
+    constexpr int WR = 16 / RT;
+    const int l16 = lane & 15, g4 = lane >> 4;
+    float *rmax = reinterpret_cast<float *>(lds);            // [WR][128]
+    float *rsum = rmax + WR * G16_BN;
+    int *rarg = reinterpret_cast<int *>(rsum + WR * G16_BN);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int colb = 64 * wc + 16 * ct + l16;
+      const float bv = bias[t.col0 + colb];
+      float best = -__builtin_inff(), sum = 0.f;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rr = 16 * RT * wr + 16 * rt + 4 * g4 + i;
+          const float z = acc[rt][ct][i] + bv;
+          const bool pos = z > 0.f;
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(pos);
+          if (l16 == 0 && rr < t.rows)
+            bits[(size_t)(t.row0 + rr) * (C / 16) + ((t.col0 + 64 * wc + 16 * ct) >> 4)] = (uint16_t)(bal >> (16 * g4));
+          const float h = pos ? z : slope * z;
+          const bool in = rr < t.rows;
+          sum += in ? h : 0.f;
+          if (in && h > best) best = h, bi = t.p0 + rr;
+        }
+      // the four lane groups hold interleaved rows of the same column: (value, lowest row) and the sum in a fixed order
+#pragma unroll
+      for (int m = 16; m <= 32; m <<= 1) {
+        const float ov = __shfl_xor(best, m, 64), os = __shfl_xor(sum, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+        sum = (lane & m) ? os + sum : sum + os;
+      }
+      if (g4 == 0) rmax[wr * G16_BN + colb] = best, rsum[wr * G16_BN + colb] = sum, rarg[wr * G16_BN + colb] = bi;
+    }
+    __syncthreads();
+    if (wr == 0 && g4 == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int colb = 64 * wc + 16 * ct + l16;
+        float best = rmax[colb], sum = rsum[colb];
+        int bi = rarg[colb];
+#pragma unroll
+        for (int w = 1; w < WR; ++w) {  // ascending rows: strict > keeps the lowest row
+          const float ov = rmax[w * G16_BN + colb];
+          if (ov > best) best = ov, bi = rarg[w * G16_BN + colb];
+          sum += rsum[w * G16_BN + colb];
+        }
+        const size_t o = (size_t)t.rb * C + t.col0 + colb;
+        pmax[o] = best, psum[o] = sum, parg[o] = bi;
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------- the kernel
+template <int WR, class AProd, class Epi, bool SYNC_EPI>
+__global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_t *__restrict__ Wp, int npts, int chunks, int nrb,
+                                                         int ncb, int N, int K, Epi epi, int *range_flag) {
+  constexpr int NT = WR * 128;       // threads: WR x 2 waves
+  constexpr int RT = 16 / WR;        // 16-row MFMA tiles per wave: 4 (64 x 64 per wave, two waves per SIMD) or 8 (128 x 64, one)
+  constexpr int U = 2048 / NT;       // A slots (four consecutive k of one row) per thread and K step
+  constexpr int V = 512 / NT;        // B chunks (eight consecutive k of one column, per piece) per thread and K step
+  extern __shared__ __attribute__((aligned(16))) char sG16[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l16 = lane & 15, g4 = lane >> 4;
+  G16Tile t;
+  {
+    int rb, cb;
+    const int id = blockIdx.x;
+    if ((nrb & 7) == 0) {
+      const int xcd = id & 7, slot = id >> 3;
+      cb = slot % ncb;
+      rb = (slot / ncb) * 8 + xcd;
+    } else {
+      cb = id % ncb;
+      rb = id / ncb;
+    }
+    t.rb = rb;
+    t.b = rb / chunks;
+    t.p0 = (rb % chunks) * G16_BM;
+    t.row0 = (long long)t.b * npts + t.p0;
+    t.rows = min(G16_BM, npts - t.p0);
+    t.col0 = cb * G16_BN;
+  }
+  const int nk = K / G16_KS;
+
+  // Operands travel global -> registers -> (split) -> LDS: the loads of K step s + 1 are issued at the top of step s and written
+  // to the other LDS stage after the step's MFMAs.  (A second register set with the loads two steps ahead and the two waves of
+  // a SIMD staggered, as in csrc/victim_bf3.hip, was measured: 177 -> 188 us at 32768 x 512 x 1024, it spills.)
+  struct Set {
+    typename AProd::Regs a;
+    uint4 b[V][2];
+  };
+  Set s0;
+  // B: 128 columns x 4 sixteen-byte chunks per piece; chunk e = tid + NT v -> column e >> 2, chunk e & 3
+  const uint16_t *bsrc = Wp + (size_t)(t.col0 + (tid >> 2)) * K + 8 * (tid & 3);
+  auto fetch = [&](Set &st, int ks) {
+    ap.fetch(st.a, t, ks * G16_KS, tid);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const uint16_t *bp = bsrc + (size_t)(NT / 4) * v * K + ks * G16_KS;
+      st.b[v][0] = *reinterpret_cast<const uint4 *>(bp);
+      st.b[v][1] = *reinterpret_cast<const uint4 *>(bp + (size_t)N * K);
+    }
+  };
+  float big = 0.f;
+  auto stash = [&](const Set &st, int stage) {
+    char *base = sG16 + (size_t)stage * G16_STAGE;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float a[4];
+      ap.values(st.a, t, u, tid, a);
+      f16x4m h1, h2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h1[j] = (_Float16)a[j];
+        h2[j] = (_Float16)((a[j] - (float)h1[j]) * G16_SCALE);
+        big = fmaxf(big, fabsf(a[j]));
+      }
+      char *dst = base + g16_off((tid >> 3) + (NT / 8) * u, (tid & 7) >> 1) + 8 * (tid & 1);
+      *reinterpret_cast<uint2 *>(dst) = __builtin_bit_cast(uint2, h1);
+      *reinterpret_cast<uint2 *>(dst + G16_APIECE) = __builtin_bit_cast(uint2, h2);
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      char *bd = base + 2 * G16_APIECE + g16_off((tid >> 2) + (NT / 4) * v, tid & 3);
+      *reinterpret_cast<uint4 *>(bd) = st.b[v][0];
+      *reinterpret_cast<uint4 *>(bd + G16_BPIECE) = st.b[v][1];
+    }
+  };
+
+  f32x4m acc[RT][4], accl[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f}, accl[rt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int ks) {
+    const char *base = sG16 + (size_t)(ks & 1) * G16_STAGE;
+    // rows 16 x + l16: (row >> 2) & 3 = (l16 >> 2) & 3 for every 16-row tile, so one swizzled offset serves all of them
+    const char *ab = base + 16 * RT * wr * G16_RS + g16_off(l16, g4);
+    const char *bb = base + 2 * G16_APIECE + 64 * wc * G16_RS + g16_off(l16, g4);
+    uint4 fb[4][2];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      fb[ct][0] = *reinterpret_cast<const uint4 *>(bb + 16 * ct * G16_RS);
+      fb[ct][1] = *reinterpret_cast<const uint4 *>(bb + 16 * ct * G16_RS + G16_BPIECE);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const f16x8m ahi = as_f16x8m(*reinterpret_cast<const uint4 *>(ab + 16 * rt * G16_RS));
+      const f16x8m alo = as_f16x8m(*reinterpret_cast<const uint4 *>(ab + 16 * rt * G16_RS + G16_APIECE));
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        accl[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, as_f16x8m(fb[ct][0]), accl[rt][ct], 0, 0, 0);
+        accl[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, as_f16x8m(fb[ct][1]), accl[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, as_f16x8m(fb[ct][0]), acc[rt][ct], 0, 0, 0);
+      }
+    }
+  };
+  fetch(s0, 0);
+  stash(s0, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    __syncthreads();  // stage ks & 1 (written during step ks - 1) is complete; the other stage is no longer being read
+    // requested AFTER the barrier: __syncthreads() waits for every load in flight, and these have the whole matrix phase to land
+    if (ks + 1 < nk) fetch(s0, ks + 1);
+    compute(ks);
+    if (ks + 1 < nk) stash(s0, (ks + 1) & 1);
+  }
+  if (!(big < 65504.f) && range_flag != nullptr) *range_flag = 1;  // beyond fp16 (or NaN): the caller refuses the result
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[rt][ct][i] = fmaf(accl[rt][ct][i], 1.f / G16_SCALE, acc[rt][ct][i]);
+  if constexpr (SYNC_EPI) __syncthreads();  // the epilogue reuses the LDS ring
+  epi.template operator()<RT>(t, acc, wr, wc, lane, sG16);
+}
+
+// out[b] = [max over the cloud's row blocks | sum / n], arg = the row of the max (lowest on ties: blocks ascend)
+__global__ void pool_merge_k(const float *__restrict__ pmax, const float *__restrict__ psum, const int32_t *__restrict__ parg,
+                             int B, int chunks, int C, float inv_n, float *__restrict__ out, int32_t *__restrict__ arg) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int b = e / C, c = e % C;
+  float best = -__builtin_inff(), sum = 0.f;
+  int bi = 0;
+  for (int k = 0; k < chunks; ++k) {
+    const size_t o = (size_t)(b * chunks + k) * C + c;
+    const float v = pmax[o];
+    if (v > best) best = v, bi = parg[o];
+    sum += psum[o];
+  }
+  out[(size_t)b * 2 * C + c] = best;
+  out[(size_t)b * 2 * C + C + c] = sum * inv_n;
+  arg[(size_t)b * C + c] = bi;
+}
+
+// W [N][K] fp32 -> pieces [2][N][K] fp16
+__global__ void split_rows_f16x2_k(const float *__restrict__ W, uint16_t *__restrict__ Wp, long long total, int *range_flag) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const float a = W[e];
+  const _Float16 h1 = (_Float16)a;
+  const _Float16 h2 = (_Float16)((a - (float)h1) * G16_SCALE);
+  Wp[e] = __builtin_bit_cast(uint16_t, h1);
+  Wp[total + e] = __builtin_bit_cast(uint16_t, h2);
+  if (!(fabsf(a) < 65504.f) && range_flag != nullptr) *range_flag = 1;
+}
+
+constexpr int G16_WR = HITADV_G16_WR;  // wave rows per block: 4 = eight waves of 64 x 64, 2 = four waves of 128 x 64
+constexpr int G16_U = 2048 / (G16_WR * 128);
+
+template <class AProd, class Epi, bool SYNC_EPI>
+static int launch_gemm16(const AProd &ap, const uint16_t *Wp, int B, int npts, int N, int K, const Epi &epi, int32_t *range_flag,
+                         hipStream_t s) {
+  const int chunks = (npts + G16_BM - 1) / G16_BM, nrb = B * chunks, ncb = N / G16_BN;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f16x2_k<G16_WR, AProd, Epi, SYNC_EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G16_STAGE);
+  (void)once;
+  gemm_f16x2_k<G16_WR, AProd, Epi, SYNC_EPI><<<dim3((unsigned)(nrb * ncb)), G16_WR * 128, 2 * G16_STAGE, s>>>(
+      ap, Wp, npts, chunks, nrb, ncb, N, K, epi, range_flag);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool g16_shape_ok(long long M, int N, int K) { return M > 0 && M < (1ll << 31) && N > 0 && K > 0 && (N % G16_BN) == 0 && (K % G16_KS) == 0; }
+
+}  // namespace hitadv
+
+using namespace hitadv;
+
+extern "C" int hitadv_gemm_f16x2_supported(int N, int K) { return (N > 0 && K > 0 && (N % G16_BN) == 0 && (K % G16_KS) == 0) ? 1 : 0; }
+
+extern "C" int hitadv_split_rows_f16x2(const float *W, int N, int K, uint16_t *Wp, int32_t *range_flag, void *stream) {
+  if (!W || !Wp || N <= 0 || K <= 0) return HITADV_E_ARG;
+  const long long total = (long long)N * K;
+  split_rows_f16x2_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, Wp, total, range_flag);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_gemm_f16x2(const float *X, const float *mask, const uint16_t *Wp, const float *bias, int64_t M, int N, int K,
+                                 int relu, float *C, int32_t *range_flag, void *stream) {
+  if (!X || !Wp || !C || !g16_shape_ok(M, N, K) || ((uintptr_t)X & 15) || ((uintptr_t)Wp & 15) || (mask && ((uintptr_t)mask & 15)))
+    return HITADV_E_ARG;
+  const PlainEpi epi{C, bias, N, relu};
+  if (mask != nullptr)
+    return launch_gemm16<PlainA<true, G16_U>, PlainEpi, false>(PlainA<true, G16_U>{X, mask, K}, Wp, 1, (int)M, N, K, epi, range_flag, (hipStream_t)stream);
+  return launch_gemm16<PlainA<false, G16_U>, PlainEpi, false>(PlainA<false, G16_U>{X, nullptr, K}, Wp, 1, (int)M, N, K, epi, range_flag,
+                                                       (hipStream_t)stream);
+}
+
+extern "C" int64_t hitadv_linear_lrelu_pool_scratch(int B, int npts, int C) {
+  if (B <= 0 || npts <= 0 || C <= 0) return 0;
+  return (int64_t)B * ((npts + G16_BM - 1) / G16_BM) * C;
+}
+
+extern "C" int hitadv_linear_lrelu_pool_fwd(const float *X, const uint16_t *Wp, const float *bias, int B, int npts, int Cin, int C,
+                                            float slope, float *pmax, float *psum, int32_t *parg, uint32_t *bits, float *out,
+                                            int32_t *arg, int32_t *range_flag, void *stream) {
+  if (!X || !Wp || !bias || !pmax || !psum || !parg || !bits || !out || !arg || B <= 0 || npts <= 0 ||
+      !g16_shape_ok((long long)B * npts, C, Cin) || ((uintptr_t)X & 15) || ((uintptr_t)Wp & 15))
+    return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const PoolEpi epi{bias, reinterpret_cast<uint16_t *>(bits), pmax, psum, parg, C, slope};
+  const int rc = launch_gemm16<PlainA<false, G16_U>, PoolEpi, true>(PlainA<false, G16_U>{X, nullptr, Cin}, Wp, B, npts, C, Cin, epi, range_flag, s);
+  if (rc) return rc;
+  const int chunks = (npts + G16_BM - 1) / G16_BM;
+  pool_merge_k<<<(unsigned)((B * C + 255) / 256), 256, 0, s>>>(pmax, psum, parg, B, chunks, C, 1.f / (float)npts, out, arg);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_linear_lrelu_pool_bwd(const float *gout, const int32_t *arg, const uint32_t *bits, const uint16_t *Wtp, int B,
+                                            int npts, int Cin, int C, float slope, float *dX, int32_t *range_flag, void *stream) {
+  if (!gout || !arg || !bits || !Wtp || !dX || B <= 0 || npts <= 0 || !g16_shape_ok((long long)B * npts, Cin, C) ||
+      ((uintptr_t)gout & 15) || ((uintptr_t)arg & 15) || ((uintptr_t)Wtp & 15))
+    return HITADV_E_ARG;
+  const PoolBwdA<G16_U> ap{bits, gout, arg, C, slope, 1.f / (float)npts};
+  const PlainEpi epi{dX, nullptr, Cin, 0};
+  return launch_gemm16<PoolBwdA<G16_U>, PlainEpi, false>(ap, Wtp, B, npts, Cin, C, epi, range_flag, (hipStream_t)stream);
+}

@@ -145,6 +145,19 @@ class FoldedDGCNN(nn.Module):
             getattr(self, name).copy_(t)
         return self
 
+    fused_embedding = True  # conv5 + LeakyReLU + max / mean pooling as one fp16x2 MFMA kernel (False: GEMM + lrelu_pool)
+
+    def _c5_pieces(self, flag):
+        """fp16 pieces of the embedding layer's weights, forward ([C,Cin]) and backward ([Cin,C]) operand: split once per weight."""
+        key = (self.c5_w.data_ptr(), self.c5_w._version)
+        hit = getattr(self, '_c5_cache', None)
+        if hit is None or hit[0] != key:
+            made = (key, ops.split_rows_f16x2(self.c5_w.t().contiguous(), flag), ops.split_rows_f16x2(self.c5_w, flag))
+            if torch.cuda.is_current_stream_capturing():
+                return made[1:]
+            self._c5_cache = hit = made
+        return hit[1:]
+
     def _edge(self, h, B, N, l):
         """h [B*N,Cin] -> [B*N,Cout]"""
         with torch.no_grad():
@@ -169,7 +182,18 @@ class FoldedDGCNN(nn.Module):
         for l in (1, 2, 3, 4):
             h = self._edge(h, B, N, l)
             feats.append(h)
-        z = torch.addmm(self.c5_b, torch.cat(feats, dim=1), self.c5_w).view(B, N, -1)
+        x5 = torch.cat(feats, dim=1)
+        if x5.is_cuda and self.fused_embedding and ops.gemm_f16x2_supported(*self.c5_w.shape[::-1]) \
+                and ops.gemm_f16x2_supported(*self.c5_w.shape):
+            # the embedding layer, its activation and both poolings in one kernel on the fp16 matrix cores (fp32-accurate
+            # two-piece products): the [B*N, 1024] activation never exists, forward or backward (hitadv_linear_lrelu_pool_*)
+            from . import _pointwise
+            flag = _pointwise.range_flag(x5.device)
+            g = ops.linear_lrelu_pool(x5, *self._c5_pieces(flag), self.c5_b, B, N, 0.2, flag)
+            g = F.leaky_relu(torch.addmm(self.l1_b, g, self.l1_w), negative_slope=0.2)
+            g = F.leaky_relu(torch.addmm(self.l2_b, g, self.l2_w), negative_slope=0.2)
+            return torch.addmm(self.l3_b, g, self.l3_w)
+        z = torch.addmm(self.c5_b, x5, self.c5_w).view(B, N, -1)
         if z.is_cuda and ops.lrelu_pool_supported(z.shape[2]):
             g = ops.lrelu_pool(z, 0.2)  # activation + both poolings in one pass over z
         else:

@@ -179,8 +179,9 @@ class _LinearReLU(torch.autograd.Function):
 
 
 class _PointNetHip(torch.autograd.Function):
-    """logits, trans_feat = f(x) and d/dx of it, entirely on libhitadv_hip (f32 MFMA kernels, csrc/pointnet.hip +
-    the fused 128->1024 layers of csrc/victim.hip): 21 launches forward, 14 backward, no rocBLAS/MIOpen.
+    """logits, trans_feat = f(x) and d/dx of it, entirely on libhitadv_hip (csrc/pointnet.hip + the fused 128->1024
+    layers of csrc/victim_bf3.hip / victim.hip, in the view's ``matrix_mode``): 15 launches forward, 14 backward, no
+    rocBLAS/MIOpen.
     Weights are constants (no weight gradients: the attack never uses them)."""
 
     @staticmethod
@@ -194,8 +195,7 @@ class _PointNetHip(torch.autograd.Function):
         # STN3d
         a1s, a2s = E(R, 64), E(R, 128)
         def lin_max(a, name, relu):
-            """128 -> 1024 shared layer + max over the points: bf16x3 split (fp32-accurate, 2.7x less matrix time) or the
-            f32 MFMA form (``view.matrix_mode = 'f32'``)."""
+            """128 -> 1024 shared layer + max over the points in the view's matrix mode."""
             if v.matrix_mode == 'bf16x3':
                 return ops.linear_max_fwd_bf16x3(a, v.pieces(name), B, N, bias=getattr(v, name + '_b'), relu=relu,
                                                  blocks=v.linear_max_blocks)

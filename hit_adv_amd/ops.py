@@ -844,6 +844,73 @@ def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False, pieces=None
     return (out, arg.view(*lead, arg.shape[-1])) if return_arg else out
 
 
+def gemm_f16x2_supported(N, K):
+    """Whether ``gemm_f16x2`` / ``linear_lrelu_pool`` are built for N output columns over a K-deep contraction."""
+    return bool(_lib.load().hitadv_gemm_f16x2_supported(int(N), int(K)))
+
+
+def split_rows_f16x2(W, range_flag=None):
+    """W [N,K] fp32 (N output columns) -> the two fp16 pieces [2,N,K] (int16 storage) the fp16x2 GEMMs take as their B operand."""
+    W = _dev(W.detach(), "W")
+    N, K = W.shape
+    Wp = torch.empty(2, N, K, device=W.device, dtype=torch.int16)
+    _lib.call("hitadv_split_rows_f16x2", _p(W), N, K, _p(Wp), _p(range_flag), _stream())
+    return Wp
+
+
+def gemm_f16x2(x, Wp, bias=None, relu=False, mask=None, range_flag=None):
+    """act((x . [mask > 0]) W^T + bias) for x [M,K], Wp = split_rows_f16x2(W [N,K]): an fp32-accurate GEMM on the fp16 matrix
+    cores (two pieces per operand, three exact products; include/hitadv.h).  No autograd: the callers write their chain rule."""
+    x = _dev(x, "x")
+    M, K = x.shape
+    _, N, K2 = Wp.shape
+    if K2 != K or not gemm_f16x2_supported(N, K):
+        raise ValueError("gemm_f16x2: x [%d,%d] against pieces [2,%d,%d]" % (M, K, N, K2))
+    if mask is not None:
+        mask = _dev(mask, "mask")
+    out = torch.empty(M, N, device=x.device)
+    _lib.call("hitadv_gemm_f16x2", _p(x), _p(mask), _p(Wp), _p(bias), M, N, K, 1 if relu else 0, _p(out), _p(range_flag), _stream())
+    return out
+
+
+class LinearLReluPool(torch.autograd.Function):
+    """DGCNN's embedding layer fused with its activation and poolings: x [B*npts,Cin] -> [max_p | mean_p] of
+    lrelu(x W^T + bias) [B,2C].  The [B*npts,C] activation never exists; the backward pass rebuilds the gradient in front of
+    the layer from a one-bit-per-value sign mask and the arg-max table inside the input-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, Wp, Wtp, bias, B, npts, slope, range_flag):
+        x = _dev(x, "x")
+        _, C, Cin = Wp.shape
+        n = int(_lib.load().hitadv_linear_lrelu_pool_scratch(B, npts, C))
+        pmax, psum = torch.empty(n, device=x.device), torch.empty(n, device=x.device)
+        parg = torch.empty(n, device=x.device, dtype=torch.int32)
+        bits = torch.empty(B * npts, C // 32, device=x.device, dtype=torch.int32)
+        out = torch.empty(B, 2 * C, device=x.device)
+        arg = torch.empty(B, C, device=x.device, dtype=torch.int32)
+        _lib.call("hitadv_linear_lrelu_pool_fwd", _p(x), _p(Wp), _p(bias), B, npts, Cin, C, ctypes.c_float(slope), _p(pmax),
+                  _p(psum), _p(parg), _p(bits), _p(out), _p(arg), _p(range_flag), _stream())
+        ctx.save_for_backward(arg, bits, Wtp)
+        ctx.dims, ctx.slope, ctx.flag = (B, npts, Cin, C), slope, range_flag
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, g, _):
+        arg, bits, Wtp = ctx.saved_tensors
+        B, npts, Cin, C = ctx.dims
+        dX = torch.empty(B * npts, Cin, device=g.device)
+        _lib.call("hitadv_linear_lrelu_pool_bwd", _p(g.contiguous()), _p(arg), _p(bits), _p(Wtp), B, npts, Cin, C,
+                  ctypes.c_float(ctx.slope), _p(dX), _p(ctx.flag), _stream())
+        return dX, None, None, None, None, None, None, None
+
+
+def linear_lrelu_pool(x, Wp, Wtp, bias, B, npts, slope=0.2, range_flag=None, return_arg=False):
+    """x [B*npts,Cin]; Wp = split_rows_f16x2(W [C,Cin]), Wtp = split_rows_f16x2(W^T [Cin,C]) -> out [B,2C] (max | mean)."""
+    out, arg = LinearLReluPool.apply(x.contiguous(), Wp, Wtp, bias, B, npts, slope, range_flag)
+    return (out, arg) if return_arg else out
+
+
 def lrelu_pool(Z, slope=0.2, return_arg=False):
     """``return_arg``: also the int32 [B,C] table of the points the maxima were taken at (the kernel's own tie rule)."""
     out, arg = LReluPool.apply(Z, slope)

@@ -310,7 +310,7 @@ int hitadv_linear_max_fwd_f16x2(const float *X, const uint16_t *W2, const float 
  * eval mode with every BatchNorm folded into the layer in front of it, as four building blocks that together
  * with hitadv_linear_max_fwd / hitadv_linear_max_bwd give logits = f(x) and d logits / d x without any
  * rocBLAS / MIOpen call.  Activations are points-major [B*N,C]; x and its gradient are [B,3,N] as the attack
- * holds them.  Wt = [Cin,Cout] (forward operand), Wr = [Cout,Cin] (backward operand).  All f32 MFMA.
+ * holds them.  Wt = [Cin,Cout] (forward operand), Wr = [Cout,Cin] (backward operand).  Matrix products: see `mode` below.
  *
  * hitadv_pointnet_rowmlp_fwd: the shared per-point layers in front of a 128->1024 layer, 64 points per block.
  *   stage 0 (STN3d, :168-171)       x -> o0 = relu(x W0 + b0) [.,64] -> o2 = relu(o0 W2 + b2) [.,128]
@@ -508,6 +508,34 @@ int hitadv_group_linear_max_fwd(const float *X, const uint16_t *W2, const float 
                                 float *out, int32_t *arg, int32_t *range_flag, void *stream);
 int hitadv_group_linear_max_bwd(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2, int64_t G, int ns,
                                 int Cin, int Cout, float *dX, int32_t *range_flag, void *stream);
+
+/* ------------------------------------------------------------------ fp32-accurate GEMMs on the fp16 matrix cores
+ * The victims' wide 1x1 convolutions are GEMMs over [B*N] rows (PyTorch-ROCm: hipBLASLt's f32 GEMM, which runs at the f32
+ * MFMA rate).  These entry points run them in V1's fp16x2 scheme (hitadv_linear_max_fwd_f16x2: two fp16 pieces per operand,
+ * three exact products per useful one, fp32 accumulators; error against float64 below the f32 GEMM's) at 2-3x the speed.
+ *   hitadv_split_rows_f16x2     W [N,K] fp32 (N output columns) -> Wp [2][N][K] fp16 pieces, once per weight
+ *   hitadv_gemm_f16x2           C [M,N] = act((X . [mask > 0]) Wp^T + bias): X [M,K]; mask [M,K] or NULL (the input gradient
+ *                               of a ReLU'd layer: X = dOut, mask = the saved output, Wp = pieces of Wt); bias [N] or NULL;
+ *                               relu 0/1.  N % 128 == 0, K % 32 == 0 (hitadv_gemm_f16x2_supported).
+ *   hitadv_linear_lrelu_pool_fwd   DGCNN's embedding layer with its activation and both poolings (model/dgcnn_cls.py:63-64,
+ *                               101-104: conv5 -> bn5 -> LeakyReLU -> adaptive_max_pool1d | adaptive_avg_pool1d -> cat):
+ *                               z = X Wp^T + bias per point (X [B*npts,Cin], BatchNorm folded into Wp / bias), out [B,2C] =
+ *                               [max_p lrelu(z) | mean_p lrelu(z)], arg [B,C] int32 = the lowest point attaining the max,
+ *                               bits [B*npts, C/32] = (z > 0): the [B*npts,C] activation never exists.  pmax / psum / parg:
+ *                               scratch of hitadv_linear_lrelu_pool_scratch(B,npts,C) elements each.
+ *   hitadv_linear_lrelu_pool_bwd   dX [B*npts,Cin] = G Wtp^T with G[p,c] = s(z[p,c]) (gout[b,C+c] / npts + [arg[b,c] == p]
+ *                               gout[b,c]) rebuilt on the fly from bits / arg (s = 1 or the slope); Wtp = pieces of Wt [Cin,C].
+ * range_flag as for hitadv_linear_max_fwd_f16x2 (may be NULL). */
+int hitadv_gemm_f16x2_supported(int N, int K);
+int hitadv_split_rows_f16x2(const float *W, int N, int K, uint16_t *Wp, int32_t *range_flag, void *stream);
+int hitadv_gemm_f16x2(const float *X, const float *mask, const uint16_t *Wp, const float *bias, int64_t M, int N, int K, int relu,
+                      float *C, int32_t *range_flag, void *stream);
+int64_t hitadv_linear_lrelu_pool_scratch(int B, int npts, int C);
+int hitadv_linear_lrelu_pool_fwd(const float *X, const uint16_t *Wp, const float *bias, int B, int npts, int Cin, int C, float slope,
+                                 float *pmax, float *psum, int32_t *parg, uint32_t *bits, float *out, int32_t *arg,
+                                 int32_t *range_flag, void *stream);
+int hitadv_linear_lrelu_pool_bwd(const float *gout, const int32_t *arg, const uint32_t *bits, const uint16_t *Wtp, int B, int npts,
+                                 int Cin, int C, float slope, float *dX, int32_t *range_flag, void *stream);
 
 /* G independent attacks STACKED (HiT_ADV.attack_many on the PointNet engine: one victim pass over the G*B clouds): the three
  * launches around that pass for all G groups at once.  Every per-cloud argument is the group-0 pointer of a buffer that

@@ -989,10 +989,13 @@ def test_fc_layer_mfma(A, B, K, NOUT):
     close(A.sum_partials(cu(part), cu(bias.expand(B, NOUT).contiguous())), part.sum(1) + bias, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,Np", [(4, 1024), (3, 1000), (2, 77), (33, 256)])
-def test_pointnet_engine_matches_module(B, Np):
+@pytest.mark.parametrize("B,Np,mode", [(4, 1024, 'fp16x2'), (3, 1000, 'fp16x2'), (2, 77, 'fp16x2'), (33, 256, 'fp16x2'),
+                                       (3, 1000, 'bf16x3'), (2, 77, 'f32'), (4, 1024, 'f32')])
+def test_pointnet_engine_matches_module(B, Np, mode):
     """The HIP PointNet engine (rowmlp / linear_max / fc_layer kernels) against the nn.Module evaluated in float64
-    on the CPU: logits, trans_feat and the input gradient -- also for a gradient arriving through trans_feat."""
+    on the CPU: logits, trans_feat and the input gradient -- also for a gradient arriving through trans_feat.  In each of
+    the engine's matrix modes: 'fp16x2' (default: shared layers and the 128 -> 1024 layers on the fp16 cores, packed pieces
+    in between), 'bf16x3' and 'f32' (shared layers as exact f32 MFMA chains)."""
     from hit_adv_amd.model.pointnet import PointNetFeatureModel
     torch.manual_seed(B + Np)
     m = PointNetFeatureModel(40, normal_channel=False).eval()
@@ -1015,8 +1018,10 @@ def test_pointnet_engine_matches_module(B, Np):
     gboth, = torch.autograd.grad((ld * wl.double()).sum() + (td * wt.double()).sum(), xd)
     view = m.cuda().attack_view()
     assert view.hip_engine
+    view.matrix_mode = mode
     xc = cu(x).requires_grad_()
     lh, th = view(xc)
+    view.check_range()
     close(lh, ld.float(), rtol=1e-4, atol=2e-5)
     close(th, td.float(), rtol=1e-4, atol=2e-5)
     gh, = torch.autograd.grad((lh * cu(wl)).sum(), xc, retain_graph=True)
@@ -1033,6 +1038,119 @@ def test_pointnet_engine_matches_module(B, Np):
     gt, = torch.autograd.grad((lt * cu(wl)).sum(), xt)
     close(lh, lt, rtol=1e-4, atol=2e-5)
     close(gh, gt, rtol=1e-3, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize("B,Np", [(3, 1000), (2, 64), (5, 130)])
+def test_packed_pieces_equal_the_split_in_v1(A, B, Np):
+    """rowmlp_fwd mode 2 hands its 128-wide activation on as packed words (fp16 hi | fp16 lo << 16): the words are the two
+    pieces V1 would split the mode-1 activation into, the 64-wide activation is the same bits in both modes, and V1 on the
+    packed words returns the bits of V1 on the floats."""
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    torch.manual_seed(Np)
+    view = PointNetFeatureModel(40, normal_channel=False).cuda().eval().attack_view()
+    data, _ = synth_batch(B, Np, first=3)
+    x = data[:, :, :3].transpose(1, 2).contiguous().cuda()
+    R = B * Np
+    a1f, a2f, a1p, a2p = (torch.empty(R, c, device='cuda') for c in (64, 128, 64, 128))
+    A.pointnet_rowmlp_fwd(0, B, Np, view.s2_w, view.s2_b, a2f, x=x, W0=view.s1_w, b0=view.s1_b, o0=a1f, mode=1,
+                          range_flag=view.range_flag)
+    A.pointnet_rowmlp_fwd(0, B, Np, view.s2_w, view.s2_b, a2p, x=x, W0=view.s1_w, b0=view.s1_b, o0=a1p, mode=2,
+                          range_flag=view.range_flag)
+    assert torch.equal(a1f, a1p)
+    words = a2p.view(torch.int32)
+    hi = (words & 0xffff).to(torch.int16).view(torch.float16)
+    lo = (words >> 16).to(torch.int16).view(torch.float16)
+    h1 = a2f.half()
+    h2 = ((a2f - h1.float()) * 2048.0).half()
+    assert torch.equal(hi, h1) and torch.equal(lo, h2)
+    assert torch.equal(words != 0, a2f != 0)  # what the backward pass uses the packed activation for: the ReLU mask
+    # mode 1 against the exact f32 chain of mode 0: fp32 roundoff of a 64-deep product
+    a1e, a2e = torch.empty(R, 64, device='cuda'), torch.empty(R, 128, device='cuda')
+    A.pointnet_rowmlp_fwd(0, B, Np, view.s2_w, view.s2_b, a2e, x=x, W0=view.s1_w, b0=view.s1_b, o0=a1e, mode=0)
+    assert torch.equal(a1e, a1f)  # the 3 -> 64 layer is exact f32 on the VALU in every mode
+    close(a2f, a2e, rtol=0, atol=2e-6 * float(a2e.abs().max()))
+    g1, j1 = A.linear_max_fwd_f16x2(a2f, view.pieces('s3', 2), B, Np, bias=view.s3_b, relu=True, range_flag=view.range_flag)
+    g2, j2 = A.linear_max_fwd_f16x2(a2p, view.pieces('s3', 2), B, Np, bias=view.s3_b, relu=True, range_flag=view.range_flag,
+                                    packed=True)
+    assert torch.equal(g1, g2) and torch.equal(j1, j2)
+    view.check_range()
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (4096, 512, 1024), (777, 1024, 512), (3, 32, 128), (70000, 128, 256)])
+def test_gemm_f16x2_is_fp32_accurate(A, M, K, N):
+    """The fp16x2 GEMM (two fp16 pieces per operand, three exact products) against float64: no further from it than torch's
+    f32 GEMM, with bias / ReLU / a ReLU-mask gate on the input; pieces reconstruct the weights; bitwise reproducible."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    mask = torch.randn(M, K, generator=g)
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    Wp = A.split_rows_f16x2(cu(W), range_flag=flag)
+    pieces = Wp.view(torch.float16).float().cpu()
+    rec = pieces[0].double() + pieces[1].double() / 2048.0
+    assert float((rec - W.double()).abs().max()) <= 2.0 ** -22 * float(W.abs().max())
+    ref = x.double() @ W.double().t()
+    scale = float(ref.abs().max())
+    got = A.gemm_f16x2(cu(x), Wp, range_flag=flag)
+    lib = (cu(x) @ cu(W).t()).cpu()
+    err, err_lib = float((got.cpu().double() - ref).abs().max()), float((lib.double() - ref).abs().max())
+    assert err <= max(err_lib, 2e-7 * scale), (err, err_lib)
+    close(got, ref.float(), rtol=0, atol=5e-7 * scale)
+    assert torch.equal(got, A.gemm_f16x2(cu(x), Wp, range_flag=flag))
+    got = A.gemm_f16x2(cu(x), Wp, bias=cu(bias), relu=True, range_flag=flag)
+    close(got, (ref + bias.double()).clamp_min(0.).float(), rtol=0, atol=5e-7 * scale)
+    refm = (x.double() * (mask > 0)) @ W.double().t()
+    close(A.gemm_f16x2(cu(x), Wp, mask=cu(mask), range_flag=flag), refm.float(), rtol=0, atol=5e-7 * scale)
+    assert int(flag.item()) == 0
+    x[0, 0] = 7e4  # beyond fp16
+    A.gemm_f16x2(cu(x), Wp, range_flag=flag)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("B,Np,Cin,C", [(2, 1024, 512, 1024), (3, 500, 512, 1024), (2, 77, 128, 128), (1, 256, 512, 256)])
+def test_linear_lrelu_pool_forward_and_backward(A, B, Np, Cin, C):
+    """DGCNN's embedding layer + LeakyReLU + max / mean pooling in one kernel against the float64 composition: values, the
+    arg-max table (lowest point on ties), the sign bit mask through the gradient, bitwise reproducibility."""
+    g = torch.Generator().manual_seed(B * 1000 + Np + C)
+    x = torch.randn(B * Np, Cin, generator=g)
+    x[5] = x[3]  # two points of cloud 0 with identical features: a tie wherever one of them is the maximum
+    W = torch.randn(C, Cin, generator=g) / Cin ** 0.5
+    bias = torch.randn(C, generator=g) * 0.1
+    w = torch.randn(B, 2 * C, generator=g)
+    xd = x.double().requires_grad_()
+    z = (xd @ W.double().t() + bias.double()).view(B, Np, C)
+    h = torch.nn.functional.leaky_relu(z, negative_slope=0.2)
+    ref = torch.cat((h.max(dim=1)[0], h.mean(dim=1)), dim=1).detach()
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    Wp, Wtp = A.split_rows_f16x2(cu(W), flag), A.split_rows_f16x2(cu(W.t().contiguous()), flag)
+    xc = cu(x).requires_grad_()
+    out, arg = A.linear_lrelu_pool(xc, Wp, Wtp, cu(bias), B, Np, 0.2, flag, return_arg=True)
+    scale = float(ref.abs().max())
+    close(out, ref.float(), rtol=0, atol=1e-6 * scale)
+    # the table: a maximiser of the float64 activation to within fp32 noise, and the LOWEST point among exact ties
+    h = h.detach()
+    hmax = h.max(dim=1)[0]
+    at = h.gather(1, arg.cpu().long().unsqueeze(1)).squeeze(1)
+    assert float((hmax - at).abs().max()) <= 2e-6 * scale
+    assert not bool((arg[0].cpu() == 5).any())  # point 3 wins every tie with its copy
+    assert int(flag.item()) == 0
+    # gradient: route the max half through the kernel's own table (fp32 near-ties may pick another winner than float64)
+    gd_max = torch.zeros(B, Np, C, dtype=torch.float64).scatter_(1, arg.cpu().long().unsqueeze(1), w[:, :C].double().unsqueeze(1))
+    gd = (gd_max + w[:, C:].double().unsqueeze(1) / Np) * torch.where(z.detach() > 0, 1.0, 0.2)
+    gref = gd.view(B * Np, C) @ W.double()
+    out.backward(cu(w))
+    # a sign bit may differ from float64's where |z| is at fp32 noise: there the slope is 1 instead of 0.2 or the reverse, which
+    # moves the gradient of that point by at most 0.8 |g[p,c]| |W[c,:]|; everything else is held to fp32 roundoff
+    amb = (z.detach().abs() < 1e-5 * float(z.detach().abs().max())).double().view(B * Np, C)
+    slack = 0.8 * (amb * (gd_max + w[:, C:].double().unsqueeze(1) / Np).abs().view(B * Np, C)) @ W.double().abs()
+    diff = (xc.grad.cpu().double() - gref).abs()
+    assert float(amb.mean()) < 1e-3
+    assert bool((diff <= slack + 2e-6 * float(gref.abs().max())).all()), float((diff - slack).max())
+    x2 = cu(x).requires_grad_()
+    out2, arg2 = A.linear_lrelu_pool(x2, Wp, Wtp, cu(bias), B, Np, 0.2, flag, return_arg=True)
+    out2.backward(cu(w))
+    assert torch.equal(out, out2) and torch.equal(arg, arg2) and torch.equal(xc.grad, x2.grad)
 
 
 @pytest.mark.parametrize("B,Np,D,K", [(2, 1024, 64, 5), (3, 500, 64, 20), (2, 1024, 128, 5), (1, 130, 128, 20), (2, 33, 64, 8)])

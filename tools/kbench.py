@@ -16,6 +16,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hit_adv_amd import _lib, ops  # noqa: E402
 
 
+def timed_eager(fn, reps=20):
+    """Average duration of a torch-level function (its own launches + allocator), events on the current stream."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) * 1e3 / reps
+
+
 def timed(fn, reps):
     """Average launch duration: 20 back-to-back launches captured into a hipGraph (so the host's ctypes call
     rate cannot open gaps between them), replayed reps/20 times between two events."""
@@ -174,6 +188,38 @@ def main():
         fi = torch.empty(B, N, 5, dtype=torch.int64, device='cuda')
         us = timed(lambda s=s0: lib.hitadv_knn_features(p(feat), p(fx), B, N, D, 5, p(fi), s), a.reps)
         out['knn_features_D%d_K5' % D] = dict(us=round(us, 2), TFLOPs=round(2.0 * B * N * N * D / us / 1e6, 1))
+    # fp32-accurate GEMMs on the fp16 cores against the library's f32 GEMM, and DGCNN's fused embedding layer
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for M, K, N in ((32768, 512, 1024), (32768, 1024, 512), (131072, 128, 256), (524288, 128, 128), (32768, 256, 256)):
+        xa = torch.randn(M, K, generator=g).cuda()
+        Wn = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+        Wt_ = Wn.t().contiguous()
+        Wp = ops.split_rows_f16x2(Wn, flag)
+        cbuf = torch.empty(M, N, device='cuda')
+        us = timed(lambda s=s0: lib.hitadv_gemm_f16x2(p(xa), None, p(Wp), None, M, N, K, 0, p(cbuf), p(flag), s), 20)
+        us_lib = timed_eager(lambda: torch.mm(xa, Wt_, out=cbuf))
+        out['gemm_f16x2_%dx%dx%d' % (M, K, N)] = dict(us=round(us, 1), useful_TFLOPs=round(2.0 * M * K * N / us / 1e6, 1),
+                                                      executed_f16_TFLOPs=round(6.0 * M * K * N / us / 1e6, 1),
+                                                      torch_mm_f32_us=round(us_lib, 1))
+        del xa, Wn, Wt_, Wp, cbuf
+    Bc, Nc, Cin, Cc = 32, 1024, 512, 1024
+    xa = torch.randn(Bc * Nc, Cin, generator=g).cuda().requires_grad_()
+    Wn = (torch.randn(Cc, Cin, generator=g) / Cin ** 0.5).cuda()
+    bc = torch.randn(Cc, generator=g).cuda()
+    Wp, Wtp = ops.split_rows_f16x2(Wn, flag), ops.split_rows_f16x2(Wn.t().contiguous(), flag)
+    wgt = torch.randn(Bc, 2 * Cc, generator=g).cuda()
+    o = ops.linear_lrelu_pool(xa, Wp, Wtp, bc, Bc, Nc, 0.2, flag)
+    us_f = timed_eager(lambda: ops.linear_lrelu_pool(xa.detach(), Wp, Wtp, bc, Bc, Nc, 0.2, flag))
+    us_b = timed_eager(lambda: torch.autograd.grad(o, xa, wgt, retain_graph=True))
+    Wt_ = Wn.t().contiguous()
+
+    def lib_fwd():
+        return ops.lrelu_pool(torch.addmm(bc, xa.detach(), Wt_).view(Bc, Nc, Cc), 0.2)
+    o2 = ops.lrelu_pool(torch.addmm(bc, xa, Wt_).view(Bc, Nc, Cc), 0.2)
+    out['linear_lrelu_pool_32x1024_512x1024'] = dict(fwd_us=round(us_f, 1), bwd_us=round(us_b, 1),
+                                                     addmm_plus_lrelu_pool_fwd_us=round(timed_eager(lib_fwd), 1),
+                                                     addmm_plus_lrelu_pool_bwd_us=round(timed_eager(
+                                                         lambda: torch.autograd.grad(o2, xa, wgt, retain_graph=True)), 1))
     print(json.dumps(out))
 
 

@@ -10,7 +10,9 @@ their written bounds: those are already set from measurement and vary with the h
 
     python tools/make_parity_pins.py gpurun_out/parity_report_gpu.json [more reports ...] > tests/golden/parity_pins.json
 
-Several reports (different boxes / runs) are merged by taking the LARGEST achieved error per comparison."""
+Several reports (different boxes / runs) are merged by taking the LARGEST achieved error per comparison;
+``--keep tests/golden/parity_pins.json`` also merges the pins already committed the same way (box-to-box variation of earlier
+runs stays covered; a comparison that got worse than 4x its committed pin is listed on stderr first)."""
 import json
 import sys
 
@@ -19,7 +21,11 @@ SKIP = ('cfg5', 'raw relative L2', 'fraction of elements')
 
 
 def main(paths):
-    pins = {}
+    pins, kept = {}, {}
+    if paths and paths[0] == '--keep':
+        with open(paths[1]) as f:
+            kept = json.load(f)
+        paths = paths[2:]
     for path in paths:
         with open(path) as f:
             report = json.load(f)
@@ -42,6 +48,13 @@ def main(paths):
                     continue
                 slot = pins.setdefault(test, {}).setdefault(what, dict(max_abs=0.0, written_rtol=r['rtol'], written_atol=r['atol']))
                 slot['max_abs'] = max(slot['max_abs'], r['max_abs'])
+    for test, slots in kept.items():
+        for what, slot in slots.items():
+            mine = pins.setdefault(test, {}).get(what)
+            if mine is not None and mine['max_abs'] > 4 * slot['max_abs']:
+                sys.stderr.write("worse than 4x the committed pin: %s / %s: %.3g -> %.3g\n" % (test, what, slot['max_abs'], mine['max_abs']))
+            if mine is None or mine['max_abs'] < slot['max_abs']:
+                pins[test][what] = slot
     json.dump(pins, sys.stdout, indent=1, sort_keys=True)
     sys.stdout.write("\n")
 
