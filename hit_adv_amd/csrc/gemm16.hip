@@ -1,5 +1,5 @@
 // fp32-accurate GEMMs on the fp16 matrix cores for the victims' wide 1x1 convolutions, and DGCNN's embedding layer fused
-// with its activation and poolings (model/dgcnn_cls.py:63-64,101-104: conv5 -> bn5 -> LeakyReLU(0.2) -> adaptive_max_pool1d
+// with its activation and poolings (model/dgcnn_cls.py:70-72,101-106: conv5 -> bn5 -> LeakyReLU(0.2) -> adaptive_max_pool1d
 // | adaptive_avg_pool1d -> cat) -- forward and input gradient.
 //
 // Arithmetic: V1's fp16x2 scheme (csrc/victim_bf3.hip): every operand is two fp16 pieces, a = a1 + 2^-11 a2 (+ <= 2^-24 |a|),

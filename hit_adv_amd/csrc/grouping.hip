@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void edge_max_bwd_k(const float *__restrict__ 
 }  // namespace hitadv
 
 // ---------------------------------------------------------------------------------------------------
-// DGCNN's global pooling (model/dgcnn_cls.py:117-121): LeakyReLU of the embedding layer's pre-activation Z [B,N,C], then
+// DGCNN's global pooling (model/dgcnn_cls.py:101-106): LeakyReLU of the embedding layer's pre-activation Z [B,N,C], then
 // max and mean over the points, concatenated -> [B,2C].  One pass over Z (the activation tensor itself is never
 // written): a block owns 64 channels of one cloud, 16 lanes x float4 across the channels, 16 row groups down the points;
 // the row groups are combined in fixed order, so the mean is the same bits every run.  arg = first point attaining the max.

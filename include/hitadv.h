@@ -404,7 +404,7 @@ int hitadv_edge_max_bwd(const float *dout, const float *out, const int32_t *arg,
                         int k, float slope, float *dU, float *dV, int ldg, int32_t *scratch, void *stream);
 int64_t hitadv_edge_max_bwd_scratch_ints(int B, int N, int k);
 
-/* DGCNN's pooling after the embedding layer (model/dgcnn_cls.py:117-121: LeakyReLU, adaptive_max_pool1d and
+/* DGCNN's pooling after the embedding layer (model/dgcnn_cls.py:101-106: LeakyReLU, adaptive_max_pool1d and
  * adaptive_avg_pool1d over the points, concatenated), from the layer's PRE-activation Z [B,N,C] points-major, C % 64 == 0:
  *   out[b,c] = max_i lrelu(Z[b,i,c]),  out[b,C+c] = mean_i lrelu(Z[b,i,c]),  arg[b,c] = first i attaining the max.
  * One pass over Z, fixed summation order.  Backward: dZ[b,i,c] = lrelu'(Z) * (g[b,C+c]/N + (i == arg[b,c]) g[b,c]). */
@@ -517,7 +517,7 @@ int hitadv_group_linear_max_bwd(const float *dOut, const float *out, const int32
  *   hitadv_gemm_f16x2           C [M,N] = act((X . [mask > 0]) Wp^T + bias): X [M,K]; mask [M,K] or NULL (the input gradient
  *                               of a ReLU'd layer: X = dOut, mask = the saved output, Wp = pieces of Wt); bias [N] or NULL;
  *                               relu 0/1.  N % 128 == 0, K % 32 == 0 (hitadv_gemm_f16x2_supported).
- *   hitadv_linear_lrelu_pool_fwd   DGCNN's embedding layer with its activation and both poolings (model/dgcnn_cls.py:63-64,
+ *   hitadv_linear_lrelu_pool_fwd   DGCNN's embedding layer with its activation and both poolings (model/dgcnn_cls.py:70-72,
  *                               101-104: conv5 -> bn5 -> LeakyReLU -> adaptive_max_pool1d | adaptive_avg_pool1d -> cat):
  *                               z = X Wp^T + bias per point (X [B*npts,Cin], BatchNorm folded into Wp / bias), out [B,2C] =
  *                               [max_p lrelu(z) | mean_p lrelu(z)], arg [B,C] int32 = the lowest point attaining the max,
