@@ -221,7 +221,8 @@ struct PoolEpi {
 };
 
 // ---------------------------------------------------------------------------------------------- the kernel
-template <int WR, class AProd, class Epi, bool SYNC_EPI>
+// ABL != 0: tuning builds only (tools/tune/g16_ablate.py: the kernel with one cost removed; results are garbage)
+template <int WR, class AProd, class Epi, bool SYNC_EPI, int ABL = 0>
 __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_t *__restrict__ Wp, int npts, int chunks, int nrb,
                                                          int ncb, int N, int K, Epi epi, int *range_flag) {
   constexpr int NT = WR * 128;       // threads: WR x 2 waves
@@ -264,6 +265,9 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
   // B: 128 columns x 4 sixteen-byte chunks per piece; chunk e = tid + NT v -> column e >> 2, chunk e & 3
   const uint16_t *bsrc = Wp + (size_t)(t.col0 + (tid >> 2)) * K + 8 * (tid & 3);
   auto fetch = [&](Set &st, int ks) {
+    if constexpr (ABL == 2) {
+      if (ks > 0) return;  // no global loads after the first step
+    }
     ap.fetch(st.a, t, ks * G16_KS, tid);
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -280,11 +284,16 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
       float a[4];
       ap.values(st.a, t, u, tid, a);
       f16x4m h1, h2;
+      if constexpr (ABL == 1) {  // no conversions: raw bits
+        h1 = __builtin_bit_cast(f16x4m, make_uint2(__float_as_uint(a[0]), __float_as_uint(a[1])));
+        h2 = __builtin_bit_cast(f16x4m, make_uint2(__float_as_uint(a[2]), __float_as_uint(a[3])));
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        h1[j] = (_Float16)a[j];
-        h2[j] = (_Float16)((a[j] - (float)h1[j]) * G16_SCALE);
-        big = fmaxf(big, fabsf(a[j]));
+        for (int j = 0; j < 4; ++j) {
+          h1[j] = (_Float16)a[j];
+          h2[j] = (_Float16)((a[j] - (float)h1[j]) * G16_SCALE);
+          big = fmaxf(big, fabsf(a[j]));
+        }
       }
       char *dst = base + g16_off((tid >> 3) + (NT / 8) * u, (tid & 7) >> 1) + 8 * (tid & 1);
       *reinterpret_cast<uint2 *>(dst) = __builtin_bit_cast(uint2, h1);
@@ -305,6 +314,7 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
     for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f}, accl[rt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int ks) {
+    if constexpr (ABL == 3) return;  // no LDS reads, no MFMAs
     const char *base = sG16 + (size_t)(ks & 1) * G16_STAGE;
     // rows 16 x + l16: (row >> 2) & 3 = (l16 >> 2) & 3 for every 16-row tile, so one swizzled offset serves all of them
     const char *ab = base + 16 * RT * wr * G16_RS + g16_off(l16, g4);
@@ -321,6 +331,11 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
       const f16x8m alo = as_f16x8m(*reinterpret_cast<const uint4 *>(ab + 16 * rt * G16_RS + G16_APIECE));
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
+        if constexpr (ABL == 4) {  // one product instead of three
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, as_f16x8m(fb[ct][0]), acc[rt][ct], 0, 0, 0);
+          accl[rt][ct][0] += (float)alo[0] + (float)as_f16x8m(fb[ct][1])[0];
+          continue;
+        }
         accl[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, as_f16x8m(fb[ct][0]), accl[rt][ct], 0, 0, 0);
         accl[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, as_f16x8m(fb[ct][1]), accl[rt][ct], 0, 0, 0);
         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, as_f16x8m(fb[ct][0]), acc[rt][ct], 0, 0, 0);
@@ -451,3 +466,30 @@ extern "C" int hitadv_linear_lrelu_pool_bwd(const float *gout, const int32_t *ar
   const PlainEpi epi{dX, nullptr, Cin, 0};
   return launch_gemm16<PoolBwdA<G16_U>, PlainEpi, false>(ap, Wtp, B, npts, Cin, C, epi, range_flag, (hipStream_t)stream);
 }
+
+#ifdef HITADV_G16_TUNE
+template <int ABL>
+static int g16_ablate_launch(const float *X, const uint16_t *Wp, long long M, int N, int K, float *C, hipStream_t s) {
+  using AP = PlainA<false, G16_U>;
+  const AP ap{X, nullptr, K};
+  const PlainEpi epi{C, nullptr, N, 0};
+  const int chunks = (int)((M + G16_BM - 1) / G16_BM), nrb = chunks, ncb = N / G16_BN;
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f16x2_k<G16_WR, AP, PlainEpi, false, ABL>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G16_STAGE);
+  (void)once;
+  gemm_f16x2_k<G16_WR, AP, PlainEpi, false, ABL><<<dim3((unsigned)(nrb * ncb)), G16_WR * 128, 2 * G16_STAGE, s>>>(
+      ap, Wp, (int)M, chunks, nrb, ncb, N, K, epi, nullptr);
+  return (int)hipGetLastError();
+}
+extern "C" int hitadv_gemm_f16x2_ablate(int abl, const float *X, const uint16_t *Wp, long long M, int N, int K, float *C, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (abl) {
+    case 0: return g16_ablate_launch<0>(X, Wp, M, N, K, C, s);
+    case 1: return g16_ablate_launch<1>(X, Wp, M, N, K, C, s);
+    case 2: return g16_ablate_launch<2>(X, Wp, M, N, K, C, s);
+    case 3: return g16_ablate_launch<3>(X, Wp, M, N, K, C, s);
+    case 4: return g16_ablate_launch<4>(X, Wp, M, N, K, C, s);
+  }
+  return -1;
+}
+#endif

@@ -51,6 +51,30 @@ for w in $WHAT; do
       done
       python tools/pmc_summary.py $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_FETCH_SIZE.csv > $OUT/kbench_traffic.json 2>> $OUT/pmc_WRITE_SIZE.log
       rm -f $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv ;;
+    pmc_mfma)  # SQ counters of V1 and G16, one pass per counter group (a pass fails as a whole on an unknown counter name)
+      i=0
+      for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+                 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU" \
+                 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16"; do
+        i=$((i+1)); rm -rf /tmp/prof/pm$i
+        timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/prof/pm$i -- python3 tools/mfma_pmc_probe.py > $OUT/pmc_mfma_$i.log 2>&1
+        f=$(find /tmp/prof/pm$i -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" /tmp/prof/pmc_mfma_$i.csv
+      done
+      python - > $OUT/mfma_pmc.txt <<'PY'
+import csv, glob, collections
+for f in sorted(glob.glob('/tmp/prof/pmc_mfma_*.csv')):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        per[(r['Kernel_Name'][:70], r['Dispatch_Id'])][r['Counter_Name']] += float(r['Counter_Value'])
+    for (k, d), cs in per.items():
+        for c, v in cs.items():
+            acc[(k, cs.get('Grid_Size', 0))][c].append(v)
+    for (k, _), cs in acc.items():
+        if 'linear_max_fwd_bf3' in k or 'gemm_f16x2' in k:
+            print(f.split('_')[-1][:-4], k, {c: round(sum(v) / len(v)) for c, v in cs.items()}, 'launches', len(next(iter(cs.values()))))
+PY
+      ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -15 $OUT/pytest_gpu.log
       cp gpurun_out/parity_report_gpu.json $OUT/parity_report.json; cp gpurun_out/parity_rows_gpu.json $OUT/parity_rows.json ;;
