@@ -44,6 +44,16 @@ def get_graph_feature(x, k=20, idx=None, dim9=False):
     return torch.cat((nbr - ctr, ctr), dim=3).permute(0, 3, 1, 2).contiguous()
 
 
+def _block1x1(block, x):
+    """``Sequential(Conv(1x1), BatchNorm, LeakyReLU)`` of the module: in eval mode on the GPU the 1x1 convolution is one GEMM with
+    the BatchNorm folded in (model/_pointwise.py: MIOpen has no tuned solver for these shapes and falls back to
+    ``naive_conv_*``, 6.8 ms per call at B = 32 -- profiles/r03_cfg3_kernel_stats.csv); otherwise the modules themselves."""
+    from ._pointwise import conv1x1, fast_pm
+    if fast_pm(block[0], block[1], x) and not torch.is_grad_enabled():
+        return block[2](conv1x1(block[0], block[1], x))
+    return block(x)
+
+
 class DGCNN_cls(nn.Module):
     def __init__(self, args, output_channels=40):
         super().__init__()
@@ -75,9 +85,9 @@ class DGCNN_cls(nn.Module):
         feats = []
         h = x
         for conv in (self.conv1, self.conv2, self.conv3, self.conv4):
-            h = conv(get_graph_feature(h, k=self.k)).max(dim=-1)[0]
+            h = _block1x1(conv, get_graph_feature(h, k=self.k)).max(dim=-1)[0]
             feats.append(h)
-        h = self.conv5(torch.cat(feats, dim=1))
+        h = _block1x1(self.conv5, torch.cat(feats, dim=1))
         g = torch.cat((F.adaptive_max_pool1d(h, 1).view(B, -1), F.adaptive_avg_pool1d(h, 1).view(B, -1)), 1)
         g = self.dp1(F.leaky_relu(self.bn6(self.linear1(g)), negative_slope=0.2))
         g = self.dp2(F.leaky_relu(self.bn7(self.linear2(g)), negative_slope=0.2))
