@@ -195,11 +195,14 @@ __global__ __launch_bounds__(512) void group_linear_max_fwd_k(const float *__res
 // block = 4 waves = 256 threads; thread c (and c + 256 ...) owns channel c of the tile's groups; wave w owns the output
 // columns [16 NCB w, 16 NCB (w + 1)): CIN = 64 NCB.  Wb2 = the pieces of Wt[CIN, COUT] in V1's fragment order with the roles
 // of the two dimensions swapped (contraction over the channels): hitadv_split_weights_f16x2(Wt, CIN, COUT, ...).
-template <int CIN, int NS, int COUT>
+// MASKED: dX is also gated by (xmask > 0), xmask [G*NS, CIN] = the layer's INPUT when that is itself a ReLU output (the shared
+// layer in front): the ReLU backward pass of that layer -- a read of dX, a read of the activation and a write as large as
+// both -- happens on the way out of this kernel instead.
+template <int CIN, int NS, int COUT, bool MASKED>
 __global__ __launch_bounds__(256) void group_linear_max_bwd_k(const float *__restrict__ dOut, const float *__restrict__ outv,
                                                               const int32_t *__restrict__ arg, const uint16_t *__restrict__ Wb2,
                                                               long long groups, int tiles_per_block, float *__restrict__ dX,
-                                                              int *range_flag) {
+                                                              int *range_flag, const float *__restrict__ xmask) {
   constexpr int NCB = CIN / 64;           // 16-column tiles per wave
   constexpr int KSL = COUT / 32;          // 32-deep slices of the contraction over the channels
   constexpr int RS = 2 * COUT + 32;       // bytes per LDS row of one piece of the A operand
@@ -230,8 +233,18 @@ __global__ __launch_bounds__(256) void group_linear_max_bwd_k(const float *__res
   // the A operand starts as zeros and is returned to zeros after every tile (each thread clears the cells it set)
   for (int e = threadIdx.x; e < 2 * PIECE / 16; e += 256) reinterpret_cast<uint4 *>(sB)[e] = make_uint4(0, 0, 0, 0);
   __syncthreads();
+  constexpr int NM = GM_TM * CIN / 4 / 256;  // float4 cells of the output tile per thread
   for (int tile = 0; tile < ntiles; ++tile) {
     const long long grp0 = (t0 + tile) * gpt;
+    float4 mk[MASKED ? NM : 1];
+    if constexpr (MASKED) {  // requested first: the loads land while the tile's products run
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const int e = threadIdx.x + 256 * i, r = e / (CIN / 4), c4 = e % (CIN / 4);
+        const long long row = min(grp0 * NS + r, groups * NS - 1);
+        mk[i] = *reinterpret_cast<const float4 *>(xmask + (size_t)row * CIN + 4 * c4);
+      }
+    }
     int cell[NSEG][CPT];
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg)
@@ -297,10 +310,17 @@ __global__ __launch_bounds__(256) void group_linear_max_bwd_k(const float *__res
           *reinterpret_cast<_Float16 *>(sB + PIECE + cell[sg][q]) = (_Float16)0.f;
         }
     const long long row0 = grp0 * NS, rows_all = groups * NS;
-    for (int e = threadIdx.x; e < GM_TM * CIN / 4; e += 256) {
-      const int r = e / (CIN / 4), c4 = e % (CIN / 4);
-      if (row0 + r < rows_all)
-        *reinterpret_cast<float4 *>(dX + (size_t)(row0 + r) * CIN + 4 * c4) = *reinterpret_cast<const float4 *>(sOut + r * LDO + 4 * c4);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      const int e = threadIdx.x + 256 * i, r = e / (CIN / 4), c4 = e % (CIN / 4);
+      float4 v = *reinterpret_cast<const float4 *>(sOut + r * LDO + 4 * c4);
+      if constexpr (MASKED) {
+        v.x = mk[i].x > 0.f ? v.x : 0.f;
+        v.y = mk[i].y > 0.f ? v.y : 0.f;
+        v.z = mk[i].z > 0.f ? v.z : 0.f;
+        v.w = mk[i].w > 0.f ? v.w : 0.f;
+      }
+      if (row0 + r < rows_all) *reinterpret_cast<float4 *>(dX + (size_t)(row0 + r) * CIN + 4 * c4) = v;
     }
     __syncthreads();
   }
@@ -323,20 +343,20 @@ static int launch_fwd(const float *X, const uint16_t *W2, const float *bias, lon
   return 0;
 }
 
-template <int CIN, int NS, int COUT>
+template <int CIN, int NS, int COUT, bool MASKED>
 static int launch_bwd(const float *dOut, const float *outv, const int32_t *arg, const uint16_t *Wb2, long long G, float *dX,
-                      int32_t *range_flag, hipStream_t s) {
+                      int32_t *range_flag, const float *xmask, hipStream_t s) {
   const long long ntiles = (G * NS + GM_TM - 1) / GM_TM;
   long long blocks = min(ntiles, 1024ll);
   int tpb = (int)((ntiles + blocks - 1) / blocks);
   if (tpb < 4) tpb = (int)min(4ll, ntiles);
   blocks = (ntiles + tpb - 1) / tpb;
   const size_t shm = (size_t)2 * GM_TM * (2 * COUT + 32) + (size_t)GM_TM * (CIN + 4) * sizeof(float);
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&group_linear_max_bwd_k<CIN, NS, COUT>),
+  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&group_linear_max_bwd_k<CIN, NS, COUT, MASKED>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(2 * GM_TM * (2 * COUT + 32) + GM_TM * (CIN + 4) * sizeof(float)));
   (void)once;
-  group_linear_max_bwd_k<CIN, NS, COUT><<<(unsigned)blocks, 256, shm, s>>>(dOut, outv, arg, Wb2, G, tpb, dX, range_flag);
+  group_linear_max_bwd_k<CIN, NS, COUT, MASKED><<<(unsigned)blocks, 256, shm, s>>>(dOut, outv, arg, Wb2, G, tpb, dX, range_flag, xmask);
   return 0;
 }
 
@@ -367,16 +387,21 @@ extern "C" int hitadv_group_linear_max_fwd(const float *X, const uint16_t *W2, c
   return 0;
 }
 
-extern "C" int hitadv_group_linear_max_bwd(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2,
-                                           int64_t G, int ns, int Cin, int Cout, float *dX, int32_t *range_flag, void *stream) {
+static int glm_bwd(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2, int64_t G, int ns, int Cin,
+                   int Cout, const float *xmask, float *dX, int32_t *range_flag, void *stream) {
   if (!dOut || !out || !arg || !Wb2 || !dX || G <= 0 || !hitadv_group_linear_max_supported(Cin, Cout, ns) ||
-      ((uintptr_t)dX & 15) || ((uintptr_t)Wb2 & 15))
+      ((uintptr_t)dX & 15) || ((uintptr_t)Wb2 & 15) || ((uintptr_t)xmask & 15))
     return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
 #define HITADV_GLM_BWD(CI, CO)                                                                                          \
   if (Cin == CI && Cout == CO) {                                                                                        \
-    if (ns == 32) launch_bwd<CI, 32, CO>(dOut, out, arg, Wb2, G, dX, range_flag, s);                                    \
-    else launch_bwd<CI, 64, CO>(dOut, out, arg, Wb2, G, dX, range_flag, s);                                             \
+    if (xmask != nullptr) {                                                                                             \
+      if (ns == 32) launch_bwd<CI, 32, CO, true>(dOut, out, arg, Wb2, G, dX, range_flag, xmask, s);                     \
+      else launch_bwd<CI, 64, CO, true>(dOut, out, arg, Wb2, G, dX, range_flag, xmask, s);                              \
+    } else {                                                                                                            \
+      if (ns == 32) launch_bwd<CI, 32, CO, false>(dOut, out, arg, Wb2, G, dX, range_flag, nullptr, s);                  \
+      else launch_bwd<CI, 64, CO, false>(dOut, out, arg, Wb2, G, dX, range_flag, nullptr, s);                           \
+    }                                                                                                                   \
   }
   HITADV_GLM_BWD(64, 128)
   HITADV_GLM_BWD(128, 128)
@@ -384,4 +409,16 @@ extern "C" int hitadv_group_linear_max_bwd(const float *dOut, const float *out, 
 #undef HITADV_GLM_BWD
   HITADV_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int hitadv_group_linear_max_bwd(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2,
+                                           int64_t G, int ns, int Cin, int Cout, float *dX, int32_t *range_flag, void *stream) {
+  return glm_bwd(dOut, out, arg, Wb2, G, ns, Cin, Cout, nullptr, dX, range_flag, stream);
+}
+
+extern "C" int hitadv_group_linear_max_bwd_masked(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2,
+                                                  int64_t G, int ns, int Cin, int Cout, const float *xmask, float *dX,
+                                                  int32_t *range_flag, void *stream) {
+  if (!xmask) return HITADV_E_ARG;
+  return glm_bwd(dOut, out, arg, Wb2, G, ns, Cin, Cout, xmask, dX, range_flag, stream);
 }

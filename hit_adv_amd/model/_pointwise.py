@@ -93,6 +93,23 @@ class _LinearReLU(torch.autograd.Function):
         return dx, dW, db
 
 
+class _LinearReLUGatedLater(torch.autograd.Function):
+    """``_LinearReLU`` whose consumer applies this layer's ReLU backward itself: the gradient arriving here is already gated by
+    (y > 0) (``ops.group_linear_max(..., relu_input=True)`` does it on the way out of its backward kernel), so the backward
+    pass is the GEMM alone -- the separate pass over the [rows, Cout] gradient and activation is gone."""
+
+    @staticmethod
+    def forward(ctx, x2, W, b):
+        y = torch._addmm_activation(b, x2, W.t(), use_gelu=False)
+        ctx.save_for_backward(W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        W, = ctx.saved_tensors
+        return g.contiguous() @ W, None, None
+
+
 WEIGHT_GRADS = False  # True: the fused layers also return gradients for the (eval-mode) parameters
 
 
@@ -134,10 +151,24 @@ def check_range(device):
 FUSED_GROUP_MAX = True  # last shared layer of a sample-and-group block + max over the neighbours as one fp16x2 MFMA kernel
 
 
-def linear_relu_max_pm(conv, bn, x):
+def linear_relu_then_max_pm(conv_mid, bn_mid, conv, bn, x):
+    """Two shared layers and the max over the neighbours: relu(bn_mid(conv_mid(x))) -> ``linear_relu_max_pm``.  Where the fused
+    last layer applies, the middle layer's ReLU backward rides on that kernel's output (no separate pass over the
+    [.., ns, C] gradient); otherwise the plain composition."""
+    from .. import ops
+    Wm, bm = _folded(conv_mid, bn_mid)
+    W, b = _folded(conv, bn)
+    if (FUSED_GROUP_MAX and x.is_cuda and b is not None and bm is not None and not WEIGHT_GRADS
+            and ops.group_linear_max_supported(W.shape[1], W.shape[0], x.shape[-2])):
+        y = _LinearReLUGatedLater.apply(x.reshape(-1, x.shape[-1]), Wm.detach(), bm.detach()).view(*x.shape[:-1], Wm.shape[0])
+        return linear_relu_max_pm(conv, bn, y, relu_input=True)
+    return linear_relu_max_pm(conv, bn, linear_relu_pm(conv_mid, bn_mid, x))
+
+
+def linear_relu_max_pm(conv, bn, x, relu_input=False):
     """relu(bn(conv(.))) applied to points-major x [..., ns, Cin] followed by the max over the ns neighbours -> [..., Cout]:
     ``hitadv_group_linear_max`` where the shape is supported (no [.., ns, Cout] activation, no ReLU / max passes, a sparse
-    backward), the GEMM + max otherwise."""
+    backward), the GEMM + max otherwise.  ``relu_input``: see ``ops.GroupLinearMax`` (fused path only)."""
     from .. import ops
     W, b = _folded(conv, bn)
     if (FUSED_GROUP_MAX and x.is_cuda and b is not None and not WEIGHT_GRADS
@@ -150,7 +181,8 @@ def linear_relu_max_pm(conv, bn, x):
             if not torch.cuda.is_current_stream_capturing():
                 _PIECE_CACHE[id(conv)] = made
             pieces = made
-        return ops.group_linear_max(x.contiguous(), W, b, flag, pieces=pieces[1:])
+        return ops.group_linear_max(x.contiguous(), W, b, flag, pieces=pieces[1:], relu_input=relu_input)
+    assert not relu_input, "relu_input is a property of the fused path"
     return linear_relu_pm(conv, bn, x).max(dim=-2)[0]
 
 

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from . import _sampling
-from ._pointwise import fast_pm, linear_relu_max_pm, linear_relu_pm, split_first_layer
+from ._pointwise import fast_pm, linear_relu_max_pm, linear_relu_pm, linear_relu_then_max_pm, split_first_layer
 
 
 def index_points(points, idx):
@@ -102,10 +102,15 @@ def _grouped_from_points(self, xyz, points):
     V = torch.addmm(t, new_xyz.reshape(-1, 3), -W[:, :3].t()).view(B, self.npoint, W.shape[0])
     h = ops.group_add_relu(U, V, idx)
     rest = list(zip(self.mlp_convs, self.mlp_bns))[1:]
-    for conv, bn in rest[:-1]:
+    for conv, bn in rest[:-2]:
         h = linear_relu_pm(conv, bn, h)
-    # the last shared layer and the max over the neighbours in one kernel (csrc/group_mlp.hip) where the shape allows
-    return new_xyz.permute(0, 2, 1), linear_relu_max_pm(rest[-1][0], rest[-1][1], h).permute(0, 2, 1)
+    # the last shared layer and the max over the neighbours in one kernel (csrc/group_mlp.hip) where the shape allows; the layer
+    # in front of it hands its ReLU backward to that kernel
+    if len(rest) >= 2:
+        out = linear_relu_then_max_pm(rest[-2][0], rest[-2][1], rest[-1][0], rest[-1][1], h)
+    else:
+        out = linear_relu_max_pm(rest[-1][0], rest[-1][1], h)
+    return new_xyz.permute(0, 2, 1), out.permute(0, 2, 1)
 
 
 PointNetSetAbstraction._grouped_from_points = _grouped_from_points

@@ -808,7 +808,7 @@ class GroupLinearMax(torch.autograd.Function):
     are constants (the folded eval-mode layer); the gradient goes to ``x`` only."""
 
     @staticmethod
-    def forward(ctx, x, Wr, bias, range_flag, W2=None, Wb2=None):
+    def forward(ctx, x, Wr, bias, range_flag, W2=None, Wb2=None, relu_input=False):
         x = _dev(x, "x")
         G, ns, Cin = x.shape
         Cout = Wr.shape[0]
@@ -819,7 +819,10 @@ class GroupLinearMax(torch.autograd.Function):
         arg = torch.empty(G, Cout, device=x.device, dtype=torch.int32)
         _lib.call("hitadv_group_linear_max_fwd", _p(x), _p(W2), _p(bias), G, ns, Cin, Cout, _p(out), _p(arg), _p(range_flag),
                   _stream())
-        ctx.save_for_backward(out, arg, Wb2)
+        # ``relu_input``: x is the ReLU output of the layer in front and the caller wants THAT layer's ReLU backward applied to
+        # the gradient this node returns (dX gated by x > 0 on its way out of the kernel; the producer must then not gate again)
+        ctx.relu_input = bool(relu_input)
+        ctx.save_for_backward(out, arg, Wb2, *((x,) if relu_input else ()))
         ctx.dims = (G, ns, Cin, Cout)
         ctx.range_flag = range_flag
         ctx.mark_non_differentiable(arg)
@@ -827,19 +830,23 @@ class GroupLinearMax(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _ga):
-        out, arg, Wb2 = ctx.saved_tensors
+        out, arg, Wb2 = ctx.saved_tensors[:3]
         G, ns, Cin, Cout = ctx.dims
         dX = torch.empty(G, ns, Cin, device=out.device)
-        _lib.call("hitadv_group_linear_max_bwd", _p(g.contiguous()), _p(out), _p(arg), _p(Wb2), G, ns, Cin, Cout, _p(dX),
-                  _p(ctx.range_flag), _stream())
-        return dX, None, None, None, None, None
+        if ctx.relu_input:
+            _lib.call("hitadv_group_linear_max_bwd_masked", _p(g.contiguous()), _p(out), _p(arg), _p(Wb2), G, ns, Cin, Cout,
+                      _p(ctx.saved_tensors[3]), _p(dX), _p(ctx.range_flag), _stream())
+        else:
+            _lib.call("hitadv_group_linear_max_bwd", _p(g.contiguous()), _p(out), _p(arg), _p(Wb2), G, ns, Cin, Cout, _p(dX),
+                      _p(ctx.range_flag), _stream())
+        return dX, None, None, None, None, None, None
 
 
-def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False, pieces=None):
+def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False, pieces=None, relu_input=False):
     """x [..., ns, Cin] -> relu(max over the ns rows of (x W^T + bias)) [..., Cout]; see ``GroupLinearMax``."""
     lead = x.shape[:-2]
     W2, Wb2 = pieces if pieces is not None else (None, None)  # ``pieces``: (split_weights_f16x2(Wr), split_weights_f16x2(Wr.t())) kept by the caller
-    out, arg = GroupLinearMax.apply(x.reshape(-1, x.shape[-2], x.shape[-1]), Wr, bias, range_flag, W2, Wb2)
+    out, arg = GroupLinearMax.apply(x.reshape(-1, x.shape[-2], x.shape[-1]), Wr, bias, range_flag, W2, Wb2, relu_input)
     out = out.view(*lead, out.shape[-1])
     return (out, arg.view(*lead, arg.shape[-1])) if return_arg else out
 

@@ -508,6 +508,12 @@ int hitadv_group_linear_max_fwd(const float *X, const uint16_t *W2, const float 
                                 float *out, int32_t *arg, int32_t *range_flag, void *stream);
 int hitadv_group_linear_max_bwd(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2, int64_t G, int ns,
                                 int Cin, int Cout, float *dX, int32_t *range_flag, void *stream);
+/* ... with dX also gated by (xmask > 0), xmask [G*ns, Cin] = the layer's input when that is the ReLU output of the shared layer in
+ * front (model/pointnet2_utils.py:197-200: the MLP is conv -> bn -> relu per layer): that layer's ReLU backward pass happens on
+ * the way out of this kernel. */
+int hitadv_group_linear_max_bwd_masked(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2, int64_t G,
+                                       int ns, int Cin, int Cout, const float *xmask, float *dX, int32_t *range_flag,
+                                       void *stream);
 
 /* ------------------------------------------------------------------ fp32-accurate GEMMs on the fp16 matrix cores
  * The victims' wide 1x1 convolutions are GEMMs over [B*N] rows (PyTorch-ROCm: hipBLASLt's f32 GEMM, which runs at the f32

@@ -868,6 +868,12 @@ def test_group_linear_max_forward_and_backward(A, G, ns, Cin, Cout):
     assert int(flag.item()) == 0
     out2, arg2 = A.group_linear_max(cu(x), cu(Wr), cu(bias), flag, return_arg=True)
     assert torch.equal(out2, out) and torch.equal(arg2, arg)  # bitwise reproducible
+    # relu_input: the same gradient gated by (x > 0) on its way out of the kernel (x is a ReLU output: a third of it is zero)
+    xm = cu(x).requires_grad_()
+    om = A.group_linear_max(xm, cu(Wr), cu(bias), flag, relu_input=True)
+    (om * cu(wgt)).sum().backward()
+    assert torch.equal(om, out) and torch.equal(xm.grad, torch.where(xm.detach() > 0, xg.grad, torch.zeros_like(xg.grad)))
+    assert float((x > 0).float().mean()) < 0.7
 
 
 def test_linear_max_fwd_f16x2_raises_its_range_flag(A):
