@@ -96,6 +96,11 @@ def main():
         ix = torch.empty(B, N, K, device='cuda', dtype=torch.int64)
         us = timed(lambda s=s0: lib.hitadv_knn_points(p(x), p(x), B, N, N, K, 0, p(d), p(ix), 1, s), max(20, a.reps // 4))
         out['knn_K%d' % K] = dict(us=round(us, 2), Gpairs_per_s=round(B * N * N / us / 1e3, 1))
+        if K in (6, 17):  # its backward (query-side gather + reference-side owner-computes scatter)
+            gd = torch.randn(B, N, K, generator=g).cuda()
+            g1, g2 = torch.empty_like(x), torch.empty_like(x)
+            us = timed(lambda s=s0: lib.hitadv_knn_points_bwd(p(x), p(x), p(ix), 1, p(gd), B, N, N, K, p(g1), p(g2), s), max(20, a.reps // 4))
+            out['knn_bwd_K%d' % K] = dict(us=round(us, 2))
     ori = x.transpose(1, 2).contiguous()
     central = ori[:, :, :C].contiguous()
     Pm = (torch.rand(B, C, 3, generator=g) * 0.55).cuda()
