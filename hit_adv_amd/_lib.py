@@ -53,6 +53,9 @@ PROTOTYPES = {
     "hitadv_group_linear_max_bwd": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P],
     "hitadv_group_linear_max_bwd_masked": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_gemm_f16x2_supported": [_I, _I],
+    "hitadv_group_linear_max_g16_supported": [_I, _I, _I],
+    "hitadv_group_linear_max_g16_fwd": [_P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],
+    "hitadv_group_linear_max_g16_bwd": [_P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_split_rows_f16x2": [_P, _I, _I, _P, _P, _P],
     "hitadv_gemm_f16x2": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P],
     "hitadv_linear_lrelu_pool_scratch": [_I, _I, _I],

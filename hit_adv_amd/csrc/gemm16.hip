@@ -127,6 +127,35 @@ struct PoolBwdA {
   }
 };
 
+// d z[p,c] of  out[g,c] = relu(max_j z[g NS + j, c] + b[c]):  dm[g,c] where arg[g,c] == j (dm = d out gated by out > 0, [G,C]).
+template <int U, int NS>
+struct GroupBwdA {
+  static constexpr int RSTEP = G16_BM / U;
+  const float *dm;      // [G][C]
+  const int32_t *arg;   // [G][C]
+  int C;
+  struct Regs {
+    float4 d[U];
+    int4 a[U];
+  };
+  __device__ __forceinline__ void fetch(Regs &r, const G16Tile &t, int k0, int tid) const {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = t.row0 + min((tid >> 3) + RSTEP * u, t.rows - 1);
+      const size_t o = (size_t)(row / NS) * C + k0 + 4 * (tid & 7);
+      r.d[u] = *reinterpret_cast<const float4 *>(dm + o);
+      r.a[u] = *reinterpret_cast<const int4 *>(arg + o);
+    }
+  }
+  __device__ __forceinline__ void values(const Regs &r, const G16Tile &t, int u, int tid, float (&o)[4]) const {
+    const int j = (int)((t.row0 + (tid >> 3) + RSTEP * u) % NS);
+    o[0] = r.a[u].x == j ? r.d[u].x : 0.f;
+    o[1] = r.a[u].y == j ? r.d[u].y : 0.f;
+    o[2] = r.a[u].z == j ? r.d[u].z : 0.f;
+    o[3] = r.a[u].w == j ? r.d[u].w : 0.f;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------- epilogues
 // A wave's accumulators: acc[rt][ct][i] = row 16 RT wr + 16 rt + 4 (lane / 16) + i, column 64 wc + 16 ct + lane % 16 of the block
 // (RT row tiles per wave: 4 with eight waves per block, 8 with four).
@@ -134,6 +163,7 @@ struct PlainEpi {
   float *C;
   const float *bias;
   int N, relu;
+  const float *gate = nullptr;  // [M,N] or NULL: the result is zeroed where gate <= 0 (the ReLU backward of the layer in front)
   template <int RT>
   __device__ __forceinline__ void operator()(const G16Tile &t, f32x4m (&acc)[RT][4], int wr, int wc, int lane, char *) const {
     const int l16 = lane & 15, g4 = lane >> 4;
@@ -148,8 +178,59 @@ struct PlainEpi {
           const int rr = 16 * RT * wr + 16 * rt + 4 * g4 + i;
           float v = acc[rt][ct][i] + bv;
           v = relu ? fmaxf(v, 0.f) : v;
-          if (rr < t.rows) C[(size_t)(t.row0 + rr) * N + col] = v;
+          if (rr < t.rows) {
+            const size_t o = (size_t)(t.row0 + rr) * N + col;
+            if (gate != nullptr) v = gate[o] > 0.f ? v : 0.f;
+            C[o] = v;
+          }
         }
+    }
+  }
+};
+
+// out[g,c] = relu(max_j z[g NS + j, c] + bias[c]), arg[g,c] = the lowest such j: a wave's 64 rows hold 64 / NS whole groups, so
+// the reduction stays inside the wave (rows of a column: 16 per lane, four lane groups).
+template <int NS>
+struct GroupMaxEpi {
+  const float *bias;
+  float *out;
+  int32_t *arg;
+  int C;
+  template <int RT>
+  __device__ __forceinline__ void operator()(const G16Tile &t, f32x4m (&acc)[RT][4], int wr, int wc, int lane, char *) const {
+    static_assert(RT == 4 && (NS == 32 || NS == 64), "a wave tile of 64 rows, groups of 32 or 64 rows");
+    constexpr int TPG = NS / 16;  // 16-row tiles per group
+    const int l16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int col = t.col0 + 64 * wc + 16 * ct + l16;
+      const float bv = bias[col];
+#pragma unroll
+      for (int h = 0; h < 64 / NS; ++h) {
+        float best = -__builtin_inff();
+        int bi = 0;
+#pragma unroll
+        for (int r = 0; r < TPG; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = acc[h * TPG + r][ct][i];
+            const bool gt = v > best;  // a lane's rows ascend: the first maximum stays
+            best = gt ? v : best;
+            bi = gt ? 16 * r + 4 * g4 + i : bi;
+          }
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+          const float ov = __shfl_xor(best, m, 64);
+          const int oi = __shfl_xor(bi, m, 64);
+          if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+        }
+        const int rr = 64 * wr + h * NS;
+        if (g4 == 0 && rr < t.rows) {
+          const size_t o = (size_t)((t.row0 + rr) / NS) * C + col;
+          out[o] = fmaxf(best + bv, 0.f);
+          arg[o] = bi;
+        }
+      }
     }
   }
 };
@@ -465,6 +546,35 @@ extern "C" int hitadv_linear_lrelu_pool_bwd(const float *gout, const int32_t *ar
   const PoolBwdA<G16_U> ap{bits, gout, arg, C, slope, 1.f / (float)npts};
   const PlainEpi epi{dX, nullptr, Cin, 0};
   return launch_gemm16<PoolBwdA<G16_U>, PlainEpi, false>(ap, Wtp, B, npts, Cin, C, epi, range_flag, (hipStream_t)stream);
+}
+
+extern "C" int hitadv_group_linear_max_g16_supported(int Cin, int Cout, int ns) {
+  return ((ns == 32 || ns == 64) && hitadv_gemm_f16x2_supported(Cout, Cin) && hitadv_gemm_f16x2_supported(Cin, Cout)) ? 1 : 0;
+}
+
+extern "C" int hitadv_group_linear_max_g16_fwd(const float *X, const uint16_t *Wp, const float *bias, int64_t G, int ns, int Cin,
+                                               int Cout, float *out, int32_t *arg, int32_t *range_flag, void *stream) {
+  if (!X || !Wp || !bias || !out || !arg || G <= 0 || !hitadv_group_linear_max_g16_supported(Cin, Cout, ns) ||
+      !g16_shape_ok(G * ns, Cout, Cin) || ((uintptr_t)X & 15) || ((uintptr_t)Wp & 15))
+    return HITADV_E_ARG;
+  using AP = PlainA<false, G16_U>;
+  const AP ap{X, nullptr, Cin};
+  hipStream_t s = (hipStream_t)stream;
+  if (ns == 32) return launch_gemm16<AP, GroupMaxEpi<32>, false>(ap, Wp, 1, (int)(G * ns), Cout, Cin, GroupMaxEpi<32>{bias, out, arg, Cout}, range_flag, s);
+  return launch_gemm16<AP, GroupMaxEpi<64>, false>(ap, Wp, 1, (int)(G * ns), Cout, Cin, GroupMaxEpi<64>{bias, out, arg, Cout}, range_flag, s);
+}
+
+extern "C" int hitadv_group_linear_max_g16_bwd(const float *dm, const int32_t *arg, const uint16_t *Wtp, int64_t G, int ns, int Cin,
+                                               int Cout, const float *xmask, float *dX, int32_t *range_flag, void *stream) {
+  if (!dm || !arg || !Wtp || !dX || G <= 0 || !hitadv_group_linear_max_g16_supported(Cin, Cout, ns) ||
+      !g16_shape_ok(G * ns, Cin, Cout) || ((uintptr_t)dm & 15) || ((uintptr_t)arg & 15) || ((uintptr_t)Wtp & 15))
+    return HITADV_E_ARG;
+  PlainEpi epi{dX, nullptr, Cin, 0};
+  epi.gate = xmask;
+  hipStream_t s = (hipStream_t)stream;
+  if (ns == 32)
+    return launch_gemm16<GroupBwdA<G16_U, 32>, PlainEpi, false>(GroupBwdA<G16_U, 32>{dm, arg, Cout}, Wtp, 1, (int)(G * ns), Cin, Cout, epi, range_flag, s);
+  return launch_gemm16<GroupBwdA<G16_U, 64>, PlainEpi, false>(GroupBwdA<G16_U, 64>{dm, arg, Cout}, Wtp, 1, (int)(G * ns), Cin, Cout, epi, range_flag, s);
 }
 
 #ifdef HITADV_G16_TUNE

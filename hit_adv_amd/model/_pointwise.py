@@ -159,7 +159,8 @@ def linear_relu_then_max_pm(conv_mid, bn_mid, conv, bn, x):
     Wm, bm = _folded(conv_mid, bn_mid)
     W, b = _folded(conv, bn)
     if (FUSED_GROUP_MAX and x.is_cuda and b is not None and bm is not None and not WEIGHT_GRADS
-            and ops.group_linear_max_supported(W.shape[1], W.shape[0], x.shape[-2])):
+            and (ops.group_linear_max_supported(W.shape[1], W.shape[0], x.shape[-2])
+                 or ops.group_linear_max_g16_supported(W.shape[1], W.shape[0], x.shape[-2]))):
         y = _LinearReLUGatedLater.apply(x.reshape(-1, x.shape[-1]), Wm.detach(), bm.detach()).view(*x.shape[:-1], Wm.shape[0])
         return linear_relu_max_pm(conv, bn, y, relu_input=True)
     return linear_relu_max_pm(conv, bn, linear_relu_pm(conv_mid, bn_mid, x))
@@ -182,7 +183,19 @@ def linear_relu_max_pm(conv, bn, x, relu_input=False):
                 _PIECE_CACHE[id(conv)] = made
             pieces = made
         return ops.group_linear_max(x.contiguous(), W, b, flag, pieces=pieces[1:], relu_input=relu_input)
-    assert not relu_input, "relu_input is a property of the fused path"
+    if (FUSED_GROUP_MAX and x.is_cuda and b is not None and not WEIGHT_GRADS
+            and ops.group_linear_max_g16_supported(W.shape[1], W.shape[0], x.shape[-2])):
+        # widths the register-resident kernels do not cover (PCT's second Local_op, 256 -> 256): the tiled GEMM core
+        flag = range_flag(x.device)
+        key = ('g16', W.data_ptr(), W._version)
+        pieces = _PIECE_CACHE.get(id(conv))
+        if pieces is None or pieces[0] != key:
+            made = (key, ops.split_rows_f16x2(W, flag), ops.split_rows_f16x2(W.t().contiguous(), flag))
+            if not torch.cuda.is_current_stream_capturing():
+                _PIECE_CACHE[id(conv)] = made
+            pieces = made
+        return ops.group_linear_max_g16(x.contiguous(), pieces[1], pieces[2], b, flag, relu_input=relu_input)
+    assert not relu_input, "relu_input is a property of the fused paths"
     return linear_relu_pm(conv, bn, x).max(dim=-2)[0]
 
 

@@ -842,6 +842,47 @@ class GroupLinearMax(torch.autograd.Function):
         return dX, None, None, None, None, None, None
 
 
+def group_linear_max_g16_supported(Cin, Cout, ns):
+    """The same fused layer on the tiled GEMM core (csrc/gemm16.hip) -- the widths the register-resident kernels do not cover."""
+    return bool(_lib.load().hitadv_group_linear_max_g16_supported(int(Cin), int(Cout), int(ns)))
+
+
+class GroupLinearMaxG16(torch.autograd.Function):
+    """``GroupLinearMax`` on ``gemm_f16x2_k``: Wp = split_rows_f16x2(Wr [Cout,Cin]), Wtp = split_rows_f16x2(Wr.t())."""
+
+    @staticmethod
+    def forward(ctx, x, Wp, Wtp, bias, range_flag, relu_input=False):
+        x = _dev(x, "x")
+        G, ns, Cin = x.shape
+        Cout = Wp.shape[1]
+        out = torch.empty(G, Cout, device=x.device)
+        arg = torch.empty(G, Cout, device=x.device, dtype=torch.int32)
+        _lib.call("hitadv_group_linear_max_g16_fwd", _p(x), _p(Wp), _p(bias), G, ns, Cin, Cout, _p(out), _p(arg), _p(range_flag),
+                  _stream())
+        ctx.relu_input = bool(relu_input)
+        ctx.save_for_backward(out, arg, Wtp, *((x,) if relu_input else ()))
+        ctx.dims, ctx.range_flag = (G, ns, Cin, Cout), range_flag
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, g, _ga):
+        out, arg, Wtp = ctx.saved_tensors[:3]
+        G, ns, Cin, Cout = ctx.dims
+        dm = torch.where(out > 0, g, torch.zeros_like(g)).contiguous()  # [G,Cout]: the layer's own ReLU
+        dX = torch.empty(G, ns, Cin, device=out.device)
+        _lib.call("hitadv_group_linear_max_g16_bwd", _p(dm), _p(arg), _p(Wtp), G, ns, Cin, Cout,
+                  _p(ctx.saved_tensors[3]) if ctx.relu_input else None, _p(dX), _p(ctx.range_flag), _stream())
+        return dX, None, None, None, None, None
+
+
+def group_linear_max_g16(x, Wp, Wtp, bias, range_flag=None, return_arg=False, relu_input=False):
+    lead = x.shape[:-2]
+    out, arg = GroupLinearMaxG16.apply(x.reshape(-1, x.shape[-2], x.shape[-1]), Wp, Wtp, bias, range_flag, relu_input)
+    out = out.view(*lead, out.shape[-1])
+    return (out, arg.view(*lead, arg.shape[-1])) if return_arg else out
+
+
 def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False, pieces=None, relu_input=False):
     """x [..., ns, Cin] -> relu(max over the ns rows of (x W^T + bias)) [..., Cout]; see ``GroupLinearMax``."""
     lead = x.shape[:-2]

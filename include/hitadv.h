@@ -532,6 +532,17 @@ int hitadv_group_linear_max_bwd_masked(const float *dOut, const float *out, cons
  *   hitadv_linear_lrelu_pool_bwd   dX [B*npts,Cin] = G Wtp^T with G[p,c] = s(z[p,c]) (gout[b,C+c] / npts + [arg[b,c] == p]
  *                               gout[b,c]) rebuilt on the fly from bits / arg (s = 1 or the slope); Wtp = pieces of Wt [Cin,C].
  * range_flag as for hitadv_linear_max_fwd_f16x2 (may be NULL). */
+/*   hitadv_group_linear_max_g16_*   hitadv_group_linear_max_fwd / _bwd_masked (below) for the widths its register-resident form
+ *                               does not cover (PCT's second Local_op: 256 -> 256 over 32 neighbours, model/pct_cls.py:14-24), on
+ *                               this GEMM core: the forward epilogue reduces max / arg-max over each group of ns rows inside the
+ *                               wave that holds them; the backward operand is rebuilt from arg and dm = dOut gated by out > 0
+ *                               ([G,Cout], the caller's one small element-wise pass); xmask [G*ns,Cin] or NULL gates dX as in
+ *                               hitadv_group_linear_max_bwd_masked.  Wp / Wtp: hitadv_split_rows_f16x2 of Wr [Cout,Cin] / Wt. */
+int hitadv_group_linear_max_g16_supported(int Cin, int Cout, int ns);
+int hitadv_group_linear_max_g16_fwd(const float *X, const uint16_t *Wp, const float *bias, int64_t G, int ns, int Cin, int Cout,
+                                    float *out, int32_t *arg, int32_t *range_flag, void *stream);
+int hitadv_group_linear_max_g16_bwd(const float *dm, const int32_t *arg, const uint16_t *Wtp, int64_t G, int ns, int Cin, int Cout,
+                                    const float *xmask, float *dX, int32_t *range_flag, void *stream);
 int hitadv_gemm_f16x2_supported(int N, int K);
 int hitadv_split_rows_f16x2(const float *W, int N, int K, uint16_t *Wp, int32_t *range_flag, void *stream);
 int hitadv_gemm_f16x2(const float *X, const float *mask, const uint16_t *Wp, const float *bias, int64_t M, int N, int K, int relu,

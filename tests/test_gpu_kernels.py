@@ -882,6 +882,48 @@ def test_group_linear_max_forward_and_backward(A, G, ns, Cin, Cout):
     assert float((x > 0).float().mean()) < 0.7
 
 
+@pytest.mark.parametrize("G,ns,Cin,Cout", [(300, 32, 256, 256), (70, 64, 128, 384), (9, 32, 128, 128)])
+def test_group_linear_max_on_the_gemm_core(A, G, ns, Cin, Cout):
+    """The same fused layer on the tiled GEMM core (the widths the register-resident kernels do not cover): values, winners
+    (lowest row on ties), the routed gradient, the gradient gated by the ReLU of the layer in front, reproducibility -- and,
+    where both forms exist, the same winners and values to fp32 roundoff."""
+    g = torch.Generator().manual_seed(G * 3 + ns + Cout)
+    x = torch.randn(G, ns, Cin, generator=g).relu()
+    x[0, 5] = x[0, 2]
+    Wr = torch.randn(Cout, Cin, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g) * 0.3
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    assert A.group_linear_max_g16_supported(Cin, Cout, ns)
+    Wp, Wtp = A.split_rows_f16x2(cu(Wr), flag), A.split_rows_f16x2(cu(Wr.t().contiguous()), flag)
+    xg = cu(x).requires_grad_()
+    out, arg = A.group_linear_max_g16(xg, Wp, Wtp, cu(bias), flag, return_arg=True)
+    y = x.double() @ Wr.double().t() + bias.double()
+    ref = y.max(dim=1).values.clamp_min(0.)
+    s = float(ref.abs().max())
+    close(out / s, ref.float() / s, rtol=0, atol=2e-6, what='group_linear_max_g16 vs float64 (over the output scale)')
+    top2 = y.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4 * s
+    assert torch.equal(arg.cpu().long()[clear], y.argmax(dim=1)[clear])
+    assert int((arg[0] == 5).sum()) == 0 and int(arg.min()) >= 0 and int(arg.max()) < ns
+    wgt = torch.randn(G, Cout, generator=g)
+    (out * cu(wgt)).sum().backward()
+    gd = torch.zeros(G, ns, Cin, dtype=torch.float64)
+    contrib = (wgt.double() * (out.detach().cpu().double() > 0)).unsqueeze(-1) * Wr.double().unsqueeze(0)
+    gd.scatter_add_(1, arg.cpu().long().unsqueeze(-1).expand(-1, -1, Cin), contrib)
+    sg = float(gd.abs().max())
+    close(xg.grad / sg, gd.float() / sg, rtol=0, atol=2e-6, what='group_linear_max_g16 backward vs float64 (over the gradient scale)')
+    xm = cu(x).requires_grad_()
+    om, am = A.group_linear_max_g16(xm, Wp, Wtp, cu(bias), flag, return_arg=True, relu_input=True)
+    (om * cu(wgt)).sum().backward()
+    assert torch.equal(om, out) and torch.equal(am, arg)
+    assert torch.equal(xm.grad, torch.where(xm.detach() > 0, xg.grad, torch.zeros_like(xg.grad)))
+    if A.group_linear_max_supported(Cin, Cout, ns):
+        o2, a2 = A.group_linear_max(cu(x), cu(Wr), cu(bias), flag, return_arg=True)
+        close(o2, out, rtol=0, atol=2e-6 * s)
+        assert torch.equal(a2.cpu()[clear], arg.cpu()[clear])
+    assert int(flag.item()) == 0
+
+
 def test_linear_max_fwd_f16x2_raises_its_range_flag(A):
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2 * 64, 128, generator=g).relu()
