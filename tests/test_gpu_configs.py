@@ -234,7 +234,12 @@ def test_pct_gradient_vs_float64_module_on_the_same_tables():
     feed = _sampling.feed_for(gm, 2, 1024, 1, 'cuda')
     log, saved = _record_tables(PCT, ['fps', 'knn_point'])
     winners, pre_pool = [], []
-    real_max, real_pool, real_group = torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max
+    real_max, real_pool, real_group, real_g16 = torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16
+
+    def spy_g16(xx, Wp, Wtp, bias, flag=None, return_arg=False, **kw):  # the second Local_op's last layer: the tiled GEMM core
+        out, arg = real_g16(xx, Wp, Wtp, bias, flag, return_arg=True, **kw)
+        winners.append(arg.detach().cpu().long())
+        return (out, arg) if return_arg else out
 
     def spy_group(xx, Wr, bias, flag=None, return_arg=False, **kw):  # Local_op's last layer + max over the neighbours, fused
         out, arg = real_group(xx, Wr, bias, flag, return_arg=True, **kw)
@@ -253,13 +258,13 @@ def test_pct_gradient_vs_float64_module_on_the_same_tables():
         pre_pool.append(Z.detach().cpu())
         return out
     try:
-        torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max = spy_max, spy_pool, spy_group
+        torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16 = spy_max, spy_pool, spy_group, spy_g16
         xg = x.cuda().requires_grad_()
         with _sampling.using(feed):
             logits = gm(xg)
         (logits * w.cuda()).sum().backward()
     finally:
-        torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max = real_max, real_pool, real_group
+        torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16 = real_max, real_pool, real_group, real_g16
         _restore(PCT, saved)
     assert len(log['fps']) == 2 and len(log['knn_point']) == 2
     assert [tuple(t.shape) for t in winners] == [(2, 512, 128), (2, 256, 256), (2, 1024)] and len(pre_pool) == 1
