@@ -5,8 +5,11 @@
 // Arithmetic: V1's fp16x2 scheme (csrc/victim_bf3.hip): every operand is two fp16 pieces, a = a1 + 2^-11 a2 (+ <= 2^-24 |a|),
 // three exact fp16 x fp16 products per useful one accumulate in fp32 (v_mfma_f32_16x16x32_f16) into two accumulator sets
 // (one per power of two), joined once by fmaf.  Error against float64: below the library's f32 GEMM (tools/split_gemm_probe.py:
-// 3.6e-7 against 1.0e-6 of the scale at K = 512), at 2-3x its speed: hipBLASLt's f32 GEMM runs at the f32 MFMA rate (120-140
-// TFLOP/s measured here), this kernel executes three times the flop at ~8x the rate.
+// 3.6e-7 against 1.0e-6 of the scale at K = 512), at 1.6x its speed at K >= 256 (172 against 272 us for 32768 x 512 x 1024:
+// hipBLASLt's f32 GEMM runs at the f32 MFMA rate, this kernel executes three times the flop at the rate hipBLASLt's own fp16
+// kernel reaches at this K).  The kernel is bound by operand delivery, not by the three products (profiles/r03_g16_ablation.json).
+// The same core carries the last shared layer + max over the neighbours of a sample-and-group block for the widths
+// csrc/group_mlp.hip does not cover (GroupMaxEpi / GroupBwdA).
 //
 //   gemm_f16x2_k<AProd, Epi>   C-tile 256 x 128 per block of 8 waves (4 x 2, a wave owns 64 x 64 = 16 MFMA tiles x 2 accumulator
 //                              sets = 128 VGPRs), K in steps of 32 (one MFMA slice) through a two-stage LDS ring: the A operand
@@ -33,7 +36,7 @@ __device__ __forceinline__ f16x8m as_f16x8m(uint4 u) { return __builtin_bit_cast
 constexpr int G16_BM = 256, G16_BN = 128, G16_KS = 32, G16_RS = 64;
 constexpr int G16_APIECE = G16_BM * G16_RS;
 constexpr int G16_BPIECE = G16_BN * G16_RS;
-constexpr int G16_STAGE = 2 * G16_APIECE + 2 * G16_BPIECE;  // 61,440 bytes; two stages
+constexpr int G16_STAGE = 2 * G16_APIECE + 2 * G16_BPIECE;  // 49,152 bytes; two stages
 constexpr float G16_SCALE = 2048.f;
 // byte offset of 16-byte chunk c of LDS row r (see the header)
 __device__ __forceinline__ int g16_off(int r, int c) { return r * G16_RS + 16 * (c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3)); }
