@@ -53,6 +53,8 @@ PROTOTYPES = {
     "hitadv_group_linear_max_bwd": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P],
     "hitadv_group_linear_max_bwd_masked": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_gemm_f16x2_supported": [_I, _I],
+    "hitadv_bmm_f32_supported": [_I, _I, _I],
+    "hitadv_bmm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hitadv_group_linear_max_g16_supported": [_I, _I, _I],
     "hitadv_group_linear_max_g16_fwd": [_P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_group_linear_max_g16_bwd": [_P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],

@@ -892,6 +892,52 @@ def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False, pieces=None
     return (out, arg.view(*lead, arg.shape[-1])) if return_arg else out
 
 
+def bmm_supported(M, N, K):
+    return bool(_lib.load().hitadv_bmm_f32_supported(int(M), int(N), int(K)))
+
+
+def _bmm_raw(a, b, ta, tb):
+    Bn = a.shape[0]
+    M, K = (a.shape[2], a.shape[1]) if ta else (a.shape[1], a.shape[2])
+    N = b.shape[1] if tb else b.shape[2]
+    c = torch.empty(Bn, M, N, device=a.device)
+    _lib.call("hitadv_bmm_f32", _p(a), _p(b), _p(c), Bn, M, N, K, 1 if ta else 0, 1 if tb else 0, _stream())
+    return c
+
+
+class Bmm(torch.autograd.Function):
+    """C[b] = op(a[b]) op(b[b]) for small batched fp32 matrices (hitadv_bmm_f32: exact fp32 chains, 64 x 64 tiles); ``ta`` / ``tb``:
+    the operand is STORED transposed ([K,M] / [N,K]).  The backward pass is four more calls of the same kernel."""
+
+    @staticmethod
+    def forward(ctx, a, b, ta, tb):
+        a, b = _dev(a, "a").contiguous(), _dev(b, "b").contiguous()
+        ctx.save_for_backward(a, b)
+        ctx.t = (bool(ta), bool(tb))
+        return _bmm_raw(a, b, ta, tb)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ta, tb = ctx.t
+        g = g.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _bmm_raw(b, g, tb, True) if ta else _bmm_raw(g, b, False, not tb)
+        if ctx.needs_input_grad[1]:
+            db = _bmm_raw(g, a, True, ta) if tb else _bmm_raw(a, g, not ta, False)
+        return da, db, None, None
+
+
+def bmm(a, b, trans_a=False, trans_b=False):
+    """``torch.bmm(op(a), op(b))`` where every dimension allows the tiled kernel (multiples of 64 / 64 / 32), else torch's."""
+    M, K = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
+    N = b.shape[1] if trans_b else b.shape[2]
+    if a.is_cuda and a.dtype == torch.float32 and min(M, N, K) >= 64 and M % 64 == 0 and N % 64 == 0 and K % 64 == 0:
+        return Bmm.apply(a, b, trans_a, trans_b)  # K % 64: the backward products contract over M or N and tile over K
+    return torch.bmm(a.transpose(1, 2) if trans_a else a, b.transpose(1, 2) if trans_b else b)
+
+
 def gemm_f16x2_supported(N, K):
     """Whether ``gemm_f16x2`` / ``linear_lrelu_pool`` are built for N output columns over a K-deep contraction."""
     return bool(_lib.load().hitadv_gemm_f16x2_supported(int(N), int(K)))

@@ -554,6 +554,14 @@ int hitadv_linear_lrelu_pool_fwd(const float *X, const uint16_t *Wp, const float
 int hitadv_linear_lrelu_pool_bwd(const float *gout, const int32_t *arg, const uint32_t *bits, const uint16_t *Wtp, int B, int npts,
                                  int Cin, int C, float slope, float *dX, int32_t *range_flag, void *stream);
 
+/* Small batched fp32 products for PCT's offset attention (model/pct_cls.py:111-139 and its backward: energy = q k, x_r = v attention):
+ * C[b] [M,N] = op(A[b]) op(B[b]) for `batches` contiguous matrices; trans_a: A is stored [K,M] (else [M,K]); trans_b: B is stored
+ * [N,K] (else [K,N]).  Exact fp32 FMA chains (k ascending) on the f32 matrix cores, 64 x 64 tiles: the library's batched GEMM
+ * runs such a call on `batches` workgroups.  M, N multiples of 64, K a multiple of 32 (hitadv_bmm_f32_supported). */
+int hitadv_bmm_f32_supported(int M, int N, int K);
+int hitadv_bmm_f32(const float *A, const float *B, float *C, int batches, int M, int N, int K, int trans_a, int trans_b,
+                   void *stream);
+
 /* G independent attacks STACKED (HiT_ADV.attack_many on the PointNet engine: one victim pass over the G*B clouds): the three
  * launches around that pass for all G groups at once.  Every per-cloud argument is the group-0 pointer of a buffer that
  * holds the G groups' rows one after the other (B clouds each); every per-group scalar or scratch likewise, with the stride

@@ -1130,6 +1130,31 @@ def test_packed_pieces_equal_the_split_in_v1(A, B, Np):
     view.check_range()
 
 
+@pytest.mark.parametrize("Bn,M,N,K,ta,tb", [(3, 256, 256, 64, False, True), (2, 256, 256, 256, True, False), (5, 64, 128, 192, False, False),
+                                           (1, 128, 64, 64, True, True), (32, 256, 64, 256, False, False)])
+def test_bmm_matches_float64_and_autograd(A, Bn, M, N, K, ta, tb):
+    """The tiled batched product (PCT's attention blocks) against float64, all four storage combinations, and its backward --
+    four more calls of the same kernel -- against autograd through torch.bmm; bitwise reproducible."""
+    g = torch.Generator().manual_seed(M + N + K + Bn)
+    a = torch.randn(Bn, *((K, M) if ta else (M, K)), generator=g)
+    b = torch.randn(Bn, *((N, K) if tb else (K, N)), generator=g)
+    w = torch.randn(Bn, M, N, generator=g)
+    ad, bd = a.double().requires_grad_(), b.double().requires_grad_()
+    ref = torch.bmm(ad.transpose(1, 2) if ta else ad, bd.transpose(1, 2) if tb else bd)
+    (ref * w.double()).sum().backward()
+    ag, bg = cu(a).requires_grad_(), cu(b).requires_grad_()
+    out = A.bmm(ag, bg, ta, tb)
+    assert out.shape == (Bn, M, N)
+    close(out, ref.detach().float(), rtol=0, atol=2e-6 * float(ref.detach().abs().max()))
+    (out * cu(w)).sum().backward()
+    close(ag.grad, ad.grad.float(), rtol=0, atol=2e-6 * float(ad.grad.abs().max()))
+    close(bg.grad, bd.grad.float(), rtol=0, atol=2e-6 * float(bd.grad.abs().max()))
+    assert torch.equal(out, A.bmm(cu(a), cu(b), ta, tb))
+    # shapes the tiles do not cover go to torch.bmm
+    x, y = cu(torch.randn(2, 10, 7, generator=g)), cu(torch.randn(2, 7, 5, generator=g))
+    assert torch.equal(A.bmm(x, y), torch.bmm(x, y))
+
+
 @pytest.mark.parametrize("M,K,N", [(1000, 64, 128), (4096, 512, 1024), (777, 1024, 512), (3, 32, 128), (70000, 128, 256)])
 def test_gemm_f16x2_is_fp32_accurate(A, M, K, N):
     """The fp16x2 GEMM (two fp16 pieces per operand, three exact products) against float64: no further from it than torch's
