@@ -199,6 +199,34 @@ def linear_relu_max_pm(conv, bn, x, relu_input=False):
     return linear_relu_pm(conv, bn, x).max(dim=-2)[0]
 
 
+FUSED_EMBEDDING_POOL = True  # a wide layer + LeakyReLU + pooling over the points as one fp16x2 GEMM kernel (csrc/gemm16.hip)
+
+
+def linear_lrelu_maxpool_pm(conv, bn, x, slope=0.2):
+    """max over the points of lrelu(bn(conv(x))) for points-major x [B,n,Cin] -> [B,Cout] (PCT's ``conv_fuse`` + LeakyReLU +
+    ``adaptive_max_pool1d``, model/pct_cls.py:65-68): ``hitadv_linear_lrelu_pool`` where the widths allow -- the [B,n,Cout]
+    activation never exists, forward or backward --, else the GEMM + ``ops.lrelu_pool``."""
+    from .. import ops
+    W, b = _folded(conv, bn)
+    B, n, Cin = x.shape
+    C = W.shape[0]
+    if (FUSED_EMBEDDING_POOL and x.is_cuda and b is not None and not WEIGHT_GRADS and ops.gemm_f16x2_supported(C, Cin)
+            and ops.gemm_f16x2_supported(Cin, C)):
+        flag = range_flag(x.device)
+        key = ('pool', W.data_ptr(), W._version)
+        pieces = _PIECE_CACHE.get(id(conv))
+        if pieces is None or pieces[0] != key:
+            made = (key, ops.split_rows_f16x2(W, flag), ops.split_rows_f16x2(W.t().contiguous(), flag))
+            if not torch.cuda.is_current_stream_capturing():
+                _PIECE_CACHE[id(conv)] = made
+            pieces = made
+        return ops.linear_lrelu_pool(x.reshape(B * n, Cin), pieces[1], pieces[2], b, B, n, slope, flag)[:, :C]
+    z = F.linear(x, W, b)
+    if x.is_cuda and ops.lrelu_pool_supported(C):
+        return ops.lrelu_pool(z.contiguous(), slope)[:, :C]
+    return F.leaky_relu(z, negative_slope=slope).max(dim=1)[0]
+
+
 def split_first_layer(conv, bn, n_rel):
     """The first shared layer of a sample-and-group block, W [rel ; rest] + t with rel = (neighbour - centre)[:n_rel],
     as the pair (W, t) of the folded layer: the caller forms U = [x_j ; rest_j] W^T per POINT and V = -c_i W[:, :n_rel]^T

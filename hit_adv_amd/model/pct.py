@@ -18,7 +18,8 @@ import torch.nn.functional as F
 
 from .. import ops
 from . import _sampling
-from ._pointwise import conv1x1, fast_pm, linear_pm, linear_relu_max_pm, linear_relu_pm, split_first_layer
+from ._pointwise import (conv1x1, fast_pm, linear_lrelu_maxpool_pm, linear_pm, linear_relu_max_pm, linear_relu_pm,
+                         split_first_layer)
 from .pointnet2 import index_points
 
 
@@ -174,11 +175,8 @@ class Pct(nn.Module):
         h = linear_relu_pm(self.conv2, self.bn2, linear_relu_pm(self.conv1, self.bn1, xyz))
         new_xyz, p0 = self.gather_local_0.from_points(xyz, h, 512, 32)
         new_xyz, p1 = self.gather_local_1.from_points(new_xyz, p0, 256, 32)
-        z = linear_pm(self.conv_fuse[0], self.conv_fuse[1], torch.cat([self.pt_last.forward_pm(p1), p1], dim=2))
-        if ops.lrelu_pool_supported(z.shape[2]):
-            g = ops.lrelu_pool(z.contiguous(), 0.2)[:, :z.shape[2]]  # activation + max over the points in one pass
-        else:
-            g = F.leaky_relu(z, negative_slope=0.2).max(dim=1)[0]
+        # conv_fuse + BatchNorm + LeakyReLU + the max over the points: one kernel where the widths allow (_pointwise)
+        g = linear_lrelu_maxpool_pm(self.conv_fuse[0], self.conv_fuse[1], torch.cat([self.pt_last.forward_pm(p1), p1], dim=2))
         g = self.dp1(F.leaky_relu(self.bn6(self.linear1(g)), negative_slope=0.2))
         g = self.dp2(F.leaky_relu(self.bn7(self.linear2(g)), negative_slope=0.2))
         return self.linear3(g)

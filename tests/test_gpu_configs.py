@@ -206,7 +206,7 @@ def test_dgcnn_gradient_vs_float64_module_on_the_same_graphs():
 
 def test_pct_gradient_vs_float64_module_on_the_same_tables():
     """PCT at B = 2, N = 1024 on the SAME FPS and kNN grouping tables: (a) the GPU fast path (points-major GEMMs,
-    hitadv_group_add_relu, hitadv_lrelu_pool), (b) the plain nn.Module in fp32 on the GPU, (c) the plain nn.Module in
+    hitadv_group_add_relu, the fused last layers and pooled embedding layer), (b) the plain nn.Module in fp32 on the GPU, (c) the plain nn.Module in
     float64 on the CPU.
 
     What round 2 read as "the fast path loses gradient accuracy" (tools/pct_grad_bisect.py, tools/pct_grad_where.py;
@@ -257,14 +257,26 @@ def test_pct_gradient_vs_float64_module_on_the_same_tables():
         winners.append(arg.detach().cpu().long())
         pre_pool.append(Z.detach().cpu())
         return out
+
+    real_fused = ops.linear_lrelu_pool
+
+    def spy_fused(xx, Wp, Wtp, bias, Bn, npts, slope=0.2, flag=None, return_arg=False):  # conv_fuse + LeakyReLU + max pool, fused
+        out, arg = real_fused(xx, Wp, Wtp, bias, Bn, npts, slope, flag, return_arg=True)
+        winners.append(arg.detach().cpu().long())
+        pieces = Wp.view(torch.float16).float()  # the layer's pre-activation never exists on this path: rebuilt here from the
+        W = pieces[0] + pieces[1] / 2048.0       # operands the kernel was given (fp32 GEMM: the same values to fp32 rounding)
+        pre_pool.append((xx.detach() @ W.t() + bias).view(Bn, npts, -1).cpu())
+        return (out, arg) if return_arg else out
     try:
         torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16 = spy_max, spy_pool, spy_group, spy_g16
+        ops.linear_lrelu_pool = spy_fused
         xg = x.cuda().requires_grad_()
         with _sampling.using(feed):
             logits = gm(xg)
         (logits * w.cuda()).sum().backward()
     finally:
         torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16 = real_max, real_pool, real_group, real_g16
+        ops.linear_lrelu_pool = real_fused
         _restore(PCT, saved)
     assert len(log['fps']) == 2 and len(log['knn_point']) == 2
     assert [tuple(t.shape) for t in winners] == [(2, 512, 128), (2, 256, 256), (2, 1024)] and len(pre_pool) == 1
