@@ -503,7 +503,7 @@ def reduce_over_ranks(elapsed_s, succeeded, attacked, dev, world, collectives):
 
 
 def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_step, in_flight, info, collectives,
-             matrix_mode=None, host=None):
+             matrix_mode=None, host=None, backend="nccl (RCCL)"):
     """The fields every configuration's line carries (throughput is whole-job: clouds of all ranks / max-over-ranks time)."""
     B, N = cfg['B'], cfg['N']
     clouds = steps * B * world
@@ -523,13 +523,84 @@ def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_
         "cloud_iterations_per_s": clouds * iters_per_step / elapsed,
         "attack_success": {"succeeded": succeeded, "attacked": attacked},
         # what RCCL saw: the calls each rank made in this run (all zero in a single-process run)
-        "collectives_per_rank": dict(collectives, world=world, backend="nccl (RCCL)" if world > 1 else None),
+        "collectives_per_rank": dict(collectives, world=world, backend=backend if world > 1 else None),
     }
+
+
+def launch_ranks(n, argv):
+    """``bench.py --gpus N`` without a launcher: start the N ranks ourselves.  Runs BEFORE this process has made any GPU
+    call (importing torch is not one): N children of this same file, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment (what ``torch.distributed.run`` would have set); every child's output passes through,
+    so rank 0's JSON line is the one line on stdout.  Returns the exit code: non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HITADV_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE,
+                                      text=True, bufsize=1))
+
+    def relay(p):  # stdout carries the JSON line and nothing else (gloo, for one, logs its connections to stdout)
+        for text in p.stdout:
+            out = sys.stdout if text.startswith('{"metric"') else sys.stderr
+            out.write(text)
+            out.flush()
+    import threading
+    readers = [threading.Thread(target=relay, args=(p,), daemon=True) for p in procs]
+    for t in readers:
+        t.start()
+    rc = 0
+    try:
+        for r, p in enumerate(procs):
+            code = p.wait()
+            if code != 0:
+                print("bench.py: rank %d exited with code %d" % (r, code), file=sys.stderr)
+                rc = rc or code or 1
+                for q in procs:  # the other ranks would wait for it in a collective forever
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        for t in readers:
+            t.join(5)
+    return rc
+
+
+def mock_job(cfg, steps, warmup, world, rank, collectives):
+    """``--mock-cpu``: the launcher / barrier / reduction self-test that runs without a GPU (gloo).  NO attack runs: a
+    step is a short sleep and the line says so in `data` -- it can never be read as a measurement."""
+    def sync():
+        if world > 1:
+            dist.barrier()
+            collectives['barrier'] += 1
+    time.sleep(0.01 * warmup)
+    sync()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * steps * (1 + rank))  # ranks differ: the line must carry the slowest one's time
+    sync()
+    elapsed, succeeded, attacked = reduce_over_ranks(time.perf_counter() - t0, steps, steps * cfg['B'], "cpu", world, collectives)
+    if rank == 0:
+        line = headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, NUM_ITER * BINARY_STEP, 1, dict(mock=True),
+                        collectives, backend="gloo")
+        line["data"] = "MOCK: launcher self-test on CPU, no attack ran, value is not a measurement"
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--mock-cpu", action="store_true",
+                    help="self-test of the N-rank launcher and the reduction on CPU (gloo); no attack runs, nothing is measured")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
@@ -548,18 +619,34 @@ def main():
     concurrent = max(1, cfg['concurrent'] if args.concurrent is None else args.concurrent)
     B, N = cfg['B'], cfg['N']
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher around us: be the launcher (no GPU call so far)
+        if not args.mock_cpu and torch.cuda.device_count() < args.gpus:  # device_count() does not start the runtime
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:  # the line's n_gpus is the world that ran: never let the two disagree silently
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
+                 "--nproc-per-node %d ... bench.py --gpus %d), or leave WORLD_SIZE unset and bench.py starts them"
+                 % (args.gpus, world, args.gpus, args.gpus))
     collectives = dict(barrier=0, all_reduce_max=0, all_reduce_sum=0)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    from hit_adv_amd import _lib
-    _lib.load()  # fail loudly if the HIP library is missing
+    if args.mock_cpu:
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        return mock_job(cfg, steps, warmup, world, rank, collectives)
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)
+        from hit_adv_amd import _lib
+        _lib.load()  # fail loudly if the HIP library is missing
 
     # N ranks x (attacks in flight) Python-driven graph replays share one host: every rank keeps to its share of the cores
     # (intra-op threads only matter for the CPU baseline leg, which runs at N = 1)
@@ -673,7 +760,7 @@ def main():
             else:
                 line["cpu_baseline"] = cpu_baseline_cw_sweep(cfg)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

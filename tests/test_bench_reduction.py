@@ -81,3 +81,38 @@ def test_bench_flop_model_of_the_pointnet_forward():
 def test_bench_help_runs_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True)
     assert out.returncode == 0 and '--config' in out.stdout
+
+
+def _bench(*argv, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *argv], capture_output=True, text=True, env=e,
+                          timeout=300)
+
+
+def test_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it): bench.py starts the two ranks itself before any GPU call and
+    relays rank 0's line -- exactly one line on stdout, n_gpus = 2, the collectives of a world of 2 (gloo stands in for
+    RCCL; --mock-cpu runs no attack and says so in `data`)."""
+    out = _bench('--gpus', '2', '--steps', '2', '--warmup', '1', '--mock-cpu')
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1
+    assert line['collectives_per_rank'] == {'barrier': 2, 'all_reduce_max': 1, 'all_reduce_sum': 1, 'world': 2, 'backend': 'gloo'}
+    assert line['attack_success']['attacked'] == 2 * 2 * 32          # both ranks' clouds
+    assert line['value'] == 2 * 2 * 32 / (line['ms_per_step'] * 2 / 1e3)
+    assert line['ms_per_step'] >= 2 * 10.                           # the slower rank (rank 1 sleeps twice as long)
+    assert line['data'].startswith('MOCK')                          # never to be read as a measurement
+
+
+def test_gpus_must_equal_the_world_that_runs():
+    """A launcher that started a different number of ranks than --gpus says is an error, not a line with the wrong
+    n_gpus; and so is a rank that dies (exit code of the whole job is non-zero, no line)."""
+    out = _bench('--gpus', '2', '--mock-cpu', env={'WORLD_SIZE': '1'})
+    assert out.returncode != 0 and '"n_gpus"' not in out.stdout and 'WORLD_SIZE=1' in out.stderr
+    out = _bench('--gpus', '1', '--mock-cpu', env={'WORLD_SIZE': '2', 'RANK': '0'})
+    assert out.returncode != 0 and '"n_gpus"' not in out.stdout
+    out = _bench('--gpus', '2', '--steps', '1')                     # the real job on a box without two GPUs
+    assert out.returncode != 0 and '"n_gpus"' not in out.stdout
