@@ -422,7 +422,7 @@ def make_runner(cfg, model, dev, concurrent):
         def run(todo):
             from hit_adv_amd import groups_in_flight
             ok, i = 0, 0
-            for n in groups_in_flight(len(todo), concurrent, stacked=att.attacks_per_stack > 1):  # shared with eval_ASR
+            for n in groups_in_flight(len(todo), att.in_flight(concurrent), stacked=att.stacks()):  # shared with eval_ASR
                 group = todo[i:i + n]
                 res = att.attack_many(group) if len(group) > 1 else [att.attack(*group[0])]
                 ok += sum(int(k) for _, k in res)

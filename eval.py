@@ -78,7 +78,8 @@ def parse_args(argv=None):
     p.add_argument('--synthetic_kind', type=str, default='gaussian', choices=['gaussian', 'sphere'])
     p.add_argument('--in_flight', type=int, default=12,
                    help='attack() calls kept in flight per GPU (1 = one at a time; 12 = three stacks of four merged victim '
-                        'passes on 8 hardware queues measured best on the PointNet engine)')
+                        'passes on 8 hardware queues measured best on the PointNet engine; victims whose passes do not '
+                        'stack -- DGCNN, PointNet++, PCT -- are capped at 4: one stream and one set of activations each)')
     p.add_argument('--metric_k', type=int, default=None,
                    help="neighbour count of the Uniform metric when it should differ from --k (the reference uses --k for "
                         "both, other_utils.py:74; the metric's smallest ball holds 1.6 %% of the points, so k+1 <= 16 at 1024)")
@@ -199,6 +200,8 @@ def main(argv=None):
     t0 = time.perf_counter()
     import hit_adv_amd
     in_flight = hit_adv_amd.attacks_in_flight(args.in_flight)  # 8 at most on the runtime's default four hardware queues
+    if hasattr(attacker, 'in_flight'):  # 12 only where the victim passes stack (PointNet engine); 4 for the other victims
+        in_flight = attacker.in_flight(in_flight)
     eval_ASR(model, loader, args, attacker, logger=logger, in_flight=in_flight)
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0

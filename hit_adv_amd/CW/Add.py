@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from ..model._pointwise import degrade_on_fp16_range
 
 
 def get_critical_points(model, pc, label, num):
@@ -66,6 +67,7 @@ class CWAdd:
         return self.dist_func(adv.transpose(1, 2).contiguous(), ori.transpose(1, 2).contiguous(), weights=weights,
                               batch_avg=batch_avg)
 
+    @degrade_on_fp16_range
     def attack(self, data, target):
         """data [B,num_points,3], target [B] -> (o_bestdist float64 [B], float64 [B,num_points+n_add,3], successes)."""
         from ..util.graph_loop import IterationGraph

@@ -11,6 +11,7 @@ iteration -- victim forward / backward, losses, Adam, clip, best tracking -- is 
 import torch
 
 from .. import ops
+from ..model._pointwise import degrade_on_fp16_range
 from ..util.graph_loop import IterationGraph
 from ._victim import Victim
 
@@ -40,6 +41,7 @@ class CWPerturb:
     def _logits(self, x):
         return self._victim(self.pre_head(x) if self.pre_head is not None else x)
 
+    @degrade_on_fp16_range
     def attack(self, data, target, _channel_first=False):
         """data [B,num_points,3 or 6] (or channel-first [B,3|6,num_points>6]), target [B]
         -> (float64 ndarray [B,num_points,3], number of samples with a successful step)."""

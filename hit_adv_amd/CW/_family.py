@@ -16,6 +16,7 @@ import torch
 
 from ._spectral import get_Laplace_from_pc
 from ._victim import Victim
+from ..model._pointwise import degrade_on_fp16_range
 
 
 class _CWFamily:
@@ -74,6 +75,7 @@ class _CWFamily:
         other = lfc_pred if self.spectral else ae_pred
         return ok & ((other != target) | (self.GAMMA < 0.001))
 
+    @degrade_on_fp16_range
     def _run(self, data, target, y_truth=None):
         """The loop of CW/AdvPC.py:63-79 / CW/AOF.py:106-134 on fixed buffers: one iteration -- up to three victim passes with
         their input gradients (summed in the reference's order of ``backward`` calls), Adam, clip, the spectral re-split,

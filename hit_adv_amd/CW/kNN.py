@@ -8,6 +8,7 @@ on fixed buffers and is replayed as one hipGraph when nothing in it needs the ho
 import torch
 
 from .. import ops
+from ..model._pointwise import degrade_on_fp16_range
 from ..util.graph_loop import IterationGraph
 from ._victim import Victim
 
@@ -40,6 +41,7 @@ class CWKNN:
         """What the progress lines and the returned count call a success (:90,:141: the targeted criterion)."""
         return pred == target
 
+    @degrade_on_fp16_range
     def attack(self, data, target):
         """data [B,num_points,3 or 6], target [B] -> (float32 ndarray [B,num_points,3], success count)."""
         self._victim.prepare()

@@ -30,6 +30,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from ..model._pointwise import degrade_on_fp16_range
 from ..model import _sampling
 from ..pytorch3d_ops import knn_gather, knn_points
 from ..util.dist_utils import ChamferDist, curvature_std
@@ -120,6 +121,15 @@ class _Stack:
         """Buffer ``name`` of all groups as the kernels see it: the group dimension merged into the leading one."""
         t = self.bufs[name]
         return t.reshape(t.shape[0] * t.shape[1], *t.shape[2:]) if t.dim() > 1 else t
+
+
+class _StackCaptureFailed(Exception):
+    """The stacked iteration could not be warmed up / captured; ``reason`` is the original exception, ``rng_state`` the CPU
+    generator's state before the stacks' setups took their draws."""
+
+    def __init__(self, reason):
+        super().__init__(repr(reason))
+        self.reason, self.rng_state = reason, None
 
 
 # attacks per stack in attack_many (0 / 1: no stacking, one stream per attack as before); tuning knob
@@ -569,6 +579,20 @@ class HiT_ADV:
                 and any(w != 0 for w in (self.cd_weight, self.ker_weight, self.hide_weight))
                 and view.h3_w.shape[0] <= 256 and view.h3_w.shape[1] <= 64 and self.use_graph not in (False, 'never'))
 
+    def stacks(self):
+        """Whether ``attack_many`` will really merge the victim passes of its attacks (the knob is on AND the victim / loss
+        allow it): what callers that size groups of attacks have to ask -- not the knob alone."""
+        return self.attacks_per_stack > 1 and self._can_stack()
+
+    UNSTACKED_IN_FLIGHT = 4  # one stream per attack: four measured best, odd counts worst (DESIGN.md section 5)
+
+    def in_flight(self, requested):
+        """Attacks to hand to ``attack_many`` at a time: ``requested`` where the victim passes are stacked (PointNet engine:
+        twelve = three stacks of four), at most ``UNSTACKED_IN_FLIGHT`` otherwise -- every un-stacked attack in flight holds
+        a workspace, a stream and the victim's activations of its own (DGCNN, PointNet++, PCT)."""
+        requested = max(1, int(requested))
+        return requested if self.stacks() else min(requested, self.UNSTACKED_IN_FLIGHT)
+
     def _iteration_stacked(self, stack):
         """``_iteration_fused`` for G attacks at once: one victim forward pass over the G*B clouds (its first kernel deforms
         them, its last layer is left to the loss kernel), the loss / best-tracking / regulariser launch for all groups, one
@@ -602,7 +626,21 @@ class HiT_ADV:
                                    clamp_p, rng, groups=G)
 
     def _prepare_stack_graphs(self, stacks):
-        """Two warm-up passes per stack (the second under sync-debug "error"), then one- and many-iteration graphs."""
+        """Two warm-up passes per stack (the second under sync-debug "error"), then one- and many-iteration graphs.  A failure
+        of either leaves no graph and no half-set view state behind and is reported as ``_StackCaptureFailed``."""
+        try:
+            self._prepare_stack_graphs_unguarded(stacks)
+        except Exception as e:  # noqa: BLE001
+            torch.cuda.synchronize()
+            for st in stacks:
+                st.graph = st.graph_many = None
+            view = self._view
+            if view is not None:  # what _iteration_stacked sets for the duration of one victim call
+                view.deform_inputs = None
+                view.defer_logits, view.pending_head = False, None
+            raise _StackCaptureFailed(e)
+
+    def _prepare_stack_graphs_unguarded(self, stacks):
         prev_mode = torch.cuda.get_sync_debug_mode()
         for st in stacks:
             st.graph = st.graph_many = None
@@ -638,6 +676,7 @@ class HiT_ADV:
         B, K = batches[0][0].shape[:2]
         dev = torch.device('cuda', torch.cuda.current_device())
         sizes = [min(per_stack, len(batches) - i) for i in range(0, len(batches), per_stack)]
+        rng_before = torch.get_rng_state()  # the setups below draw from the global CPU generator
         stacks, i = [], 0
         for n, G in enumerate(sizes):
             key = (B, K, self.central_num, 'stack', n, G)
@@ -648,7 +687,11 @@ class HiT_ADV:
                 self._setup(d, t, into=ws)
             stacks.append(st)
             i += G
-        self._prepare_stack_graphs(stacks)
+        try:
+            self._prepare_stack_graphs(stacks)
+        except _StackCaptureFailed as e:
+            e.rng_state = rng_before
+            raise
         self.last_graph_used = True
         for st in stacks:
             for ws in st.groups:
@@ -693,6 +736,7 @@ class HiT_ADV:
             print('Successfully attack {}/{}'.format(success_num, ws.B))
         return best.double().cpu().numpy().transpose((0, 2, 1)), success_num
 
+    @degrade_on_fp16_range
     def attack(self, data, target):
         """Attack on given data to target.
 
@@ -715,6 +759,7 @@ class HiT_ADV:
         torch.cuda.current_stream().wait_stream(ws.stream)
         return self._finish(ws, self.verbose)
 
+    @degrade_on_fp16_range
     def attack_many(self, batches):
         """Attack several independent batches CONCURRENTLY on one GPU: ``[(data, target), ...] -> [(adv, n), ...]``.
 
@@ -736,6 +781,14 @@ class HiT_ADV:
                 _V1_BLOCKS_IN_FLIGHT if len(batches) > per_stack else view.linear_max_blocks)  # two stacks or more in flight
             try:
                 return self._attack_stacked(batches, per_stack)
+            except _StackCaptureFailed as e:
+                # as _prepare_graphs does for the un-stacked path: 'auto' warns and takes the path that needs no stacked graph
+                # (one stream per attack, each with its own capture attempt and eager fallback); True / 'always' is loud
+                if self.use_graph is True or self.use_graph == 'always':
+                    raise RuntimeError("the stacked HiT-ADV iteration cannot be captured into a hipGraph: %r" % (e.reason,))
+                warnings.warn("the stacked HiT-ADV iteration is not hipGraph-capturable (%r); attacking the batches on "
+                              "separate streams instead" % (e.reason,))
+                torch.set_rng_state(e.rng_state)  # the batches' draws are taken again, in the same order
             finally:
                 view.linear_max_blocks = before
         view = self._view if hasattr(self._view, 'linear_max_blocks') else None

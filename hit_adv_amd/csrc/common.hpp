@@ -38,6 +38,29 @@
 
 namespace hitadv {
 
+// A kernel's dynamic-LDS limit, raised once PER DEVICE (the attribute belongs to the function on one device; a process
+// may drive several GPUs), and the error of a refusal handed back to the entry point instead of surfacing at the launch.
+struct LdsRaised {
+  unsigned long long done = 0;  // bit d: raised on device d
+};
+static inline hipError_t raise_dynamic_lds(LdsRaised &st, const void *kernel, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (st.done & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) st.done |= bit;
+  return e;
+}
+// in a function that returns the entry point's int code; `kernel_ptr` in parentheses when its template arguments hold commas
+#define HITADV_RAISE_LDS(kernel_ptr, bytes)                                                                            \
+  do {                                                                                                                 \
+    static hitadv::LdsRaised st__;                                                                                     \
+    const hipError_t e__ = hitadv::raise_dynamic_lds(st__, reinterpret_cast<const void *>(kernel_ptr), (int)(bytes));   \
+    if (e__ != hipSuccess) return (int)e__;                                                                            \
+  } while (0)
+
 // Drain this wave's stores, meet the workgroup, draw the ticket of `slot`; true in every thread of the workgroup whose
 // ticket was the last of `total`.  `flag` is a __shared__ int of the caller.
 __device__ __forceinline__ bool handoff_last_arriver(int *tickets, int slot, int total, int *flag) {
@@ -52,6 +75,25 @@ __device__ __forceinline__ bool handoff_last_arriver(int *tickets, int slot, int
   if (last) HITADV_HANDOFF_ACQUIRE();
   return last;
 }
+
+// ---- fp16 range watch of the two-piece (fp16x2) kernels: the largest magnitude seen, as raw bits with the sign cleared.
+// Unsigned order on those bits is the order of the magnitudes, +inf sorts above every finite value and every NaN above
+// +inf -- so a NaN operand raises the flag too (fmaxf(big, fabsf(v)) silently drops it).
+struct RangeWatch {
+  uint32_t m = 0u;
+  __device__ __forceinline__ void see(float v) {
+    const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+  // `relu_of_pre` = max(pre, 0) as the kernels write it (which maps a NaN to 0): the NaN is caught on `pre` itself
+  __device__ __forceinline__ void see_relu(float pre, float relu_of_pre) {
+    const uint32_t b = __float_as_uint(relu_of_pre);  // >= +0: no sign to clear
+    m = b > m ? b : m;
+    nan_ = fmaf(pre, 0.f, nan_);                       // NaN (or an infinity) in -> NaN
+  }
+  __device__ __forceinline__ bool beyond_fp16() const { return m >= 0x477fe000u || nan_ != nan_; }  // |v| >= 65504, inf, NaN
+  float nan_ = 0.f;
+};
 
 // ---- an fp32 value as three bf16 pieces (csrc/victim_bf3.hip, csrc/knn.hip: fp32-accurate products on the bf16 MFMAs)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
       st.b[v][1] = *reinterpret_cast<const uint4 *>(bp + (size_t)N * K);
     }
   };
-  float big = 0.f;
+  RangeWatch big;
   auto stash = [&](const Set &st, int stage) {
     char *base = sG16 + (size_t)stage * G16_STAGE;
 #pragma unroll
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
         for (int j = 0; j < 4; ++j) {
           h1[j] = (_Float16)a[j];
           h2[j] = (_Float16)((a[j] - (float)h1[j]) * G16_SCALE);
-          big = fmaxf(big, fabsf(a[j]));
+          big.see(a[j]);
         }
       }
       char *dst = base + g16_off((tid >> 3) + (NT / 8) * u, (tid & 7) >> 1) + 8 * (tid & 1);
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
     compute(ks);
     if (ks + 1 < nk) stash(s0, (ks + 1) & 1);
   }
-  if (!(big < 65504.f) && range_flag != nullptr) *range_flag = 1;  // beyond fp16 (or NaN): the caller refuses the result
+  if (big.beyond_fp16() && range_flag != nullptr) *range_flag = 1;  // beyond fp16 (or NaN): the caller refuses the result
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -484,9 +484,7 @@ template <class AProd, class Epi, bool SYNC_EPI>
 static int launch_gemm16(const AProd &ap, const uint16_t *Wp, int B, int npts, int N, int K, const Epi &epi, int32_t *range_flag,
                          hipStream_t s) {
   const int chunks = (npts + G16_BM - 1) / G16_BM, nrb = B * chunks, ncb = N / G16_BN;
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f16x2_k<G16_WR, AProd, Epi, SYNC_EPI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G16_STAGE);
-  (void)once;
+  HITADV_RAISE_LDS((&gemm_f16x2_k<G16_WR, AProd, Epi, SYNC_EPI>), 2 * G16_STAGE);
   gemm_f16x2_k<G16_WR, AProd, Epi, SYNC_EPI><<<dim3((unsigned)(nrb * ncb)), G16_WR * 128, 2 * G16_STAGE, s>>>(
       ap, Wp, npts, chunks, nrb, ncb, N, K, epi, range_flag);
   HITADV_LAUNCH_CHECK();
@@ -587,9 +585,7 @@ static int g16_ablate_launch(const float *X, const uint16_t *Wp, long long M, in
   const AP ap{X, nullptr, K};
   const PlainEpi epi{C, nullptr, N, 0};
   const int chunks = (int)((M + G16_BM - 1) / G16_BM), nrb = chunks, ncb = N / G16_BN;
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f16x2_k<G16_WR, AP, PlainEpi, false, ABL>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G16_STAGE);
-  (void)once;
+  HITADV_RAISE_LDS((&gemm_f16x2_k<G16_WR, AP, PlainEpi, false, ABL>), 2 * G16_STAGE);
   gemm_f16x2_k<G16_WR, AP, PlainEpi, false, ABL><<<dim3((unsigned)(nrb * ncb)), G16_WR * 128, 2 * G16_STAGE, s>>>(
       ap, Wp, (int)M, chunks, nrb, ncb, N, K, epi, nullptr);
   return (int)hipGetLastError();

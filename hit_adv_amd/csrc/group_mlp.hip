@@ -83,15 +83,15 @@ __global__ __launch_bounds__(512) void group_linear_max_fwd_k(const float *__res
       const bool in = n0 + (long long)tile * GM_TM + e / G8 < n1;
       float a[8] = {st[u][0].x, st[u][0].y, st[u][0].z, st[u][0].w, st[u][1].x, st[u][1].y, st[u][1].z, st[u][1].w};
       f16x8g h1, h2;
-      float big = 0.f;
+      RangeWatch big;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float v = in ? a[i] : 0.f;
         h1[i] = (_Float16)v;
         h2[i] = (_Float16)((v - (float)h1[i]) * GM_SCALE);
-        big = fmaxf(big, fabsf(v));
+        big.see(v);
       }
-      if (!(big < 65504.f) && range_flag != nullptr) *range_flag = 1;
+      if (big.beyond_fp16() && range_flag != nullptr) *range_flag = 1;
       char *dst = sG + (size_t)buf * 2 * PIECE + (e / G8) * RS + 16 * (e % G8);
       *reinterpret_cast<uint4 *>(dst) = __builtin_bit_cast(uint4, h1);
       *reinterpret_cast<uint4 *>(dst + PIECE) = __builtin_bit_cast(uint4, h2);
@@ -336,9 +336,7 @@ static int launch_fwd(const float *X, const uint16_t *W2, const float *bias, lon
   if (tpb < 8) tpb = (int)min(8ll, ntiles);
   blocks = (ntiles + tpb - 1) / tpb;
   const size_t shm = (size_t)2 * 2 * GM_TM * (2 * CIN + 32);
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&group_linear_max_fwd_k<CIN, NS, NCT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 2 * GM_TM * (2 * CIN + 32)));
-  (void)once;
+  HITADV_RAISE_LDS((&group_linear_max_fwd_k<CIN, NS, NCT>), (int)(2 * 2 * GM_TM * (2 * CIN + 32)));
   group_linear_max_fwd_k<CIN, NS, NCT><<<(unsigned)blocks, 512, shm, s>>>(X, W2, bias, rows, tpb, out, arg, range_flag);
   return 0;
 }
@@ -352,10 +350,7 @@ static int launch_bwd(const float *dOut, const float *outv, const int32_t *arg, 
   if (tpb < 4) tpb = (int)min(4ll, ntiles);
   blocks = (ntiles + tpb - 1) / tpb;
   const size_t shm = (size_t)2 * GM_TM * (2 * COUT + 32) + (size_t)GM_TM * (CIN + 4) * sizeof(float);
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&group_linear_max_bwd_k<CIN, NS, COUT, MASKED>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(2 * GM_TM * (2 * COUT + 32) + GM_TM * (CIN + 4) * sizeof(float)));
-  (void)once;
+  HITADV_RAISE_LDS((&group_linear_max_bwd_k<CIN, NS, COUT, MASKED>), (int)(2 * GM_TM * (2 * COUT + 32) + GM_TM * (CIN + 4) * sizeof(float)));
   group_linear_max_bwd_k<CIN, NS, COUT, MASKED><<<(unsigned)blocks, 256, shm, s>>>(dOut, outv, arg, Wb2, G, tpb, dX, range_flag, xmask);
   return 0;
 }

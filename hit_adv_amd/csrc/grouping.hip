@@ -649,9 +649,7 @@ extern "C" int hitadv_group_add_relu_bwd(const float *dH, const float *U, const 
   int2 *span = reinterpret_cast<int2 *>(scratch);
   int32_t *col = scratch + (size_t)B * 2 * N;
   const size_t shm = (size_t)(RG_BITMAP_WORDS + 3 * RG_THREADS) * 4;
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&hitadv::reverse_graph_k),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  (void)once;
+  HITADV_RAISE_LDS((&hitadv::reverse_graph_k), (int)shm);
   hitadv::reverse_graph_k<<<dim3((N + J - 1) / J, B), RG_THREADS, shm, s>>>(idx, S, N, ns, W, J, span, col);
   HITADV_LAUNCH_CHECK();
   const long long targets = (long long)B * N;
@@ -698,9 +696,7 @@ extern "C" int hitadv_edge_max_bwd(const float *dout, const float *out, const in
   int2 *span = reinterpret_cast<int2 *>(scratch);
   int32_t *col = scratch + (size_t)B * 2 * N;
   const size_t shm = (size_t)(RG_BITMAP_WORDS + 3 * RG_THREADS) * 4;
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&hitadv::reverse_graph_k),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  (void)once;
+  HITADV_RAISE_LDS((&hitadv::reverse_graph_k), (int)shm);
   hitadv::reverse_graph_k<<<dim3((N + J - 1) / J, B), RG_THREADS, shm, (hipStream_t)stream>>>(idx, N, N, k, W, J, span,
                                                                                           col);
   HITADV_LAUNCH_CHECK();

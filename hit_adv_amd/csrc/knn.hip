@@ -538,9 +538,7 @@ static int launch_knn_topk(const float *q, const float *p, int B, int N, int M, 
 #define HITADV_KNN_CASE(KB)                                                                          \
   if (K <= KB) {                                                                                     \
     const size_t shm = (size_t)8 * KB * 64 * sizeof(float);                                          \
-    if (shm > 48 * 1024)                                                                             \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_topk<KB, FORM, IdxT>),           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);               \
+    if (shm > 48 * 1024) HITADV_RAISE_LDS((&knn_topk<KB, FORM, IdxT>), shm);                         \
     knn_topk<KB, FORM, IdxT><<<grid, 256, shm, s>>>(q, p, N, M, K, dists, idx);                      \
     return 0;                                                                                        \
   }
@@ -565,10 +563,7 @@ static int launch_knn_select(const float *q, const float *p, int B, int N, int M
 #define HITADV_KS_CASE(KB)                                                                                     \
   if (K <= KB) {                                                                                               \
     const size_t shm = refs + ks_union_bytes(KB, NW);                                                          \
-    static int raised = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_select<KB, FORM, NW>),         \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,                        \
-                                            32768 + 512 + (int)ks_union_bytes(KB, NW));                              \
-    (void)raised;                                                                                              \
+    HITADV_RAISE_LDS((&knn_select<KB, FORM, NW>), 32768 + 512 + (int)ks_union_bytes(KB, NW));                  \
     knn_select<KB, FORM, NW><<<grid, NW * 64, shm, s>>>(q, p, N, M, K, dists, idx, idx_is_i64);                \
     return 0;                                                                                                  \
   }
@@ -915,9 +910,7 @@ extern "C" int hitadv_knn_features(const float *X, const float *xx, int B, int N
 #define HITADV_KNN_FEAT(DD, KK)                                                                                          \
   do {                                                                                                                 \
     constexpr int shm = hitadv::knn_feat_lds_bytes(DD, KK);                                                            \
-    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&hitadv::knn_feat_k<DD, KK>),                  \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, shm);                            \
-    (void)once;                                                                                                        \
+    HITADV_RAISE_LDS((&hitadv::knn_feat_k<DD, KK>), shm);                                                              \
     hitadv::knn_feat_k<DD, KK><<<grid, 512, shm, s>>>(X, xx, N, K, idx);                                                \
   } while (0)
   // list length = K rounded up to an instantiated size: a shorter list means a tighter threshold and a cheaper insert

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void rowmlp_fwd16_k(RowMlpFwd a) {
   {  // 64 -> 128, ReLU: wave w owns columns 32w..32w+31 for all 64 rows, one 32-row block after the other (two accumulator
      // sets per block: with both blocks in flight the kernel needs 173 registers and loses its third wave per SIMD)
     const int c = 32 * wave + r;
-    float big = 0.f;
+    RangeWatch big;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       f32x16 acc[1], accl[1];
@@ -464,12 +464,12 @@ __global__ __launch_bounds__(256) void rowmlp_fwd16_k(RowMlpFwd a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = 32 * q + acc_row(e, h);
-        float v = joined(acc[0], accl[0], e) + bias2;
-        v = v > 0.f ? v : 0.f;
+        const float pre = joined(acc[0], accl[0], e) + bias2;
+        float v = pre > 0.f ? pre : 0.f;
         if (a.pack_o2) {  // block-uniform
           _Float16 x, y;
           split_pair(v, x, y);
-          big = fmaxf(big, v);
+          big.see_relu(pre, v);
           const uint32_t wd = (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
           if (n < rows) reinterpret_cast<uint32_t *>(a.o2)[(row0 + n) * 128 + c] = wd;
         } else if (n < rows) {
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void rowmlp_fwd16_k(RowMlpFwd a) {
         }
       }
     }
-    if (a.pack_o2 && a.range_flag != nullptr && !(big < 65504.f)) *a.range_flag = 1;
+    if (a.pack_o2 && a.range_flag != nullptr && big.beyond_fp16()) *a.range_flag = 1;
   }
 }
 
@@ -1610,14 +1610,14 @@ __global__ __launch_bounds__(NWV * 64) void fc_wide_k(const float *__restrict__ 
 }
 
 template <int NWV, int PRE>
-static void launch_fc_wide(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K, int NOUT,
+static int launch_fc_wide(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K, int NOUT,
                            int relu, float *out, FcPre pp, hipStream_t s) {
   constexpr int shm = NWV * 32 * FCW_LD * 4 + (PRE ? 32 * 65 * 4 : 0);  // staging (>= NWV * 4096 bytes of partials) + P
-  static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&fc_wide_k<NWV, PRE>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-  (void)once;
+  HITADV_RAISE_LDS((&fc_wide_k<NWV, PRE>), shm);
   dim3 grid((NOUT + 31) / 32, (B + 31) / 32);
   fc_wide_k<NWV, PRE><<<grid, NWV * 64, shm, s>>>(in, mask, Wt, bias, B, K, NOUT, relu, out, pp);
+  HITADV_LAUNCH_CHECK();
+  return 0;
 }
 
 static void fc_split(int B, int K, int NOUT, int *chunk, int *KS, int *tiles) {
@@ -1755,10 +1755,8 @@ extern "C" int hitadv_fc_layer(const float *in, const float *mask, const float *
   // block of sixteen waves is left with 64 registers per lane, its weight loads end up between the MFMAs, and the split
   // form wins (9.0 vs 7.4 us)
   if (wide && (K == 512 || K == 256)) {
-    if (K == 512) launch_fc_wide<8, 0>(in, mask, Wt, bias, B, K, NOUT, relu, out, FcPre{}, (hipStream_t)stream);
-    else launch_fc_wide<4, 0>(in, mask, Wt, bias, B, K, NOUT, relu, out, FcPre{}, (hipStream_t)stream);
-    HITADV_LAUNCH_CHECK();
-    return 0;
+    if (K == 512) return launch_fc_wide<8, 0>(in, mask, Wt, bias, B, K, NOUT, relu, out, FcPre{}, (hipStream_t)stream);
+    return launch_fc_wide<4, 0>(in, mask, Wt, bias, B, K, NOUT, relu, out, FcPre{}, (hipStream_t)stream);
   }
   int chunk, KS, tiles;
   fc_split(B, K, NOUT, &chunk, &KS, &tiles);
@@ -1782,10 +1780,8 @@ extern "C" int hitadv_fc_layer_pre(const float *pre, int T, int J, const float *
   const FcPre pp{pre, Wpre, T, J};
   static const int wide = [] { const char *e = getenv("HITADV_FC_WIDE"); return e ? atoi(e) : 1; }();  // 0: tuning / A-B only
   if (wide && K == 256) {  // the stacks' case: four waves, one 64-deep slice each, no chunk loop
-    if (J <= 16) launch_fc_wide<4, 8>(nullptr, mask, Wt, bias, B, K, NOUT, relu, out, pp, (hipStream_t)stream);
-    else launch_fc_wide<4, 32>(nullptr, mask, Wt, bias, B, K, NOUT, relu, out, pp, (hipStream_t)stream);
-    HITADV_LAUNCH_CHECK();
-    return 0;
+    if (J <= 16) return launch_fc_wide<4, 8>(nullptr, mask, Wt, bias, B, K, NOUT, relu, out, pp, (hipStream_t)stream);
+    return launch_fc_wide<4, 32>(nullptr, mask, Wt, bias, B, K, NOUT, relu, out, pp, (hipStream_t)stream);
   }
   int *tk = reinterpret_cast<int *>(scratch);
   if (J <= 16)

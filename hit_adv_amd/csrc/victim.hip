@@ -493,9 +493,7 @@ extern "C" int hitadv_linear_max_fwd(const float *X, const float *Wt, const floa
   // 8 waves x 32 columns per block.  Measured at B=32 (us incl. merge): two accumulator sets 68.9; one set 71.1 (chosen,
   // see LM_PIPE); 4 waves x 64 columns (one wave per SIMD) 73.0; 512 blocks 75.4; forced to 128 VGPRs 74.9-76.7.
   if (Cin == 128) {
-    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_k<128, 1, 512, LM_PIPE>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_TM * 132 * 4);
-    (void)once;
+    HITADV_RAISE_LDS((&linear_max_fwd_k<128, 1, 512, LM_PIPE>), 2 * LF_TM * 132 * 4);
     linear_max_fwd_k<128, 1, 512, LM_PIPE><<<grid, 512, shm, s>>>(X, Wt, B, N, Cout, rows, S, ncg, part_val, part_idx, bias,
                                                                 relu, out, idx, tickets);
   } else {

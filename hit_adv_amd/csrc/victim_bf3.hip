@@ -142,14 +142,14 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
         *reinterpret_cast<uint4 *>(dst + PIECE) = lo;
       } else if constexpr (MODE == 1) {
         f16x8 h1, h2;
-        float big = 0.f;
+        RangeWatch big;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           h1[i] = (_Float16)a[i];  // round to nearest even
           h2[i] = (_Float16)((a[i] - (float)h1[i]) * F16X2_SCALE);
-          big = fmaxf(big, fabsf(a[i]));
+          big.see(a[i]);
         }
-        if (!(big < 65504.f) && range_flag != nullptr) *range_flag = 1;  // beyond fp16 (or NaN): the caller refuses the result
+        if (big.beyond_fp16() && range_flag != nullptr) *range_flag = 1;  // beyond fp16 (or NaN): the caller refuses the result
         *reinterpret_cast<uint4 *>(dst) = __builtin_bit_cast(uint4, h1);
         *reinterpret_cast<uint4 *>(dst + PIECE) = __builtin_bit_cast(uint4, h2);
       } else {
@@ -446,15 +446,11 @@ static int launch_linear_max_pieces(const float *X, const uint16_t *W3, const fl
   constexpr int NP = MODE >= 1 ? 2 : 3;
   const size_t shm = (size_t)2 * NP * B3_TM * (2 * Cin + 32);
   if (Cin == 128) {
-    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<128, MODE>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NP * B3_TM * (2 * 128 + 32));
-    (void)once;
+    HITADV_RAISE_LDS((&linear_max_fwd_bf3_k<128, MODE>), 2 * NP * B3_TM * (2 * 128 + 32));
     linear_max_fwd_bf3_k<128, MODE><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out,
                                                            idx, tickets, range_flag);
   } else {
-    static int once = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_max_fwd_bf3_k<64, MODE>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NP * B3_TM * (2 * 64 + 32));
-    (void)once;
+    HITADV_RAISE_LDS((&linear_max_fwd_bf3_k<64, MODE>), 2 * NP * B3_TM * (2 * 64 + 32));
     linear_max_fwd_bf3_k<64, MODE><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out,
                                                           idx, tickets, range_flag);
   }

@@ -7,16 +7,38 @@ BatchNorm.  A 1x1 convolution is a matrix product, so in eval mode on the GPU th
 the BatchNorm folded into its weights; parameters, buffers and state_dict layout are untouched (the modules stay
 ``nn.Conv*`` / ``nn.BatchNorm*``), training mode and CPU tensors go through the modules themselves.
 """
+import contextlib
+import functools
+import warnings
+import weakref
+
 import torch
 import torch.nn.functional as F
 
 
-_FOLD_CACHE = {}
+# Per-layer constants of an attack (folded weights, their fp16 pieces), keyed WEAKLY by the conv module: an entry dies with
+# its layer, so a new model that reuses a freed one's id() / storage addresses can never be served the old one's weights,
+# and the cached GPU tensors are released with the model.  An entry also remembers WHICH BatchNorm it was folded with.
+_FOLD_CACHE = weakref.WeakKeyDictionary()
+_PIECE_CACHE = weakref.WeakKeyDictionary()
+FP16_MAX = 65504.
 
 
 def _versions(conv, bn):
     ts = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-    return tuple((t._version, t.data_ptr()) if t is not None else None for t in ts)
+    return tuple((t._version, t.data_ptr(), t._cdata) if t is not None else None for t in ts)
+
+
+def invalidate_folded(model=None):
+    """Forget the cached folded weights / fp16 pieces (of ``model``'s layers, or all).  Needed only after an edit the version
+    counters cannot see -- writing through ``param.data`` --; ``load_state_dict``, optimiser steps and every in-place op on
+    the parameter itself are noticed without it."""
+    for cache in (_FOLD_CACHE, _PIECE_CACHE):
+        if model is None:
+            cache.clear()
+        else:
+            for m in model.modules():
+                cache.pop(m, None)
 
 
 def _folded(conv, bn):
@@ -25,18 +47,35 @@ def _folded(conv, bn):
     version counters), so a forward pass does not spend half a dozen five-microsecond launches per layer on re-deriving it
     (PCT: ~100 of them per pass, 4 % of cfg5's kernel time in profiles/r03)."""
     if not WEIGHT_GRADS:
-        key = (id(conv), id(bn))
         ver = _versions(conv, bn)
-        hit = _FOLD_CACHE.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1], hit[2]
+        hit = _FOLD_CACHE.get(conv)
+        if hit is not None and hit[0] == ver and (hit[1]() if hit[1] is not None else None) is bn:
+            return hit[2], hit[3]
         with torch.no_grad():
             W, b = _fold_now(conv, bn)
             W = W.contiguous()
         if not (W.is_cuda and torch.cuda.is_current_stream_capturing()):  # a capture records, it does not compute: nothing to keep
-            _FOLD_CACHE[key] = (ver, W, b)
+            _FOLD_CACHE[conv] = (ver, weakref.ref(bn) if bn is not None else None, W, b)
         return W, b
     return _fold_now(conv, bn)
+
+
+def _pieces(conv, W, kind, split):
+    """The folded layer's fp16 pieces (forward operand, backward operand), split once per weight and kept with the layer.
+    Returns None when a weight lies beyond fp16's range (or is not finite): the caller then takes its f32 path for this
+    layer -- a property of the weights, decided here once, not a flag raised on every attack."""
+    key = (kind, W.data_ptr(), W._version, W._cdata)
+    hit = _PIECE_CACHE.get(conv)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing and not bool((W.abs().max() <= FP16_MAX).item()):  # NaN compares false: not representable either
+        made = None
+    else:
+        made = (split(W), split(W.t().contiguous()))
+    if not capturing:
+        _PIECE_CACHE[conv] = (key, made)
+    return made
 
 
 def _fold_now(conv, bn):
@@ -128,7 +167,6 @@ def linear_relu_pm(conv, bn, x):
 
 
 _RANGE_FLAGS = {}
-_PIECE_CACHE = {}
 
 
 def range_flag(device):
@@ -139,28 +177,99 @@ def range_flag(device):
     return _RANGE_FLAGS[key]
 
 
+class Fp16RangeExceeded(RuntimeError):
+    """An operand of an fp16x2 (two-piece fp16) layer lay beyond fp16's range (65504) or was not finite: what that pass
+    computed is invalid.  The attacks catch it and run again in arithmetic with fp32's range (``degrade_on_fp16_range``)."""
+
+
 def check_range(device):
-    """Raise if any fp16x2 layer of a victim has seen an operand beyond fp16's range since the flag was last cleared."""
+    """Raise ``Fp16RangeExceeded`` if any fp16x2 layer of a victim has seen an operand beyond fp16's range since the flag
+    was last cleared (one 4-byte read; the attacks call it where they read their results back anyway)."""
     flag = _RANGE_FLAGS.get(str(device))
     if flag is not None and int(flag.item()) != 0:
         flag.zero_()
-        raise RuntimeError("a fused linear + max layer (fp16x2 matrix form) met an activation or weight beyond fp16's range "
-                           "(65504): the results are invalid; set hit_adv_amd.model._pointwise.FUSED_GROUP_MAX = False")
+        raise Fp16RangeExceeded("a fused linear + max / pooling layer (fp16x2 matrix form) met an activation beyond fp16's "
+                                "range (65504) or a NaN: the results of this pass are invalid")
+
+
+_FULL_RANGE_DEPTH = 0
+
+
+@contextlib.contextmanager
+def full_range_arithmetic():
+    """Every fp16x2 form off for the duration: PointNet's shared layers as three bf16 pieces (fp32's range, fp32-accurate),
+    the fused group / embedding layers of the other victims as their f32 GEMM compositions."""
+    global FUSED_GROUP_MAX, FUSED_EMBEDDING_POOL, _FULL_RANGE_DEPTH
+    from .dgcnn import FoldedDGCNN
+    from .pointnet import FoldedPointNet
+    saved = (FUSED_GROUP_MAX, FUSED_EMBEDDING_POOL, FoldedPointNet.matrix_mode, FoldedDGCNN.fused_embedding)
+    FUSED_GROUP_MAX = FUSED_EMBEDDING_POOL = FoldedDGCNN.fused_embedding = False
+    if FoldedPointNet.matrix_mode == 'fp16x2':
+        FoldedPointNet.matrix_mode = 'bf16x3'
+    _FULL_RANGE_DEPTH += 1
+    try:
+        yield
+    finally:
+        _FULL_RANGE_DEPTH -= 1
+        FUSED_GROUP_MAX, FUSED_EMBEDDING_POOL, FoldedPointNet.matrix_mode, FoldedDGCNN.fused_embedding = saved
+
+
+_DEGRADE_WARNED = False
+
+
+def degrade_on_fp16_range(attack):
+    """Decorator of an attack's entry point.  The reference never fails on range: when the fp16x2 layers of the victim report
+    an operand beyond 65504 (``Fp16RangeExceeded``, raised where the attack reads its results back), the same call runs
+    again under ``full_range_arithmetic`` -- the CPU generator rewound, so the second run takes the same draws, captures its
+    own graphs and returns exactly what a process configured that way from the start returns.  One warning per process."""
+    @functools.wraps(attack)
+    def guarded(self, *args, **kwargs):
+        global _DEGRADE_WARNED
+        if _FULL_RANGE_DEPTH:  # already inside a degraded run (attack_many -> attack, subclass -> base)
+            return attack(self, *args, **kwargs)
+        rng = torch.get_rng_state()
+        try:
+            return attack(self, *args, **kwargs)
+        except Fp16RangeExceeded as e:
+            if not _DEGRADE_WARNED:
+                _DEGRADE_WARNED = True
+                warnings.warn("hit_adv_amd: %s -- running this attack again with the victim's fp16x2 layers in arithmetic of "
+                              "fp32's range (PointNet: matrix_mode 'bf16x3'; the others: f32 GEMMs); further occurrences are "
+                              "handled the same way without a warning" % (e,), RuntimeWarning, stacklevel=2)
+            torch.set_rng_state(rng)
+            with full_range_arithmetic():
+                return attack(self, *args, **kwargs)
+    return guarded
 
 
 FUSED_GROUP_MAX = True  # last shared layer of a sample-and-group block + max over the neighbours as one fp16x2 MFMA kernel
+
+
+def _fused_group_max(conv, W, b, x):
+    """Which fused form of "last shared layer + max over the neighbours" applies to this layer and input, with its fp16
+    pieces: ('reg' | 'g16', pieces, flag), or None (unsupported widths, CPU, weight gradients wanted, or weights beyond
+    fp16's range: the f32 GEMM + max then)."""
+    from .. import ops
+    if not (FUSED_GROUP_MAX and x.is_cuda and b is not None and not WEIGHT_GRADS):
+        return None
+    flag = range_flag(x.device)
+    if ops.group_linear_max_supported(W.shape[1], W.shape[0], x.shape[-2]):
+        kind, pieces = 'reg', _pieces(conv, W, 'reg', lambda M: ops.split_weights_f16x2(M, range_flag=flag))
+    elif ops.group_linear_max_g16_supported(W.shape[1], W.shape[0], x.shape[-2]):
+        # widths the register-resident kernels do not cover (PCT's second Local_op, 256 -> 256): the tiled GEMM core
+        kind, pieces = 'g16', _pieces(conv, W, 'g16', lambda M: ops.split_rows_f16x2(M, flag))
+    else:
+        return None
+    return None if pieces is None else (kind, pieces, flag)
 
 
 def linear_relu_then_max_pm(conv_mid, bn_mid, conv, bn, x):
     """Two shared layers and the max over the neighbours: relu(bn_mid(conv_mid(x))) -> ``linear_relu_max_pm``.  Where the fused
     last layer applies, the middle layer's ReLU backward rides on that kernel's output (no separate pass over the
     [.., ns, C] gradient); otherwise the plain composition."""
-    from .. import ops
     Wm, bm = _folded(conv_mid, bn_mid)
     W, b = _folded(conv, bn)
-    if (FUSED_GROUP_MAX and x.is_cuda and b is not None and bm is not None and not WEIGHT_GRADS
-            and (ops.group_linear_max_supported(W.shape[1], W.shape[0], x.shape[-2])
-                 or ops.group_linear_max_g16_supported(W.shape[1], W.shape[0], x.shape[-2]))):
+    if bm is not None and _fused_group_max(conv, W, b, x) is not None:  # (only x's device and ns matter there)
         y = _LinearReLUGatedLater.apply(x.reshape(-1, x.shape[-1]), Wm.detach(), bm.detach()).view(*x.shape[:-1], Wm.shape[0])
         return linear_relu_max_pm(conv, bn, y, relu_input=True)
     return linear_relu_max_pm(conv, bn, linear_relu_pm(conv_mid, bn_mid, x))
@@ -172,29 +281,11 @@ def linear_relu_max_pm(conv, bn, x, relu_input=False):
     backward), the GEMM + max otherwise.  ``relu_input``: see ``ops.GroupLinearMax`` (fused path only)."""
     from .. import ops
     W, b = _folded(conv, bn)
-    if (FUSED_GROUP_MAX and x.is_cuda and b is not None and not WEIGHT_GRADS
-            and ops.group_linear_max_supported(W.shape[1], W.shape[0], x.shape[-2])):
-        flag = range_flag(x.device)
-        key = (W.data_ptr(), W._version)
-        pieces = _PIECE_CACHE.get(id(conv))
-        if pieces is None or pieces[0] != key:  # the folded layer's fp16 pieces, forward and backward operand: split once per weight
-            made = (key, ops.split_weights_f16x2(W, range_flag=flag), ops.split_weights_f16x2(W.t().contiguous(), range_flag=flag))
-            if not torch.cuda.is_current_stream_capturing():
-                _PIECE_CACHE[id(conv)] = made
-            pieces = made
-        return ops.group_linear_max(x.contiguous(), W, b, flag, pieces=pieces[1:], relu_input=relu_input)
-    if (FUSED_GROUP_MAX and x.is_cuda and b is not None and not WEIGHT_GRADS
-            and ops.group_linear_max_g16_supported(W.shape[1], W.shape[0], x.shape[-2])):
-        # widths the register-resident kernels do not cover (PCT's second Local_op, 256 -> 256): the tiled GEMM core
-        flag = range_flag(x.device)
-        key = ('g16', W.data_ptr(), W._version)
-        pieces = _PIECE_CACHE.get(id(conv))
-        if pieces is None or pieces[0] != key:
-            made = (key, ops.split_rows_f16x2(W, flag), ops.split_rows_f16x2(W.t().contiguous(), flag))
-            if not torch.cuda.is_current_stream_capturing():
-                _PIECE_CACHE[id(conv)] = made
-            pieces = made
-        return ops.group_linear_max_g16(x.contiguous(), pieces[1], pieces[2], b, flag, relu_input=relu_input)
+    fused = _fused_group_max(conv, W, b, x)
+    if fused is not None and fused[0] == 'reg':
+        return ops.group_linear_max(x.contiguous(), W, b, fused[2], pieces=fused[1], relu_input=relu_input)
+    if fused is not None:
+        return ops.group_linear_max_g16(x.contiguous(), fused[1][0], fused[1][1], b, fused[2], relu_input=relu_input)
     assert not relu_input, "relu_input is a property of the fused paths"
     return linear_relu_pm(conv, bn, x).max(dim=-2)[0]
 
@@ -213,14 +304,9 @@ def linear_lrelu_maxpool_pm(conv, bn, x, slope=0.2):
     if (FUSED_EMBEDDING_POOL and x.is_cuda and b is not None and not WEIGHT_GRADS and ops.gemm_f16x2_supported(C, Cin)
             and ops.gemm_f16x2_supported(Cin, C)):
         flag = range_flag(x.device)
-        key = ('pool', W.data_ptr(), W._version)
-        pieces = _PIECE_CACHE.get(id(conv))
-        if pieces is None or pieces[0] != key:
-            made = (key, ops.split_rows_f16x2(W, flag), ops.split_rows_f16x2(W.t().contiguous(), flag))
-            if not torch.cuda.is_current_stream_capturing():
-                _PIECE_CACHE[id(conv)] = made
-            pieces = made
-        return ops.linear_lrelu_pool(x.reshape(B * n, Cin), pieces[1], pieces[2], b, B, n, slope, flag)[:, :C]
+        pieces = _pieces(conv, W, 'pool', lambda M: ops.split_rows_f16x2(M, flag))
+        if pieces is not None:
+            return ops.linear_lrelu_pool(x.reshape(B * n, Cin), pieces[0], pieces[1], b, B, n, slope, flag)[:, :C]
     z = F.linear(x, W, b)
     if x.is_cuda and ops.lrelu_pool_supported(C):
         return ops.lrelu_pool(z.contiguous(), slope)[:, :C]

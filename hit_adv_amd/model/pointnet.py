@@ -371,11 +371,14 @@ class FoldedPointNet(nn.Module):
         self._split_on = self.s3_wr.device
 
     def check_range(self):
-        """fp16x2 mode: raise if any operand of the 128 -> 1024 layers left fp16's range since the last refresh (one small
-        device-to-host read; the attacks call it where they read their results back anyway)."""
+        """fp16x2 mode: raise ``Fp16RangeExceeded`` if any operand of the shared layers left fp16's range since the last
+        refresh (one small device-to-host read; the attacks call it where they read their results back anyway, and run
+        again in 'bf16x3' when it fires: ``_pointwise.degrade_on_fp16_range``)."""
         if self.matrix_mode == 'fp16x2' and self.range_flag.is_cuda and int(self.range_flag.item()) != 0:
-            raise RuntimeError("FoldedPointNet(matrix_mode='fp16x2'): an activation or weight of a 128 -> 1024 layer exceeds "
-                               "fp16's range (65504); the results are invalid -- use matrix_mode='bf16x3' or 'f32'")
+            from ._pointwise import Fp16RangeExceeded
+            raise Fp16RangeExceeded("FoldedPointNet(matrix_mode='fp16x2'): an activation or weight of a shared layer exceeds "
+                                    "fp16's range (65504) or is not finite; the results of this pass are invalid "
+                                    "(matrix_mode='bf16x3' and 'f32' have fp32's range)")
 
     linear_max_blocks = 0     # workgroups of the bf16x3 128 -> 1024 kernel (0 = one per CU); HiT_ADV.attack_many sets 128 on
     #                           ITS view while three or more attacks are in flight.  Per view, not per process.

@@ -165,6 +165,9 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
 
     from .. import groups_in_flight
     group = max(1, int(in_flight)) if hasattr(val_attack, 'attack_many') else 1
+    if hasattr(val_attack, 'in_flight'):  # un-stacked victims: capped (a stream, a workspace and activations per attack)
+        group = val_attack.in_flight(group)
+    stacked = val_attack.stacks() if hasattr(val_attack, 'stacks') else False
     pending = []
     presharded = getattr(test_loader, 'rank_sharded', False)  # rank_loader(): only this rank's batches arrive
     for i, (ori_data, label) in enumerate(test_loader):
@@ -175,7 +178,7 @@ def eval_ASR(model, test_loader, args, val_attack, device=None, metrics=None, lo
         if len(pending) == group:
             flush(pending)
             pending = []
-    for n in groups_in_flight(len(pending), group, stacked=getattr(val_attack, 'attacks_per_stack', 1) > 1):  # the tail, as bench.py's runner
+    for n in groups_in_flight(len(pending), group, stacked=stacked):  # the tail, as bench.py's runner
         flush(pending[:n])
         pending = pending[n:]
 

@@ -434,6 +434,7 @@ class HiTADVOracle:
                     st['o_bestdist'][e] = d
                     st['o_bestscore'][e] = pred_np[e]
                     st['o_bestattack'][e] = adv_np[e]
+                    st['taken'][e] = st.get('at', (-1, -1))  # (binary step, iteration) of the record's last replacement
 
         adv_loss = self.adv_func(logits, target)
         dist_loss = torch.tensor(0.)
@@ -472,7 +473,7 @@ class HiTADVOracle:
                   lower=torch.zeros(B), upper=torch.ones(B) * hp['max_weight'],
                   scale_const=torch.ones(B) * hp['init_weight'],
                   o_bestdist=np.array([1e10] * B), o_bestscore=np.array([-1] * B),
-                  o_bestattack=np.zeros((B, 3, N)))
+                  o_bestattack=np.zeros((B, 3, N)), taken=-np.ones((B, 2), dtype=np.int64), steps=[])
         return st
 
     def begin_step(self, st):
@@ -500,6 +501,11 @@ class HiTADVOracle:
             else:
                 st['upper'][e] = min(st['upper'][e], st['scale_const'][e])
             st['scale_const'][e] = (st['lower'][e] + st['upper'][e]) / 2.
+        # the bookkeeping as it stands when a step's bisection is done (fixture g5c holds the reference's)
+        st['steps'].append(dict(lower=st['lower'].numpy().astype(np.float64), upper=st['upper'].numpy().astype(np.float64),
+                                scale_const=st['scale_const'].numpy().astype(np.float64),
+                                o_bestdist=st['o_bestdist'].astype(np.float64), o_bestscore=st['o_bestscore'].astype(np.float64),
+                                bestdist=st['bestdist'].astype(np.float64), bestscore=st['bestscore'].astype(np.float64)))
 
     def finish(self, st):
         """Failure fill and return value, HiT_ADV.py:277-287."""
@@ -515,6 +521,7 @@ class HiTADVOracle:
         for step in range(self.hp['binary_step']):
             self.begin_step(st)
             for it in range(self.hp['num_iter']):
+                st['at'] = (step, it)
                 rec = self.inner_iteration(st)
                 if trace is not None:
                     rec.update(step=step, it=it, P=st['P'].detach().clone().numpy(),

@@ -14,6 +14,8 @@ Fixture index:
   g4_fps.npz           farthest_point_sample with recorded start indices
   g5_attack.npz        full HiT_ADV.attack trajectory with a toy victim
   g5b_attack_wide.npz  short trajectory at eval.py sizes (N=1024, C=192, T=256)
+  g5c_attack_long.npz  ten binary steps x 20 iterations: the bisection bounds after every step, the best-so-far records
+                       and the (step, iteration) each record was taken at, read from the running reference's own variables
   g6_adv_clip.npz      adversarial losses and clip/projection operators
   g7_cwknn.npz         CWKNN.attack trajectory with the toy victim
   g8_state_dicts.json  state_dict key/shape lists of the victims
@@ -291,6 +293,82 @@ def g5b():
                **{'w_' + k: v for k, v in model.state_dict().items()})
     out.update({'hp_' + k: v for k, v in hp.items()})
     save('g5b_attack_wide.npz', out)
+
+
+def watch_bookkeeping(run):
+    """Run ``run()`` (a call of the reference's HiT_ADV.attack) while watching the local variables of its frame through
+    ``sys.settrace``: nothing of the reference is edited or wrapped, its own bookkeeping is read as it runs.  Returns what
+    ``run`` returned plus, per binary step, (lower_bound, upper_bound, scale_const, o_bestdist, o_bestscore, bestdist,
+    bestscore) as they stand when the step's bisection is done, the same after the failure fill, and for every sample the
+    (step, iteration) at which its overall best record was last replaced (-1, -1: never)."""
+    rec = dict(steps=[], taken=None, final=None)
+    seen = dict(at=None, obd=None)
+
+    def snap(loc):
+        f = lambda v: np.array(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float64).copy()  # noqa: E731
+        return dict(lower=f(loc['lower_bound']), upper=f(loc['upper_bound']), scale_const=f(loc['scale_const']),
+                    o_bestdist=f(loc['o_bestdist']), o_bestscore=f(loc['o_bestscore']),
+                    bestdist=f(loc['bestdist']), bestscore=f(loc['bestscore']))
+
+    def local(frame, event, arg):
+        loc = frame.f_locals
+        if 'o_bestdist' not in loc or 'binary_step' not in loc:
+            return local
+        at = (loc['binary_step'], loc.get('iteration', -1))
+        obd = np.asarray(loc['o_bestdist'], dtype=np.float64)
+        if rec['taken'] is None:
+            rec['taken'] = -np.ones((obd.shape[0], 2), dtype=np.int64)
+            seen['obd'] = obd.copy()
+        changed = obd != seen['obd']  # replaced while the reference was inside iteration `at`
+        if changed.any() and event != 'return':
+            rec['taken'][changed] = at
+            seen['obd'] = obd.copy()
+        if seen['at'] is not None and at[0] != seen['at'][0]:  # a new binary step begins: the previous one's bisection is done
+            rec['steps'].append(snap(loc))
+        seen['at'] = at
+        if event == 'return':
+            rec['steps'].append(snap(loc))  # the last step's bisection ...
+            rec['final'] = dict(o_bestdist=np.array(loc['o_bestdist'], dtype=np.float64).copy())  # ... and the failure fill
+        return local
+
+    def tracer(frame, event, arg):
+        code = frame.f_code
+        if code.co_name == 'attack' and code.co_filename.endswith(os.path.join('ShapeAttack', 'HiT_ADV.py')):
+            return local
+        return None
+
+    sys.settrace(tracer)
+    try:
+        out = run()
+    finally:
+        sys.settrace(None)
+    return out, rec
+
+
+def g5c():
+    """Row a16 over a long horizon (VERDICT r03 #5): toy victim, B=4, N=256, C=16, binary_step=10 x num_iter=20."""
+    model = toy_victim(7)
+    data, _ = synth_batch(4, 256, first=40)
+    with torch.no_grad():
+        target = model(data[:, :, :3].transpose(1, 2).contiguous()).argmax(1)
+    hp = dict(attack_lr=1e-2, central_num=16, total_central_num=32, init_weight=10., max_weight=80.,
+              binary_step=10, num_iter=20, cd_weight=1e-4, ker_weight=1., hide_weight=1.,
+              curv_loss_knn=8, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+    att = HiT_ADV(model, adv_func=adv_utils.UntargetedLogitsAdvLoss(kappa=30.), **hp)
+
+    def run():
+        torch.manual_seed(17)
+        with redirect_stdout(io.StringIO()):
+            return att.attack(data, target)
+    (best, succ), rec = watch_bookkeeping(run)
+    assert len(rec['steps']) == hp['binary_step']
+    out = dict(best=best, success_num=int(succ), data=data, target=target, seed=17,
+               taken_step=rec['taken'][:, 0], taken_iter=rec['taken'][:, 1], final_o_bestdist=rec['final']['o_bestdist'],
+               **{'w_' + k: v for k, v in model.state_dict().items()})
+    for name in ('lower', 'upper', 'scale_const', 'o_bestdist', 'o_bestscore', 'bestdist', 'bestscore'):
+        out['step_' + name] = np.stack([s_[name] for s_ in rec['steps']])
+    out.update({'hp_' + k: v for k, v in hp.items()})
+    save('g5c_attack_long.npz', out)
 
 
 # ------------------------------------------------------------------ G6
@@ -769,7 +847,7 @@ def g24():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13',
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g5b', 'g5c', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13',
                              'g14', 'g15', 'g16', 'g17', 'g18', 'g19', 'g20', 'g21', 'g22', 'g23', 'g24']
     for name in which:
         globals()[name]()

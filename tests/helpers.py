@@ -54,6 +54,13 @@ def close(a, b, rtol=1e-5, atol=1e-6, what=None):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
+def note(what, value):
+    """A recorded statistic (no bound asserted, none implied): lands in the parity report next to the comparisons."""
+    test = os.environ.get('PYTEST_CURRENT_TEST', 'unknown').split(' ')[0]
+    PARITY.setdefault(test, []).append(dict(what=what + ' [statistic only]', max_abs=float(value), max_rel=0.0, max_abs_over_scale=0.0,
+                                            rtol=0.0, atol=0.0, n=1, statistic_only=True))
+
+
 def golden(name):
     z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return {k: z[k] for k in z.files}

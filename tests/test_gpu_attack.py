@@ -67,6 +67,62 @@ def test_hit_adv_follows_reference_trajectory(use_graph, fused):
                 close(np.clip(row['sigma'], 0.1, 1.2), fx['sigma'][i + 1], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_hit_adv_bookkeeping_over_ten_binary_steps(use_graph):
+    """Row a16 on a long horizon (fixture g5c: the reference's own variables, read while it ran 10 binary steps x 20
+    iterations): after every step the device-resident bisection bounds, distance weight and best records equal the
+    reference's -- bounds, weights and predicted classes exactly, distances to 1e-5 --, the overall best of every sample is
+    last replaced at the same (step, iteration), and the failure fill / returned clouds / success count agree.  With the
+    captured graphs (ten iterations per replay) and with the eager loop."""
+    fx = golden('g5c_attack_long.npz')
+    att = _attacker(fx, use_graph=use_graph)
+    steps, taken, last = [], -np.ones((4, 2), dtype=np.int64), dict(obd=None, at=(-1, -1))
+    end_step, begin_step, iteration = att._end_step, att._begin_step, att._iteration
+
+    def cpu(t):
+        return t.detach().cpu().numpy().astype(np.float64)
+
+    def watched_begin(ws, binary_step):
+        last['at'] = (binary_step, -1)
+        begin_step(ws, binary_step)
+
+    def watched_iteration(ws):  # eager loop only: which iteration replaced a sample's overall best
+        last['at'] = (last['at'][0], last['at'][1] + 1)
+        iteration(ws)
+        obd = cpu(ws.state['o_bestdist'])
+        if last['obd'] is not None:
+            taken[obd != last['obd']] = last['at']
+        last['obd'] = obd
+
+    def watched_end(ws):
+        end_step(ws)
+        st = ws.state
+        steps.append(dict(lower=cpu(ws.lower), upper=cpu(ws.upper), scale_const=cpu(ws.scale_const),
+                          o_bestdist=cpu(st['o_bestdist']), o_bestscore=cpu(st['o_bestscore']),
+                          bestdist=cpu(st['bestdist']), bestscore=cpu(st['bestscore'])))
+
+    att._begin_step, att._end_step = watched_begin, watched_end
+    if not use_graph:
+        att._iteration = watched_iteration
+    torch.manual_seed(int(fx['seed']))
+    # the watcher needs the overall best before the first iteration: 1e10 everywhere (as _reset_search leaves it)
+    last['obd'] = np.full(4, 1e10)
+    best, succ = att.attack(T(fx['data']), T(fx['target']))
+    assert att.last_graph_used == bool(use_graph) and len(steps) == 10
+    for i, rec in enumerate(steps):
+        for name in ('lower', 'upper', 'scale_const', 'o_bestscore', 'bestscore'):
+            np.testing.assert_array_equal(rec[name], fx['step_' + name][i], err_msg="%s after step %d" % (name, i))
+        for name in ('o_bestdist', 'bestdist'):
+            close(rec[name], fx['step_' + name][i], rtol=1e-5, atol=0, what='%s_step%d' % (name, i))
+    if not use_graph:
+        np.testing.assert_array_equal(taken[:, 0], fx['taken_step'])
+        np.testing.assert_array_equal(taken[:, 1], fx['taken_iter'])
+    close(att.last_bestdist, fx['final_o_bestdist'], rtol=1e-5, atol=0, what='final_o_bestdist')
+    close(best, fx['best'], rtol=0, atol=1e-5, what='best')
+    assert int(succ) == int(fx['success_num'])
+    np.testing.assert_array_equal(att.last_lower_bound.numpy().astype(np.float64), fx['step_lower'][-1])
+
+
 def test_hit_adv_wide_configuration_vs_reference():
     fx = golden('g5b_attack_wide.npz')  # N=1024, C=192, T=256: eval.py sizes
     att = _attacker(fx)
@@ -533,10 +589,12 @@ def test_dgcnn_victim_on_gpu_and_under_attack():
     logits = m(x)
     # feature-space neighbour tables come from GPU GEMMs; a near-tie can pick another neighbour, so the
     # tolerance is looser than for a fixed graph
-    close(logits, fx['logits'], rtol=2e-3, atol=2e-4)
+    close(logits, fx['logits'], rtol=1e-4, atol=2e-5, what='DGCNN logits vs the reference (g10)')
     (logits * T(fx['grad_w']).cuda()).sum().backward()
-    g = x.grad.cpu().numpy()
-    assert np.abs(g - fx['grad_x']).max() <= 0.05 * np.abs(fx['grad_x']).max()
+    # through the recording helpers (pinned at 4x what MI355X achieves); a flipped feature-space neighbour would move a
+    # whole edge's contribution, so the bounds are the gradient_close pair, not an elementwise one
+    gradient_close(x.grad, fx['grad_x'], 'DGCNN input gradient vs the reference (g10)', frac_bound=2e-3, l2_bound=1e-3)
+    close(x.grad, fx['grad_x'], rtol=0, atol=1e-3 * float(np.abs(fx['grad_x']).max()), what='DGCNN input gradient vs the reference (g10), max |diff|')
     data, _ = synth_batch(4, 512, first=1200)
     with torch.no_grad():
         label = m(data[:, :, :3].transpose(1, 2).contiguous().cuda()).argmax(1)
@@ -690,7 +748,7 @@ def test_pct_victim_on_gpu():
     logits = m(x)
     close(logits, fx['logits'], rtol=1e-4, atol=1e-5, what='PCT logits vs the reference (g12)')
     (logits * T(fx['grad_w']).cuda()).sum().backward()
-    gradient_close(x.grad, fx['grad_x'], 'PCT input gradient vs the reference (g12)', frac_bound=1., l2_bound=0.15)
+    gradient_close(x.grad, fx['grad_x'], 'PCT input gradient vs the reference (g12)', frac_bound=0.5, l2_bound=0.04)
 
 
 def test_hit_adv_pointnet_gpu_vs_cpu_oracle_short_run():
@@ -861,6 +919,114 @@ def test_attack_many_equals_sequential_attacks(per_stack):
     torch.manual_seed(78)
     ref = att.attack(*batches[0])
     assert np.array_equal(again[0], ref[0])
+
+
+def test_attack_many_headline_configuration():
+    """The configuration bench.py's headline times -- twelve batches of 32 x 1024, eval.py hyper-parameters (C = 192), three
+    stacks of four on three streams with V1 on 128 workgroups -- returns the bits of twelve back-to-back ``attack()`` calls
+    (binary_step x num_iter shortened to 2 x 6: the loop is the same graph replayed)."""
+    import hit_adv_amd
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(0)
+    m = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    batches = []
+    for i in range(12):
+        d, _ = synth_batch(32, 1024, first=4000 + 32 * i)
+        with torch.no_grad():
+            lab = m(d[:, :, :3].transpose(1, 2).contiguous().cuda())[0].argmax(1)
+        batches.append((d.cuda(), lab))
+    hp = dict(binary_step=2, num_iter=6, attack_lr=1e-2, init_weight=10., max_weight=80., cd_weight=1e-4, ker_weight=1.,
+              hide_weight=1., curv_loss_knn=16, central_num=192, total_central_num=256, max_sigm=1.2, min_sigm=0.1, budget=0.55,
+              verbose=False)
+    att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), **hp)
+    torch.manual_seed(31)
+    seq = [att.attack(d, l) for d, l in batches]
+    att2 = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), **hp)
+    assert att2.attacks_per_stack == 4 and att2.stacks() and att2.in_flight(12) == 12
+    torch.manual_seed(31)
+    par = att2.attack_many(batches)
+    stacks = [k for k in att2._ws if isinstance(k[3], str)]
+    assert att2.last_graph_used and len(stacks) == 3 and all(k[5] == 4 for k in stacks)  # three stacks of four really ran
+    if hit_adv_amd.hardware_queues() < 8:
+        pytest.skip("the stacks ran, but on the runtime's 4 hardware queues (GPU_MAX_HW_QUEUES was not in place in time)")
+    for i, ((a, na), (b, nb)) in enumerate(zip(seq, par)):
+        assert np.array_equal(a, b) and int(na) == int(nb), "batch %d differs between the stacks and its own attack()" % i
+
+
+def _overflowing_pointnet(scale=4e5):
+    """A PointNet whose STN3d 64 -> 128 activations reach ~1e5 (beyond fp16's 65504; far inside fp32's range)."""
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    torch.manual_seed(0)
+    m = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    with torch.no_grad():
+        m.feat.stn.conv2.weight.mul_(scale)
+    return m
+
+
+@pytest.mark.parametrize("many", [False, True])
+def test_fp16_range_degrades_to_bf16x3_instead_of_raising(many):
+    """The reference never fails on range.  When an activation leaves fp16's range the fp16x2 engine's flag trips; the attack
+    then runs again with the shared layers as three bf16 pieces (fp32's range) -- same draws from the CPU generator, fresh
+    graphs -- and returns exactly what a process that was configured with ``matrix_mode = 'bf16x3'`` from the start returns."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model import _pointwise
+    from hit_adv_amd.model.pointnet import FoldedPointNet
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    assert FoldedPointNet.matrix_mode == 'fp16x2'
+    m = _overflowing_pointnet()
+    batches = []
+    for i in range(2 if many else 1):
+        d, lab = synth_batch(4, 256, first=7000 + 4 * i)
+        batches.append((d.cuda(), lab.cuda()))
+    hp = dict(binary_step=2, num_iter=6, cd_weight=1e-4, ker_weight=1., hide_weight=1., curv_loss_knn=8, central_num=16,
+              total_central_num=32, max_sigm=1.2, min_sigm=0.1, budget=0.55, verbose=False)
+    run = (lambda a: a.attack_many(batches)) if many else (lambda a: [a.attack(*batches[0])])
+    _pointwise._DEGRADE_WARNED = False
+    att = HiT_ADV(m, UntargetedLogitsAdvLoss(30.), **hp)
+    torch.manual_seed(9)
+    with pytest.warns(RuntimeWarning, match="fp32's range"):
+        got = run(att)
+    assert FoldedPointNet.matrix_mode == 'fp16x2'  # the degradation lasted for that call only
+    torch.manual_seed(9)
+    with _pointwise.full_range_arithmetic():
+        assert FoldedPointNet.matrix_mode == 'bf16x3'
+        want = run(HiT_ADV(m, UntargetedLogitsAdvLoss(30.), **hp))
+    for (a, na), (b, nb) in zip(got, want):
+        assert np.isfinite(a).all() and np.array_equal(a, b) and int(na) == int(nb)
+    # a second overflowing call degrades again, silently
+    import warnings as W
+    torch.manual_seed(9)
+    with W.catch_warnings():
+        W.simplefilter("error")
+        again = run(att)
+    assert all(np.array_equal(a, b) for (a, _), (b, _) in zip(again, want))
+
+
+def test_fp16_range_watch_sees_nan():
+    """A NaN operand raises the range flag too (``fmaxf`` would drop it): the packed V2 -> V1 hand-off and the unpacked split."""
+    from hit_adv_amd import ops
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    torch.manual_seed(0)
+    m = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
+    v = m.attack_view()
+    x = torch.randn(2, 3, 256, device='cuda')
+    v(x)
+    assert int(v.range_flag.item()) == 0
+    xn = x.clone()
+    xn[1, 0, 17] = float('nan')
+    v(xn)
+    assert int(v.range_flag.item()) == 1
+    # the un-packed split inside V1 (MODE 1)
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    a = torch.randn(2 * 256, 128, device='cuda')
+    W2 = ops.split_weights_f16x2(torch.randn(1024, 128, device='cuda') * 0.1, range_flag=flag)
+    ops.linear_max_fwd_f16x2(a, W2, 2, 256, range_flag=flag)
+    assert int(flag.item()) == 0
+    a[300, 5] = float('nan')
+    ops.linear_max_fwd_f16x2(a, W2, 2, 256, range_flag=flag)
+    assert int(flag.item()) == 1
 
 
 # ------------------------------------------------------------------ the remaining CW attacks (fixtures g14-g21)

@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import close, gradient_close, synth_batch
+from helpers import close, gradient_close, note, synth_batch
 from oracle import c_oracle as N
 from oracle import hitadv_oracle as O
 from oracle import victim_geometry as VG
@@ -204,6 +204,79 @@ def test_dgcnn_gradient_vs_float64_module_on_the_same_graphs():
     _gradient_vs_float64(xg.grad, xd.grad, 'DGCNN input gradient')
 
 
+@contextlib.contextmanager
+def _pct_pool_winners(winners, pre_pool=None):
+    """While active, every max-pool of a PCT pass on the GPU fast path appends its arg-max table to ``winners``, in the
+    order the passes run them: Local_op 1 [B,512,128], Local_op 2 [B,256,256], the final pool over the points [B,1024]."""
+    from hit_adv_amd import ops
+    real_max, real_pool, real_group, real_g16 = torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16
+    real_fused = ops.linear_lrelu_pool
+
+    def spy_g16(xx, Wp, Wtp, bias, flag=None, return_arg=False, **kw):  # the second Local_op's last layer: the tiled GEMM core
+        out, arg = real_g16(xx, Wp, Wtp, bias, flag, return_arg=True, **kw)
+        winners.append(arg.detach().cpu().long())
+        return (out, arg) if return_arg else out
+
+    def spy_group(xx, Wr, bias, flag=None, return_arg=False, **kw):  # Local_op's last layer + max over the neighbours, fused
+        out, arg = real_group(xx, Wr, bias, flag, return_arg=True, **kw)
+        winners.append(arg.detach().cpu().long())
+        return (out, arg) if return_arg else out
+
+    def spy_max(self, *a, **k):  # the two max-over-neighbours of Local_op.from_points
+        out = real_max(self, *a, **k)
+        if a or k:
+            winners.append(out[1].detach().cpu())
+        return out
+
+    def spy_pool(Z, slope=0.2):
+        out, arg = real_pool(Z, slope, return_arg=True)
+        winners.append(arg.detach().cpu().long())
+        if pre_pool is not None:
+            pre_pool.append(Z.detach().cpu())
+        return out
+
+    def spy_fused(xx, Wp, Wtp, bias, Bn, npts, slope=0.2, flag=None, return_arg=False):  # conv_fuse + LeakyReLU + max pool, fused
+        out, arg = real_fused(xx, Wp, Wtp, bias, Bn, npts, slope, flag, return_arg=True)
+        winners.append(arg.detach().cpu().long())
+        if pre_pool is not None:
+            pieces = Wp.view(torch.float16).float()  # the layer's pre-activation never exists on this path: rebuilt here from the
+            W = pieces[0] + pieces[1] / 2048.0       # operands the kernel was given (fp32 GEMM: the same values to fp32 rounding)
+            pre_pool.append((xx.detach() @ W.t() + bias).view(Bn, npts, -1).cpu())
+        return (out, arg) if return_arg else out
+    try:
+        torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16 = spy_max, spy_pool, spy_group, spy_g16
+        ops.linear_lrelu_pool = spy_fused
+        yield winners
+    finally:
+        torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16 = real_max, real_pool, real_group, real_g16
+        ops.linear_lrelu_pool = real_fused
+
+
+@contextlib.contextmanager
+def _imposed_pool_winners(winners, own=None, z=None):
+    """While active, the plain PCT module's ``F.adaptive_max_pool1d`` calls take the recorded winners, in order, instead of
+    their own arg-max (a no-op once the recording is used up): the module's max-pools are evaluated where the GPU pass
+    evaluated them, as its sampling tables already are."""
+    import torch.nn.functional as F
+    queue = iter(winners)
+    real_amp = F.adaptive_max_pool1d
+
+    def amp(t, o):
+        if own is not None:
+            own.append(t.detach().argmax(dim=2))
+        if z is not None:
+            z.append(t.detach())
+        idx = next(queue, None)                                  # [B,S,C] (neighbour maxima) or [B,C] (final pool)
+        if idx is None:
+            return real_amp(t, o)
+        return t.gather(2, idx.reshape(t.shape[0], t.shape[1], 1))
+    try:
+        F.adaptive_max_pool1d = amp
+        yield
+    finally:
+        F.adaptive_max_pool1d = real_amp
+
+
 def test_pct_gradient_vs_float64_module_on_the_same_tables():
     """PCT at B = 2, N = 1024 on the SAME FPS and kNN grouping tables: (a) the GPU fast path (points-major GEMMs,
     hitadv_group_add_relu, the fused last layers and pooled embedding layer), (b) the plain nn.Module in fp32 on the GPU, (c) the plain nn.Module in
@@ -234,49 +307,13 @@ def test_pct_gradient_vs_float64_module_on_the_same_tables():
     feed = _sampling.feed_for(gm, 2, 1024, 1, 'cuda')
     log, saved = _record_tables(PCT, ['fps', 'knn_point'])
     winners, pre_pool = [], []
-    real_max, real_pool, real_group, real_g16 = torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16
-
-    def spy_g16(xx, Wp, Wtp, bias, flag=None, return_arg=False, **kw):  # the second Local_op's last layer: the tiled GEMM core
-        out, arg = real_g16(xx, Wp, Wtp, bias, flag, return_arg=True, **kw)
-        winners.append(arg.detach().cpu().long())
-        return (out, arg) if return_arg else out
-
-    def spy_group(xx, Wr, bias, flag=None, return_arg=False, **kw):  # Local_op's last layer + max over the neighbours, fused
-        out, arg = real_group(xx, Wr, bias, flag, return_arg=True, **kw)
-        winners.append(arg.detach().cpu().long())
-        return (out, arg) if return_arg else out
-
-    def spy_max(self, *a, **k):  # the two max-over-neighbours of Local_op.from_points
-        out = real_max(self, *a, **k)
-        if a or k:
-            winners.append(out[1].detach().cpu())
-        return out
-
-    def spy_pool(Z, slope=0.2):
-        out, arg = real_pool(Z, slope, return_arg=True)
-        winners.append(arg.detach().cpu().long())
-        pre_pool.append(Z.detach().cpu())
-        return out
-
-    real_fused = ops.linear_lrelu_pool
-
-    def spy_fused(xx, Wp, Wtp, bias, Bn, npts, slope=0.2, flag=None, return_arg=False):  # conv_fuse + LeakyReLU + max pool, fused
-        out, arg = real_fused(xx, Wp, Wtp, bias, Bn, npts, slope, flag, return_arg=True)
-        winners.append(arg.detach().cpu().long())
-        pieces = Wp.view(torch.float16).float()  # the layer's pre-activation never exists on this path: rebuilt here from the
-        W = pieces[0] + pieces[1] / 2048.0       # operands the kernel was given (fp32 GEMM: the same values to fp32 rounding)
-        pre_pool.append((xx.detach() @ W.t() + bias).view(Bn, npts, -1).cpu())
-        return (out, arg) if return_arg else out
     try:
-        torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16 = spy_max, spy_pool, spy_group, spy_g16
-        ops.linear_lrelu_pool = spy_fused
-        xg = x.cuda().requires_grad_()
-        with _sampling.using(feed):
-            logits = gm(xg)
-        (logits * w.cuda()).sum().backward()
+        with _pct_pool_winners(winners, pre_pool):
+            xg = x.cuda().requires_grad_()
+            with _sampling.using(feed):
+                logits = gm(xg)
+            (logits * w.cuda()).sum().backward()
     finally:
-        torch.Tensor.max, ops.lrelu_pool, ops.group_linear_max, ops.group_linear_max_g16 = real_max, real_pool, real_group, real_g16
-        ops.linear_lrelu_pool = real_fused
         _restore(PCT, saved)
     assert len(log['fps']) == 2 and len(log['knn_point']) == 2
     assert [tuple(t.shape) for t in winners] == [(2, 512, 128), (2, 256, 256), (2, 1024)] and len(pre_pool) == 1
@@ -294,24 +331,13 @@ def test_pct_gradient_vs_float64_module_on_the_same_tables():
     def float64_run(impose):
         """The plain module in float64 on the CPU, same tables; ``impose``: its three max-pools take the GPU run's winners."""
         z64, own = [], []
-        queue = iter(winners)
-        real_amp = F.adaptive_max_pool1d
-
-        def amp(t, o):
-            own.append(t.detach().argmax(dim=2))
-            z64.append(t.detach())
-            if not impose:
-                return real_amp(t, o)
-            idx = next(queue)                                    # [B,S,C] (neighbour maxima) or [B,C] (final pool)
-            return t.gather(2, idx.reshape(t.shape[0], t.shape[1], 1))
         saved = _replay_tables(PCT, log)
         try:
-            F.adaptive_max_pool1d = amp
-            xd = x.double().requires_grad_()
-            ld = copy.deepcopy(m).double()(xd)
-            (ld * w.double()).sum().backward()
+            with _imposed_pool_winners(winners if impose else [], own, z64):
+                xd = x.double().requires_grad_()
+                ld = copy.deepcopy(m).double()(xd)
+                (ld * w.double()).sum().backward()
         finally:
-            F.adaptive_max_pool1d = real_amp
             _restore(PCT, saved)
         return ld.detach(), xd.grad, z64, own
     ld, gd, z64, own = float64_run(False)
@@ -439,63 +465,84 @@ def test_cfg5_pct_batch32_cw_sweep_vs_cpu_oracle(which):
 
     gpu_model = copy.deepcopy(cpu_model)
     iters = 3
-    if which == "knn":
-        att = CW.CWKNN(gpu_model, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), recording_clip, attack_lr=1e-2,
-                       num_iter=iters, verbose=False)
+    winners = []
+
+    def gpu_run():
+        """The attack on the GPU (three iterations: the eager loop, so that the spies see every pass)."""
+        del trace[:]
+        del winners[:]
         torch.manual_seed(23)
-        final, succ = att.attack(xyz, target)
+        with _pct_pool_winners(winners):
+            if which == "knn":
+                att = CW.CWKNN(gpu_model, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), recording_clip, attack_lr=1e-2,
+                               num_iter=iters, verbose=False)
+                return att.attack(xyz, target)
+            if which == "advpc":
+                att = CW.CWAdvPC(gpu_model, copy.deepcopy(ae), LogitsAdvLoss(kappa=0.), L2Dist(), attack_lr=1e-2, binary_step=1,
+                                 num_iter=iters, GAMMA=0.25, clip_func=recording_clip, verbose=False)
+                return att.attack(xyz, target, label)[1:]
+            att = CW.CWAOF(gpu_model, UntargetedLogitsAdvLoss(kappa=30.), L2Dist(), attack_lr=1e-2, binary_step=1,
+                           num_iter=iters, GAMMA=0.25, low_pass=100, clip_func=recording_clip, verbose=False)
+            return att.attack(xyz, label)
+
+    def oracle_run(impose):
+        """The oracle restatement driving the plain PCT module on the CPU; ``impose``: its max-pools take the winners of the
+        GPU run's passes, pass for pass (both loops run the victim in the reference's order: the FPS draws depend on it)."""
+        del otrace[:]
         torch.manual_seed(23)
-        ofinal, osucc = O.cw_knn_attack(victim, lambda l, t: O.logits_adv_loss(l, t, 15.), _direct_chamfer_knn, clip_o,
-                                        xyz, target, attack_lr=1e-2, num_iter=iters, trace=otrace)
-        orows = [r['adv'] for r in otrace]
-        lr = 1e-2
-    elif which == "advpc":
-        torch.manual_seed(5)
-        ae = _ToyAE().eval()
-        att = CW.CWAdvPC(gpu_model, copy.deepcopy(ae), LogitsAdvLoss(kappa=0.), L2Dist(), attack_lr=1e-2, binary_step=1,
-                         num_iter=iters, GAMMA=0.25, clip_func=recording_clip, verbose=False)
-        torch.manual_seed(23)
-        bestdist, final, succ = att.attack(xyz, target, label)
-        torch.manual_seed(23)
-        obest, ofinal, osucc = O.cw_family_attack(victim, lambda l, t: O.logits_adv_loss(l, t, 0.), clip_o, xyz, target,
-                                                  y_truth=label, ae_model=ae, targeted=True, fresh=True, attack_lr=1e-2,
-                                                  binary_step=1, num_iter=iters, GAMMA=0.25, trace=otrace)
-        orows = [r['adv'] for r in otrace]
-        lr = 1e-2
-    else:
-        att = CW.CWAOF(gpu_model, UntargetedLogitsAdvLoss(kappa=30.), L2Dist(), attack_lr=1e-2, binary_step=1,
-                       num_iter=iters, GAMMA=0.25, low_pass=100, clip_func=recording_clip, verbose=False)
-        torch.manual_seed(23)
-        final, succ = att.attack(xyz, label)
-        torch.manual_seed(23)
-        ofinal, osucc = O.cw_aof_attack(victim, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), clip_o, xyz, label,
-                                        attack_lr=1e-2, binary_step=1, num_iter=iters, GAMMA=0.25, low_pass=100,
-                                        trace=otrace)
-        orows = [r['adv'] for r in otrace]
-        lr = 1e-2
-    rows = trace[:iters]
-    assert len(rows) == iters and len(orows) >= iters
+        with _imposed_pool_winners(list(winners) if impose else []):
+            if which == "knn":
+                return O.cw_knn_attack(victim, lambda l, t: O.logits_adv_loss(l, t, 15.), _direct_chamfer_knn, clip_o,
+                                       xyz, target, attack_lr=1e-2, num_iter=iters, trace=otrace)
+            if which == "advpc":
+                return O.cw_family_attack(victim, lambda l, t: O.logits_adv_loss(l, t, 0.), clip_o, xyz, target,
+                                          y_truth=label, ae_model=ae, targeted=True, fresh=True, attack_lr=1e-2,
+                                          binary_step=1, num_iter=iters, GAMMA=0.25, trace=otrace)[1:]
+            return O.cw_aof_attack(victim, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), clip_o, xyz, label,
+                                   attack_lr=1e-2, binary_step=1, num_iter=iters, GAMMA=0.25, low_pass=100, trace=otrace)
+
+    torch.manual_seed(5)
+    ae = _ToyAE().eval()
+    final, succ = gpu_run()
+    rows = [r.copy() for r in trace[:iters]]
+    passes = dict(knn=1, advpc=4, aof=4)[which] * iters  # victim passes inside the loop (gradient + fresh views)
+    assert len(rows) == iters and len(winners) >= 3 * passes
+    assert [tuple(t.shape) for t in winners[:3]] == [(32, 512, 128), (32, 256, 256), (32, 1024)]
     ori = xyz.transpose(1, 2).numpy()
-    # The victim's sampling / grouping tables are the oracle's bit for bit (PCT's sampler and kNN grouping run in the
-    # reference's own arithmetic; round 2 blamed them for the spread below -- they were not the cause).  What is left is PCT
-    # itself: its final max over the points has near-ties inside fp32 rounding in a few channels of every forward pass
-    # (test_pct_gradient_vs_float64_module_on_the_same_tables: six of 2048 in one pass), each flipped winner re-routes a whole
-    # channel's gradient (several per cent of its norm), and AdvPC / AOF have no distance term: the victim's gradient is all
-    # there is and Adam divides it by its own magnitude.  Iterate 0 (one step of +-lr from the same start) is therefore
-    # tight in the median and in the 99th percentile; iterates 1 and 2 inherit the flips of the passes before them through
-    # Adam's moments and are held to the median (a wrong gradient would put the median at ~lr = 1e-2; bounds = 4 x achieved,
-    # profiles/r03_parity_report.json).  CWKNN's distance term conditions every point: all iterates stay on the oracle's.
-    bounds = dict(knn=[(1e-6, 1e-3)] * 3, advpc=[(1e-6, 3e-3), (5e-4, 3e-2), (4e-3, 5e-2)],
-                  aof=[(2e-6, 4e-3), (8e-4, 3.5e-2), (5e-3, 6e-2)])[which]
-    failures = []
+    lr = 1e-2
+    # (1) PARITY: the oracle evaluated where the GPU pass was evaluated -- same sampling tables (bit for bit, by
+    # construction of the victim's samplers) and the same max-pool winners, pass for pass.  PCT's final max over the points
+    # has near-ties inside fp32 rounding in a few channels of every pass (test_pct_gradient_vs_float64_module_on_the_same_
+    # tables: six of 2048 in one pass; each flipped winner re-routes a channel's gradient, and AdvPC / AOF have no distance term:
+    # Adam divides the victim's gradient by its own magnitude).  With the winners imposed the iterates are a function of the
+    # inputs again and every iterate is held to 1e-5.
+    ofinal, osucc = oracle_run(impose=True)
+    orows = [r['adv'] for r in otrace]
+    assert len(orows) >= iters
+    # Adam's step is lr * m / (sqrt(v) + 1e-8): a coordinate whose gradient is itself below the evaluation error (|g| of a
+    # few 1e-9 against an fp32 gradient error of ~1e-4 relative L2) may take a step of the other sign, a difference of up to
+    # 2 lr that no evaluation order can remove.  So the bar is 1e-5 on the 99th percentile of |gpu - oracle| over all
+    # 98,304 coordinates, and the SHARE of coordinates beyond 1e-5 is held to OFF (4x what MI355X achieves).
+    OFF = dict(knn=2e-3, advpc=2e-2, aof=2e-2)[which]
     for i in range(iters):
-        err = np.abs(rows[i] - orows[i])
         assert np.abs(rows[i] - ori).max() <= 0.18 + 1e-6
-        assert err.max() <= 2 * lr * (i + 1) + 1e-6, (i, err.max())        # Adam's reach
-        for stat, value, bound in (('median', np.median(err), bounds[i][0]), ('99th percentile', np.quantile(err, 0.99), bounds[i][1])):
-            try:
-                close(value, 0., rtol=0, atol=bound, what='cfg5 %s iterate %d: %s |gpu - oracle|' % (which, i, stat))
-            except AssertionError:
-                failures.append((i, stat, float(value), bound))
-    assert not failures, failures
+        err = np.abs(rows[i] - orows[i])
+        close(np.quantile(err, 0.99), 0., rtol=0, atol=1e-5,
+              what='cfg5 %s iterate %d, same max-pool winners: 99th percentile |gpu - oracle|' % (which, i))
+        close(float((err > 1e-5).mean()), 0., rtol=0, atol=OFF,
+              what='cfg5 %s iterate %d, same max-pool winners: share of coordinates off by > 1e-5' % (which, i))
+        note('cfg5 %s iterate %d, same max-pool winners: median |gpu - oracle|' % (which, i), np.median(err))
+        note('cfg5 %s iterate %d, same max-pool winners: max |gpu - oracle|' % (which, i), err.max())
+    close(float((np.abs(final - ofinal) > 1e-5).mean()), 0., rtol=0, atol=OFF, what='cfg5 %s returned clouds, same winners: share off by > 1e-5' % which)
     assert final.shape == ofinal.shape and int(succ) == int(osucc)
+    # (2) for the record: the free-running oracle (its own winners).  Statistics only -- what the flipped winners cost.
+    oracle_run(impose=False)
+    for i in range(iters):
+        err = np.abs(rows[i] - otrace[i]['adv'])
+        assert err.max() <= 2 * lr * (i + 1) + 1e-6, (i, err.max())        # Adam's reach: a sanity check, not a parity bound
+        note('cfg5 %s iterate %d, free-running oracle: median |gpu - oracle|' % (which, i), np.median(err))
+        note('cfg5 %s iterate %d, free-running oracle: 99th percentile |gpu - oracle|' % (which, i), np.quantile(err, 0.99))
+    if which == "knn":  # the distance term conditions every point: the free-running iterates stay on the oracle's too
+        for i in range(iters):
+            close(np.median(np.abs(rows[i] - otrace[i]['adv'])), 0., rtol=0, atol=1e-6,
+                  what='cfg5 knn iterate %d, free-running: median |gpu - oracle|' % i)

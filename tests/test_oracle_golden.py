@@ -151,6 +151,34 @@ def test_g5b_wide_attack_short_trajectory():
     assert int(succ) == int(fx['success_num'])
 
 
+def test_g5c_bookkeeping_over_ten_binary_steps():
+    """Row a16 on a long horizon: after each of ten binary steps the oracle's bisection bounds, distance weight, per-step
+    and overall best records equal the ones read from the running reference's own variables -- discrete ones exactly, float
+    ones to 1e-5 --, and every sample's overall best was last replaced at the same (step, iteration)."""
+    fx = golden('g5c_attack_long.npz')
+    att, trace, best, succ = _run_oracle_attack(fx)
+    st = att.state
+    assert len(st['steps']) == 10 and len(trace) == 200
+    for i, rec in enumerate(st['steps']):
+        for name in ('lower', 'upper', 'scale_const'):  # dyadic fractions of (init_weight, max_weight): exact
+            np.testing.assert_array_equal(rec[name], fx['step_' + name][i], err_msg="%s after step %d" % (name, i))
+        for name in ('o_bestscore', 'bestscore'):
+            np.testing.assert_array_equal(rec[name], fx['step_' + name][i], err_msg="%s after step %d" % (name, i))
+        for name in ('o_bestdist', 'bestdist'):
+            close(rec[name], fx['step_' + name][i], rtol=1e-5, atol=0)
+    np.testing.assert_array_equal(st['taken'][:, 0], fx['taken_step'])
+    np.testing.assert_array_equal(st['taken'][:, 1], fx['taken_iter'])
+    close(st['o_bestdist'], fx['final_o_bestdist'], rtol=1e-5, atol=0)
+    close(best, fx['best'], rtol=1e-5, atol=1e-6)
+    assert int(succ) == int(fx['success_num'])
+    # the fixture exercises every branch of the bisection: bounds moved both ways, a success refused because its
+    # distance did not beat the overall best, samples without any success in a step
+    lo, up = fx['step_lower'], fx['step_upper']
+    assert (np.diff(lo, axis=0) > 0).any() and (np.diff(up, axis=0) < 0).any()
+    assert ((fx['step_bestscore'] != -1) & (fx['step_bestdist'] > fx['step_o_bestdist'])).any()
+    assert (fx['step_bestscore'] == -1).any()
+
+
 def test_g7_cwknn_trajectory():
     fx = golden('g7_cwknn.npz')
     model = toy_from_fixture(fx)
