@@ -323,11 +323,19 @@ def loop_floor(B, N, classes=40, matrix_mode='bf16x3', C=192):
     hbm += 3 * 2 * 4.0 * 1024 * 128 + 4.0 * B * N * 3 * 4      # 128 -> 1024 weights (as pieces: the same bytes), clouds in / out
     hbm += 4.0 * B * (C * 4 * 4 + tiles // B * 4096 * 2)        # attack parameters + Adam moments, transform-gradient partials
     us = dict(bf16_mfma=bf16_flop / BF16_MFMA_PEAK / 1e6, f32_mfma=f32_flop / F32_MFMA_PEAK / 1e6, hbm=hbm / HBM_PEAK_GBS / 1e3)
+    # two readings of the same three times: ADDED (no overlap at all: what a serial schedule of perfect kernels takes) and the
+    # MAX of matrix time and HBM time (perfect overlap: below this no schedule can go)
     return dict(executed_bf16_flop=bf16_flop, executed_f32_mfma_flop=f32_flop, hbm_bytes=hbm,
-                us=dict({k: round(v, 2) for k, v in us.items()}), loop_floor_us=round(sum(us.values()), 2))
+                us=dict({k: round(v, 2) for k, v in us.items()}), loop_floor_us=round(sum(us.values()), 2),
+                loop_floor_max_us=round(max(us['bf16_mfma'] + us['f32_mfma'], us['hbm']), 2))
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline
+# The port's inner iteration against the imported reference's, measured in the build container (the reference cannot travel):
+# tests/golden/time_reference.py, B = 8, 8 threads, median of 22 iterations each, both warmed up, runs alternated; the two
+# execute the same torch ops in the same number (op-for-op profile in DESIGN.md section 7), the ratio is host noise around 1.
+PORT_OVER_REFERENCE = dict(ratio=1.01, measured="build container, 8 cores: three runs of tests/golden/time_reference.py 8 12 "
+                                                "gave 1.12, 0.94, 0.96 (outputs equal to 0.0)", reference_runs_on_gpu_box=False)
 def _cores():
     try:
         avail = len(os.sched_getaffinity(0))
@@ -367,7 +375,7 @@ def cpu_baseline_hit_adv(cfg, timed_iters):
     return dict(value=B / total, unit="clouds/s", cores=cores, host_cpus=avail, kind="port",
                 sample="setup (%.1f s) + 1 warm-up + %d timed inner iterations at B=%d (%.2f s/iter), extrapolated to "
                        "%d x %d iterations" % (t_setup, timed_iters, B, t_iter, BINARY_STEP, NUM_ITER),
-                s_per_iteration=round(t_iter, 3))
+                s_per_iteration=round(t_iter, 3), port_over_reference=PORT_OVER_REFERENCE)
 
 
 def cpu_baseline_cw_sweep(cfg):
@@ -386,14 +394,25 @@ def cpu_baseline_cw_sweep(cfg):
         label = logits_of(model, xyz.transpose(1, 2).contiguous()).argmax(1)
     target = (label + 1) % cfg['classes']
     clip = lambda pc, ori: O.clip_points_linf(pc, ori, 0.18)  # noqa: E731
-    n = 3
+    n, reps = 3, 3
 
     def per_iteration(run):
-        t0 = time.perf_counter()
-        run(1)
-        t1 = time.perf_counter()
-        run(1 + n)
-        return max(1e-9, (time.perf_counter() - t1) - (t1 - t0)) / n, t1 - t0
+        """(seconds per inner iteration, seconds of a one-iteration call): calls of 1 and 1 + n iterations timed in
+        ALTERNATION, `reps` times each, medians taken -- the difference of two single noisy timings can come out negative."""
+        short, long_ = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            run(1)
+            t1 = time.perf_counter()
+            run(1 + n)
+            t2 = time.perf_counter()
+            short.append(t1 - t0)
+            long_.append(t2 - t1)
+        one, many = sorted(short)[reps // 2], sorted(long_)[reps // 2]
+        if many <= one:
+            raise RuntimeError("cpu_baseline: %d iterations (%.3f s) timed no longer than one (%.3f s): the host is too noisy "
+                               "to extrapolate from; rerun" % (1 + n, many, one))
+        return (many - one) / n, one
 
     it_adv, f_adv = per_iteration(lambda k: O.cw_family_attack(model, lambda l, t: O.logits_adv_loss(l, t, 0.), clip, xyz, target,
                                                                y_truth=label, ae_model=ae, targeted=True, fresh=True,
@@ -405,8 +424,8 @@ def cpu_baseline_cw_sweep(cfg):
     # f_* = one call with a single iteration (setup + 1 iteration + final forward); AdvPC and AOF run two binary steps
     total = (2 * f_adv + 398 * it_adv) + (f_knn + 2499 * it_knn) + (2 * f_aof + 398 * it_aof)
     return dict(value=B / total, unit="clouds/s", cores=cores, host_cpus=avail, kind="port",
-                sample="per attack: one 1-iteration call + %d further timed iterations at B=%d (AdvPC %.2f, kNN %.2f, AOF %.2f "
-                       "s/iter), extrapolated to 2x200 + 2500 + 2x200 iterations" % (n, B, it_adv, it_knn, it_aof),
+                sample="per attack: calls of 1 and %d iterations alternated %d times, medians, at B=%d (AdvPC %.2f, kNN %.2f, AOF "
+                       "%.2f s/iter), extrapolated to 2x200 + 2500 + 2x200 iterations" % (1 + n, reps, B, it_adv, it_knn, it_aof),
                 s_per_iteration=dict(advpc=round(it_adv, 3), knn=round(it_knn, 3), aof=round(it_aof, 3)))
 
 
@@ -433,10 +452,15 @@ def make_runner(cfg, model, dev, concurrent):
             short = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=1, num_iter=4, verbose=False, **HP)
             short.attack(*batch)
 
+        def profiled(batch):  # a slice of the real job for `top_kernels`: setup + 100 captured iterations
+            part = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=1, num_iter=100, verbose=False, **HP)
+            part.attack(*batch)
+
         def hit_info():
             stacked = any(isinstance(k[3], str) for k in att._ws)  # attack_many merged the victim passes of its attacks
             return dict(hip_graph=att.last_graph_used, num_iter=NUM_ITER, binary_step=BINARY_STEP, central_num=HP["central_num"],
                         attacks_per_stack=att.attacks_per_stack if stacked else 1)
+        prewarm.profiled = profiled
         return run, prewarm, hit_info, NUM_ITER * BINARY_STEP
 
     from hit_adv_amd import CW
@@ -449,11 +473,12 @@ def make_runner(cfg, model, dev, concurrent):
 
     def attacks(short):
         kw = dict(verbose=False)
+        n_adv, n_knn = (2, 20) if short is True else (short if short else (None, None))  # (AdvPC / AOF, kNN) iterations
         a = CW.CWAdvPC(model, ae, LogitsAdvLoss(kappa=0.), L2Dist(), clip_func=clip, **kw,
-                       **(dict(binary_step=1, num_iter=2) if short else {}))
-        k = CW.CWKNN(model, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), clip, **kw, **(dict(num_iter=20) if short else {}))
+                       **(dict(binary_step=1, num_iter=n_adv) if short else {}))
+        k = CW.CWKNN(model, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), clip, **kw, **(dict(num_iter=n_knn) if short else {}))
         f = CW.CWAOF(model, UntargetedLogitsAdvLoss(kappa=30.), L2Dist(), clip_func=clip, **kw,
-                     **(dict(binary_step=1, num_iter=2) if short else {}))
+                     **(dict(binary_step=1, num_iter=n_adv) if short else {}))
         return a, k, f
 
     def sweep(batch, short=False):
@@ -486,7 +511,10 @@ def make_runner(cfg, model, dev, concurrent):
                     attacks=["CWAdvPC 2x200", "CWKNN 2500", "CWAOF 2x200"],
                     seconds_per_attack_last_step=dict(advpc=sec[0], knn=sec[1], aof=sec[2]))
 
-    return run, (lambda batch: sweep(batch, short=True)), info, 2 * 200 + 2500 + 2 * 200
+    def prewarm(batch):
+        return sweep(batch, short=True)
+    prewarm.profiled = lambda batch: sweep(batch, short=(16, 48))  # a slice of the real sweep for `top_kernels` (captured loops)
+    return run, prewarm, info, 2 * 200 + 2500 + 2 * 200
 
 
 def reduce_over_ranks(elapsed_s, succeeded, attacked, dev, world, collectives):
@@ -525,6 +553,54 @@ def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_
         # what RCCL saw: the calls each rank made in this run (all zero in a single-process run)
         "collectives_per_rank": dict(collectives, world=world, backend=backend if world > 1 else None),
     }
+
+
+def top_kernels(job, k=3):
+    """The k kernels with the most device time while ``job()`` runs (torch.profiler's device activity records; hipGraph
+    replays are traced kernel by kernel).  Informational: the committed rocprofv3 summaries under profiles/ are the record."""
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        job()
+        torch.cuda.synchronize()
+    rows = [(e.key, getattr(e, 'self_device_time_total', None) or getattr(e, 'self_cuda_time_total', 0.), e.count)
+            for e in prof.key_averages()]
+    rows = [r for r in rows if r[1] > 0]
+    total = sum(r[1] for r in rows) or 1.
+    rows.sort(key=lambda r: -r[1])
+    return [dict(kernel=name.split('(')[0][:96], share=round(t / total, 4), calls=int(c), us_avg=round(t / max(c, 1), 2))
+            for name, t, c in rows[:k]]
+
+
+OTHER_CONFIGS = dict(cfg3=dict(steps=4, warmup=0), cfg4=dict(steps=2, warmup=0), cfg5=dict(steps=1, warmup=0))
+
+
+def other_configs(timeout_s=240):
+    """cfg3 / cfg4 / cfg5 in front of the driver: each as a CHILD process of this same file (a fault in one of them cannot
+    take the headline line with it), a short warm-up attack and then the timed steps of its own defaults; what comes back is
+    the child's own line, cut down to the measurement, the graph flags, the roofline kernel and the top kernels."""
+    import subprocess
+    out = {}
+    for name, o in OTHER_CONFIGS.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(o['steps']), "--warmup", str(o['warmup']),
+               "--no-cpu-baseline", "--top-kernels"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+            if r.returncode != 0 or not lines:
+                out[name] = dict(error="exit code %d" % r.returncode, stderr_tail=r.stderr[-400:])
+                continue
+            d = json.loads(lines[-1])
+            cfgd = d["config"]
+            out[name] = dict(metric=d["metric"], value=d["value"], unit=d["unit"], steps=d["steps"], warmup=d["warmup"],
+                             ms_per_step=d["ms_per_step"], attacks_in_flight_per_gpu=cfgd.get("attacks_in_flight_per_gpu"),
+                             **{k: v for k, v in cfgd.items() if k.startswith("hip_graph") or k == "seconds_per_attack_last_step"},
+                             attack_success=d["attack_success"],
+                             roofline={k: d["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
+                             top_kernels=d.get("top_kernels"), wall_s=round(time.perf_counter() - t0, 1))
+        except subprocess.TimeoutExpired:
+            out[name] = dict(error="no line within %d s" % timeout_s)
+    return out
 
 
 def launch_ranks(n, argv):
@@ -605,6 +681,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="cfg2: skip the short driver-visible runs of cfg3 / cfg4 / cfg5 appended as `other_configs`")
+    ap.add_argument("--top-kernels", action="store_true",
+                    help="append `top_kernels`: the three kernels with the most device time in one short profiled pass")
     ap.add_argument("--no-single", action="store_true", help="cfg2: skip the extra one-attack-in-flight measurement")
     ap.add_argument("--no-f32", action="store_true", help="cfg2: skip the extra f32-matrix-mode measurement")
     ap.add_argument("--matrix-mode", choices=["bf16x3", "fp16x2", "f32"], default=None,
@@ -732,10 +812,12 @@ def main():
             eff = elapsed / steps / iters_per_step * 1e6  # wall time per B=32 iteration, all attacks in flight counted
             line["end_to_end"] = dict(
                 floor, us_per_iteration=round(eff, 2), attacks_in_flight=in_flight,
-                frac=round(floor['loop_floor_us'] / eff, 4), dense_forward_flops=pointnet_forward_flops(B, N),
+                frac=round(floor['loop_floor_us'] / eff, 4), frac_of_max_floor=round(floor['loop_floor_max_us'] / eff, 4),
+                dense_forward_flops=pointnet_forward_flops(B, N),
                 note="loop_floor_us = executed bf16 flop / 2.5 PF + executed f32-MFMA flop / 157.3 TF + HBM bytes / 8 TB/s of "
                      "ONE B=32 iteration (bench.py::loop_floor); us_per_iteration = ms_per_step / 5000 with "
-                     "`attacks_in_flight` attacks sharing the GPU; frac = floor / measured")
+                     "`attacks_in_flight` attacks sharing the GPU; frac = floor / measured; loop_floor_max_us = max(matrix time, HBM "
+                     "time) of the same iteration (perfect overlap), frac_of_max_floor = that / measured")
             if single is not None:
                 us1 = single / iters_per_step * 1e6
                 line["single_attack"] = {"value": B / single, "unit": "clouds/s", "ms_per_step": single * 1e3, "steps": extra,
@@ -754,9 +836,21 @@ def main():
             line["roofline"] = roofline_group_add_relu(dev, B, N, 512, 32, 64, "PointNet++ sa1")
         else:
             line["roofline"] = roofline_group_add_relu(dev, B, 512, 256, 32, 256, "PCT gather_local_1")
+        if args.top_kernels:
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    line["top_kernels"] = top_kernels(lambda: prewarm.profiled(batches[-1]))
+                line["top_kernels_note"] = ("torch.profiler over a slice of the job: setup + 100 iterations of one HiT-ADV attack "
+                                            "(cfg5: 16 + 48 + 16 iterations of the three attacks), after the timed region")
+            except Exception as e:  # noqa: BLE001  (informational: never costs the line)
+                line["top_kernels"] = None
+                line["top_kernels_note"] = "profiler unavailable: %r" % (e,)
+        if args.config == 'cfg2' and world == 1 and not args.no_other_configs:
+            line["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             if cfg['attack'] == 'hit_adv':
-                line["cpu_baseline"] = cpu_baseline_hit_adv(cfg, 5 if args.config == 'cfg2' else 2)
+                line["cpu_baseline"] = cpu_baseline_hit_adv(cfg, 10 if args.config == 'cfg2' else 2)
             else:
                 line["cpu_baseline"] = cpu_baseline_cw_sweep(cfg)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

@@ -382,6 +382,13 @@ __global__ __launch_bounds__(256) void rowmlp_fwd16_k(RowMlpFwd a) {
       }
       __syncthreads();
     }
+    // the cloud itself: a coordinate that is not finite would be mapped to 0 by the first ReLU below and never be seen again
+    // (the reference propagates it into NaN logits): raise the range flag, the caller then refuses / re-runs the pass
+    if (STAGE == 0 && a.range_flag != nullptr && threadIdx.x < 192) {
+      RangeWatch xw;
+      xw.see(sX[threadIdx.x]);
+      if (xw.beyond_fp16()) *a.range_flag = 1;
+    }
     const float *xin = sX;
     if (STAGE == 1) {  // x' = x @ T3   (torch.bmm(x, trans), :124)
       if (threadIdx.x < 192) {
