@@ -45,6 +45,7 @@ elif torch.cuda.is_initialized() or os.environ.get("ROCPROFILER_LIBRARY_CTOR") o
 else:
     HW_QUEUES = 8
 
+SEQUENTIAL_SWEEP = False  # cfg5: --sequential-sweep
 NUM_ITER, BINARY_STEP = 500, 10
 HP = dict(attack_lr=1e-2, central_num=192, total_central_num=256, init_weight=10., max_weight=80.,
           cd_weight=1e-4, ker_weight=1., hide_weight=1., curv_loss_knn=16, max_sigm=1.2, min_sigm=0.1,
@@ -486,20 +487,23 @@ def make_runner(cfg, model, dev, concurrent):
         xyz = data[:, :, :3].contiguous()
         target = (label + 1) % cfg['classes']
         a, k, f = attacks(short)
+        calls = [(a, (xyz, target, label)), (k, (xyz, target)), (f, (xyz, label))]
         t = [time.perf_counter()]
-        _, _, s1 = a.attack(xyz, target, label)
-        torch.cuda.synchronize()
-        t.append(time.perf_counter())
-        _, s2 = k.attack(xyz, target)
-        torch.cuda.synchronize()
-        t.append(time.perf_counter())
-        _, s3 = f.attack(xyz, label)
-        torch.cuda.synchronize()
-        t.append(time.perf_counter())
+        if SEQUENTIAL_SWEEP:  # one attack after the other (round 3's form; A/B switch --sequential-sweep)
+            res = []
+            for att, args in calls:
+                res.append(att.attack(*args))
+                torch.cuda.synchronize()
+                t.append(time.perf_counter())
+        else:  # the three attacks in flight at once, results those of the sequence (CW.attack_concurrently)
+            res = CW.attack_concurrently(calls)
+            torch.cuda.synchronize()
+            t.append(time.perf_counter())
+        (_, _, s1), (_, s2), (_, s3) = res
         if not short:
             made['graph'] = k.last_graph_used
             made['graph_advpc'], made['graph_aof'] = a.last_graph_used, f.last_graph_used
-            made.setdefault('seconds', []).append([round(t[i + 1] - t[i], 3) for i in range(3)])
+            made.setdefault('seconds', []).append([round(t[i + 1] - t[i], 3) for i in range(len(t) - 1)])
         return int(s1) + int(s2) + int(s3)
 
     def run(todo):
@@ -507,9 +511,14 @@ def make_runner(cfg, model, dev, concurrent):
 
     def info():
         sec = made.get('seconds', [[0, 0, 0]])[-1]
-        return dict(hip_graph_knn=made.get('graph'), hip_graph_advpc=made.get('graph_advpc'), hip_graph_aof=made.get('graph_aof'),
-                    attacks=["CWAdvPC 2x200", "CWKNN 2500", "CWAOF 2x200"],
-                    seconds_per_attack_last_step=dict(advpc=sec[0], knn=sec[1], aof=sec[2]))
+        out = dict(hip_graph_knn=made.get('graph'), hip_graph_advpc=made.get('graph_advpc'), hip_graph_aof=made.get('graph_aof'),
+                   attacks=["CWAdvPC 2x200", "CWKNN 2500", "CWAOF 2x200"])
+        if SEQUENTIAL_SWEEP:
+            out.update(sweep="one attack after the other", seconds_per_attack_last_step=dict(advpc=sec[0], knn=sec[1], aof=sec[2]))
+        else:
+            out.update(sweep="the three attacks in flight at once on three streams (CW.attack_concurrently: results of the "
+                             "sequence)", seconds_last_step=sec[0])
+        return out
 
     def prewarm(batch):
         return sweep(batch, short=True)
@@ -594,7 +603,7 @@ def other_configs(timeout_s=240):
             cfgd = d["config"]
             out[name] = dict(metric=d["metric"], value=d["value"], unit=d["unit"], steps=d["steps"], warmup=d["warmup"],
                              ms_per_step=d["ms_per_step"], attacks_in_flight_per_gpu=cfgd.get("attacks_in_flight_per_gpu"),
-                             **{k: v for k, v in cfgd.items() if k.startswith("hip_graph") or k == "seconds_per_attack_last_step"},
+                             **{k: v for k, v in cfgd.items() if k.startswith("hip_graph") or k in ("seconds_per_attack_last_step", "seconds_last_step", "sweep")},
                              attack_success=d["attack_success"],
                              roofline={k: d["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
                              top_kernels=d.get("top_kernels"), wall_s=round(time.perf_counter() - t0, 1))
@@ -685,6 +694,7 @@ def main():
                     help="cfg2: skip the short driver-visible runs of cfg3 / cfg4 / cfg5 appended as `other_configs`")
     ap.add_argument("--top-kernels", action="store_true",
                     help="append `top_kernels`: the three kernels with the most device time in one short profiled pass")
+    ap.add_argument("--sequential-sweep", action="store_true", help="cfg5: one attack after the other instead of three in flight")
     ap.add_argument("--no-single", action="store_true", help="cfg2: skip the extra one-attack-in-flight measurement")
     ap.add_argument("--no-f32", action="store_true", help="cfg2: skip the extra f32-matrix-mode measurement")
     ap.add_argument("--matrix-mode", choices=["bf16x3", "fp16x2", "f32"], default=None,
@@ -693,6 +703,8 @@ def main():
     ap.add_argument("--concurrent", type=int, default=None,
                     help="independent attack() batches in flight per GPU (separate HIP streams; 1 = strictly serial)")
     args = ap.parse_args()
+    global SEQUENTIAL_SWEEP
+    SEQUENTIAL_SWEEP = args.sequential_sweep
     cfg = CONFIGS[args.config]
     steps = cfg['steps'] if args.steps is None else args.steps
     warmup = cfg['warmup'] if args.warmup is None else args.warmup

@@ -26,3 +26,7 @@ class CWAOF(_CWFamily):
     def attack(self, data, target):
         """data [B,num_points,3|6], target [B] (true labels; untargeted) -> (float32 ndarray [B,num_points,3], successes)."""
         return self._run(data, target)[1:]
+
+    @staticmethod
+    def _shape_result(out):
+        return out[1:]

@@ -7,7 +7,50 @@ _EXPORTS = {
     'CWTAOF': 'TAOF', 'CWUAdvPC': 'UAdvPC', 'CWAdvPC': 'AdvPC', 'CWUAEAOF': 'UAEAOF', 'CWAddClusters': 'Add_Cluster',
     'CWAddObjects': 'Add_Objects',
 }
-__all__ = sorted(_EXPORTS)
+__all__ = sorted(_EXPORTS) + ['attack_concurrently']
+
+
+def attack_concurrently(calls):
+    """Several independent CW attacks on one GPU at once: ``[(attacker, args), ...] -> [attacker.attack(*args), ...]``.
+
+    The results are those of calling the attacks one after the other, in the order given: every attack takes ALL its random
+    numbers when its turn comes in that order (``steps()`` draws them up front, in the reference's order within the attack)
+    and captures its iteration; only then do the loops start, each on a stream of its own -- the host queues one attack's
+    replays and goes on to the next while the GPU works through all of them.  A PCT / DGCNN / PointNet++ pass at batch 32
+    is hundreds of kernels of a few microseconds that leave most of the chip idle: three attacks in flight fill it.
+    Attackers without ``steps()`` (CWPerturb, the Add family) and a pass that left fp16's range fall back to the plain
+    sequence.  No progress lines are printed in a meaningful order: construct the attackers with ``verbose=False``."""
+    import torch
+    from ..model._pointwise import Fp16RangeExceeded
+    calls = [(a, tuple(args)) for a, args in calls]
+    if len(calls) < 2 or not all(hasattr(a, 'steps') for a, _ in calls):
+        return [a.attack(*args) for a, args in calls]
+    rng = torch.get_rng_state()
+    here = torch.cuda.current_stream()
+    streams = [torch.cuda.Stream() for _ in calls]
+    gens = [a.steps(*args) for a, args in calls]
+    results = [None] * len(calls)
+    try:
+        for stop in ('ready', 'enqueued', None):  # every attack to the same stop before any goes on: setups first, loops after
+            for i, (g, st) in enumerate(zip(gens, streams)):
+                if stop == 'ready':
+                    st.wait_stream(here)
+                with torch.cuda.stream(st):
+                    try:
+                        while True:
+                            if next(g) == stop:
+                                break
+                    except StopIteration as done:
+                        results[i] = done.value
+        for st in streams:
+            here.wait_stream(st)
+        return results
+    except Fp16RangeExceeded:
+        for g in gens:
+            g.close()
+        torch.cuda.synchronize()
+        torch.set_rng_state(rng)
+        return [a.attack(*args) for a, args in calls]  # each degrades on its own (model/_pointwise.py)
 
 
 def __getattr__(name):

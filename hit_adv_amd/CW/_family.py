@@ -17,6 +17,7 @@ import torch
 from ._spectral import get_Laplace_from_pc
 from ._victim import Victim
 from ..model._pointwise import degrade_on_fp16_range
+from ..util.graph_loop import drive
 
 
 class _CWFamily:
@@ -77,10 +78,29 @@ class _CWFamily:
 
     @degrade_on_fp16_range
     def _run(self, data, target, y_truth=None):
+        return drive(self._run_steps(data, target, y_truth))
+
+    def steps(self, *args):
+        """The attack as a generator (``CW.attack_concurrently``): same arguments and return value as ``attack``."""
+        out = yield from self._run_steps(*args)
+        return self._shape_result(out)
+
+    @staticmethod
+    def _shape_result(out):
+        """What ``attack`` makes of ``_run``'s (o_bestdist, clouds, successes); the AOF classes drop the first."""
+        return out
+
+    def _run_steps(self, data, target, y_truth=None):
         """The loop of CW/AdvPC.py:63-79 / CW/AOF.py:106-134 on fixed buffers: one iteration -- up to three victim passes with
         their input gradients (summed in the reference's order of ``backward`` calls), Adam, clip, the spectral re-split,
         the fresh predictions and the best-so-far bookkeeping -- is one body that is captured into a hipGraph and replayed
-        ``num_iter`` times per binary step when nothing in it needs the host (util/graph_loop.py)."""
+        ``num_iter`` times per binary step when nothing in it needs the host (util/graph_loop.py).
+
+        A generator with two stops (``util/graph_loop.py::drive`` runs it through; ``CW.attack_concurrently`` interleaves
+        several): ``'ready'`` when every random number of the attack has been drawn -- in the reference's order: per binary
+        step the jitter, then the victim's FPS starts pass by pass, last the pass that counts the successes -- and the
+        iteration is captured; ``'enqueued'`` when all iterations are queued on the attack's stream and the next thing is
+        the host reading results back."""
         from .. import ops
         from ..util.graph_loop import IterationGraph
         self._victim.prepare()
@@ -178,18 +198,26 @@ class _CWFamily:
         total_iters = self.binary_step * self.num_iter
         graph = getattr(self, 'use_graph', 'auto') if total_iters >= 16 else False
         loop = IterationGraph(iteration, graph, 'the %s iteration' % type(self).__name__)
-        if graph not in (False, 'never'):
-            self._victim.open_feed(B, K, total_iters * passes, dev)  # a sampling victim's draws, device-resident
+        # a sampling victim's FPS starts live in a device table (+ 1 row: the pass that counts the successes at the end)
+        self._victim.open_feed(B, K, total_iters * passes + 1, dev)
+        # every random number of the attack, now, in the reference's order
+        per_step = self.num_iter * passes
+        jitter, starts = [], []
+        for _ in range(self.binary_step):
+            jitter.append(torch.randn((B, 3, K)).cuda() * 1e-7)
+            starts.append(self._victim.draw(per_step))
+        last_starts = self._victim.draw(1)
         if loop.probe():
             start_search()
             if spectral:
                 with torch.no_grad():
                     V.zero_()  # the probing passes only need SOME basis; the first binary step computes the real one
             loop.capture()
+        yield 'ready'
         start_search()
         for binary_step in range(self.binary_step):
-            start_step(ori.clone() + torch.randn((B, 3, K)).cuda() * 1e-7)
-            self._victim.load(binary_step * self.num_iter * passes, self.num_iter * passes)  # this step's passes, drawn now
+            start_step(ori.clone() + jitter[binary_step])
+            self._victim.put(binary_step * per_step, starts[binary_step])
             loop.enter()
             for it in range(self.num_iter):
                 loop.step()
@@ -198,13 +226,15 @@ class _CWFamily:
                         binary_step, it, n_ok.item(), B, shown.item(), 0.))
             loop.leave_step()
         loop.leave()
-        self._victim.close_feed()
         self.last_graph_used = loop.reason is None
         with torch.no_grad():
             best = torch.where((o_bestscore < 0)[:, None, None], adv, o_bestattack)  # failures: the last iterate
             adv_pc = self.clip_func(best, ori) if self.final_clip else best
+            self._victim.put(total_iters * passes, last_starts)
             preds = self._logits(adv_pc).argmax(dim=-1)
-            success_num = ((preds == target) if self.targeted else (preds != target)).sum().item()
+        yield 'enqueued'
+        success_num = ((preds == target) if self.targeted else (preds != target)).sum().item()
+        self._victim.close_feed()
         if self.verbose:
             print('Successfully attack {}/{}'.format(success_num, B))
         return (o_bestdist.double().cpu().numpy(), adv_pc.detach().cpu().numpy().transpose((0, 2, 1)), success_num)

@@ -23,6 +23,21 @@ class Victim:
         if self.feed is not None:
             self.feed.load(offset, forwards)
 
+    def draw(self, forwards):
+        """The CPU table of ``forwards`` passes' draws, taken NOW from the CPU generator (None for a deterministic victim):
+        an attack that takes all its random numbers up front calls this where the reference's passes would have drawn and
+        ``put``s the rows when their turn comes."""
+        if self.feed is None or forwards <= 0:
+            return None
+        return _sampling.StartFeed.draw(self.feed.highs, self.feed.B, forwards)
+
+    def put(self, offset, table):
+        """Rows drawn earlier (``draw``) into [offset, offset + len) and the cursor onto the first of them."""
+        if self.feed is not None:
+            if table is not None:
+                self.feed.table[offset:offset + table.shape[0]].copy_(table)
+            self.feed.seek(offset)
+
     def close_feed(self):
         """End of an attack's loop: drop the feed; loud if a fused fp16x2 layer of the victim left fp16's range meanwhile."""
         self.feed = None

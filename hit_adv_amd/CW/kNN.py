@@ -9,6 +9,7 @@ import torch
 
 from .. import ops
 from ..model._pointwise import degrade_on_fp16_range
+from ..util.graph_loop import drive
 from ..util.graph_loop import IterationGraph
 from ._victim import Victim
 
@@ -44,6 +45,11 @@ class CWKNN:
     @degrade_on_fp16_range
     def attack(self, data, target):
         """data [B,num_points,3 or 6], target [B] -> (float32 ndarray [B,num_points,3], success count)."""
+        return drive(self.steps(data, target))
+
+    def steps(self, data, target):
+        """``attack`` as a generator with two stops (CW/_family.py::_run_steps): 'ready' (all random numbers drawn, the
+        iteration captured) and 'enqueued' (every iteration queued, results not read back yet)."""
         self._victim.prepare()
         B, K = data.shape[:2]
         pc = data.float().cuda().detach().transpose(1, 2).contiguous()
@@ -83,13 +89,14 @@ class CWKNN:
 
         graph = self.use_graph if self.num_iter >= 16 else False
         loop = IterationGraph(iteration, graph, 'the kNN attack iteration')
-        if graph not in (False, 'never'):
-            self._victim.open_feed(B, K, self.num_iter + 1, dev)  # a sampling victim's draws, device-resident
+        self._victim.open_feed(B, K, self.num_iter + 1, dev)  # a sampling victim's draws, device-resident
+        starts = self._victim.draw(self.num_iter + 1)  # drawn where the reference's first forward pass would start drawing
         if loop.probe():
             reset()
             loop.capture()
+        yield 'ready'
         reset()
-        self._victim.load(0, self.num_iter + 1)  # drawn where the reference's first forward pass would draw
+        self._victim.put(0, starts)
         loop.enter()
         report_every = max(1, self.num_iter // 5)
         for it in range(self.num_iter):
@@ -100,7 +107,9 @@ class CWKNN:
         loop.leave()
         self.last_graph_used = loop.reason is None
         with torch.no_grad():
-            success_num = self._success(self._logits(adv).argmax(dim=-1), target).sum().item()
+            hit = self._success(self._logits(adv).argmax(dim=-1), target).sum()
+        yield 'enqueued'
+        success_num = hit.item()
         self._victim.close_feed()
         if self.verbose:
             print('Successfully attack {}/{}'.format(success_num, B))

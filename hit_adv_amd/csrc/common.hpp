@@ -36,6 +36,32 @@
 #define HITADV_HANDOFF_ACQUIRE() ((void)0)
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------
+// Diagnostic build only (make ablate -> tools/build/libhitadv_hip_ablate.so, loaded through HITADV_LIBRARY): entry points of
+// the kernel families named in the environment variable HITADV_ABLATE ("fc", "v1", "v2", "v3", comma separated) return
+// without launching, so that a timing run shows what a family costs the LOOP (its share of throughput, which is not its
+// share of summed kernel time when several attacks overlap).  Results of such a run are garbage by construction; the
+// product library contains none of this.
+#ifdef HITADV_ABLATE
+#include <cstdlib>
+#include <cstring>
+static inline bool hitadv_ablated(const char *tag) {
+  const char *e = getenv("HITADV_ABLATE");
+  if (!e) return false;
+  const size_t n = strlen(tag);
+  for (const char *p = e; (p = strstr(p, tag)) != nullptr; p += n)
+    if ((p == e || p[-1] == ',') && (p[n] == 0 || p[n] == ',')) return true;
+  return false;
+}
+#define HITADV_ABLATE_RETURN(tag)                    \
+  do {                                               \
+    static const bool off__ = hitadv_ablated(tag);   \
+    if (off__) return 0;                             \
+  } while (0)
+#else
+#define HITADV_ABLATE_RETURN(tag) ((void)0)
+#endif
+
 namespace hitadv {
 
 // A kernel's dynamic-LDS limit, raised once PER DEVICE (the attribute belongs to the function on one device; a process

@@ -1649,6 +1649,7 @@ extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float
                                           const float *b0, const float *W1, const float *b1, const float *W2,
                                           const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N,
                                           int mode, int32_t *range_flag, void *stream) {
+  HITADV_ABLATE_RETURN("v2");
   if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || !W2 || !b2 || !o2 || mode < 0 || mode > 2) return HITADV_E_ARG;
   if (stage < 2 && (!x || !W0 || !b0 || !o0)) return HITADV_E_ARG;
   if (stage == 1 && (!T || !W1 || !b1 || !o1)) return HITADV_E_ARG;
@@ -1673,6 +1674,7 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, c
                                               const float *b1, const float *W2, const float *b2, float *xp, float *o0,
                                               float *o1, float *o2, int B, int N, int mode, int32_t *range_flag,
                                               void *stream) {
+  HITADV_ABLATE_RETURN("v2");
   if (B <= 0 || N <= 0 || !x || !F5 || !W6 || !b6 || !Tout || !W0 || !b0 || !W1 || !b1 || !W2 || !b2 || !o0 || !o1 || !o2 ||
       mode < 0 || mode > 2)
     return HITADV_E_ARG;
@@ -1689,6 +1691,7 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *
                                                  const float *sigma, int C, float *adv, float *inv_den, const float *W0,
                                                  const float *b0, const float *W2, const float *b2, float *o0, float *o2,
                                                  int B, int N, int mode, int32_t *range_flag, void *stream) {
+  HITADV_ABLATE_RETURN("v2");
   if (B <= 0 || N <= 0 || C <= 0 || C > 256 || !ori || !central || !perturb || !sigma || !adv || !inv_den || !W0 || !b0 ||
       !W2 || !b2 || !o0 || !o2 || mode < 0 || mode > 2)
     return HITADV_E_ARG;
@@ -1709,6 +1712,7 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
                                           const float *W0r, const float *T, const float *x, const float *dPin,
                                           float *dTpart, float *out, const uint64_t *pres_in, uint64_t *pres_out, int B,
                                           int N, int mode, void *stream) {
+  HITADV_ABLATE_RETURN("v3");
   if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || N > 65535 || Cout <= 0 || Cout > 256 * BW_CH || !dg || !idx ||
       !W3r || !A2 || !W2r || !out || mode < 0 || mode > 2)
     return HITADV_E_ARG;
@@ -1739,6 +1743,7 @@ extern "C" int hitadv_debug_v3_stamps(unsigned long long *host, int n) {
 
 extern "C" int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out,
                                    void *stream) {
+  HITADV_ABLATE_RETURN("fc");
   if (!part || !out || B <= 0 || T <= 0 || M <= 0) return HITADV_E_ARG;
   const long long total = (long long)B * M;
   sum_partials_k<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(part, extra, T, M, out, total);
@@ -1755,6 +1760,7 @@ extern "C" int64_t hitadv_fc_layer_scratch_floats(int B, int K, int NOUT) {
 
 extern "C" int hitadv_fc_layer(const float *in, const float *mask, const float *Wt, const float *bias, int B, int K,
                                int NOUT, int relu, float *out, float *scratch, void *stream) {
+  HITADV_ABLATE_RETURN("fc");
   if (!in || !Wt || !out || !scratch || B <= 0 || K <= 0 || NOUT <= 0) return HITADV_E_ARG;
   if ((K & 3) == 0 && (((uintptr_t)in | (uintptr_t)mask) & 15)) return HITADV_E_ARG;
   static const int wide = [] { const char *e = getenv("HITADV_FC_WIDE"); return e ? atoi(e) : 1; }();  // 0: tuning / A-B only
@@ -1778,6 +1784,7 @@ extern "C" int hitadv_fc_layer(const float *in, const float *mask, const float *
 extern "C" int hitadv_fc_layer_pre(const float *pre, int T, int J, const float *Wpre, const float *mask, const float *Wt,
                                    const float *bias, int B, int K, int NOUT, int relu, float *out, float *scratch,
                                    void *stream) {
+  HITADV_ABLATE_RETURN("fc");
   if (!pre || !Wpre || !Wt || !out || !scratch || B <= 0 || K <= 0 || NOUT <= 0 || T <= 0 || J <= 0 || J > 64)
     return HITADV_E_ARG;
   int chunk, KS, tiles;

@@ -435,6 +435,16 @@ template <int MODE>
 static int launch_linear_max_pieces(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin, int Cout,
                                     int relu, int blocks, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
                                     int32_t *tickets, int32_t *range_flag, void *stream) {
+#ifdef HITADV_ABLATE
+  {  // "v1" ablated: the arg-max table still has to hold valid point indices for the backward kernels that gather through it
+    static const bool off__ = hitadv_ablated("v1");
+    if (off__) {
+      (void)hipMemsetAsync(idx, 0, sizeof(int64_t) * (size_t)B * Cout, (hipStream_t)stream);
+      (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * Cout, (hipStream_t)stream);
+      return 0;
+    }
+  }
+#endif
   if (!X || !W3 || !part_val || !part_idx || !out || !idx || !tickets || B <= 0 || N <= 0 || Cout <= 0 || (Cout & 63) ||
       (Cin != 64 && Cin != 128) || ((uintptr_t)X & 15) || ((uintptr_t)W3 & 15) || (blocks != 0 && (blocks < 8 || blocks > 256)))
     return HITADV_E_ARG;

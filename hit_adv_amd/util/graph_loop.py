@@ -93,3 +93,12 @@ class IterationGraph:
         """Make the caller's stream wait for the iterations; drop the graph."""
         torch.cuda.current_stream().wait_stream(self.stream)
         self.graph = None
+
+
+def drive(steps):
+    """Run an attack written as a generator (its stops are there for ``CW.attack_concurrently``) through to its result."""
+    try:
+        while True:
+            next(steps)
+    except StopIteration as done:
+        return done.value

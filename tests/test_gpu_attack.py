@@ -593,8 +593,8 @@ def test_dgcnn_victim_on_gpu_and_under_attack():
     (logits * T(fx['grad_w']).cuda()).sum().backward()
     # through the recording helpers (pinned at 4x what MI355X achieves); a flipped feature-space neighbour would move a
     # whole edge's contribution, so the bounds are the gradient_close pair, not an elementwise one
-    gradient_close(x.grad, fx['grad_x'], 'DGCNN input gradient vs the reference (g10)', frac_bound=2e-3, l2_bound=1e-3)
-    close(x.grad, fx['grad_x'], rtol=0, atol=1e-3 * float(np.abs(fx['grad_x']).max()), what='DGCNN input gradient vs the reference (g10), max |diff|')
+    gradient_close(x.grad, fx['grad_x'], 'DGCNN input gradient vs the reference (g10)', frac_bound=1e-3, l2_bound=1e-5)  # achieved 0 / 7.8e-7
+    close(x.grad, fx['grad_x'], rtol=0, atol=1e-5 * float(np.abs(fx['grad_x']).max()), what='DGCNN input gradient vs the reference (g10), max |diff|')  # achieved 6e-7 of the scale
     data, _ = synth_batch(4, 512, first=1200)
     with torch.no_grad():
         label = m(data[:, :, :3].transpose(1, 2).contiguous().cuda()).argmax(1)
@@ -1366,3 +1366,45 @@ def test_more_distance_operators_match_reference():
                                                      batch_avg=False)
     close(d, fx['l2chamfer'], rtol=1e-5)
     close(CurvDist(curv_loss_knn=2)(ori, adv.detach(), normal), fx['curv'], rtol=1e-4)
+
+
+def test_cw_attacks_in_flight_at_once_return_what_the_sequence_returns():
+    """``CW.attack_concurrently``: AdvPC, kNN and AOF on a PCT victim (which draws FPS starts in every forward pass), three in
+    flight on three streams, against the same three called one after the other from the same seed: every attack takes its
+    random numbers where its turn in the sequence comes, so the clouds, the distances and the success counts are the same
+    bits (PCT's kernels are deterministic; cfg5's sweep in bench.py runs this way)."""
+    import argparse
+    from hit_adv_amd import CW
+    from hit_adv_amd.model import pct as PCT
+    from hit_adv_amd.util.adv_utils import LogitsAdvLoss, UntargetedLogitsAdvLoss
+    from hit_adv_amd.util.clip_utils import ClipPointsLinf
+    from hit_adv_amd.util.dist_utils import ChamferkNNDist, L2Dist
+    torch.manual_seed(3)
+    m = PCT.Pct(argparse.Namespace(dropout=0.2), output_channels=40).eval().cuda()
+    ae = _ToyAE().eval().cuda()
+    data, _ = synth_batch(4, 1024, first=8800)
+    xyz = data[:, :, :3].contiguous().cuda()
+    with torch.no_grad():
+        torch.manual_seed(4)
+        label = m(xyz.transpose(1, 2).contiguous()).argmax(1)
+    target = (label + 1) % 40
+    clip = ClipPointsLinf(budget=0.18)
+
+    def calls():
+        kw = dict(verbose=False)
+        a = CW.CWAdvPC(m, ae, LogitsAdvLoss(kappa=0.), L2Dist(), clip_func=clip, binary_step=2, num_iter=10, **kw)
+        k = CW.CWKNN(m, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), clip, num_iter=30, **kw)
+        f = CW.CWAOF(m, UntargetedLogitsAdvLoss(kappa=30.), L2Dist(), clip_func=clip, binary_step=2, num_iter=10, low_pass=100, **kw)
+        return [(a, (xyz, target, label)), (k, (xyz, target)), (f, (xyz, label))]
+    torch.manual_seed(41)
+    seq = [att.attack(*args) for att, args in calls()]
+    state_after_sequence = torch.get_rng_state()
+    torch.manual_seed(41)
+    together = calls()
+    par = CW.attack_concurrently(together)
+    assert all(att.last_graph_used for att, _ in together)
+    assert torch.equal(torch.get_rng_state(), state_after_sequence)  # the same draws were taken
+    for s_, p_ in zip(seq, par):
+        assert len(s_) == len(p_)
+        for x, y in zip(s_, p_):
+            assert np.array_equal(np.asarray(x), np.asarray(y))

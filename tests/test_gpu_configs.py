@@ -222,9 +222,9 @@ def _pct_pool_winners(winners, pre_pool=None):
         winners.append(arg.detach().cpu().long())
         return (out, arg) if return_arg else out
 
-    def spy_max(self, *a, **k):  # the two max-over-neighbours of Local_op.from_points
+    def spy_max(self, *a, **k):  # the max over the neighbours of Local_op.from_points where the fused layer does not apply
         out = real_max(self, *a, **k)
-        if a or k:
+        if (a or k) and self.dim() == 4:  # [B,S,nsample,C]; the attacks' own .max calls (logits, losses) are 1-D / 2-D
             winners.append(out[1].detach().cpu())
         return out
 
