@@ -53,19 +53,26 @@ class Local_op(nn.Module):
         self.bn1 = nn.BatchNorm1d(out_channels)
         self.bn2 = nn.BatchNorm1d(out_channels)
 
-    def from_points(self, xyz, points, npoint, nsample):
+    def from_points(self, xyz, points, npoint, nsample, tables=None):
         """sample_and_group + forward without the grouped tensor (eval mode on the GPU): xyz [B,N,3], points [B,N,D] ->
         (new_xyz [B,S,3], features [B,S,C] points-major).  The first convolution is split over the neighbour and the
         centre, W [x_j - c_i ; c_i] = Wa x_j + (Wb - Wa) c_i: one GEMM over the N points, one over the S centres and
         ``hitadv_group_add_relu`` replace the [B,S,nsample,2D] gather / subtract / concat and a GEMM over S*nsample rows.
-        Draws the FPS start exactly where ``sample_and_group`` does."""
+        Draws the FPS start exactly where ``sample_and_group`` does.  ``tables`` = (fps_idx, new_xyz, idx, ready) when the
+        caller has the sampling / grouping tables computed ahead on another stream (``Pct._tables_ahead``): the per-point
+        product below does not need them and runs meanwhile."""
         xyz = xyz.contiguous()
         D = points.shape[-1]
-        fps_idx = fps(xyz, npoint)
-        new_xyz = index_points(xyz, fps_idx)
-        idx = knn_point(nsample, xyz, new_xyz)
         W, t = split_first_layer(self.conv1, self.bn1, D)
-        U = torch.matmul(points, W[:, :D].t())
+        if tables is None:
+            fps_idx = fps(xyz, npoint)
+            new_xyz = index_points(xyz, fps_idx)
+            idx = knn_point(nsample, xyz, new_xyz)
+            U = torch.matmul(points, W[:, :D].t())
+        else:
+            U = torch.matmul(points, W[:, :D].t())
+            fps_idx, new_xyz, idx, ready = tables
+            torch.cuda.current_stream().wait_event(ready)
         V = torch.addmm(t, index_points(points, fps_idx).reshape(-1, D), (W[:, D:] - W[:, :D]).t()).view(-1, npoint, W.shape[0])
         return new_xyz, linear_relu_max_pm(self.conv2, self.bn2, ops.group_add_relu(U, V, idx))
 
@@ -168,13 +175,47 @@ class Pct(nn.Module):
         of those 512 (:62,65)."""
         return [N, 512]
 
+    tables_ahead = True  # the FPS / kNN chain of both Local_ops on a second stream (False: in line, as the reference orders it)
+    _side = {}
+
+    def _tables_ahead(self, xyz):
+        """Both Local_ops' sampling and grouping tables -- FPS 512 of N, kNN 32; FPS 256 of those 512, kNN 32 -- depend on the
+        coordinates alone, and FPS is a serial chain of one workgroup per cloud (32 of 256 CUs busy for ~0.45 ms per pass at
+        B = 32): they run on a second stream while the first per-point layers and the first Local_op's products use the
+        rest of the chip.  Inside a captured iteration this becomes a fork / join of the graph.  Same calls in the same
+        order as in line (the FPS starts are read from the feed in call order); nothing here carries gradient."""
+        dev = xyz.device
+        cur = torch.cuda.current_stream(dev)
+        side = Pct._side.get(dev)
+        if side is None:
+            side = Pct._side[dev] = torch.cuda.Stream(dev)
+        pts = xyz.detach()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            f0 = fps(pts, 512)
+            c0 = index_points(pts, f0)
+            i0 = knn_point(32, pts, c0)
+            e0 = torch.cuda.Event()
+            e0.record(side)
+            f1 = fps(c0, 256)
+            c1 = index_points(c0, f1)
+            i1 = knn_point(32, c0, c1)
+            e1 = torch.cuda.Event()
+            e1.record(side)
+        if not torch.cuda.is_current_stream_capturing():  # eager: the allocator must know the other stream uses them
+            pts.record_stream(side)
+            for t in (f0, c0, i0, f1, c1, i1):
+                t.record_stream(cur)
+        return (f0, c0, i0, e0), (f1, c1, i1, e1)
+
     def _forward_points_major(self, x):
         """Eval mode on the GPU: every tensor stays points-major [B,N,C], so each 1x1 convolution is one GEMM with the
         BatchNorm folded in and bias / ReLU in its epilogue, and nothing is permuted or copied between layers."""
         xyz = x.permute(0, 2, 1).contiguous()
+        t0, t1 = self._tables_ahead(xyz) if self.tables_ahead else (None, None)
         h = linear_relu_pm(self.conv2, self.bn2, linear_relu_pm(self.conv1, self.bn1, xyz))
-        new_xyz, p0 = self.gather_local_0.from_points(xyz, h, 512, 32)
-        new_xyz, p1 = self.gather_local_1.from_points(new_xyz, p0, 256, 32)
+        new_xyz, p0 = self.gather_local_0.from_points(xyz, h, 512, 32, tables=t0)
+        new_xyz, p1 = self.gather_local_1.from_points(new_xyz, p0, 256, 32, tables=t1)
         # conv_fuse + BatchNorm + LeakyReLU + the max over the points: one kernel where the widths allow (_pointwise)
         g = linear_lrelu_maxpool_pm(self.conv_fuse[0], self.conv_fuse[1], torch.cat([self.pt_last.forward_pm(p1), p1], dim=2))
         g = self.dp1(F.leaky_relu(self.bn6(self.linear1(g)), negative_slope=0.2))

@@ -467,11 +467,35 @@ def test_cfg5_pct_batch32_cw_sweep_vs_cpu_oracle(which):
     iters = 3
     winners = []
 
+    from hit_adv_amd.CW import _family
+    from hit_adv_amd.model import pct as PCT
+    tables, bases = {}, []
+
     def gpu_run():
-        """The attack on the GPU (three iterations: the eager loop, so that the spies see every pass)."""
+        """The attack on the GPU (three iterations: the eager loop, so that the spies see every pass): besides the iterates it
+        leaves the discrete choices of every victim pass -- FPS and kNN-grouping tables, max-pool winners -- and, for AOF, the
+        eigenbasis of the graph Laplacian it split the cloud in."""
         del trace[:]
         del winners[:]
+        del bases[:]
         torch.manual_seed(23)
+        log, saved = _record_tables(PCT, ['fps', 'knn_point'])
+        tables.clear()
+        tables.update(log)
+        real_basis = _family.get_Laplace_from_pc
+
+        def basis(pc, *a, **k):
+            e, v = real_basis(pc, *a, **k)
+            bases.append((e.detach().cpu(), v.detach().cpu()))
+            return e, v
+        _family.get_Laplace_from_pc = basis
+        try:
+            return _gpu_attack()
+        finally:
+            _family.get_Laplace_from_pc = real_basis
+            _restore(PCT, saved)
+
+    def _gpu_attack():
         with _pct_pool_winners(winners):
             if which == "knn":
                 att = CW.CWKNN(gpu_model, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), recording_clip, attack_lr=1e-2,
@@ -486,11 +510,26 @@ def test_cfg5_pct_batch32_cw_sweep_vs_cpu_oracle(which):
             return att.attack(xyz, label)
 
     def oracle_run(impose):
-        """The oracle restatement driving the plain PCT module on the CPU; ``impose``: its max-pools take the winners of the
-        GPU run's passes, pass for pass (both loops run the victim in the reference's order: the FPS draws depend on it)."""
+        """The oracle restatement driving the plain PCT module on the CPU; ``impose``: every discrete choice of the GPU run is
+        replayed into it, pass for pass (both loops run the victim in the reference's order) -- the module's samplers return
+        the recorded FPS / kNN tables, its max-pools take the recorded winners, AOF's split uses the recorded eigenbasis
+        (rocSOLVER's and LAPACK's bases differ inside near-degenerate eigenspaces at the low-pass cut)."""
         del otrace[:]
         torch.manual_seed(23)
-        with _imposed_pool_winners(list(winners) if impose else []):
+        if not impose:
+            return _oracle_attack(victim)
+        saved = _replay_tables(PCT, {k: list(v) for k, v in tables.items()})
+        real_eig, queue = O.laplace_eig, iter(list(bases))
+        O.laplace_eig = lambda pc, k=30: next(queue)
+        try:
+            with _imposed_pool_winners(list(winners)):
+                return _oracle_attack(cpu_model)  # the plain module: CpuVictim would put its own samplers in place
+        finally:
+            O.laplace_eig = real_eig
+            _restore(PCT, saved)
+
+    def _oracle_attack(victim):
+        with contextlib.nullcontext():
             if which == "knn":
                 return O.cw_knn_attack(victim, lambda l, t: O.logits_adv_loss(l, t, 15.), _direct_chamfer_knn, clip_o,
                                        xyz, target, attack_lr=1e-2, num_iter=iters, trace=otrace)
@@ -523,17 +562,23 @@ def test_cfg5_pct_batch32_cw_sweep_vs_cpu_oracle(which):
     # few 1e-9 against an fp32 gradient error of ~1e-4 relative L2) may take a step of the other sign, a difference of up to
     # 2 lr that no evaluation order can remove.  So the bar is 1e-5 on the 99th percentile of |gpu - oracle| over all
     # 98,304 coordinates, and the SHARE of coordinates beyond 1e-5 is held to OFF (4x what MI355X achieves).
-    OFF = dict(knn=2e-3, advpc=2e-2, aof=2e-2)[which]
+    # With every discrete choice replayed, EVERY iterate is held to 1e-5 at the 99th percentile of |gpu - oracle| over the
+    # 98,304 coordinates (achieved 1.1e-6 ... 5.1e-6); the share of coordinates beyond 1e-5 -- the tiny-gradient coordinates
+    # whose Adam step can take the other sign, and what later iterates inherit from them -- is held to 4 x what MI355X
+    # achieves (profiles/r04_parity_report.json: knn 4.4e-4 ... 6.9e-4; advpc 1.1e-3, 2.0e-3, 3.4e-3; aof 3.2e-4, 1.9e-3, 3.2e-3).
+    BOUNDS = dict(knn=[(1e-5, 2.8e-3)] * 3, advpc=[(1e-5, 4.6e-3), (1e-5, 8e-3), (1e-5, 1.4e-2)],
+                  aof=[(1e-5, 1.3e-3), (1e-5, 7.5e-3), (1e-5, 1.3e-2)])[which]
     for i in range(iters):
         assert np.abs(rows[i] - ori).max() <= 0.18 + 1e-6
         err = np.abs(rows[i] - orows[i])
-        close(np.quantile(err, 0.99), 0., rtol=0, atol=1e-5,
-              what='cfg5 %s iterate %d, same max-pool winners: 99th percentile |gpu - oracle|' % (which, i))
-        close(float((err > 1e-5).mean()), 0., rtol=0, atol=OFF,
-              what='cfg5 %s iterate %d, same max-pool winners: share of coordinates off by > 1e-5' % (which, i))
-        note('cfg5 %s iterate %d, same max-pool winners: median |gpu - oracle|' % (which, i), np.median(err))
-        note('cfg5 %s iterate %d, same max-pool winners: max |gpu - oracle|' % (which, i), err.max())
-    close(float((np.abs(final - ofinal) > 1e-5).mean()), 0., rtol=0, atol=OFF, what='cfg5 %s returned clouds, same winners: share off by > 1e-5' % which)
+        close(np.quantile(err, 0.99), 0., rtol=0, atol=BOUNDS[i][0],
+              what='cfg5 %s iterate %d, same discrete choices: 99th percentile |gpu - oracle|' % (which, i))
+        close(float((err > 1e-5).mean()), 0., rtol=0, atol=BOUNDS[i][1],
+              what='cfg5 %s iterate %d, same discrete choices: share of coordinates off by > 1e-5' % (which, i))
+        note('cfg5 %s iterate %d, same discrete choices: median |gpu - oracle|' % (which, i), np.median(err))
+        note('cfg5 %s iterate %d, same discrete choices: max |gpu - oracle|' % (which, i), err.max())
+    close(float((np.abs(final - ofinal) > 1e-5).mean()), 0., rtol=0, atol=BOUNDS[-1][1],
+          what='cfg5 %s returned clouds, same discrete choices: share off by > 1e-5' % which)
     assert final.shape == ofinal.shape and int(succ) == int(osucc)
     # (2) for the record: the free-running oracle (its own winners).  Statistics only -- what the flipped winners cost.
     oracle_run(impose=False)
