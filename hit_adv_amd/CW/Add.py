@@ -100,25 +100,25 @@ class CWAdd:
             logits = self._logits(torch.cat([ori, adv], dim=-1))
             pred = logits.argmax(dim=-1)
             with torch.no_grad():
-                shown_adv.copy_(adv_loss)    # the progress line shows the losses of the PREVIOUS iteration (:113-116)
-                shown_dist.copy_(dist_loss)
-                hits.copy_((pred == target).sum())
-                last_input.copy_(adv)
+                ops.assign(shown_adv, adv_loss)    # the progress line shows the losses of the PREVIOUS iteration (:113-116)
+                ops.assign(shown_dist, dist_loss)
+                ops.assign(hits, (pred == target).sum())
+                ops.assign(last_input, adv)
                 dist_val = self._dist(adv, ori, batch_avg=False).detach().double()
                 hit = pred == target
                 better = hit & (dist_val < bestdist)
-                bestdist.copy_(torch.where(better, dist_val, bestdist))
-                bestscore.copy_(torch.where(better, pred, bestscore))
+                ops.assign(bestdist, torch.where(better, dist_val, bestdist))
+                ops.assign(bestscore, torch.where(better, pred, bestscore))
                 o_better = hit & (dist_val < o_bestdist)
-                o_bestdist.copy_(torch.where(o_better, dist_val, o_bestdist))
-                o_bestscore.copy_(torch.where(o_better, pred, o_bestscore))
-                o_bestattack.copy_(torch.where(o_better[:, None, None], adv.detach(), o_bestattack))
+                ops.assign(o_bestdist, torch.where(o_better, dist_val, o_bestdist))
+                ops.assign(o_bestscore, torch.where(o_better, pred, o_bestscore))
+                ops.assign(o_bestattack, torch.where(o_better[:, None, None], adv.detach(), o_bestattack))
             a = self.adv_func(logits, target).mean()
             d = self._dist(adv, ori, weights=weight).mean()
             g, = torch.autograd.grad(a + d, adv)
             with torch.no_grad():
-                adv_loss.copy_(a)
-                dist_loss.copy_(d)
+                ops.assign(adv_loss, a.detach())
+                ops.assign(dist_loss, d.detach())
                 ops.adam_single(adv, g, m, v, step, self.attack_lr)  # torch.optim.Adam's update (defaults)
 
         def start_step(first):

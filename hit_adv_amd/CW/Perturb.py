@@ -79,26 +79,26 @@ class CWPerturb:
             logits = self._logits(adv)
             pred = logits.argmax(dim=1)
             with torch.no_grad():
-                last_input.copy_(adv)  # what the reference calls input_val (:125)
+                ops.assign(last_input, adv)  # what the reference calls input_val (:125)
                 dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2])).double()
                 hit = pred == target
-                hits.copy_(hit.sum())
+                ops.assign(hits, hit.sum())
                 better = hit & (dist_val < bestdist)
-                bestdist.copy_(torch.where(better, dist_val, bestdist))
-                bestscore.copy_(torch.where(better, pred, bestscore))
+                ops.assign(bestdist, torch.where(better, dist_val, bestdist))
+                ops.assign(bestscore, torch.where(better, pred, bestscore))
                 o_better = hit & (dist_val < o_bestdist)
-                o_bestdist.copy_(torch.where(o_better, dist_val, o_bestdist))
-                o_bestscore.copy_(torch.where(o_better, pred, o_bestscore))
-                o_bestattack.copy_(torch.where(o_better[:, None, None], adv, o_bestattack))
+                ops.assign(o_bestdist, torch.where(o_better, dist_val, o_bestdist))
+                ops.assign(o_bestscore, torch.where(o_better, pred, o_bestscore))
+                ops.assign(o_bestattack, torch.where(o_better[:, None, None], adv, o_bestattack))
             a = self.adv_func(logits, target).mean()
             d = self.dist_func(adv, ori, weight).mean()
             g, = torch.autograd.grad(a + d, adv)
             with torch.no_grad():
-                adv_loss.copy_(a)
-                dist_loss.copy_(d)
+                ops.assign(adv_loss, a.detach())
+                ops.assign(dist_loss, d.detach())
                 ops.adam_single(adv, g, m, v, step, self.attack_lr)  # torch.optim.Adam's update (:119, defaults)
                 if self.clip_func is not None:
-                    adv.copy_(self.clip_func(adv.clone(), ori))
+                    ops.assign(adv, self.clip_func(ops.copy_of(adv), ori))
 
         def start_step(init):
             with torch.no_grad():

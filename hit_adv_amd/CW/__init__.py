@@ -21,11 +21,10 @@ def attack_concurrently(calls):
     Attackers without ``steps()`` (CWPerturb, the Add family) and a pass that left fp16's range fall back to the plain
     sequence.  No progress lines are printed in a meaningful order: construct the attackers with ``verbose=False``."""
     import os
-    import threading
+    import time
 
     import torch
     from ..model._pointwise import Fp16RangeExceeded
-    THREADS = os.environ.get("HITADV_CW_THREADS", "1") != "0"  # 0: one host thread queues all loops (A/B switch)
     calls = [(a, tuple(args)) for a, args in calls]
     if len(calls) < 2 or not all(hasattr(a, 'steps') for a, _ in calls):
         return [a.attack(*args) for a, args in calls]
@@ -34,42 +33,48 @@ def attack_concurrently(calls):
     streams = [torch.cuda.Stream() for _ in calls]
     gens = [a.steps(*args) for a, args in calls]
     results = [None] * len(calls)
-    def advance(i, stop):
+    def advance(i, stops):
+        """Generator i to its next stop in ``stops`` (None: to its end); True once it has returned its result."""
         with torch.cuda.stream(streams[i]):
             try:
                 while True:
-                    if next(gens[i]) == stop:
-                        return
+                    if next(gens[i]) in stops:
+                        return False
             except StopIteration as done:
                 results[i] = done.value
+                return True
 
     try:
         for i, st in enumerate(streams):  # setups first, one after the other: draws in sequence order, captures undisturbed
             st.wait_stream(here)
-            advance(i, 'ready')
-        # the loops: one host thread per attack.  Launching a captured PCT iteration costs the host about what it costs the
-        # GPU to run it (a thousand-odd graph nodes), so ONE thread feeding three streams feeds none of them fast enough
-        # (measured: 18.97 s for cfg5's sweep against 19.61 s in sequence); graph launches release the interpreter lock.
-        failures = []
-
-        def loop(i):
-            try:
-                advance(i, 'enqueued')
-            except BaseException as e:  # noqa: BLE001  (re-raised in the caller's thread)
-                failures.append(e)
-        if THREADS:
-            workers = [threading.Thread(target=loop, args=(i,), name='hitadv-cw-%d' % i) for i in range(len(gens))]
-            for w in workers:
-                w.start()
-            for w in workers:
-                w.join()
-        else:
+            advance(i, ('ready',))
+        # the loops: the host queues one binary step of one attack and goes on to the next attack (launching a captured PCT
+        # iteration costs the host 0.85 ms against ~4 ms of GPU time: tools/graph_launch_cost.py); going round by binary
+        # step keeps a host-side wait at the start of an attack's next step from holding up the others' queues
+        # the loops: the host goes round the attacks, a few iterations of each per turn (CW/_family.py::TURN), the longer
+        # loops taking proportionally more turns per round so that all of them end together; launching a captured PCT
+        # iteration costs the host 0.85 ms against ~4 ms of GPU time (tools/graph_launch_cost.py), so one thread keeps
+        # every stream's queue full and waits only where the runtime's own limit on queued work makes it wait
+        totals = [max(1, int(getattr(a, 'total_iterations', 1))) for a, _ in calls]
+        share = [max(1, round(t / min(totals))) for t in totals]
+        queued = [False] * len(gens)
+        trace = os.environ.get("HITADV_CW_TIMELINE") == "1"  # diagnostic: when the host got each attack fully queued
+        t0 = time.perf_counter()
+        while not all(queued):
             for i in range(len(gens)):
-                loop(i)
-        if failures:
-            raise failures[0]
+                with torch.cuda.stream(streams[i]):
+                    for _ in range(share[i]):
+                        if queued[i]:
+                            break
+                        queued[i] = next(gens[i]) == 'enqueued'
+                        if queued[i] and trace:
+                            print("hitadv cw timeline: attack %d (%s) fully queued at %.3f s" % (
+                                i, type(calls[i][0]).__name__, time.perf_counter() - t0))
+        if trace:
+            torch.cuda.synchronize()
+            print("hitadv cw timeline: GPU drained at %.3f s" % (time.perf_counter() - t0))
         for i in range(len(gens)):  # results are read back in sequence order
-            advance(i, None)
+            advance(i, ())
         for st in streams:
             here.wait_stream(st)
         return results

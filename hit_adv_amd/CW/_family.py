@@ -14,10 +14,17 @@ afterwards); the spectral split uses the HIP-kNN Laplacian of ``CW/_spectral.py`
 """
 import torch
 
+from .. import ops
 from ._spectral import get_Laplace_from_pc
 from ._victim import Victim
 from ..model._pointwise import degrade_on_fp16_range
 from ..util.graph_loop import drive
+
+
+# Iterations an attack queues before a driver of several attacks (``CW.attack_concurrently``) moves on to the next one.  The
+# runtime lets the host run only so far ahead of the GPU (a captured PCT iteration is thousands of queue packets): a host that
+# queues one attack's whole loop first spends that attack's full GPU time doing so, and the others start when it is done.
+TURN = 4
 
 
 class _CWFamily:
@@ -80,6 +87,10 @@ class _CWFamily:
     def _run(self, data, target, y_truth=None):
         return drive(self._run_steps(data, target, y_truth))
 
+    @property
+    def total_iterations(self):
+        return self.binary_step * self.num_iter
+
     def steps(self, *args):
         """The attack as a generator (``CW.attack_concurrently``): same arguments and return value as ``attack``."""
         out = yield from self._run_steps(*args)
@@ -96,11 +107,11 @@ class _CWFamily:
         the fresh predictions and the best-so-far bookkeeping -- is one body that is captured into a hipGraph and replayed
         ``num_iter`` times per binary step when nothing in it needs the host (util/graph_loop.py).
 
-        A generator with two stops (``util/graph_loop.py::drive`` runs it through; ``CW.attack_concurrently`` interleaves
+        A generator with stops (``util/graph_loop.py::drive`` runs it through; ``CW.attack_concurrently`` interleaves
         several): ``'ready'`` when every random number of the attack has been drawn -- in the reference's order: per binary
-        step the jitter, then the victim's FPS starts pass by pass, last the pass that counts the successes -- and the
-        iteration is captured; ``'enqueued'`` when all iterations are queued on the attack's stream and the next thing is
-        the host reading results back."""
+        step the jitter, then the victim's FPS starts pass by pass, last the pass that counts the successes --, uploaded, and
+        the iteration is captured; ``'turn'`` every ``TURN`` queued iterations; ``'enqueued'`` when everything is queued on
+        the attack's stream and the next thing is the host reading results back."""
         from .. import ops
         from ..util.graph_loop import IterationGraph
         self._victim.prepare()
@@ -150,15 +161,15 @@ class _CWFamily:
                 g = g + torch.autograd.grad(lfc_loss, var)[0]
                 total = total + lfc_loss.detach()
             with torch.no_grad():
-                shown.copy_(total)
+                ops.assign(shown, total)
                 ops.adam_single(var, g, m, v, step, self.attack_lr)  # torch.optim.Adam's update (defaults, no weight decay)
-                adv.copy_(self.clip_func((var + hfc if spectral else var).clone(), ori))
+                ops.assign(adv, self.clip_func(var + hfc if spectral else ops.copy_of(var), ori))
                 if spectral:
                     new_l, new_h = self._split(adv, V)
-                    var.copy_(new_l)
-                    hfc.copy_(new_h)
+                    ops.assign(var, new_l)
+                    ops.assign(hfc, new_h)
                 else:
-                    var.copy_(adv)
+                    ops.assign(var, adv)
                 if self.fresh:
                     pred = self._logits(adv).argmax(dim=1)
                     lfc_pred = self._logits(var).argmax(dim=1) if spectral else None
@@ -169,10 +180,10 @@ class _CWFamily:
                     ae_pred = ae_logits.argmax(dim=1) if ae_logits is not None else None
                 dist_val = torch.sqrt(torch.sum((adv - ori) ** 2, dim=[1, 2]))
                 ok = self._better(pred, lfc_pred, ae_pred, target, y_truth) & (dist_val < o_bestdist)
-                o_bestdist.copy_(torch.where(ok, dist_val, o_bestdist))
-                o_bestscore.copy_(torch.where(ok, pred, o_bestscore))
-                o_bestattack.copy_(torch.where(ok[:, None, None], adv, o_bestattack))
-                n_ok.copy_(self._progress(pred, lfc_pred, ae_pred, target))
+                ops.assign(o_bestdist, torch.where(ok, dist_val, o_bestdist))
+                ops.assign(o_bestscore, torch.where(ok, pred, o_bestscore))
+                ops.assign(o_bestattack, torch.where(ok[:, None, None], adv, o_bestattack))
+                ops.assign(n_ok, self._progress(pred, lfc_pred, ae_pred, target))
 
         def start_step(init):
             with torch.no_grad():
@@ -207,6 +218,7 @@ class _CWFamily:
             jitter.append(torch.randn((B, 3, K)).cuda() * 1e-7)
             starts.append(self._victim.draw(per_step))
         last_starts = self._victim.draw(1)
+        self._victim.put_all(starts + [last_starts])  # one upload, here: none inside the loop (it would hold the host)
         if loop.probe():
             start_search()
             if spectral:
@@ -217,20 +229,23 @@ class _CWFamily:
         start_search()
         for binary_step in range(self.binary_step):
             start_step(ori.clone() + jitter[binary_step])
-            self._victim.put(binary_step * per_step, starts[binary_step])
+            self._victim.seek(binary_step * per_step)
             loop.enter()
             for it in range(self.num_iter):
                 loop.step()
                 if self.verbose and it % report_every == 0:
                     print('Step {}, iteration {}, success {}/{}\nadv_loss: {:.4f}, dist_loss: {:.4f}'.format(
                         binary_step, it, n_ok.item(), B, shown.item(), 0.))
+                if it % TURN == TURN - 1:
+                    yield 'turn'  # a driver of several attacks goes round here (see TURN)
             loop.leave_step()
+            yield 'turn'
         loop.leave()
         self.last_graph_used = loop.reason is None
         with torch.no_grad():
             best = torch.where((o_bestscore < 0)[:, None, None], adv, o_bestattack)  # failures: the last iterate
             adv_pc = self.clip_func(best, ori) if self.final_clip else best
-            self._victim.put(total_iters * passes, last_starts)
+            self._victim.seek(total_iters * passes)
             preds = self._logits(adv_pc).argmax(dim=-1)
         yield 'enqueued'
         success_num = ((preds == target) if self.targeted else (preds != target)).sum().item()

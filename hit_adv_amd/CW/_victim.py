@@ -5,6 +5,8 @@ module's current weights at the start of every ``attack()``.  ``fast_victim=Fals
 module itself (the reference's behaviour, ShapeAttack/HiT_ADV.py has the same switch)."""
 
 
+import torch
+
 from ..model import _sampling
 
 
@@ -36,6 +38,20 @@ class Victim:
         if self.feed is not None:
             if table is not None:
                 self.feed.table[offset:offset + table.shape[0]].copy_(table)
+            self.feed.seek(offset)
+
+    def put_all(self, tables):
+        """Every row of the attack at once, in pass order (a list of ``draw`` results; None entries skipped): ONE upload at
+        setup.  An upload from pageable host memory waits for the stream it is issued on -- inside the loop it would hold the
+        host until the binary step before it has run, and with it every other attack the host has yet to queue."""
+        if self.feed is not None:
+            rows = [t for t in tables if t is not None]
+            if rows:
+                rows = torch.cat(rows)
+                self.feed.table[:rows.shape[0]].copy_(rows)
+
+    def seek(self, offset):
+        if self.feed is not None:
             self.feed.seek(offset)
 
     def close_feed(self):

@@ -11,6 +11,7 @@ from .. import ops
 from ..model._pointwise import degrade_on_fp16_range
 from ..util.graph_loop import drive
 from ..util.graph_loop import IterationGraph
+from ._family import TURN
 from ._victim import Victim
 
 
@@ -47,6 +48,10 @@ class CWKNN:
         """data [B,num_points,3 or 6], target [B] -> (float32 ndarray [B,num_points,3], success count)."""
         return drive(self.steps(data, target))
 
+    @property
+    def total_iterations(self):
+        return self.num_iter
+
     def steps(self, data, target):
         """``attack`` as a generator with two stops (CW/_family.py::_run_steps): 'ready' (all random numbers drawn, the
         iteration captured) and 'enqueued' (every iteration queued, results not read back yet)."""
@@ -73,12 +78,12 @@ class CWKNN:
             d = self.dist_func(adv.transpose(1, 2).contiguous(), ori_pts).mean() * K
             g, = torch.autograd.grad(a + d, adv)
             with torch.no_grad():
-                hits.copy_(self._success(logits.argmax(dim=1), target).sum())
-                adv_loss.copy_(a)
-                dist_loss.copy_(d)
+                ops.assign(hits, self._success(logits.argmax(dim=1), target).sum())
+                ops.assign(adv_loss, a.detach())
+                ops.assign(dist_loss, d.detach())
                 ops.adam_single(adv, g, m, v, step, self.attack_lr)  # torch.optim.Adam's update (:74, defaults)
                 if self.clip_func is not None:
-                    adv.copy_(self._clip(adv.clone(), ori, normal))
+                    ops.assign(adv, self._clip(ops.copy_of(adv), ori, normal))
 
         def reset():
             with torch.no_grad():
@@ -91,12 +96,13 @@ class CWKNN:
         loop = IterationGraph(iteration, graph, 'the kNN attack iteration')
         self._victim.open_feed(B, K, self.num_iter + 1, dev)  # a sampling victim's draws, device-resident
         starts = self._victim.draw(self.num_iter + 1)  # drawn where the reference's first forward pass would start drawing
+        self._victim.put_all([starts])
         if loop.probe():
             reset()
             loop.capture()
         yield 'ready'
         reset()
-        self._victim.put(0, starts)
+        self._victim.seek(0)
         loop.enter()
         report_every = max(1, self.num_iter // 5)
         for it in range(self.num_iter):
@@ -104,6 +110,8 @@ class CWKNN:
             if self.verbose and it % report_every == 0:
                 print('Iteration {}/{}, success {}/{}\nadv_loss: {:.4f}, dist_loss: {:.4f}'.format(
                     it, self.num_iter, hits.item(), B, adv_loss.item(), dist_loss.item()))
+            if it % TURN == TURN - 1:
+                yield 'turn'
         loop.leave()
         self.last_graph_used = loop.reason is None
         with torch.no_grad():

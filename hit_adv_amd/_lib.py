@@ -27,6 +27,7 @@ PROTOTYPES = {
     "hitadv_deform_bwd_scratch_floats": [_I, _I, _I],
     "hitadv_best_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hitadv_adam_step": [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _L, _F, _P, _P],
+    "hitadv_copy": [_P, _P, _L, _P],
     "hitadv_fps_from_start": [_P, _P, _I, _I, _I, _P, _P],
     "hitadv_fps_pct": [_P, _P, _I, _I, _I, _P, _P],
     "hitadv_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],

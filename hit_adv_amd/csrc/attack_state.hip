@@ -220,6 +220,40 @@ extern "C" int hitadv_best_update(const float *logits, const int64_t *label, con
   return 0;
 }
 
+// byte copy as a kernel: 16-byte words where both addresses allow, single bytes for the rest
+__global__ __launch_bounds__(256) void copy_k(uint4 *__restrict__ dst, const uint4 *__restrict__ src, long long words,
+                                              unsigned char *__restrict__ dtail, const unsigned char *__restrict__ stail, int tail) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < words; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) dtail[threadIdx.x] = stail[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void copy_bytes_k(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src,
+                                                    long long n) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+extern "C" int hitadv_copy(void *dst, const void *src, int64_t nbytes, void *stream) {
+  if (nbytes < 0 || (nbytes > 0 && (!dst || !src))) return HITADV_E_ARG;
+  if (nbytes == 0 || dst == src) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+    const long long words = nbytes / 16;
+    const int tail = (int)(nbytes - words * 16);
+    const long long blocks = words > 0 ? (words + 255) / 256 : 1;
+    copy_k<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, s>>>(
+        reinterpret_cast<uint4 *>(dst), reinterpret_cast<const uint4 *>(src), words,
+        reinterpret_cast<unsigned char *>(dst) + words * 16, reinterpret_cast<const unsigned char *>(src) + words * 16, tail);
+  } else {
+    const long long blocks = (nbytes + 255) / 256;
+    copy_bytes_k<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, s>>>(reinterpret_cast<unsigned char *>(dst),
+                                                                          reinterpret_cast<const unsigned char *>(src), nbytes);
+  }
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int hitadv_adam_step(float *perturb, const float *g_perturb, float *m_perturb, float *v_perturb,
                                 int64_t n_perturb, float lr_perturb, float *sigma, const float *g_sigma,
                                 float *m_sigma, float *v_sigma, int64_t n_sigma, float lr_sigma, int32_t *step,

@@ -993,6 +993,8 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int rb = wave & 1, cb = wave >> 1;
+  V3_STAMP_DECL;
+  V3_STAMP(0);
   const unsigned long long rowmask = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
   const unsigned long long incoming =
       (STAGE == 2 ? 0ull : (a.pres_in != nullptr ? a.pres_in[(size_t)b * ntiles + tile] : ~0ull)) & rowmask;
@@ -1034,7 +1036,9 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
     rank[ch] = __popcll(m & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-  const unsigned long long present = s_present;
+V3_STAMP(1);
+
+    const unsigned long long present = s_present;
   const int D = __popcll(present);
   const int R = (D + 31) >> 5;
   if (threadIdx.x == 0 && a.pres_out != nullptr) a.pres_out[(size_t)b * ntiles + tile] = present;
@@ -1072,7 +1076,9 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
     }
   if (threadIdx.x < 128) list[M + threadIdx.x] = make_int2(0, 0);
   __syncthreads();
-  // ---- gather on the fp16 matrix cores
+V3_STAMP(2);
+
+    // ---- gather on the fp16 matrix cores
   f32x16 gacc[2], gaccl[2];
   zero(gacc[0]);
   zero(gacc[1]);
@@ -1082,7 +1088,9 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
     gather_rows16<true>(list, M, a.W3r + 32 * wave + r, r, h, gacc, gaccl);
   else
     gather_rows16<false>(list, M, a.W3r + 32 * wave + r, r, h, gacc, gaccl);
-  // ---- everything the chain will need from global memory
+V3_STAMP(3);
+
+    // ---- everything the chain will need from global memory
   const bool act = rb < R;
   uint4 w2h[8], w2l[8], w1h[4], w1l[4];
   if (act) load_w16<128, false>(a.W2r, 64, 32 * cb, r, h, w2h, w2l);
@@ -1124,7 +1132,9 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
       }
     }
   __syncthreads();
-  if (act) {  // through the 64->128 layer: [32R,128] @ W2r[128,64]
+V3_STAMP(4);
+
+    if (act) {  // through the 64->128 layer: [32R,128] @ W2r[128,64]
     if (STAGE == 1) load_w16<64, false>(a.W1r, 64, 32 * cb, r, h, w1h, w1l);
     if (STAGE == 2) load_w16<64, true>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1h, w1l);
     if (STAGE == 1) {
@@ -1151,7 +1161,9 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
     }
   }
   __syncthreads();
-  if (STAGE == 2) {  // tD is dead: its first half takes the h1 rows (left operand of the transform gradient) as pieces
+V3_STAMP(5);
+
+    if (STAGE == 2) {  // tD is dead: its first half takes the h1 rows (left operand of the transform gradient) as pieces
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = threadIdx.x + 256 * u;
@@ -1198,6 +1210,8 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
         if (i < D) a.out[(row0 + s_rowmap[i]) * 64 + 32 * cb + r] = joined(acc[0], accl[0], e);
       }
     }
+    V3_STAMP(7);
+    V3_STAMP_FLUSH();
     return;
   }
 
@@ -1216,7 +1230,9 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
     inH = tF0;
     inL = tF1;
   }
-  if (wave < 3) {  // 64 -> 3 backwards on the VALU:  g[i,c] = sum_k d[i,k] * W0r[k,c]; the row comes back as hi + 2^-11 lo
+V3_STAMP(6);
+
+    if (wave < 3) {  // 64 -> 3 backwards on the VALU:  g[i,c] = sum_k d[i,k] * W0r[k,c]; the row comes back as hi + 2^-11 lo
     const int c = wave, i = lane;
     float v = 0.f;
     if (i < D) {
@@ -1259,6 +1275,8 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
       a.dTpart[((size_t)b * ntiles + tile) * 9 + q] = v;
     }
   }
+  V3_STAMP(7);
+  V3_STAMP_FLUSH();
 }
 
 // out[b,m] = sum_t part[b,t,m] (+ extra[b,m]), ascending t.

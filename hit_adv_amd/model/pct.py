@@ -175,7 +175,11 @@ class Pct(nn.Module):
         of those 512 (:62,65)."""
         return [N, 512]
 
-    tables_ahead = True  # the FPS / kNN chain of both Local_ops on a second stream (False: in line, as the reference orders it)
+    # the FPS / kNN chain of both Local_ops on a second stream.  OFF: measured on MI355X (tools/stream_overlap_probe.py), the
+    # forked pass costs 7.8-8.1 ms as a captured graph against 3.63 ms in line -- the runtime executes a graph with parallel
+    # branches segment by segment with cross-stream waits -- and 3.5 vs 2.3 ms per pass with three such graphs in flight.
+    # Kept as a switch (the eager path does overlap: FPS 6.5 ms + a GEMM stream 16.2 ms run in 17.7 ms together).
+    tables_ahead = False
     _side = {}
 
     def _tables_ahead(self, xyz):

@@ -475,6 +475,30 @@ def adam_single(p, g, m, v, step, lr):
               ctypes.c_float(0.), _p(step), _stream())
 
 
+def assign(dst, src):
+    """``dst.copy_(src)`` for the state an attack loop keeps at fixed addresses, as a KERNEL: a contiguous same-dtype
+    ``copy_`` is hipMemcpyAsync, i.e. a memcpy node of the captured iteration, and those make graph launches on several
+    streams serialise and hold the host (include/hitadv.h, hitadv_copy).  Anything else (dtype change, strides, broadcast,
+    CPU) is an element-wise kernel already and goes through ``copy_``."""
+    if (torch.is_tensor(src) and dst.is_cuda and src.is_cuda and dst.device == src.device and dst.dtype == src.dtype
+            and dst.shape == src.shape and dst.is_contiguous() and src.is_contiguous()):
+        _lib.call("hitadv_copy", _p(dst), _p(src), dst.numel() * dst.element_size(), _stream())
+        torch.autograd.graph.increment_version(dst)  # an in-place write autograd did not see: saved-tensor checks stay honest
+        return dst
+    with torch.no_grad():
+        return dst.copy_(src)
+
+
+def copy_of(src):
+    """``src.detach().clone()`` without the memcpy node (see ``assign``)."""
+    src = src.detach()
+    if src.is_cuda and src.is_contiguous():
+        out = torch.empty_like(src)
+        _lib.call("hitadv_copy", _p(out), _p(src), src.numel() * src.element_size(), _stream())
+        return out
+    return src.clone()
+
+
 # --------------------------------------------------------------------------- FPS
 def fps_from_start(xyz, npoint, start):
     """xyz[B,N,3], start[B] int64 -> idx[B,npoint] int64 (ShapeAttack/HiT_ADV.py:489-510 semantics)."""

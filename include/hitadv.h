@@ -139,6 +139,13 @@ int hitadv_adam_step(float *perturb, const float *g_perturb, float *m_perturb, f
                      int64_t n_perturb, float lr_perturb, float *sigma, const float *g_sigma,
                      float *m_sigma, float *v_sigma, int64_t n_sigma, float lr_sigma,
                      int32_t *step, void *stream);
+/* dst[0, nbytes) = src[0, nbytes) by a KERNEL (16-byte words, grid-stride; the two ranges must not overlap).  The attack
+ * loops keep their state at fixed addresses and move it with this instead of hipMemcpyAsync (what a contiguous
+ * tensor.copy_ / clone is, as in ShapeAttack/HiT_ADV.py:186-217's host copies): inside a captured iteration a memcpy NODE
+ * makes graph launches of three streams serialise and holds the host (tools/stream_overlap_probe.py: three streams of
+ * captured PCT passes take 1.92x one stream's time without such nodes, 2.47x with seven per pass). */
+int hitadv_copy(void *dst, const void *src, int64_t nbytes, void *stream);
+
 /* The same step with the gradient given as g + g2 (g2 may be NULL: the deformation's and the regulariser's terms
  * need no separate add), followed by the projection the reference applies at the top of the next iteration
  * (ShapeAttack/HiT_ADV.py:157-158; skipped for a group when lo > hi).  *step is the 1-based step number and is

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Where the time of the PointNet engine's backward kernels (rowmlp_bwd_k, stages 2 / 1 / 0) goes: a diagnostic build of the
+"""Where the time of the PointNet engine's backward kernels (rowmlp_bwd16_k in the default fp16x2 mode, rowmlp_bwd_k otherwise; stages 2 / 1 / 0) goes: a diagnostic build of the
 library with wall-clock stamps at the phase boundaries of every block.
 
-    tools/v3_phases.py --build      # here (cross-compiles hit_adv_amd/libhitadv_hip_stamps.so with -DHITADV_STAMPS)
-    gpurun -- python tools/v3_phases.py
+    tools/v3_phases.py --build      # here (cross-compiles tools/build/libhitadv_hip_stamps.so with -DHITADV_STAMPS)
+    gpurun -- python tools/v3_phases.py [B]     # B clouds in the pass (default 32; 128 = one stack of four attacks)
 """
 import ctypes
 import json
@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, 'hit_adv_amd', 'libhitadv_hip_stamps.so')
+LIB = os.path.join(ROOT, 'tools', 'build', 'libhitadv_hip_stamps.so')
 PHASES = ['arg-max table, ballot', 'list build', 'gather (MFMA)', 'operand requests, tile store', 'ReLU mask, 128->64 product',
           '64->64 (stage 1), barrier', '64->3 and outputs']
 
@@ -21,6 +21,7 @@ def build():
     src = os.path.join(ROOT, 'hit_adv_amd', 'csrc')
     objs = [os.path.join(src, f) for f in os.listdir(src) if f.endswith('.o') and f != 'pointnet.o']
     subprocess.check_call(['make', '-C', src])
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-slp-vectorize',
                            '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'), '-DHITADV_STAMPS', '-c',
                            os.path.join(src, 'pointnet.hip'), '-o', '/tmp/pointnet_stamps.o'])
@@ -41,7 +42,8 @@ def main():
     torch.manual_seed(0)
     model = PointNetFeatureModel(40, normal_channel=False).cuda().eval()
     view = model.attack_view()
-    data, _ = synth_batch(32, 1024)
+    B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 32
+    data, _ = synth_batch(B, 1024)
     x = data[:, :, :3].transpose(1, 2).contiguous().cuda().requires_grad_()
     for _ in range(3):
         out = view(x)
