@@ -63,7 +63,7 @@ CONFIGS = {
                  metric="attacked point-clouds/sec (HiT-ADV, DGCNN k=5, N=1024, 500 iters)",
                  workload="cfg3: synthetic ModelNet40-shaped clouds, 1024 pts, batch 32 per GPU (256 over 8 GPUs), DGCNN "
                           "victim k=5 (random init, eval mode), HiT-ADV eval.py hyper-parameters, 500 x 10 iterations"),
-    'cfg4': dict(victim='pointnet++', B=64, N=2048, classes=16, attack='hit_adv', steps=2, warmup=0, concurrent=2,
+    'cfg4': dict(victim='pointnet++', B=64, N=2048, classes=16, attack='hit_adv', steps=4, warmup=0, concurrent=4,
                  metric="attacked point-clouds/sec (HiT-ADV, PointNet++ SSG, N=2048, 500 iters)",
                  workload="cfg4: synthetic ShapeNetPart-shaped clouds, 2048 pts, batch 64, PointNet++ SSG victim (16 object "
                           "categories, random init, eval mode), HiT-ADV eval.py hyper-parameters, 500 x 10 iterations"),
@@ -580,7 +580,7 @@ def top_kernels(job, k=3):
             for name, t, c in rows[:k]]
 
 
-OTHER_CONFIGS = dict(cfg3=dict(steps=4, warmup=0), cfg4=dict(steps=2, warmup=0), cfg5=dict(steps=1, warmup=0))
+OTHER_CONFIGS = dict(cfg3=dict(steps=4, warmup=0), cfg4=dict(steps=4, warmup=0), cfg5=dict(steps=1, warmup=0))
 
 
 def other_configs(timeout_s=240):
