@@ -554,6 +554,7 @@ struct RowMlpBwd {
   unsigned long long *pres_out;       // [B,tiles] rows of this tile that receive any gradient in this stage, or NULL
   int N, Cout;
   int a2_packed;                      // mode 2: A2 holds packed fp16 pieces (rowmlp_fwd16_k, pack_o2), not fp32 values
+  int *overflow;                      // [B,tiles] (two-word tiles only) 1: the tile has more than 64 winning points, see FIXUP
 };
 
 constexpr int BW_CH = 4;  // Cout <= 256 * BW_CH
@@ -977,28 +978,44 @@ __device__ __forceinline__ void gather_rows16(const int2 *list, int M, const flo
   }
 }
 
-template <int STAGE>
+// NW = 64-point words per block tile.  The work of a block is set by the points that RECEIVE gradient (the max routes each
+// channel's gradient to one point: ~10 of 64), not by the points it covers, and a block's time is a chain of global round
+// trips and barriers (~13 us at two blocks per CU): at NW = 2 a 128-cloud stack is two rounds of 1024 blocks instead of four
+// of 2048.  The compacted rows still have to fit the 64-row piece tiles: a tile with more than 64 winning points (rare) is
+// processed word by word (``passes``), each pass exactly the NW = 1 algorithm on its 64 points, the tile's transform-gradient
+// partial summed over the passes in word order.
+// FIXUP: the same kernel launched a second time behind the first (NW > 1 only).  The first launch (FIXUP = false) runs the
+// single pass and nothing else -- with the pass loop in it the register allocator needs 256 registers and 0.3-0.8 KB of scratch
+// per lane instead of 211-226 and none -- and marks a tile it cannot take (more than 64 winning points) in a.overflow; the
+// second launch returns at once for every other tile and takes the marked ones word by word.
+template <int STAGE, int NW, bool FIXUP>
 __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
+  constexpr int BT = 64 * NW;  // points per block tile
+  if (FIXUP && a.overflow[(size_t)blockIdx.y * gridDim.x + blockIdx.x] == 0) return;  // block-uniform
   // piece tiles: tD [2][64 rows][128] (the gathered, masked gradient; later reused as tF [2][64][64]), tE [2][64][64]
   __shared__ __attribute__((aligned(16))) char tD[2][PM_TM * PM_LH128], tE[2][PM_TM * PM_LH64];
-  __shared__ float sX[PM_TM * 3], sG[PM_TM * 3];
+  __shared__ float sX[BT * 3], sG[PM_TM * 3];
   __shared__ int s_cnt[BW_CH][4];
-  __shared__ unsigned long long s_present;
+  __shared__ unsigned long long s_present[NW];
   __shared__ int s_rowmap[PM_TM];
   char *tF0 = tD[0], *tF1 = tD[0] + PM_TM * PM_LH64;   // two 64-wide piece tiles inside tD[0] (dead by then)
   int2 *list = reinterpret_cast<int2 *>(tE[0]);         // [256 * BW_CH + 128] entries = 9.2 KB <= 2 x 9.2 KB of tE; dead before tE is written
-  const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, n0 = tile * PM_TM, N = a.N, Cout = a.Cout;
-  const int rows = min(PM_TM, N - n0);
+  const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, n0 = tile * BT, N = a.N, Cout = a.Cout;
+  const int rows = min(BT, N - n0);
   const size_t row0 = (size_t)b * N + n0;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int rb = wave & 1, cb = wave >> 1;
   V3_STAMP_DECL;
   V3_STAMP(0);
-  const unsigned long long rowmask = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
-  const unsigned long long incoming =
-      (STAGE == 2 ? 0ull : (a.pres_in != nullptr ? a.pres_in[(size_t)b * ntiles + tile] : ~0ull)) & rowmask;
-  if (threadIdx.x == 0) s_present = incoming;
+  unsigned long long incoming[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int rw = min(64, max(0, rows - 64 * w));
+    const unsigned long long rowmask = rw >= 64 ? ~0ull : ((1ull << rw) - 1ull);
+    incoming[w] = (STAGE == 2 ? 0ull : (a.pres_in != nullptr ? a.pres_in[((size_t)b * ntiles + tile) * NW + w] : ~0ull)) & rowmask;
+  }
+  if (threadIdx.x < NW) s_present[threadIdx.x] = incoming[threadIdx.x];
   __syncthreads();
   int mn[BW_CH];
   float mg[BW_CH];
@@ -1020,259 +1037,336 @@ __global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
       mg[ch] = (in && (!gated || tm[ch] > 0.f)) ? tg[ch] : 0.f;
     }
   }
-  if (STAGE == 1 && threadIdx.x < 192) {
-    const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
-    sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
+  if (STAGE == 1) {
+    for (int e = threadIdx.x; e < 3 * BT; e += 256) {
+      const int c = e / BT, n = e - c * BT;
+      sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
+    }
   }
   unsigned rank[BW_CH];
 #pragma unroll
-  for (int ch = 0; ch < BW_CH; ++ch) {
+  for (int ch = 0; ch < BW_CH; ++ch) {  // ranks of the single-pass case (every hit of the tile), ready behind the same barrier
     const int n = mn[ch];
     const bool hit = n >= 0 && n < rows && mg[ch] != 0.f;
     const unsigned long long m = __ballot(hit);
     if (lane == 0) s_cnt[ch][wave] = __popcll(m);
-    if (hit) atomicOr(&s_present, 1ull << n);
+    if (hit) atomicOr(&s_present[n >> 6], 1ull << (n & 63));
     mn[ch] = hit ? n : -1;
     rank[ch] = __popcll(m & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-V3_STAMP(1);
-
-    const unsigned long long present = s_present;
-  const int D = __popcll(present);
-  const int R = (D + 31) >> 5;
-  if (threadIdx.x == 0 && a.pres_out != nullptr) a.pres_out[(size_t)b * ntiles + tile] = present;
-  if (D == 0) {  // block-uniform: nothing arrives in this tile
+  V3_STAMP(1);
+  unsigned long long present[NW];
+  int Dall = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    present[w] = s_present[w];
+    Dall += __popcll(present[w]);
+  }
+  if (threadIdx.x < NW && a.pres_out != nullptr) a.pres_out[((size_t)b * ntiles + tile) * NW + threadIdx.x] = s_present[threadIdx.x];
+  if (Dall == 0) {  // block-uniform: nothing arrives in this tile
+    if (NW > 1 && !FIXUP && threadIdx.x == 0) a.overflow[(size_t)b * ntiles + tile] = 0;
     if (STAGE == 2) {
       float4 *o = reinterpret_cast<float4 *>(a.dTpart + ((size_t)b * ntiles + tile) * 4096);
       for (int e = threadIdx.x; e < 1024; e += 256) o[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       if (STAGE == 1 && threadIdx.x < 9) a.dTpart[((size_t)b * ntiles + tile) * 9 + threadIdx.x] = 0.f;
-      if (threadIdx.x < 192) {
-        const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+      for (int e = threadIdx.x; e < 3 * BT; e += 256) {
+        const int c = e / BT, n = e - c * BT;
         if (n < rows) {
           const size_t o = ((size_t)b * 3 + c) * N + n0 + n;
           a.out[o] = STAGE == 0 ? 0.f + a.dPin[o] : 0.f;
         }
       }
     }
-    return;
-  }
-  if (threadIdx.x < PM_TM && ((present >> threadIdx.x) & 1ull))
-    s_rowmap[__popcll(present & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
-  int M = 0;
-#pragma unroll
-  for (int ch = 0; ch < BW_CH; ++ch)
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w == wave && mn[ch] >= 0) {
-        _Float16 gh, gl;
-        split_pair(mg[ch], gh, gl);
-        const uint32_t g2 = (uint32_t)__builtin_bit_cast(uint16_t, gh) | ((uint32_t)__builtin_bit_cast(uint16_t, gl) << 16);
-        list[M + rank[ch]] = make_int2((ch * 256 + (int)threadIdx.x) | (__popcll(present & ((1ull << mn[ch]) - 1ull)) << 16),
-                                       (int)g2);
-      }
-      M += s_cnt[ch][w];
-    }
-  if (threadIdx.x < 128) list[M + threadIdx.x] = make_int2(0, 0);
-  __syncthreads();
-V3_STAMP(2);
-
-    // ---- gather on the fp16 matrix cores
-  f32x16 gacc[2], gaccl[2];
-  zero(gacc[0]);
-  zero(gacc[1]);
-  zero(gaccl[0]);
-  zero(gaccl[1]);
-  if (D > 32)
-    gather_rows16<true>(list, M, a.W3r + 32 * wave + r, r, h, gacc, gaccl);
-  else
-    gather_rows16<false>(list, M, a.W3r + 32 * wave + r, r, h, gacc, gaccl);
-V3_STAMP(3);
-
-    // ---- everything the chain will need from global memory
-  const bool act = rb < R;
-  uint4 w2h[8], w2l[8], w1h[4], w1l[4];
-  if (act) load_w16<128, false>(a.W2r, 64, 32 * cb, r, h, w2h, w2l);
-  float m1v[16], mhv[16], dhv[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int i = 32 * rb + acc_row(e, h);
-    m1v[e] = STAGE != 2 ? a.A1[(row0 + s_rowmap[min(i, D - 1)]) * 64 + 32 * cb + r] : 0.f;
-  }
-  // ReLU mask of the 64 -> 128 layer in the gather's accumulator layout: row 32 q + acc_row(e, h), column 32 wave + r
-  float a2m[2][16];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = 32 * q + acc_row(e, h);
-      // rows past D carry row D-1's mask: they are exact zeros.  Packed pieces (mode 2): a ReLU output is positive iff its word
-      // (hi | lo << 16) is not zero
-      a2m[q][e] = a.A2[(row0 + s_rowmap[min(i, D - 1)]) * 128 + 32 * wave + r];
-    }
-  float4 h1t[4];
-  if (STAGE == 2) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = threadIdx.x + 256 * u;
-      const int i = e >> 4;
-      h1t[u] = *reinterpret_cast<const float4 *>(a.H1 + (row0 + s_rowmap[min(i, D - 1)]) * 64 + 4 * (e & 15));
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = 32 * q + acc_row(e, h);
-      if (q < R) {
-        const float v = joined(gacc[q], gaccl[q], e);
-        const bool pos = a.a2_packed ? __float_as_uint(a2m[q][e]) != 0u : a2m[q][e] > 0.f;
-        put_pieces(tD[0], tD[1], PM_LH128, i, 32 * wave + r, pos ? v : 0.f);
-      }
-    }
-  __syncthreads();
-V3_STAMP(4);
-
-    if (act) {  // through the 64->128 layer: [32R,128] @ W2r[128,64]
-    if (STAGE == 1) load_w16<64, false>(a.W1r, 64, 32 * cb, r, h, w1h, w1l);
-    if (STAGE == 2) load_w16<64, true>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1h, w1l);
-    if (STAGE == 1) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = 32 * rb + acc_row(e, h);
-        const bool in = i < D;
-        const int p = s_rowmap[min(i, D - 1)];
-        const size_t o = (row0 + p) * 64 + 32 * cb + r;
-        const float hv = a.H1[o], dv = a.dH1in[o];
-        mhv[e] = in ? hv : 0.f;
-        dhv[e] = (in && ((incoming >> p) & 1ull)) ? dv : 0.f;
-      }
-    }
-    f32x16 acc[1], accl[1];
-    zero(acc[0]);
-    zero(accl[0]);
-    mfma_apply16<128, 1>(tD[0], tD[1], PM_LH128, 32 * rb, w2h, w2l, acc, accl, r, h);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float v = joined(acc[0], accl[0], e);
-      if (STAGE != 2) v = m1v[e] > 0.f ? v : 0.f;
-      put_pieces(tE[0], tE[1], PM_LH64, 32 * rb + acc_row(e, h), 32 * cb + r, v);
-    }
-  }
-  __syncthreads();
-V3_STAMP(5);
-
-    if (STAGE == 2) {  // tD is dead: its first half takes the h1 rows (left operand of the transform gradient) as pieces
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = threadIdx.x + 256 * u;
-      const int n = e / 16, c = 4 * (e % 16);
-      put_pieces(tF0, tF1, PM_LH64, n, c, h1t[u].x);
-      put_pieces(tF0, tF1, PM_LH64, n, c + 1, h1t[u].y);
-      put_pieces(tF0, tF1, PM_LH64, n, c + 2, h1t[u].z);
-      put_pieces(tF0, tF1, PM_LH64, n, c + 3, h1t[u].w);
-    }
-    __syncthreads();
-    // (a) dT64 partial of this tile:  sum_n h1[n,i] * d[n,j]   (A = h1^T, B = d, K = the compacted points, ascending): both
-    //     operands are read down the rows of their tiles, eight 2-byte reads per piece and step
-    {
-      f32x16 acc, accl;
-      zero(acc);
-      zero(accl);
-      for (int s16 = 0; s16 < 2 * R; ++s16) {
-        h8v ah, al, bh, bl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int n = 16 * s16 + 8 * h + j;
-          ah[j] = *reinterpret_cast<const _Float16 *>(tF0 + n * PM_LH64 + 2 * (32 * rb + r));
-          al[j] = *reinterpret_cast<const _Float16 *>(tF1 + n * PM_LH64 + 2 * (32 * rb + r));
-          bh[j] = *reinterpret_cast<const _Float16 *>(tE[0] + n * PM_LH64 + 2 * (32 * cb + r));
-          bl[j] = *reinterpret_cast<const _Float16 *>(tE[1] + n * PM_LH64 + 2 * (32 * cb + r));
-        }
-        accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accl, 0, 0, 0);
-        accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accl, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-      }
-      float *o = a.dTpart + ((size_t)b * ntiles + tile) * 4096;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[(32 * rb + acc_row(e, h)) * 64 + 32 * cb + r] = joined(acc, accl, e);
-    }
-    // (b) dH1 = d @ T64^T, written for the compacted points only
-    if (act) {
-      f32x16 acc[1], accl[1];
-      zero(acc[0]);
-      zero(accl[0]);
-      mfma_apply16<64, 1>(tE[0], tE[1], PM_LH64, 32 * rb, w1h, w1l, acc, accl, r, h);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = 32 * rb + acc_row(e, h);
-        if (i < D) a.out[(row0 + s_rowmap[i]) * 64 + 32 * cb + r] = joined(acc[0], accl[0], e);
-      }
-    }
     V3_STAMP(7);
     V3_STAMP_FLUSH();
     return;
   }
-
-  const char *inH = tE[0], *inL = tE[1];
-  if (STAGE == 1) {  // through t1, add the gradient arriving at h1 from the encoder, through e1's ReLU
-    if (act) {
+  // One pass over all the tile's points (the common case), or -- more than 64 winning points -- one pass per word.
+  if (NW > 1 && !FIXUP) {
+    if (threadIdx.x == 0) a.overflow[(size_t)b * ntiles + tile] = Dall > PM_TM;
+    if (Dall > PM_TM) return;  // block-uniform: left to the second launch
+  }
+  const bool single = !FIXUP;  // (a tile reaches the second launch only with more than 64 winning points)
+  const int passes = single ? 1 : NW;
+#pragma unroll 1
+  for (int pass = 0; pass < passes; ++pass) {
+    constexpr int keep = 0;
+    // the points this pass works on (all of the tile's, or one 64-point word of it) and writes outputs for
+    unsigned long long act[NW];
+    int D = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      act[w] = (single || w == pass) ? present[w] : 0ull;
+      D += __popcll(act[w]);
+    }
+    auto in_pass = [&](int n) { return single || (n >> 6) == pass; };
+    auto cidx = [&](int n) {  // compact index of point n among the pass's winning points (ascending)
+      int c = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        if (w < (n >> 6)) c += __popcll(act[w]);
+        if (w == (n >> 6)) c += __popcll(act[w] & ((1ull << (n & 63)) - 1ull));
+      }
+      return c;
+    };
+    auto has = [&](const unsigned long long (&set)[NW], int n) {
+      unsigned long long v = 0ull;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (w == (n >> 6)) v = set[w];
+      return ((v >> (n & 63)) & 1ull) != 0ull;
+    };
+    const bool first = pass == 0;
+    if (!single) {  // (rare) the lists of this word alone: ranks again, behind the barrier that also retires the previous pass
+      __syncthreads();
+#pragma unroll
+      for (int ch = 0; ch < BW_CH; ++ch) {
+        const bool hit = mn[ch] >= 0 && in_pass(mn[ch]);
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_cnt[ch][wave] = __popcll(m);
+        rank[ch] = __popcll(m & ((1ull << lane) - 1ull));
+      }
+      __syncthreads();
+    }
+    const int R = (D + 31) >> 5;
+    if (D == 0) {  // (only in a multi-pass tile) a word without winners: zeros for its points, nothing to add to the partials
+      if (STAGE == 2) {
+        if (first) {
+          float4 *o = reinterpret_cast<float4 *>(a.dTpart + ((size_t)b * ntiles + tile) * 4096);
+          for (int e = threadIdx.x; e < 1024; e += 256) o[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {
+        if (STAGE == 1 && first && threadIdx.x < 9) a.dTpart[((size_t)b * ntiles + tile) * 9 + threadIdx.x] = 0.f;
+        for (int e = threadIdx.x; e < 3 * BT; e += 256) {
+          const int c = e / BT, n = e - c * BT;
+          if (n < rows && in_pass(n)) {
+            const size_t o = ((size_t)b * 3 + c) * N + n0 + n;
+            a.out[o] = STAGE == 0 ? 0.f + a.dPin[o] : 0.f;
+          }
+        }
+      }
+      continue;
+    }
+    if (threadIdx.x < BT && has(act, threadIdx.x)) s_rowmap[cidx(threadIdx.x)] = threadIdx.x;
+    int M = 0;
+#pragma unroll
+    for (int ch = 0; ch < BW_CH; ++ch)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w == wave && mn[ch] >= 0 && in_pass(mn[ch])) {
+          _Float16 gh, gl;
+          split_pair(mg[ch], gh, gl);
+          const uint32_t g2 = (uint32_t)__builtin_bit_cast(uint16_t, gh) | ((uint32_t)__builtin_bit_cast(uint16_t, gl) << 16);
+          list[M + rank[ch]] = make_int2((ch * 256 + (int)threadIdx.x) | (cidx(mn[ch]) << 16), (int)g2);
+        }
+        M += s_cnt[ch][w];
+      }
+    if (threadIdx.x < 128) list[M + threadIdx.x] = make_int2(0, 0);
+    __syncthreads();
+    V3_STAMP(2);
+    // ---- gather on the fp16 matrix cores
+    f32x16 gacc[2], gaccl[2];
+    zero(gacc[0]);
+    zero(gacc[1]);
+    zero(gaccl[0]);
+    zero(gaccl[1]);
+    if (D > 32)
+      gather_rows16<true>(list, M, (a.W3r + keep) + 32 * wave + r, r, h, gacc, gaccl);
+    else
+      gather_rows16<false>(list, M, (a.W3r + keep) + 32 * wave + r, r, h, gacc, gaccl);
+    V3_STAMP(3);
+    // ---- everything the chain will need from global memory
+    const bool act_rows = rb < R;
+    uint4 w2h[8], w2l[8], w1h[4], w1l[4];
+    if (act_rows) load_w16<128, false>((a.W2r + keep), 64, 32 * cb, r, h, w2h, w2l);
+    float m1v[16], mhv[16], dhv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = 32 * rb + acc_row(e, h);
+      m1v[e] = STAGE != 2 ? (a.A1 + keep)[(row0 + s_rowmap[min(i, D - 1)]) * 64 + 32 * cb + r] : 0.f;
+    }
+    // ReLU mask of the 64 -> 128 layer in the gather's accumulator layout: row 32 q + acc_row(e, h), column 32 wave + r
+    float a2m[2][16];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = 32 * q + acc_row(e, h);
+        // rows past D carry row D-1's mask: they are exact zeros.  Packed pieces (mode 2): a ReLU output is positive iff its word
+        // (hi | lo << 16) is not zero
+        a2m[q][e] = (a.A2 + keep)[(row0 + s_rowmap[min(i, D - 1)]) * 128 + 32 * wave + r];
+      }
+    float4 h1t[4];
+    if (STAGE == 2) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const int i = e >> 4;
+        h1t[u] = *reinterpret_cast<const float4 *>((a.H1 + keep) + (row0 + s_rowmap[min(i, D - 1)]) * 64 + 4 * (e & 15));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = 32 * q + acc_row(e, h);
+        if (q < R) {
+          const float v = joined(gacc[q], gaccl[q], e);
+          const bool pos = a.a2_packed ? __float_as_uint(a2m[q][e]) != 0u : a2m[q][e] > 0.f;
+          put_pieces(tD[0], tD[1], PM_LH128, i, 32 * wave + r, pos ? v : 0.f);
+        }
+      }
+    __syncthreads();
+    V3_STAMP(4);
+    if (act_rows) {  // through the 64->128 layer: [32R,128] @ W2r[128,64]
+      if (STAGE == 1) load_w16<64, false>((a.W1r + keep), 64, 32 * cb, r, h, w1h, w1l);
+      if (STAGE == 2) load_w16<64, true>((a.T + keep) + (size_t)b * 4096, 64, 32 * cb, r, h, w1h, w1l);
+      if (STAGE == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = 32 * rb + acc_row(e, h);
+          const bool in = i < D;
+          const int p = s_rowmap[min(i, D - 1)];
+          const size_t o = (row0 + p) * 64 + 32 * cb + r;
+          const float hv = (a.H1 + keep)[o], dv = (a.dH1in + keep)[o];
+          mhv[e] = in ? hv : 0.f;
+          dhv[e] = (in && has(incoming, p)) ? dv : 0.f;
+        }
+      }
       f32x16 acc[1], accl[1];
       zero(acc[0]);
       zero(accl[0]);
-      mfma_apply16<64, 1>(tE[0], tE[1], PM_LH64, 32 * rb, w1h, w1l, acc, accl, r, h);
+      mfma_apply16<128, 1>(tD[0], tD[1], PM_LH128, 32 * rb, w2h, w2l, acc, accl, r, h);
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        put_pieces(tF0, tF1, PM_LH64, 32 * rb + acc_row(e, h), 32 * cb + r, mhv[e] > 0.f ? joined(acc[0], accl[0], e) + dhv[e] : 0.f);
+      for (int e = 0; e < 16; ++e) {
+        float v = joined(acc[0], accl[0], e);
+        if (STAGE != 2) v = m1v[e] > 0.f ? v : 0.f;
+        put_pieces(tE[0], tE[1], PM_LH64, 32 * rb + acc_row(e, h), 32 * cb + r, v);
+      }
     }
     __syncthreads();
-    inH = tF0;
-    inL = tF1;
-  }
-V3_STAMP(6);
-
-    if (wave < 3) {  // 64 -> 3 backwards on the VALU:  g[i,c] = sum_k d[i,k] * W0r[k,c]; the row comes back as hi + 2^-11 lo
-    const int c = wave, i = lane;
-    float v = 0.f;
-    if (i < D) {
+    V3_STAMP(5);
+    if (STAGE == 2) {  // tD is dead: its first half takes the h1 rows (left operand of the transform gradient) as pieces
 #pragma unroll
-      for (int k8 = 0; k8 < 8; ++k8) {
-        const h8v dh = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(inH + i * PM_LH64 + 16 * k8));
-        const h8v dl = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(inL + i * PM_LH64 + 16 * k8));
+      for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const int n = e / 16, c = 4 * (e % 16);
+        put_pieces(tF0, tF1, PM_LH64, n, c, h1t[u].x);
+        put_pieces(tF0, tF1, PM_LH64, n, c + 1, h1t[u].y);
+        put_pieces(tF0, tF1, PM_LH64, n, c + 2, h1t[u].z);
+        put_pieces(tF0, tF1, PM_LH64, n, c + 3, h1t[u].w);
+      }
+      __syncthreads();
+      // (a) dT64 partial of this tile:  sum_n h1[n,i] * d[n,j]   (A = h1^T, B = d, K = the compacted points, ascending): both
+      //     operands are read down the rows of their tiles, eight 2-byte reads per piece and step
+      {
+        f32x16 acc, accl;
+        zero(acc);
+        zero(accl);
+        for (int s16 = 0; s16 < 2 * R; ++s16) {
+          h8v ah, al, bh, bl;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v = fmaf(fmaf((float)dl[j], 1.f / PM_SC, (float)dh[j]), a.W0r[(8 * k8 + j) * 3 + c], v);
-      }
-    }
-    sG[i * 3 + c] = v;
-  }
-  __syncthreads();
-  if (STAGE == 0) {
-    if (wave < 3) {
-      const int c = wave, n = lane;
-      if (n < rows) {
-        const size_t o = ((size_t)b * 3 + c) * N + n0 + n;
-        const float v = ((present >> n) & 1ull) ? sG[__popcll(present & ((1ull << n) - 1ull)) * 3 + c] : 0.f;
-        a.out[o] = v + a.dPin[o];
-      }
-    }
-  } else {
-    const float *T = a.T + (size_t)b * 9;
-    if (wave < 3) {
-      const int i = wave, n = lane;
-      if (n < rows) {
-        float v = 0.f;
-        if ((present >> n) & 1ull) {
-          const float *g = sG + __popcll(present & ((1ull << n) - 1ull)) * 3;
-          v = fmaf(g[2], T[i * 3 + 2], fmaf(g[1], T[i * 3 + 1], g[0] * T[i * 3]));
+          for (int j = 0; j < 8; ++j) {
+            const int n = 16 * s16 + 8 * h + j;
+            ah[j] = *reinterpret_cast<const _Float16 *>(tF0 + n * PM_LH64 + 2 * (32 * rb + r));
+            al[j] = *reinterpret_cast<const _Float16 *>(tF1 + n * PM_LH64 + 2 * (32 * rb + r));
+            bh[j] = *reinterpret_cast<const _Float16 *>(tE[0] + n * PM_LH64 + 2 * (32 * cb + r));
+            bl[j] = *reinterpret_cast<const _Float16 *>(tE[1] + n * PM_LH64 + 2 * (32 * cb + r));
+          }
+          accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accl, 0, 0, 0);
+          accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accl, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
         }
-        a.out[((size_t)b * 3 + i) * N + n0 + n] = v;
+        float *o = a.dTpart + ((size_t)b * ntiles + tile) * 4096;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float *d = o + (32 * rb + acc_row(e, h)) * 64 + 32 * cb + r;
+          const float v = joined(acc, accl, e);
+          *d = first ? v : *d + v;  // a later pass adds to what this thread wrote in the pass before (word order)
+        }
       }
-    } else if (threadIdx.x < 192 + 9) {
-      const int q = threadIdx.x - 192, i = q / 3, j = q % 3;
+      // (b) dH1 = d @ T64^T, written for the compacted points only
+      if (act_rows) {
+        f32x16 acc[1], accl[1];
+        zero(acc[0]);
+        zero(accl[0]);
+        mfma_apply16<64, 1>(tE[0], tE[1], PM_LH64, 32 * rb, w1h, w1l, acc, accl, r, h);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = 32 * rb + acc_row(e, h);
+          if (i < D) a.out[(row0 + s_rowmap[i]) * 64 + 32 * cb + r] = joined(acc[0], accl[0], e);
+        }
+      }
+      continue;
+    }
+
+    const char *inH = tE[0], *inL = tE[1];
+    if (STAGE == 1) {  // through t1, add the gradient arriving at h1 from the encoder, through e1's ReLU
+      if (act_rows) {
+        f32x16 acc[1], accl[1];
+        zero(acc[0]);
+        zero(accl[0]);
+        mfma_apply16<64, 1>(tE[0], tE[1], PM_LH64, 32 * rb, w1h, w1l, acc, accl, r, h);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          put_pieces(tF0, tF1, PM_LH64, 32 * rb + acc_row(e, h), 32 * cb + r, mhv[e] > 0.f ? joined(acc[0], accl[0], e) + dhv[e] : 0.f);
+      }
+      __syncthreads();
+      inH = tF0;
+      inL = tF1;
+    }
+    V3_STAMP(6);
+    if (wave < 3) {  // 64 -> 3 backwards on the VALU:  g[i,c] = sum_k d[i,k] * W0r[k,c]; the row comes back as hi + 2^-11 lo
+      const int c = wave, i = lane;
       float v = 0.f;
-      for (int ci = 0; ci < D; ++ci) v = fmaf(sX[s_rowmap[ci] * 3 + i], sG[ci * 3 + j], v);
-      a.dTpart[((size_t)b * ntiles + tile) * 9 + q] = v;
+      if (i < D) {
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+          const h8v dh = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(inH + i * PM_LH64 + 16 * k8));
+          const h8v dl = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(inL + i * PM_LH64 + 16 * k8));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v = fmaf(fmaf((float)dl[j], 1.f / PM_SC, (float)dh[j]), (a.W0r + keep)[(8 * k8 + j) * 3 + c], v);
+        }
+      }
+      sG[i * 3 + c] = v;
+    }
+    __syncthreads();
+    if (STAGE == 0) {
+      if (wave < 3) {
+        const int c = wave;
+#pragma unroll
+        for (int n = lane; n < BT; n += 64) {
+          if (n < rows && in_pass(n)) {
+            const size_t o = ((size_t)b * 3 + c) * N + n0 + n;
+            const float v = has(act, n) ? sG[cidx(n) * 3 + c] : 0.f;
+            a.out[o] = v + a.dPin[o];
+          }
+        }
+      }
+    } else {
+      const float *T = (a.T + keep) + (size_t)b * 9;
+      if (wave < 3) {
+        const int i = wave;
+#pragma unroll
+        for (int n = lane; n < BT; n += 64) {
+          if (n < rows && in_pass(n)) {
+            float v = 0.f;
+            if (has(act, n)) {
+              const float *g = sG + cidx(n) * 3;
+              v = fmaf(g[2], T[i * 3 + 2], fmaf(g[1], T[i * 3 + 1], g[0] * T[i * 3]));
+            }
+            a.out[((size_t)b * 3 + i) * N + n0 + n] = v;
+          }
+        }
+      } else if (threadIdx.x < 192 + 9) {
+        const int q = threadIdx.x - 192, i = q / 3, j = q % 3;
+        float v = 0.f;
+        for (int ci = 0; ci < D; ++ci) v = fmaf(sX[s_rowmap[ci] * 3 + i], sG[ci * 3 + j], v);
+        float *d = a.dTpart + ((size_t)b * ntiles + tile) * 9 + q;
+        *d = first ? v : *d + v;
+      }
     }
   }
   V3_STAMP(7);
@@ -1724,12 +1818,24 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *
 
 extern "C" int64_t hitadv_pointnet_rowmlp_tiles(int N) { return N > 0 ? (N + PM_TM - 1) / PM_TM : 0; }
 
+// 64-point words per block tile of the backward kernels: 2 for the fp16 form (rowmlp_bwd16_k<., 2>), 1 for the f32 form.
+// HITADV_V3_WORDS=1 keeps the fp16 form at one word (A/B timing only).
+static int bwd_words(int mode) {
+  static const int fp16_words = [] { const char *e = getenv("HITADV_V3_WORDS"); return e && atoi(e) == 1 ? 1 : 2; }();
+  return mode >= 1 ? fp16_words : 1;
+}
+extern "C" int hitadv_pointnet_rowmlp_bwd_words(int mode) { return bwd_words(mode); }
+extern "C" int64_t hitadv_pointnet_rowmlp_bwd_tiles(int N, int mode) {
+  const int bt = PM_TM * bwd_words(mode);
+  return N > 0 ? (N + bt - 1) / bt : 0;
+}
+
 extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const float *gmask, const int64_t *idx,
                                           const float *W3r, int Cout, const float *A2, const float *W2r,
                                           const float *A1, const float *W1r, const float *H1, const float *dH1in,
                                           const float *W0r, const float *T, const float *x, const float *dPin,
-                                          float *dTpart, float *out, const uint64_t *pres_in, uint64_t *pres_out, int B,
-                                          int N, int mode, void *stream) {
+                                          float *dTpart, float *out, const uint64_t *pres_in, uint64_t *pres_out,
+                                          int32_t *overflow, int B, int N, int mode, void *stream) {
   HITADV_ABLATE_RETURN("v3");
   if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || N > 65535 || Cout <= 0 || Cout > 256 * BW_CH || !dg || !idx ||
       !W3r || !A2 || !W2r || !out || mode < 0 || mode > 2)
@@ -1739,13 +1845,25 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
   if (stage == 2 && (!H1 || !T || !dTpart)) return HITADV_E_ARG;
   RowMlpBwd a{dg, gmask, idx, W3r, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out,
               reinterpret_cast<const unsigned long long *>(pres_in), reinterpret_cast<unsigned long long *>(pres_out), N,
-              Cout, mode == 2};
-  dim3 grid((N + PM_TM - 1) / PM_TM, B);
+              Cout, mode == 2, overflow};
+  dim3 grid((unsigned)hitadv_pointnet_rowmlp_bwd_tiles(N, mode), B);
   hipStream_t s = (hipStream_t)stream;
-  if (mode >= 1) {
-    if (stage == 0) rowmlp_bwd16_k<0><<<grid, 256, 0, s>>>(a);
-    else if (stage == 1) rowmlp_bwd16_k<1><<<grid, 256, 0, s>>>(a);
-    else rowmlp_bwd16_k<2><<<grid, 256, 0, s>>>(a);
+  if (mode >= 1 && bwd_words(mode) == 2) {
+    if (!overflow) return HITADV_E_ARG;
+    if (stage == 0) {
+      rowmlp_bwd16_k<0, 2, false><<<grid, 256, 0, s>>>(a);
+      rowmlp_bwd16_k<0, 2, true><<<grid, 256, 0, s>>>(a);
+    } else if (stage == 1) {
+      rowmlp_bwd16_k<1, 2, false><<<grid, 256, 0, s>>>(a);
+      rowmlp_bwd16_k<1, 2, true><<<grid, 256, 0, s>>>(a);
+    } else {
+      rowmlp_bwd16_k<2, 2, false><<<grid, 256, 0, s>>>(a);
+      rowmlp_bwd16_k<2, 2, true><<<grid, 256, 0, s>>>(a);
+    }
+  } else if (mode >= 1) {
+    if (stage == 0) rowmlp_bwd16_k<0, 1, false><<<grid, 256, 0, s>>>(a);
+    else if (stage == 1) rowmlp_bwd16_k<1, 1, false><<<grid, 256, 0, s>>>(a);
+    else rowmlp_bwd16_k<2, 1, false><<<grid, 256, 0, s>>>(a);
   } else if (stage == 0) rowmlp_bwd_k<0><<<grid, 256, 0, s>>>(a);
   else if (stage == 1) rowmlp_bwd_k<1><<<grid, 256, 0, s>>>(a);
   else rowmlp_bwd_k<2><<<grid, 256, 0, s>>>(a);

@@ -1535,3 +1535,57 @@ def test_merged_iteration_launches_equal_the_launches_they_merge(A, B, K, Np, C)
             assert torch.equal(Pa, Pb) and torch.equal(Sa, Sb) and torch.equal(Pa, Pc) and torch.equal(Sa, Sc)
             for x, y, z in zip(ma, mb, mc):
                 assert torch.equal(x, y) and torch.equal(x, z)
+
+
+@pytest.mark.parametrize("pattern", ["crowded", "random", "one_crowded_tile"])
+def test_rowmlp_bwd_two_word_tiles_and_their_overflow_path(A, pattern):
+    """The fp16 backward chain covers two 64-point words per block and leaves a tile with more than 64 winning points to a
+    second launch that takes it word by word.  Against the f32 chain (one word per block, no such path) on the same
+    synthetic arg-max tables: 'crowded' sends the 1024 channels to 128 distinct points of the first tile of every cloud (both
+    words full: the second launch does all the work), 'random' is the usual sparse case, 'one_crowded_tile' mixes the two;
+    N = 1000 leaves a ragged last tile (a full word and 40 points).  All three stages, outputs, per-tile partials (summed over
+    the tiles: the two forms cut the cloud differently) and the row-presence tables (the same bits in both layouts)."""
+    torch.manual_seed(5)
+    B, N, Cout = 3, 1000, 1024
+    R = B * N
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(7)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)  # noqa: E731
+    if pattern == "crowded":
+        idx = (torch.arange(Cout) % 128).expand(B, Cout).contiguous()
+    elif pattern == "random":
+        idx = torch.randint(0, N, (B, Cout), generator=g)
+    else:
+        idx = torch.randint(0, N, (B, Cout), generator=g)
+        idx[:, :700] = 384 + (torch.arange(700) % 100)  # 100 distinct points of the 128-point tile [384, 512)
+    idx = idx.to(dev)
+    dg, gmask = rnd(B, Cout), rnd(B, Cout)
+    W3r, W2r, W1r, W0r = rnd(Cout, 128) * 0.1, rnd(128, 64) * 0.1, rnd(64, 64) * 0.1, rnd(64, 3) * 0.1
+    A2, A1, H1 = rnd(R, 128), rnd(R, 64), rnd(R, 64)
+    T64, T3, x, dPin = rnd(B, 64, 64) * 0.1, rnd(B, 9), rnd(B, 3, N), rnd(B, 3, N)
+
+    def run(mode):
+        tiles, words = A.pointnet_rowmlp_bwd_tiles(N, mode)
+        pres2 = torch.zeros(B, tiles, words, device=dev, dtype=torch.int64)
+        pres1 = torch.zeros(B, tiles, words, device=dev, dtype=torch.int64)
+        dT64, dT3 = torch.full((B, tiles, 4096), float('nan'), device=dev), torch.full((B, tiles, 9), float('nan'), device=dev)
+        dH1 = torch.zeros(R, 64, device=dev)
+        dPts, dX = torch.full((B, 3, N), float('nan'), device=dev), torch.full((B, 3, N), float('nan'), device=dev)
+        A.pointnet_rowmlp_bwd(2, B, N, dg, idx, W3r, A2, W2r, dH1, H1=H1, T=T64, dTpart=dT64, pres_out=pres2, mode=mode)
+        A.pointnet_rowmlp_bwd(1, B, N, dg, idx, W3r, A2, W2r, dPts, gmask=gmask, A1=A1, W1r=W1r, H1=H1, dH1in=dH1, W0r=W0r,
+                              T=T3, x=x, dTpart=dT3, pres_in=pres2, pres_out=pres1, mode=mode)
+        A.pointnet_rowmlp_bwd(0, B, N, dg, idx, W3r, A2, W2r, dX, gmask=gmask, A1=A1, W0r=W0r, dPin=dPts, pres_in=pres1, mode=mode)
+        torch.cuda.synchronize()
+        return dict(dH1=dH1, dT64=dT64.sum(1), dT3=dT3.sum(1), dPts=dPts, dX=dX, pres2=pres2.reshape(B, -1), pres1=pres1.reshape(B, -1),
+                    words=words)
+    f32, f16 = run(0), run(1)
+    assert f32['words'] == 1 and f16['words'] == 2
+    assert torch.equal(f32['pres2'], f16['pres2']) and torch.equal(f32['pres1'], f16['pres1'])
+    if pattern == "crowded":
+        assert int(f16['pres2'][0, 0]) == -1 and int(f16['pres2'][0, 1]) == -1  # both words of the first tile full
+    for name in ('dH1', 'dT64', 'dT3', 'dPts', 'dX'):
+        a, b = f16[name], f32[name]
+        assert torch.isfinite(a).all() and torch.isfinite(b).all(), name
+        close(a, b, rtol=1e-4, atol=2e-6 * float(b.abs().max()), what='rowmlp_bwd two-word tiles vs one-word f32 chain: %s (%s)' % (name, pattern))
+    again = run(1)
+    assert all(torch.equal(again[k], f16[k]) for k in ('dH1', 'dT64', 'dT3', 'dPts', 'dX'))  # bitwise reproducible
