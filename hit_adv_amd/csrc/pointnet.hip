@@ -1818,8 +1818,9 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *
 
 extern "C" int64_t hitadv_pointnet_rowmlp_tiles(int N) { return N > 0 ? (N + PM_TM - 1) / PM_TM : 0; }
 
-// 64-point words per block tile of the backward kernels: 2 for the fp16 form (rowmlp_bwd16_k<., 2>), 1 for the f32 form.
-// HITADV_V3_WORDS=1 keeps the fp16 form at one word (A/B timing only).
+// 64-point words per block tile of the backward kernels: 2 for the fp16 form (rowmlp_bwd16_k<., 2, .>), 1 for the f32 form.
+// HITADV_V3_WORDS=1 keeps the fp16 form at one word (A/B timing only).  Measured, cfg2 headline job on one box: one word
+// 43.7 clouds/s, two 48.2 (a second box: 47.7), four 47.0 (more tiles over 64 winning points, longer gathers).
 static int bwd_words(int mode) {
   static const int fp16_words = [] { const char *e = getenv("HITADV_V3_WORDS"); return e && atoi(e) == 1 ? 1 : 2; }();
   return mode >= 1 ? fp16_words : 1;
