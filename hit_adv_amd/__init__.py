@@ -16,7 +16,8 @@ import warnings as _warnings
 # attack_many() runs stacks of independent attacks on their own HIP streams; with the runtime's default of 4 hardware queues
 # three or more of them serialise again (bench.py: 30.3 vs 37.4 clouds/s at twelve attacks in three stacks).  The variable is read ONCE, when the HIP runtime starts: setting
 # it here only helps if nothing has touched the GPU yet (importing torch is fine; torch.cuda.is_available(), set_device(),
-# init_process_group('nccl') and a profiler's preloaded library are not).
+# init_process_group('nccl') and a profiler's preloaded library are not).  This is the ONE thing the package changes in the
+# importing process's environment; HITADV_KEEP_ENVIRONMENT=1 switches it off (attacks in flight are then capped for 4 queues).
 _HW_QUEUES_WANTED = 8
 
 
@@ -26,7 +27,10 @@ def _runtime_started():
 
 
 _preset = _os.environ.get("GPU_MAX_HW_QUEUES")
-if _preset is None:
+if _os.environ.get("HITADV_KEEP_ENVIRONMENT") == "1":
+    # the importing process does not want its environment touched: whatever the runtime's queue count is, it stays
+    _QUEUES_IN_TIME = _preset is not None
+elif _preset is None:
     _os.environ["GPU_MAX_HW_QUEUES"] = str(_HW_QUEUES_WANTED)
     _QUEUES_IN_TIME = not _runtime_started()
     if not _QUEUES_IN_TIME:

@@ -167,8 +167,8 @@ def test_hit_adv_graph_and_eager_agree_and_prints_progress():
 
 
 def test_hit_adv_pointnet_engine_follows_the_cpu_oracle():
-    """The bench's own victim: HiT-ADV with the PointNet HIP engine (f32 MFMA victim kernels, autograd-free iteration,
-    hipGraph) against the CPU oracle driving the plain nn.Module -- same centres bit for bit, the iterates of a whole
+    """The bench's own victim: HiT-ADV with the PointNet HIP engine (default matrix mode fp16x2: two fp16 pieces per operand,
+    fp32-accurate; autograd-free iteration, hipGraph) against the CPU oracle driving the plain nn.Module -- same centres bit for bit, the iterates of a whole
     binary step within fp32 re-association noise, same returned clouds and success count."""
     import copy
     from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV

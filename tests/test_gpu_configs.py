@@ -398,8 +398,8 @@ def test_cfg4_pointnet2_batch64_hit_adv_vs_cpu_oracle_and_graph():
     assert ws.feed is not None and ws.feed.table.shape == (2, 2, 64)
     same = (ws.central.cpu() == oracle.state['central']).all(dim=1).float().mean().item()
     assert same >= 0.995, same
-    # achieved on MI355X (profiles/r02_parity_report.json): |gpu - oracle| <= 1.1e-6 (boundary points of the ball query --
-    # Gram form in the reference, direct form here -- did not move a single iterate beyond fp32 rounding)
+    # achieved on MI355X: |gpu - oracle| <= 1.1e-6 (the victim's FPS and ball-query tables are the oracle's bit for bit: both
+    # evaluate the reference's own Gram-form expressions, test_cfg4_pointnet2_batch64_2048_points_tables_and_float64_module)
     for i, row in enumerate(rec.rows):
         close(row['adv'], trace[i]['adv'], rtol=1e-4, atol=2e-5, what='cfg4 iterate %d' % i)
     close(best, obest, rtol=1e-4, atol=2e-5, what='cfg4 result')
