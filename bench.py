@@ -200,9 +200,10 @@ def roofline_group_add_relu(dev, B, N, S, ns, C, what):
     us = graph_timed(lambda s: lib.hitadv_group_add_relu_fwd(_p(U), _p(V), _p(idx), B, N, S, ns, C, _p(H), s))
     alg = 4 * B * S * ns * C + 4 * B * (N + S) * C + 8 * B * S * ns
     ach = alg / (us * 1e-6) / 1e9
+    traffic, src = _traffic("hitadv::group_add_relu_fwd_k@" + ("cfg4" if "PointNet++" in what else "cfg5"))
     return dict(kernel="group_add_relu_fwd_k (%s: B=%d, N=%d, S=%d, nsample=%d, C=%d)" % (what, B, N, S, ns, C), bound="hbm",
-                achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
-                us_per_launch=round(us, 2), algorithmic_bytes=alg)
+                achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+                traffic_source=src, us_per_launch=round(us, 2), algorithmic_bytes=alg)
 
 
 def hot_loop_kernels(dev, B=32, N=1024):

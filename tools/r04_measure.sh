@@ -51,6 +51,31 @@ for w in $WHAT; do
       done
       python tools/pmc_summary.py $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_FETCH_SIZE.csv > $OUT/kbench_traffic.json 2>> $OUT/pmc_WRITE_SIZE.log
       rm -f $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv ;;
+    pmc_gar)  # HBM traffic of cfg4's / cfg5's roofline kernel (group_add_relu_fwd_k at the two shapes), merged into kbench_traffic.json
+      for c in cfg4 cfg5; do
+        for ctr in FETCH_SIZE WRITE_SIZE; do
+          rm -rf /tmp/prof/gar_$ctr
+          timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/prof/gar_$ctr -- python3 tools/gar_probe.py $c > $OUT/pmc_gar_${c}_$ctr.log 2>&1
+          f=$(find /tmp/prof/gar_$ctr -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" /tmp/prof/gar_${c}_$ctr.csv
+        done
+        python tools/pmc_summary.py /tmp/prof/gar_${c}_WRITE_SIZE.csv /tmp/prof/gar_${c}_FETCH_SIZE.csv > $OUT/gar_traffic_$c.json
+      done
+      python - $OUT <<'PY'
+import json, sys
+out = sys.argv[1]
+try:
+    merged = json.load(open(out + '/kbench_traffic.json'))
+except Exception:
+    merged = {}
+for c in ('cfg4', 'cfg5'):
+    d = json.load(open('%s/gar_traffic_%s.json' % (out, c)))
+    for k, v in d.items():
+        if 'group_add_relu_fwd_k' in k:
+            merged[k + '@' + c] = v
+json.dump(merged, open(out + '/kbench_traffic.json', 'w'), indent=1)
+print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in merged.items()}))
+PY
+      ;;
     pmc_mfma)  # SQ counters of V1 and G16, one pass per counter group (a pass fails as a whole on an unknown counter name)
       i=0
       for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
