@@ -1818,16 +1818,21 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *
 
 extern "C" int64_t hitadv_pointnet_rowmlp_tiles(int N) { return N > 0 ? (N + PM_TM - 1) / PM_TM : 0; }
 
-// 64-point words per block tile of the backward kernels: 2 for the fp16 form (rowmlp_bwd16_k<., 2, .>), 1 for the f32 form.
-// HITADV_V3_WORDS=1 keeps the fp16 form at one word (A/B timing only).  Measured, cfg2 headline job on one box: one word
-// 43.7 clouds/s, two 48.2 (a second box: 47.7), four 47.0 (more tiles over 64 winning points, longer gathers).
-static int bwd_words(int mode) {
-  static const int fp16_words = [] { const char *e = getenv("HITADV_V3_WORDS"); return e && atoi(e) == 1 ? 1 : 2; }();
-  return mode >= 1 ? fp16_words : 1;
+// 64-point words per block tile of the backward kernels: 2 in the fp16 modes, 1 in the f32 mode -- for EVERY launch size.
+// (At B = 32 x 1024 points one word is exactly one round of blocks and the two-word form only adds its second launch: one
+// attack alone runs at 329 instead of 312 us per iteration.  But the two forms sum a tile's rows in different groupings, and
+// an attack inside a 128-cloud stack has to return the bits of the same attack run alone (B = 32): one form for all sizes.)
+// HITADV_V3_WORDS=1|2 overrides (A/B timing).  Measured, cfg2 headline job (128-cloud launches): one word 43.7 clouds/s,
+// two 48.2 (a second box: 47.7), four 47.0 (more tiles over 64 winning points, longer gathers).
+extern "C" int hitadv_pointnet_rowmlp_bwd_words(int B, int N, int mode) {
+  static const int forced = [] { const char *e = getenv("HITADV_V3_WORDS"); return e ? atoi(e) : 0; }();
+  (void)B;
+  (void)N;
+  if (mode < 1) return 1;
+  return forced == 1 ? 1 : 2;
 }
-extern "C" int hitadv_pointnet_rowmlp_bwd_words(int mode) { return bwd_words(mode); }
-extern "C" int64_t hitadv_pointnet_rowmlp_bwd_tiles(int N, int mode) {
-  const int bt = PM_TM * bwd_words(mode);
+extern "C" int64_t hitadv_pointnet_rowmlp_bwd_tiles(int N, int words) {
+  const int bt = PM_TM * (words == 2 ? 2 : 1);
   return N > 0 ? (N + bt - 1) / bt : 0;
 }
 
@@ -1836,10 +1841,10 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
                                           const float *A1, const float *W1r, const float *H1, const float *dH1in,
                                           const float *W0r, const float *T, const float *x, const float *dPin,
                                           float *dTpart, float *out, const uint64_t *pres_in, uint64_t *pres_out,
-                                          int32_t *overflow, int B, int N, int mode, void *stream) {
+                                          int32_t *overflow, int words, int B, int N, int mode, void *stream) {
   HITADV_ABLATE_RETURN("v3");
   if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || N > 65535 || Cout <= 0 || Cout > 256 * BW_CH || !dg || !idx ||
-      !W3r || !A2 || !W2r || !out || mode < 0 || mode > 2)
+      !W3r || !A2 || !W2r || !out || mode < 0 || mode > 2 || words < 1 || words > 2 || (mode == 0 && words != 1))
     return HITADV_E_ARG;
   if (stage == 0 && (!A1 || !W0r || !dPin)) return HITADV_E_ARG;
   if (stage == 1 && (!A1 || !W1r || !H1 || !dH1in || !W0r || !T || !x || !dTpart)) return HITADV_E_ARG;
@@ -1847,9 +1852,9 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
   RowMlpBwd a{dg, gmask, idx, W3r, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out,
               reinterpret_cast<const unsigned long long *>(pres_in), reinterpret_cast<unsigned long long *>(pres_out), N,
               Cout, mode == 2, overflow};
-  dim3 grid((unsigned)hitadv_pointnet_rowmlp_bwd_tiles(N, mode), B);
+  dim3 grid((unsigned)hitadv_pointnet_rowmlp_bwd_tiles(N, words), B);
   hipStream_t s = (hipStream_t)stream;
-  if (mode >= 1 && bwd_words(mode) == 2) {
+  if (mode >= 1 && words == 2) {
     if (!overflow) return HITADV_E_ARG;
     if (stage == 0) {
       rowmlp_bwd16_k<0, 2, false><<<grid, 256, 0, s>>>(a);

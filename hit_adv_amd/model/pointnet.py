@@ -253,7 +253,7 @@ class _PointNetHip(torch.autograd.Function):
         R = B * N
         E = lambda *s: torch.empty(*s, device=x.device)  # noqa: E731
         cm = 2 if v.matrix_mode == 'fp16x2' else 0  # the mode the forward pass ran in (2: a2* hold packed pieces)
-        tiles, words = ops.pointnet_rowmlp_bwd_tiles(N, cm)
+        tiles, words = ops.pointnet_rowmlp_bwd_tiles(B, N, cm)
         if dlogits is None:
             dlogits = torch.zeros(B, v.h3_w.shape[1], device=x.device)
         # head and encoder tail
@@ -267,7 +267,7 @@ class _PointNetHip(torch.autograd.Function):
         pres2 = torch.empty(B, tiles, words, device=x.device, dtype=torch.int64)
         pres1 = torch.empty(B, tiles, words, device=x.device, dtype=torch.int64)
         over = torch.empty(B, tiles, device=x.device, dtype=torch.int32) if words > 1 else None  # tiles left to the second launch
-        ops.pointnet_rowmlp_bwd(2, B, N, dg, je, v.e3_wr, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp, pres_out=pres2, mode=cm, overflow=over)
+        ops.pointnet_rowmlp_bwd(2, B, N, dg, je, v.e3_wr, a2e, v.e2_wr, dH1, H1=h1, T=T64, dTpart=dTp, pres_out=pres2, mode=cm, overflow=over, words=words)
         dT64 = ops.sum_partials(dTp, None if dT64_ext is None else dT64_ext.reshape(B, 4096).contiguous())
         # STNkd, first encoder layer, input transform
         d = ops.fc_layer(dT64, v.t6_wr)
@@ -275,7 +275,7 @@ class _PointNetHip(torch.autograd.Function):
         dgt = ops.fc_layer(d, v.t4_wr, mask=f4t)
         dTp, dPts = E(B, tiles, 9), E(B, 3, N)
         ops.pointnet_rowmlp_bwd(1, B, N, dgt, jt, v.t3_wr, a2t, v.t2_wr, dPts, gmask=gt, A1=a1t, W1r=v.t1_wr, H1=h1,
-                                dH1in=dH1, W0r=v.e1_wr, T=T3, x=x, dTpart=dTp, pres_in=pres2, pres_out=pres1, mode=cm, overflow=over)
+                                dH1in=dH1, W0r=v.e1_wr, T=T3, x=x, dTpart=dTp, pres_in=pres2, pres_out=pres1, mode=cm, overflow=over, words=words)
         # STN3d: the sum of the tiles' dT3 partials, fc3 and fc2 backwards in one launch
         if v.fold_small_layers:
             d = ops.fc_layer_pre(dTp, v.s6_wr, v.s5_wr, mask=f5s)
@@ -284,7 +284,7 @@ class _PointNetHip(torch.autograd.Function):
         dgs = ops.fc_layer(d, v.s4_wr, mask=f4s)
         dX = E(B, 3, N)
         ops.pointnet_rowmlp_bwd(0, B, N, dgs, js, v.s3_wr, a2s, v.s2_wr, dX, gmask=gs, A1=a1s, W0r=v.s1_wr, dPin=dPts,
-                                pres_in=pres1, mode=cm, overflow=over)
+                                pres_in=pres1, mode=cm, overflow=over, words=words)
         return dX, None
 
 

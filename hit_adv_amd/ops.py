@@ -705,27 +705,31 @@ def pointnet_rowmlp_fwd_deform(B, N, ori, central, perturb, sigma, adv, inv_den,
 
 
 def pointnet_rowmlp_bwd(stage, B, N, dg, idx, W3r, A2, W2r, out, gmask=None, A1=None, W1r=None, H1=None, dH1in=None,
-                        W0r=None, T=None, x=None, dPin=None, dTpart=None, pres_in=None, pres_out=None, mode=0, overflow=None):
+                        W0r=None, T=None, x=None, dPin=None, dTpart=None, pres_in=None, pres_out=None, mode=0, overflow=None,
+                        words=1):
     """``pres_in`` / ``pres_out``: int64 [B, tiles, words] row-presence bit sets handed from stage to stage (see hitadv.h,
     ``pointnet_rowmlp_bwd_tiles``);
-    ``mode`` 1: the products on the fp16 matrix cores, two pieces per operand; ``overflow``: int32 [B, tiles] scratch, needed
-    when the mode's tiles have two words."""
-    if overflow is None and pointnet_rowmlp_bwd_tiles(N, mode)[1] > 1:
-        overflow = torch.empty(B, pointnet_rowmlp_bwd_tiles(N, mode)[0], device=dg.device, dtype=torch.int32)
+    ``mode`` 1: the products on the fp16 matrix cores, two pieces per operand; ``words``: 64-point words per block (the tables'
+    last dimension); ``overflow``: int32 [B, tiles] scratch, needed with two words."""
+    if overflow is None and words > 1:
+        overflow = torch.empty(B, pointnet_rowmlp_bwd_tiles(B, N, mode, words)[0], device=dg.device, dtype=torch.int32)
     _lib.call("hitadv_pointnet_rowmlp_bwd", stage, _p(dg), _p(gmask), _p(idx), _p(W3r), W3r.shape[0], _p(A2), _p(W2r),
               _p(A1), _p(W1r), _p(H1), _p(dH1in), _p(W0r), _p(T), _p(x), _p(dPin), _p(dTpart), _p(out), _p(pres_in),
-              _p(pres_out), _p(overflow), B, N, int(mode), _stream())
+              _p(pres_out), _p(overflow), int(words), B, N, int(mode), _stream())
 
 
 def pointnet_rowmlp_tiles(N):
     return int(_lib.load().hitadv_pointnet_rowmlp_tiles(N))
 
 
-def pointnet_rowmlp_bwd_tiles(N, mode=0):
-    """(tiles, words): a block of ``pointnet_rowmlp_bwd`` covers ``words`` 64-point words of a cloud; the per-tile partials are
-    [B, tiles, .] and the row-presence tables int64 [B, tiles, words] (include/hitadv.h)."""
+def pointnet_rowmlp_bwd_tiles(B, N, mode=0, words=None):
+    """(tiles, words): a block of ``pointnet_rowmlp_bwd`` covers ``words`` 64-point words of a cloud (None: what the library
+    recommends for this launch size); the per-tile partials are [B, tiles, .] and the row-presence tables int64
+    [B, tiles, words] (include/hitadv.h)."""
     lib = _lib.load()
-    return int(lib.hitadv_pointnet_rowmlp_bwd_tiles(N, int(mode))), int(lib.hitadv_pointnet_rowmlp_bwd_words(int(mode)))
+    if words is None:
+        words = int(lib.hitadv_pointnet_rowmlp_bwd_words(int(B), int(N), int(mode)))
+    return int(lib.hitadv_pointnet_rowmlp_bwd_tiles(int(N), int(words))), int(words)
 
 
 class EdgeMax(torch.autograd.Function):

@@ -370,19 +370,20 @@ int64_t hitadv_pointnet_rowmlp_tiles(int N);
  * pres_in [B,tiles] is the previous stage's pres_out and says which rows of dH1in (stage 1) / dPin (stage 0) are
  * non-zero -- stage 2 writes ONLY the rows of dH1 in its pres_out, and stage 1 reads dH1in only at pres_in rows.
  * pres_in == NULL: every row of the incoming gradient may be non-zero (dense behaviour; dH1in fully defined).
- * "tiles" here = hitadv_pointnet_rowmlp_bwd_tiles(N, mode): a backward block covers W = hitadv_pointnet_rowmlp_bwd_words(mode)
- * 64-point words (2 in the fp16 modes: the work is set by the ~10 of 64 points that receive gradient, so the larger tile halves
- * the number of latency-bound blocks; 1 in mode 0), and pres_in / pres_out are [B,tiles,W] (one bit set per word).
- * overflow: int32 [B,tiles] scratch, required when W = 2 (may be NULL otherwise): the compacted rows of a tile live in
+ * "tiles" here = hitadv_pointnet_rowmlp_bwd_tiles(N, words): a backward block covers `words` 64-point words (1 or 2; mode 0:
+ * 1).  The work of a block is set by the ~10 of 64 points that receive gradient, so the larger tile halves the number of
+ * latency-bound blocks; hitadv_pointnet_rowmlp_bwd_words(B, N, mode) recommends 2 where one word would be more than one round
+ * of blocks on the chip.  pres_in / pres_out are [B,tiles,words] (one bit set per word: the same 64-bit words in both forms).
+ * overflow: int32 [B,tiles] scratch, required when words = 2 (may be NULL otherwise): the compacted rows of a tile live in
  * 64-row LDS tiles, so a two-word tile with more than 64 winning points is marked there by the first of the entry point's
  * two launches and taken word by word by the second (which returns at once for every other tile). */
-int64_t hitadv_pointnet_rowmlp_bwd_tiles(int N, int mode);
-int hitadv_pointnet_rowmlp_bwd_words(int mode);
+int64_t hitadv_pointnet_rowmlp_bwd_tiles(int N, int words);
+int hitadv_pointnet_rowmlp_bwd_words(int B, int N, int mode);
 int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const float *gmask, const int64_t *idx, const float *W3r,
                                int Cout, const float *A2, const float *W2r, const float *A1, const float *W1r,
                                const float *H1, const float *dH1in, const float *W0r, const float *T, const float *x,
                                const float *dPin, float *dTpart, float *out, const uint64_t *pres_in,
-                               uint64_t *pres_out, int32_t *overflow, int B, int N, int mode, void *stream);
+                               uint64_t *pres_out, int32_t *overflow, int words, int B, int N, int mode, void *stream);
 /* out[b,m] = (extra ? extra[b,m] : 0) + sum_t part[b,t,m], ascending t. */
 int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out, void *stream);
 /* out[B,NOUT] = act(in'[B,K] @ Wt[K,NOUT] + bias), in' = in gated by (mask > 0) when mask != NULL (the backward of a

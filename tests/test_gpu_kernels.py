@@ -1565,16 +1565,16 @@ def test_rowmlp_bwd_two_word_tiles_and_their_overflow_path(A, pattern):
     T64, T3, x, dPin = rnd(B, 64, 64) * 0.1, rnd(B, 9), rnd(B, 3, N), rnd(B, 3, N)
 
     def run(mode):
-        tiles, words = A.pointnet_rowmlp_bwd_tiles(N, mode)
+        tiles, words = A.pointnet_rowmlp_bwd_tiles(B, N, mode, words=2 if mode else 1)
         pres2 = torch.zeros(B, tiles, words, device=dev, dtype=torch.int64)
         pres1 = torch.zeros(B, tiles, words, device=dev, dtype=torch.int64)
         dT64, dT3 = torch.full((B, tiles, 4096), float('nan'), device=dev), torch.full((B, tiles, 9), float('nan'), device=dev)
         dH1 = torch.zeros(R, 64, device=dev)
         dPts, dX = torch.full((B, 3, N), float('nan'), device=dev), torch.full((B, 3, N), float('nan'), device=dev)
-        A.pointnet_rowmlp_bwd(2, B, N, dg, idx, W3r, A2, W2r, dH1, H1=H1, T=T64, dTpart=dT64, pres_out=pres2, mode=mode)
+        A.pointnet_rowmlp_bwd(2, B, N, dg, idx, W3r, A2, W2r, dH1, H1=H1, T=T64, dTpart=dT64, pres_out=pres2, mode=mode, words=words)
         A.pointnet_rowmlp_bwd(1, B, N, dg, idx, W3r, A2, W2r, dPts, gmask=gmask, A1=A1, W1r=W1r, H1=H1, dH1in=dH1, W0r=W0r,
-                              T=T3, x=x, dTpart=dT3, pres_in=pres2, pres_out=pres1, mode=mode)
-        A.pointnet_rowmlp_bwd(0, B, N, dg, idx, W3r, A2, W2r, dX, gmask=gmask, A1=A1, W0r=W0r, dPin=dPts, pres_in=pres1, mode=mode)
+                              T=T3, x=x, dTpart=dT3, pres_in=pres2, pres_out=pres1, mode=mode, words=words)
+        A.pointnet_rowmlp_bwd(0, B, N, dg, idx, W3r, A2, W2r, dX, gmask=gmask, A1=A1, W0r=W0r, dPin=dPts, pres_in=pres1, mode=mode, words=words)
         torch.cuda.synchronize()
         return dict(dH1=dH1, dT64=dT64.sum(1), dT3=dT3.sum(1), dPts=dPts, dX=dX, pres2=pres2.reshape(B, -1), pres1=pres1.reshape(B, -1),
                     words=words)

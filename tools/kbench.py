@@ -175,12 +175,12 @@ def main():
         for mode, tag in ((0, '_f32'), (1, '_fp16x2')):
             us = timed(lambda s=s0: lib.hitadv_pointnet_rowmlp_bwd(0, p(dgs), p(gm), p(jj), p(view.s3_wr), 1024, p(a2s),
                                                                    p(view.s2_wr), p(a1s), None, None, None, p(view.s1_wr),
-                                                                   None, None, p(dpin), None, p(dx), None, None, p(over), B, N, mode, s),
+                                                                   None, None, p(dpin), None, p(dx), None, None, p(over), 1, B, N, mode, s),
                        a.reps)
             out['rowmlp_bwd0_' + name + '_dense_rows' + tag] = dict(us=round(us, 2))
             us = timed(lambda s=s0: lib.hitadv_pointnet_rowmlp_bwd(0, p(dgs), p(gm), p(jj), p(view.s3_wr), 1024, p(a2s),
                                                                    p(view.s2_wr), p(a1s), None, None, None, p(view.s1_wr),
-                                                                   None, None, p(dpin), None, p(dx), p(pres), None, p(over), B, N, mode, s),
+                                                                   None, None, p(dpin), None, p(dx), p(pres), None, p(over), 1, B, N, mode, s),
                        a.reps)
             out['rowmlp_bwd0_' + name + tag] = dict(us=round(us, 2))
     for mode, tag in ((0, '_f32'), (1, '_fp16x2')):
