@@ -40,6 +40,9 @@ struct AdamTail {
   AdamArgs adam;
 };
 
+// threads per block of deform_bwd (one per centre): whole waves, at most four -- C = 192 on 256 threads left a wave idle
+static inline int deform_bwd_width(int C) { return C >= 256 ? 256 : 64 * ((C + 63) / 64); }
+
 __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
                                                   const float *__restrict__ central,
                                                   const float *perturb,  // (no __restrict__: the Adam tail writes them)
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
   const int cnt = min(DB_PTS, N - n0);
   // the thread's centre is requested together with the slab's points, not after the barrier behind them (one global round
   // trip instead of two); threads past C read centre C-1 and leave before they would write
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // blockDim.x = the centres rounded up to whole waves, at most 256
   const int jc = min(j, C - 1);
   const float *cp = central + (size_t)b * 3 * C + jc;
   const float cx = cp[0], cy = cp[C], cz = cp[2 * C];
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
     __hip_atomic_store(out + 3 * C, asg / (s * s * s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!handoff_last_arriver(tail.tickets, b, nslab * (int)gridDim.x, &s_last)) return;
-  for (int jj = threadIdx.x; jj < C; jj += 256) adam_partials_body<true>(tail.adam, b, jj);
+  for (int jj = threadIdx.x; jj < C; jj += blockDim.x) adam_partials_body<true>(tail.adam, b, jj);
   if (threadIdx.x == 0) __hip_atomic_store(&tail.tickets[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void deform_bwd_reduce(const float *__restrict
                                                          int nslab, float *__restrict__ grad_perturb,
                                                          float *__restrict__ grad_sigma) {
   const int b = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // blockDim.x = the centres rounded up to whole waves, at most 256
   if (j >= C) return;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   for (int s = 0; s < nslab; ++s) {
@@ -185,8 +188,9 @@ extern "C" int hitadv_deform_bwd_partials(const float *ori, const float *central
   if (!ori || !central || !perturb || !sigma || !adv || !inv_den || !g_adv || !partials || B <= 0 || N <= 0 || C <= 0)
     return HITADV_E_ARG;
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
-  dim3 grid((C + 255) / 256, nslab, B);
-  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{}, AdamTail{});
+  const int bw = deform_bwd_width(C);
+  dim3 grid((C + bw - 1) / bw, nslab, B);
+  deform_bwd<<<grid, bw, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{}, AdamTail{});
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -201,8 +205,9 @@ extern "C" int hitadv_deform_bwd_partials_reg(const float *ori, const float *cen
   const float *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
   const RegGrad rg{per_cloud, scal, nullptr, cd_w, 0.f, 0.f, 0.f, 0.f, B};
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
-  dim3 grid((C + 255) / 256, nslab, B);
-  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials, rg, AdamTail{});
+  const int bw = deform_bwd_width(C);
+  dim3 grid((C + bw - 1) / bw, nslab, B);
+  deform_bwd<<<grid, bw, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials, rg, AdamTail{});
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -217,8 +222,9 @@ extern "C" int hitadv_deform_bwd_partials_reg_stack(int G, const float *ori, con
   const float *per_cloud = reg_scratch + (size_t)B * RG_NPART, *scal = per_cloud + (size_t)B * 8;
   const RegGrad rg{per_cloud, scal, nullptr, cd_w, 0.f, 0.f, 0.f, 0.f, B};
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
-  dim3 grid((C + 255) / 256, nslab, G * B);
-  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials, rg, AdamTail{});
+  const int bw = deform_bwd_width(C);
+  dim3 grid((C + bw - 1) / bw, nslab, G * B);
+  deform_bwd<<<grid, bw, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials, rg, AdamTail{});
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -240,8 +246,9 @@ extern "C" int hitadv_deform_bwd_adam_reg(const float *ori, const float *central
   const AdamTail tail{tickets, AdamArgs{perturb, sigma, partials, nslab, nullptr, nullptr, m_perturb, v_perturb, m_sigma,
                                         v_sigma, B, C, lr_perturb, lo_perturb, hi_perturb, lr_sigma, lo_sigma, hi_sigma, step,
                                         rg}};
-  dim3 grid((C + 255) / 256, nslab, B);
-  deform_bwd<<<grid, 256, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials,
+  const int bw = deform_bwd_width(C);
+  dim3 grid((C + bw - 1) / bw, nslab, B);
+  deform_bwd<<<grid, bw, 0, (hipStream_t)stream>>>(ori, central, perturb, sigma, adv, inv_den, g_victim, N, C, nslab, partials,
                                                     rg_adv, tail);
   HITADV_LAUNCH_CHECK();
   return 0;
@@ -256,8 +263,9 @@ extern "C" int hitadv_deform_bwd(const float *ori, const float *central, const f
     return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nslab = (N + DB_PTS - 1) / DB_PTS;
-  dim3 grid((C + 255) / 256, nslab, B);
-  deform_bwd<<<grid, 256, 0, s>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{}, AdamTail{});
+  const int bw = deform_bwd_width(C);
+  dim3 grid((C + bw - 1) / bw, nslab, B);
+  deform_bwd<<<grid, bw, 0, s>>>(ori, central, perturb, sigma, adv, inv_den, g_adv, N, C, nslab, partials, RegGrad{}, AdamTail{});
   dim3 grid2((C + 255) / 256, B);
   deform_bwd_reduce<<<grid2, 256, 0, s>>>(partials, C, nslab, grad_perturb, grad_sigma);
   HITADV_LAUNCH_CHECK();
