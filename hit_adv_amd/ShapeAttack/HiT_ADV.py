@@ -694,7 +694,8 @@ class HiT_ADV:
         """attack_many through stacks of ``per_stack`` attacks: every stack on its own stream, its victim passes merged."""
         B, K = batches[0][0].shape[:2]
         dev = torch.device('cuda', torch.cuda.current_device())
-        sizes = [min(per_stack, len(batches) - i) for i in range(0, len(batches), per_stack)]
+        from .. import stack_sizes
+        sizes = stack_sizes(len(batches), per_stack)
         rng_before = torch.get_rng_state()  # the setups below draw from the global CPU generator
         stacks, i = [], 0
         for n, G in enumerate(sizes):

@@ -108,3 +108,22 @@ def test_driver_under_torchrun_matches_the_plain_run(tmp_path):
     a, b = _last_json(plain.stdout), _last_json(launched.stdout)
     for k in ('ASR', 'knn', 'uniform', 'curv_std', 'clean_correct', 'batches'):
         assert a[k] == b[k], k
+
+
+def test_groups_and_stacks_are_balanced():
+    """How pending batches are cut into groups of attacks in flight and a group into stacks (hit_adv_amd/__init__.py): balanced
+    where the victim passes stack (a short last group leaves streams idle), round 2's rule where every attack has a stream."""
+    import hit_adv_amd as H
+    assert H.groups_in_flight(20, 12) == [10, 10] and H.groups_in_flight(24, 12) == [12, 12] and H.groups_in_flight(13, 12) == [7, 6]
+    assert H.groups_in_flight(5, 12) == [5] and H.groups_in_flight(0, 12) == []
+    assert H.groups_in_flight(7, 4, stacked=False) == [4, 2, 1] and H.groups_in_flight(8, 4, stacked=False) == [4, 4]
+    for n in range(1, 30):
+        for inf in (1, 4, 12):
+            for st in (True, False):
+                g = H.groups_in_flight(n, inf, stacked=st)
+                assert sum(g) == n and max(g) <= inf and min(g) >= 1
+        for per in (1, 3, 4, 8):
+            s = H.stack_sizes(n, per)
+            assert sum(s) == n and max(s) - min(s) <= 1 and max(s) <= max(per, -(-n // 3))
+    assert H.stack_sizes(12, 4) == [4, 4, 4] and H.stack_sizes(10, 4) == [4, 3, 3] and H.stack_sizes(8, 4) == [3, 3, 2]
+    assert H.stack_sizes(4, 4) == [4] and H.stack_sizes(3, 4) == [3] and H.stack_sizes(3, 2) == [2, 1]
