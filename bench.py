@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md, HBM3E spec peak
 F32_MFMA_PEAK = 157.3   # TFLOP/s, dense f32-input MFMA (= the f32 vector peak), same guide
 
 CONFIGS = {
-    'cfg2': dict(victim='pointnet', B=32, N=1024, classes=40, attack='hit_adv', steps=24, warmup=12, concurrent=12,
+    'cfg2': dict(victim='pointnet', B=32, N=1024, classes=40, attack='hit_adv', steps=24, warmup=12, concurrent=24,
                  metric="attacked point-clouds/sec (HiT-ADV, PointNet, N=1024, 500 iters)",
                  workload="cfg2: synthetic ModelNet40-shaped clouds, 1024 pts, batch 32 per GPU, PointNet victim (random "
                           "init, eval mode), HiT-ADV eval.py hyper-parameters, num_iter=500 x binary_step=10 = 5000 inner "
@@ -765,7 +765,7 @@ def main():
     run, prewarm, info, iters_per_step = make_runner(cfg, model, dev, concurrent)
     nbatch = warmup + steps
     extra = 2 if (args.config == 'cfg2' and not args.no_single and world == 1) else 0
-    extra_f32 = concurrent if (extra and matrix_mode in ('bf16x3', 'fp16x2') and not args.no_f32) else 0
+    extra_f32 = min(concurrent, 12) if (extra and matrix_mode in ('bf16x3', 'fp16x2') and not args.no_f32) else 0  # one group of twelve
     batches = []
     for s in range(nbatch + extra + extra_f32 + 1):  # every (rank, step) attacks distinct clouds; all resident in HBM up front
         data, _ = synth((rank * (nbatch + extra + extra_f32 + 1) + s) * B, B, N)

@@ -76,8 +76,8 @@ def parse_args(argv=None):
                    help='attack this many batches of synthetic clouds instead of a dataset; a missing checkpoint then '
                         'means a seeded random-init victim')
     p.add_argument('--synthetic_kind', type=str, default='gaussian', choices=['gaussian', 'sphere'])
-    p.add_argument('--in_flight', type=int, default=12,
-                   help='attack() calls kept in flight per GPU (1 = one at a time; 12 = three stacks of four merged victim '
+    p.add_argument('--in_flight', type=int, default=24,
+                   help='attack() calls kept in flight per GPU (1 = one at a time; 24 = three stacks of eight merged victim '
                         'passes on 8 hardware queues measured best on the PointNet engine; victims whose passes do not '
                         'stack -- DGCNN, PointNet++, PCT -- are capped at 4: one stream and one set of activations each)')
     p.add_argument('--metric_k', type=int, default=None,

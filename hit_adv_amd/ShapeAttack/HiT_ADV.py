@@ -132,8 +132,10 @@ class _StackCaptureFailed(Exception):
         self.reason, self.rng_state = reason, None
 
 
-# attacks per stack in attack_many (0 / 1: no stacking, one stream per attack as before); tuning knob
-_STACK = int(os.environ.get("HITADV_STACK", "4"))
+# attacks per stack in attack_many (0 / 1: no stacking, one stream per attack as before); tuning knob.  Round 4, with balanced
+# stacks and round-robin launches: three stacks of 4 / 5 / 6 / 7 / 8 / 10 / 12 attacks -> 47.8 / 48.4 / 48.7 / 49.6 / 49.8-50.4 / 49.8 /
+# 49.9 clouds/s (profiles/r04_sweeps.txt): eight, i.e. twenty-four attacks in flight.
+_STACK = int(os.environ.get("HITADV_STACK", "8"))
 # workgroups of the PointNet engine's 128 -> 1024 kernel while three or more attacks share the GPU (tuning knob; see attack_many)
 _V1_BLOCKS_IN_FLIGHT = int(os.environ.get("HITADV_V1_BLOCKS_IN_FLIGHT", "128"))
 

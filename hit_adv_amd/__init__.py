@@ -54,11 +54,11 @@ def hardware_queues():
 
 
 def attacks_in_flight(requested):
-    """How many independent attacks to hand to ``attack_many`` at a time: ``requested``, capped at 8 (two stacks of four on
-    two streams) when the process has only the runtime's 4 hardware queues -- three streams on four shared queues serialise
-    again (12 in flight: 30.3 clouds/s on 4 queues, 37.4 on 8; 8 in flight on 4 queues: 35.5)."""
+    """How many independent attacks to hand to ``attack_many`` at a time: ``requested``, capped at 16 (two stacks of eight on
+    two streams, ``stack_sizes``) when the process has only the runtime's 4 hardware queues -- three streams on four shared
+    queues serialise again (round 3, 12 in flight: 30.3 clouds/s on 4 queues, 37.4 on 8; 8 in flight on 4 queues: 35.5)."""
     requested = max(1, int(requested))
-    return requested if hardware_queues() >= 8 else min(requested, 8)
+    return requested if hardware_queues() >= 8 else min(requested, 16)
 
 
 def groups_in_flight(pending, in_flight, stacked=True):
@@ -83,11 +83,11 @@ def groups_in_flight(pending, in_flight, stacked=True):
 
 def stack_sizes(attacks, per_stack):
     """How ``attacks`` stacked attacks of one group are cut into stacks (one stream each): as few stacks as ``per_stack``
-    allows, but three from six attacks on (eight as 3 + 3 + 2 on three streams: 46.9 clouds/s, as 4 + 4 on two: 45.9), and
-    balanced (ten as 4 + 3 + 3)."""
+    allows, but three from six attacks on (eight as 3 + 3 + 2 on three streams: 46.9 clouds/s, as 4 + 4 on two: 45.9) where the
+    runtime has the hardware queues for three streams, and balanced (ten as 4 + 3 + 3, twenty as 7 + 7 + 6)."""
     attacks, per_stack = int(attacks), max(1, int(per_stack))
     stacks = -(-attacks // per_stack)
-    if attacks >= 6:
+    if attacks >= 6 and hardware_queues() >= 8:
         stacks = max(stacks, 3)
     return [attacks // stacks + (1 if i < attacks % stacks else 0) for i in range(stacks)]
 

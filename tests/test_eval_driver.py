@@ -114,6 +114,7 @@ def test_groups_and_stacks_are_balanced():
     """How pending batches are cut into groups of attacks in flight and a group into stacks (hit_adv_amd/__init__.py): balanced
     where the victim passes stack (a short last group leaves streams idle), round 2's rule where every attack has a stream."""
     import hit_adv_amd as H
+    assert H.hardware_queues() >= 8  # (importing the package puts GPU_MAX_HW_QUEUES=8 in place on a process that has not started the runtime)
     assert H.groups_in_flight(20, 12) == [10, 10] and H.groups_in_flight(24, 12) == [12, 12] and H.groups_in_flight(13, 12) == [7, 6]
     assert H.groups_in_flight(5, 12) == [5] and H.groups_in_flight(0, 12) == []
     assert H.groups_in_flight(7, 4, stacked=False) == [4, 2, 1] and H.groups_in_flight(8, 4, stacked=False) == [4, 4]
