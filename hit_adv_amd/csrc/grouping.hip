@@ -520,7 +520,13 @@ namespace hitadv {
 __global__ __launch_bounds__(256) void group_add_relu_fwd_k(const float *__restrict__ U, const float *__restrict__ V,
                                                             const int64_t *__restrict__ idx, int N, int S, int ns, int C,
                                                             float *__restrict__ H, long long total4) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, i, s, c4)
+  // Workgroup ids go round the eight XCDs (id mod 8), each with an L2 of its own: in launch order every cloud's blocks land
+  // on all eight and U[b] is fetched eight times (PMC, cfg4 shape: 190 MB of reads for 50 MB of operands,
+  // profiles/r04_kbench_traffic.json).  With the ids of one XCD mapped to a contiguous eighth of the work a cloud's gathers
+  // stay in one L2.
+  long long blk = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) blk = (long long)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long long e = blk * 256 + threadIdx.x;  // (b, i, s, c4)
   if (e >= total4) return;
   const int c4n = C >> 2;
   const int c4 = (int)(e % c4n);

@@ -16,10 +16,10 @@ for w in $WHAT; do
     bench_cfg3|bench_cfg4|bench_cfg5)
       c=${w#bench_}
       timeout 1200 python bench.py --config $c > $OUT/bench_$c.log 2>&1; tail -1 $OUT/bench_$c.log > $OUT/bench_line_$c.json ;;
-    prof_headline)  # the configuration the headline runs: twelve attacks in flight as three stacks of four, eight hardware queues
+    prof_headline)  # the configuration the headline runs: twenty-four attacks in flight as three stacks of eight, eight hardware queues
       rm -rf /tmp/prof/hl
       GPU_MAX_HW_QUEUES=8 timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/hl -- \
-        python3 bench.py --steps 12 --warmup 0 --no-cpu-baseline --no-single --no-f32 --no-other-configs > $OUT/prof_headline.log 2>&1
+        python3 bench.py --steps 24 --warmup 0 --no-cpu-baseline --no-single --no-f32 --no-other-configs > $OUT/prof_headline.log 2>&1
       f=$(find /tmp/prof/hl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/cfg2_headline_kernel_stats.csv
       tail -1 $OUT/prof_headline.log > $OUT/prof_line_headline.json ;;
     prof_c4)  # four attacks in flight, one stream each (round 2's headline configuration; HITADV_STACK=1 switches the stacking off)
