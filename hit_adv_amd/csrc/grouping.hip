@@ -519,13 +519,21 @@ namespace hitadv {
 
 __global__ __launch_bounds__(256) void group_add_relu_fwd_k(const float *__restrict__ U, const float *__restrict__ V,
                                                             const int64_t *__restrict__ idx, int N, int S, int ns, int C,
-                                                            float *__restrict__ H, long long total4) {
+                                                            float *__restrict__ H, long long total4, int xcd_order,
+                                                            int blocks_per_cloud) {
   // Workgroup ids go round the eight XCDs (id mod 8), each with an L2 of its own: in launch order every cloud's blocks land
-  // on all eight and U[b] is fetched eight times (PMC, cfg4 shape: 190 MB of reads for 50 MB of operands,
-  // profiles/r04_kbench_traffic.json).  With the ids of one XCD mapped to a contiguous eighth of the work a cloud's gathers
-  // stay in one L2.
+  // on all eight and U[b] is fetched eight times (PMC, cfg4 shape: 190 MB of reads for 50 MB of operands).  xcd_order 1: the
+  // ids of one XCD take a contiguous eighth of the work; 2: XCD x takes the clouds b = x mod 8 (blocks_per_cloud > 0), so
+  // that the eight XCDs write into eight CONSECUTIVE clouds at any time.  0: launch order -- the one shipped: both XCD-local
+  // orders bring the traffic to 1.00x algorithmic and the kernel from 94.9 / 74.4 us to 101-102 / 96-101 us (cfg4 / cfg5 shape;
+  // docs/kernels/round4.md section 6): it is bound by its writes, which launch order spreads over adjacent addresses.
   long long blk = blockIdx.x;
-  if ((gridDim.x & 7u) == 0u) blk = (long long)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (xcd_order == 1 && (gridDim.x & 7u) == 0u) {
+    blk = (long long)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  } else if (xcd_order == 2 && blocks_per_cloud > 0) {
+    const long long q = blockIdx.x >> 3, x = blockIdx.x & 7u;  // q-th block of XCD x
+    blk = (q % blocks_per_cloud) + (long long)blocks_per_cloud * (8 * (q / blocks_per_cloud) + x);
+  }
   const long long e = blk * 256 + threadIdx.x;  // (b, i, s, c4)
   if (e >= total4) return;
   const int c4n = C >> 2;
@@ -628,8 +636,15 @@ extern "C" int hitadv_group_add_relu_fwd(const float *U, const float *V, const i
       (((uintptr_t)U | (uintptr_t)V | (uintptr_t)H) & 15))
     return HITADV_E_ARG;
   const long long total4 = (long long)B * S * ns * (C >> 2);
+  static const int want = [] { const char *e = getenv("HITADV_GAR_XCD"); return e ? atoi(e) : 0; }();  // tuning knob, see the kernel
+  const long long per_cloud4 = (long long)S * ns * (C >> 2);
+  int order = want, bpc = 0;
+  if (order == 2) {
+    if ((per_cloud4 & 255) == 0 && (B & 7) == 0) bpc = (int)(per_cloud4 >> 8);
+    else order = 0;
+  }
   hitadv::group_add_relu_fwd_k<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(U, V, idx, N, S, ns, C, H,
-                                                                                              total4);
+                                                                                              total4, order, bpc);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
