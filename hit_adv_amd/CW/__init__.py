@@ -45,8 +45,11 @@ def attack_concurrently(calls):
                 return True
 
     try:
-        for i, st in enumerate(streams):  # setups first, one after the other: draws in sequence order, captures undisturbed
+        for i, st in enumerate(streams):  # setups first, one after the other: draws in sequence order ...
             st.wait_stream(here)
+            advance(i, ('probed',))
+        torch.cuda.synchronize()
+        for i in range(len(gens)):        # ... then the captures, with no eager victim work after any of them
             advance(i, ('ready',))
         # the loops: the host queues one binary step of one attack and goes on to the next attack (launching a captured PCT
         # iteration costs the host 0.85 ms against ~4 ms of GPU time: tools/graph_launch_cost.py); going round by binary

@@ -108,7 +108,7 @@ class _CWFamily:
         ``num_iter`` times per binary step when nothing in it needs the host (util/graph_loop.py).
 
         A generator with stops (``util/graph_loop.py::drive`` runs it through; ``CW.attack_concurrently`` interleaves
-        several): ``'ready'`` when every random number of the attack has been drawn -- in the reference's order: per binary
+        several): ``'probed'`` after the eager probing passes, ``'ready'`` when every random number of the attack has been drawn -- in the reference's order: per binary
         step the jitter, then the victim's FPS starts pass by pass, last the pass that counts the successes --, uploaded, and
         the iteration is captured; ``'turn'`` every ``TURN`` queued iterations; ``'enqueued'`` when everything is queued on
         the attack's stream and the next thing is the host reading results back."""
@@ -219,7 +219,10 @@ class _CWFamily:
             starts.append(self._victim.draw(per_step))
         last_starts = self._victim.draw(1)
         self._victim.put_all(starts + [last_starts])  # one upload, here: none inside the loop (it would hold the host)
-        if loop.probe():
+        capturable = loop.probe()
+        yield 'probed'  # a driver of several attacks runs EVERY attack's eager probing passes before ANY capture: on this stack a
+        #                 replay that follows eager victim work issued after a capture can fault
+        if capturable:
             start_search()
             if spectral:
                 with torch.no_grad():

@@ -97,7 +97,9 @@ class CWKNN:
         self._victim.open_feed(B, K, self.num_iter + 1, dev)  # a sampling victim's draws, device-resident
         starts = self._victim.draw(self.num_iter + 1)  # drawn where the reference's first forward pass would start drawing
         self._victim.put_all([starts])
-        if loop.probe():
+        capturable = loop.probe()
+        yield 'probed'  # (every attack's eager passes before any capture: CW/_family.py)
+        if capturable:
             reset()
             loop.capture()
         yield 'ready'
