@@ -56,6 +56,9 @@ PROTOTYPES = {
     "hitadv_gemm_f16x2_supported": [_I, _I],
     "hitadv_bmm_f32_supported": [_I, _I, _I],
     "hitadv_bmm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hitadv_offset_attention_supported": [_I],
+    "hitadv_offset_attention_fwd": [_P, _I, _I, _P, _P, _P],
+    "hitadv_offset_attention_bwd": [_P, _P, _P, _I, _I, _P, _P, _P],
     "hitadv_group_linear_max_g16_supported": [_I, _I, _I],
     "hitadv_group_linear_max_g16_fwd": [_P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_group_linear_max_g16_bwd": [_P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],

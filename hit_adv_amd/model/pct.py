@@ -108,8 +108,8 @@ class SA_Layer(nn.Module):
         """The same layer on points-major x [B,N,C] (eval mode on the GPU): the 1x1 convolutions are GEMMs over B*N rows,
         the attention products take their transposes through the BLAS flags -- no permuted copies in either direction."""
         q = linear_pm(self.q_conv, None, x)  # q_conv and k_conv share their weight (:116): one product serves both
-        attention = self.softmax(ops.bmm(q, q, False, True))  # q q^T: the tiled batched kernel (csrc/bmm.hip)
-        attention = attention / (1e-9 + attention.sum(dim=1, keepdim=True))
+        # q q^T: the tiled batched kernel (csrc/bmm.hip); softmax + column renormalisation: csrc/attention.hip
+        attention = ops.offset_attention_norm(ops.bmm(q, q, False, True))
         x_r = ops.bmm(attention, linear_pm(self.v_conv, None, x), True, False)  # attention^T v
         return x + linear_relu_pm(self.trans_conv, self.after_norm, x - x_r)
 

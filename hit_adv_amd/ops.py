@@ -977,6 +977,40 @@ def bmm(a, b, trans_a=False, trans_b=False):
     return torch.bmm(a.transpose(1, 2) if trans_a else a, b.transpose(1, 2) if trans_b else b)
 
 
+class OffsetAttentionNorm(torch.autograd.Function):
+    """PCT's offset attention between its two batched products (model/pct_cls.py:127-131): ``softmax(E, -1)`` followed by the
+    column renormalisation ``A / (1e-9 + A.sum(dim=1, keepdim=True))`` -- two launches forward and two backward instead of
+    torch's four and nine element-wise passes (csrc/attention.hip)."""
+
+    @staticmethod
+    def forward(ctx, E):
+        E = _dev(E, "E").contiguous()
+        B, N, _ = E.shape
+        A = torch.empty_like(E)
+        c = torch.empty(B, N, device=E.device)
+        _lib.call("hitadv_offset_attention_fwd", _p(E), B, N, _p(A), _p(c), _stream())
+        ctx.save_for_backward(A, c)
+        return A
+
+    @staticmethod
+    def backward(ctx, dA):
+        A, c = ctx.saved_tensors
+        B, N, _ = A.shape
+        dA = dA.contiguous()
+        dE, h = torch.empty_like(A), torch.empty_like(c)
+        _lib.call("hitadv_offset_attention_bwd", _p(dA), _p(A), _p(c), B, N, _p(h), _p(dE), _stream())
+        return dE
+
+
+def offset_attention_norm(E):
+    """``A = softmax(E, -1); A / (1e-9 + A.sum(1, keepdim=True))`` for E [B,N,N] (fused where N allows, else torch's ops)."""
+    if (E.is_cuda and E.dtype == torch.float32 and E.dim() == 3 and E.shape[1] == E.shape[2]
+            and bool(_lib.load().hitadv_offset_attention_supported(int(E.shape[2])))):
+        return OffsetAttentionNorm.apply(E)
+    A = torch.softmax(E, dim=-1)
+    return A / (1e-9 + A.sum(dim=1, keepdim=True))
+
+
 def gemm_f16x2_supported(N, K):
     """Whether ``gemm_f16x2`` / ``linear_lrelu_pool`` are built for N output columns over a K-deep contraction."""
     return bool(_lib.load().hitadv_gemm_f16x2_supported(int(N), int(K)))

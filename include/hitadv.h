@@ -578,6 +578,15 @@ int hitadv_bmm_f32_supported(int M, int N, int K);
 int hitadv_bmm_f32(const float *A, const float *B, float *C, int batches, int M, int N, int K, int trans_a, int trans_b,
                    void *stream);
 
+/* PCT's offset attention between its two batched products (model/pct_cls.py:127-131):
+ *   A = softmax(E, dim=-1);  A = A / (1e-9 + A.sum(dim=1, keepdim=True))        E, A [B,N,N], colsum [B,N] = the sums
+ * forward in two launches, backward (dE from dA, A, colsum; h [B,N] scratch) in two, every reduction in a fixed order.
+ * torch: four element-wise passes forward, nine backward.  N a multiple of 64, N <= 1024. */
+int hitadv_offset_attention_supported(int N);
+int hitadv_offset_attention_fwd(const float *E, int B, int N, float *A, float *colsum, void *stream);
+int hitadv_offset_attention_bwd(const float *dA, const float *A, const float *colsum, int B, int N, float *h, float *dE,
+                                void *stream);
+
 /* G independent attacks STACKED (HiT_ADV.attack_many on the PointNet engine: one victim pass over the G*B clouds): the three
  * launches around that pass for all G groups at once.  Every per-cloud argument is the group-0 pointer of a buffer that
  * holds the G groups' rows one after the other (B clouds each); every per-group scalar or scratch likewise, with the stride

@@ -1589,3 +1589,28 @@ def test_rowmlp_bwd_two_word_tiles_and_their_overflow_path(A, pattern):
         close(a, b, rtol=1e-4, atol=2e-6 * float(b.abs().max()), what='rowmlp_bwd two-word tiles vs one-word f32 chain: %s (%s)' % (name, pattern))
     again = run(1)
     assert all(torch.equal(again[k], f16[k]) for k in ('dH1', 'dT64', 'dT3', 'dPts', 'dX'))  # bitwise reproducible
+
+
+@pytest.mark.parametrize("B,N", [(32, 256), (3, 64), (2, 1024), (5, 192)])
+def test_offset_attention_norm_matches_torch_composition(A, B, N):
+    """PCT's softmax + column renormalisation (model/pct_cls.py:127-131) as two launches each way against torch's own ops in
+    float64: values, the gradient of a random linear functional, bitwise reproducibility; widths outside the kernel's take
+    torch's ops."""
+    g = torch.Generator().manual_seed(N)
+    E = (torch.randn(B, N, N, generator=g) * 3).cuda().requires_grad_()
+    w = torch.randn(B, N, N, generator=g).cuda()
+    out = A.offset_attention_norm(E)
+    gE, = torch.autograd.grad((out * w).sum(), E)
+    Ed = E.detach().double().requires_grad_()
+    S = torch.softmax(Ed, dim=-1)
+    ref = S / (1e-9 + S.sum(dim=1, keepdim=True))
+    gR, = torch.autograd.grad((ref * w.double()).sum(), Ed)
+    close(out, ref.float(), rtol=1e-5, atol=1e-7, what='offset attention: normalised attention vs float64')
+    close(gE, gR.float(), rtol=1e-4, atol=2e-6 * float(gR.abs().max()), what='offset attention: dE vs float64 autograd')
+    close(out.sum(dim=1), (ref.sum(dim=1)).float(), rtol=1e-5, atol=1e-6)  # columns sum to one (up to the 1e-9)
+    out2 = A.offset_attention_norm(E)
+    g2, = torch.autograd.grad((out2 * w).sum(), E)
+    assert torch.equal(out2, out) and torch.equal(g2, gE)
+    odd = torch.randn(2, 100, 100, device='cuda')
+    S2 = torch.softmax(odd, dim=-1)
+    assert torch.equal(A.offset_attention_norm(odd), S2 / (1e-9 + S2.sum(dim=1, keepdim=True)))
