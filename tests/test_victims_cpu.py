@@ -79,3 +79,55 @@ def test_start_feed_serves_the_draws_a_live_victim_would_make():
         raise AssertionError("a feed drawn for another batch size must refuse")
     except RuntimeError:
         pass
+
+
+def test_degrade_on_fp16_range_runs_the_call_again_in_full_range_arithmetic():
+    """The decorator the attacks' entry points carry (model/_pointwise.py): a call that ends in ``Fp16RangeExceeded`` is made again
+    with the CPU generator rewound and every fp16x2 form off for its duration, one warning per process; a nested call (an attack
+    that calls another decorated entry point) is not wrapped twice; other exceptions pass through."""
+    import warnings
+
+    import pytest
+    import torch
+    from hit_adv_amd.model import _pointwise as PW
+    from hit_adv_amd.model.dgcnn import FoldedDGCNN
+    from hit_adv_amd.model.pointnet import FoldedPointNet
+
+    seen = []
+
+    class Attack:
+        @PW.degrade_on_fp16_range
+        def attack(self, fail_first):
+            draw = torch.rand(3)
+            seen.append((FoldedPointNet.matrix_mode, PW.FUSED_GROUP_MAX, PW.FUSED_EMBEDDING_POOL, FoldedDGCNN.fused_embedding, draw))
+            if fail_first and len(seen) == 1:
+                raise PW.Fp16RangeExceeded("an operand beyond fp16's range")
+            return self.inner()
+
+        @PW.degrade_on_fp16_range
+        def inner(self):
+            return FoldedPointNet.matrix_mode
+
+        @PW.degrade_on_fp16_range
+        def broken(self):
+            raise ValueError("not a range problem")
+
+    before = (FoldedPointNet.matrix_mode, PW.FUSED_GROUP_MAX, PW.FUSED_EMBEDDING_POOL, FoldedDGCNN.fused_embedding)
+    assert before == ('fp16x2', True, True, True)
+    PW._DEGRADE_WARNED = False
+    torch.manual_seed(3)
+    with pytest.warns(RuntimeWarning, match="fp32's range"):
+        out = Attack().attack(True)
+    assert out == 'bf16x3' and len(seen) == 2
+    assert seen[0][:4] == before and seen[1][:4] == ('bf16x3', False, False, False)
+    assert torch.equal(seen[0][4], seen[1][4])  # the second run took the same draws
+    assert (FoldedPointNet.matrix_mode, PW.FUSED_GROUP_MAX, PW.FUSED_EMBEDDING_POOL, FoldedDGCNN.fused_embedding) == before
+    del seen[:]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # a second occurrence degrades silently
+        assert Attack().attack(True) == 'bf16x3'
+        del seen[:]
+        assert Attack().attack(False) == 'fp16x2' and len(seen) == 1
+    with pytest.raises(ValueError):
+        Attack().broken()
+    assert PW._FULL_RANGE_DEPTH == 0
