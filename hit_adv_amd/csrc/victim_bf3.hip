@@ -27,6 +27,8 @@
 // and 1.9 GHz under this load are 26 us, the rest of that is the W load, the first tile and the tail.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "hitadv.h"
 
@@ -46,7 +48,11 @@ constexpr int B3_TM = 64;
 // that raises the caller's range flag (the engine then refuses the result; `matrix_mode = 'bf16x3'` has fp32's range).
 constexpr float F16X2_SCALE = 2048.f;  // 2^11
 
-template <int CIN, int MODE>
+// FLAT (chosen by the launcher when S == 1 and N is a multiple of 128, i.e. every tile is whole and a cloud is an even number
+// of them): the clouds of a workgroup are ONE stream of tiles -- they are contiguous in X --, the running maximum is finished
+// and started again every N / 64 tiles, and the tile pipeline is neither drained nor refilled at a cloud boundary (3.3 us each
+// at N = 1024, tools/v1_bubble_probe.py).  The instantiation holds no ragged-tile or split-merge code at all.
+template <int CIN, int MODE, bool FLAT>
 __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restrict__ X, const uint16_t *__restrict__ W3,
                                                             int B_, int N, int Cout, int rows_per_split, int S, int ncg, int cpb,
                                                             float *pval, int32_t *pidx, const float *__restrict__ bias,
@@ -78,10 +84,13 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col0 = cg * 256 + wave * 32;
   const bool active = col0 < Cout;  // wave-uniform
-  const int n0 = s * rows_per_split, n1 = min(N, n0 + rows_per_split);
-  const int ntiles = (n1 - n0 + B3_TM - 1) / B3_TM;
   const float *const X0 = X;
   const int b0 = b * cpb;  // this block's first cloud: it takes cpb of them one after the other with the same W in registers
+  const int nb = min(cpb, B_ - b0);
+  const int n0 = FLAT ? 0 : s * rows_per_split;  // rows of a pass, relative to its X
+  const int n1 = FLAT ? nb * N : min(N, n0 + rows_per_split);
+  const int ntiles = (n1 - n0 + B3_TM - 1) / B3_TM;
+  int tbase = 0;  // FLAT: the stream's tile number of the current cloud's first tile
 
   // B operand of slice j (32 values of k), column tile ct (16 columns), piece p: the lane's column 16 ct + lane % 16,
   // k = 32 j + 8 (lane / 16) .. + 7.  W3 is stored in fragment order [piece][16-column block][slice][lane] x 16 bytes, so
@@ -104,25 +113,42 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   float4 stA[ST][2], stB[ST][2];
   // fetch() only issues the loads (rows past the split read a valid address); the first instruction that touches the
   // loaded registers is in stash(), a whole tile later -- a select here would make the wave wait for HBM among its MFMAs.
-  auto fetch = [&](float4 (&st)[ST][2], int tile) {
+  uint32_t soff[ST];
 #pragma unroll
-    for (int u = 0; u < ST; ++u) {
-      const int e = threadIdx.x + 512 * u;
-      const int n = n0 + tile * B3_TM + e / G8;
-      const float *sp = n < n1 ? X + (size_t)n * CIN + 8 * (e % G8) : X;
-      st[u][0] = *reinterpret_cast<const float4 *>(sp);
-      st[u][1] = *reinterpret_cast<const float4 *>(sp + 4);
+  for (int u = 0; u < ST; ++u) {
+    const int e = threadIdx.x + 512 * u;
+    soff[u] = (uint32_t)((e / G8) * CIN + 8 * (e % G8)) * 4u;
+  }
+  auto fetch = [&](float4 (&st)[ST][2], int tile, auto full_c) {
+    if constexpr (decltype(full_c)::value) {
+      const char *tb = reinterpret_cast<const char *>(X) + (size_t)(n0 + tile * B3_TM) * CIN * 4;
+#pragma unroll
+      for (int u = 0; u < ST; ++u) {
+        st[u][0] = *reinterpret_cast<const float4 *>(tb + soff[u]);
+        st[u][1] = *reinterpret_cast<const float4 *>(tb + soff[u] + 16);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < ST; ++u) {
+        const int e = threadIdx.x + 512 * u;
+        const int n = n0 + tile * B3_TM + e / G8;
+        const float *sp = n < n1 ? X + (size_t)n * CIN + 8 * (e % G8) : X;
+        st[u][0] = *reinterpret_cast<const float4 *>(sp);
+        st[u][1] = *reinterpret_cast<const float4 *>(sp + 4);
+      }
     }
   };
-  auto stash = [&](const float4 (&st)[ST][2], int tile) {
+  auto stash = [&](const float4 (&st)[ST][2], int tile, auto full_c) {
     const int buf = tile & 1;
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
-      const bool in = n0 + tile * B3_TM + e / G8 < n1;  // rows past the split are zero in LDS (and masked in the scan)
       float a[8] = {st[u][0].x, st[u][0].y, st[u][0].z, st[u][0].w, st[u][1].x, st[u][1].y, st[u][1].z, st[u][1].w};
+      if constexpr (!decltype(full_c)::value) {
+        const bool in = n0 + tile * B3_TM + e / G8 < n1;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] = in ? a[i] : 0.f;
+        for (int i = 0; i < 8; ++i) a[i] = in ? a[i] : 0.f;
+      }
       char *dst = sB3 + (size_t)buf * NP * PIECE + (e / G8) * RS + 16 * (e % G8);
       if constexpr (MODE == 2) {
         // X holds one word per value, (fp16 hi | fp16 lo << 16), written by the layer in front (csrc/pointnet.hip, pack_o2): two
@@ -176,9 +202,9 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   const bool late = wave >= 4;  // wave-uniform
   // one tile: 8 units of (slice j, row-tile pair rp): 6 A fragments (2 row tiles x 3 pieces) feed 24 MFMAs; the next
   // unit's fragments are read from LDS while this unit's MFMAs run.  Then the scan.
-  auto compute = [&](int tile) {
+  constexpr int NL = MODE >= 1 ? 4 : 1;  // fp16x2: accl collects the 2^-11 terms
+  auto products = [&](int tile, f32x4b (&acc)[4][2], f32x4b (&accl)[NL][2]) {
     const char *base = sB3 + (size_t)(tile & 1) * NP * PIECE + l16 * RS + 16 * g4;
-    f32x4b acc[4][2], accl[MODE >= 1 ? 4 : 1][2];  // fp16x2: accl collects the 2^-11 terms
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -240,9 +266,9 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
               acc[2 * rp + x][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[x][PA[t]], b[ct][PB[t]], acc[2 * rp + x][ct], 0, 0, 0);
       }
     }
-    // running (max, first arg-max) per channel: a tile-local best with an inline-constant code (4 rt + i: ascending points),
-    // joined with the tile number once
-    const bool ragged = n0 + (tile + 1) * B3_TM > n1;  // wave-uniform: only a split's last tile can be ragged
+  };
+  auto scan = [&](int tile, const f32x4b (&acc)[4][2], const f32x4b (&accl)[NL][2], auto full_c) {
+    constexpr bool ragged = !decltype(full_c)::value;
     const int row0 = n0 + tile * B3_TM + 4 * g4;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -254,72 +280,105 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
         for (int i = 0; i < 4; ++i) {
           float v = acc[rt][ct][i];
           if constexpr (MODE >= 1) v = fmaf(accl[rt][ct][i], 1.f / F16X2_SCALE, v);  // the two powers of two meet
-          if (ragged) v = row0 + 16 * rt + i < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
+          if constexpr (ragged) v = row0 + 16 * rt + i < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
           const bool g = v > tv;
           tv = g ? v : tv;
           tc = g ? 4 * rt + i : tc;
         }
       const bool g = tv > bv[ct];  // earlier tiles hold earlier points: they keep ties
       bv[ct] = g ? tv : bv[ct];
-      bi[ct] = g ? tile * 16 + tc : bi[ct];
+      bi[ct] = g ? (FLAT ? tile - tbase : tile) * 16 + tc : bi[ct];
     }
   };
-  // tile t: stA holds tile t+1 (loaded during tile t-1), tile t+2 is requested into stB; the sets swap every tile
-  auto step = [&](int tile, float4 (&have)[ST][2], float4 (&next)[ST][2]) {
-    const bool more = tile + 1 < ntiles;
-    if (tile + 2 < ntiles) fetch(next, tile + 2);
-    if (more && late) stash(have, tile + 1);
-    if (active) compute(tile);
-    if (more && !late) stash(have, tile + 1);
+  using Full = std::true_type;
+  using Ragged = std::false_type;
+  const int nfull = (n1 - n0) / B3_TM;
+  auto compute = [&](int tile, auto full_c) {
+    f32x4b acc[4][2], accl[NL][2];
+    products(tile, acc, accl);
+    scan(tile, acc, accl, full_c);
+  };
+  auto steady = [&](int tile, float4 (&have)[ST][2], float4 (&next)[ST][2]) {
+    // FLAT runs every tile through here: past the end of the stream the last tile is fetched (and written to the LDS buffer
+    // nobody reads any more) again
+    fetch(next, FLAT ? min(tile + 2, ntiles - 1) : tile + 2, Full{});
+    if (late) stash(have, tile + 1, Full{});
+    if (active) compute(tile, Full{});
+    if (!late) stash(have, tile + 1, Full{});
     __syncthreads();
   };
-  for (int bb = 0; bb < cpb && b0 + bb < B_; ++bb) {
-  b = b0 + bb;
-  X = X0 + (size_t)b * N * CIN;
-  bv[0] = bv[1] = -__builtin_inff();
-  bi[0] = bi[1] = -1;
-  if (bb > 0) __syncthreads();  // the previous cloud's last tile is no longer being read
-  fetch(stA, 0);
-  // every load issued so far (W, tile 0) completes HERE, explicitly: the first use of W is inside the loop, and a load that
-  // may still be pending at the loop entry makes the compiler's wait-count pass guard every in-loop use of W with a
-  // vmcnt wait that, on the iterations that did issue new loads, waits for THOSE (measured: tools/tune/v1bf3)
-  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-  stash(stA, 0);
-  if (ntiles > 1) fetch(stA, 1);
-  __syncthreads();
-  for (int tile = 0; tile < ntiles; tile += 2) {
-    step(tile, stA, stB);
-    if (tile + 1 < ntiles) step(tile + 1, stB, stA);
-  }
-  // code -> point index; nothing won (all rows -inf): the split's first point.  The four 16-lane groups of the wave hold
-  // the same channels, other points: two exchanges, the lower point keeps a tie.
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    bi[ct] = bi[ct] < 0 ? n0 : n0 + (bi[ct] >> 4) * B3_TM + 16 * ((bi[ct] >> 2) & 3) + 4 * g4 + (bi[ct] & 3);
-#pragma unroll
-    for (int m = 16; m <= 32; m <<= 1) {
-      const float ov = __shfl_xor(bv[ct], m, HITADV_WAVE);
-      const int oi = __shfl_xor(bi[ct], m, HITADV_WAVE);
-      if (ov > bv[ct] || (ov == bv[ct] && oi < bi[ct])) { bv[ct] = ov; bi[ct] = oi; }
-    }
-  }
-  if (active && g4 == 0) {
+  auto step = [&](int tile, float4 (&have)[ST][2], float4 (&next)[ST][2]) {
+    if (tile + 2 < nfull) return steady(tile, have, next);
+    const bool more = tile + 1 < ntiles;
+    if (tile + 2 < ntiles) fetch(next, tile + 2, Ragged{});
+    if (more && late) stash(have, tile + 1, Ragged{});
+    if (active) compute(tile, Ragged{});  // (the bounds tests also pass every row of a whole tile)
+    if (more && !late) stash(have, tile + 1, Ragged{});
+    __syncthreads();
+  };
+  // a cloud's (split's) last tile has been scanned: code -> point index (nothing won -- all rows -inf --: the pass's first
+  // point); the four 16-lane groups of the wave hold the same channels, other points: two exchanges, the lower point keeps
+  // a tie; then the result (S == 1) or this split's partial leaves, and the running maximum starts again
+  auto finish = [&]() {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const int c = col0 + 16 * ct + l16;
-      if (S == 1) {  // nothing to merge: finish here
-        float v = bv[ct] + (bias ? bias[c] : 0.f);  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
-        out[(size_t)b * Cout + c] = relu ? (v > 0.f ? v : 0.f) : v;  // max and ReLU commute
-        idx[(size_t)b * Cout + c] = bi[ct];
-      } else {
-        const size_t o = ((size_t)b * S + s) * Cout + c;
-        __hip_atomic_store(&pval[o], bv[ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&pidx[o], bi[ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bi[ct] = bi[ct] < 0 ? n0 : n0 + (bi[ct] >> 4) * B3_TM + 16 * ((bi[ct] >> 2) & 3) + 4 * g4 + (bi[ct] & 3);
+#pragma unroll
+      for (int m = 16; m <= 32; m <<= 1) {
+        const float ov = __shfl_xor(bv[ct], m, HITADV_WAVE);
+        const int oi = __shfl_xor(bi[ct], m, HITADV_WAVE);
+        if (ov > bv[ct] || (ov == bv[ct] && oi < bi[ct])) { bv[ct] = ov; bi[ct] = oi; }
       }
     }
-  }
-  }  // clouds of this block
-  if (S == 1) return;
+    if (active && g4 == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int c = col0 + 16 * ct + l16;
+        if (FLAT || S == 1) {  // nothing to merge: finish here
+          float v = bv[ct] + (bias ? bias[c] : 0.f);  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
+          out[(size_t)b * Cout + c] = relu ? (v > 0.f ? v : 0.f) : v;  // max and ReLU commute
+          idx[(size_t)b * Cout + c] = bi[ct];
+        } else {
+          const size_t o = ((size_t)b * S + s) * Cout + c;
+          __hip_atomic_store(&pval[o], bv[ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&pidx[o], bi[ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    bv[0] = bv[1] = -__builtin_inff();
+    bi[0] = bi[1] = -1;
+  };
+  for (int bb = 0; bb < (FLAT ? 1 : nb); ++bb) {
+    b = b0 + bb;  // the pass's first cloud
+    X = X0 + (size_t)b * N * CIN;
+    if (bb > 0) __syncthreads();  // the previous cloud's last tile is no longer being read
+    fetch(stA, 0, Ragged{});
+    // every load issued so far (W, tile 0) completes HERE, explicitly: the first use of W is inside the loop, and a load that
+    // may still be pending at the loop entry makes the compiler's wait-count pass guard every in-loop use of W with a
+    // vmcnt wait that, on the iterations that did issue new loads, waits for THOSE (measured: tools/tune/v1bf3)
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    stash(stA, 0, Ragged{});
+    if (ntiles > 1) fetch(stA, 1, Ragged{});
+    __syncthreads();
+    if constexpr (FLAT) {
+      const int tpc = N / B3_TM;  // even
+      for (tbase = 0; tbase < ntiles; tbase += tpc, ++b) {
+        for (int t = tbase; t < tbase + tpc; t += 2) {
+          steady(t, stA, stB);
+          steady(t + 1, stB, stA);
+        }
+        finish();
+      }
+    } else {
+      for (int tile = 0; tile < ntiles; tile += 2) {
+        step(tile, stA, stB);
+        if (tile + 1 < ntiles) step(tile + 1, stB, stA);
+      }
+      finish();
+    }
+  }  // passes of this block
+  if (FLAT || S == 1) return;
+  b = b0;  // (S > 1: one cloud per block)
   // The S splits of a (cloud, column group) meet here: the last block to draw the group's ticket merges the partials in
   // split order (= ascending points, so ties keep the first point).  Hand-off protocol of fc_layer_k (csrc/pointnet.hip).
   __shared__ int s_last;
@@ -455,15 +514,21 @@ static int launch_linear_max_pieces(const float *X, const uint16_t *W3, const fl
   dim3 grid((unsigned)(ncg * S * ((B + cpb - 1) / cpb)));
   constexpr int NP = MODE >= 1 ? 2 : 3;
   const size_t shm = (size_t)2 * NP * B3_TM * (2 * Cin + 32);
+  const bool flat = S == 1 && N % (2 * B3_TM) == 0;  // whole tiles, an even number per cloud: one stream of tiles per workgroup
+#define HITADV_V1_LAUNCH(CIN_, FLAT_)                                                                                          \
+  do {                                                                                                                         \
+    HITADV_RAISE_LDS((&linear_max_fwd_bf3_k<CIN_, MODE, FLAT_>), 2 * NP * B3_TM * (2 * CIN_ + 32));                            \
+    linear_max_fwd_bf3_k<CIN_, MODE, FLAT_><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx,   \
+                                                                   bias, relu, out, idx, tickets, range_flag);                 \
+  } while (0)
   if (Cin == 128) {
-    HITADV_RAISE_LDS((&linear_max_fwd_bf3_k<128, MODE>), 2 * NP * B3_TM * (2 * 128 + 32));
-    linear_max_fwd_bf3_k<128, MODE><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out,
-                                                           idx, tickets, range_flag);
+    if (flat) HITADV_V1_LAUNCH(128, true);
+    else HITADV_V1_LAUNCH(128, false);
   } else {
-    HITADV_RAISE_LDS((&linear_max_fwd_bf3_k<64, MODE>), 2 * NP * B3_TM * (2 * 64 + 32));
-    linear_max_fwd_bf3_k<64, MODE><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias, relu, out,
-                                                          idx, tickets, range_flag);
+    if (flat) HITADV_V1_LAUNCH(64, true);
+    else HITADV_V1_LAUNCH(64, false);
   }
+#undef HITADV_V1_LAUNCH
   HITADV_LAUNCH_CHECK();
   return 0;
 }
