@@ -48,6 +48,15 @@ constexpr int B3_TM = 64;
 // that raises the caller's range flag (the engine then refuses the result; `matrix_mode = 'bf16x3'` has fp32's range).
 constexpr float F16X2_SCALE = 2048.f;  // 2^11
 
+// Two compares into SGPR pairs / two selects on SGPR pairs, as written (see the scan of linear_max_fwd_bf3_k).
+__device__ __forceinline__ void v1_cmp2(unsigned long long &ma, unsigned long long &mb, float a, float ta, float b, float tb) {
+  asm volatile("v_cmp_eq_f32_e64 %0, %2, %3\n\tv_cmp_eq_f32_e64 %1, %4, %5" : "=s"(ma), "=s"(mb) : "v"(a), "v"(ta), "v"(b), "v"(tb));
+}
+template <int Q>
+__device__ __forceinline__ void v1_sel2(int &ca, int &cb, unsigned long long ma, unsigned long long mb) {
+  asm volatile("v_cndmask_b32_e64 %0, %0, %4, %2\n\tv_cndmask_b32_e64 %1, %1, %4, %3" : "+v"(ca), "+v"(cb) : "s"(ma), "s"(mb), "n"(Q));
+}
+
 // FLAT (chosen by the launcher when S == 1 and N is a multiple of 128, i.e. every tile is whole and a cloud is an even number
 // of them): the clouds of a workgroup are ONE stream of tiles -- they are contiguous in X --, the running maximum is finished
 // and started again every N / 64 tiles, and the tile pipeline is neither drained nor refilled at a cloud boundary (3.3 us each
@@ -270,24 +279,59 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   auto scan = [&](int tile, const f32x4b (&acc)[4][2], const f32x4b (&accl)[NL][2], auto full_c) {
     constexpr bool ragged = !decltype(full_c)::value;
     const int row0 = n0 + tile * B3_TM + 4 * g4;
+    // the tile's maximum first (v_max3: half an instruction per value, no dependent compare / select chain), then the FIRST of
+    // the 16 values equal to it -- the same (value, point) as a running strict ">" scan keeps.  The two channels' searches are
+    // written interleaved and pinned in front of their use: left to itself the compiler moves each into a branch of its own
+    // (taken whenever any lane improves, i.e. always) where every compare -> select pair waits out its hazard alone.
+    float v[2][16], tv[2];
+    int tc[2] = {15, 15};
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      float tv = -__builtin_inff();
-      int tc = 0;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float v = acc[rt][ct][i];
-          if constexpr (MODE >= 1) v = fmaf(accl[rt][ct][i], 1.f / F16X2_SCALE, v);  // the two powers of two meet
-          if constexpr (ragged) v = row0 + 16 * rt + i < n1 ? v : -__builtin_inff();  // zero-filled rows stay out
-          const bool g = v > tv;
-          tv = g ? v : tv;
-          tc = g ? 4 * rt + i : tc;
+          float y = acc[rt][ct][i];
+          if constexpr (MODE >= 1) y = fmaf(accl[rt][ct][i], 1.f / F16X2_SCALE, y);  // the two powers of two meet
+          if constexpr (ragged) y = row0 + 16 * rt + i < n1 ? y : -__builtin_inff();  // zero-filled rows stay out
+          v[ct][4 * rt + i] = y;
         }
-      const bool g = tv > bv[ct];  // earlier tiles hold earlier points: they keep ties
-      bv[ct] = g ? tv : bv[ct];
-      bi[ct] = g ? (FLAT ? tile - tbase : tile) * 16 + tc : bi[ct];
+      tv[ct] = -__builtin_inff();
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) tv[ct] = __builtin_fmaxf(__builtin_fmaxf(tv[ct], v[ct][q]), v[ct][q + 1]);
+    }
+    // tc = v[q] == tv ? q : tc for q = 14 .. 0, written out: the compiler sends every compare through VCC and pays the
+    // compare -> select hazard (2 wait states) thirty times per tile; here the compares run two steps ahead of the selects in
+    // four SGPR pairs, so each result is five instructions old when it is read.
+    {
+      unsigned long long m0, m1, m2, m3;
+      v1_cmp2(m0, m1, v[0][14], tv[0], v[1][14], tv[1]);
+      v1_cmp2(m2, m3, v[0][13], tv[0], v[1][13], tv[1]);
+#define HITADV_STEP(q, a, b)         \
+  v1_sel2<q>(tc[0], tc[1], a, b);    \
+  v1_cmp2(a, b, v[0][q - 2], tv[0], v[1][q - 2], tv[1])
+      HITADV_STEP(14, m0, m1);
+      HITADV_STEP(13, m2, m3);
+      HITADV_STEP(12, m0, m1);
+      HITADV_STEP(11, m2, m3);
+      HITADV_STEP(10, m0, m1);
+      HITADV_STEP(9, m2, m3);
+      HITADV_STEP(8, m0, m1);
+      HITADV_STEP(7, m2, m3);
+      HITADV_STEP(6, m0, m1);
+      HITADV_STEP(5, m2, m3);
+      HITADV_STEP(4, m0, m1);
+      HITADV_STEP(3, m2, m3);
+      HITADV_STEP(2, m0, m1);
+#undef HITADV_STEP
+      v1_sel2<1>(tc[0], tc[1], m2, m3);
+      v1_sel2<0>(tc[0], tc[1], m0, m1);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const bool g = tv[ct] > bv[ct];  // earlier tiles hold earlier points: they keep ties
+      bv[ct] = g ? tv[ct] : bv[ct];
+      bi[ct] = g ? (FLAT ? tile - tbase : tile) * 16 + tc[ct] : bi[ct];
     }
   };
   using Full = std::true_type;
