@@ -265,21 +265,29 @@ constexpr float PM_SC = 2048.f;   // 2^11
 constexpr int PM_LH64 = 144;      // bytes per row of a 64-wide fp16 piece tile
 constexpr int PM_LH128 = 272;
 
+// The residual as ONE fused multiply-add with the fp16 piece as a half-precision source operand (v_fma_mix*): 2048 v is
+// exact, hi (-2048) + 2048 v = 2048 (v - hi) is exact before its single rounding to fp16 -- the same bits as converting hi
+// back, subtracting, scaling and converting (five instructions per value; the splits were a quarter of the backward kernels'
+// vector instructions).
 __device__ __forceinline__ void split_pair(float v, _Float16 &hi, _Float16 &lo) {
   hi = (_Float16)v;
-  lo = (_Float16)((v - (float)hi) * PM_SC);
+  lo = (_Float16)__builtin_fmaf((float)hi, -PM_SC, v * PM_SC);
 }
+// eight values: the hi pieces two per v_cvt_pk_f16_f32, the lo pieces written into the halves of their words by
+// v_fma_mixlo / mixhi reading the packed hi pieces in place (2.5 instructions per value; the compiler's own form converts every
+// hi piece twice, once alone for the residual and once packed)
 __device__ __forceinline__ void split8v(const float (&v)[8], uint4 &hi, uint4 &lo) {
-  h8v a, b;
+  uint32_t H[4], L[4];
+  const float nsc = -PM_SC;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    _Float16 x, y;
-    split_pair(v[i], x, y);
-    a[i] = x;
-    b[i] = y;
+  for (int p = 0; p < 4; ++p) {
+    const float s0 = v[2 * p] * PM_SC, s1 = v[2 * p + 1] * PM_SC;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H[p]) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s1));
   }
-  hi = __builtin_bit_cast(uint4, a);
-  lo = __builtin_bit_cast(uint4, b);
+  hi = make_uint4(H[0], H[1], H[2], H[3]);
+  lo = make_uint4(L[0], L[1], L[2], L[3]);
 }
 // one value into the two piece tiles (row-major halves, row stride ld bytes)
 __device__ __forceinline__ void put_pieces(char *th, char *tl, int ld, int n, int c, float v) {
