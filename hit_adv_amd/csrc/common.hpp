@@ -121,6 +121,20 @@ struct RangeWatch {
   float nan_ = 0.f;
 };
 
+// The same watch on the fp16 hi pieces of a two-piece split, two per word: the split (and with it the product) breaks down
+// exactly when a hi piece is an infinity or a NaN, i.e. |a| >= 65520 or a not finite.  One AND and one packed 16-bit maximum
+// per PAIR of values.
+struct PieceWatch {
+  uint32_t m = 0u;
+  __device__ __forceinline__ void see_f16x2(uint32_t hi_pair) {
+    const uint32_t b = hi_pair & 0x7fff7fffu;
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(b), "v"(m));
+    m = r;
+  }
+  __device__ __forceinline__ bool beyond_fp16() const { return (m & 0xffffu) >= 0x7c00u || (m >> 16) >= 0x7c00u; }
+};
+
 // ---- an fp32 value as three bf16 pieces (csrc/victim_bf3.hip, csrc/knn.hip: fp32-accurate products on the bf16 MFMAs)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast(bf16x8, u); }

@@ -23,6 +23,8 @@
 //   Block order is XCD-aware: the column blocks that stream the same A rows are neighbours on one XCD (shared L2).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "hitadv.h"
 
@@ -74,8 +76,8 @@ struct PlainA {
       if constexpr (GATED) r.m[u] = *reinterpret_cast<const float4 *>(mask + o);
     }
   }
+  template <bool FULL>  // FULL: every row of the block exists (a type, not a test: see stash())
   __device__ __forceinline__ void values(const Regs &r, const G16Tile &t, int u, int tid, float (&o)[4]) const {
-    const bool in = (tid >> 3) + RSTEP * u < t.rows;
     o[0] = r.v[u].x, o[1] = r.v[u].y, o[2] = r.v[u].z, o[3] = r.v[u].w;
     if constexpr (GATED) {
       o[0] = r.m[u].x > 0.f ? o[0] : 0.f;
@@ -83,8 +85,11 @@ struct PlainA {
       o[2] = r.m[u].z > 0.f ? o[2] : 0.f;
       o[3] = r.m[u].w > 0.f ? o[3] : 0.f;
     }
+    if constexpr (!FULL) {
+      const bool in = (tid >> 3) + RSTEP * u < t.rows;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = in ? o[j] : 0.f;
+      for (int j = 0; j < 4; ++j) o[j] = in ? o[j] : 0.f;
+    }
   }
 };
 
@@ -114,9 +119,10 @@ struct PoolBwdA {
       r.w[u] = bits[(size_t)(t.row0 + rr) * (C / 32) + (k0 >> 5)];
     }
   }
+  template <bool FULL>
   __device__ __forceinline__ void values(const Regs &r, const G16Tile &t, int u, int tid, float (&o)[4]) const {
     const int rr = (tid >> 3) + RSTEP * u;
-    const bool in = rr < t.rows;
+    const bool in = FULL || rr < t.rows;
     const int p = t.p0 + rr;
     const uint32_t w = r.w[u] >> (4 * (tid & 7));
     const float gx[4] = {r.gx.x, r.gx.y, r.gx.z, r.gx.w}, gm[4] = {r.gm.x, r.gm.y, r.gm.z, r.gm.w};
@@ -150,6 +156,7 @@ struct GroupBwdA {
       r.a[u] = *reinterpret_cast<const int4 *>(arg + o);
     }
   }
+  template <bool FULL>
   __device__ __forceinline__ void values(const Regs &r, const G16Tile &t, int u, int tid, float (&o)[4]) const {
     const int j = (int)((t.row0 + (tid >> 3) + RSTEP * u) % NS);
     o[0] = r.a[u].x == j ? r.d[u].x : 0.f;
@@ -360,28 +367,39 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
       st.b[v][1] = *reinterpret_cast<const uint4 *>(bp + (size_t)N * K);
     }
   };
-  RangeWatch big;
-  auto stash = [&](const Set &st, int stage) {
+  PieceWatch big;
+  // A block whose 256 rows all exist (every block but a cloud's last) takes the FULL form: the compiler turns a run-time bounds
+  // test into a select per VALUE (csrc/victim_bf3.hip found the same), so the two forms are separate instantiations.
+  auto stash_as = [&](const Set &st, int stage, auto full_c) {
     char *base = sG16 + (size_t)stage * G16_STAGE;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       float a[4];
-      ap.values(st.a, t, u, tid, a);
-      f16x4m h1, h2;
+      ap.template values<decltype(full_c)::value>(st.a, t, u, tid, a);
+      uint2 h1, h2;
       if constexpr (ABL == 1) {  // no conversions: raw bits
-        h1 = __builtin_bit_cast(f16x4m, make_uint2(__float_as_uint(a[0]), __float_as_uint(a[1])));
-        h2 = __builtin_bit_cast(f16x4m, make_uint2(__float_as_uint(a[2]), __float_as_uint(a[3])));
+        h1 = make_uint2(__float_as_uint(a[0]), __float_as_uint(a[1]));
+        h2 = make_uint2(__float_as_uint(a[2]), __float_as_uint(a[3]));
       } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          h1[j] = (_Float16)a[j];
-          h2[j] = (_Float16)((a[j] - (float)h1[j]) * G16_SCALE);
-          big.see(a[j]);
-        }
+        // hi pieces two per v_cvt_pk_f16_f32; each lo piece ONE fused multiply-add on the packed hi piece read in place,
+        // hi (-2048) + 2048 a = 2048 (a - hi) exactly before its single rounding to fp16 (csrc/pointnet.hip::split8v: the same
+        // bits as convert / convert back / subtract / scale / convert, at half the instructions -- and on this part vector
+        // instructions are not hidden behind the matrix pipe).  The range watch looks at the hi pieces, two per instruction:
+        // the split breaks down exactly when a hi piece is an infinity or a NaN (|a| >= 65520).
+        const float nsc = -G16_SCALE;
+        const float s0 = a[0] * G16_SCALE, s1 = a[1] * G16_SCALE, s2 = a[2] * G16_SCALE, s3 = a[3] * G16_SCALE;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h1.x) : "v"(a[0]), "v"(a[1]));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h1.y) : "v"(a[2]), "v"(a[3]));
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(h2.x) : "v"(h1.x), "s"(nsc), "v"(s0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(h2.x) : "v"(h1.x), "s"(nsc), "v"(s1));
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(h2.y) : "v"(h1.y), "s"(nsc), "v"(s2));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(h2.y) : "v"(h1.y), "s"(nsc), "v"(s3));
+        big.see_f16x2(h1.x);
+        big.see_f16x2(h1.y);
       }
       char *dst = base + g16_off((tid >> 3) + (NT / 8) * u, (tid & 7) >> 1) + 8 * (tid & 1);
-      *reinterpret_cast<uint2 *>(dst) = __builtin_bit_cast(uint2, h1);
-      *reinterpret_cast<uint2 *>(dst + G16_APIECE) = __builtin_bit_cast(uint2, h2);
+      *reinterpret_cast<uint2 *>(dst) = h1;
+      *reinterpret_cast<uint2 *>(dst + G16_APIECE) = h2;
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -389,6 +407,11 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
       *reinterpret_cast<uint4 *>(bd) = st.b[v][0];
       *reinterpret_cast<uint4 *>(bd + G16_BPIECE) = st.b[v][1];
     }
+  };
+  const bool full = t.rows == G16_BM;  // block-uniform
+  auto stash = [&](const Set &st, int stage) {
+    if (full) stash_as(st, stage, std::true_type{});
+    else stash_as(st, stage, std::false_type{});
   };
 
   f32x4m acc[RT][4], accl[RT][4];
