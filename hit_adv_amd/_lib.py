@@ -102,6 +102,7 @@ PROTOTYPES = {
     "hitadv_pointnet_rowmlp_bwd": [_I, _P, _P, _P, _P, _I] + [_P] * 15 + [_I, _I, _I, _I, _P],
     "hitadv_sum_partials": [_P, _P, _I, _I, _I, _P, _P],
     "hitadv_knn_features": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "hitadv_row_sqnorm": [_P, _L, _I, _P, _P],
     "hitadv_edge_max_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "hitadv_edge_max_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _P],
     "hitadv_edge_max_bwd_scratch_ints": [_I, _I, _I],

@@ -1093,7 +1093,8 @@ def knn_features(x, K):
     (closest first, ties -> lower index); no [B,N,N] score matrix (hitadv_knn_features)."""
     x = _dev(x.detach(), "x")
     B, N, D = x.shape
-    xx = (x * x).sum(dim=2)
+    xx = torch.empty(B, N, device=x.device)
+    _lib.call("hitadv_row_sqnorm", _p(x), B * N, D, _p(xx), _stream())
     idx = torch.empty(B, N, K, device=x.device, dtype=torch.int64)
     _lib.call("hitadv_knn_features", _p(x), _p(xx), B, N, D, K, _p(idx), _stream())
     return idx

@@ -618,6 +618,9 @@ int hitadv_adam_step_partials_reg_stack(int G, float *perturb, float *sigma, con
  * per-lane sorted lists -- no [B,N,N] matrix.  X [B,N,D] points-major (D in {64,128}, 16-byte aligned), xx [B,N] = |x|^2,
  * K <= 20.  idx [B,N,K] int64, closest first (the point itself), ties -> lower index. */
 int hitadv_knn_features(const float *X, const float *xx, int B, int N, int D, int K, int64_t *idx, void *stream);
+/* xx[row] = sum_k X[row,k]^2 for X [rows,D] fp32 (D a multiple of 4, X 16-byte aligned), evaluated in a fixed order (the same
+ * bits every run): the squared norms hitadv_knn_features takes.  Host-side helper of model/dgcnn_cls.py:9 (`xx = torch.sum(x ** 2, ...)`). */
+int hitadv_row_sqnorm(const float *X, int64_t rows, int D, float *xx, void *stream);
 
 #ifdef __cplusplus
 }
