@@ -50,6 +50,8 @@ PROTOTYPES = {
     "hitadv_iteration_head_reg": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P,
                                   _P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "hitadv_group_linear_max_supported": [_I, _I, _I],
+    "hitadv_rows_linear_supported": [_I, _I],
+    "hitadv_rows_linear": [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P],
     "hitadv_group_linear_max_fwd": [_P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_group_linear_max_bwd": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P],
     "hitadv_group_linear_max_bwd_masked": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],

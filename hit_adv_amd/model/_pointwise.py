@@ -149,6 +149,24 @@ class _LinearReLUGatedLater(torch.autograd.Function):
         return g.contiguous() @ W, None, None
 
 
+class _RowsLinearReLUGatedLater(torch.autograd.Function):
+    """``_LinearReLUGatedLater`` on ``ops.rows_linear`` (csrc/rows_linear.hip): forward and input gradient of a narrow shared layer
+    over 0.5-1 M grouped rows are bound by their reads and writes, which the library's f32 GEMM moves at a third of the HBM rate."""
+
+    @staticmethod
+    def forward(ctx, x2, pieces, b, flag):
+        from .. import ops
+        ctx.back = (pieces[1], flag)
+        return ops.rows_linear(x2, pieces[0], b, True, flag)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        Wt2, flag = ctx.back
+        return ops.rows_linear(g.contiguous(), Wt2, None, False, flag), None, None, None
+
+
+FUSED_ROWS_LINEAR = True  # the middle shared layer of a sample-and-group block as ops.rows_linear (fp16x2) where its widths allow
 WEIGHT_GRADS = False  # True: the fused layers also return gradients for the (eval-mode) parameters
 
 
@@ -199,11 +217,11 @@ _FULL_RANGE_DEPTH = 0
 def full_range_arithmetic():
     """Every fp16x2 form off for the duration: PointNet's shared layers as three bf16 pieces (fp32's range, fp32-accurate),
     the fused group / embedding layers of the other victims as their f32 GEMM compositions."""
-    global FUSED_GROUP_MAX, FUSED_EMBEDDING_POOL, _FULL_RANGE_DEPTH
+    global FUSED_GROUP_MAX, FUSED_EMBEDDING_POOL, FUSED_ROWS_LINEAR, _FULL_RANGE_DEPTH
     from .dgcnn import FoldedDGCNN
     from .pointnet import FoldedPointNet
-    saved = (FUSED_GROUP_MAX, FUSED_EMBEDDING_POOL, FoldedPointNet.matrix_mode, FoldedDGCNN.fused_embedding)
-    FUSED_GROUP_MAX = FUSED_EMBEDDING_POOL = FoldedDGCNN.fused_embedding = False
+    saved = (FUSED_GROUP_MAX, FUSED_EMBEDDING_POOL, FoldedPointNet.matrix_mode, FoldedDGCNN.fused_embedding, FUSED_ROWS_LINEAR)
+    FUSED_GROUP_MAX = FUSED_EMBEDDING_POOL = FoldedDGCNN.fused_embedding = FUSED_ROWS_LINEAR = False
     if FoldedPointNet.matrix_mode == 'fp16x2':
         FoldedPointNet.matrix_mode = 'bf16x3'
     _FULL_RANGE_DEPTH += 1
@@ -211,7 +229,7 @@ def full_range_arithmetic():
         yield
     finally:
         _FULL_RANGE_DEPTH -= 1
-        FUSED_GROUP_MAX, FUSED_EMBEDDING_POOL, FoldedPointNet.matrix_mode, FoldedDGCNN.fused_embedding = saved
+        FUSED_GROUP_MAX, FUSED_EMBEDDING_POOL, FoldedPointNet.matrix_mode, FoldedDGCNN.fused_embedding, FUSED_ROWS_LINEAR = saved
 
 
 _DEGRADE_WARNED = False
@@ -270,8 +288,17 @@ def linear_relu_then_max_pm(conv_mid, bn_mid, conv, bn, x):
     Wm, bm = _folded(conv_mid, bn_mid)
     W, b = _folded(conv, bn)
     if bm is not None and _fused_group_max(conv, W, b, x) is not None:  # (only x's device and ns matter there)
-        y = _LinearReLUGatedLater.apply(x.reshape(-1, x.shape[-1]), Wm.detach(), bm.detach()).view(*x.shape[:-1], Wm.shape[0])
-        return linear_relu_max_pm(conv, bn, y, relu_input=True)
+        from .. import ops
+        x2 = x.reshape(-1, x.shape[-1])
+        pieces = None
+        if FUSED_ROWS_LINEAR and ops.rows_linear_supported(Wm.shape[1], Wm.shape[0]):
+            flag = range_flag(x.device)
+            pieces = _pieces(conv_mid, Wm, 'reg', lambda M: ops.split_weights_f16x2(M, range_flag=flag))
+        if pieces is not None:
+            y = _RowsLinearReLUGatedLater.apply(x2.contiguous(), pieces, bm.detach(), flag)
+        else:
+            y = _LinearReLUGatedLater.apply(x2, Wm.detach(), bm.detach())
+        return linear_relu_max_pm(conv, bn, y.view(*x.shape[:-1], Wm.shape[0]), relu_input=True)
     return linear_relu_max_pm(conv, bn, linear_relu_pm(conv_mid, bn_mid, x))
 
 

@@ -931,6 +931,21 @@ def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False, pieces=None
     return (out, arg.view(*lead, arg.shape[-1])) if return_arg else out
 
 
+def rows_linear_supported(Cin, Cout):
+    return bool(_lib.load().hitadv_rows_linear_supported(int(Cin), int(Cout)))
+
+
+def rows_linear(x2, W2, bias=None, relu=False, range_flag=None):
+    """act(x2 W^T + bias) for x2 [rows, Cin] (very many rows, Cin / Cout in {64, 128}) on the fp16 matrix cores at fp32 accuracy
+    (hitadv_rows_linear).  W2 = split_weights_f16x2(W [Cout, Cin]); no autograd (model/_pointwise.py wraps it)."""
+    x2 = _dev(x2, "x2")
+    rows, Cin = x2.shape
+    Cout = W2.shape[1]
+    y = torch.empty(rows, Cout, device=x2.device)
+    _lib.call("hitadv_rows_linear", _p(x2), _p(W2), _p(bias), rows, Cin, Cout, 1 if relu else 0, _p(y), _p(range_flag), _stream())
+    return y
+
+
 def bmm_supported(M, N, K):
     return bool(_lib.load().hitadv_bmm_f32_supported(int(M), int(N), int(K)))
 

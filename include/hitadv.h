@@ -520,6 +520,19 @@ int hitadv_adam_step_partials_reg(float *perturb, float *sigma, const float *par
  *        (the same layout with the roles of the two dimensions swapped); every row of dX is written.
  * range_flag as for hitadv_linear_max_fwd_f16x2 (may be NULL). */
 int hitadv_group_linear_max_supported(int Cin, int Cout, int ns);
+
+/* ---- rows_linear: Y[rows,Cout] = act(X[rows,Cin] W^T + bias) for very many rows of a narrow layer --------------------
+ * The middle shared layer of a sample-and-group block applied to the grouped rows (model/pointnet2_utils.py:197-201:
+ * `new_points = F.relu(bn(conv(new_points)))` on [B, C, nsample, npoint]; 0.5-1 M rows of 64 / 128 channels at cfg4) and, with the
+ * pieces of the transposed weights, no bias and relu = 0, its input gradient dX = dY W.  fp16x2 arithmetic (two fp16 pieces per
+ * operand, three exact products per useful one, fp32 accumulation: fp32-accurate), bound by the read of X and the write of Y.
+ *   X [rows,Cin] fp32, 16-byte aligned;  W2 = hitadv_split_weights_f16x2(W [Cout,Cin]);  bias [Cout] or NULL;  relu: 0 / 1;
+ *   Y [rows,Cout] fp32, 16-byte aligned;  range_flag: int32[1] on the device or NULL, raised (never cleared) when an entry of X is
+ *   not finite or too large for the split (|x| >= 65520).
+ * Supported: Cin, Cout in {64, 128} (hitadv_rows_linear_supported); anything else: HITADV_E_ARG. */
+int hitadv_rows_linear_supported(int Cin, int Cout);
+int hitadv_rows_linear(const float *X, const uint16_t *W2, const float *bias, int64_t rows, int Cin, int Cout, int relu, float *Y,
+                       int32_t *range_flag, void *stream);
 int hitadv_group_linear_max_fwd(const float *X, const uint16_t *W2, const float *bias, int64_t G, int ns, int Cin, int Cout,
                                 float *out, int32_t *arg, int32_t *range_flag, void *stream);
 int hitadv_group_linear_max_bwd(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2, int64_t G, int ns,

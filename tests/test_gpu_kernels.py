@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from helpers import close as _close
-from helpers import T, golden, synth_batch
+from helpers import T, golden, note, synth_batch
 from oracle import c_oracle as N
 from oracle import hitadv_oracle as O
 
@@ -880,6 +880,47 @@ def test_group_linear_max_forward_and_backward(A, G, ns, Cin, Cout):
     (om * cu(wgt)).sum().backward()
     assert torch.equal(om, out) and torch.equal(xm.grad, torch.where(xm.detach() > 0, xg.grad, torch.zeros_like(xg.grad)))
     assert float((x > 0).float().mean()) < 0.7
+
+
+@pytest.mark.parametrize("rows,Cin,Cout", [(64 * 41, 64, 64), (64 * 300 + 17, 128, 128), (5, 64, 128), (64 * 9 + 63, 128, 64),
+                                            (64 * 2500, 64, 64)])
+def test_rows_linear_is_fp32_accurate(A, rows, Cin, Cout):
+    """The middle shared layer of a sample-and-group block over very many rows (csrc/rows_linear.hip, fp16x2 arithmetic) against
+    float64: errors at fp32's roundoff, no worse than torch's f32 GEMM; whole and ragged last tiles, one and many blocks; with the
+    transposed pieces, no bias and no activation it is the layer's input gradient; the autograd node of model/_pointwise.py."""
+    g = torch.Generator().manual_seed(rows + Cin)
+    x = torch.randn(rows, Cin, generator=g).relu()
+    Wr = torch.randn(Cout, Cin, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g) * 0.3
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    W2, Wt2 = A.split_weights_f16x2(cu(Wr), range_flag=flag), A.split_weights_f16x2(cu(Wr.t().contiguous()), range_flag=flag)
+    assert A.rows_linear_supported(Cin, Cout)
+    y = A.rows_linear(cu(x), W2, cu(bias), True, flag)
+    ref = (x.double() @ Wr.double().t() + bias.double()).clamp_min(0.)
+    s = float(ref.abs().max())
+    e = float((y.cpu().double() - ref).abs().max()) / s
+    e32 = float((torch.relu(torch.nn.functional.linear(cu(x), cu(Wr), cu(bias))).cpu().double() - ref).abs().max()) / s
+    note('rows_linear %dx%d->%d: max error over the output scale (torch f32 GEMM: %.2e)' % (rows, Cin, Cout, e32), e)
+    assert e <= 2e-6 and e <= 2 * e32 + 1e-7
+    assert torch.equal(y, A.rows_linear(cu(x), W2, cu(bias), True, flag))  # the same bits every run
+    # input gradient of the layer: dX = dY W
+    gy = torch.randn(rows, Cout, generator=g)
+    dx = A.rows_linear(cu(gy), Wt2, None, False, flag)
+    rd = gy.double() @ Wr.double()
+    sd = float(rd.abs().max())
+    assert float((dx.cpu().double() - rd).abs().max()) / sd <= 2e-6
+    assert int(flag.item()) == 0
+    # the autograd node (the ReLU backward of this layer is left to its consumer: the gradient arrives gated)
+    from hit_adv_amd.model import _pointwise
+    xg = cu(x).requires_grad_()
+    yy = _pointwise._RowsLinearReLUGatedLater.apply(xg, (W2, Wt2), cu(bias), flag)
+    yy.backward(cu(gy))
+    assert torch.equal(yy, y) and torch.equal(xg.grad, dx)
+    # an entry beyond the split's range raises the flag (and only then)
+    xb = x.clone()
+    xb[rows // 2, 3] = 7e4
+    A.rows_linear(cu(xb), W2, cu(bias), True, flag)
+    assert int(flag.item()) == 1
 
 
 @pytest.mark.parametrize("G,ns,Cin,Cout", [(300, 32, 256, 256), (70, 64, 128, 384), (9, 32, 128, 128)])
