@@ -606,21 +606,63 @@ __global__ __launch_bounds__(64) void group_add_relu_du_k(const float *__restric
     const int cc = live ? c4 : 0;
     const float4 u = *reinterpret_cast<const float4 *>(U + ((size_t)(b * N + j)) * C + 4 * cc);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = seg.x; t < seg.y; ++t) {
-      const long long bi = b * S + cl[t];
-      const float4 v = *reinterpret_cast<const float4 *>(V + (size_t)bi * C + 4 * cc);
-      const bool mx = u.x + v.x > 0.f, my = u.y + v.y > 0.f, mz = u.z + v.z > 0.f, mw = u.w + v.w > 0.f;
-      for (int s0 = 0; s0 < ns; s0 += G) {
-        const long long mine = s0 + gl < ns ? idx[bi * ns + s0 + gl] : -1;
-        unsigned long long hit = (__ballot(mine == j) >> (grp * G)) & gmask;
-        while (hit) {
-          const int sl = s0 + __builtin_ctzll(hit);
-          hit &= hit - 1;
-          const float4 d = *reinterpret_cast<const float4 *>(dH + ((size_t)(bi * ns + sl)) * C + 4 * cc);
-          acc.x += mx ? d.x : 0.f;
-          acc.y += my ? d.y : 0.f;
-          acc.z += mz ? d.z : 0.f;
-          acc.w += mw ? d.w : 0.f;
+    // Four lists at a time: a list costs a chain of three dependent loads (its number, its entries, the gradient row of the
+    // matching slot), and the kernel is bound by those latencies.  The chains of four lists run side by side -- the list
+    // numbers, then their V rows and entries, then the rows of their FIRST matching slots -- while the additions keep their
+    // order (ascending list, ascending slot; the further slots of a list -- a ball query pads by repeating an entry -- are
+    // fetched where they are added).
+    constexpr int LB = 4, NCH = 64 / G;  // ns <= 64: at most 64 / G chunks of G entries per list
+    for (int t = seg.x; t < seg.y; t += LB) {
+      int li[LB];
+#pragma unroll
+      for (int q = 0; q < LB; ++q) li[q] = t + q < seg.y ? cl[t + q] : -1;
+      long long bi[LB];
+      float4 v[LB];
+      long long mine[LB][NCH];
+#pragma unroll
+      for (int q = 0; q < LB; ++q) {
+        bi[q] = b * S + max(li[q], 0);
+        v[q] = *reinterpret_cast<const float4 *>(V + (size_t)bi[q] * C + 4 * cc);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+          mine[q][ch] = (li[q] >= 0 && ch * G + gl < ns) ? idx[bi[q] * ns + ch * G + gl] : -1;  // -1 matches no target
+      }
+      unsigned long long hit[LB][NCH];
+      int first[LB];
+      float4 d0[LB];
+#pragma unroll
+      for (int q = 0; q < LB; ++q) {
+        first[q] = -1;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          hit[q][ch] = (__ballot(mine[q][ch] == j) >> (grp * G)) & gmask;  // (every lane of the group is here)
+          if (first[q] < 0 && hit[q][ch]) {
+            first[q] = ch * G + __builtin_ctzll(hit[q][ch]);
+            hit[q][ch] &= hit[q][ch] - 1;
+          }
+        }
+        d0[q] = *reinterpret_cast<const float4 *>(dH + ((size_t)(bi[q] * ns + max(first[q], 0))) * C + 4 * cc);
+      }
+#pragma unroll
+      for (int q = 0; q < LB; ++q) {
+        if (first[q] < 0) continue;  // group-uniform
+        const bool mx = u.x + v[q].x > 0.f, my = u.y + v[q].y > 0.f, mz = u.z + v[q].z > 0.f, mw = u.w + v[q].w > 0.f;
+        acc.x += mx ? d0[q].x : 0.f;
+        acc.y += my ? d0[q].y : 0.f;
+        acc.z += mz ? d0[q].z : 0.f;
+        acc.w += mw ? d0[q].w : 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          unsigned long long rest = hit[q][ch];
+          while (rest) {
+            const int sl = ch * G + __builtin_ctzll(rest);
+            rest &= rest - 1;
+            const float4 d = *reinterpret_cast<const float4 *>(dH + ((size_t)(bi[q] * ns + sl)) * C + 4 * cc);
+            acc.x += mx ? d.x : 0.f;
+            acc.y += my ? d.y : 0.f;
+            acc.z += mz ? d.z : 0.f;
+            acc.w += mw ? d.w : 0.f;
+          }
         }
       }
     }
