@@ -16,6 +16,8 @@
 // Error model: that of V1's fp16x2 form (two pieces per operand, products exact, terms below 2^-24 dropped).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "hitadv.h"
 
@@ -64,37 +66,65 @@ __global__ __launch_bounds__(512) void group_linear_max_fwd_k(const float *__res
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) bv[ct] = bias != nullptr ? bias[col0 + 16 * ct + l16] : 0.f;
 
-  float4 stA[ST][2], stB[ST][2];
-  auto fetch = [&](float4 (&st)[ST][2], int tile) {
+  // Whole tiles and the (possibly ragged) last one are separate instantiations of fetch / stash: a run-time bounds test becomes a
+  // select per VALUE, and on this part vector instructions are not hidden behind the matrix pipe (docs/kernels/round4.md section 8;
+  // csrc/victim_bf3.hip).  The split: hi pieces two per v_cvt_pk_f16_f32, each lo piece one v_fma_mixlo/hi on the packed hi piece
+  // (hi (-2048) + 2048 v is exact before its single rounding: the same bits as convert back / subtract / scale / convert); the
+  // range watch looks at the packed hi pieces (an infinity or a NaN there is exactly when the split breaks down).
+  using Full = std::true_type;
+  using Ragged = std::false_type;
+  const int nfull = (int)((n1 - n0) / GM_TM);  // tiles wholly inside the matrix
+  uint32_t soff[ST];
 #pragma unroll
-    for (int u = 0; u < ST; ++u) {
-      const int e = threadIdx.x + 512 * u;
-      const long long n = n0 + (long long)tile * GM_TM + e / G8;
-      const float *sp = n < n1 ? X + (size_t)n * CIN + 8 * (e % G8) : X;
-      st[u][0] = *reinterpret_cast<const float4 *>(sp);
-      st[u][1] = *reinterpret_cast<const float4 *>(sp + 4);
+  for (int u = 0; u < ST; ++u) {
+    const int e = threadIdx.x + 512 * u;
+    soff[u] = (uint32_t)((e / G8) * CIN + 8 * (e % G8)) * 4u;
+  }
+  float4 stA[ST][2], stB[ST][2];
+  auto fetch = [&](float4 (&st)[ST][2], int tile, auto full_c) {
+    if constexpr (decltype(full_c)::value) {
+      const char *tb = reinterpret_cast<const char *>(X) + (size_t)(n0 + (long long)tile * GM_TM) * CIN * 4;
+#pragma unroll
+      for (int u = 0; u < ST; ++u) {
+        st[u][0] = *reinterpret_cast<const float4 *>(tb + soff[u]);
+        st[u][1] = *reinterpret_cast<const float4 *>(tb + soff[u] + 16);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < ST; ++u) {
+        const int e = threadIdx.x + 512 * u;
+        const long long n = n0 + (long long)tile * GM_TM + e / G8;
+        const float *sp = n < n1 ? X + (size_t)n * CIN + 8 * (e % G8) : X;
+        st[u][0] = *reinterpret_cast<const float4 *>(sp);
+        st[u][1] = *reinterpret_cast<const float4 *>(sp + 4);
+      }
     }
   };
-  auto stash = [&](const float4 (&st)[ST][2], int tile) {
+  PieceWatch big;
+  auto stash = [&](const float4 (&st)[ST][2], int tile, auto full_c) {
     const int buf = tile & 1;
+    const float nsc = -GM_SCALE;
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
-      const bool in = n0 + (long long)tile * GM_TM + e / G8 < n1;
       float a[8] = {st[u][0].x, st[u][0].y, st[u][0].z, st[u][0].w, st[u][1].x, st[u][1].y, st[u][1].z, st[u][1].w};
-      f16x8g h1, h2;
-      RangeWatch big;
+      if constexpr (!decltype(full_c)::value) {
+        const bool in = n0 + (long long)tile * GM_TM + e / G8 < n1;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = in ? a[i] : 0.f;
-        h1[i] = (_Float16)v;
-        h2[i] = (_Float16)((v - (float)h1[i]) * GM_SCALE);
-        big.see(v);
+        for (int i = 0; i < 8; ++i) a[i] = in ? a[i] : 0.f;
       }
-      if (big.beyond_fp16() && range_flag != nullptr) *range_flag = 1;
+      uint32_t H[4], L[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float s0 = a[2 * p] * GM_SCALE, s1 = a[2 * p + 1] * GM_SCALE;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H[p]) : "v"(a[2 * p]), "v"(a[2 * p + 1]));
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s1));
+        big.see_f16x2(H[p]);
+      }
       char *dst = sG + (size_t)buf * 2 * PIECE + (e / G8) * RS + 16 * (e % G8);
-      *reinterpret_cast<uint4 *>(dst) = __builtin_bit_cast(uint4, h1);
-      *reinterpret_cast<uint4 *>(dst + PIECE) = __builtin_bit_cast(uint4, h2);
+      *reinterpret_cast<uint4 *>(dst) = make_uint4(H[0], H[1], H[2], H[3]);
+      *reinterpret_cast<uint4 *>(dst + PIECE) = make_uint4(L[0], L[1], L[2], L[3]);
     }
   };
   const bool late = wave >= 4;
@@ -173,22 +203,31 @@ __global__ __launch_bounds__(512) void group_linear_max_fwd_k(const float *__res
     }
   };
   auto step = [&](int tile, float4 (&have)[ST][2], float4 (&next)[ST][2]) {
+    if (tile + 2 < nfull) {  // tiles t, t+1, t+2 exist and are whole
+      fetch(next, tile + 2, Full{});
+      if (late) stash(have, tile + 1, Full{});
+      compute(tile);
+      if (!late) stash(have, tile + 1, Full{});
+      __syncthreads();
+      return;
+    }
     const bool more = tile + 1 < ntiles;
-    if (tile + 2 < ntiles) fetch(next, tile + 2);
-    if (more && late) stash(have, tile + 1);
+    if (tile + 2 < ntiles) fetch(next, tile + 2, Ragged{});
+    if (more && late) stash(have, tile + 1, Ragged{});
     compute(tile);
-    if (more && !late) stash(have, tile + 1);
+    if (more && !late) stash(have, tile + 1, Ragged{});
     __syncthreads();
   };
-  fetch(stA, 0);
+  fetch(stA, 0, Ragged{});
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): W and tile 0 are complete before the loop (see victim_bf3.hip)
-  stash(stA, 0);
-  if (ntiles > 1) fetch(stA, 1);
+  stash(stA, 0, Ragged{});
+  if (ntiles > 1) fetch(stA, 1, Ragged{});
   __syncthreads();
   for (int tile = 0; tile < ntiles; tile += 2) {
     step(tile, stA, stB);
     if (tile + 1 < ntiles) step(tile + 1, stB, stA);
   }
+  if (big.beyond_fp16() && range_flag != nullptr) *range_flag = 1;  // a hi piece was an infinity or a NaN: the caller refuses the result
 }
 
 // ------------------------------------------------------------------------------------------------ backward
