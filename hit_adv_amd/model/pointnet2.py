@@ -15,7 +15,8 @@ import torch.nn.functional as F
 
 from .. import ops
 from . import _sampling
-from ._pointwise import fast_pm, linear_relu_max_pm, linear_relu_pm, linear_relu_then_max_pm, split_first_layer
+from ._pointwise import (fast_pm, linear_lrelu_maxpool_pm, linear_relu_max_pm, linear_relu_pm, linear_relu_then_max_pm,
+                         split_first_layer)
 
 
 def index_points(points, idx):
@@ -79,7 +80,16 @@ class PointNetSetAbstraction(nn.Module):
             new_xyz, grouped = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points)
         if fast_pm(self.mlp_convs[0], self.mlp_bns[0], grouped):
             h = grouped  # [B,npoint,nsample,C+D] is already points-major: the shared MLP is a chain of GEMMs
-            for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            layers = list(zip(self.mlp_convs, self.mlp_bns))
+            if self.group_all and h.shape[1] == 1:
+                # the last shared layer, its ReLU and the max over the cloud's points as one kernel on the fp16 matrix cores
+                # (the pooled GEMM of DGCNN's embedding layer with slope 0: relu and max commute); the [B, n, 1024] activation,
+                # its ReLU pass and its max pass never exist, forward or backward
+                for conv, bn in layers[:-1]:
+                    h = linear_relu_pm(conv, bn, h)
+                out = linear_lrelu_maxpool_pm(layers[-1][0], layers[-1][1], h[:, 0], slope=0.)  # [B, C]
+                return new_xyz.permute(0, 2, 1), out.unsqueeze(-1)
+            for conv, bn in layers:
                 h = linear_relu_pm(conv, bn, h)
             return new_xyz.permute(0, 2, 1), h.max(dim=2)[0].permute(0, 2, 1)
         h = grouped.permute(0, 3, 2, 1)  # [B,C+D,nsample,npoint]
