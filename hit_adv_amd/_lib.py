@@ -28,6 +28,7 @@ PROTOTYPES = {
     "hitadv_best_update": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hitadv_adam_step": [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _L, _F, _P, _P],
     "hitadv_copy": [_P, _P, _L, _P],
+    "hitadv_transpose_small": [_P, _P, _I, _I, _I, _I, _P],
     "hitadv_fps_from_start": [_P, _P, _I, _I, _I, _P, _P],
     "hitadv_fps_pct": [_P, _P, _I, _I, _I, _P, _P],
     "hitadv_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],

@@ -234,6 +234,34 @@ __global__ __launch_bounds__(256) void copy_bytes_k(unsigned char *__restrict__ 
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// [B,C,N] <-> [B,N,C] for a few channels (a cloud's coordinates: C = 3): one thread per point, the channel-major side read / written
+// coalesced over the points.  torch's strided copy kernel moves the 1.5 MB of a 64 x 2048 cloud in 24 us (65 GB/s), twice per victim
+// pass and level (`xyz.permute(0, 2, 1).contiguous()` and its backward).
+template <bool TO_POINTS_MAJOR>
+__global__ __launch_bounds__(256) void transpose_small_k(const float *__restrict__ src, float *__restrict__ dst, int C, int N,
+                                                         long long total) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (b, n)
+  if (e >= total) return;
+  const long long b = e / N;
+  const int n = (int)(e - b * N);
+  for (int c = 0; c < C; ++c) {
+    const size_t cm = ((size_t)b * C + c) * N + n, pm = (size_t)e * C + c;
+    if (TO_POINTS_MAJOR) dst[pm] = src[cm];
+    else dst[cm] = src[pm];
+  }
+}
+
+extern "C" int hitadv_transpose_small(const float *src, float *dst, int B, int C, int N, int to_points_major, void *stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || C > 16 || N <= 0) return HITADV_E_ARG;
+  const long long total = (long long)B * N;
+  if (to_points_major)
+    transpose_small_k<true><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, dst, C, N, total);
+  else
+    transpose_small_k<false><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, dst, C, N, total);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int hitadv_copy(void *dst, const void *src, int64_t nbytes, void *stream) {
   if (nbytes < 0 || (nbytes > 0 && (!dst || !src))) return HITADV_E_ARG;
   if (nbytes == 0 || dst == src) return 0;

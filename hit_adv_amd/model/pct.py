@@ -215,7 +215,7 @@ class Pct(nn.Module):
     def _forward_points_major(self, x):
         """Eval mode on the GPU: every tensor stays points-major [B,N,C], so each 1x1 convolution is one GEMM with the
         BatchNorm folded in and bias / ReLU in its epilogue, and nothing is permuted or copied between layers."""
-        xyz = x.permute(0, 2, 1).contiguous()
+        xyz = ops.points_major(x)
         t0, t1 = self._tables_ahead(xyz) if self.tables_ahead else (None, None)
         h = linear_relu_pm(self.conv2, self.bn2, linear_relu_pm(self.conv1, self.bn1, xyz))
         new_xyz, p0 = self.gather_local_0.from_points(xyz, h, 512, 32, tables=t0)

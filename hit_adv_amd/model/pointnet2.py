@@ -68,7 +68,7 @@ class PointNetSetAbstraction(nn.Module):
 
     def forward(self, xyz, points):
         """xyz [B,3,N], points [B,D,N] or None -> (new_xyz [B,3,S], features [B,D',S])."""
-        xyz = xyz.permute(0, 2, 1).contiguous()
+        xyz = ops.points_major(xyz)
         if points is not None:
             points = points.permute(0, 2, 1)
         if (not self.group_all and fast_pm(self.mlp_convs[0], self.mlp_bns[0], xyz) and

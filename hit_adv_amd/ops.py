@@ -931,6 +931,32 @@ def group_linear_max(x, Wr, bias, range_flag=None, return_arg=False, pieces=None
     return (out, arg.view(*lead, arg.shape[-1])) if return_arg else out
 
 
+class _PointsMajor(torch.autograd.Function):
+    """[B,C,N] -> contiguous [B,N,C] for a few channels (hitadv_transpose_small); the backward pass is the same kernel the other way."""
+
+    @staticmethod
+    def forward(ctx, x, to_points_major):
+        x = _dev(x, "x")
+        B, P, Q = x.shape
+        C, N = (P, Q) if to_points_major else (Q, P)
+        y = torch.empty(B, Q, P, device=x.device)
+        _lib.call("hitadv_transpose_small", _p(x), _p(y), B, C, N, 1 if to_points_major else 0, _stream())
+        ctx.dir = to_points_major
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _PointsMajor.apply(g.contiguous(), not ctx.dir), None
+
+
+def points_major(x):
+    """``x.permute(0, 2, 1).contiguous()`` for x [B,C,N] with a handful of channels (coordinates); differentiable.  CPU tensors and
+    wide inputs take torch's own path."""
+    if x.is_cuda and x.dim() == 3 and x.shape[1] <= 16 and x.dtype == torch.float32:
+        return _PointsMajor.apply(x.contiguous(), True)
+    return x.permute(0, 2, 1).contiguous()
+
+
 def rows_linear_supported(Cin, Cout):
     return bool(_lib.load().hitadv_rows_linear_supported(int(Cin), int(Cout)))
 

@@ -146,6 +146,11 @@ int hitadv_adam_step(float *perturb, const float *g_perturb, float *m_perturb, f
  * captured PCT passes take 1.92x one stream's time without such nodes, 2.47x with seven per pass). */
 int hitadv_copy(void *dst, const void *src, int64_t nbytes, void *stream);
 
+/* dst [B,N,C] = src [B,C,N] transposed (to_points_major != 0) or dst [B,C,N] = src [B,N,C] (0), C <= 16: a cloud between the
+ * victims' channel-major interface (model/pointnet2_cls_ssg.py:27 `xyz [B,3,N]`) and the points-major layout its samplers work on
+ * (`xyz.permute(0, 2, 1)`, model/pointnet2_utils.py:176), as one coalesced kernel. */
+int hitadv_transpose_small(const float *src, float *dst, int B, int C, int N, int to_points_major, void *stream);
+
 /* The same step with the gradient given as g + g2 (g2 may be NULL: the deformation's and the regulariser's terms
  * need no separate add), followed by the projection the reference applies at the top of the next iteration
  * (ShapeAttack/HiT_ADV.py:157-158; skipped for a group when lo > hi).  *step is the 1-based step number and is

@@ -882,6 +882,19 @@ def test_group_linear_max_forward_and_backward(A, G, ns, Cin, Cout):
     assert float((x > 0).float().mean()) < 0.7
 
 
+def test_points_major_is_the_permuted_copy(A):
+    """ops.points_major = x.permute(0, 2, 1).contiguous() for a cloud [B,3,N] (hitadv_transpose_small), forward and backward."""
+    g = torch.Generator().manual_seed(3)
+    for B, C, N in ((5, 3, 1000), (2, 6, 77), (64, 3, 2048)):
+        x = torch.randn(B, C, N, generator=g)
+        xg = cu(x).requires_grad_()
+        y = A.points_major(xg)
+        assert y.is_contiguous() and torch.equal(y.cpu(), x.permute(0, 2, 1).contiguous())
+        w = torch.randn(B, N, C, generator=g)
+        (y * cu(w)).sum().backward()
+        assert torch.equal(xg.grad.cpu(), w.permute(0, 2, 1).contiguous())
+
+
 @pytest.mark.parametrize("rows,Cin,Cout", [(64 * 41, 64, 64), (64 * 300 + 17, 128, 128), (5, 64, 128), (64 * 9 + 63, 128, 64),
                                             (64 * 2500, 64, 64)])
 def test_rows_linear_is_fp32_accurate(A, rows, Cin, Cout):
