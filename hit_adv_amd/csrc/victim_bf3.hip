@@ -20,11 +20,16 @@
 //   compute : v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock under it than under the 32x32x16 form, and four
 //             accumulators rotate): per tile and wave 4 row tiles x 2 column tiles x (CIN/32 slices) x 6 MFMAs; the next
 //             unit's A fragments are read while the current unit's 24 MFMAs run
-//   epilogue: a lane scans its two channels' 16 points per tile into a running (max, first arg-max); four lane groups and
-//             the splits merge at the end (the last block to arrive, as in the f32 kernel).
-// Where the time goes (tools/tune/v1bf3: variants of this file with one cost removed, in-kernel clock stamped): the
-// MFMAs alone (no split, no scan, A fragments read once) take 36 us of the 40; 192 MFMAs per tile and wave at 16 cycles
-// and 1.9 GHz under this load are 26 us, the rest of that is the W load, the first tile and the tail.
+//   epilogue: a lane scans its two channels' 16 points per tile into a running (max, first arg-max): the tile maximum by
+//             v_max3, then the first value equal to it; four lane groups and the splits merge at the end (the last block
+//             to arrive, as in the f32 kernel).
+//   FLAT    : (template parameter, chosen by the launcher when there is no split and N is a multiple of 128) the clouds of a
+//             workgroup as one stream of tiles, no ragged-tile or merge code in the instantiation.
+// Where the time goes.  Round 2 (tools/tune/v1bf3: variants of this file with one cost removed, in-kernel clock stamped): the
+// MFMAs alone (no split, no scan, A fragments read once) take 36 us of the 40 of the bf16x3 form.  Round 4: on this part the
+// VECTOR instructions are not hidden behind the matrix pipe, also across the two waves of a SIMD, and the compiler had doubled
+// them (a bounds test if-converted into two selects per value; compare -> select hazards); 281 -> 137 per tile and wave took
+// the fp16x2 form from 330 to 256 us per 256 clouds on 128 workgroups (docs/kernels/round4.md section 8).
 #include <stdlib.h>
 
 #include <type_traits>
