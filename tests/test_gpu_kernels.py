@@ -1033,6 +1033,42 @@ def test_linear_max_fwd_bf16x3_same_bits_for_every_grid(A):
         A.linear_max_fwd_bf16x3(cu(x), W3, B, Np, blocks=5)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "fp16x2", "packed"])
+def test_linear_max_flat_stream_equals_the_split_form(A, mode):
+    """N a multiple of 128 and no point split selects V1's FLAT instantiation (the clouds of a workgroup as one stream of tiles, the
+    running maximum finished every N / 64 tiles); few clouds on many workgroups select the split form (merged in point order).
+    Same bits either way, an odd number of clouds over workgroups that take 2, 4 and 7 of them, ties included."""
+    g = torch.Generator().manual_seed(11)
+    B, Np, Cin, Cout = 13, 1280, 128, 1024
+    x = torch.randn(B * Np, Cin, generator=g).relu()
+    x[3 * Np + 700] = x[3 * Np + 5]   # duplicate points in different tiles of one cloud: the lower index wins
+    x[12 * Np + 64] = x[12 * Np + 63]  # ... and across a tile boundary of the last cloud
+    Wr = cu(torch.randn(Cout, Cin, generator=g) * 0.1)
+    bias = cu(torch.randn(Cout, generator=g))
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    if mode == "bf16x3":
+        W = A.split_weights_bf16x3(Wr)
+        run = lambda blocks: A.linear_max_fwd_bf16x3(cu(x), W, B, Np, bias=bias, relu=True, blocks=blocks)
+    else:
+        W = A.split_weights_f16x2(Wr, range_flag=flag)
+        xin = cu(x)
+        if mode == "packed":  # one word per value: fp16 hi | fp16 lo << 16 (what V2 hands over)
+            hi = xin.half()
+            lo = ((xin - hi.float()) * 2048.).half()
+            xin = (hi.view(torch.int16).int() & 0xffff | (lo.view(torch.int16).int() << 16)).view(torch.float32)
+        run = lambda blocks: A.linear_max_fwd_f16x2(xin, W, B, Np, bias=bias, relu=True, blocks=blocks, range_flag=flag,
+                                                     packed=(mode == "packed"))
+    ref = run(0)  # 52 (cloud, column group) pairs on 256 workgroups: five point splits per cloud, the split form
+    for blocks in (256, 128, 40, 16, 8):  # 40 and fewer: several clouds per workgroup, the FLAT form
+        out = run(blocks)
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), blocks
+    y = (x.double() @ Wr.cpu().double().t()).view(B, Np, Cout)
+    s = float(y.abs().max())
+    close(ref[0] / s, (y.max(dim=1).values + bias.cpu().double()).clamp_min(0.).float() / s, rtol=0, atol=2e-6,
+          what='V1 (%s) vs float64 over the output scale' % mode)
+    assert int(ref[1][3].eq(700).sum()) == 0 and int(ref[1][12].eq(64).sum()) == 0 and int(flag.item()) == 0
+
+
 def test_folded_pointnet_pieces_follow_the_view(A):
     """The bf16 weight pieces are registered buffers: a view built on the CPU and moved afterwards is split on its new
     device before the first forward pass, and gives the bits of a view built on the GPU."""
