@@ -53,6 +53,8 @@ PROTOTYPES = {
     "hitadv_group_linear_max_supported": [_I, _I, _I],
     "hitadv_rows_linear_supported": [_I, _I],
     "hitadv_rows_linear": [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P],
+    "hitadv_group_add_relu_linear_supported": [_I, _I, _I, _I],
+    "hitadv_group_add_relu_linear": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P],
     "hitadv_group_linear_max_fwd": [_P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],
     "hitadv_group_linear_max_bwd": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P],
     "hitadv_group_linear_max_bwd_masked": [_P, _P, _P, _P, _c.c_int64, _I, _I, _I, _P, _P, _P, _P],

@@ -192,6 +192,169 @@ __global__ __launch_bounds__(512) void rows_linear_k(const float *__restrict__ X
   if (big.beyond_fp16() && range_flag != nullptr) *range_flag = 1;  // a hi piece was an infinity or a NaN: the caller refuses the result
 }
 
+// The same layer with its INPUT produced on the way in: x[(b, i, s), :] = relu(U[b, idx[b,i,s], :] + V[b, i, :]) -- the first shared
+// layer of the block after its split over the neighbour and the centre (csrc/grouping.hip::group_add_relu_fwd_k) -- so that the
+// [B, S, ns, CIN] activation between the two layers (268 MB at cfg4's levels, written once and read once) never exists.  The
+// backward pass does not need it either (group_add_relu_bwd recomputes its ReLU mask from U and V).  Same arithmetic as
+// group_add_relu followed by rows_linear: the same bits.  Every tile is whole (rows a multiple of 64, a cloud a whole number of
+// tiles: the launcher checks): the neighbour numbers of tile t+3 and the rows of tile t+2 are requested while tile t is multiplied.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) void rows_linear_gather_k(const float *__restrict__ U, const float *__restrict__ V,
+                                                            const int64_t *__restrict__ idx, int N, int S, int ns_shift,
+                                                            const uint16_t *__restrict__ W2, const float *__restrict__ bias,
+                                                            long long rows, int tiles_per_block, int relu, float *__restrict__ Y,
+                                                            int *range_flag) {
+  constexpr int NSL = CIN / 32;
+  constexpr int RS = 2 * CIN + 32;
+  constexpr int PIECE = RL_TM * RS;
+  constexpr int G8 = CIN / 8;
+  constexpr int ST = RL_TM * G8 / 512;
+  constexpr int WC = COUT / 16, WR = 8 / WC, RT = 4 / WR;
+  constexpr int LDO = COUT + 4;
+  constexpr int OUTB = RL_TM * LDO * 4;
+  constexpr int NO = RL_TM * COUT / 4 / 512;
+  extern __shared__ __attribute__((aligned(16))) char sR[];
+  char *const sOut = sR + 4 * PIECE;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l16 = lane & 15, g4 = lane >> 4;
+  const int wc = wave % WC, wr = wave / WC;
+  const long long ntiles_all = rows / RL_TM;
+  const long long t0 = (long long)blockIdx.x * tiles_per_block;
+  const int ntiles = (int)max(0ll, min((long long)tiles_per_block, ntiles_all - t0));
+  if (ntiles <= 0) return;
+  const long long n0 = t0 * RL_TM;
+  const int last = ntiles - 1;
+  const long long cloud_rows = (long long)S << ns_shift;
+
+  uint4 w[2][NSL];
+  {
+    const uint4 *wp = reinterpret_cast<const uint4 *>(W2) + (size_t)wc * NSL * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int j = 0; j < NSL; ++j) w[p][j] = wp[((size_t)p * (COUT / 16) * NSL + j) * 64];
+  }
+  const float bv = bias != nullptr ? bias[16 * wc + l16] : 0.f;
+
+  struct Set {
+    float4 u[ST][2], v[ST][2];
+    bool ok[ST];
+  };
+  // the neighbour numbers of a tile's rows (one per staged group of this thread)
+  auto load_idx = [&](long long (&j)[ST], int tile) {
+#pragma unroll
+    for (int q = 0; q < ST; ++q) j[q] = idx[n0 + (long long)tile * RL_TM + (threadIdx.x + 512 * q) / G8];
+  };
+  auto fetch = [&](Set &st, int tile, const long long (&j)[ST]) {
+    const long long r0 = n0 + (long long)tile * RL_TM;
+    const long long b = r0 / cloud_rows;  // wave-uniform: a cloud is a whole number of tiles
+#pragma unroll
+    for (int q = 0; q < ST; ++q) {
+      const int e = threadIdx.x + 512 * q;
+      const long long bi = (r0 + e / G8) >> ns_shift;
+      st.ok[q] = j[q] >= 0 && j[q] < N;
+      const float *up = U + ((size_t)(b * N + (st.ok[q] ? j[q] : 0))) * CIN + 8 * (e % G8);
+      const float *vp = V + (size_t)bi * CIN + 8 * (e % G8);
+      st.u[q][0] = *reinterpret_cast<const float4 *>(up);
+      st.u[q][1] = *reinterpret_cast<const float4 *>(up + 4);
+      st.v[q][0] = *reinterpret_cast<const float4 *>(vp);
+      st.v[q][1] = *reinterpret_cast<const float4 *>(vp + 4);
+    }
+  };
+  PieceWatch big;
+  auto stash = [&](const Set &st, int tile) {
+    const int buf = tile & 1;
+    const float nsc = -RL_SCALE;
+#pragma unroll
+    for (int q = 0; q < ST; ++q) {
+      const int e = threadIdx.x + 512 * q;
+      const float uu[8] = {st.u[q][0].x, st.u[q][0].y, st.u[q][0].z, st.u[q][0].w, st.u[q][1].x, st.u[q][1].y, st.u[q][1].z, st.u[q][1].w};
+      const float vv[8] = {st.v[q][0].x, st.v[q][0].y, st.v[q][0].z, st.v[q][0].w, st.v[q][1].x, st.v[q][1].y, st.v[q][1].z, st.v[q][1].w};
+      float a[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = st.ok[q] ? fmaxf(uu[i] + vv[i], 0.f) : 0.f;  // group_add_relu_fwd_k's value
+      uint32_t H[4], L[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float s0 = a[2 * p] * RL_SCALE, s1 = a[2 * p + 1] * RL_SCALE;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H[p]) : "v"(a[2 * p]), "v"(a[2 * p + 1]));
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s1));
+        big.see_f16x2(H[p]);
+      }
+      char *dst = sR + (size_t)buf * 2 * PIECE + (e / G8) * RS + 16 * (e % G8);
+      *reinterpret_cast<uint4 *>(dst) = make_uint4(H[0], H[1], H[2], H[3]);
+      *reinterpret_cast<uint4 *>(dst + PIECE) = make_uint4(L[0], L[1], L[2], L[3]);
+    }
+  };
+  const bool late = wave >= 4;
+  auto compute = [&](int tile) {
+    const char *base = sR + (size_t)(tile & 1) * 2 * PIECE + (16 * RT * wr + l16) * RS + 16 * g4;
+    f32x4r acc[RT], accl[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      acc[rt] = f32x4r{0.f, 0.f, 0.f, 0.f};
+      accl[rt] = f32x4r{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+      const f16x8r bhi = as_f16x8r(w[0][j]), blo = as_f16x8r(w[1][j]);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const f16x8r ahi = as_f16x8r(*reinterpret_cast<const uint4 *>(base + rt * 16 * RS + 64 * j));
+        const f16x8r alo = as_f16x8r(*reinterpret_cast<const uint4 *>(base + PIECE + rt * 16 * RS + 64 * j));
+        accl[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi, accl[rt], 0, 0, 0);
+        accl[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo, accl[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi, acc[rt], 0, 0, 0);
+      }
+    }
+    float *so = reinterpret_cast<float *>(sOut + (size_t)(tile & 1) * OUTB) + (16 * RT * wr + 4 * g4) * LDO + 16 * wc + l16;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = fmaf(accl[rt][i], 1.f / RL_SCALE, acc[rt][i]) + bv;
+        v = relu ? fmaxf(v, 0.f) : v;
+        so[(16 * rt + i) * LDO] = v;
+      }
+  };
+  auto leave = [&](int tile) {
+    const float *so = reinterpret_cast<const float *>(sOut + (size_t)(tile & 1) * OUTB);
+    const long long row0 = n0 + (long long)tile * RL_TM;
+#pragma unroll
+    for (int q = 0; q < NO; ++q) {
+      const int e = threadIdx.x + 512 * q, r = e / (COUT / 4), c4 = e % (COUT / 4);
+      *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * COUT + 4 * c4) = *reinterpret_cast<const float4 *>(so + r * LDO + 4 * c4);
+    }
+  };
+  // every step is the steady one: past the end of the block's tiles the last tile is requested again (and written to the LDS
+  // buffer nobody reads any more)
+  auto step = [&](int tile, Set &have, Set &next, const long long (&jc)[ST], long long (&jn)[ST]) {
+    load_idx(jn, min(tile + 3, last));
+    fetch(next, min(tile + 2, last), jc);
+    if (late) stash(have, tile + 1);
+    compute(tile);
+    if (!late) stash(have, tile + 1);
+    __syncthreads();
+    leave(tile);
+  };
+  Set sa, sb;
+  long long ja[ST], jb[ST];
+  load_idx(ja, 0);
+  fetch(sa, 0, ja);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): W and tile 0 are complete before the loop (see victim_bf3.hip)
+  stash(sa, 0);
+  load_idx(ja, min(1, last));
+  fetch(sa, min(1, last), ja);
+  load_idx(jb, min(2, last));
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    step(tile, sa, sb, jb, ja);
+    if (tile + 1 < ntiles) step(tile + 1, sb, sa, ja, jb);
+  }
+  if (big.beyond_fp16() && range_flag != nullptr) *range_flag = 1;
+}
+
 template <int CIN, int COUT>
 static int launch_rows_linear(const float *X, const uint16_t *W2, const float *bias, long long rows, int relu, float *Y,
                               int32_t *range_flag, hipStream_t s) {
@@ -213,6 +376,40 @@ static int launch_rows_linear(const float *X, const uint16_t *W2, const float *b
 using namespace hitadv;
 
 extern "C" int hitadv_rows_linear_supported(int Cin, int Cout) { return ((Cin == 64 || Cin == 128) && (Cout == 64 || Cout == 128)) ? 1 : 0; }
+
+template <int CIN, int COUT>
+static int launch_rows_linear_gather(const float *U, const float *V, const int64_t *idx, int N, int S, int ns_shift, const uint16_t *W2,
+                                     const float *bias, long long rows, int relu, float *Y, int32_t *range_flag, hipStream_t s) {
+  const long long ntiles = rows / RL_TM;
+  long long blocks = min(ntiles, 256ll);
+  int tpb = (int)((ntiles + blocks - 1) / blocks);
+  if (tpb < 8) tpb = (int)min(8ll, ntiles);
+  blocks = (ntiles + tpb - 1) / tpb;
+  constexpr int shm = 4 * RL_TM * (2 * CIN + 32) + 2 * RL_TM * (COUT + 4) * 4;
+  HITADV_RAISE_LDS((&rows_linear_gather_k<CIN, COUT>), shm);
+  rows_linear_gather_k<CIN, COUT><<<(unsigned)blocks, 512, shm, s>>>(U, V, idx, N, S, ns_shift, W2, bias, rows, tpb, relu, Y, range_flag);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int hitadv_group_add_relu_linear_supported(int C, int Cout, int S, int ns) {
+  return (hitadv_rows_linear_supported(C, Cout) && (ns == 16 || ns == 32 || ns == 64) && S > 0 && ((long long)S * ns) % RL_TM == 0) ? 1 : 0;
+}
+
+extern "C" int hitadv_group_add_relu_linear(const float *U, const float *V, const int64_t *idx, int B, int N, int S, int ns, int C,
+                                            const uint16_t *W2, const float *bias, int Cout, int relu, float *Y, int32_t *range_flag,
+                                            void *stream) {
+  if (!U || !V || !idx || !W2 || !Y || B <= 0 || N <= 0 || !hitadv_group_add_relu_linear_supported(C, Cout, S, ns) ||
+      (((uintptr_t)U | (uintptr_t)V | (uintptr_t)W2 | (uintptr_t)Y) & 15))
+    return HITADV_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long long rows = (long long)B * S * ns;
+  const int sh = ns == 16 ? 4 : (ns == 32 ? 5 : 6);
+  if (C == 64 && Cout == 64) return launch_rows_linear_gather<64, 64>(U, V, idx, N, S, sh, W2, bias, rows, relu, Y, range_flag, s);
+  if (C == 64 && Cout == 128) return launch_rows_linear_gather<64, 128>(U, V, idx, N, S, sh, W2, bias, rows, relu, Y, range_flag, s);
+  if (C == 128 && Cout == 64) return launch_rows_linear_gather<128, 64>(U, V, idx, N, S, sh, W2, bias, rows, relu, Y, range_flag, s);
+  return launch_rows_linear_gather<128, 128>(U, V, idx, N, S, sh, W2, bias, rows, relu, Y, range_flag, s);
+}
 
 extern "C" int hitadv_rows_linear(const float *X, const uint16_t *W2, const float *bias, int64_t rows, int Cin, int Cout, int relu,
                                   float *Y, int32_t *range_flag, void *stream) {

@@ -302,6 +302,26 @@ def linear_relu_then_max_pm(conv_mid, bn_mid, conv, bn, x):
     return linear_relu_max_pm(conv, bn, linear_relu_pm(conv_mid, bn_mid, x))
 
 
+def grouped_first_two_then_max_pm(U, V, idx, conv_mid, bn_mid, conv, bn):
+    """A sample-and-group block behind its first layer's two per-point products: relu(U[idx] + V) -> middle shared layer -> last
+    shared layer + max over the neighbours.  Where the widths allow, the gather / add / ReLU runs inside the middle layer's kernel
+    (``ops.GroupAddReLULinear``); otherwise ``ops.group_add_relu`` and ``linear_relu_then_max_pm``."""
+    from .. import ops
+    Wm, bm = _folded(conv_mid, bn_mid)
+    W, b = _folded(conv, bn)
+    B, S, ns = idx.shape
+    if (FUSED_ROWS_LINEAR and U.is_cuda and bm is not None and not WEIGHT_GRADS
+            and ops.group_add_relu_linear_supported(Wm.shape[1], Wm.shape[0], S, ns)):
+        probe = torch.empty(0, ns, Wm.shape[0], device=U.device)  # (only the device and ns matter to the last layer's choice)
+        if _fused_group_max(conv, W, b, probe) is not None:
+            flag = range_flag(U.device)
+            pieces = _pieces(conv_mid, Wm, 'reg', lambda M: ops.split_weights_f16x2(M, range_flag=flag))
+            if pieces is not None:
+                y = ops.GroupAddReLULinear.apply(U, V, idx, pieces[0], pieces[1], bm.detach(), flag)
+                return linear_relu_max_pm(conv, bn, y, relu_input=True)
+    return linear_relu_then_max_pm(conv_mid, bn_mid, conv, bn, ops.group_add_relu(U, V, idx))
+
+
 def linear_relu_max_pm(conv, bn, x, relu_input=False):
     """relu(bn(conv(.))) applied to points-major x [..., ns, Cin] followed by the max over the ns neighbours -> [..., Cout]:
     ``hitadv_group_linear_max`` where the shape is supported (no [.., ns, Cout] activation, no ReLU / max passes, a sparse

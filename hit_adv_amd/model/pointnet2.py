@@ -15,8 +15,8 @@ import torch.nn.functional as F
 
 from .. import ops
 from . import _sampling
-from ._pointwise import (fast_pm, linear_lrelu_maxpool_pm, linear_relu_max_pm, linear_relu_pm, linear_relu_then_max_pm,
-                         split_first_layer)
+from ._pointwise import (fast_pm, grouped_first_two_then_max_pm, linear_lrelu_maxpool_pm, linear_relu_max_pm, linear_relu_pm,
+                         linear_relu_then_max_pm, split_first_layer)
 
 
 def index_points(points, idx):
@@ -110,8 +110,13 @@ def _grouped_from_points(self, xyz, points):
     src = xyz if points is None else torch.cat([xyz, points], dim=-1)
     U = torch.matmul(src, W.t())
     V = torch.addmm(t, new_xyz.reshape(-1, 3), -W[:, :3].t()).view(B, self.npoint, W.shape[0])
-    h = ops.group_add_relu(U, V, idx)
     rest = list(zip(self.mlp_convs, self.mlp_bns))[1:]
+    if len(rest) == 2:
+        # three shared layers (the reference's blocks): the gather / add / ReLU of the first one runs inside the middle layer's
+        # kernel, the last one is fused with the max over the neighbours (csrc/rows_linear.hip, csrc/group_mlp.hip)
+        out = grouped_first_two_then_max_pm(U, V, idx, rest[0][0], rest[0][1], rest[1][0], rest[1][1])
+        return new_xyz.permute(0, 2, 1), out.permute(0, 2, 1)
+    h = ops.group_add_relu(U, V, idx)
     for conv, bn in rest[:-2]:
         h = linear_relu_pm(conv, bn, h)
     # the last shared layer and the max over the neighbours in one kernel (csrc/group_mlp.hip) where the shape allows; the layer

@@ -806,6 +806,42 @@ def group_add_relu(U, V, idx):
     return GroupAddReLU.apply(U, V, idx)
 
 
+def group_add_relu_linear_supported(C, Cout, S, ns):
+    return bool(_lib.load().hitadv_group_add_relu_linear_supported(int(C), int(Cout), int(S), int(ns)))
+
+
+class GroupAddReLULinear(torch.autograd.Function):
+    """relu(relu(U[b, idx] + V[b,i]) W^T + bias) over the grouped rows -> [B,S,ns,Cout]: ``group_add_relu`` and the shared layer behind
+    it as one kernel (hitadv_group_add_relu_linear; the [B,S,ns,C] activation between them never exists).  The ReLU backward of the
+    output is left to the consumer (the gradient arrives gated, as for ``_LinearReLUGatedLater``); the backward pass is the input
+    gradient of the layer (hitadv_rows_linear on the transposed pieces) followed by ``group_add_relu``'s own."""
+
+    @staticmethod
+    def forward(ctx, U, V, idx, W2, Wt2, bias, flag):
+        U, V = _dev(U, "U"), _dev(V, "V")
+        idx = _dev(idx, "idx", torch.int64)
+        B, N, C = U.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        Cout = W2.shape[1]
+        Y = torch.empty(B, S, ns, Cout, device=U.device)
+        _lib.call("hitadv_group_add_relu_linear", _p(U), _p(V), _p(idx), B, N, S, ns, C, _p(W2), _p(bias), Cout, 1, _p(Y), _p(flag),
+                  _stream())
+        ctx.save_for_backward(U, V, idx, Wt2)
+        ctx.flag = flag
+        return Y
+
+    @staticmethod
+    def backward(ctx, g):
+        U, V, idx, Wt2 = ctx.saved_tensors
+        B, N, C = U.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        dH = rows_linear(g.reshape(-1, g.shape[-1]).contiguous(), Wt2, None, False, ctx.flag)
+        dU, dV = torch.empty_like(U), torch.empty_like(V)
+        scratch = torch.empty(B * (2 * N + S * ns), device=U.device, dtype=torch.int32)
+        _lib.call("hitadv_group_add_relu_bwd", _p(dH), _p(U), _p(V), _p(idx), B, N, S, ns, C, _p(dU), _p(dV), _p(scratch), _stream())
+        return dU, dV, None, None, None, None, None
+
+
 def group_add_relu_supported(C, ns):
     return C % 4 == 0 and ns <= 64
 

@@ -538,6 +538,14 @@ int hitadv_group_linear_max_supported(int Cin, int Cout, int ns);
 int hitadv_rows_linear_supported(int Cin, int Cout);
 int hitadv_rows_linear(const float *X, const uint16_t *W2, const float *bias, int64_t rows, int Cin, int Cout, int relu, float *Y,
                        int32_t *range_flag, void *stream);
+
+/* The two together: Y[(b,i,s), :] = act(relu(U[b, idx[b,i,s], :] + V[b,i,:]) W^T + bias) -- hitadv_group_add_relu_fwd followed by
+ * hitadv_rows_linear without the [B,S,ns,C] activation between them (same bits as the two calls).  U [B,N,C], V [B,S,C], idx
+ * [B,S,ns] int64, W2 = hitadv_split_weights_f16x2(W [Cout,C]), Y [B*S*ns, Cout].  Supported (hitadv_group_add_relu_linear_supported):
+ * C, Cout in {64, 128}, ns in {16, 32, 64}, S * ns a multiple of 64; anything else: HITADV_E_ARG. */
+int hitadv_group_add_relu_linear_supported(int C, int Cout, int S, int ns);
+int hitadv_group_add_relu_linear(const float *U, const float *V, const int64_t *idx, int B, int N, int S, int ns, int C,
+                                 const uint16_t *W2, const float *bias, int Cout, int relu, float *Y, int32_t *range_flag, void *stream);
 int hitadv_group_linear_max_fwd(const float *X, const uint16_t *W2, const float *bias, int64_t G, int ns, int Cin, int Cout,
                                 float *out, int32_t *arg, int32_t *range_flag, void *stream);
 int hitadv_group_linear_max_bwd(const float *dOut, const float *out, const int32_t *arg, const uint16_t *Wb2, int64_t G, int ns,

@@ -882,6 +882,43 @@ def test_group_linear_max_forward_and_backward(A, G, ns, Cin, Cout):
     assert float((x > 0).float().mean()) < 0.7
 
 
+@pytest.mark.parametrize("B,N,S,ns,C,Cout", [(3, 300, 64, 32, 64, 64), (2, 128, 32, 64, 128, 128), (5, 77, 8, 16, 64, 128)])
+def test_group_add_relu_linear_equals_the_two_calls(A, B, N, S, ns, C, Cout):
+    """hitadv_group_add_relu_linear (the gather / add / ReLU of a block's first layer inside the middle layer's kernel) gives the bits
+    of group_add_relu followed by rows_linear, and its autograd node the gradients of the two nodes chained; an index outside the
+    cloud yields a zero row, as in group_add_relu."""
+    g = torch.Generator().manual_seed(B * 100 + ns)
+    U = torch.randn(B, N, C, generator=g)
+    V = torch.randn(B, S, C, generator=g)
+    idx = torch.randint(0, N, (B, S, ns), generator=g)
+    idx[0, 0, 3] = -1
+    idx[B - 1, S - 1, ns - 1] = N + 5
+    Wr = torch.randn(Cout, C, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g) * 0.3
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    W2, Wt2 = A.split_weights_f16x2(cu(Wr), range_flag=flag), A.split_weights_f16x2(cu(Wr.t().contiguous()), range_flag=flag)
+    assert A.group_add_relu_linear_supported(C, Cout, S, ns)
+    Ua, Va = cu(U).requires_grad_(), cu(V).requires_grad_()
+    y = A.GroupAddReLULinear.apply(Ua, Va, cu(idx), W2, Wt2, cu(bias), flag)
+    Ub, Vb = cu(U).requires_grad_(), cu(V).requires_grad_()
+    H = A.group_add_relu(Ub, Vb, cu(idx))
+    y2 = A.rows_linear(H.detach().reshape(-1, C), W2, cu(bias), True, flag).view(B, S, ns, Cout)
+    assert torch.equal(y, y2)
+    assert torch.equal(y.detach()[0, 0, 3], torch.relu(cu(bias))) and int(flag.item()) == 0  # an index outside the cloud: a zero row in
+    gy = torch.randn(B, S, ns, Cout, generator=g)
+    y.backward(cu(gy))
+    dH = A.rows_linear(cu(gy).reshape(-1, Cout), Wt2, None, False, flag).view(B, S, ns, C)
+    H.backward(dH)
+    assert torch.equal(Ua.grad, Ub.grad) and torch.equal(Va.grad, Vb.grad)
+    # against float64 (the composition itself)
+    ok = (idx >= 0) & (idx < N)
+    Hd = torch.relu(torch.gather(U.double(), 1, idx.clamp(0, N - 1).view(B, S * ns, 1).expand(-1, -1, C)).view(B, S, ns, C)
+                    + V.double().unsqueeze(2)) * ok.unsqueeze(-1)
+    ref = torch.relu(Hd @ Wr.double().t() + bias.double())
+    s_ = float(ref.abs().max())
+    close(y / s_, ref.float() / s_, rtol=0, atol=2e-6, what='group_add_relu_linear vs float64 over the output scale')
+
+
 def test_points_major_is_the_permuted_copy(A):
     """ops.points_major = x.permute(0, 2, 1).contiguous() for a cloud [B,3,N] (hitadv_transpose_small), forward and backward."""
     g = torch.Generator().manual_seed(3)
