@@ -206,6 +206,27 @@ def roofline_group_add_relu(dev, B, N, S, ns, C, what):
                 traffic_source=src, us_per_launch=round(us, 2), algorithmic_bytes=alg)
 
 
+def roofline_group_add_relu_linear(dev, B, N, S, ns, C, what):
+    """cfg4: the first two shared layers of a sample-and-group block in one kernel, Y[(b,s,j), :] = relu(relu(U[b, idx[b,s,j], :] +
+    V[b,s,:]) W^T + bias) (hitadv_group_add_relu_linear).  Algorithmic bytes: Y written once (4*B*S*ns*C), U and V read once
+    (4*B*(N+S)*C), idx read once (8*B*S*ns); the weights (2 pieces x C x C x 2 bytes) are noise."""
+    from hit_adv_amd import _lib, ops
+    lib = _lib.load()
+    U, V = torch.randn(B, N, C, device=dev), torch.randn(B, S, C, device=dev)
+    idx = torch.randint(0, N, (B, S, ns), device=dev, dtype=torch.int64)
+    W2 = ops.split_weights_f16x2(torch.randn(C, C, device=dev) * 0.1)
+    bias = torch.randn(C, device=dev)
+    Y = torch.empty(B, S, ns, C, device=dev)
+    us = graph_timed(lambda s: lib.hitadv_group_add_relu_linear(_p(U), _p(V), _p(idx), B, N, S, ns, C, _p(W2), _p(bias), C, 1, _p(Y),
+                                                                None, s))
+    alg = 4 * B * S * ns * C + 4 * B * (N + S) * C + 8 * B * S * ns
+    ach = alg / (us * 1e-6) / 1e9
+    traffic, src = _traffic("hitadv::rows_linear_gather_k@cfg4")
+    return dict(kernel="rows_linear_gather_k<%d, %d> (%s: B=%d, N=%d, S=%d, nsample=%d; hitadv_group_add_relu_linear)" % (C, C, what, B, N, S, ns),
+                bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
+                traffic_source=src, us_per_launch=round(us, 2), algorithmic_bytes=alg)
+
+
 def hot_loop_kernels(dev, B=32, N=1024):
     """Informational: kernels that ARE on cfg2's loop -- the deformation pair and V1 (the victim's 128->1024 shared layer
     fused with the max over points, on the f32 matrix cores)."""
@@ -866,7 +887,7 @@ def main():
         elif args.config == 'cfg3':
             line["roofline"] = roofline_knn_features(dev)
         elif args.config == 'cfg4':
-            line["roofline"] = roofline_group_add_relu(dev, B, N, 512, 32, 64, "PointNet++ sa1")
+            line["roofline"] = roofline_group_add_relu_linear(dev, B, N, 512, 32, 64, "PointNet++ sa1")
         else:
             line["roofline"] = roofline_group_add_relu(dev, B, 512, 256, 32, 256, "PCT gather_local_1")
         if args.top_kernels:
