@@ -18,8 +18,16 @@ def attack_concurrently(calls):
     and captures its iteration; only then do the loops start, each on a stream of its own -- the host queues one attack's
     replays and goes on to the next while the GPU works through all of them.  A PCT / DGCNN / PointNet++ pass at batch 32
     is hundreds of kernels of a few microseconds that leave most of the chip idle: three attacks in flight fill it.
-    Attackers without ``steps()`` (CWPerturb, the Add family) and a pass that left fp16's range fall back to the plain
-    sequence.  No progress lines are printed in a meaningful order: construct the attackers with ``verbose=False``."""
+    Attackers without ``steps()`` (CWPerturb, the Add family) fall back to the plain sequence.  No progress lines are printed
+    in a meaningful order: construct the attackers with ``verbose=False``.
+
+    fp16 range: the flag a fused fp16x2 layer raises is ONE PER DEVICE, so an overflow in any of the attacks invalidates all
+    of them: all are thrown away and run again one after the other, each degrading on its own (model/_pointwise.py).  On
+    that path and on any other exception (a failed capture under ``use_graph=True``, out of memory, KeyboardInterrupt)
+    the GPU is drained FIRST and only then are the generators closed -- closing one drops its captured graph and the graph's
+    private memory pool, and doing that under a replay still in flight on another stream is a memory access fault (found in
+    round 5 by a sharpened PCT victim whose first attack overflowed while the other two were still running) -- the victims'
+    feeds are closed, the side streams joined to the caller's, and the exception (other than the range one) re-raised."""
     import os
     import time
 
@@ -44,6 +52,7 @@ def attack_concurrently(calls):
                 results[i] = done.value
                 return True
 
+    finished = False
     try:
         for i, st in enumerate(streams):  # setups first, one after the other: draws in sequence order ...
             st.wait_stream(here)
@@ -51,9 +60,6 @@ def attack_concurrently(calls):
         torch.cuda.synchronize()
         for i in range(len(gens)):        # ... then the captures, with no eager victim work after any of them
             advance(i, ('ready',))
-        # the loops: the host queues one binary step of one attack and goes on to the next attack (launching a captured PCT
-        # iteration costs the host 0.85 ms against ~4 ms of GPU time: tools/graph_launch_cost.py); going round by binary
-        # step keeps a host-side wait at the start of an attack's next step from holding up the others' queues
         # the loops: the host goes round the attacks, a few iterations of each per turn (CW/_family.py::TURN), the longer
         # loops taking proportionally more turns per round so that all of them end together; launching a captured PCT
         # iteration costs the host 0.85 ms against ~4 ms of GPU time (tools/graph_launch_cost.py), so one thread keeps
@@ -78,15 +84,31 @@ def attack_concurrently(calls):
             print("hitadv cw timeline: GPU drained at %.3f s" % (time.perf_counter() - t0))
         for i in range(len(gens)):  # results are read back in sequence order
             advance(i, ())
-        for st in streams:
-            here.wait_stream(st)
+        finished = True
         return results
     except Fp16RangeExceeded:
-        for g in gens:
-            g.close()
-        torch.cuda.synchronize()
-        torch.set_rng_state(rng)
-        return [a.attack(*args) for a, args in calls]  # each degrades on its own (model/_pointwise.py)
+        pass  # cleaned up below, then the plain sequence
+    finally:
+        if not finished:
+            torch.cuda.synchronize()  # FIRST: no replay of any attack may still be in flight when its graph is dropped
+            for g in gens:
+                g.close()
+            for a, _ in calls:
+                victim = getattr(a, '_victim', None)
+                if victim is not None:
+                    victim.feed = None
+            from ..model import _pointwise
+            for flag in _pointwise._RANGE_FLAGS.values():  # what the attacks that were still running raised meanwhile
+                flag.zero_()
+            for a, _ in calls:
+                view = getattr(getattr(a, '_victim', None), 'view', None)
+                if hasattr(view, 'range_flag'):
+                    view.range_flag.zero_()
+            torch.cuda.synchronize()
+        for st in streams:
+            here.wait_stream(st)
+    torch.set_rng_state(rng)
+    return [a.attack(*args) for a, args in calls]  # each degrades on its own (model/_pointwise.py)
 
 
 def __getattr__(name):

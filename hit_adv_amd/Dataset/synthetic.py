@@ -63,3 +63,40 @@ class ToyVictim(torch.nn.Module):
     def forward(self, x):
         h = torch.relu(self.conv(x))
         return self.fc(torch.max(h, 2)[0])
+
+
+def shake_bn(model, seed=1, mean_std=0.05, var_spread=0.2):
+    """Running statistics of every BatchNorm layer away from their initial 0 / 1, from one CPU generator in module order: a
+    random-init victim in eval mode whose normalisation layers are not identities (what a trained checkpoint looks like to
+    the attack).  A pure function of (architecture, seed, mean_std, var_spread): fixtures store the three numbers, not the
+    statistics.  Call before moving the model to a device."""
+    g = torch.Generator('cpu').manual_seed(int(seed))
+    bn = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, bn):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * mean_std)
+                mod.running_var.copy_(1. - var_spread + 2. * var_spread * torch.rand(mod.running_var.shape, generator=g))
+    return model
+
+
+def sphere_batch(b, n, first=0):
+    """``b`` surface-like clouds (``SyntheticClouds(kind='sphere')``) starting at id ``first``: ``(data [b,n,6], label [b])``."""
+    ds = SyntheticClouds(b, n, kind='sphere', first=first)
+    rows = [ds[i] for i in range(b)]
+    return torch.stack([r[0] for r in rows]), torch.stack([r[1] for r in rows])
+
+
+def sharpen(model, gain):
+    """Every convolution / linear WEIGHT (not the biases) times ``gain``.  A default-initialised deep victim in eval mode
+    computes logits that are its last layer's bias plus a feature term a hundred times smaller: every cloud lands in the
+    class of the largest bias and no bounded deformation moves it (0 / 256 successes on PointNet++, 0 / 96 on PCT in
+    round 4's bench lines).  A gain > 1 compounds through the layers until the feature term decides the class, which is
+    what a trained victim looks like to an attack.  The toy victims of fixtures g5 / g7 are made the same way
+    (``conv.weight.mul_(3.0)``)."""
+    kinds = (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Linear)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, kinds):
+                mod.weight.mul_(gain)
+    return model

@@ -87,6 +87,16 @@ static inline hipError_t raise_dynamic_lds(LdsRaised &st, const void *kernel, in
     if (e__ != hipSuccess) return (int)e__;                                                                            \
   } while (0)
 
+// An index table that leaves a kernel holds VALID rows whatever the input was.  The selection kernels start their lists
+// at a sentinel (0x7fffffff / -1) that a comparison with NaN never replaces: a cloud that went NaN (a diverged attack, an
+// fp16-range overflow that the caller only notices when it reads its results back) would otherwise hand the sentinel to the
+// gather of the backward pass -- a wild read, on a bad day a memory access fault that takes the process down instead of the
+// range flag's clean re-run (round 5: PCT x3 weights under CW.attack_concurrently).  The values that belong to such an
+// entry stay NaN / inf, which is what the caller can see.
+__device__ __forceinline__ int sane_index(int i, int limit, int fallback) {
+  return (unsigned)i < (unsigned)limit ? i : min(fallback, limit - 1);
+}
+
 // Drain this wave's stores, meet the workgroup, draw the ticket of `slot`; true in every thread of the workgroup whose
 // ticket was the last of `total`.  `flag` is a __shared__ int of the caller.
 __device__ __forceinline__ bool handoff_last_arriver(int *tickets, int slot, int total, int *flag) {

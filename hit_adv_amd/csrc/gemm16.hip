@@ -305,7 +305,7 @@ struct PoolEpi {
           sum += rsum[w * G16_BN + colb];
         }
         const size_t o = (size_t)t.rb * C + t.col0 + colb;
-        pmax[o] = best, psum[o] = sum, parg[o] = bi;
+        pmax[o] = best, psum[o] = sum, parg[o] = bi == 0x7fffffff ? t.p0 : bi;  // (all-NaN column: a valid row, the range flag is up)
       }
     }
   }

@@ -13,6 +13,14 @@
 
 namespace hitadv {
 
+// diagnostic: how often a selection kernel of this file replaced a sentinel / out-of-range index (sane_index) since the
+// library was loaded, per site (hitadv_debug_knn_sane_hits); 0 on every finite input
+__device__ unsigned int g_knn_sane_hits[8];
+__device__ __forceinline__ int sane_index_at(int site, int i, int limit, int fallback) {
+  if ((unsigned)i >= (unsigned)limit) atomicAdd(&g_knn_sane_hits[site], 1u);
+  return sane_index(i, limit, fallback);
+}
+
 constexpr int KNN_RCH = 1024;
 
 // One block = 64 queries x 4 waves.  Every wave scans a quarter of each staged reference chunk for the
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) void knn_topk(const float *__restrict__ q, con
       bi = bw == w ? hi4[w] : bi;
     }
     od[t] = bd;
-    oi[t] = (IdxT)bi;
+    oi[t] = (IdxT)sane_index_at(0, bi, M, t);
     // advance the winning list
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -369,6 +377,7 @@ __global__ __launch_bounds__(NW * 64) void knn_select(const float *__restrict__ 
       bi = take ? hi4[w] : bi;
     }
     od[t] = bd;
+    bi = sane_index_at(1, bi, M, t);
     if (idx_is_i64) o64[t] = bi;
     else o32[t] = bi;
 #pragma unroll
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(64) void topk_rows(const float *__restrict__ P, lon
     for (int t = 0; t < KB; ++t)
       if (t < K) {
         vals[row * K + t] = LARGEST ? -d[t] : d[t];
-        idx[row * K + t] = ix[t];
+        idx[row * K + t] = sane_index_at(2, ix[t], M, t);
       }
   }
 }
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(256) void knn_bwd_q(const float *__restrict__ q, co
   p += (size_t)b * M * 3;
   float ax = 0.f, ay = 0.f, az = 0.f;
   for (int t = 0; t < K; ++t) {
-    const int j = (int)idx[((size_t)b * N + i) * K + t];
+    const int j = sane_index_at(3, (int)idx[((size_t)b * N + i) * K + t], M, 0);  // (a caller's table: never a wild read)
     const float g2 = 2.0f * g[((size_t)b * N + i) * K + t];
     ax = ax + g2 * (qx - p[j * 3]);
     ay = ay + g2 * (qy - p[j * 3 + 1]);
@@ -654,6 +663,10 @@ extern "C" int hitadv_topk_rows(const float *P, int64_t rows, int M, int K, int 
   HITADV_TOPK_CASE(64)
 #undef HITADV_TOPK_CASE
   return HITADV_E_ARG;
+}
+
+extern "C" int hitadv_debug_knn_sane_hits(unsigned int *host8) {
+  return host8 && hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_knn_sane_hits), 8 * sizeof(unsigned int)) == hipSuccess ? 0 : HITADV_E_ARG;
 }
 
 extern "C" int hitadv_knn_points_bwd(const float *q, const float *p, const void *idx, int idx_is_i64,
@@ -892,7 +905,7 @@ __global__ __launch_bounds__(512) void knn_feat_k(const float *__restrict__ X, c
         const int i = p[l] < KB ? mi[s0 + l * KB + p[l]] : 0x7fffffff;
         if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bl = l; }
       }
-      o[t] = bi;
+      o[t] = sane_index_at(4, bi, N, t);
 #pragma unroll
       for (int l = 0; l < 4; ++l) p[l] += bl == l ? 1 : 0;
     }

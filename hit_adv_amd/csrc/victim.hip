@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void max_over_points_merge(const float *__rest
   if (bias != nullptr) best = best + bias[c];  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
   if (relu) best = best > 0.f ? best : 0.f;    // max and ReLU commute
   out[e] = best;
-  idx[e] = bi;
+  idx[e] = max(bi, 0);
 }
 
 
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__
       if (S == 1 && tickets != nullptr) {  // nothing to merge: finish here
         float v = bv[cb] + (bias ? bias[c] : 0.f);  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
         out[(size_t)b * Cout + c] = relu ? (v > 0.f ? v : 0.f) : v;  // max and ReLU commute
-        idx[(size_t)b * Cout + c] = bi[cb];
+        idx[(size_t)b * Cout + c] = max(bi[cb], 0);
       } else {
         const size_t o = ((size_t)b * S + s) * Cout + c;
         __hip_atomic_store(&pval[o], bv[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NT) void linear_max_fwd_k(const float *__restrict__
     }
     best += bias ? bias[c] : 0.f;
     out[(size_t)b * Cout + c] = relu ? (best > 0.f ? best : 0.f) : best;
-    idx[(size_t)b * Cout + c] = bidx;
+    idx[(size_t)b * Cout + c] = max(bidx, 0);
   }
   if (threadIdx.x == 0) __hip_atomic_store(&tickets[b * ncg + cg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
         if (FLAT || S == 1) {  // nothing to merge: finish here
           float v = bv[ct] + (bias ? bias[c] : 0.f);  // rounding is monotonic: max_n(y_n + b) == max_n(y_n) + b
           out[(size_t)b * Cout + c] = relu ? (v > 0.f ? v : 0.f) : v;  // max and ReLU commute
-          idx[(size_t)b * Cout + c] = bi[ct];
+          idx[(size_t)b * Cout + c] = max(bi[ct], 0);  // (-1 only if every value was NaN: the range flag is up, the table stays valid)
         } else {
           const size_t o = ((size_t)b * S + s) * Cout + c;
           __hip_atomic_store(&pval[o], bv[ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
     }
     best += bias ? bias[c] : 0.f;
     out[(size_t)b * Cout + c] = relu ? (best > 0.f ? best : 0.f) : best;
-    idx[(size_t)b * Cout + c] = bidx;
+    idx[(size_t)b * Cout + c] = max(bidx, 0);
   }
   if (threadIdx.x == 0) __hip_atomic_store(&tickets[b * ncg + cg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

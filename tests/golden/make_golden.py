@@ -371,6 +371,92 @@ def g5c():
     save('g5c_attack_long.npz', out)
 
 
+
+def g5d(steps=2, iters=50):
+    """The headline configuration's victim at a horizon that means something: the imported reference's
+    HiT_ADV.attack on cfg2's shape -- seeded PointNetFeatureModel (the reference's own class) with shaken BatchNorm
+    statistics, B=32, N=1024, C=192, T=256, eval.py's hyper-parameters, binary_step=2 x num_iter=50.  The victim seed /
+    shake were chosen (tools/explore_success.py, on the GPU build) so that some clouds succeed in both steps, some in the
+    first only and some never: every branch of the best-tracking and of the bisection fires.  Stored: per iteration the
+    logits, adv_loss and the per-sample distance the bookkeeping compares; (P, sigma) every tenth iteration; the deformed
+    clouds at iterations 0 and 49 of each step; the reference's own bookkeeping variables after each step (sys.settrace);
+    the returned clouds and success count.  Weights are NOT stored: they are torch.manual_seed(0) + the default
+    initialisation + Dataset.synthetic.shake_bn(seed=2), a checksum of every tensor is."""
+    from model.feature_models import PointNetFeatureModel
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from hit_adv_amd.Dataset.synthetic import shake_bn
+    shake = dict(seed=2, mean_std=0.05, var_spread=0.2)
+    torch.manual_seed(0)
+    model = PointNetFeatureModel(40, normal_channel=False)
+    model.eval()
+    shake_bn(model, **shake)
+    first, seed = 7000, 21
+    data, _ = synth_batch(32, 1024, first=first)
+    with torch.no_grad():
+        clean = model(data[:, :, :3].transpose(1, 2).contiguous())[0]
+    target = clean.argmax(1)
+    hp = dict(attack_lr=1e-2, central_num=192, total_central_num=256, init_weight=10., max_weight=80.,
+              binary_step=steps, num_iter=iters, cd_weight=1e-4, ker_weight=1., hide_weight=1.,
+              curv_loss_knn=16, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+    att = HiT_ADV(model, adv_func=adv_utils.UntargetedLogitsAdvLoss(kappa=30.), **hp)
+    trace = dict(P=[], sigma=[], adv=[], logits=[], adv_loss=[], dist_val=[])
+    cap = {}
+    orig_tl, orig_kd = att.transformation_loss, att.kernel_density
+    count = dict(it=0)
+
+    def tl(adv_data, perturb_mat, gauss_delta, batch_avg=True):
+        out = orig_tl(adv_data, perturb_mat, gauss_delta, batch_avg)
+        if not batch_avg:  # exactly once per iteration (:195): the distance the best-tracking compares
+            it = count['it'] % iters
+            trace['dist_val'].append(out.detach().clone())
+            if it % 10 == 0 or it == iters - 1:
+                trace['P'].append(perturb_mat.detach().clone())
+                trace['sigma'].append(gauss_delta.detach().clone())
+            if it in (0, iters - 1):
+                trace['adv'].append(adv_data.detach().clone())
+            count['it'] += 1
+        return out
+
+    def kd(central_points, pc, delta):
+        cap['central'] = central_points.detach().clone()
+        return orig_kd(central_points, pc, delta)
+
+    class Adv(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, logits, targets):
+            v = self.inner(logits, targets)
+            trace['logits'].append(logits.detach().clone())
+            trace['adv_loss'].append(v.detach().clone())
+            return v
+
+    att.transformation_loss, att.kernel_density = tl, kd
+    att.adv_func = Adv(att.adv_func)
+
+    def run():
+        torch.manual_seed(seed)
+        with redirect_stdout(io.StringIO()):
+            return att.attack(data, target)
+    import time
+    t0 = time.time()
+    (best, succ), rec = watch_bookkeeping(run)
+    print("g5d: reference attack %d x %d at B=32 took %.0f s; success %d / 32" % (steps, iters, time.time() - t0, int(succ)))
+    assert len(rec['steps']) == steps and count['it'] == steps * iters
+    out = {k: torch.stack(v) for k, v in trace.items()}
+    out.update(cap)
+    out.update(best=best, success_num=int(succ), target=target, clean_logits=clean, seed=seed, first=first, model_seed=0,
+               shake_seed=shake['seed'], shake_mean_std=shake['mean_std'], shake_var_spread=shake['var_spread'],
+               taken_step=rec['taken'][:, 0], taken_iter=rec['taken'][:, 1], final_o_bestdist=rec['final']['o_bestdist'],
+               kept_iterations=np.array([i for i in range(iters) if i % 10 == 0 or i == iters - 1]),
+               weight_checksum=np.array([float(v.double().abs().sum()) for v in model.state_dict().values()]))
+    for name in ('lower', 'upper', 'scale_const', 'o_bestdist', 'o_bestscore', 'bestdist', 'bestscore'):
+        out['step_' + name] = np.stack([s_[name] for s_ in rec['steps']])
+    out.update({'hp_' + k: v for k, v in hp.items()})
+    save('g5d_attack_pointnet.npz', out)
+
+
 # ------------------------------------------------------------------ G6
 def g6():
     g = torch.Generator('cpu').manual_seed(21)

@@ -109,3 +109,17 @@ def gradient_close(g, gd, what, frac_bound=2e-3, l2_bound=3e-2):
         dict(what=what + ' (fraction of elements off by > 1e-3, relative L2 error)', max_abs=bad, max_rel=l2,
              max_abs_over_scale=l2, rtol=l2_bound, atol=frac_bound, n=int(g.numel())))
     assert bad <= frac_bound and l2 <= l2_bound, (what, bad, l2)
+
+
+def pointnet_from_fixture(fx):
+    """The PointNet victim of fixture g5d: NOT stored (14 MB) -- it is ``torch.manual_seed(model_seed)`` + the default
+    initialisation + ``shake_bn``; the fixture carries a checksum of every tensor of the reference's own instance."""
+    from hit_adv_amd.Dataset.synthetic import shake_bn
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    torch.manual_seed(int(fx['model_seed']))
+    m = PointNetFeatureModel(40, normal_channel=False).eval()
+    shake_bn(m, seed=int(fx['shake_seed']), mean_std=float(fx['shake_mean_std']), var_spread=float(fx['shake_var_spread']))
+    sums = np.array([float(v.double().abs().sum()) for v in m.state_dict().values()])
+    np.testing.assert_allclose(sums, fx['weight_checksum'], rtol=1e-12, atol=0,
+                               err_msg="the seeded PointNet is not the one the fixture was made with")
+    return m

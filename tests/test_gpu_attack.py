@@ -1411,3 +1411,71 @@ def test_cw_attacks_in_flight_at_once_return_what_the_sequence_returns():
         assert len(s_) == len(p_)
         for x, y in zip(s_, p_):
             assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_cw_attacks_in_flight_survive_an_fp16_range_overflow():
+    """Round 5: a PCT victim whose activations leave fp16's range part of the way into an attack (every weight x 3: logits of
+    a few hundred; the adversarial clouds of AdvPC push a fused layer's input past 65504 after some tens of iterations)
+    under ``CW.attack_concurrently``.  The first attack to finish raises the device's range flag while the other is still
+    replaying; the driver used to close the generators -- dropping their captured graphs and the graphs' memory pools --
+    BEFORE draining the GPU: a memory access fault that took the process down (found by tools/explore_success.py; setup
+    of tools/fault_repro.py advpc+knn).  Now: all attacks are thrown away, the GPU drained, and the plain sequence runs in
+    full-range arithmetic -- the same bits as calling the attacks one after the other, which degrade the same way."""
+    import argparse
+    import warnings
+    from hit_adv_amd import CW
+    from hit_adv_amd.Dataset.synthetic import sharpen
+    from hit_adv_amd.model import _pointwise
+    from hit_adv_amd.model import pct as PCT
+    from hit_adv_amd.util.adv_utils import LogitsAdvLoss
+    from hit_adv_amd.util.clip_utils import ClipPointsLinf
+    from hit_adv_amd.util.dist_utils import ChamferkNNDist, L2Dist
+
+    class AE(torch.nn.Module):  # bench.py's stand-in auto-encoder
+        def __init__(self):
+            super().__init__()
+            self.enc, self.dec = torch.nn.Conv1d(3, 16, 1), torch.nn.Conv1d(16, 3, 1)
+
+        def forward(self, x):
+            return x + 0.05 * self.dec(torch.tanh(self.enc(x)))
+    torch.manual_seed(0)
+    m = sharpen(PCT.Pct(argparse.Namespace(dropout=0.2), output_channels=40).eval(), 3.0).cuda()
+    data, _ = synth_batch(32, 1024, first=7000)
+    xyz = data[:, :, :3].contiguous().cuda()
+    with torch.no_grad():
+        label = m(xyz.transpose(1, 2).contiguous()).argmax(1)
+    target = (label + 1) % 40
+    torch.manual_seed(2)
+    ae = AE().eval().cuda()
+    clip = ClipPointsLinf(budget=0.18)
+    start = torch.get_rng_state()
+
+    def calls():
+        kw = dict(verbose=False)
+        a = CW.CWAdvPC(m, ae, LogitsAdvLoss(kappa=0.), L2Dist(), clip_func=clip, binary_step=2, num_iter=60, **kw)
+        k = CW.CWKNN(m, LogitsAdvLoss(kappa=15.), ChamferkNNDist(), clip, num_iter=300, **kw)
+        return [(a, (xyz, target, label)), (k, (xyz, target))]
+    raised = []
+    inner = _pointwise.check_range
+
+    def counting(device):
+        try:
+            inner(device)
+        except _pointwise.Fp16RangeExceeded:
+            raised.append(1)
+            raise
+    _pointwise.check_range = counting
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            par = CW.attack_concurrently(calls())
+            concurrent_raises = len(raised)
+            torch.set_rng_state(start)
+            seq = [att.attack(*args) for att, args in calls()]
+    finally:
+        _pointwise.check_range = inner
+    assert concurrent_raises >= 1, "the victim did not leave fp16's range: the test tests nothing"
+    for s_, p_ in zip(seq, par):
+        for x, y in zip(s_, p_):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    torch.cuda.synchronize()

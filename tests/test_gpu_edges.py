@@ -188,3 +188,42 @@ def test_hit_adv_pointnet_engine_odd_shapes_graph_equals_eager(B, n):
     adv = torch.from_numpy(res[True][0]).float().transpose(1, 2).contiguous().cuda()
     with torch.no_grad():
         close(m.attack_view()(adv)[0].cpu().numpy(), m(adv)[0].cpu().numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_index_tables_stay_in_range_when_a_cloud_is_not_finite():
+    """A cloud that went NaN / inf (a diverged attack; an fp16-range overflow the caller only learns of when it reads its
+    results back) must not turn into a wild read: the selection kernels start their lists at a sentinel index that a
+    comparison with NaN never replaces, and until round 5 the sentinel reached the gather of the backward pass (a memory
+    access fault under CW.attack_concurrently with a sharpened PCT victim).  Every table that leaves a kernel holds valid
+    rows; the VALUES of the broken cloud stay NaN, the other clouds are untouched."""
+    from hit_adv_amd import ops
+    from hit_adv_amd.util.dist_utils import KNNDist
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 300, 3, generator=g)
+    bad = x.clone()
+    bad[1] = float('nan')          # a whole cloud
+    bad[2, 7] = float('inf')       # one point
+    bad[2, 9, 1] = float('nan')
+    xb = bad.cuda()
+    for K in (1, 6, 17):
+        for form in (ops.FORM_DIRECT, ops.FORM_GRAM_KNN):
+            d, idx = ops.KnnPoints.apply(xb, xb, K, form)
+            assert int(idx.min()) >= 0 and int(idx.max()) < 300, (K, form)
+            d0, i0 = ops.KnnPoints.apply(x[:1].cuda(), x[:1].cuda(), K, form)
+            assert torch.equal(idx[0], i0[0]) and torch.equal(d[0], d0[0])  # the finite cloud: as if alone
+    pc = xb.clone().requires_grad_()
+    loss = KNNDist(k=5)(pc, batch_avg=False)
+    grad, = torch.autograd.grad(loss.sum(), pc)   # used to read p[0x7fffffff * 3]
+    torch.cuda.synchronize()
+    assert torch.isfinite(grad[0]).all()
+    # the 128 -> 1024 layer + max over the points: the arg-max table of a NaN cloud is a valid row too
+    h = torch.randn(2 * 256, 128, generator=g).cuda()
+    h[:256] = float('nan')
+    W = (torch.randn(1024, 128, generator=g) * 0.1).cuda()
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for out in (ops.linear_max_fwd_f16x2(h, ops.split_weights_f16x2(W), 2, 256, relu=True, range_flag=flag),
+                ops.linear_max_fwd_bf16x3(h, ops.split_weights_bf16x3(W), 2, 256, relu=True),
+                ops.linear_max_fwd(h, W.t().contiguous(), 2, 256, relu=True)):
+        arg = out[1]
+        assert int(arg.min()) >= 0 and int(arg.max()) < 256
+    assert int(flag.item()) == 1  # ... and the fp16x2 form said so

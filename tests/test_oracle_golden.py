@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import T, golden, golden_json, hp_from_fixture, toy_from_fixture
+from helpers import T, golden, golden_json, hp_from_fixture, pointnet_from_fixture, synth_batch, toy_from_fixture
 from oracle import hitadv_oracle as O
 
 RT = dict(rtol=1e-5, atol=1e-6)
@@ -177,6 +177,43 @@ def test_g5c_bookkeeping_over_ten_binary_steps():
     assert (np.diff(lo, axis=0) > 0).any() and (np.diff(up, axis=0) < 0).any()
     assert ((fx['step_bestscore'] != -1) & (fx['step_bestdist'] > fx['step_o_bestdist'])).any()
     assert (fx['step_bestscore'] == -1).any()
+
+
+def test_g5d_real_pointnet_headline_shape_first_iterations():
+    """Fixture g5d = the imported reference's HiT_ADV.attack on cfg2's own shape (seeded PointNetFeatureModel with shaken BN
+    statistics, B=32, N=1024, C=192, T=256, 2 x 50 iterations).  The whole run takes the oracle five minutes; here its FIRST
+    ELEVEN iterations (the reference draws a step's parameters at the step's start, so they do not depend on num_iter):
+    centres bit-equal, logits' arg-max, adversarial loss, the per-sample distance of the bookkeeping, the first deformed cloud
+    and the parameters after ten Adam steps.  The GPU tests hold all 100 iterations (tests/test_gpu_headline_parity.py)."""
+    fx = golden('g5d_attack_pointnet.npz')
+    model = pointnet_from_fixture(fx)
+    data, _ = synth_batch(32, 1024, first=int(fx['first']))
+    hp = hp_from_fixture(fx)
+    hp.update(binary_step=1, num_iter=11)
+    with torch.no_grad():
+        clean = model(data[:, :, :3].transpose(1, 2).contiguous())[0]
+    close(clean, fx['clean_logits'], rtol=0, atol=1e-6)
+    assert (clean.argmax(1).numpy() == fx['target']).all()
+    oracle = O.HiTADVOracle(model, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), **hp)
+    trace = []
+    torch.manual_seed(int(fx['seed']))
+    oracle.attack(data, T(fx['target']), trace=trace)
+    assert torch.equal(oracle.state['central'], T(fx['central']))
+    margin = np.sort(fx['logits'], -1)
+    margin = margin[..., -1] - margin[..., -2]
+    for i, rec in enumerate(trace):
+        sure = margin[i] > 1e-5
+        assert (rec['pred'][sure] == fx['logits'][i].argmax(1)[sure]).all(), i
+        close(rec['adv_loss'], fx['adv_loss'][i], rtol=1e-5, atol=1e-6)
+        close(rec['dist_val'], fx['dist_val'][i], rtol=1e-5, atol=1e-7)
+    close(trace[0]['adv'], fx['adv'][0], rtol=0, atol=1e-6)
+    assert int(fx['kept_iterations'][1]) == 10
+    close(np.clip(trace[9]['P'], -hp['budget'], hp['budget']), fx['P'][1], rtol=0, atol=1e-6)
+    close(np.clip(trace[9]['sigma'], hp['min_sigm'], hp['max_sigm']), fx['sigma'][1], rtol=0, atol=1e-6)
+    # what the fixture exercises: successes in both steps, in the first only, never; records replaced in both steps
+    lo = fx['step_lower']
+    assert set(np.unique(lo[-1])) == {0., 10., 45.} and 0 < int(fx['success_num']) < 32
+    assert (fx['taken_step'] == 0).any() and (fx['taken_step'] == 1).any()
 
 
 def test_g7_cwknn_trajectory():
