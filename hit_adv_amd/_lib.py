@@ -102,6 +102,7 @@ PROTOTYPES = {
     "hitadv_pointnet_rowmlp_fwd_stn": [_P] * 15 + [_I, _I, _I, _P, _P],
     "hitadv_pointnet_rowmlp_fwd_deform": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "hitadv_pointnet_rowmlp_tiles": [_I],
+    "hitadv_pointnet_rowmlp_form": [_I],
     "hitadv_pointnet_rowmlp_bwd_tiles": [_I, _I],
     "hitadv_pointnet_rowmlp_bwd_words": [_I, _I, _I],
     "hitadv_pointnet_rowmlp_bwd": [_I, _P, _P, _P, _P, _I] + [_P] * 15 + [_I, _I, _I, _I, _P],

@@ -10,14 +10,18 @@ constexpr float LOG2E = 1.4426950408889634f;
 // One block = DF_PTS points of cloud b (tile = which).  CMAX = centres staged per LDS pass.  xs != nullptr: the deformed
 // points of the tile are also left in LDS, xs[3 * lane + d] (zeros past N), for a caller that goes on with them
 // (csrc/pointnet.hip: the PointNet engine's first kernel).
+// LDS the body needs, in float4: CMAX (centre + exponent scale) + CMAX (translation) + 4 * DF_PTS (the waves' partial sums)
 template <int CMAX>
-__device__ __forceinline__ void deform_fwd_body(const float *__restrict__ ori, const float *__restrict__ central,
-                                                const float *__restrict__ perturb, const float *__restrict__ sigma, int N,
-                                                int C, float *__restrict__ adv, float *__restrict__ inv_den, const int b,
-                                                const int tile, float *xs) {
-  __shared__ float4 sc[CMAX];  // cx cy cz a
-  __shared__ float4 sp[CMAX];  // px py pz -
-  __shared__ float4 part[4][DF_PTS];
+__host__ __device__ constexpr int deform_fwd_lds_float4() { return 2 * CMAX + 4 * DF_PTS; }
+
+template <int CMAX>
+__device__ __forceinline__ void deform_fwd_body_in(float4 *lds, const float *__restrict__ ori, const float *__restrict__ central,
+                                                   const float *__restrict__ perturb, const float *__restrict__ sigma, int N,
+                                                   int C, float *__restrict__ adv, float *__restrict__ inv_den, const int b,
+                                                   const int tile, float *xs) {
+  float4 *const sc = lds;                // cx cy cz a
+  float4 *const sp = lds + CMAX;         // px py pz -
+  float4(*const part)[DF_PTS] = reinterpret_cast<float4(*)[DF_PTS]>(lds + 2 * CMAX);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = tile * DF_PTS + lane;
   const int nn = n < N ? n : N - 1;
@@ -75,6 +79,16 @@ __device__ __forceinline__ void deform_fwd_body(const float *__restrict__ ori, c
   } else if (wave == 0 && xs != nullptr) {
     xs[3 * lane] = xs[3 * lane + 1] = xs[3 * lane + 2] = 0.f;
   }
+}
+
+// ... with LDS of its own (csrc/deform.hip, rowmlp_fwd_k / rowmlp_fwd16_k)
+template <int CMAX>
+__device__ __forceinline__ void deform_fwd_body(const float *__restrict__ ori, const float *__restrict__ central,
+                                                const float *__restrict__ perturb, const float *__restrict__ sigma, int N,
+                                                int C, float *__restrict__ adv, float *__restrict__ inv_den, const int b,
+                                                const int tile, float *xs) {
+  __shared__ float4 lds[deform_fwd_lds_float4<CMAX>()];
+  deform_fwd_body_in<CMAX>(lds, ori, central, perturb, sigma, N, C, adv, inv_den, b, tile, xs);
 }
 
 

@@ -313,6 +313,24 @@ __device__ __forceinline__ void load_w16(const float *__restrict__ W, int ldw, i
   for (int s = 0; s < K / 16; ++s) split8v(v[s], wh[s], wl[s]);
 }
 
+// the same fragments, one 16-deep slice at a time (8 values in flight instead of K / 2: for a reload inside a loop that holds
+// other things in registers; its latency is paid once per cloud)
+template <int K, bool TRANSB>
+__device__ __forceinline__ void load_w16_seq(const float *__restrict__ W, int ldw, int col, int r, int h, uint4 (&wh)[K / 16],
+                                             uint4 (&wl)[K / 16]) {
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = 16 * s + 8 * h + i;
+      v[i] = TRANSB ? W[(size_t)(col + r) * ldw + k] : W[(size_t)k * ldw + col + r];
+    }
+    split8v(v, wh[s], wl[s]);
+    asm volatile("" ::: "memory");  // (keeps the slices' loads from being hoisted together again)
+  }
+}
+
 // acc[rb] += A[row_base + 32 rb .. +32)[0..K) @ B: three MFMAs per 16 values of k (lo x hi and hi x lo into accl, hi x hi into acc)
 template <int K, int NRB>
 __device__ __forceinline__ void mfma_apply16(const char *th, const char *tl, int ld, int row_base, const uint4 (&wh)[K / 16],
@@ -441,7 +459,11 @@ __global__ __launch_bounds__(256) void rowmlp_fwd16_k(RowMlpFwd a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int n = 32 * rb + acc_row(e, h), c = 32 * cb + r;
-      const float v = joined(acc[0], accl[0], e);
+      float v = joined(acc[0], accl[0], e);
+      // the pieces are the split of the fp32 value that is STORED: without this the compiler folds the fma above and the
+      // conversion to fp16 into one v_fma_mixlo_f16 (a single rounding of the exact fma: another hi piece in 1 of ~8000
+      // values; found in round 5 when rowmlp_stream_k, which splits the rounded value, differed in 0.4 % of the rows)
+      asm volatile("" : "+v"(v));
       put_pieces(tA[0], tA[1], PM_LH64, n, c, v);
       if (a.o0 != nullptr && n < rows) a.o0[(row0 + n) * 64 + c] = v;
     }
@@ -494,6 +516,308 @@ __global__ __launch_bounds__(256) void rowmlp_fwd16_k(RowMlpFwd a) {
     }
     if (a.pack_o2 && a.range_flag != nullptr && big.beyond_fp16()) *a.range_flag = 1;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// rowmlp_stream_k (round 5): the SAME layers, the same arithmetic per element -- every value it writes is the bit pattern
+// rowmlp_fwd16_k writes (tests/test_gpu_kernels.py::test_rowmlp_stream_equals_the_tile_kernel) -- with the data movement of
+// csrc/rows_linear.hip.  What the counters said about rowmlp_fwd16_k at the stacked launch size (256 clouds,
+// profiles/r05_loop_traffic.json): 45.5 / 26.7 / 20.1 M vector instructions per launch = 100 % / 65 % / 72 % of the kernel's
+// duration at four cycles each on the chip's 1024 SIMDs -- it is bound by its VECTOR INSTRUCTIONS, not by its stores
+// (2.3-3.7 TB/s) and not by latency: ~1600 per wave and tile, of which a quarter re-loads and re-splits the block's weights
+// for every 64 points, and most of the rest is per-VALUE work: one fp16 conversion pair, two 2-byte LDS stores, one
+// 4-byte global store with its own 64-bit address for every value a layer produces.  Here:
+//   * a workgroup streams `tpb` consecutive 64-point tiles: the weights' pieces are loaded and split ONCE per workgroup
+//     (per cloud for the per-cloud 64 x 64 transform);
+//   * the products are taken TRANSPOSED (A = the weights, B = the activation: D[channel][point]; the same products summed in
+//     the same order over k, so the same bits: tools/tune/mfma_transpose_probe.hip): a lane's accumulator then holds runs of
+//     four consecutive CHANNELS of one point -- pieces are made two per v_cvt_pk_f16_f32 and leave as 8-byte LDS stores,
+//     values as 16-byte ones;
+//   * every result goes to an LDS tile first and leaves as WHOLE ROWS, 16 bytes per lane (MI355X_MICROARCH.md, stores);
+//   * the 3 -> 64 layer keeps its exact-f32 chain, sixteen consecutive channels per thread with the wave's slice of W in SGPRs.
+// LDS (two workgroups per CU): the piece images P1 (first 64-wide activation) and P2 (second, stages 1 / 2), fp32 tiles O64
+// (/ O64b, stage 1) and the 128-wide result tile O128, which ALIASES what is dead by the time it is written:
+//   stage 0:  P1 | [O64 ......... O128]                      52 KB   (O64 has left before the barrier in front of the epilogue;
+//                                                                     the deformation's own LDS is in there too, between tiles)
+//   stage 1:  [P1 | O64 = O128] | P2 | O64b                  72 KB   (P1 and O64 are dead after the middle layer's barrier)
+//   stage 2:  P1 | P2 | [O64 ......... O128]                 71 KB
+constexpr int RS_P = PM_TM * PM_LH64;          // bytes of one 64-wide piece image (64 rows x 144 B)
+constexpr int RS_O64 = PM_TM * PM_L64 * 4;     // bytes of an fp32 64 x 64 tile (row stride 68 floats)
+constexpr int RS_O128 = PM_TM * PM_L128 * 4;   // bytes of a 64 x 128 tile of 32-bit words (row stride 132)
+static_assert(2 * RS_P + RS_O64 >= RS_O128, "stage 1: the 128-wide tile aliases P1 + O64");
+static_assert(deform_fwd_lds_float4<256>() * 16 <= RS_O128, "stage 0: the deformation's LDS is the result tile's");
+template <int STAGE>
+__host__ __device__ constexpr int rowmlp_stream_lds() {
+  return STAGE == 0 ? 2 * RS_P + RS_O128 : (STAGE == 1 ? 4 * RS_P + 2 * RS_O64 : 4 * RS_P + RS_O128);
+}
+
+// D[32 channels of this wave's block][32 points of block pb] += W^T x^T over k = 0..63: weights as the A operand (registers),
+// the activation's piece rows as the B operand.  Per 16 values of k the three MFMAs of mfma_apply16, in its order.
+__device__ __forceinline__ void mfma_cols16(const char *th, const char *tl, int pb, const uint4 (&wh)[4], const uint4 (&wl)[4],
+                                            f32x16 &acc, f32x16 &accl, int r, int h) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const h8v bh = __builtin_bit_cast(h8v, wh[s]), bl = __builtin_bit_cast(h8v, wl[s]);
+    const int o = (32 * pb + r) * PM_LH64 + 2 * (16 * s + 8 * h);
+    const h8v ah = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(th + o));
+    const h8v al = __builtin_bit_cast(h8v, *reinterpret_cast<const uint4 *>(tl + o));
+    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, accl, 0, 0, 0);
+    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, accl, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc, 0, 0, 0);
+  }
+}
+
+// four values -> their fp16 pieces, two words each (hi pieces two per conversion, lo pieces by v_fma_mix: split8v's bits,
+// which are split_pair's: tools/tune/split_probe.hip)
+__device__ __forceinline__ void split4v(const float (&v)[4], uint2 &hi, uint2 &lo) {
+  uint32_t H[2], L[2];
+  const float nsc = -PM_SC;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float s0 = v[2 * p] * PM_SC, s1 = v[2 * p + 1] * PM_SC;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H[p]) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s1));
+  }
+  hi = make_uint2(H[0], H[1]);
+  lo = make_uint2(L[0], L[1]);
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(256, 2) void rowmlp_stream_k(RowMlpFwd a, int tiles_per_cloud, int total_tiles, int tpb) {
+  extern __shared__ __attribute__((aligned(16))) char sRS[];
+  char *const P1h = sRS, *const P1l = sRS + RS_P;
+  char *const P2h = sRS + (STAGE == 1 ? 2 * RS_P + RS_O64 : 2 * RS_P), *const P2l = P2h + RS_P;  // (stages 1, 2)
+  float *const O64 = reinterpret_cast<float *>(sRS + (STAGE == 2 ? 4 * RS_P : 2 * RS_P));
+  float *const O64b = reinterpret_cast<float *>(sRS + 4 * RS_P + RS_O64);  // STAGE 1 only
+  uint32_t *const O128 = STAGE == 1 ? reinterpret_cast<uint32_t *>(sRS) : reinterpret_cast<uint32_t *>(O64);
+  __shared__ float sX[PM_TM * 3], sXp[PM_TM * 3];
+  __shared__ float sTp[4][9], sT[9];
+  __shared__ __attribute__((aligned(16))) float sB2[128], sB1[64];
+  const int N = a.N;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int t_begin = blockIdx.x * tpb, t_end = min(total_tiles, t_begin + tpb);
+  if (t_begin >= t_end) return;
+
+  // the wave's weights, once: the last layer's 32 channels 32 wave .. +31, the middle layer's 32 (wave & 1) .. +31
+  uint4 w2h[4], w2l[4], w1h[4], w1l[4];
+  load_w16<64, false>(a.W2, 128, 32 * wave, r, h, w2h, w2l);
+  if (threadIdx.x < 128) sB2[threadIdx.x] = a.b2[threadIdx.x];
+  if (STAGE == 1 && threadIdx.x < 64) sB1[threadIdx.x] = a.b1[threadIdx.x];
+  const int cb = wave & 1, pbm = wave >> 1;  // middle layer: channel block, point block
+  if (STAGE == 1) load_w16<64, false>(a.W1, 64, 32 * cb, r, h, w1h, w1l);
+  // 3 -> 64: this wave's sixteen channels 16 wave .. +15 (wave-uniform addresses: the compiler keeps them in SGPRs)
+  float w0[3][16], bb0[16];
+  if (STAGE < 2) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      w0[0][c] = a.W0[16 * wave + c];
+      w0[1][c] = a.W0[64 + 16 * wave + c];
+      w0[2][c] = a.W0[128 + 16 * wave + c];
+      bb0[c] = a.b0[16 * wave + c];
+    }
+  }
+  RangeWatch big;
+  int cloud = -1;
+  float4 hin_next[4];
+  auto fetch_hin = [&](int t) {  // STAGE 2: the next tile's 64 x 64 rows, requested a tile ahead
+    const int b = t / tiles_per_cloud, n0 = (t % tiles_per_cloud) * PM_TM;
+    const int rows = min(PM_TM, N - n0);
+    fetch_tile<64>(a.hin + ((size_t)b * N + n0) * 64, rows, hin_next);
+  };
+  if (STAGE == 2) fetch_hin(t_begin);
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int b = t / tiles_per_cloud, tile = t % tiles_per_cloud, n0 = tile * PM_TM;
+    const int rows = min(PM_TM, N - n0);
+    const size_t row0 = (size_t)b * N + n0;
+    const bool new_cloud = b != cloud;  // block-uniform
+    cloud = b;
+    // ------------------------------------------------------------------ phase 0: the tile's input
+    if (STAGE < 2) {
+      if (STAGE == 0 && a.d_ori != nullptr) {
+        // (its LDS is the result tile's: dead between the tiles)
+        deform_fwd_body_in<256>(reinterpret_cast<float4 *>(O128), a.d_ori, a.d_central, a.d_perturb, a.d_sigma, N, a.d_C, a.d_adv, a.d_inv, b,
+                                tile, sX);
+      } else if (threadIdx.x < 192) {
+        const int c = threadIdx.x >> 6, n = threadIdx.x & 63;
+        sX[n * 3 + c] = n < rows ? a.x[((size_t)b * 3 + c) * N + n0 + n] : 0.f;
+      }
+      const bool ownT = STAGE == 1 && a.F5 != nullptr;  // block-uniform
+      if (ownT && new_cloud) {  // STN3d's last layer for this cloud: rowmlp_fwd16_k's evaluation, once per cloud and workgroup
+        const float f = a.F5[(size_t)b * 256 + threadIdx.x];
+        float p[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) p[q] = f * a.W6[threadIdx.x * 9 + q];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+          for (int q = 0; q < 9; ++q) p[q] += __shfl_xor(p[q], m, HITADV_WAVE);
+        if (lane < 9) {
+          float v = p[0];
+#pragma unroll
+          for (int q = 1; q < 9; ++q) v = lane == q ? p[q] : v;
+          sTp[wave][lane] = v;
+        }
+      }
+      __syncthreads();
+      if (ownT && new_cloud) {
+        if (threadIdx.x < 9) {
+          const float v = ((sTp[0][threadIdx.x] + sTp[1][threadIdx.x]) + sTp[2][threadIdx.x]) + sTp[3][threadIdx.x] + a.b6[threadIdx.x];
+          sT[threadIdx.x] = v;
+          if (tile == 0) a.Tout[(size_t)b * 9 + threadIdx.x] = v;
+        }
+        __syncthreads();
+      }
+      if (STAGE == 0 && a.range_flag != nullptr && threadIdx.x < 192) {  // a cloud that is not finite (see rowmlp_fwd16_k)
+        RangeWatch xw;
+        xw.see(sX[threadIdx.x]);
+        if (xw.beyond_fp16()) *a.range_flag = 1;
+      }
+      const float *xin = sX;
+      if (STAGE == 1) {  // x' = x @ T3
+        if (threadIdx.x < 192) {
+          const int n = threadIdx.x / 3, j = threadIdx.x % 3;
+          const float *T = ownT ? sT : a.T + (size_t)b * 9;
+          const float v = fmaf(sX[n * 3 + 2], T[6 + j], fmaf(sX[n * 3 + 1], T[3 + j], sX[n * 3] * T[j]));
+          sXp[threadIdx.x] = v;
+          if (a.xp != nullptr && n < rows) a.xp[row0 * 3 + threadIdx.x] = v;
+        }
+        __syncthreads();
+        xin = sXp;
+      }
+      {  // 3 -> 64, ReLU: point `lane`, channels 16 wave .. +15
+        const float x0 = xin[lane * 3], x1 = xin[lane * 3 + 1], x2 = xin[lane * 3 + 2];
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const float y = fmaf(x2, w0[2][c], fmaf(x1, w0[1][c], fmaf(x0, w0[0][c], bb0[c])));
+          v[c] = y > 0.f ? y : 0.f;
+        }
+        float *so = O64 + lane * PM_L64 + 16 * wave;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(so + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float v8[8] = {v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]};
+          uint4 hi, lo;
+          split8v(v8, hi, lo);
+          *reinterpret_cast<uint4 *>(P1h + lane * PM_LH64 + 2 * (16 * wave + 8 * q)) = hi;
+          *reinterpret_cast<uint4 *>(P1l + lane * PM_LH64 + 2 * (16 * wave + 8 * q)) = lo;
+        }
+      }
+    } else {  // STAGE 2: h1's rows (in registers since the last tile) -> pieces; the cloud's 64 x 64 transform as weights
+      if (new_cloud) load_w16_seq<64, false>(a.T + (size_t)b * 4096, 64, 32 * cb, r, h, w1h, w1l);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const int n = e / 16, c = 4 * (e % 16);
+        const float v4[4] = {hin_next[u].x, hin_next[u].y, hin_next[u].z, hin_next[u].w};
+        uint2 hi, lo;
+        split4v(v4, hi, lo);
+        *reinterpret_cast<uint2 *>(P1h + n * PM_LH64 + 2 * c) = hi;
+        *reinterpret_cast<uint2 *>(P1l + n * PM_LH64 + 2 * c) = lo;
+      }
+      if (t + 1 < t_end) fetch_hin(t + 1);
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ phase 1: the first activation leaves; the middle layer
+    auto leave64 = [&](const float *src, float *dst) {  // an fp32 64 x 64 tile -> global, whole rows
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const int n = e >> 4, c4 = e & 15;
+        const float4 v = *reinterpret_cast<const float4 *>(src + n * PM_L64 + 4 * c4);
+        if (n < rows) *reinterpret_cast<float4 *>(dst + (row0 + n) * 64 + 4 * c4) = v;
+      }
+    };
+    if (STAGE < 2) leave64(O64, a.o0);
+    const char *inH = P1h, *inL = P1l;
+    if (STAGE >= 1) {  // STAGE 1: t1 = relu(W1 e1 + b1); STAGE 2: h1' = h1 @ T64 (no bias, no ReLU)
+      f32x16 acc, accl;
+      zero(acc);
+      zero(accl);
+      mfma_cols16(P1h, P1l, pbm, w1h, w1l, acc, accl, r, h);
+      const int n = 32 * pbm + r;
+      float *so = (STAGE == 1 ? O64b : O64) + n * PM_L64 + 32 * cb + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v4[4];
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (STAGE == 1) bv = *reinterpret_cast<const float4 *>(sB1 + 32 * cb + 8 * g + 4 * h);
+        const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = joined(acc, accl, 4 * g + i);
+          if (STAGE == 1) {
+            v = v + bq[i];
+            v = v > 0.f ? v : 0.f;
+          }
+          v4[i] = v;
+        }
+        *reinterpret_cast<float4 *>(so + 8 * g) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        uint2 hi, lo;
+        split4v(v4, hi, lo);
+        *reinterpret_cast<uint2 *>(P2h + n * PM_LH64 + 2 * (32 * cb + 8 * g + 4 * h)) = hi;
+        *reinterpret_cast<uint2 *>(P2l + n * PM_LH64 + 2 * (32 * cb + 8 * g + 4 * h)) = lo;
+      }
+      __syncthreads();
+      if (STAGE == 1) leave64(O64b, a.o1);
+      else if (a.o0 != nullptr) leave64(O64, a.o0);
+      inH = P2h;
+      inL = P2l;
+    }
+    // ------------------------------------------------------------------ phase 2: 64 -> 128, ReLU, one 32-point block at a time
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x16 acc2, accl2;
+      zero(acc2);
+      zero(accl2);
+      mfma_cols16(inH, inL, q, w2h, w2l, acc2, accl2, r, h);
+      // stages 0 / 2: O64 (under the result tile) has been read by everybody (stage 1: its barrier is the middle layer's)
+      if (STAGE != 1 && q == 0) __syncthreads();
+      const int n = 32 * q + r;
+      uint32_t *so = O128 + n * PM_L128 + 32 * wave + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v4[4];
+        const float4 bv = *reinterpret_cast<const float4 *>(sB2 + 32 * wave + 8 * g + 4 * h);
+        const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float pre = joined(acc2, accl2, 4 * g + i) + bq[i];
+          v4[i] = pre > 0.f ? pre : 0.f;
+          if (a.pack_o2) big.see_relu(pre, v4[i]);
+        }
+        uint4 w;
+        if (a.pack_o2) {  // block-uniform: one word per value, fp16 hi | fp16 lo << 16
+          uint2 hi, lo;
+          split4v(v4, hi, lo);
+          w.x = (hi.x & 0xffffu) | (lo.x << 16);
+          w.y = (hi.x >> 16) | (lo.x & 0xffff0000u);
+          w.z = (hi.y & 0xffffu) | (lo.y << 16);
+          w.w = (hi.y >> 16) | (lo.y & 0xffff0000u);
+        } else {
+          w = make_uint4(__float_as_uint(v4[0]), __float_as_uint(v4[1]), __float_as_uint(v4[2]), __float_as_uint(v4[3]));
+        }
+        *reinterpret_cast<uint4 *>(so + 8 * g) = w;
+      }
+    }
+    __syncthreads();
+    {  // the 64 x 128 tile leaves, 512 bytes per row
+      uint32_t *dst = reinterpret_cast<uint32_t *>(a.o2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const int n = e >> 5, c4 = e & 31;
+        const uint4 v = *reinterpret_cast<const uint4 *>(O128 + n * PM_L128 + 4 * c4);
+        if (n < rows) *reinterpret_cast<uint4 *>(dst + (row0 + n) * 128 + 4 * c4) = v;
+      }
+    }
+    __syncthreads();  // the tile's LDS is free again
+  }
+  if (a.pack_o2 && a.range_flag != nullptr && big.beyond_fp16()) *a.range_flag = 1;
 }
 
 // dA2[D,32 columns of this wave] = S[D,M] @ W3r[list,:]: the gather of the max-pool gradient as MFMAs.  S[i,k] = g_k if
@@ -1765,6 +2089,45 @@ static void fc_split(int B, int K, int NOUT, int *chunk, int *KS, int *tiles) {
 
 using namespace hitadv;
 
+// which kernel serves the fp16 modes of hitadv_pointnet_rowmlp_fwd*: 0 = rowmlp_stream_k (default), 1 = rowmlp_fwd16_k (one
+// 64-point tile per workgroup: the round-3 kernel, kept as the reference the streaming one is held to, bit for bit)
+static int g_rowmlp_form = 0;
+extern "C" int hitadv_pointnet_rowmlp_form(int form) {
+  const int before = g_rowmlp_form;
+  if (form == 0 || form == 1) g_rowmlp_form = form;
+  return before;
+}
+
+template <int STAGE>
+static int launch_rowmlp_stream(const RowMlpFwd &a, int B, hipStream_t s) {
+  const int tpc = (a.N + PM_TM - 1) / PM_TM;  // tiles per cloud
+  const long long total = (long long)B * tpc;
+  if (total > 0x7fffffffLL) return HITADV_E_ARG;
+  // two workgroups per CU; a workgroup's run of tiles is a whole number of clouds or a whole fraction of one (the per-cloud
+  // work -- STN3d's last layer, the 64 x 64 transform's pieces -- is then done once per run)
+  int tpb = (int)((total + 511) / 512);
+  if (tpb >= tpc) tpb = ((tpb + tpc - 1) / tpc) * tpc;
+  else
+    while (tpc % tpb) ++tpb;
+  const int blocks = (int)((total + tpb - 1) / tpb);
+  constexpr int shm = rowmlp_stream_lds<STAGE>();
+  HITADV_RAISE_LDS((&rowmlp_stream_k<STAGE>), shm);
+  rowmlp_stream_k<STAGE><<<blocks, 256, shm, s>>>(a, tpc, (int)total, tpb);
+  return 0;
+}
+static int launch_rowmlp16(int stage, const RowMlpFwd &a, int B, hipStream_t s) {
+  if (g_rowmlp_form == 0) {
+    if (stage == 0) return launch_rowmlp_stream<0>(a, B, s);
+    if (stage == 1) return launch_rowmlp_stream<1>(a, B, s);
+    return launch_rowmlp_stream<2>(a, B, s);
+  }
+  dim3 grid((a.N + PM_TM - 1) / PM_TM, B);
+  if (stage == 0) rowmlp_fwd16_k<0><<<grid, 256, 0, s>>>(a);
+  else if (stage == 1) rowmlp_fwd16_k<1><<<grid, 256, 0, s>>>(a);
+  else rowmlp_fwd16_k<2><<<grid, 256, 0, s>>>(a);
+  return 0;
+}
+
 extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float *T, const float *hin, const float *W0,
                                           const float *b0, const float *W1, const float *b1, const float *W2,
                                           const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N,
@@ -1779,9 +2142,8 @@ extern "C" int hitadv_pointnet_rowmlp_fwd(int stage, const float *x, const float
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
   hipStream_t s = (hipStream_t)stream;
   if (mode >= 1) {
-    if (stage == 0) rowmlp_fwd16_k<0><<<grid, 256, 0, s>>>(a);
-    else if (stage == 1) rowmlp_fwd16_k<1><<<grid, 256, 0, s>>>(a);
-    else rowmlp_fwd16_k<2><<<grid, 256, 0, s>>>(a);
+    const int rc = launch_rowmlp16(stage, a, B, s);
+    if (rc != 0) return rc;
   } else if (stage == 0) rowmlp_fwd_k<0><<<grid, 256, 0, s>>>(a);
   else if (stage == 1) rowmlp_fwd_k<1><<<grid, 256, 0, s>>>(a);
   else rowmlp_fwd_k<2><<<grid, 256, 0, s>>>(a);
@@ -1801,8 +2163,10 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, c
   RowMlpFwd a{x, nullptr, nullptr, W0, b0, W1, b1, W2, b2, xp, o0, o1, o2, N, F5, W6, b6, Tout,
               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, mode == 2, range_flag};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
-  if (mode >= 1) rowmlp_fwd16_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  else rowmlp_fwd_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  if (mode >= 1) {
+    const int rc = launch_rowmlp16(1, a, B, (hipStream_t)stream);
+    if (rc != 0) return rc;
+  } else rowmlp_fwd_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   HITADV_LAUNCH_CHECK();
   return 0;
 }
@@ -1818,8 +2182,10 @@ extern "C" int hitadv_pointnet_rowmlp_fwd_deform(const float *ori, const float *
   RowMlpFwd a{adv, nullptr, nullptr, W0, b0, nullptr, nullptr, W2, b2, nullptr, o0, nullptr, o2, N, nullptr, nullptr, nullptr,
               nullptr, ori, central, perturb, sigma, adv, inv_den, C, mode == 2, range_flag};
   dim3 grid((N + PM_TM - 1) / PM_TM, B);
-  if (mode >= 1) rowmlp_fwd16_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  else rowmlp_fwd_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  if (mode >= 1) {
+    const int rc = launch_rowmlp16(0, a, B, (hipStream_t)stream);
+    if (rc != 0) return rc;
+  } else rowmlp_fwd_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   HITADV_LAUNCH_CHECK();
   return 0;
 }

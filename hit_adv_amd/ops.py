@@ -722,6 +722,12 @@ def pointnet_rowmlp_tiles(N):
     return int(_lib.load().hitadv_pointnet_rowmlp_tiles(N))
 
 
+def pointnet_rowmlp_form(form=-1):
+    """0: the streaming forward kernel (default), 1: one 64-point tile per workgroup (the same bits; include/hitadv.h).
+    Process-wide; returns the previous value; no argument only reads."""
+    return int(_lib.load().hitadv_pointnet_rowmlp_form(int(form)))
+
+
 def pointnet_rowmlp_bwd_tiles(B, N, mode=0, words=None):
     """(tiles, words): a block of ``pointnet_rowmlp_bwd`` covers ``words`` 64-point words of a cloud (None: what the library
     recommends for this launch size); the per-tile partials are [B, tiles, .] and the row-presence tables int64

@@ -359,6 +359,12 @@ int hitadv_pointnet_rowmlp_fwd_stn(const float *x, const float *F5, const float 
                                    const float *b2, float *xp, float *o0, float *o1, float *o2, int B, int N, int mode,
                                    int32_t *range_flag, void *stream);
 int64_t hitadv_pointnet_rowmlp_tiles(int N);
+/* Which kernel serves modes 1 / 2 of the three forward entry points above: 0 (default) = the STREAMING form (round 5: a
+ * workgroup takes a run of tiles, weights split once per workgroup, transposed products so that pieces and results leave a
+ * lane four channels at a time, every result row-wise through an LDS tile); 1 = one 64-point tile per workgroup (the round-3
+ * kernel).  The two write the same bits; the switch exists so that a test can say so and a profile can compare them.
+ * Process-wide; returns the previous value; any other argument only reads. */
+int hitadv_pointnet_rowmlp_form(int form);
 /* Input-gradient chain of the same stages, starting at the max-pooled output of the stage's 128->Cout layer:
  * dg [B,Cout] is the gradient there, idx [B,Cout] the arg-max point of every channel (hitadv_linear_max_fwd),
  * gmask [B,Cout] the ReLU'd forward output (NULL when that layer has no ReLU), W3r [Cout,128] the layer's weights.

@@ -1741,3 +1741,72 @@ def test_offset_attention_norm_matches_torch_composition(A, B, N):
     odd = torch.randn(2, 100, 100, device='cuda')
     S2 = torch.softmax(odd, dim=-1)
     assert torch.equal(A.offset_attention_norm(odd), S2 / (1e-9 + S2.sum(dim=1, keepdim=True)))
+
+
+@pytest.mark.parametrize("B,Np", [(3, 1000), (2, 64), (5, 130), (64, 1024), (9, 2048)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_rowmlp_stream_equals_the_tile_kernel(A, B, Np, mode):
+    """Round 5: the streaming forward kernel of the PointNet engine's shared layers (rowmlp_stream_k: a workgroup takes a
+    run of tiles, weights split once, transposed products, results row-wise through LDS) writes the bits of the round-3
+    kernel (one 64-point tile per workgroup) -- all three stages, the deformation and the input transform evaluated inside,
+    packed and unpacked 128-wide activation, ragged last tiles, runs of tiles that cross clouds (B = 64 x 16 tiles = 2 per
+    workgroup ... B = 9 x 32 tiles) -- and raises the range flag on the same inputs."""
+    g = torch.Generator().manual_seed(B * 7 + Np + mode)
+    C, R = 48, B * Np
+    ori = cu(torch.randn(B, 3, Np, generator=g) * 0.4)
+    central = ori[:, :, :C].contiguous()
+    P, S = cu((torch.rand(B, C, 3, generator=g) - 0.5) * 0.5), cu(0.1 + 1.1 * torch.rand(B, C, generator=g))
+    W0, b0 = cu(torch.randn(3, 64, generator=g)), cu(torch.randn(64, generator=g))
+    W1, b1 = cu(torch.randn(64, 64, generator=g) * 0.2), cu(torch.randn(64, generator=g))
+    W2, b2 = cu(torch.randn(64, 128, generator=g) * 0.2), cu(torch.randn(128, generator=g))
+    T3 = cu(torch.eye(3).repeat(B, 1, 1) + 0.1 * torch.randn(B, 3, 3, generator=g)).reshape(B, 9).contiguous()
+    T64 = cu(torch.eye(64).repeat(B, 1, 1) + 0.05 * torch.randn(B, 64, 64, generator=g)).contiguous()
+    F5, W6, b6 = cu(torch.randn(B, 256, generator=g).relu()), cu(torch.randn(256, 9, generator=g) * 0.05), cu(torch.randn(9, generator=g))
+    hin = cu(torch.randn(R, 64, generator=g).relu())
+
+    def run(form):
+        before = A.pointnet_rowmlp_form(form)
+        try:
+            out = {}
+            flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+            new = lambda *shape: torch.full(shape, float('nan'), device='cuda')  # noqa: E731
+            # stage 0 on a given cloud, and with the deformation inside
+            o0, o2 = new(R, 64), new(R, 128)
+            A.pointnet_rowmlp_fwd(0, B, Np, W2, b2, o2, x=ori, W0=W0, b0=b0, o0=o0, mode=mode, range_flag=flag)
+            out['s0'] = (o0, o2)
+            adv, inv, o0, o2 = new(B, 3, Np), new(B, Np), new(R, 64), new(R, 128)
+            A.pointnet_rowmlp_fwd_deform(B, Np, ori, central, P, S, adv, inv, W0, b0, W2, b2, o0, o2, mode=mode, range_flag=flag)
+            out['s0d'] = (adv, inv, o0, o2)
+            # stage 1 with a given transform, and with STN3d's last layer inside
+            xp, o0, o1, o2 = new(R, 3), new(R, 64), new(R, 64), new(R, 128)
+            A.pointnet_rowmlp_fwd(1, B, Np, W2, b2, o2, x=ori, T=T3, W0=W0, b0=b0, W1=W1, b1=b1, xp=xp, o0=o0, o1=o1, mode=mode,
+                                  range_flag=flag)
+            out['s1'] = (xp, o0, o1, o2)
+            Tout, xp, o0, o1, o2 = new(B, 9), new(R, 3), new(R, 64), new(R, 64), new(R, 128)
+            A.pointnet_rowmlp_fwd_stn(B, Np, ori, F5, W6, b6, Tout, W0, b0, W1, b1, W2, b2, o0, o1, o2, xp=xp, mode=mode, range_flag=flag)
+            out['s1t'] = (Tout, xp, o0, o1, o2)
+            # stage 2, with and without its 64-wide output
+            o0, o2 = new(R, 64), new(R, 128)
+            A.pointnet_rowmlp_fwd(2, B, Np, W2, b2, o2, T=T64, hin=hin, o0=o0, mode=mode, range_flag=flag)
+            out['s2'] = (o0, o2)
+            o2 = new(R, 128)
+            A.pointnet_rowmlp_fwd(2, B, Np, W2, b2, o2, T=T64, hin=hin, mode=mode, range_flag=flag)
+            out['s2n'] = (o2,)
+            out['flag'] = (flag.clone(),)
+            # a value beyond fp16's range raises the flag in both forms (mode 2 watches)
+            big = hin.clone()
+            big[R // 2, 5] = 7e4
+            flag2 = torch.zeros(1, dtype=torch.int32, device='cuda')
+            A.pointnet_rowmlp_fwd(2, B, Np, W2 * 50., b2, new(R, 128), T=T64, hin=big, mode=mode, range_flag=flag2)
+            out['flag_big'] = (flag2,)
+            torch.cuda.synchronize()
+            return out
+        finally:
+            A.pointnet_rowmlp_form(before)
+    tile, stream = run(1), run(0)
+    for key in tile:
+        for i, (x, y) in enumerate(zip(tile[key], stream[key])):
+            assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y), (key, i)
+    assert int(tile['flag'][0]) == 0
+    if mode == 2:
+        assert int(tile['flag_big'][0]) == 1

@@ -3,8 +3,8 @@
 
     python tools/loop_pmc_summary.py OUT.json WRITE.csv FETCH.csv [SQ1.csv SQ2.csv ...]
 
-A kernel belongs to the LOOP if it was launched a multiple of 39 times (the probe runs 3 stacks x 13 iterations; setup kernels
-come in multiples of 24); every kernel's launch count is listed under `all_kernels`.  HBM bytes per MI355X_MICROARCH.md: counters in KiB, WRITE_SIZE exact, FETCH_SIZE doubled (gfx950 reports half
+Dispatches up to the last setup-only kernel (FPS / kNN tables) are dropped; of the rest a kernel belongs to the LOOP if it was
+launched a multiple of 39 times (3 stacks x 13 iterations); every kernel's launch count is listed under `all_kernels`.  HBM bytes per MI355X_MICROARCH.md: counters in KiB, WRITE_SIZE exact, FETCH_SIZE doubled (gfx950 reports half
 the bytes of a wide coalesced read stream); both raw figures are kept.  Everything is per STACKED iteration (eight attacks of
 32 clouds); `per_b32_iteration` divides by eight."""
 import collections
@@ -17,8 +17,13 @@ ITER, STACK = 39, 8  # 3 stacks x 13 iterations; 8 attacks per stack
 
 def load(path):
     per = collections.defaultdict(lambda: collections.defaultdict(float))  # (kernel, dispatch) -> counter -> value (summed over XCDs / SEs)
-    for r in csv.DictReader(open(path)):
-        # the setup's own victim pass (get_gradient, B = 32) launches the loop's kernels too: the grid tells them apart
+    rows = list(csv.DictReader(open(path)))
+    # the setups (24 of them, all before the first iteration) launch the victim's kernels too (get_gradient), V1 on the very
+    # grid the loop uses: everything up to the last dispatch of a setup-only kernel (FPS, the kNN tables) is not the loop
+    setup_end = max([int(r['Dispatch_Id']) for r in rows if 'fps<' in r['Kernel_Name'] or 'knn_select' in r['Kernel_Name']] or [0])
+    for r in rows:
+        if int(r['Dispatch_Id']) <= setup_end:
+            continue
         per[(r['Kernel_Name'] + ' grid ' + r.get('Grid_Size', '?'), r['Dispatch_Id'])][r['Counter_Name']] += float(r['Counter_Value'])
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for (k, _), cs in per.items():
