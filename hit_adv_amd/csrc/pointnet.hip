@@ -2089,12 +2089,14 @@ static void fc_split(int B, int K, int NOUT, int *chunk, int *KS, int *tiles) {
 
 using namespace hitadv;
 
-// which kernel serves the fp16 modes of hitadv_pointnet_rowmlp_fwd*: 0 = rowmlp_stream_k (default), 1 = rowmlp_fwd16_k (one
-// 64-point tile per workgroup: the round-3 kernel, kept as the reference the streaming one is held to, bit for bit)
-static int g_rowmlp_form = 0;
+// which kernel serves the fp16 modes of hitadv_pointnet_rowmlp_fwd*: 0 = rowmlp_stream_k, 1 = rowmlp_fwd16_k (one 64-point
+// tile per workgroup: the round-3 kernel, kept as the reference the streaming one is held to, bit for bit), 2 = the
+// streaming kernel except for stage 0 with the deformation inside (its 192 exp / sqrt per point want more waves per SIMD than
+// the streaming kernel's two: 81 vs 86 us per 256 clouds, tools/v2_probe.py)
+static int g_rowmlp_form = 2;
 extern "C" int hitadv_pointnet_rowmlp_form(int form) {
   const int before = g_rowmlp_form;
-  if (form == 0 || form == 1) g_rowmlp_form = form;
+  if (form >= 0 && form <= 2) g_rowmlp_form = form;
   return before;
 }
 
@@ -2116,7 +2118,7 @@ static int launch_rowmlp_stream(const RowMlpFwd &a, int B, hipStream_t s) {
   return 0;
 }
 static int launch_rowmlp16(int stage, const RowMlpFwd &a, int B, hipStream_t s) {
-  if (g_rowmlp_form == 0) {
+  if (g_rowmlp_form == 0 || (g_rowmlp_form == 2 && !(stage == 0 && a.d_ori != nullptr))) {
     if (stage == 0) return launch_rowmlp_stream<0>(a, B, s);
     if (stage == 1) return launch_rowmlp_stream<1>(a, B, s);
     return launch_rowmlp_stream<2>(a, B, s);

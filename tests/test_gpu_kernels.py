@@ -1810,3 +1810,69 @@ def test_rowmlp_stream_equals_the_tile_kernel(A, B, Np, mode):
     assert int(tile['flag'][0]) == 0
     if mode == 2:
         assert int(tile['flag_big'][0]) == 1
+
+
+def _packed_words(h):
+    """fp32 -> one word per value (fp16 hi | fp16 lo << 16, lo = the residual scaled by 2^11): what rowmlp_fwd mode 2 writes."""
+    hi = h.half()
+    lo = ((h - hi.float()) * 2048.).half()
+    return ((hi.view(torch.int16).int() & 0xffff) | (lo.view(torch.int16).int() << 16)).contiguous()
+
+
+@pytest.mark.parametrize("B,Np,blocks", [(256, 1024, 128), (64, 1024, 256), (96, 256, 0), (130, 128, 64)])
+def test_filtered_linear_max_equals_the_full_evaluation(A, B, Np, blocks):
+    """Round 5, csrc/victim_filter.hip: the 128 -> 1024 layer + max over the points with ONE fp16 product per value and the
+    exact evaluation of the candidates only.  Against the unfiltered fp16x2 kernel on the same packed activation: the
+    maxima to fp32 roundoff (both are three exact products per term; the summation orders differ), the arg-max EQUAL wherever
+    the two best exact values of a channel are further apart than that roundoff, and in any case a point whose value is the
+    maximum to roundoff.  The result does not depend on the seeds: zeros, random points, last call's winners -- the same bits."""
+    g = torch.Generator().manual_seed(B + Np)
+    h = cu(torch.randn(B * Np, 128, generator=g).relu() * torch.rand(B * Np, 1, generator=g))  # rows of different norms
+    W = cu(torch.randn(1024, 128, generator=g) * 0.1)
+    bias = cu(torch.randn(1024, generator=g) * 0.1)
+    assert A.linear_max_filter_supported(B, Np, 128, 1024, blocks)
+    xp, W2, wn = _packed_words(h), A.split_weights_f16x2(W), A.weight_row_norms(W)
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    full_v, full_i = A.linear_max_fwd_f16x2(xp, W2, B, Np, bias=bias, relu=True, blocks=blocks, packed=True)
+    outs = []
+    for seeds in (torch.zeros(B, 1024, dtype=torch.int64, device='cuda'),
+                  torch.randint(-5, Np + 5, (B, 1024), generator=g).cuda(),
+                  full_i.clone()):
+        v, i = A.linear_max_fwd_f16x2_filtered(xp, W2, wn, B, Np, seeds, bias=bias, relu=True, blocks=blocks, range_flag=flag)
+        assert torch.equal(seeds, i)  # the winners are left as the next call's seeds
+        outs.append((v, i))
+    assert int(flag.item()) == 0
+    for v, i in outs[1:]:
+        assert torch.equal(v, outs[0][0]) and torch.equal(i, outs[0][1])
+    v, i = outs[0]
+    assert int(i.min()) >= 0 and int(i.max()) < Np
+    scale = float(full_v.abs().max())
+    close(v, full_v, rtol=0, atol=2e-6 * scale, what='maxima')
+    # float64 evaluation of the pieces at both winners
+    hi, lo = h.half().double(), ((h - h.half().float()) * 2048.).half().double()
+    whi, wlo = W.half().double(), ((W - W.half().float()) * 2048.).half().double()
+    def exact(points):  # [B,1024] -> value of channel c at points[b,c]
+        rows = (torch.arange(B, device='cuda')[:, None] * Np + points).reshape(-1)
+        ah, al = hi[rows].view(B, 1024, 128), lo[rows].view(B, 1024, 128)
+        return (ah * whi[None]).sum(-1) + ((al * whi[None]).sum(-1) + (ah * wlo[None]).sum(-1)) / 2048.
+    e_f, e_full = exact(i), exact(full_i)
+    assert float((e_f - e_full).abs().max()) <= 4e-6 * scale       # the filtered winner IS a maximiser (to roundoff)
+    differ = i != full_i
+    note('channels whose arg-max differs from the unfiltered kernel (near-ties)', float(differ.sum()))
+    assert float(differ.double().mean()) < 2e-3
+    assert float((e_f - e_full).abs()[differ].max() if differ.any() else 0.) <= 4e-6 * scale
+
+
+def test_filtered_linear_max_reports_lists_that_do_not_fit(A):
+    """A cloud of IDENTICAL points: every point is a candidate for every channel, no list of 512 holds them -- the kernel
+    must say so (range flag) instead of returning a winner it has not checked."""
+    B, Np = 256, 1024
+    g = torch.Generator().manual_seed(1)
+    h = cu(torch.randn(B * Np, 128, generator=g).relu())
+    h[:Np] = h[0]
+    W = cu(torch.randn(1024, 128, generator=g) * 0.1)
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    seeds = torch.zeros(B, 1024, dtype=torch.int64, device='cuda')
+    A.linear_max_fwd_f16x2_filtered(_packed_words(h), A.split_weights_f16x2(W), A.weight_row_norms(W), B, Np, seeds, relu=True,
+                                    blocks=128, range_flag=flag)
+    assert int(flag.item()) == 1
