@@ -22,7 +22,7 @@
 // (MFMA, VALU chain) each stay within 128 x 2^-24 sum |a||w| of their exact sums; sum_k |a_k| |w_k| <= |a_n| |w_c| (Cauchy-Schwarz).
 // eps = 1.05e-3 > 2^-10 (1 + 2^-11) + 3 x 128 x 2^-24 with 4 % to spare; |a_n| is floored at 1e-3 (covers the subnormal case:
 // 128 x 2^-25 |w|_inf < 1.05e-3 x 1e-3 x |w_c|), and taken from the hi pieces with a 0.2 % allowance.
-// Lists that do not fit (512 entries per cloud and 32 channels: pathological input, e.g. a cloud of identical points) raise the
+// Lists that do not fit (HITADV_V1F_CAP = 2048 entries per cloud and 32 channels: pathological input, e.g. a cloud of identical points) raise the
 // caller's range flag: the attack then runs again on the form without the filter (model/_pointwise.py::degrade_on_fp16_range).
 #include <stdlib.h>
 
@@ -205,7 +205,22 @@ __global__ __launch_bounds__(512) void vf_stream_k(const uint32_t *__restrict__ 
     // the tile's bound: eps |w_c| max_rows |a_n| (hi pieces, 0.2 % allowance; floor: see the header)
     const float a2 = __uint_as_float((uint32_t)sNorm[tile & 1]);
     const float amax = fmaxf(__builtin_sqrtf(a2) * 1.002f, VF_AMIN);
-    const float t0 = fmaf(-ew[0], amax, th[0]), t1 = fmaf(-ew[1], amax, th[1]);
+    // every value of the tile is itself a lower bound of the maximum once its error is taken off: the lane's bound rises with
+    // the stream (a poor seed -- the first iteration of an attack -- costs some tens of candidates per channel, not hundreds)
+    float t01[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float d = ew[ct] * amax;
+      float m = __builtin_fmaxf(__builtin_fmaxf(acc[0][ct][0], acc[0][ct][1]), acc[0][ct][2]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int i = (rt == 0 ? 3 : 0); i < 4; i += 2)
+          m = i + 1 < 4 ? __builtin_fmaxf(__builtin_fmaxf(m, acc[rt][ct][i]), acc[rt][ct][i + 1]) : __builtin_fmaxf(m, acc[rt][ct][i]);
+      th[ct] = __builtin_fmaxf(th[ct], m - d);
+      t01[ct] = th[ct] - d;
+    }
+    const float t0 = t01[0], t1 = t01[1];
     const uint32_t pbase = (uint32_t)(tile_in_cloud * VF_TM + 4 * g4) << 8;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -263,34 +278,41 @@ __global__ __launch_bounds__(256) void vf_refine_k(const uint32_t *__restrict__ 
                                                    const float *__restrict__ bias, int N, int Cout, int relu,
                                                    const uint32_t *__restrict__ cand, const int32_t *__restrict__ ccount,
                                                    float *__restrict__ out, int64_t *__restrict__ idx, int64_t *__restrict__ seed) {
-  __shared__ float sVal[4][VF_CAP];
-  __shared__ uint32_t sE[4][VF_CAP];
+  constexpr int CH = 256;  // entries per pass
+  __shared__ float sVal[4][CH];
+  __shared__ uint32_t sE[4][CH];
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rg = blockIdx.x * 4 + wave;
   if (32 * rg >= Cout) return;
   const size_t region = (size_t)b * (Cout / 32) + rg;
   const int cnt = min(ccount[region], VF_CAP);
   const int q = lane & 15, grp = lane >> 4;
-  for (int i = lane; i < cnt; i += 64) sE[wave][i] = cand[region * VF_CAP + i];
-  for (int e0 = 0; e0 < cnt; e0 += 4) {
-    const int e = min(e0 + grp, cnt - 1);
-    const uint32_t ent = sE[wave][e];
-    const int n = sane_index((int)(ent >> 8), N, 0), c = 32 * rg + (int)(ent & 31u);
-    const float v = vf_exact(Xp + ((size_t)b * N + n) * VF_CIN, W2, Cout, c, q);
-    if (q == 0 && e0 + grp < cnt) sVal[wave][e0 + grp] = v;
-  }
   // lane c of the wave: the best of its channel's entries (ties: the lower point); lanes 32-63 take the odd entries
   const int ch = lane & 31, half = lane >> 5;
   float best = -__builtin_inff();
   int bp = 0x7fffffff;
-  for (int e = half; e < cnt; e += 2) {
-    const uint32_t ent = sE[wave][e];
-    const float v = sVal[wave][e];
-    const int p = (int)(ent >> 8);
-    const bool mine = (int)(ent & 31u) == ch;
-    const bool take = mine && (v > best || (v == best && p < bp));
-    best = take ? v : best;
-    bp = take ? p : bp;
+  for (int c0 = 0; c0 < cnt; c0 += CH) {
+    const int m = min(CH, cnt - c0);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < m; i += 64) sE[wave][i] = cand[region * VF_CAP + c0 + i];
+    __builtin_amdgcn_wave_barrier();
+    for (int e0 = 0; e0 < m; e0 += 4) {
+      const int e = min(e0 + grp, m - 1);
+      const uint32_t ent = sE[wave][e];
+      const int n = sane_index((int)(ent >> 8), N, 0), c = 32 * rg + (int)(ent & 31u);
+      const float v = vf_exact(Xp + ((size_t)b * N + n) * VF_CIN, W2, Cout, c, q);
+      if (q == 0 && e0 + grp < m) sVal[wave][e0 + grp] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int e = half; e < m; e += 2) {
+      const uint32_t ent = sE[wave][e];
+      const float v = sVal[wave][e];
+      const int p = (int)(ent >> 8);
+      const bool mine = (int)(ent & 31u) == ch;
+      const bool take = mine && (v > best || (v == best && p < bp));
+      best = take ? v : best;
+      bp = take ? p : bp;
+    }
   }
   {
     const float ov = __shfl_xor(best, 32, HITADV_WAVE);

@@ -326,7 +326,7 @@ int hitadv_linear_max_fwd_f16x2_packed(const uint32_t *Xp, const uint16_t *W2, c
  *                     channels: pathological input); out / idx are then invalid and the caller uses the unfiltered form
  * Supported (hitadv_linear_max_filter_supported): Cin = 128, Cout a multiple of 256, N a multiple of 128, and at least as
  * many (cloud, 256-channel group) pairs as workgroups (`blocks`, 0 = 256): whole clouds stream through a workgroup. */
-#define HITADV_V1F_CAP 512
+#define HITADV_V1F_CAP 2048
 int hitadv_linear_max_filter_supported(int B, int N, int Cin, int Cout, int blocks);
 int64_t hitadv_linear_max_filter_scratch_words(int B, int Cout);
 int hitadv_linear_max_fwd_f16x2_filtered(const uint32_t *Xp, const uint16_t *W2, const float *wnorm, const float *bias, int B,

@@ -1816,7 +1816,8 @@ def _packed_words(h):
     """fp32 -> one word per value (fp16 hi | fp16 lo << 16, lo = the residual scaled by 2^11): what rowmlp_fwd mode 2 writes."""
     hi = h.half()
     lo = ((h - hi.float()) * 2048.).half()
-    return ((hi.view(torch.int16).int() & 0xffff) | (lo.view(torch.int16).int() << 16)).contiguous()
+    # (held in a float32-typed tensor, as the engine's own buffers are: ops._dev() would CONVERT an int32 tensor)
+    return ((hi.view(torch.int16).int() & 0xffff) | (lo.view(torch.int16).int() << 16)).contiguous().view(torch.float32)
 
 
 @pytest.mark.parametrize("B,Np,blocks", [(256, 1024, 128), (64, 1024, 256), (96, 256, 0), (130, 128, 64)])
@@ -1864,7 +1865,7 @@ def test_filtered_linear_max_equals_the_full_evaluation(A, B, Np, blocks):
 
 
 def test_filtered_linear_max_reports_lists_that_do_not_fit(A):
-    """A cloud of IDENTICAL points: every point is a candidate for every channel, no list of 512 holds them -- the kernel
+    """A cloud of IDENTICAL points: every point is a candidate for every channel, no list of 2048 holds them (32 channels x 1024 points) -- the kernel
     must say so (range flag) instead of returning a winner it has not checked."""
     B, Np = 256, 1024
     g = torch.Generator().manual_seed(1)
