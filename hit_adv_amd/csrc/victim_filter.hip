@@ -22,8 +22,18 @@
 // (MFMA, VALU chain) each stay within 128 x 2^-24 sum |a||w| of their exact sums; sum_k |a_k| |w_k| <= |a_n| |w_c| (Cauchy-Schwarz).
 // eps = 1.05e-3 > 2^-10 (1 + 2^-11) + 3 x 128 x 2^-24 with 4 % to spare; |a_n| is floored at 1e-3 (covers the subnormal case:
 // 128 x 2^-25 |w|_inf < 1.05e-3 x 1e-3 x |w_c|), and taken from the hi pieces with a 0.2 % allowance.
-// Lists that do not fit (HITADV_V1F_CAP = 2048 entries per cloud and 32 channels: pathological input, e.g. a cloud of identical points) raise the
-// caller's range flag: the attack then runs again on the form without the filter (model/_pointwise.py::degrade_on_fp16_range).
+// Lists that do not fit (HITADV_V1F_CAP = 2048 entries per cloud and 32 channels: pathological input, e.g. a cloud of identical
+// points) raise the caller's range flag.
+//
+// STATUS (round 5, docs/kernels/round5.md): correct (tests/test_gpu_kernels.py::test_filtered_linear_max_*: maxima to fp32
+// roundoff, a maximiser as arg-max, independent of the seeds, overfull lists reported) and NOT faster yet, so the engine does not
+// use it: 257 us per 256 clouds on 128 workgroups against the unfiltered kernel's 257 (seed 22 + stream 185 + refine 50).  What
+// the stream taught: on this chip a tile's MFMA time (2 waves x 32 x 16 cycles per SIMD), its LDS fragment reads (8 waves x 16 KB
+// at 128 B / clock per CU) and its vector instructions (4 cycles each) ADD UP here (3040 cycles per tile = 1024 + 1024 + ~1000)
+// where the unfiltered kernel overlaps them (4256 measured against 3072 + 2048 + 1184): with a third of the matrix work the
+// per-tile latencies (bound -> accumulator start values, accumulators -> sign bits -> lists) are no longer hidden by two waves
+// per SIMD.  Next steps if taken up again: 64 channels per wave (half the fragment reads per MFMA), the tile norms from the
+// producer (rowmlp_stream_k) instead of the stash, candidates grouped by channel in the refine pass (half its traffic).
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -77,8 +87,8 @@ __global__ __launch_bounds__(256) void vf_seed_k(const uint32_t *__restrict__ Xp
   const int rg = blockIdx.x * 4 + wave;  // 32 channels
   if (32 * rg >= Cout) return;
   const int q = lane & 15, grp = lane >> 4;
-#pragma unroll 2
-  for (int e0 = 0; e0 < 32; e0 += 4) {
+#pragma unroll
+  for (int e0 = 0; e0 < 32; e0 += 4) {  // (fully unrolled: the eight rounds' loads are all in flight together)
     const int c = 32 * rg + e0 + grp;
     const int n = sane_index((int)seed[(size_t)b * Cout + c], N, 0);
     const float v = vf_exact(Xp + ((size_t)b * N + n) * VF_CIN, W2, Cout, c, q);
@@ -89,6 +99,8 @@ __global__ __launch_bounds__(256) void vf_seed_k(const uint32_t *__restrict__ Xp
 // The stream: the clouds of a workgroup as one sequence of 64-point tiles (linear_max_fwd_bf3_k's FLAT form: N a multiple of
 // 128, no split), hi pieces only.  block = 8 waves, 256 channels (32 per wave); a lane's accumulators: acc[rt][ct][i] = point
 // 16 rt + 4 (lane / 16) + i of the tile, channel 16 ct + lane % 16.
+// ABL != 0: tuning builds only (hitadv_debug_vf_ablate: the kernel with one cost removed; results are garbage)
+template <int ABL>
 __global__ __launch_bounds__(512) void vf_stream_k(const uint32_t *__restrict__ Xp, const uint16_t *__restrict__ W2,
                                                    const float *__restrict__ wnorm, int B_, int N, int Cout, int ncg, int cpb,
                                                    const float *__restrict__ theta, uint32_t *__restrict__ cand,
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(512) void vf_stream_k(const uint32_t *__restrict__ 
   constexpr int ST = VF_TM * G8 / 512;       // groups staged per thread per tile (2)
   extern __shared__ __attribute__((aligned(16))) char sVF[];  // 2 x hi image, then the waves' candidate lists
   uint32_t *const sEnt = reinterpret_cast<uint32_t *>(sVF + 2 * VF_PIECE);
-  __shared__ unsigned long long sNorm[2];    // (tile number << 32 | bits of max_rows sum_k ah^2): newer tiles win the atomic max
+  __shared__ __attribute__((aligned(16))) float sNorm[2][8];              // per tile buffer and wave: max over the wave's rows of sum_k ah^2
   int cg, b;
   {  // XCD-aware block order (linear_max_fwd_bf3_k): the column-group blocks that stream the same tiles share an XCD
     const int id = blockIdx.x, nrg = (B_ + cpb - 1) / cpb;
@@ -117,7 +129,6 @@ __global__ __launch_bounds__(512) void vf_stream_k(const uint32_t *__restrict__ 
   const int tpc = N / VF_TM;                 // tiles per cloud (even)
   const int ntiles = nb * tpc;
   const uint32_t *const X = Xp + (size_t)b0 * N * VF_CIN;
-  if (threadIdx.x == 0) sNorm[0] = sNorm[1] = 0ull;
 
   uint4 w[2][VF_NSL];  // hi pieces of the wave's 32 channels: column tile ct, slice j
   {
@@ -148,6 +159,7 @@ __global__ __launch_bounds__(512) void vf_stream_k(const uint32_t *__restrict__ 
   };
   auto stash = [&](const uint4 (&st)[ST][2], int tile) {
     const int buf = tile & 1;
+    float sq[ST];
 #pragma unroll
     for (int u = 0; u < ST; ++u) {
       const int e = threadIdx.x + 512 * u;
@@ -157,17 +169,32 @@ __global__ __launch_bounds__(512) void vf_stream_k(const uint32_t *__restrict__ 
       hi.z = __builtin_amdgcn_perm(st[u][1].y, st[u][1].x, 0x05040100u);
       hi.w = __builtin_amdgcn_perm(st[u][1].w, st[u][1].z, 0x05040100u);
       *reinterpret_cast<uint4 *>(sVF + (size_t)buf * VF_PIECE + (e / G8) * VF_RS + 16 * (e % G8)) = hi;
-      // |ah|^2 of the row: this thread's eight values, then the row's 16 lanes (row_shr sums end in the row's last lane)
-      float s = 0.f;
-      s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2f, hi.x), __builtin_bit_cast(f16x2f, hi.x), s, false);
-      s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2f, hi.y), __builtin_bit_cast(f16x2f, hi.y), s, false);
-      s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2f, hi.z), __builtin_bit_cast(f16x2f, hi.z), s, false);
-      s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2f, hi.w), __builtin_bit_cast(f16x2f, hi.w), s, false);
-      s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x111, 0xf, 0xf, true));  // row_shr:1
-      s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x112, 0xf, 0xf, true));  // row_shr:2
-      s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x114, 0xf, 0xf, true));  // row_shr:4
-      s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x118, 0xf, 0xf, true));  // row_shr:8
-      if (l16 == 15) atomicMax(&sNorm[buf], ((unsigned long long)(unsigned)(tile + 1) << 32) | __float_as_uint(s));
+      // |ah|^2 of the row: this thread's eight values ...
+      float q = 0.f;
+      q = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2f, hi.x), __builtin_bit_cast(f16x2f, hi.x), q, false);
+      q = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2f, hi.y), __builtin_bit_cast(f16x2f, hi.y), q, false);
+      q = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2f, hi.z), __builtin_bit_cast(f16x2f, hi.z), q, false);
+      q = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2f, hi.w), __builtin_bit_cast(f16x2f, hi.w), q, false);
+      sq[u] = q;
+    }
+    if (ABL != 3) {
+      // ... then the row's 16 lanes (row_shr sums end in the row's last lane), the larger of the thread's two rows, the wave's four
+      // row groups (row_bcast), and ONE plain store per wave: no atomics (the compiler turns a same-address LDS atomic of a
+      // divergent value into a loop over the active lanes)
+#pragma unroll
+      for (int u = 0; u < ST; ++u) {
+        sq[u] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq[u]), 0x111, 0xf, 0xf, true));  // row_shr:1
+        sq[u] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq[u]), 0x112, 0xf, 0xf, true));  // row_shr:2
+        sq[u] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq[u]), 0x114, 0xf, 0xf, true));  // row_shr:4
+        sq[u] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sq[u]), 0x118, 0xf, 0xf, true));  // row_shr:8
+      }
+      float m = ST > 1 ? __builtin_fmaxf(sq[0], sq[ST - 1]) : sq[0];  // valid in lanes 15, 31, 47, 63 (sums of squares: >= 0)
+      m = l16 == 15 ? m : 0.f;
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x142, 0xa, 0xf, false));  // row_bcast:15
+      m = __builtin_fmaxf(m, a);
+      const float c = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x143, 0xc, 0xf, false));  // row_bcast:31
+      m = __builtin_fmaxf(m, c);
+      if (lane == 63) sNorm[buf][wave] = m;
     }
   };
 
@@ -180,11 +207,21 @@ __global__ __launch_bounds__(512) void vf_stream_k(const uint32_t *__restrict__ 
   };
   auto compute = [&](int tile, int tile_in_cloud) {
     const char *base = sVF + (size_t)(tile & 1) * VF_PIECE + l16 * VF_RS + 16 * g4;
+    // the tile's bound first: eps |w_c| max_rows |a_n| (hi pieces, 0.2 % allowance; floor: see the header).  The accumulators START
+    // at -t (t = the lane's current lower bound of the channel's maximum minus the bound): after the products their SIGN BIT says
+    // whether a value can still be the maximum -- one instruction per value (below) instead of a compare and a select
+    const float4 na = *reinterpret_cast<const float4 *>(&sNorm[tile & 1][0]), nb = *reinterpret_cast<const float4 *>(&sNorm[tile & 1][4]);
+    const float a2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(na.x, na.y), __builtin_fmaxf(na.z, na.w)),
+                                     __builtin_fmaxf(__builtin_fmaxf(nb.x, nb.y), __builtin_fmaxf(nb.z, nb.w)));
+    const float amax = fmaxf(__builtin_sqrtf(a2) * 1.002f, VF_AMIN);
+    const float d0 = ew[0] * amax, d1 = ew[1] * amax;
+    const float t0 = th[0] - d0, t1 = th[1] - d1;
     f32x4f acc[4][2];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f32x4f{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < 4; ++rt) {
+      acc[rt][0] = f32x4f{-t0, -t0, -t0, -t0};
+      acc[rt][1] = f32x4f{-t1, -t1, -t1, -t1};
+    }
     uint4 fa[2][4];  // [buffer][row tile]: the next slice's A fragments are read while this slice's MFMAs run
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) fa[0][rt] = *reinterpret_cast<const uint4 *>(base + rt * 16 * VF_RS);
@@ -199,43 +236,50 @@ __global__ __launch_bounds__(512) void vf_stream_k(const uint32_t *__restrict__ 
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8f, fa[j & 1][rt]), __builtin_bit_cast(f16x8f, w[ct][j]),
+          if (ABL != 2) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8f, fa[j & 1][rt]), __builtin_bit_cast(f16x8f, w[ct][j]),
                                                                acc[rt][ct], 0, 0, 0);
     }
-    // the tile's bound: eps |w_c| max_rows |a_n| (hi pieces, 0.2 % allowance; floor: see the header)
-    const float a2 = __uint_as_float((uint32_t)sNorm[tile & 1]);
-    const float amax = fmaxf(__builtin_sqrtf(a2) * 1.002f, VF_AMIN);
-    // every value of the tile is itself a lower bound of the maximum once its error is taken off: the lane's bound rises with
-    // the stream (a poor seed -- the first iteration of an attack -- costs some tens of candidates per channel, not hundreds)
-    float t01[2];
+    // acc = yhat - t (the start value adds one rounding of size 2^-24 |t| to the sum: inside eps's 4 % reserve).  Every value of the
+    // tile is itself a lower bound of the maximum once its error is taken off: the lane's bound rises with the stream (a poor seed --
+    // the first iteration of an attack -- costs some tens of candidates per channel, not hundreds).
+    uint32_t miss[2] = {0u, 0u};  // bit 15 - j: value j = 4 rt + i is BELOW the bound (v_alignbit: miss = 2 miss + sign(acc))
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      const float d = ew[ct] * amax;
       float m = __builtin_fmaxf(__builtin_fmaxf(acc[0][ct][0], acc[0][ct][1]), acc[0][ct][2]);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int i = (rt == 0 ? 3 : 0); i < 4; i += 2)
           m = i + 1 < 4 ? __builtin_fmaxf(__builtin_fmaxf(m, acc[rt][ct][i]), acc[rt][ct][i + 1]) : __builtin_fmaxf(m, acc[rt][ct][i]);
-      th[ct] = __builtin_fmaxf(th[ct], m - d);
-      t01[ct] = th[ct] - d;
+      // max yhat = m + t; the new bound: max(th, max yhat - d)  (rounded down by the 0.2 % / 4 % reserves)
+      float nt = __builtin_fmaxf(th[ct], (m + (ct ? t1 : t0)) - (ct ? d1 : d0));
+      nt = __builtin_fmaxf(nt, __shfl_xor(nt, 16, HITADV_WAVE));  // the channel's four lanes (other rows of the tile) share it
+      nt = __builtin_fmaxf(nt, __shfl_xor(nt, 32, HITADV_WAVE));
+      th[ct] = nt;
+      if (ABL != 4) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) miss[ct] = __builtin_amdgcn_alignbit(miss[ct], __float_as_uint(acc[rt][ct][i]), 31);
+      }
     }
-    const float t0 = t01[0], t1 = t01[1];
-    const uint32_t pbase = (uint32_t)(tile_in_cloud * VF_TM + 4 * g4) << 8;
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool hit = acc[rt][ct][i] >= (ct ? t1 : t0);
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-          if (m != 0ull) {  // wave-uniform, rare: the hitting lanes append (point << 8 | channel of the wave)
-            const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (hit && pos < VF_CAP) myEnt[pos] = pbase + ((uint32_t)(16 * rt + i) << 8) + (uint32_t)(16 * ct + l16);
-            cnt += __builtin_popcountll(m);
-          }
-        }
+    uint32_t bits[2] = {~miss[0] & 0xffffu, ~miss[1] & 0xffffu};
+    if (ABL == 4) bits[0] = bits[1] = 0u;
+    uint32_t both = bits[0] | (bits[1] << 16);
+    if (ABL == 1) both = 0u;
+    if (__builtin_amdgcn_ballot_w64(both != 0u) != 0ull) {  // wave-uniform; the lanes with hits take them out one by one
+      const uint32_t pbase = (uint32_t)(tile_in_cloud * VF_TM + 4 * g4) << 8;
+      unsigned long long act;
+      while ((act = __builtin_amdgcn_ballot_w64(both != 0u)) != 0ull) {
+        const bool on = both != 0u;
+        const int k = on ? 31 - __builtin_clz(both) : 0;   // highest set bit first: ct = k / 16, value j = 15 - k % 16
+        both &= ~(on ? (1u << k) : 0u);
+        const int j = 15 - (k & 15);
+        const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        if (on && pos < VF_CAP) myEnt[pos] = pbase + ((uint32_t)(16 * (j >> 2) + (j & 3)) << 8) + (uint32_t)(16 * (k >> 4) + l16);
+        cnt += __builtin_popcountll(act);
+      }
+    }
   };
   auto flush = [&](int cloud) {  // the cloud's list leaves; an overfull one raises the flag (the caller re-runs without the filter)
     const size_t region = (size_t)(b0 + cloud) * (Cout / 32) + (col0 >> 5);
@@ -296,6 +340,7 @@ __global__ __launch_bounds__(256) void vf_refine_k(const uint32_t *__restrict__ 
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < m; i += 64) sE[wave][i] = cand[region * VF_CAP + c0 + i];
     __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
     for (int e0 = 0; e0 < m; e0 += 4) {
       const int e = min(e0 + grp, m - 1);
       const uint32_t ent = sE[wave][e];
@@ -340,6 +385,14 @@ static int vf_clouds_per_block(int B, int Cout, int blocks) {
 
 using namespace hitadv;
 
+// tuning only: 1 = no candidate bookkeeping, 2 = no MFMAs, 3 = no row-norm atomics, 4 = no compares (results are garbage)
+static int g_vf_ablate = 0;
+extern "C" int hitadv_debug_vf_ablate(int what) {
+  const int before = g_vf_ablate;
+  if (what >= 0 && what <= 4) g_vf_ablate = what;
+  return before;
+}
+
 extern "C" int hitadv_linear_max_filter_supported(int B, int N, int Cin, int Cout, int blocks) {
   if (B <= 0 || N <= 0 || Cin != VF_CIN || Cout <= 0 || (Cout & 255) || N % (2 * VF_TM) || N > (1 << 20) ||
       (blocks != 0 && (blocks < 8 || blocks > 256)))
@@ -368,8 +421,20 @@ extern "C" int hitadv_linear_max_fwd_f16x2_filtered(const uint32_t *Xp, const ui
   vf_seed_k<<<small, 256, 0, s>>>(Xp, W2, N, Cout, seed, theta);
   const int ncg = Cout / 256, cpb = vf_clouds_per_block(B, Cout, blocks);
   const int shm = 2 * VF_PIECE + 8 * VF_CAP * 4;
-  HITADV_RAISE_LDS((&vf_stream_k), shm);
-  vf_stream_k<<<ncg * ((B + cpb - 1) / cpb), 512, shm, s>>>(Xp, W2, wnorm, B, N, Cout, ncg, cpb, theta, cand, ccount, range_flag);
+  const dim3 grid(ncg * ((B + cpb - 1) / cpb));
+#define HITADV_VF_LAUNCH(ABL_)                                                                                           \
+  do {                                                                                                                   \
+    HITADV_RAISE_LDS((&vf_stream_k<ABL_>), shm);                                                                         \
+    vf_stream_k<ABL_><<<grid, 512, shm, s>>>(Xp, W2, wnorm, B, N, Cout, ncg, cpb, theta, cand, ccount, range_flag);       \
+  } while (0)
+  switch (g_vf_ablate) {
+    case 1: HITADV_VF_LAUNCH(1); break;
+    case 2: HITADV_VF_LAUNCH(2); break;
+    case 3: HITADV_VF_LAUNCH(3); break;
+    case 4: HITADV_VF_LAUNCH(4); break;
+    default: HITADV_VF_LAUNCH(0);
+  }
+#undef HITADV_VF_LAUNCH
   vf_refine_k<<<small, 256, 0, s>>>(Xp, W2, bias, N, Cout, relu, cand, ccount, out, idx, seed);
   HITADV_LAUNCH_CHECK();
   return 0;
