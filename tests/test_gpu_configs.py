@@ -431,6 +431,14 @@ def _pct():
 
 
 def _direct_chamfer_knn(adv, ori):
+    """ChamferkNNDist in the DIRECT form ((dx^2 + dy^2) + dz^2), the form the product evaluates by default.  Round 5 tried the
+    reference's Gram form on both sides here (``ChamferkNNDist(reference_arithmetic=True)`` against ``O.chamfer_knn_dist``,
+    VERDICT r04 #3): the 99th percentile of |gpu - oracle| went from 2e-6 to 2e-3 in the FIRST iterate.  The Gram form's
+    squared distances of near neighbours (1e-4) are differences of numbers of order 1: which of two near-tied neighbours
+    ranks fifth is decided by the last bit of a 3-term dot product, and torch's CPU ``bmm`` on the GPU box's host does not
+    sum it the way the build host's does (the kernel reproduces the latter bit for bit: tests/test_oracle_gram.py, which
+    runs where the fixtures were made).  The Gram form is pinned where it can be: fixture g7 / g24 (the reference's own
+    outputs), the C restatement against torch on the build host, the kernel against the C restatement."""
     P = O.pairwise_sqdist_direct(ori, adv)
     cham = P.min(dim=1).values.mean(dim=1)
     S = torch.sort(O.pairwise_sqdist_direct(adv, adv), dim=-1, stable=True).values[..., 1:6].mean(-1)
@@ -591,3 +599,59 @@ def test_cfg5_pct_batch32_cw_sweep_vs_cpu_oracle(which):
         for i in range(iters):
             close(np.median(np.abs(rows[i] - otrace[i]['adv'])), 0., rtol=0, atol=1e-6,
                   what='cfg5 knn iterate %d, free-running: median |gpu - oracle|' % i)
+
+
+def _tuned_victim(name):
+    """The victims of bench.py's cfg3 / cfg4 / cfg5 (bench.VICTIM_TUNING: seeded init, every weight x 1.5, PointNet++ / PCT with
+    shaken BatchNorm statistics) -- victims a bounded attack can move, so that some clouds succeed and some do not."""
+    from hit_adv_amd.Dataset.synthetic import shake_bn, sharpen
+    torch.manual_seed(0)
+    if name == 'dgcnn':
+        from hit_adv_amd.model.dgcnn import DGCNN_cls
+        return sharpen(DGCNN_cls(argparse.Namespace(k=5, emb_dims=1024, dropout=0.2), output_channels=40).eval(), 1.5)
+    if name == 'pointnet++':
+        from hit_adv_amd.model.pointnet2 import get_model
+        return shake_bn(sharpen(get_model(16, normal_channel=False).eval(), 1.5), seed=2)
+    from hit_adv_amd.model.pct import Pct
+    return shake_bn(sharpen(Pct(argparse.Namespace(dropout=0.2), output_channels=40).eval(), 1.5), seed=2)
+
+
+@pytest.mark.parametrize("name", ["dgcnn", "pointnet++", "pct"])
+def test_other_victims_twenty_iterations_with_both_bookkeeping_branches_vs_cpu_oracle(name):
+    """VERDICT r04 #1c: the other configurations' victims (as bench.py builds them) under HiT-ADV for 20 iterations, B = 8,
+    N = 1024, against the CPU oracle -- on victims where some clouds succeed and some do not (5 / 8, 6 / 8, 2 / 8 on MI355X, the
+    same clouds on both sides), so that the success branch of the best tracking and BOTH directions of the bisection run.
+    Free-running: the oracle's victim draws its own sampling tables (PointNet++ / PCT: from the same CPU generator state),
+    nothing is imposed.  Achieved on MI355X: |gpu - oracle| of the returned clouds <= 1.9e-4 (DGCNN), 6e-7 (PointNet++),
+    5.1e-5 (PCT); asserted: the same centres, the same success flags up to one cloud inside fp32 noise, the 99th percentile
+    of the result at 1e-3 (5x the worst achieved) and its maximum at one Adam step."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    cpu_model = _tuned_victim(name)
+    victim = VG.CpuVictim(cpu_model) if name in ('pointnet++', 'pct') else cpu_model
+    data, _ = synth_batch(8, 1024, first=7000)
+    torch.manual_seed(1)
+    label = _labels(victim, data)
+    hp = dict(binary_step=1, num_iter=20, **HP)
+    oracle = O.HiTADVOracle(victim, lambda l, t: O.untargeted_logits_adv_loss(l, t, 30.), **hp)
+    torch.manual_seed(21)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obest, osucc = oracle.attack(data, label)
+    att = HiT_ADV(copy.deepcopy(cpu_model), UntargetedLogitsAdvLoss(30.), verbose=False, **hp)
+    torch.manual_seed(21)
+    best, succ = att.attack(data, label)
+    ws = next(iter(att._ws.values()))
+    same = (ws.central.cpu() == oracle.state['central']).all(dim=1).float().mean().item()
+    assert same >= 0.99, same
+    ok_gpu = att.last_lower_bound.numpy() > 0
+    ok_cpu = oracle.state['lower'].numpy() > 0
+    note('%s: successes on the GPU' % name, float(ok_gpu.sum()))
+    note('%s: successes in the oracle' % name, float(ok_cpu.sum()))
+    note('%s: clouds whose success flag differs' % name, float((ok_gpu != ok_cpu).sum()))
+    assert 0 < int(succ) < 8 and 0 < int(osucc) < 8          # both branches ran, on both sides
+    assert int((ok_gpu != ok_cpu).sum()) <= 1                  # (a cloud that flips inside fp32 noise in the last iterations)
+    agree = ok_gpu == ok_cpu
+    err = np.abs(best - obest)[agree]
+    note('%s: result, largest |gpu - oracle| over the agreeing clouds' % name, float(err.max()))
+    note('%s: result, 99th percentile' % name, float(np.quantile(err, 0.99)))
+    assert float(np.quantile(err, 0.99)) <= 1e-3 and float(err.max()) <= 5e-2

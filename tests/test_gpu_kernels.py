@@ -34,9 +34,18 @@ def close(a, b, rtol=1e-05, atol=1e-6, what=None):
     _close(a, b, rtol=rtol, atol=atol, what=what)
 
 
-def clouds(b, n, first=0):
-    data, _ = synth_batch(b, n, first=first)
+def clouds(b, n, first=0, kind='gaussian'):
+    """``kind='sphere'``: the surface-like distribution (points on the unit sphere, 1 % radial noise): a scan's
+    neighbour statistics, and many more near-tied distances than an iid Gaussian cloud has."""
+    if kind == 'sphere':
+        from hit_adv_amd.Dataset.synthetic import sphere_batch
+        data, _ = sphere_batch(b, n, first=first)
+    else:
+        data, _ = synth_batch(b, n, first=first)
     return data[:, :, :3].contiguous(), data[:, :, 3:].contiguous()
+
+
+KINDS = pytest.mark.parametrize("kind", ["gaussian", "sphere"])
 
 
 # ------------------------------------------------------------------ K1 pairwise
@@ -73,10 +82,11 @@ def test_pairwise_generic_dim(A):
 
 
 # ------------------------------------------------------------------ K2 fused NN-min
+@KINDS
 @pytest.mark.parametrize("n,m", [(1024, 1024), (256, 1024), (1000, 37), (1, 5), (130, 2049)])
-def test_nn_min_bit_exact_both_directions(A, n, m):
-    x, _ = clouds(3, n, 120)
-    y, _ = clouds(3, m, 130)
+def test_nn_min_bit_exact_both_directions(A, n, m, kind):
+    x, _ = clouds(3, n, 120, kind)
+    y, _ = clouds(3, m, 130, kind)
     mx, ax, my, ay = (t.cpu() for t in A.nn_min(cu(x), cu(y)))
     rx, rax = N.nn_min(x, y)
     ry, ray = N.nn_min(y, x)
@@ -199,10 +209,11 @@ def test_nn_min_backward_matches_autograd_of_direct_matrix(A):
 
 
 # ------------------------------------------------------------------ K4 kNN
+@KINDS
 @pytest.mark.parametrize("K", [1, 4, 5, 6, 8, 16, 17, 20, 30, 32, 33, 64])
-def test_knn_points_bit_exact(A, K):
+def test_knn_points_bit_exact(A, K, kind):
     from hit_adv_amd.pytorch3d_ops import knn_points
-    x, _ = clouds(2, 1024, 180)
+    x, _ = clouds(2, 1024, 180, kind)
     q = x[:, :300].contiguous()
     r = knn_points(cu(q), cu(x), K=K)
     d, ix = N.knn_points(q, x, K)
@@ -236,12 +247,13 @@ def test_knn_points_gram_knn_form_bit_exact(A, K):
 
 @pytest.mark.parametrize("K,m,form", [(2, 1024, 0), (5, 1024, 2), (6, 1024, 0), (6, 2048, 2), (8, 512, 0), (12, 1024, 0),
                                       (17, 1024, 0), (17, 2048, 0), (18, 1000, 2)])
-def test_knn_points_full_batch_with_ties_and_falling_distances(A, K, m, form):
+@KINDS
+def test_knn_points_full_batch_with_ties_and_falling_distances(A, K, m, form, kind):
     """A batch as large as the attack's own calls (16 clouds x 1061 queries, ragged last block), with one cloud made of six
     distinct points (exact ties everywhere) and one whose references come ever closer (the logs overflow and compact)."""
     B, n = 16, 1024 + 37  # ragged last block
-    x, _ = clouds(B, m, 184)
-    q, _ = clouds(B, n, 185)
+    x, _ = clouds(B, m, 184, kind)
+    q, _ = clouds(B, n, 185, kind)
     g = torch.Generator().manual_seed(K)
     x[1] = torch.randn(1, 6, 3, generator=g)[:, torch.randint(0, 6, (m,), generator=g)]  # six distinct points: ties
     x[2, :, 0] = torch.linspace(5.0, 0.5, m)  # every next reference is closer: the logs overflow and compact
@@ -400,9 +412,10 @@ def test_fps_from_start_vs_reference_vector(A):
     assert idx.dtype == torch.int64 and (idx.cpu().numpy() == fx['idx']).all()
 
 
+@KINDS
 @pytest.mark.parametrize("n,m", [(1024, 256), (2048, 512), (300, 300), (64, 5), (5000, 64)])
-def test_fps_from_start_bit_exact_sizes(A, n, m):
-    x, _ = clouds(3, n, 240)
+def test_fps_from_start_bit_exact_sizes(A, n, m, kind):
+    x, _ = clouds(3, n, 240, kind)
     start = torch.tensor([0, n - 1, n // 2])
     assert torch.equal(A.fps_from_start(cu(x), m, cu(start)).cpu(), N.fps_from_start(x, m, start))
 
@@ -428,11 +441,12 @@ def test_fps_pct_reproduces_the_reference_table(A):
 
 @pytest.mark.parametrize("n,s,radius,nsample", [(1024, 512, 0.2, 32), (512, 128, 0.4, 64), (2048, 512, 0.2, 32), (300, 77, 0.3, 16),
                                                 (64, 48, 0.05, 8)])
-def test_query_ball_point_victim_bit_exact(A, n, s, radius, nsample):
+@KINDS
+def test_query_ball_point_victim_bit_exact(A, n, s, radius, nsample, kind):
     """The victims' ball query (model/pointnet2_utils.py:87-107) on the reference's Gram-form square_distance (oracle form
     3): threshold = the fp32 value of the double radius ** 2, ``>`` excluded, index order, padded with the first hit, an
     empty ball = n."""
-    x, _ = clouds(3, n, 246)
+    x, _ = clouds(3, n, 246, kind)
     q = x[:, :s].contiguous().clone()
     q[0, 1] = 50.  # an empty ball
     for k in range(2, min(s, 40)):  # points ON the sphere up to rounding: where the two forms and the two thresholds part

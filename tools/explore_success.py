@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--first", type=int, default=7000)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--gains", type=float, nargs="+", default=[1.0])
     ap.add_argument("--shake-seeds", type=lambda v: None if v == "none" else int(v), nargs="+", default=[None])
     ap.add_argument("--cw", action="store_true", help="pct: the short CW sweep of bench.py instead of HiT-ADV")
@@ -57,8 +59,16 @@ def main():
     shakes = [(g, None if s is None else dict(seed=s, mean_std=0.05, var_spread=0.2)) for g in args.gains for s in args.shake_seeds]
     for name in args.victims:
         cfg = dict(next(c for c in bench.CONFIGS.values() if c['victim'] == name))
+        if args.batch:
+            cfg['B'] = args.batch
+        if args.points:
+            cfg['N'] = args.points
         for gain, shake in shakes:
+            tuning = bench.VICTIM_TUNING.pop(name, None)  # (this tool applies its own)
+            bench.VICTIM_TUNING[name] = dict(gain=1.0, shake=None)
             model = bench.build_victim(cfg)
+            if tuning is not None:
+                bench.VICTIM_TUNING[name] = tuning
             if gain != 1.0:
                 sharpen(model, gain)
             if shake is not None:
