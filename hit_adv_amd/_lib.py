@@ -109,6 +109,7 @@ PROTOTYPES = {
     "hitadv_pointnet_rowmlp_bwd_tiles": [_I, _I],
     "hitadv_pointnet_rowmlp_bwd_words": [_I, _I, _I],
     "hitadv_pointnet_rowmlp_bwd": [_I, _P, _P, _P, _P, _I] + [_P] * 15 + [_I, _I, _I, _I, _P],
+    "hitadv_pointnet_rowmlp_bwd_fix": [_I, _P, _P, _P, _P, _I] + [_P] * 15 + [_I, _I, _I, _I, _P, _P],
     "hitadv_sum_partials": [_P, _P, _I, _I, _I, _P, _P],
     "hitadv_knn_features": [_P, _P, _I, _I, _I, _I, _P, _P],
     "hitadv_row_sqnorm": [_P, _L, _I, _P, _P],

@@ -173,6 +173,24 @@ __device__ __forceinline__ void split3x8(const float4 &lo4, const float4 &hi4, u
   p3 = make_uint4(pack_hi(l[0], l[1]), pack_hi(l[2], l[3]), pack_hi(l[4], l[5]), pack_hi(l[6], l[7]));
 }
 
+// sqrt(d), correctly rounded, for d = 0 or 2^-96 <= d < 2^96 (squared distances of clouds in the unit ball: never subnormal,
+// never huge).  hipcc's own lowering of __builtin_sqrtf is this very fix-up of v_sqrt_f32 (the neighbours one ulp down / up,
+// two FMAs for the signs of the residuals, two selects) wrapped in a scaling branch for d < 2^-96 and a class test for 0 / inf:
+// five more vector instructions per value of the deformation's 38 (round 5: the deformation kernels are bound by their vector
+// instructions -- 32.9 M per deform_bwd launch = 100 % of its duration, profiles/r05_loop_traffic.json).  Same bits on the
+// stated range; d = 0 gives 0 (the down-neighbour of 0 is a NaN pattern whose comparisons fail).
+__device__ __forceinline__ float sqrt_rn_ranged(float d) {
+  float s = __builtin_amdgcn_sqrtf(d);
+  const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float vp = fmaf(-dn, s, d), vs = fmaf(-up, s, d);
+  s = vp <= 0.f ? dn : s;
+  s = vs > 0.f ? up : s;
+  return s;
+}
+// 2^x for x <= 0 with results below 2^-126 flushed to zero (v_exp_f32 alone: exp2f() scales such arguments to return
+// subnormals, four more instructions).  For sums that are not divided by: a term of 1e-38 is not seen by an fp32 sum.
+__device__ __forceinline__ float exp2_flush(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // Canonical squared distance: ((dx*dx + dy*dy) + dz*dz), one fp32 rounding per operation.
 // The translation unit is built with -ffp-contract=off so nothing here fuses into an FMA.
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void deform_bwd(const float *__restrict__ ori,
   for (int t = 0; t < (j < C ? cnt : 0); ++t) {
     const float4 pt = sxyz[t];
     const float4 g = sg[t];
-    const float r = __builtin_sqrtf(sqdist3(pt.x, pt.y, pt.z, cx, cy, cz));
-    const float k = exp2f(r * a2);
+    const float r = sqrt_rn_ranged(sqdist3(pt.x, pt.y, pt.z, cx, cy, cz));
+    const float k = exp2_flush(r * a2);
     apx = fmaf(g.x, k, apx);
     apy = fmaf(g.y, k, apy);
     apz = fmaf(g.z, k, apz);

@@ -45,7 +45,7 @@ __device__ __forceinline__ void deform_fwd_body_in(float4 *lds, const float *__r
     for (int j = lo; j < hi; ++j) {
       const float4 c = sc[j];
       const float4 p = sp[j];
-      const float r = __builtin_sqrtf(sqdist3(x, y, z, c.x, c.y, c.z));
+      const float r = sqrt_rn_ranged(sqdist3(x, y, z, c.x, c.y, c.z));  // (k itself keeps exp2f: the sum of the k is divided by)
       const float k = exp2f(r * c.w);
       sx = fmaf(k, p.x, sx);
       sy = fmaf(k, p.y, sy);

@@ -887,6 +887,8 @@ struct RowMlpBwd {
   int N, Cout;
   int a2_packed;                      // mode 2: A2 holds packed fp16 pieces (rowmlp_fwd16_k, pack_o2), not fp32 values
   int *overflow;                      // [B,tiles] (two-word tiles only) 1: the tile has more than 64 winning points, see FIXUP
+  const int *fix_parent;              // one-word launch as the SECOND launch of the two-word form (round 5): [B,tiles/2] = the first
+                                      // launch's overflow table; a block whose 128-point parent tile is not marked leaves at once
 };
 
 constexpr int BW_CH = 4;  // Cout <= 256 * BW_CH
@@ -1321,9 +1323,24 @@ __device__ __forceinline__ void gather_rows16(const int2 *list, int M, const flo
 // per lane instead of 211-226 and none -- and marks a tile it cannot take (more than 64 winning points) in a.overflow; the
 // second launch returns at once for every other tile and takes the marked ones word by word.
 template <int STAGE, int NW, bool FIXUP>
-__global__ __launch_bounds__(256, 2) void rowmlp_bwd16_k(RowMlpBwd a) {
+// (the second launch -- tiles with more than 64 winning points, both words in turn -- keeps the lists of both passes alive: at
+// two workgroups per CU it spilled 0.9-1.6 KB per lane to scratch and ran 6x slower than its work: 388 us per stage-1 launch on
+// surface-like clouds, where half the tiles take it (round 5, tools/r05 sphere runs); one workgroup per CU: AGPRs, no scratch)
+__global__ __launch_bounds__(256, FIXUP ? 1 : 2) void rowmlp_bwd16_k(RowMlpBwd a) {
   constexpr int BT = 64 * NW;  // points per block tile
   if (FIXUP && a.overflow[(size_t)blockIdx.y * gridDim.x + blockIdx.x] == 0) return;  // block-uniform
+  if (NW == 1 && !FIXUP && a.fix_parent != nullptr) {  // block-uniform: this word's tile was done by the first launch
+    if (a.fix_parent[(size_t)blockIdx.y * (gridDim.x >> 1) + (blockIdx.x >> 1)] == 0) return;
+    if ((int)blockIdx.x * BT >= a.N) {  // (the second word of a ragged last tile: no points, a zero partial)
+      if (STAGE == 2) {
+        float4 *o = reinterpret_cast<float4 *>(a.dTpart + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4096);
+        for (int e = threadIdx.x; e < 1024; e += 256) o[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (STAGE == 1 && threadIdx.x < 9) {
+        a.dTpart[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 + threadIdx.x] = 0.f;
+      }
+      return;
+    }
+  }
   // piece tiles: tD [2][64 rows][128] (the gathered, masked gradient; later reused as tF [2][64][64]), tE [2][64][64]
   __shared__ __attribute__((aligned(16))) char tD[2][PM_TM * PM_LH128], tE[2][PM_TM * PM_LH64];
   __shared__ float sX[BT * 3], sG[PM_TM * 3];
@@ -2212,12 +2229,35 @@ extern "C" int64_t hitadv_pointnet_rowmlp_bwd_tiles(int N, int words) {
   return N > 0 ? (N + bt - 1) / bt : 0;
 }
 
+// how the two-word form handles a tile with more than 64 winning points: 1 (default) = two blocks of the one-word kernel,
+// 0 = the two-pass instantiation of the two-word kernel (round 4)
+static int g_v3_fix_form = [] { const char *e = getenv("HITADV_V3_FIX"); return e ? atoi(e) : 1; }();
+
+// part[b,t,:] = fix[b,2t,:] + fix[b,2t+1,:] for the tiles the two-word launch left to the one-word launch (word order)
+__global__ __launch_bounds__(256) void merge_fix_partials_k(float *__restrict__ part, const float *__restrict__ fix,
+                                                            const int *__restrict__ over, int M) {
+  const size_t bt = blockIdx.x;
+  if (over[bt] == 0) return;
+  for (int m = threadIdx.x; m < M; m += 256) part[bt * M + m] = fix[2 * bt * M + m] + fix[(2 * bt + 1) * M + m];
+}
+
 extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const float *gmask, const int64_t *idx,
                                           const float *W3r, int Cout, const float *A2, const float *W2r,
                                           const float *A1, const float *W1r, const float *H1, const float *dH1in,
                                           const float *W0r, const float *T, const float *x, const float *dPin,
                                           float *dTpart, float *out, const uint64_t *pres_in, uint64_t *pres_out,
                                           int32_t *overflow, int words, int B, int N, int mode, void *stream) {
+  return hitadv_pointnet_rowmlp_bwd_fix(stage, dg, gmask, idx, W3r, Cout, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out,
+                                        pres_in, pres_out, overflow, words, B, N, mode, nullptr, stream);
+}
+
+extern "C" int hitadv_pointnet_rowmlp_bwd_fix(int stage, const float *dg, const float *gmask, const int64_t *idx,
+                                              const float *W3r, int Cout, const float *A2, const float *W2r,
+                                              const float *A1, const float *W1r, const float *H1, const float *dH1in,
+                                              const float *W0r, const float *T, const float *x, const float *dPin,
+                                              float *dTpart, float *out, const uint64_t *pres_in, uint64_t *pres_out,
+                                              int32_t *overflow, int words, int B, int N, int mode, float *dTfix,
+                                              void *stream) {
   HITADV_ABLATE_RETURN("v3");
   if (stage < 0 || stage > 2 || B <= 0 || N <= 0 || N > 65535 || Cout <= 0 || Cout > 256 * BW_CH || !dg || !idx ||
       !W3r || !A2 || !W2r || !out || mode < 0 || mode > 2 || words < 1 || words > 2 || (mode == 0 && words != 1))
@@ -2227,10 +2267,32 @@ extern "C" int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const floa
   if (stage == 2 && (!H1 || !T || !dTpart)) return HITADV_E_ARG;
   RowMlpBwd a{dg, gmask, idx, W3r, A2, W2r, A1, W1r, H1, dH1in, W0r, T, x, dPin, dTpart, out,
               reinterpret_cast<const unsigned long long *>(pres_in), reinterpret_cast<unsigned long long *>(pres_out), N,
-              Cout, mode == 2, overflow};
+              Cout, mode == 2, overflow, nullptr};
   dim3 grid((unsigned)hitadv_pointnet_rowmlp_bwd_tiles(N, words), B);
   hipStream_t s = (hipStream_t)stream;
-  if (mode >= 1 && words == 2) {
+  if (mode >= 1 && words == 2 && (dTfix != nullptr || stage == 0) && overflow && g_v3_fix_form == 1) {
+    // Round 5: the tiles with more than 64 winning points go to the ONE-WORD kernel (two blocks per tile, each a plain
+    // single pass), not to the two-pass instantiation (which keeps both passes' lists alive and spilled: 388 us per stage-1
+    // launch on surface-like clouds, where half the tiles take this path; the one-word kernel does ALL tiles in 60).  Their
+    // per-tile partials are the two words' partials added in word order.
+    RowMlpBwd f = a;
+    f.fix_parent = overflow;
+    f.overflow = nullptr;
+    f.dTpart = dTfix;
+    const dim3 grid1(2 * grid.x, B);
+    if (stage == 0) {
+      rowmlp_bwd16_k<0, 2, false><<<grid, 256, 0, s>>>(a);
+      rowmlp_bwd16_k<0, 1, false><<<grid1, 256, 0, s>>>(f);
+    } else if (stage == 1) {
+      rowmlp_bwd16_k<1, 2, false><<<grid, 256, 0, s>>>(a);
+      rowmlp_bwd16_k<1, 1, false><<<grid1, 256, 0, s>>>(f);
+      merge_fix_partials_k<<<grid.x * B, 256, 0, s>>>(dTpart, dTfix, overflow, 9);
+    } else {
+      rowmlp_bwd16_k<2, 2, false><<<grid, 256, 0, s>>>(a);
+      rowmlp_bwd16_k<2, 1, false><<<grid1, 256, 0, s>>>(f);
+      merge_fix_partials_k<<<grid.x * B, 256, 0, s>>>(dTpart, dTfix, overflow, 4096);
+    }
+  } else if (mode >= 1 && words == 2) {
     if (!overflow) return HITADV_E_ARG;
     if (stage == 0) {
       rowmlp_bwd16_k<0, 2, false><<<grid, 256, 0, s>>>(a);

@@ -735,16 +735,19 @@ def pointnet_rowmlp_fwd_deform(B, N, ori, central, perturb, sigma, adv, inv_den,
 
 def pointnet_rowmlp_bwd(stage, B, N, dg, idx, W3r, A2, W2r, out, gmask=None, A1=None, W1r=None, H1=None, dH1in=None,
                         W0r=None, T=None, x=None, dPin=None, dTpart=None, pres_in=None, pres_out=None, mode=0, overflow=None,
-                        words=1):
+                        words=1, dTfix=None):
     """``pres_in`` / ``pres_out``: int64 [B, tiles, words] row-presence bit sets handed from stage to stage (see hitadv.h,
     ``pointnet_rowmlp_bwd_tiles``);
     ``mode`` 1: the products on the fp16 matrix cores, two pieces per operand; ``words``: 64-point words per block (the tables'
     last dimension); ``overflow``: int32 [B, tiles] scratch, needed with two words."""
     if overflow is None and words > 1:
         overflow = torch.empty(B, pointnet_rowmlp_bwd_tiles(B, N, mode, words)[0], device=dg.device, dtype=torch.int32)
-    _lib.call("hitadv_pointnet_rowmlp_bwd", stage, _p(dg), _p(gmask), _p(idx), _p(W3r), W3r.shape[0], _p(A2), _p(W2r),
+    if words > 1 and dTfix is None and stage > 0 and dTpart is not None:
+        # scratch of the second launch (include/hitadv.h: hitadv_pointnet_rowmlp_bwd_fix): two one-word partials per tile
+        dTfix = torch.empty(B, 2 * dTpart.shape[1], dTpart.shape[2], device=dg.device)
+    _lib.call("hitadv_pointnet_rowmlp_bwd_fix", stage, _p(dg), _p(gmask), _p(idx), _p(W3r), W3r.shape[0], _p(A2), _p(W2r),
               _p(A1), _p(W1r), _p(H1), _p(dH1in), _p(W0r), _p(T), _p(x), _p(dPin), _p(dTpart), _p(out), _p(pres_in),
-              _p(pres_out), _p(overflow), int(words), B, N, int(mode), _stream())
+              _p(pres_out), _p(overflow), int(words), B, N, int(mode), _p(dTfix), _stream())
 
 
 def pointnet_rowmlp_tiles(N):

@@ -417,6 +417,17 @@ int hitadv_pointnet_rowmlp_bwd(int stage, const float *dg, const float *gmask, c
                                const float *H1, const float *dH1in, const float *W0r, const float *T, const float *x,
                                const float *dPin, float *dTpart, float *out, const uint64_t *pres_in,
                                uint64_t *pres_out, int32_t *overflow, int words, int B, int N, int mode, void *stream);
+/* The same with scratch for the second launch of the two-word form (words = 2): dTfix [B, 2 * tiles, 9] (stage 1) or
+ * [B, 2 * tiles, 4096] (stage 2), unused (may be NULL) in stage 0.  With it the tiles the first launch leaves (more than 64
+ * winning points in 128) are done by the one-word kernel, two blocks per tile, and their partials added in word order --
+ * instead of by a two-pass instantiation that spills (round 5: 6x faster on surface-like clouds, where half the tiles take
+ * this path; nothing changes where none does).  dTfix == NULL: hitadv_pointnet_rowmlp_bwd. */
+int hitadv_pointnet_rowmlp_bwd_fix(int stage, const float *dg, const float *gmask, const int64_t *idx, const float *W3r,
+                                   int Cout, const float *A2, const float *W2r, const float *A1, const float *W1r,
+                                   const float *H1, const float *dH1in, const float *W0r, const float *T, const float *x,
+                                   const float *dPin, float *dTpart, float *out, const uint64_t *pres_in,
+                                   uint64_t *pres_out, int32_t *overflow, int words, int B, int N, int mode, float *dTfix,
+                                   void *stream);
 /* out[b,m] = (extra ? extra[b,m] : 0) + sum_t part[b,t,m], ascending t. */
 int hitadv_sum_partials(const float *part, const float *extra, int B, int T, int M, float *out, void *stream);
 /* out[B,NOUT] = act(in'[B,K] @ Wt[K,NOUT] + bias), in' = in gated by (mask > 0) when mask != NULL (the backward of a
