@@ -199,7 +199,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     import hit_adv_amd
-    in_flight = hit_adv_amd.attacks_in_flight(args.in_flight)  # 8 at most on the runtime's default four hardware queues
+    in_flight = hit_adv_amd.attacks_in_flight(args.in_flight)  # capped at 16 (two stacks of eight) on the runtime's default four hardware queues: hit_adv_amd.attacks_in_flight (the cap of 8 was measured in round 3: 35.5 clouds/s; 16 on four queues has not been measured)
     if hasattr(attacker, 'in_flight'):  # 12 only where the victim passes stack (PointNet engine); 4 for the other victims
         in_flight = attacker.in_flight(in_flight)
     eval_ASR(model, loader, args, attacker, logger=logger, in_flight=in_flight)

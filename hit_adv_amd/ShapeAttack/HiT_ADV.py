@@ -591,7 +591,7 @@ class HiT_ADV:
 
     def in_flight(self, requested):
         """Attacks to hand to ``attack_many`` at a time: ``requested`` where the victim passes are stacked (PointNet engine:
-        twelve = three stacks of four), at most ``UNSTACKED_IN_FLIGHT`` otherwise -- every un-stacked attack in flight holds
+        24 by default = three balanced stacks of up to eight, ``hit_adv_amd.stack_sizes``), at most ``UNSTACKED_IN_FLIGHT`` otherwise -- every un-stacked attack in flight holds
         a workspace, a stream and the victim's activations of its own (DGCNN, PointNet++, PCT)."""
         requested = max(1, int(requested))
         return requested if self.stacks() else min(requested, self.UNSTACKED_IN_FLIGHT)
