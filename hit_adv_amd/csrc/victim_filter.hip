@@ -253,8 +253,12 @@ __global__ __launch_bounds__(512) void vf_stream_k(const uint32_t *__restrict__ 
           m = i + 1 < 4 ? __builtin_fmaxf(__builtin_fmaxf(m, acc[rt][ct][i]), acc[rt][ct][i + 1]) : __builtin_fmaxf(m, acc[rt][ct][i]);
       // max yhat = m + t; the new bound: max(th, max yhat - d)  (rounded down by the 0.2 % / 4 % reserves)
       float nt = __builtin_fmaxf(th[ct], (m + (ct ? t1 : t0)) - (ct ? d1 : d0));
-      nt = __builtin_fmaxf(nt, __shfl_xor(nt, 16, HITADV_WAVE));  // the channel's four lanes (other rows of the tile) share it
-      nt = __builtin_fmaxf(nt, __shfl_xor(nt, 32, HITADV_WAVE));
+      // the channel's four lanes (other rows of the tile) share it -- where it moves most (a cloud's first tiles), then now and then:
+      // two dependent LDS round trips at the end of a tile are not free with two waves per SIMD
+      if (ABL != 5 && (tile_in_cloud < 2 || (tile_in_cloud & 3) == 3)) {  // wave-uniform
+        nt = __builtin_fmaxf(nt, __shfl_xor(nt, 16, HITADV_WAVE));
+        nt = __builtin_fmaxf(nt, __shfl_xor(nt, 32, HITADV_WAVE));
+      }
       th[ct] = nt;
       if (ABL != 4) {
 #pragma unroll
@@ -389,7 +393,7 @@ using namespace hitadv;
 static int g_vf_ablate = 0;
 extern "C" int hitadv_debug_vf_ablate(int what) {
   const int before = g_vf_ablate;
-  if (what >= 0 && what <= 4) g_vf_ablate = what;
+  if (what >= 0 && what <= 5) g_vf_ablate = what;
   return before;
 }
 
@@ -432,6 +436,7 @@ extern "C" int hitadv_linear_max_fwd_f16x2_filtered(const uint32_t *Xp, const ui
     case 2: HITADV_VF_LAUNCH(2); break;
     case 3: HITADV_VF_LAUNCH(3); break;
     case 4: HITADV_VF_LAUNCH(4); break;
+    case 5: HITADV_VF_LAUNCH(5); break;
     default: HITADV_VF_LAUNCH(0);
   }
 #undef HITADV_VF_LAUNCH

@@ -21,7 +21,7 @@ seed = torch.zeros(B, 1024, device=dev, dtype=torch.int64)
 call = lambda s: lib.hitadv_linear_max_fwd_f16x2_filtered(p(xp), p(W2), p(wn), p(bias), B, N, 128, 1024, 1, blocks, p(seed), p(scratch), p(fo), p(fi), p(flag), s)
 call(None); call(None); torch.cuda.synchronize()
 good = seed.clone()
-for abl in (0, 1, 2, 3, 4):
+for abl in (0, 5, 1, 4):
     lib.hitadv_debug_vf_ablate(abl)
     seed.copy_(good)
     us = bench.graph_timed(lambda s: (call(s), lib.hitadv_copy(p(good), p(seed), B * 1024 * 8, s) if hasattr(lib, 'hitadv_copy') and False else None))
