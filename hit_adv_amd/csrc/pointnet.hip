@@ -1256,6 +1256,13 @@ __global__ __launch_bounds__(256, STAGE == 1 ? 2 : 3) void rowmlp_bwd_k(RowMlpBw
 // the accumulators (masks fetched in the accumulator's layout), so the tile exists in LDS only as pieces and the separate
 // mask pass with its barrier is gone; the 64 -> 3 layer reads its rows back as hi + 2^-11 lo.
 // dA2[D rows, 32 columns of this wave] = S[D,M] @ W3r[list,:] as above, 16 list entries per MFMA step.
+// Round 5: the selection matrix S (one non-zero per column: entry k routes its gradient to compact row i_k) is built on the
+// PACKED gradient word (fp16 hi | fp16 lo << 16): one compare and ONE select per entry, lane and row block, the two piece vectors
+// then assembled by byte permutes (v_perm_b32, two per pair of entries) -- it used to be a decode of both pieces and a select
+// per piece (~100 vector instructions per 8 entries; the gather was most of the kernel's vector work, and the counters put the
+// kernel at 50 % vector-instruction time: profiles/r05_loop_traffic.json).  The same fragments, bit for bit.  (Tried first: the
+// fragments out of a per-wave LDS tile that 16 lanes scatter the entries into -- four dependent LDS round trips per 8 entries:
+// 2.4x SLOWER end to end.)
 template <bool TWO>
 __device__ __forceinline__ void gather_rows16(const int2 *list, int M, const float *__restrict__ Wc, int r, int h,
                                               f32x16 (&acc)[2], f32x16 (&accl)[2]) {
@@ -1269,27 +1276,32 @@ __device__ __forceinline__ void gather_rows16(const int2 *list, int M, const flo
       bv[t] = Wc[(size_t)(en[t].x & 0xffff) * 128];
     }
   };
+  const uint32_t row0 = (uint32_t)r << 16, row1 = (uint32_t)(32 + r) << 16;
   auto multiply = [&](const int2 (&en)[16], const float (&bv)[16]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       float bq[8];
-      h8v ah0, al0, ah1, al1;
+      uint32_t w0[8], w1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int2 e = en[8 * s + j];
         bq[j] = bv[8 * s + j];
-        const int i = e.x >> 16;
-        const uint32_t g2 = (uint32_t)e.y;  // (hi piece, lo piece) of the gradient value
-        const _Float16 gh = __builtin_bit_cast(_Float16, (uint16_t)(g2 & 0xffffu));
-        const _Float16 gl = __builtin_bit_cast(_Float16, (uint16_t)(g2 >> 16));
-        const _Float16 z = (_Float16)0.f;
-        ah0[j] = i == r ? gh : z;
-        al0[j] = i == r ? gl : z;
-        if (TWO) {
-          ah1[j] = i == 32 + r ? gh : z;
-          al1[j] = i == 32 + r ? gl : z;
-        }
+        const uint32_t key = (uint32_t)e.x & 0xffff0000u;  // the entry's compact row << 16
+        w0[j] = key == row0 ? (uint32_t)e.y : 0u;          // (hi piece | lo piece << 16) of the gradient value, or nothing
+        if (TWO) w1[j] = key == row1 ? (uint32_t)e.y : 0u;
       }
+      uint4 h0, l0, h1, l1;
+      h0.x = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u), l0.x = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u);
+      h0.y = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u), l0.y = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u);
+      h0.z = __builtin_amdgcn_perm(w0[5], w0[4], 0x05040100u), l0.z = __builtin_amdgcn_perm(w0[5], w0[4], 0x07060302u);
+      h0.w = __builtin_amdgcn_perm(w0[7], w0[6], 0x05040100u), l0.w = __builtin_amdgcn_perm(w0[7], w0[6], 0x07060302u);
+      if (TWO) {
+        h1.x = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u), l1.x = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u);
+        h1.y = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u), l1.y = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u);
+        h1.z = __builtin_amdgcn_perm(w1[5], w1[4], 0x05040100u), l1.z = __builtin_amdgcn_perm(w1[5], w1[4], 0x07060302u);
+        h1.w = __builtin_amdgcn_perm(w1[7], w1[6], 0x05040100u), l1.w = __builtin_amdgcn_perm(w1[7], w1[6], 0x07060302u);
+      }
+      const h8v ah0 = __builtin_bit_cast(h8v, h0), al0 = __builtin_bit_cast(h8v, l0);
       uint4 wh, wl;
       split8v(bq, wh, wl);
       const h8v bh = __builtin_bit_cast(h8v, wh), bl = __builtin_bit_cast(h8v, wl);
@@ -1297,6 +1309,7 @@ __device__ __forceinline__ void gather_rows16(const int2 *list, int M, const flo
       accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl, accl[0], 0, 0, 0);
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh, acc[0], 0, 0, 0);
       if (TWO) {
+        const h8v ah1 = __builtin_bit_cast(h8v, h1), al1 = __builtin_bit_cast(h8v, l1);
         accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh, accl[1], 0, 0, 0);
         accl[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl, accl[1], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh, acc[1], 0, 0, 0);
