@@ -102,6 +102,151 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
   }
 }
 
+// Round 5: fps_lean, the step of MODE 0 / MODE 2 (256 < N <= 4080).  A step is a serial chain on ONE CU; with one wave per SIMD
+// every instruction of any kind costs the wave ~4.6 cycles and every LDS round trip ~90, so the step is priced in instructions
+// and trips (docs/kernels/round5.md §8; tools/tune/fps_step_probe.hip stamps the parts).  Against fps<> above:
+//   * distances of two points per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32; the same roundings in the same order)
+//   * the running distance alone is reduced, as its bit pattern: a max inside the lane, 6 DPP maxima across the wave -- the
+//     64-bit (distance, tie) key per point and its two 32-bit reductions are gone.  The winner's index is then found from the
+//     wave's maximum M: ballot(run[u] >= M) for u = PT-1 .. 0 leaves the lowest u that holds it and the lowest lane of that u,
+//     i.e. the lowest point index (k = thread + threads * u), which is what the key's tie word encoded.
+//   * PCT's distance is sqrt(clamped d): sqrt is monotone and correctly rounded, so min(run, sqrt(d)) = sqrt(min(run^2, d))
+//     exactly (1e5 = sqrt(1e10) exactly): the running value is kept SQUARED and one sqrt per wave and step replaces one per
+//     point.  Points tie with the maximum when their sqrt rounds to the same float s, i.e. when run^2 >= t, t = the smallest
+//     float whose sqrt rounds to s = the smallest float >= ((s + pred(s)) / 2)^2, evaluated exactly in fp64 (a 25-bit number
+//     squared has 50 bits; it is never itself a float, so no rounding tie exists).
+//   * the waves' (bits of the distance, ~index) keys meet in ONE LDS word by ds_max_u64: after the barrier the winner is one
+//     8-byte read, not NW slots and NW - 1 64-bit compare-selects (three words in rotation, so that clearing needs no barrier).
+//   * 8 waves per cloud for N > 1024 (two per SIMD interleave; each carries half of the points).
+// Tried and dropped: the candidates' coordinates out of the holder lane's registers (v_readlane under a scalar branch tree on
+// u) posted beside the key, to save the LDS read of the winner's coordinates -- the branch tree and the five reads after the
+// barrier cost more than the trip (N = 1024: 0.56 us per step against 0.36).
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// the smallest float x with sqrt_rn(x) == s (s > 0 finite, the correctly rounded sqrt of some float)
+__device__ __forceinline__ float sqrt_preimage_floor(float s) {
+  const float sp = __uint_as_float(__float_as_uint(s) - 1u);
+  const double mid = ((double)s + (double)sp) * 0.5;
+  const double m2 = mid * mid;
+  const float t = (float)m2;
+  return (double)t < m2 ? __uint_as_float(__float_as_uint(t) + 1u) : t;
+}
+
+// PROBE (tools/tune/fps_step_probe.hip only; results are garbage): 1 no read of the winner's coordinates, 2 no exchange between
+// the waves, 3 no search for the holder, 4 no reduction across the lanes, 5 cycle stamps -- what each part of the step costs.
+// NW = waves per cloud.  A wave alone on its SIMD issues one instruction (of any kind) every 4-5 cycles at best and waits out
+// every dependency itself; two waves per SIMD (NW = 8) interleave, and each carries half of the points.
+template <int PT, bool PCT, int NW, typename IdxT, int PROBE = 0>
+__global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xyz, const int64_t *__restrict__ start, int N, int m,
+                                                    IdxT *__restrict__ idx) {
+  static_assert(PT % 2 == 0, "two points per packed instruction");
+  constexpr int PP = PT / 2, TH = 64 * NW;
+  extern __shared__ float4 spts[];  // the cloud: (x, y, z, |p|^2)
+  __shared__ unsigned long long s_key[3];  // step j's winner: the waves' keys meet in word j % 3 by ds_max_u64 (no merge to compute)
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  xyz += (size_t)b * N * 3;
+  idx += (size_t)b * m;
+  f2v px[PP], py[PP], pz[PP], rp[PP];
+  // running distances as BIT PATTERNS: they are >= +0, where unsigned order is float order, so v_min_u32 / v_max_u32 / the
+  // unsigned DPP max do the float work without the canonicalising v_max_f32 x, x that IEEE mode puts in front of every float
+  // min / max; a NaN distance (any sign) is a large unsigned number and never replaces a running value, like `d < run`.
+  // Points past N hold 0 = the distance +0: they tie with an exhausted cloud's points and lose to them on the index.
+  uint32_t run[PT];
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    const int k = threadIdx.x + TH * u;
+    const bool in = k < N;
+    const int kk = in ? k : 0;
+    const float x = xyz[kk * 3], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
+    const float r = (x * x + y * y) + z * z;
+    px[u >> 1][u & 1] = x, py[u >> 1][u & 1] = y, pz[u >> 1][u & 1] = z, rp[u >> 1][u & 1] = r;
+    run[u] = in ? fbits(1e10f) : 0u;  // PCT: (1e5)^2
+    if (in) spts[k] = make_float4(x, y, z, r);
+  }
+  int far = (int)start[b];
+  if (threadIdx.x < 3) s_key[threadIdx.x] = 0ull;
+  typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+  const uint32_t key_at = (uint32_t)(uintptr_t)(lds_u64 *)&s_key[0];
+  int j3 = 0;  // j % 3
+  __syncthreads();
+  unsigned long long acc_t[5] = {0, 0, 0, 0, 0}, t_prev = 0;  // PROBE 5: shader cycles per part of the step, summed over the steps
+  auto stamp = [&](int i) {
+    if (PROBE == 5) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      acc_t[i] += t - t_prev;
+      t_prev = t;
+    }
+  };
+  if (PROBE == 5) t_prev = __builtin_readcyclecounter();
+  for (int j = 0; j < m; ++j) {
+    if (wave == 0) idx[j] = (IdxT)far;  // a scalar branch; the wave's lanes store one value to one address
+    float4 c;
+    if (PROBE == 1)
+      c = make_float4(far * 1e-4f, far * 2e-4f, far * 3e-4f, far * 1e-5f);
+    else
+      c = spts[far];
+    if (PROBE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(0);
+    const f2v cx2 = {c.x, c.x}, cy2 = {c.y, c.y}, cz2 = {c.z, c.z}, rc2 = {c.w, c.w};
+    uint32_t lb = 0u;
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+      uint32_t d0, d1;
+      if (PCT) {  // common.hpp::pct_dist before its sqrt, two points at a time
+        const f2v zz = __builtin_elementwise_fma(cy2, py[p], cx2 * px[p]) + cz2 * pz[p];
+        const f2v m2 = {-2.0f, -2.0f};
+        const f2v d = __builtin_elementwise_fma(m2, zz, rc2 + rp[p]);
+        d0 = d[0] < 0.f ? fbits(1e-7f) : fbits(d[0]);
+        d1 = d[1] < 0.f ? fbits(1e-7f) : fbits(d[1]);
+      } else {  // common.hpp::sqdist3(point, centroid)
+        const f2v dx = px[p] - cx2, dy = py[p] - cy2, dz = pz[p] - cz2;
+        const f2v d = (dx * dx + dy * dy) + dz * dz;
+        d0 = fbits(d[0]), d1 = fbits(d[1]);
+      }
+      run[2 * p] = d0 < run[2 * p] ? d0 : run[2 * p];
+      run[2 * p + 1] = d1 < run[2 * p + 1] ? d1 : run[2 * p + 1];
+      const uint32_t pm = run[2 * p] > run[2 * p + 1] ? run[2 * p] : run[2 * p + 1];
+      lb = pm > lb ? pm : lb;
+    }
+    if (PROBE == 5) asm volatile("" : "+v"(lb));
+    stamp(1);
+    const uint32_t M = PROBE == 4 ? (uint32_t)__builtin_amdgcn_readlane((int)lb, 63) : wave_max_u32_dpp(lb);  // wave-uniform
+    uint32_t value = M, floor = M;
+    if (PCT) {
+      const float sq = __builtin_sqrtf(__uint_as_float(M));
+      value = fbits(sq);
+      floor = sq > 0.f ? fbits(sqrt_preimage_floor(sq)) : 0u;
+    }
+    int U = 0;
+    unsigned long long holders = 0ull;
+#pragma unroll
+    for (int u = PT - 1; u >= (PROBE == 3 ? PT - 1 : 0); --u) {
+      const unsigned long long h = __builtin_amdgcn_ballot_w64(run[u] >= floor);
+      if (h) holders = h, U = u;
+    }
+    const uint32_t k = (uint32_t)(TH * U + 64 * wave + (int)__builtin_ctzll(holders));  // u = 0 of every wave is inside the cloud
+    const unsigned long long key = ((unsigned long long)value << 32) | (0xFFFFFFFFu - k);
+    stamp(2);
+    if (PROBE == 2) {
+      far = (int)k % N;
+      continue;
+    }
+    if (lane == 0) asm volatile("ds_max_u64 %0, %1" ::"v"(key_at + 8u * (uint32_t)j3), "v"(key) : "memory");
+    __syncthreads();
+    stamp(3);
+    const unsigned long long w = s_key[j3];
+    j3 = j3 == 2 ? 0 : j3 + 1;
+    // word (j + 2) % 3 was last read before this barrier and is next written after the next one: clear it in between
+    if (wave == 0) s_key[j3 == 2 ? 0 : j3 + 1] = 0ull;
+    far = (int)(0xFFFFFFFFu - (uint32_t)(w & 0xffffffffu));
+    if (PROBE == 5) asm volatile("" : "+v"(far));
+    stamp(4);
+  }
+  if (PROBE == 5 && threadIdx.x == 0 && m >= 5)
+    for (int i = 0; i < 5; ++i) idx[i] = (IdxT)acc_t[i];
+}
+
 __global__ __launch_bounds__(256) void gather_points_k(int c, int n, int npoints,
                                                        const float *__restrict__ points,
                                                        const int32_t *__restrict__ idx,
@@ -131,6 +276,8 @@ __global__ __launch_bounds__(256) void gather_points_grad_k(int c, int n, int np
       for (int l = 0; l < c; ++l) gp[(size_t)l * n] += go[(size_t)l * npoints + j];
 }
 
+static int g_fps_form = 1;  // MODE 0 / 2 with 256 < N <= 4080: 1 = fps_lean; 0 = the 64-bit-key kernel everywhere (A/B, tests)
+
 template <int MODE, typename IdxT>
 static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int m, IdxT *idx, hipStream_t s) {
   int ref_bs = 1, ref_bits = 0;
@@ -140,8 +287,27 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
       ++ref_bits;
     }
   }
-  const int use_lds = N <= 4096;
+  const int use_lds = N <= 4080;  // the cloud as float4 + the slots inside the 64 KB a launch gets without opting in
   const size_t shm = use_lds ? (size_t)N * sizeof(float4) : 0;
+  if (MODE != 1 && g_fps_form != 0 && use_lds && N > 256) {  // fps_lean: the cloud in LDS, 4 or 8 waves per cloud
+#define HITADV_FPS_LEAN(PT, NW)                                                                                   \
+  if (N <= 64 * NW * PT) {                                                                                        \
+    fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx);                              \
+    return 0;                                                                                                     \
+  }
+    // waves per cloud (tools/tune/fps_step_probe.hip, us per step at 4 / 8 / 16 waves): N = 2048 0.381 / 0.349 / 0.379, N = 1024
+    // 0.301 / 0.293; PCT's distance at N = 1024 0.379 / 0.419 (its sqrt and threshold are per wave)
+    if (MODE != 2 && N > 1024) {
+      HITADV_FPS_LEAN(4, 8)
+      HITADV_FPS_LEAN(8, 8)
+    } else {
+      HITADV_FPS_LEAN(2, 4)
+      HITADV_FPS_LEAN(4, 4)
+      HITADV_FPS_LEAN(8, 4)
+      HITADV_FPS_LEAN(16, 4)
+    }
+#undef HITADV_FPS_LEAN
+  }
 #define HITADV_FPS_CASE(PT)                                                                       \
   if (N <= 256 * PT) {                                                                            \
     fps<PT, MODE, IdxT><<<B, 256, shm, s>>>(xyz, start, N, m, ref_bs, ref_bits, use_lds, idx);     \
@@ -161,6 +327,12 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
 }  // namespace hitadv
 
 using namespace hitadv;
+
+extern "C" int hitadv_debug_fps_form(int form) {
+  const int old = g_fps_form;
+  if (form == 0 || form == 1) g_fps_form = form;
+  return old;
+}
 
 extern "C" int hitadv_fps_from_start(const float *xyz, const int64_t *start, int B, int N, int m,
                                      int64_t *idx, void *stream) {

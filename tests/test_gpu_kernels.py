@@ -432,6 +432,28 @@ def test_fps_pct_bit_exact_sizes(A, n, m):
     assert torch.equal(A.fps_pct(cu(x), m, cu(start), reference=False).cpu(), N.fps_from_start(x, m, start))
 
 
+@pytest.mark.parametrize("n,m", [(600, 600), (1024, 400), (2048, 300), (4500, 40)])
+def test_fps_both_samplers_on_a_lattice_of_exact_ties(A, n, m):
+    """Coordinates on a coarse lattice with repeated points: most steps have several points at exactly the maximal running
+    distance (and, for PCT's sampler, distinct squared distances whose sqrt rounds to one float), and m = n drives every
+    running distance to zero -- the lowest index must win each time (model/pointnet2_utils.py:63-84 through torch.max;
+    util/other_utils.py:254-272).  The 64-bit-key kernel and the lean one (sampling.hip) must both give the oracle's table."""
+    g = torch.Generator().manual_seed(77 + n)
+    x = torch.randint(-3, 4, (3, n, 3), generator=g).float() * 0.25
+    x[1] += 0.001 * torch.randn(n, 3, generator=g).round(decimals=3)  # near-lattice: values one or two ulps apart
+    start = torch.tensor([0, n - 1, 5])
+    want0, want2 = N.fps_from_start(x, m, start), N.fps_pct(x, m, start)
+    from hit_adv_amd import _lib
+    L = _lib.load()
+    try:
+        for form in (0, 1):
+            L.hitadv_debug_fps_form(form)
+            assert torch.equal(A.fps_from_start(cu(x), m, cu(start)).cpu(), want0), form
+            assert torch.equal(A.fps_pct(cu(x), m, cu(start), reference=True).cpu(), want2), form
+    finally:
+        L.hitadv_debug_fps_form(1)
+
+
 def test_fps_pct_reproduces_the_reference_table(A):
     fx = golden('g12_pct.npz')
     pts = T(fx['x']).transpose(1, 2).contiguous()
