@@ -46,6 +46,22 @@ __device__ __forceinline__ int g16_off(int r, int c) { return r * G16_RS + 16 * 
 #define HITADV_G16_WR 4
 #endif
 
+// eight values -> their fp16 pieces (csrc/pointnet.hip::split8v with this file's scale: hi pieces two per v_cvt_pk_f16_f32, each lo
+// piece one v_fma_mix on the packed hi piece read in place; the bits of stash_as() below)
+__device__ __forceinline__ void split8v_g16(const float (&v)[8], uint4 &hi, uint4 &lo) {
+  uint32_t H[4], L[4];
+  const float nsc = -G16_SCALE;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float s0 = v[2 * p] * G16_SCALE, s1 = v[2 * p + 1] * G16_SCALE;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(H[p]) : "v"(v[2 * p]), "v"(v[2 * p + 1]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L[p]) : "v"(H[p]), "s"(nsc), "v"(s1));
+  }
+  hi = make_uint4(H[0], H[1], H[2], H[3]);
+  lo = make_uint4(L[0], L[1], L[2], L[3]);
+}
+
 struct G16Tile {
   int b;          // cloud (plain GEMM: 0)
   int p0;         // first point of the block within the cloud
@@ -469,6 +485,215 @@ __global__ __launch_bounds__(WR * 128) void gemm_f16x2_k(AProd ap, const uint16_
   epi.template operator()<RT>(t, acc, wr, wc, lane, sG16);
 }
 
+// ---------------------------------------------------------------------------------------------- the ring kernel (round 5)
+// gemm_f16x2_k above is bound by operand delivery, not by its products (docs/kernels/other_victims.md: with no LDS reads and no
+// MFMAs it still takes 98 of 159 us): operands travel global -> registers -> split -> LDS one K step ahead, every wave's staging
+// sits between every wave's products, and a second register set spills.  Here NOTHING is staged through registers:
+//   * both operands go global -> LDS by global_load_lds_dwordx4 (16 bytes per lane, a wave fills 1 KB of LDS in lane order; the
+//     swizzle is applied on the GLOBAL side: lane p fetches the chunk that belongs at LDS position p), into a THREE-stage ring,
+//     so the loads of K step s + 2 are in flight while step s multiplies; one s_barrier and one s_waitcnt vmcnt per step
+//   * a plain fp32 A operand lands in LDS as fp32 rows (128 bytes per row and step) and is split into its two fp16 pieces by the
+//     wave that reads the fragment (split8v: the same bits as the staging split; the two waves of a row block both split their
+//     rows: 28 vector instructions per 16 x 32 fragment against 48 MFMAs of 16 cycles)
+//   * the products, their order and the accumulators are gemm_f16x2_k's: the results are the same bits.
+// LDS-DMA and its waits are inline asm: the compiler's counter tracking would put s_waitcnt vmcnt(0) in front of every LDS read
+// that may alias a DMA write, which is exactly the wait the ring exists to avoid.
+constexpr int GR_AROW = 128;                        // bytes per fp32 A row and K step
+constexpr int GR_A = G16_BM * GR_AROW;              // 32 KB
+constexpr int GR_STAGE = GR_A + 2 * G16_BPIECE;     // 48 KB
+constexpr int GR_STAGES = 3;
+// 16-byte chunk c of fp32 row r sits at position c ^ s(r), s = bit 1 of r | bit 2 of r << 2: the sixteen lanes a ds_read_b128 serves
+// together (rows 0-3, 12-15 at chunk 2 g, rows 4-11 at chunk 2 g + 2) then cover the sixteen 16-byte slots of a 256-byte bank
+// row once (rows alternate between its halves, s takes {0, 1, 4, 5} on each parity of either row set)
+__device__ __forceinline__ int gr_swz(int r) { return ((r >> 1) & 1) | (((r >> 2) & 1) << 2); }
+
+// (m0 is not a clobber the compiler accepts; nothing else in this kernel uses it: gfx9 LDS instructions do not read m0)
+__device__ __forceinline__ void gr_dma16(uint32_t lds_at, uint32_t voff, const void *sbase) {
+  const unsigned long long a = (unsigned long long)(uintptr_t)sbase;
+  const unsigned long long u = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_at)), "v"(voff),
+               "s"(u)
+               : "memory");
+}
+
+// ABL != 0: tuning builds only (tools/tune/g16_ablate.py; results are garbage): 11 no MFMAs, 12 no split (raw bits), 13 no LDS reads,
+// split or MFMAs (the DMA ring and its barriers alone), 14 no DMA after the prologue, 15 one product instead of three
+template <class Epi, bool SYNC_EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_f16x2_ring_k(const float *__restrict__ X, const uint16_t *__restrict__ Wp, int npts,
+                                                         int chunks, int nrb, int ncb, int N, int K, Epi epi, int *range_flag) {
+  constexpr int RT = 4;
+  extern __shared__ __attribute__((aligned(16))) char sG16[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l16 = lane & 15, g4 = lane >> 4;
+  G16Tile t;
+  {
+    int rb, cb;
+    const int id = blockIdx.x;
+    if ((nrb & 7) == 0) {
+      const int xcd = id & 7, slot = id >> 3;
+      cb = slot % ncb;
+      rb = (slot / ncb) * 8 + xcd;
+    } else {
+      cb = id % ncb;
+      rb = id / ncb;
+    }
+    t.rb = rb;
+    t.b = rb / chunks;
+    t.p0 = (rb % chunks) * G16_BM;
+    t.row0 = (long long)t.b * npts + t.p0;
+    t.rows = min(G16_BM, npts - t.p0);
+    t.col0 = cb * G16_BN;
+  }
+  const int nk = K / G16_KS;
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char *)sG16;
+  // A: wave-load i of this wave fills rows 8 (4 wave + i) .. + 7 (1 KB): lane p -> row + (p >> 3), position p & 7
+  uint32_t va[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 8 * (4 * wave + i) + (lane >> 3);
+    va[i] = (uint32_t)min(r, t.rows - 1) * (uint32_t)K * 4u + 16u * (uint32_t)((lane & 7) ^ gr_swz(r));
+  }
+  // B: wave-load j fills piece j, columns 16 wave .. + 15 (1 KB): lane p -> column + (p >> 2), position p & 3 (g16_off's swizzle)
+  const int bcol = 16 * wave + (lane >> 2);
+  const uint32_t vb = (uint32_t)bcol * (uint32_t)K * 2u + 16u * (uint32_t)((lane & 3) ^ ((0x78 >> (2 * ((bcol >> 2) & 3))) & 3));
+  const char *abase = reinterpret_cast<const char *>(X + (size_t)t.row0 * K);
+  const char *bbase0 = reinterpret_cast<const char *>(Wp + (size_t)t.col0 * K);
+  const char *bbase1 = bbase0 + (size_t)N * K * 2;
+  auto issue = [&](int ks) {
+    const uint32_t st = lds0 + (uint32_t)(ks % GR_STAGES) * GR_STAGE;
+    const char *ak = abase + (size_t)ks * (G16_KS * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gr_dma16(st + 1024u * (uint32_t)(4 * wave + i), va[i], ak);
+    gr_dma16(st + GR_A + 1024u * (uint32_t)wave, vb, bbase0 + (size_t)ks * (G16_KS * 2));
+    gr_dma16(st + GR_A + G16_BPIECE + 1024u * (uint32_t)wave, vb, bbase1 + (size_t)ks * (G16_KS * 2));
+  };
+
+  f32x4m acc[RT][4], accl[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f}, accl[rt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  PieceWatch big;
+  // fragment rows 16 x + l16: bits 1, 2 (A) and (row >> 2) & 3 (B) of the row are l16's, one swizzled offset serves every tile
+  const int aoff = l16 * GR_AROW + 16 * ((2 * g4) ^ gr_swz(l16)), aoff1 = l16 * GR_AROW + 16 * ((2 * g4 + 1) ^ gr_swz(l16));
+  const int boff = g16_off(l16, g4);
+  // The fragments of step s + 1 are read WHILE step s multiplies: a barrier aligns the waves, and with the reads at the top of a
+  // step every wave waited out the LDS at the same time, then every wave split, then every wave multiplied (measured: delivery
+  // alone 63 us, products 59, split 20, and 148 in all -- nothing overlapped).  So a step is: split the A rows read during the
+  // previous step (raw fp32 -> pieces, in registers), wait + barrier for stage s + 1, request stage s + 3 into the buffer stage
+  // s has just left, request the A rows of step s + 1 from LDS, then the products column tile by column tile, each tile's B
+  // fragments re-read for step s + 1 as soon as its twelve products are issued.
+  uint4 fb[4][2];
+  float4 fa[RT][2];
+  uint4 ah[RT], al[RT];
+  auto frag_base = [&](int ks) { return sG16 + (size_t)(ks % GR_STAGES) * GR_STAGE; };
+  auto read_a = [&](int ks) {
+    if constexpr (ABL == 13) return;
+    const char *ab = frag_base(ks) + 64 * wr * GR_AROW + aoff, *ab1 = frag_base(ks) + 64 * wr * GR_AROW + aoff1;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      fa[rt][0] = *reinterpret_cast<const float4 *>(ab + 16 * rt * GR_AROW);
+      fa[rt][1] = *reinterpret_cast<const float4 *>(ab1 + 16 * rt * GR_AROW);
+    }
+  };
+  auto read_b = [&](int ks, int ct) {
+    if constexpr (ABL == 13) return;
+    const char *bb = frag_base(ks) + GR_A + 64 * wc * G16_RS + boff;
+    fb[ct][0] = *reinterpret_cast<const uint4 *>(bb + 16 * ct * G16_RS);
+    fb[ct][1] = *reinterpret_cast<const uint4 *>(bb + 16 * ct * G16_RS + G16_BPIECE);
+  };
+  auto split_a = [&]() {
+    if constexpr (ABL == 13) return;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float4 v0 = fa[rt][0], v1 = fa[rt][1];
+      const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if constexpr (ABL == 12) {
+        ah[rt] = __builtin_bit_cast(uint4, v0), al[rt] = __builtin_bit_cast(uint4, v1);
+      } else {
+        split8v_g16(v, ah[rt], al[rt]);
+        big.see_f16x2(ah[rt].x), big.see_f16x2(ah[rt].y), big.see_f16x2(ah[rt].z), big.see_f16x2(ah[rt].w);
+      }
+    }
+  };
+  auto products = [&](int ct) {
+    if constexpr (ABL == 13) return;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const f16x8m ahi = as_f16x8m(ah[rt]), alo = as_f16x8m(al[rt]);
+      if constexpr (ABL == 11) {
+        accl[rt][ct][0] += (float)alo[0] + (float)as_f16x8m(fb[ct][1])[0] + (float)ahi[1] + (float)as_f16x8m(fb[ct][0])[2];
+        continue;
+      }
+      if constexpr (ABL == 15) {
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, as_f16x8m(fb[ct][0]), acc[rt][ct], 0, 0, 0);
+        accl[rt][ct][0] += (float)alo[0] + (float)as_f16x8m(fb[ct][1])[0];
+        continue;
+      }
+    }
+    if constexpr (ABL == 11 || ABL == 15) return;
+    // the two products into accl[rt][ct] are four MFMAs apart, not back to back (the second reads the first's result)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) accl[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8m(al[rt]), as_f16x8m(fb[ct][0]), accl[rt][ct], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8m(ah[rt]), as_f16x8m(fb[ct][0]), acc[rt][ct], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) accl[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8m(ah[rt]), as_f16x8m(fb[ct][1]), accl[rt][ct], 0, 0, 0);
+  };
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  // stage 0: this wave's loads (the twelve newer ones may fly), then every wave's
+  if (nk > 2)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nk > 1)
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_a(0);
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) read_b(0, ct);
+  for (int ks = 0; ks < nk; ++ks) {
+    split_a();  // (waits for the A rows of this step, requested during the previous one)
+    __builtin_amdgcn_sched_barrier(0);
+    const bool more = ks + 1 < nk;
+    if (more) {
+      // stage ks + 1: this wave's loads have landed (six newer ones, stage ks + 2's, may still fly) ...
+      if (ks + 2 < nk && ABL != 14)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // ... and after the barrier every wave's have; every wave has also taken stage ks out of LDS, whose buffer stage ks + 3 refills
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (ks + 3 < nk && ABL != 14) issue(ks + 3);
+      read_a(ks + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      products(ct);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) read_b(ks + 1, ct);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (big.beyond_fp16() && range_flag != nullptr) *range_flag = 1;  // beyond fp16 (or NaN): the caller refuses the result
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[rt][ct][i] = fmaf(accl[rt][ct][i], 1.f / G16_SCALE, acc[rt][ct][i]);
+  if constexpr (SYNC_EPI) __syncthreads();  // the epilogue reuses the LDS ring
+  epi.template operator()<RT>(t, acc, wr, wc, lane, sG16);
+}
+
 // out[b] = [max over the cloud's row blocks | sum / n], arg = the row of the max (lowest on ties: blocks ascend)
 __global__ void pool_merge_k(const float *__restrict__ pmax, const float *__restrict__ psum, const int32_t *__restrict__ parg,
                              int B, int chunks, int C, float inv_n, float *__restrict__ out, int32_t *__restrict__ arg) {
@@ -514,6 +739,21 @@ static int launch_gemm16(const AProd &ap, const uint16_t *Wp, int B, int npts, i
   return 0;
 }
 
+static int g_g16_ring = 1;  // plain fp32 A operands: 1 = gemm_f16x2_ring_k where it is faster (K >= 256), 0 = gemm_f16x2_k, 2 = the ring for every K >= 64 (tests)
+
+template <class Epi, bool SYNC_EPI>
+static int launch_gemm16_plain(const float *X, const uint16_t *Wp, int B, int npts, int N, int K, const Epi &epi, int32_t *range_flag,
+                               hipStream_t s) {
+  if (!g_g16_ring || K / G16_KS < 2 || (g_g16_ring == 1 && K < 256))
+    return launch_gemm16<PlainA<false, G16_U>, Epi, SYNC_EPI>(PlainA<false, G16_U>{X, nullptr, K}, Wp, B, npts, N, K, epi, range_flag, s);
+  const int chunks = (npts + G16_BM - 1) / G16_BM, nrb = B * chunks, ncb = N / G16_BN;
+  HITADV_RAISE_LDS((&gemm_f16x2_ring_k<Epi, SYNC_EPI>), GR_STAGES * GR_STAGE);
+  gemm_f16x2_ring_k<Epi, SYNC_EPI><<<dim3((unsigned)(nrb * ncb)), 512, GR_STAGES * GR_STAGE, s>>>(X, Wp, npts, chunks, nrb, ncb, N, K, epi,
+                                                                                               range_flag);
+  HITADV_LAUNCH_CHECK();
+  return 0;
+}
+
 static bool g16_shape_ok(long long M, int N, int K) { return M > 0 && M < (1ll << 31) && N > 0 && K > 0 && (N % G16_BN) == 0 && (K % G16_KS) == 0; }
 
 }  // namespace hitadv
@@ -537,8 +777,13 @@ extern "C" int hitadv_gemm_f16x2(const float *X, const float *mask, const uint16
   const PlainEpi epi{C, bias, N, relu};
   if (mask != nullptr)
     return launch_gemm16<PlainA<true, G16_U>, PlainEpi, false>(PlainA<true, G16_U>{X, mask, K}, Wp, 1, (int)M, N, K, epi, range_flag, (hipStream_t)stream);
-  return launch_gemm16<PlainA<false, G16_U>, PlainEpi, false>(PlainA<false, G16_U>{X, nullptr, K}, Wp, 1, (int)M, N, K, epi, range_flag,
-                                                       (hipStream_t)stream);
+  return launch_gemm16_plain<PlainEpi, false>(X, Wp, 1, (int)M, N, K, epi, range_flag, (hipStream_t)stream);
+}
+
+extern "C" int hitadv_debug_g16_ring(int on) {
+  const int old = g_g16_ring;
+  if (on >= 0 && on <= 2) g_g16_ring = on;
+  return old;
 }
 
 extern "C" int64_t hitadv_linear_lrelu_pool_scratch(int B, int npts, int C) {
@@ -554,7 +799,7 @@ extern "C" int hitadv_linear_lrelu_pool_fwd(const float *X, const uint16_t *Wp, 
     return HITADV_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const PoolEpi epi{bias, reinterpret_cast<uint16_t *>(bits), pmax, psum, parg, C, slope};
-  const int rc = launch_gemm16<PlainA<false, G16_U>, PoolEpi, true>(PlainA<false, G16_U>{X, nullptr, Cin}, Wp, B, npts, C, Cin, epi, range_flag, s);
+  const int rc = launch_gemm16_plain<PoolEpi, true>(X, Wp, B, npts, C, Cin, epi, range_flag, s);
   if (rc) return rc;
   const int chunks = (npts + G16_BM - 1) / G16_BM;
   pool_merge_k<<<(unsigned)((B * C + 255) / 256), 256, 0, s>>>(pmax, psum, parg, B, chunks, C, 1.f / (float)npts, out, arg);
@@ -581,11 +826,9 @@ extern "C" int hitadv_group_linear_max_g16_fwd(const float *X, const uint16_t *W
   if (!X || !Wp || !bias || !out || !arg || G <= 0 || !hitadv_group_linear_max_g16_supported(Cin, Cout, ns) ||
       !g16_shape_ok(G * ns, Cout, Cin) || ((uintptr_t)X & 15) || ((uintptr_t)Wp & 15))
     return HITADV_E_ARG;
-  using AP = PlainA<false, G16_U>;
-  const AP ap{X, nullptr, Cin};
   hipStream_t s = (hipStream_t)stream;
-  if (ns == 32) return launch_gemm16<AP, GroupMaxEpi<32>, false>(ap, Wp, 1, (int)(G * ns), Cout, Cin, GroupMaxEpi<32>{bias, out, arg, Cout}, range_flag, s);
-  return launch_gemm16<AP, GroupMaxEpi<64>, false>(ap, Wp, 1, (int)(G * ns), Cout, Cin, GroupMaxEpi<64>{bias, out, arg, Cout}, range_flag, s);
+  if (ns == 32) return launch_gemm16_plain<GroupMaxEpi<32>, false>(X, Wp, 1, (int)(G * ns), Cout, Cin, GroupMaxEpi<32>{bias, out, arg, Cout}, range_flag, s);
+  return launch_gemm16_plain<GroupMaxEpi<64>, false>(X, Wp, 1, (int)(G * ns), Cout, Cin, GroupMaxEpi<64>{bias, out, arg, Cout}, range_flag, s);
 }
 
 extern "C" int hitadv_group_linear_max_g16_bwd(const float *dm, const int32_t *arg, const uint16_t *Wtp, int64_t G, int ns, int Cin,
@@ -615,6 +858,27 @@ static int g16_ablate_launch(const float *X, const uint16_t *Wp, long long M, in
 }
 extern "C" int hitadv_gemm_f16x2_ablate(int abl, const float *X, const uint16_t *Wp, long long M, int N, int K, float *C, void *stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (abl >= 10) {
+    const PlainEpi epi{C, nullptr, N, 0};
+    const int chunks = (int)((M + G16_BM - 1) / G16_BM), nrb = chunks, ncb = N / G16_BN;
+#define HITADV_RING_ABL(A_)                                                                                                    \
+  case A_: {                                                                                                                   \
+    HITADV_RAISE_LDS((&gemm_f16x2_ring_k<PlainEpi, false, A_ == 10 ? 0 : A_>), GR_STAGES * GR_STAGE);                          \
+    gemm_f16x2_ring_k<PlainEpi, false, A_ == 10 ? 0 : A_><<<dim3((unsigned)(nrb * ncb)), 512, GR_STAGES * GR_STAGE, s>>>(       \
+        X, Wp, (int)M, chunks, nrb, ncb, N, K, epi, nullptr);                                                                  \
+    return (int)hipGetLastError();                                                                                             \
+  }
+    switch (abl) {
+      HITADV_RING_ABL(10)
+      HITADV_RING_ABL(11)
+      HITADV_RING_ABL(12)
+      HITADV_RING_ABL(13)
+      HITADV_RING_ABL(14)
+      HITADV_RING_ABL(15)
+    }
+#undef HITADV_RING_ABL
+    return -1;
+  }
   switch (abl) {
     case 0: return g16_ablate_launch<0>(X, Wp, M, N, K, C, s);
     case 1: return g16_ablate_launch<1>(X, Wp, M, N, K, C, s);

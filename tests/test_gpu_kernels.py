@@ -1350,6 +1350,57 @@ def test_gemm_f16x2_is_fp32_accurate(A, M, K, N):
     assert int(flag.item()) == 1
 
 
+@pytest.mark.parametrize("M,K,N", [(256, 64, 128), (700, 96, 128), (2048 + 37, 512, 256), (4096, 1024, 512), (300, 32, 128)])
+def test_gemm_f16x2_ring_kernel_equals_the_staged_kernel(A, M, K, N):
+    """gemm_f16x2_ring_k (operands global -> LDS by DMA into a three-stage ring, the fp32 A rows split by the wave that reads them)
+    computes gemm_f16x2_k's products in its order: the same bits, for whole and partial row blocks, 1 to 32 K steps (K = 32 stays
+    on the staged kernel), with the bias / ReLU epilogue; and the fused DGCNN layer and the range flag through the same switch."""
+    from hit_adv_amd import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(M * 3 + K + N)
+    x = torch.randn(M, K, generator=g) * torch.logspace(-3, 2, K)  # columns of very different magnitudes
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    Wp = A.split_rows_f16x2(cu(W), range_flag=flag)
+    outs = {}
+    try:
+        for ring in (0, 2):  # 2: the ring kernel whatever K (1, the default, keeps K < 256 on the staged kernel)
+            L.hitadv_debug_g16_ring(ring)
+            outs[ring] = (A.gemm_f16x2(cu(x), Wp, range_flag=flag), A.gemm_f16x2(cu(x), Wp, bias=cu(bias), relu=True, range_flag=flag))
+        assert int(flag.item()) == 0
+        assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+        big = x.clone()
+        big[M // 2, K - 1] = 7e4  # beyond fp16: both kernels must raise the flag
+        for ring in (0, 2):
+            L.hitadv_debug_g16_ring(ring)
+            flag.zero_()
+            A.gemm_f16x2(cu(big), Wp, range_flag=flag)
+            assert int(flag.item()) == 1, ring
+    finally:
+        L.hitadv_debug_g16_ring(1)
+
+
+@pytest.mark.parametrize("B,Np,Cin,C", [(3, 300, 64, 128), (2, 1024, 512, 1024)])
+def test_linear_lrelu_pool_ring_kernel_equals_the_staged_kernel(A, B, Np, Cin, C):
+    from hit_adv_amd import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(B + Np + C)
+    x = torch.randn(B * Np, Cin, generator=g)
+    W = torch.randn(C, Cin, generator=g) / Cin ** 0.5
+    bias = torch.randn(C, generator=g) * 0.1
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    Wp, Wtp = A.split_rows_f16x2(cu(W), flag), A.split_rows_f16x2(cu(W.t().contiguous()), flag)
+    res = {}
+    try:
+        for ring in (0, 2):
+            L.hitadv_debug_g16_ring(ring)
+            res[ring] = A.linear_lrelu_pool(cu(x), Wp, Wtp, cu(bias), B, Np, 0.2, flag, return_arg=True)
+    finally:
+        L.hitadv_debug_g16_ring(1)
+    assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
+
+
 @pytest.mark.parametrize("B,Np,Cin,C", [(2, 1024, 512, 1024), (3, 500, 512, 1024), (2, 77, 128, 128), (1, 256, 512, 256)])
 def test_linear_lrelu_pool_forward_and_backward(A, B, Np, Cin, C):
     """DGCNN's embedding layer + LeakyReLU + max / mean pooling in one kernel against the float64 composition: values, the

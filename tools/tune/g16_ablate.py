@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where the time of gemm_f16x2_k goes: the kernel rebuilt with -DHITADV_G16_TUNE, timed with one cost removed at a time
 (0 as shipped, 1 no fp16 conversions in the stash, 2 no global loads after the first K step, 3 no LDS reads / MFMAs, 4 one
-product instead of three).  Builds /tmp/libg16.so with hipcc on the box; prints one JSON line."""
+product instead of three; 10-15: gemm_f16x2_ring_k as shipped, no MFMAs, no split, the DMA ring alone, no DMA after the
+prologue, one product).  Builds /tmp/libg16.so with hipcc on the box; prints one JSON line."""
 import ctypes
 import json
 import os
@@ -29,7 +30,7 @@ for M, K, N in ((32768, 512, 1024), (32768, 1024, 512)):
     s = P(torch.cuda.current_stream().cuda_stream)
     lib.hitadv_split_rows_f16x2(P(W.data_ptr()), N, K, P(Wp.data_ptr()), None, s)
     row = {}
-    for abl in (0, 1, 2, 3, 4, 0):
+    for abl in (0, 1, 2, 3, 4, 0, 10, 11, 12, 13, 14, 15, 10):
         for _ in range(3):
             lib.hitadv_gemm_f16x2_ablate(abl, P(x.data_ptr()), P(Wp.data_ptr()), M, N, K, P(C.data_ptr()), s)
         torch.cuda.synchronize()
