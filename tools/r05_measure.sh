@@ -29,7 +29,7 @@ for what in "$@"; do
       rm -rf /tmp/prof/cfg2
       timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/cfg2 -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-single --no-f32 --no-other-configs --no-cpu-baseline > $OUT/prof_cfg2.log 2>&1
       f=$(find /tmp/prof/cfg2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/cfg2_headline_kernel_stats.csv
-      tail -1 $OUT/prof_cfg2.log > $OUT/prof_line_headline.json; head -12 $OUT/cfg2_headline_kernel_stats.csv ;;
+      grep -m1 '^{"metric"' $OUT/prof_cfg2.log > $OUT/prof_line_headline.json; head -12 $OUT/cfg2_headline_kernel_stats.csv ;;
     kbench)
       timeout 300 python tools/kbench.py > $OUT/kbench.json 2> $OUT/kbench.err; tail -c 600 $OUT/kbench.json ;;
   esac
