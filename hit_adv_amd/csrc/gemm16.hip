@@ -664,10 +664,12 @@ __global__ __launch_bounds__(512) void gemm_f16x2_ring_k(const float *__restrict
     const bool more = ks + 1 < nk;
     if (more) {
       // stage ks + 1: this wave's loads have landed (six newer ones, stage ks + 2's, may still fly) ...
+      // (lgkmcnt(0): the B fragments of THIS step, read from stage ks during the previous one, are in registers before any wave may
+      // request stage ks + 3 into that buffer -- split_a() above only waited for the A rows, which were requested first)
       if (ks + 2 < nk && ABL != 14)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
       else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       // ... and after the barrier every wave's have; every wave has also taken stage ks out of LDS, whose buffer stage ks + 3 refills
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

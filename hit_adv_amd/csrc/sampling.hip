@@ -232,7 +232,10 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
       far = (int)k % N;
       continue;
     }
-    if (lane == 0) asm volatile("ds_max_u64 %0, %1" ::"v"(key_at + 8u * (uint32_t)j3), "v"(key) : "memory");
+    // (the wait is part of the asm: the compiler does not know this is an LDS operation and puts no s_waitcnt between it and the
+    // barrier -- the winner read after the barrier then depends on the order the LDS happens to serve the waves in, which a
+    // co-resident kernel's LDS traffic changed: tests/test_gpu_attack.py::test_cw_attacks_in_flight_at_once_...)
+    if (lane == 0) asm volatile("ds_max_u64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(key_at + 8u * (uint32_t)j3), "v"(key) : "memory");
     __syncthreads();
     stamp(3);
     const unsigned long long w = s_key[j3];
@@ -295,8 +298,8 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
     fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx);                              \
     return 0;                                                                                                     \
   }
-    // waves per cloud (tools/tune/fps_step_probe.hip, us per step at 4 / 8 / 16 waves): N = 2048 0.381 / 0.349 / 0.379, N = 1024
-    // 0.301 / 0.293; PCT's distance at N = 1024 0.379 / 0.419 (its sqrt and threshold are per wave)
+    // waves per cloud (tools/tune/fps_step_probe.hip, us per step at 4 / 8 / 16 waves, before the posting lane's wait): N = 2048
+    // 0.381 / 0.349 / 0.379, N = 1024 0.301 / 0.293; PCT's distance at N = 1024 0.379 / 0.419 (its sqrt and threshold are per wave)
     if (MODE != 2 && N > 1024) {
       HITADV_FPS_LEAN(4, 8)
       HITADV_FPS_LEAN(8, 8)

@@ -30,6 +30,11 @@ for what in "$@"; do
       timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/cfg2 -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-single --no-f32 --no-other-configs --no-cpu-baseline > $OUT/prof_cfg2.log 2>&1
       f=$(find /tmp/prof/cfg2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/cfg2_headline_kernel_stats.csv
       grep -m1 '^{"metric"' $OUT/prof_cfg2.log > $OUT/prof_line_headline.json; head -12 $OUT/cfg2_headline_kernel_stats.csv ;;
+    probes)  # the FPS step's parts, G16's ablations and counters
+      timeout 100 ./tools/tune/fps_step_probe > $OUT/fps_step_probe.txt 2>&1; tail -3 $OUT/fps_step_probe.txt
+      timeout 100 ./tools/tune/clock_probe > $OUT/clock_probe.txt 2>&1
+      timeout 600 python tools/tune/g16_ablate.py 2>/dev/null | tail -1 > $OUT/g16_ablation.json; cat $OUT/g16_ablation.json
+      bash tools/g16_pmc.sh > $OUT/g16_pmc.txt 2>&1; cat $OUT/g16_pmc.txt ;;
     kbench)
       timeout 300 python tools/kbench.py > $OUT/kbench.json 2> $OUT/kbench.err; tail -c 600 $OUT/kbench.json ;;
   esac
