@@ -100,6 +100,20 @@ def test_fps_maximum_and_unsupported_sizes(A):
     assert A.fps_from_start(one.cuda(), 3, torch.zeros(2, dtype=torch.int64).cuda()).tolist() == [[0, 0, 0], [0, 0, 0]]
 
 
+@pytest.mark.parametrize("n", [256, 257, 512, 513, 1024, 1025, 2048, 2049, 4080, 4081])
+def test_fps_kernel_boundaries_both_samplers(A, n):
+    """Every size at which the sampling launcher changes kernel or shape (sampling.hip::launch_fps: <= 256 the 64-bit-key kernel,
+    then fps_lean at 2 / 4 / 8 points per lane on 4 waves, 8 waves above 1024, the cloud out of LDS above 4080), with a NaN
+    point, for both samplers and for as many samples as the cloud has points at the small sizes."""
+    x = pts(2, n, 900 + n)
+    x[1, 3] = float('nan')  # never chosen after the start: its distances compare false
+    start = torch.tensor([n - 1, 0])
+    m = n if n <= 513 else 70
+    assert torch.equal(A.fps_from_start(x.cuda(), m, start.cuda()).cpu(), N.fps_from_start(x, m, start))
+    y = pts(2, n, 901 + n)
+    assert torch.equal(A.fps_pct(y.cuda(), m, start.cuda(), reference=True).cpu(), N.fps_pct(y, m, start))
+
+
 def test_natives_ragged_sizes(A):
     from hit_adv_amd.pointnet2_ops import _ext
     x = pts(2, 333, 50)
