@@ -35,6 +35,34 @@ for what in "$@"; do
       timeout 100 ./tools/tune/clock_probe > $OUT/clock_probe.txt 2>&1
       timeout 600 python tools/tune/g16_ablate.py 2>/dev/null | tail -1 > $OUT/g16_ablation.json; cat $OUT/g16_ablation.json
       bash tools/g16_pmc.sh > $OUT/g16_pmc.txt 2>&1; cat $OUT/g16_pmc.txt ;;
+    pmc_k1)  # HBM traffic of K1 / K2 (and cfg4's / cfg5's roofline kernel): separate --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share one)
+      for ctr in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/prof/pmc_$ctr
+        timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/prof/pmc_$ctr -- python3 tools/k1_probe.py > $OUT/pmc_$ctr.log 2>&1
+        f=$(find /tmp/prof/pmc_$ctr -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" /tmp/prof/pmc_$ctr.csv
+      done
+      python tools/pmc_summary.py /tmp/prof/pmc_WRITE_SIZE.csv /tmp/prof/pmc_FETCH_SIZE.csv > $OUT/kbench_traffic.json 2>> $OUT/pmc_WRITE_SIZE.log
+      for c in cfg4 cfg5; do
+        for ctr in FETCH_SIZE WRITE_SIZE; do
+          rm -rf /tmp/prof/gar_$ctr
+          timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/prof/gar_$ctr -- python3 tools/gar_probe.py $c > $OUT/pmc_gar_${c}_$ctr.log 2>&1
+          f=$(find /tmp/prof/gar_$ctr -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" /tmp/prof/gar_${c}_$ctr.csv
+        done
+        python tools/pmc_summary.py /tmp/prof/gar_${c}_WRITE_SIZE.csv /tmp/prof/gar_${c}_FETCH_SIZE.csv > $OUT/gar_traffic_$c.json
+      done
+      python - $OUT <<'PY'
+import json, sys
+out = sys.argv[1]
+merged = json.load(open(out + '/kbench_traffic.json'))
+for c in ('cfg4', 'cfg5'):
+    d = json.load(open('%s/gar_traffic_%s.json' % (out, c)))
+    for k, v in d.items():
+        if 'group_add_relu_fwd_k' in k or 'rows_linear_gather' in k:
+            merged[k + '@' + c] = v
+json.dump(merged, open(out + '/kbench_traffic.json', 'w'), indent=1)
+print(json.dumps({k: v['hbm_bytes_per_launch'] for k, v in merged.items()}))
+PY
+      ;;
     kbench)
       timeout 300 python tools/kbench.py > $OUT/kbench.json 2> $OUT/kbench.err; tail -c 600 $OUT/kbench.json ;;
   esac
