@@ -741,7 +741,7 @@ static int launch_gemm16(const AProd &ap, const uint16_t *Wp, int B, int npts, i
   return 0;
 }
 
-static int g_g16_ring = 1;  // plain fp32 A operands: 1 = gemm_f16x2_ring_k where it is faster (K >= 256), 0 = gemm_f16x2_k, 2 = the ring for every K >= 64 (tests)
+static int g_g16_ring = [] { const char *e = getenv("HITADV_G16_RING"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();  // plain fp32 A operands: 1 = gemm_f16x2_ring_k where it is faster (K >= 256), 0 = gemm_f16x2_k, 2 = the ring for every K >= 64 (tests)
 
 template <class Epi, bool SYNC_EPI>
 static int launch_gemm16_plain(const float *X, const uint16_t *Wp, int B, int npts, int N, int K, const Epi &epi, int32_t *range_flag,

@@ -11,6 +11,8 @@
 //                 thread-slot tie order of the reference's shared-memory tree)
 //        MODE 2 : PCT's sampler, util/other_utils.py:254-272: given start, distances by get_dists (:237-251: sqrt of
 //                 the clamped Gram form in torch's own fp32 arithmetic, common.hpp::pct_dist), running distance 1e5
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "hitadv.h"
 
@@ -121,7 +123,11 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
 // Tried and dropped: the candidates' coordinates out of the holder lane's registers (v_readlane under a scalar branch tree on
 // u) posted beside the key, to save the LDS read of the winner's coordinates -- the branch tree and the five reads after the
 // barrier cost more than the trip (N = 1024: 0.56 us per step against 0.36).
+#ifndef HITADV_FPS_DIAG
+#define HITADV_FPS_DIAG 0
+#endif
 typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ unsigned int g_fps_dbg[8];  // HITADV_FPS_DIAG == 4: [0] registers != memory at the end, [1] LDS copy != registers at the end, [2] points checked
 
 // the smallest float x with sqrt_rn(x) == s (s > 0 finite, the correctly rounded sqrt of some float)
 __device__ __forceinline__ float sqrt_preimage_floor(float s) {
@@ -136,13 +142,14 @@ __device__ __forceinline__ float sqrt_preimage_floor(float s) {
 // the waves, 3 no search for the holder, 4 no reduction across the lanes, 5 cycle stamps -- what each part of the step costs.
 // NW = waves per cloud.  A wave alone on its SIMD issues one instruction (of any kind) every 4-5 cycles at best and waits out
 // every dependency itself; two waves per SIMD (NW = 8) interleave, and each carries half of the points.
-template <int PT, bool PCT, int NW, typename IdxT, int PROBE = 0>
+template <int PT, bool PCT, int NW, typename IdxT, int PROBE = 0, bool SLOTS = false>
 __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xyz, const int64_t *__restrict__ start, int N, int m,
                                                     IdxT *__restrict__ idx) {
   static_assert(PT % 2 == 0, "two points per packed instruction");
   constexpr int PP = PT / 2, TH = 64 * NW;
   extern __shared__ float4 spts[];  // the cloud: (x, y, z, |p|^2)
   __shared__ unsigned long long s_key[3];  // step j's winner: the waves' keys meet in word j % 3 by ds_max_u64 (no merge to compute)
+  __shared__ unsigned long long s_slot[2][NW];  // SLOTS: one word per wave instead, merged by every thread
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   xyz += (size_t)b * N * 3;
@@ -158,7 +165,13 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
     const int k = threadIdx.x + TH * u;
     const bool in = k < N;
     const int kk = in ? k : 0;
+#ifdef HITADV_FPS_COHERENT_LOADS  // diagnostic: agent-scope loads (past this CU's L1)
+    const float x = __hip_atomic_load(&xyz[kk * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float y = __hip_atomic_load(&xyz[kk * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float z = __hip_atomic_load(&xyz[kk * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     const float x = xyz[kk * 3], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
+#endif
     const float r = (x * x + y * y) + z * z;
     px[u >> 1][u & 1] = x, py[u >> 1][u & 1] = y, pz[u >> 1][u & 1] = z, rp[u >> 1][u & 1] = r;
     run[u] = in ? fbits(1e10f) : 0u;  // PCT: (1e5)^2
@@ -180,12 +193,27 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
   };
   if (PROBE == 5) t_prev = __builtin_readcyclecounter();
   for (int j = 0; j < m; ++j) {
+#if HITADV_FPS_DIAG == 1
+    __threadfence_block();
+    __syncthreads();
+#endif
+#if HITADV_FPS_DIAG == 2
+    if (threadIdx.x == 0) idx[j] = (IdxT)far;
+#else
     if (wave == 0) idx[j] = (IdxT)far;  // a scalar branch; the wave's lanes store one value to one address
+#endif
     float4 c;
     if (PROBE == 1)
       c = make_float4(far * 1e-4f, far * 2e-4f, far * 3e-4f, far * 1e-5f);
+#if HITADV_FPS_DIAG == 3
+    else {
+      c.x = xyz[far * 3], c.y = xyz[far * 3 + 1], c.z = xyz[far * 3 + 2];
+      c.w = (c.x * c.x + c.y * c.y) + c.z * c.z;
+    }
+#else
     else
       c = spts[far];
+#endif
     if (PROBE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     stamp(0);
     const f2v cx2 = {c.x, c.x}, cy2 = {c.y, c.y}, cz2 = {c.z, c.z}, rc2 = {c.w, c.w};
@@ -235,19 +263,52 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
     // (the wait is part of the asm: the compiler does not know this is an LDS operation and puts no s_waitcnt between it and the
     // barrier -- the winner read after the barrier then depends on the order the LDS happens to serve the waves in, which a
     // co-resident kernel's LDS traffic changed: tests/test_gpu_attack.py::test_cw_attacks_in_flight_at_once_...)
-    if (lane == 0) asm volatile("ds_max_u64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(key_at + 8u * (uint32_t)j3), "v"(key) : "memory");
-    __syncthreads();
-    stamp(3);
-    const unsigned long long w = s_key[j3];
-    j3 = j3 == 2 ? 0 : j3 + 1;
-    // word (j + 2) % 3 was last read before this barrier and is next written after the next one: clear it in between
-    if (wave == 0) s_key[j3 == 2 ? 0 : j3 + 1] = 0ull;
+    unsigned long long w;
+    if constexpr (SLOTS) {
+      if (lane == 0) s_slot[j & 1][wave] = key;
+      __syncthreads();
+      w = s_slot[j & 1][0];
+#pragma unroll
+      for (int t = 1; t < NW; ++t) {
+        const unsigned long long o = s_slot[j & 1][t];
+        w = o > w ? o : w;
+      }
+    } else {
+      if (lane == 0) {
+        unsigned long long before;  // the RETURNING form: its data coming back is proof that the LDS has performed the operation
+        asm volatile("ds_max_rtn_u64 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(before) : "v"(key_at + 8u * (uint32_t)j3), "v"(key) : "memory");
+        (void)before;
+      }
+      __syncthreads();
+      stamp(3);
+      w = s_key[j3];
+      j3 = j3 == 2 ? 0 : j3 + 1;
+      // word (j + 2) % 3 was last read before this barrier and is next written after the next one: clear it in between
+      if (wave == 0) s_key[j3 == 2 ? 0 : j3 + 1] = 0ull;
+    }
     far = (int)(0xFFFFFFFFu - (uint32_t)(w & 0xffffffffu));
     if (PROBE == 5) asm volatile("" : "+v"(far));
     stamp(4);
   }
   if (PROBE == 5 && threadIdx.x == 0 && m >= 5)
     for (int i = 0; i < 5; ++i) idx[i] = (IdxT)acc_t[i];
+#if HITADV_FPS_DIAG == 4
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < PT; ++u) {
+    const int k = threadIdx.x + TH * u;
+    if (k < N) {
+      const float gx = __hip_atomic_load(&xyz[k * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const float gy = __hip_atomic_load(&xyz[k * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const float gz = __hip_atomic_load(&xyz[k * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const float rx = px[u >> 1][u & 1], ry = py[u >> 1][u & 1], rz = pz[u >> 1][u & 1];
+      const float4 l = spts[k];
+      if (!(gx == rx && gy == ry && gz == rz)) atomicAdd(&g_fps_dbg[0], 1u);
+      if (!(l.x == rx && l.y == ry && l.z == rz)) atomicAdd(&g_fps_dbg[1], 1u);
+      atomicAdd(&g_fps_dbg[2], 1u);
+    }
+  }
+#endif
 }
 
 __global__ __launch_bounds__(256) void gather_points_k(int c, int n, int npoints,
@@ -279,7 +340,7 @@ __global__ __launch_bounds__(256) void gather_points_grad_k(int c, int n, int np
       for (int l = 0; l < c; ++l) gp[(size_t)l * n] += go[(size_t)l * npoints + j];
 }
 
-static int g_fps_form = 1;  // MODE 0 / 2 with 256 < N <= 4080: 1 = fps_lean; 0 = the 64-bit-key kernel everywhere (A/B, tests)
+static int g_fps_form = [] { const char *e = getenv("HITADV_FPS_FORM"); return e && e[0] == '0' ? 0 : 1; }();  // MODE 0 / 2 with 256 < N <= 4080: 1 = fps_lean; 0 = the 64-bit-key kernel everywhere (A/B, tests)
 
 template <int MODE, typename IdxT>
 static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int m, IdxT *idx, hipStream_t s) {
@@ -295,12 +356,17 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
   if (MODE != 1 && g_fps_form != 0 && use_lds && N > 256) {  // fps_lean: the cloud in LDS, 4 or 8 waves per cloud
 #define HITADV_FPS_LEAN(PT, NW)                                                                                   \
   if (N <= 64 * NW * PT) {                                                                                        \
-    fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx);                              \
+    if (slots_exchange)                                                                                           \
+      fps_lean<PT, MODE == 2, NW, IdxT, 0, true><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx);                   \
+    else                                                                                                          \
+      fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx);                            \
     return 0;                                                                                                     \
   }
     // waves per cloud (tools/tune/fps_step_probe.hip, us per step at 4 / 8 / 16 waves, before the posting lane's wait): N = 2048
     // 0.381 / 0.349 / 0.379, N = 1024 0.301 / 0.293; PCT's distance at N = 1024 0.379 / 0.419 (its sqrt and threshold are per wave)
-    if (MODE != 2 && N > 1024) {
+    static const bool slots_exchange = [] { const char *e = getenv("HITADV_FPS_EXCH"); return e && e[0] == 's'; }();  // A/B
+    static const bool four_waves_only = [] { const char *e = getenv("HITADV_FPS_WAVES"); return e && e[0] == '4'; }();  // A/B
+    if (MODE != 2 && N > 1024 && !four_waves_only) {
       HITADV_FPS_LEAN(4, 8)
       HITADV_FPS_LEAN(8, 8)
     } else {
@@ -330,6 +396,10 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
 }  // namespace hitadv
 
 using namespace hitadv;
+
+extern "C" int hitadv_debug_fps_counters(unsigned int *host8) {
+  return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(hitadv::g_fps_dbg), sizeof(unsigned int) * 8);
+}
 
 extern "C" int hitadv_debug_fps_form(int form) {
   const int old = g_fps_form;

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""HITADV_FPS_CHECK diagnostic: PointNet++ under HiT-ADV, short horizon, in four modes -- {eager, graphs} x {1, 2 attacks in
+flight} -- counting the clouds whose FPS table differs between the two sampling kernels."""
+import os, sys
+os.environ.setdefault("HITADV_FPS_CHECK", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from hit_adv_amd import ops
+from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+cfg = bench.CONFIGS['cfg4']
+dev = torch.device('cuda', 0)
+model = bench.build_victim(cfg).to(dev)
+from hit_adv_amd.Dataset.synthetic import synth_batch
+def batch(i):
+    data, _ = synth_batch(cfg['B'], cfg['N'], first=100 * i)
+    data = data.to(dev)
+    with torch.no_grad():
+        o = model(data[:, :, :3].transpose(1, 2).contiguous()); lab = (o[0] if isinstance(o, tuple) else o).argmax(1)
+    return data, lab
+bs = [batch(0), batch(1)]
+for graph in (False,):
+    for n in (1, 2):
+        for v in ops._FPS_CHECK.values():
+            if isinstance(v, torch.Tensor): v.zero_()
+        torch.manual_seed(5)
+        att = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=1, num_iter=40, verbose=False, use_graph=graph, **bench.HP)
+        if n == 1:
+            att.attack(*bs[0])
+        else:
+            att.attack_many(bs)
+        torch.cuda.synchronize()
+        import ctypes
+        from hit_adv_amd import _lib
+        buf = (ctypes.c_uint * 8)()
+        try:
+            _lib.load().hitadv_debug_fps_counters(buf)
+        except AttributeError:
+            pass
+        print('graph', graph, 'in flight', n, ops.fps_check_counts(), 'kernel counters', list(buf)[:3], flush=True)
