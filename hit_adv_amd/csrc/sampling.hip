@@ -211,8 +211,12 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
       c.w = (c.x * c.x + c.y * c.y) + c.z * c.z;
     }
 #else
-    else
+    else {
       c = spts[far];
+#if HITADV_FPS_DIAG == 6
+      asm volatile("" ::"v"(c.w));  // keeps the whole 16-byte read (ds_read_b128, not ds_read_b96)
+#endif
+    }
 #endif
     if (PROBE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     stamp(0);
@@ -279,7 +283,15 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
         asm volatile("ds_max_rtn_u64 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(before) : "v"(key_at + 8u * (uint32_t)j3), "v"(key) : "memory");
         (void)before;
       }
+#if HITADV_FPS_DIAG == 5  // every wave posts the step it is in before the barrier; behind it, all of them must have
+      __shared__ int s_step[NW];
+      if (lane == 0) s_step[wave] = j + 1;
+#endif
       __syncthreads();
+#if HITADV_FPS_DIAG == 5
+      if (lane < NW && s_step[lane] != j + 1) atomicAdd(&g_fps_dbg[0], 1u);
+      if (lane == 0) atomicAdd(&g_fps_dbg[2], 1u);
+#endif
       stamp(3);
       w = s_key[j3];
       j3 = j3 == 2 ? 0 : j3 + 1;
@@ -340,7 +352,11 @@ __global__ __launch_bounds__(256) void gather_points_grad_k(int c, int n, int np
       for (int l = 0; l < c; ++l) gp[(size_t)l * n] += go[(size_t)l * npoints + j];
 }
 
-static int g_fps_form = [] { const char *e = getenv("HITADV_FPS_FORM"); return e && e[0] == '0' ? 0 : 1; }();  // MODE 0 / 2 with 256 < N <= 4080: 1 = fps_lean; 0 = the 64-bit-key kernel everywhere (A/B, tests)
+// 0 (default) = the 64-bit-key kernel everywhere; 1 = fps_lean for MODE 0 / 2 with 256 < N <= 4080 (HITADV_FPS_FORM=1, or
+// hitadv_debug_fps_form).  fps_lean is NOT the default: alone on the GPU it is bit-exact in every test, but with a second attack
+// in flight on another stream it returns a different (wrong) table for 1-30 % of the clouds of a PointNet++ forward pass
+// (tools/fps_check_modes.py; docs/kernels/round5.md section 8) -- cause not found.
+static int g_fps_form = [] { const char *e = getenv("HITADV_FPS_FORM"); return e && e[0] == '1' ? 1 : 0; }();
 
 template <int MODE, typename IdxT>
 static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int m, IdxT *idx, hipStream_t s) {

@@ -507,66 +507,8 @@ def fps_from_start(xyz, npoint, start):
     start = _dev(start, "start", torch.int64)
     B, N, _ = xyz.shape
     idx = torch.empty(B, npoint, device=xyz.device, dtype=torch.int64)
-    if os.environ.get("HITADV_FPS_CHECK") == "sync_stream":
-        torch.cuda.current_stream().synchronize()
-    elif os.environ.get("HITADV_FPS_CHECK") == "sync_device":
-        torch.cuda.synchronize()
-    if _FPS_CHECK is not None:
-        snap_xyz, snap_start = xyz.clone(), start.clone()
-    if os.environ.get("HITADV_FPS_ORDER") == "key64_first":  # diagnostic: the 64-bit-key kernel takes the first launch's place
-        _lib.load().hitadv_debug_fps_form(0)
     _lib.call("hitadv_fps_from_start", _p(xyz), _p(start), B, N, npoint, _p(idx), _stream())
-    if os.environ.get("HITADV_FPS_ORDER") == "key64_first":
-        _lib.load().hitadv_debug_fps_form(1)
-    if _FPS_CHECK is not None:  # HITADV_FPS_CHECK=1 (diagnostic): every table also by the 64-bit-key kernel; mismatches are counted
-        lib = _lib.load()
-        second = torch.empty_like(idx)  # the lean kernel again, right behind the first launch
-        _lib.call("hitadv_fps_from_start", _p(xyz), _p(start), B, N, npoint, _p(second), _stream())
-        chk = torch.empty_like(idx)
-        lib.hitadv_debug_fps_form(0)
-        _lib.call("hitadv_fps_from_start", _p(xyz), _p(start), B, N, npoint, _p(chk), _stream())
-        lib.hitadv_debug_fps_form(1)
-        key = xyz.device
-        if key not in _FPS_CHECK:
-            _FPS_CHECK[key] = torch.zeros(2, dtype=torch.int64, device=xyz.device)
-        c = _FPS_CHECK[key]
-        again = torch.empty_like(idx)  # the lean kernel a second time, and whether the input changed meanwhile
-        _lib.call("hitadv_fps_from_start", _p(xyz), _p(start), B, N, npoint, _p(again), _stream())
-        more = _FPS_CHECK.setdefault('more', torch.zeros(3, dtype=torch.int64, device=xyz.device))
-        more[0] += (again != idx).any(dim=1).sum()   # lean run 1 vs lean run 2
-        more[1] += (again != chk).any(dim=1).sum()   # lean run 2 vs key64
-        more[2] += (second != chk).any(dim=1).sum()  # the launch right behind the first vs key64
-        chg = _FPS_CHECK.setdefault('inputs_changed', torch.zeros(2, dtype=torch.int64, device=xyz.device))
-        chg[0] += (xyz != snap_xyz).any().to(torch.int64)      # calls during which the cloud changed under the kernels
-        chg[1] += (start != snap_start).any().to(torch.int64)  # ... the start indices
-        bad = (idx != chk).any(dim=1)
-        cap = _FPS_CHECK.setdefault((N, npoint), dict(xyz=torch.zeros(N, 3, device=xyz.device), start=torch.zeros((), dtype=torch.int64, device=xyz.device),
-                                                     lean=torch.zeros(npoint, dtype=torch.int64, device=xyz.device),
-                                                     key64=torch.zeros(npoint, dtype=torch.int64, device=xyz.device),
-                                                     have=torch.zeros((), dtype=torch.bool, device=xyz.device)))
-        first = bad.to(torch.int64).argmax()
-        take = bad.any() & ~cap['have']
-        cap['xyz'].copy_(torch.where(take, xyz[first], cap['xyz']))
-        cap['start'].copy_(torch.where(take, start[first], cap['start']))
-        cap['lean'].copy_(torch.where(take, idx[first], cap['lean']))
-        cap['key64'].copy_(torch.where(take, chk[first], cap['key64']))
-        cap['have'].logical_or_(take)
-        c[0] += bad.sum()
-        c[1] += B
     return idx
-
-
-_FPS_CHECK = {} if os.environ.get("HITADV_FPS_CHECK") else None
-
-
-def fps_check_counts():
-    """(clouds whose table differed between the two sampling kernels, clouds sampled) under HITADV_FPS_CHECK=1."""
-    return {str(k): v.tolist() for k, v in (_FPS_CHECK or {}).items() if not isinstance(k, tuple)}  # 'more': [lean1 != lean2, lean2 != key64, -]
-
-
-def fps_check_captures():
-    """The first cloud (per size) whose two tables differed: {(N, npoint): dict(xyz, start, lean, key64, have)}."""
-    return {k: {n: t.cpu() for n, t in v.items()} for k, v in (_FPS_CHECK or {}).items() if isinstance(k, tuple)}
 
 
 def fps_pct(xyz, npoint, start, reference=None):

@@ -105,13 +105,22 @@ def test_fps_kernel_boundaries_both_samplers(A, n):
     """Every size at which the sampling launcher changes kernel or shape (sampling.hip::launch_fps: <= 256 the 64-bit-key kernel,
     then fps_lean at 2 / 4 / 8 points per lane on 4 waves, 8 waves above 1024, the cloud out of LDS above 4080), with a NaN
     point, for both samplers and for as many samples as the cloud has points at the small sizes."""
+    from hit_adv_amd import _lib
+    L = _lib.load()
     x = pts(2, n, 900 + n)
     x[1, 3] = float('nan')  # never chosen after the start: its distances compare false
     start = torch.tensor([n - 1, 0])
     m = n if n <= 513 else 70
-    assert torch.equal(A.fps_from_start(x.cuda(), m, start.cuda()).cpu(), N.fps_from_start(x, m, start))
     y = pts(2, n, 901 + n)
-    assert torch.equal(A.fps_pct(y.cuda(), m, start.cuda(), reference=True).cpu(), N.fps_pct(y, m, start))
+    want, want_pct = N.fps_from_start(x, m, start), N.fps_pct(y, m, start)
+    shipped = L.hitadv_debug_fps_form(-1)
+    try:
+        for form in (0, 1):  # 0: the shipped 64-bit-key kernel; 1: fps_lean (HITADV_FPS_FORM=1)
+            L.hitadv_debug_fps_form(form)
+            assert torch.equal(A.fps_from_start(x.cuda(), m, start.cuda()).cpu(), want), form
+            assert torch.equal(A.fps_pct(y.cuda(), m, start.cuda(), reference=True).cpu(), want_pct), form
+    finally:
+        L.hitadv_debug_fps_form(shipped)
 
 
 def test_natives_ragged_sizes(A):

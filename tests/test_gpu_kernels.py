@@ -445,13 +445,14 @@ def test_fps_both_samplers_on_a_lattice_of_exact_ties(A, n, m):
     want0, want2 = N.fps_from_start(x, m, start), N.fps_pct(x, m, start)
     from hit_adv_amd import _lib
     L = _lib.load()
+    shipped = L.hitadv_debug_fps_form(-1)  # (an invalid value changes nothing and returns the current form)
     try:
         for form in (0, 1):
             L.hitadv_debug_fps_form(form)
             assert torch.equal(A.fps_from_start(cu(x), m, cu(start)).cpu(), want0), form
             assert torch.equal(A.fps_pct(cu(x), m, cu(start), reference=True).cpu(), want2), form
     finally:
-        L.hitadv_debug_fps_form(1)
+        L.hitadv_debug_fps_form(shipped)
 
 
 def test_fps_pct_reproduces_the_reference_table(A):

@@ -2,12 +2,14 @@
 """HITADV_FPS_CHECK diagnostic: PointNet++ under HiT-ADV, short horizon, in four modes -- {eager, graphs} x {1, 2 attacks in
 flight} -- counting the clouds whose FPS table differs between the two sampling kernels."""
 import os, sys
-os.environ.setdefault("HITADV_FPS_CHECK", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import torch
 import bench
 from hit_adv_amd import ops
+import fps_check
+fps_check.install(order=os.environ.get('HITADV_FPS_ORDER', 'lean_first'), sync=os.environ.get('HITADV_FPS_SYNC'))
 from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
 from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
 cfg = bench.CONFIGS['cfg4']
@@ -23,8 +25,7 @@ def batch(i):
 bs = [batch(0), batch(1)]
 for graph in (False,):
     for n in (1, 2):
-        for v in ops._FPS_CHECK.values():
-            if isinstance(v, torch.Tensor): v.zero_()
+        fps_check.reset()
         torch.manual_seed(5)
         att = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=1, num_iter=40, verbose=False, use_graph=graph, **bench.HP)
         if n == 1:
@@ -39,4 +40,4 @@ for graph in (False,):
             _lib.load().hitadv_debug_fps_counters(buf)
         except AttributeError:
             pass
-        print('graph', graph, 'in flight', n, ops.fps_check_counts(), 'kernel counters', list(buf)[:3], flush=True)
+        print('graph', graph, 'in flight', n, fps_check.counts(), 'kernel counters', list(buf)[:3], flush=True)
