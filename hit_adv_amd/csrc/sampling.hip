@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
 // Round 5: fps_lean, the step of MODE 0 / MODE 2 (256 < N <= 4080).  A step is a serial chain on ONE CU; with one wave per SIMD
 // every instruction of any kind costs the wave ~4.6 cycles and every LDS round trip ~90, so the step is priced in instructions
 // and trips (docs/kernels/round5.md §8; tools/tune/fps_step_probe.hip stamps the parts).  Against fps<> above:
-//   * distances of two points per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32; the same roundings in the same order)
+//   * (NOT two points per instruction: with v_pk_add_f32 / v_pk_mul_f32 on the coordinates -- bit-exact in every test, -20 % of
+//     a step's instructions -- a lane now and then missed ONE update of its running distance, only while another stream's kernels
+//     shared the GPU; both samples caught were in lanes 48-63, right behind a v_mov_b32 that fed the packed instruction's
+//     broadcast operand.  tools/fps_check_modes.py, docs/kernels/round5.md section 8.  Plain instructions since.)
 //   * the running distance alone is reduced, as its bit pattern: a max inside the lane, 6 DPP maxima across the wave -- the
 //     64-bit (distance, tie) key per point and its two 32-bit reductions are gone.  The winner's index is then found from the
 //     wave's maximum M: ballot(run[u] >= M) for u = PT-1 .. 0 leaves the lowest u that holds it and the lowest lane of that u,
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
 #ifndef HITADV_FPS_DIAG
 #define HITADV_FPS_DIAG 0
 #endif
-typedef float f2v __attribute__((ext_vector_type(2)));
-__device__ unsigned int g_fps_dbg[8];  // HITADV_FPS_DIAG == 4: [0] registers != memory at the end, [1] LDS copy != registers at the end, [2] points checked
+__device__ unsigned int g_fps_dbg[8];
+__device__ unsigned long long g_fps_hash[4096];  // HITADV_FPS_DIAG == 8: per block, a hash of the sequence of winners the kernel itself saw  // HITADV_FPS_DIAG == 4: [0] registers != memory at the end, [1] LDS copy != registers at the end, [2] points checked
 
 // the smallest float x with sqrt_rn(x) == s (s > 0 finite, the correctly rounded sqrt of some float)
 __device__ __forceinline__ float sqrt_preimage_floor(float s) {
@@ -144,9 +147,8 @@ __device__ __forceinline__ float sqrt_preimage_floor(float s) {
 // every dependency itself; two waves per SIMD (NW = 8) interleave, and each carries half of the points.
 template <int PT, bool PCT, int NW, typename IdxT, int PROBE = 0, bool SLOTS = false>
 __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xyz, const int64_t *__restrict__ start, int N, int m,
-                                                    IdxT *__restrict__ idx) {
-  static_assert(PT % 2 == 0, "two points per packed instruction");
-  constexpr int PP = PT / 2, TH = 64 * NW;
+                                                    IdxT *__restrict__ idx, unsigned long long *dbg_log = nullptr) {
+  constexpr int TH = 64 * NW;
   extern __shared__ float4 spts[];  // the cloud: (x, y, z, |p|^2)
   __shared__ unsigned long long s_key[3];  // step j's winner: the waves' keys meet in word j % 3 by ds_max_u64 (no merge to compute)
   __shared__ unsigned long long s_slot[2][NW];  // SLOTS: one word per wave instead, merged by every thread
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   xyz += (size_t)b * N * 3;
   idx += (size_t)b * m;
-  f2v px[PP], py[PP], pz[PP], rp[PP];
+  float px[PT], py[PT], pz[PT], rp[PT];
   // running distances as BIT PATTERNS: they are >= +0, where unsigned order is float order, so v_min_u32 / v_max_u32 / the
   // unsigned DPP max do the float work without the canonicalising v_max_f32 x, x that IEEE mode puts in front of every float
   // min / max; a NaN distance (any sign) is a large unsigned number and never replaces a running value, like `d < run`.
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
     const float x = xyz[kk * 3], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
 #endif
     const float r = (x * x + y * y) + z * z;
-    px[u >> 1][u & 1] = x, py[u >> 1][u & 1] = y, pz[u >> 1][u & 1] = z, rp[u >> 1][u & 1] = r;
+    px[u] = x, py[u] = y, pz[u] = z, rp[u] = r;
     run[u] = in ? fbits(1e10f) : 0u;  // PCT: (1e5)^2
     if (in) spts[k] = make_float4(x, y, z, r);
   }
@@ -192,10 +194,19 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
     }
   };
   if (PROBE == 5) t_prev = __builtin_readcyclecounter();
+#if HITADV_FPS_DIAG == 8
+  unsigned long long seen = 0ull;
+#endif
   for (int j = 0; j < m; ++j) {
+#if HITADV_FPS_DIAG == 8
+    seen = seen * 1000003ull + (unsigned long long)(unsigned int)far;
+#endif
 #if HITADV_FPS_DIAG == 1
     __threadfence_block();
     __syncthreads();
+#endif
+#if HITADV_FPS_DIAG >= 100  // a pure delay per step (64 x (DIAG - 100) cycles): does the failure depend on how long a step takes?
+    __builtin_amdgcn_s_sleep(HITADV_FPS_DIAG - 100);
 #endif
 #if HITADV_FPS_DIAG == 2
     if (threadIdx.x == 0) idx[j] = (IdxT)far;
@@ -216,30 +227,42 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
 #if HITADV_FPS_DIAG == 6
       asm volatile("" ::"v"(c.w));  // keeps the whole 16-byte read (ds_read_b128, not ds_read_b96)
 #endif
+#if HITADV_FPS_DIAG == 9  // what lane 63 of every wave used as this step's winner and centre, and how many lanes were active
+      if (dbg_log != nullptr && lane == 63) {
+        unsigned long long *l2 = dbg_log + (size_t)gridDim.x * m * NW;
+        l2[((size_t)blockIdx.x * m + j) * NW + wave] = ((unsigned long long)__float_as_uint(c.x) << 32) | ((unsigned long long)__builtin_popcountll(__builtin_amdgcn_read_exec()) << 24) | (unsigned int)(far & 0xffffff);
+      }
+#endif
+#if HITADV_FPS_DIAG == 7  // the centre out of LDS against the same point out of memory, per lane and step
+      {
+        const float gx = xyz[far * 3], gy = xyz[far * 3 + 1], gz = xyz[far * 3 + 2];
+        if (!(gx == c.x && gy == c.y && gz == c.z)) {
+          const unsigned int n = atomicAdd(&g_fps_dbg[0], 1u);
+          if (n == 0) {
+            g_fps_dbg[3] = (unsigned int)far, g_fps_dbg[4] = (unsigned int)j, g_fps_dbg[5] = threadIdx.x, g_fps_dbg[6] = __float_as_uint(c.x),
+            g_fps_dbg[7] = __float_as_uint(gx);
+          }
+        }
+        if (lane == 0) atomicAdd(&g_fps_dbg[2], 1u);
+      }
+#endif
     }
 #endif
     if (PROBE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     stamp(0);
-    const f2v cx2 = {c.x, c.x}, cy2 = {c.y, c.y}, cz2 = {c.z, c.z}, rc2 = {c.w, c.w};
     uint32_t lb = 0u;
 #pragma unroll
-    for (int p = 0; p < PP; ++p) {
-      uint32_t d0, d1;
-      if (PCT) {  // common.hpp::pct_dist before its sqrt, two points at a time
-        const f2v zz = __builtin_elementwise_fma(cy2, py[p], cx2 * px[p]) + cz2 * pz[p];
-        const f2v m2 = {-2.0f, -2.0f};
-        const f2v d = __builtin_elementwise_fma(m2, zz, rc2 + rp[p]);
-        d0 = d[0] < 0.f ? fbits(1e-7f) : fbits(d[0]);
-        d1 = d[1] < 0.f ? fbits(1e-7f) : fbits(d[1]);
-      } else {  // common.hpp::sqdist3(point, centroid)
-        const f2v dx = px[p] - cx2, dy = py[p] - cy2, dz = pz[p] - cz2;
-        const f2v d = (dx * dx + dy * dy) + dz * dz;
-        d0 = fbits(d[0]), d1 = fbits(d[1]);
+    for (int u = 0; u < PT; ++u) {
+      uint32_t d;
+      if (PCT) {  // common.hpp::pct_dist before its sqrt
+        const float zz = fmaf(c.y, py[u], c.x * px[u]) + c.z * pz[u];
+        const float dd = fmaf(-2.0f, zz, c.w + rp[u]);
+        d = dd < 0.f ? fbits(1e-7f) : fbits(dd);
+      } else {
+        d = fbits(sqdist3(px[u], py[u], pz[u], c.x, c.y, c.z));
       }
-      run[2 * p] = d0 < run[2 * p] ? d0 : run[2 * p];
-      run[2 * p + 1] = d1 < run[2 * p + 1] ? d1 : run[2 * p + 1];
-      const uint32_t pm = run[2 * p] > run[2 * p + 1] ? run[2 * p] : run[2 * p + 1];
-      lb = pm > lb ? pm : lb;
+      run[u] = d < run[u] ? d : run[u];
+      lb = run[u] > lb ? run[u] : lb;
     }
     if (PROBE == 5) asm volatile("" : "+v"(lb));
     stamp(1);
@@ -267,6 +290,9 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
     // (the wait is part of the asm: the compiler does not know this is an LDS operation and puts no s_waitcnt between it and the
     // barrier -- the winner read after the barrier then depends on the order the LDS happens to serve the waves in, which a
     // co-resident kernel's LDS traffic changed: tests/test_gpu_attack.py::test_cw_attacks_in_flight_at_once_...)
+#if HITADV_FPS_DIAG == 9  // every wave's key of every step: log[block][step][wave]
+    if (dbg_log != nullptr && lane == 0) dbg_log[((size_t)blockIdx.x * m + j) * NW + wave] = key;
+#endif
     unsigned long long w;
     if constexpr (SLOTS) {
       if (lane == 0) s_slot[j & 1][wave] = key;
@@ -304,6 +330,9 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
   }
   if (PROBE == 5 && threadIdx.x == 0 && m >= 5)
     for (int i = 0; i < 5; ++i) idx[i] = (IdxT)acc_t[i];
+#if HITADV_FPS_DIAG == 8
+  if (threadIdx.x == 0 && blockIdx.x < 4096) g_fps_hash[blockIdx.x] = seen;
+#endif
 #if HITADV_FPS_DIAG == 4
   __syncthreads();
 #pragma unroll
@@ -313,7 +342,7 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
       const float gx = __hip_atomic_load(&xyz[k * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       const float gy = __hip_atomic_load(&xyz[k * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       const float gz = __hip_atomic_load(&xyz[k * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const float rx = px[u >> 1][u & 1], ry = py[u >> 1][u & 1], rz = pz[u >> 1][u & 1];
+      const float rx = px[u], ry = py[u], rz = pz[u];
       const float4 l = spts[k];
       if (!(gx == rx && gy == ry && gz == rz)) atomicAdd(&g_fps_dbg[0], 1u);
       if (!(l.x == rx && l.y == ry && l.z == rz)) atomicAdd(&g_fps_dbg[1], 1u);
@@ -352,11 +381,10 @@ __global__ __launch_bounds__(256) void gather_points_grad_k(int c, int n, int np
       for (int l = 0; l < c; ++l) gp[(size_t)l * n] += go[(size_t)l * npoints + j];
 }
 
-// 0 (default) = the 64-bit-key kernel everywhere; 1 = fps_lean for MODE 0 / 2 with 256 < N <= 4080 (HITADV_FPS_FORM=1, or
-// hitadv_debug_fps_form).  fps_lean is NOT the default: alone on the GPU it is bit-exact in every test, but with a second attack
-// in flight on another stream it returns a different (wrong) table for 1-30 % of the clouds of a PointNet++ forward pass
-// (tools/fps_check_modes.py; docs/kernels/round5.md section 8) -- cause not found.
-static int g_fps_form = [] { const char *e = getenv("HITADV_FPS_FORM"); return e && e[0] == '1' ? 1 : 0; }();
+// 1 (default) = fps_lean for MODE 0 / 2 with 256 < N <= 4080; 0 = the 64-bit-key kernel everywhere (HITADV_FPS_FORM=0, or
+// hitadv_debug_fps_form: A/B, tests)
+static unsigned long long *g_fps_log_ptr = nullptr;  // HITADV_FPS_DIAG == 9: where the next fps_lean launch logs its waves' keys
+static int g_fps_form = [] { const char *e = getenv("HITADV_FPS_FORM"); return e && e[0] == '0' ? 0 : 1; }();
 
 template <int MODE, typename IdxT>
 static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int m, IdxT *idx, hipStream_t s) {
@@ -375,7 +403,7 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
     if (slots_exchange)                                                                                           \
       fps_lean<PT, MODE == 2, NW, IdxT, 0, true><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx);                   \
     else                                                                                                          \
-      fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx);                            \
+      fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx, g_fps_log_ptr);             \
     return 0;                                                                                                     \
   }
     // waves per cloud (tools/tune/fps_step_probe.hip, us per step at 4 / 8 / 16 waves, before the posting lane's wait): N = 2048
@@ -412,6 +440,16 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
 }  // namespace hitadv
 
 using namespace hitadv;
+
+extern "C" int hitadv_debug_fps_hashes(unsigned long long *dev_out, int n, void *stream) {  // device-to-device, in stream order
+  return (int)hipMemcpyFromSymbolAsync(dev_out, HIP_SYMBOL(hitadv::g_fps_hash), sizeof(unsigned long long) * (n < 4096 ? n : 4096), 0,
+                                       hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+
+extern "C" int hitadv_debug_fps_log(unsigned long long *dev_log) {
+  g_fps_log_ptr = dev_log;
+  return 0;
+}
 
 extern "C" int hitadv_debug_fps_counters(unsigned int *host8) {
   return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(hitadv::g_fps_dbg), sizeof(unsigned int) * 8);

@@ -3,6 +3,7 @@
 -- fps_lean first (or the 64-bit-key kernel first with order='key64_first'), fps_lean again right behind it, the 64-bit-key
 kernel, fps_lean once more -- and counts, on the device, the clouds whose tables differ.  `counts()` / `captures()` read the
 results.  tools/fps_check_modes.py and tools/fps_check_cfg4.py drive it; docs/kernels/round5.md section 8 has what it found."""
+import ctypes
 import os
 
 import torch
@@ -29,12 +30,29 @@ def install(order='lean_first', sync=None):
 
         def launch(form):
             out = torch.empty(B, npoint, device=dev, dtype=torch.int64)
+            if os.environ.get("HITADV_FPS_PREFILL"):  # what a wrong table is made of: values the kernel computed, or what the buffer held before
+                out.fill_(-7)
             lib.hitadv_debug_fps_form(form)
             _lib.call("hitadv_fps_from_start", _p(xyz), _p(start), B, N, npoint, _p(out), _stream())
             return out
+        logging = bool(os.environ.get("HITADV_FPS_LOG")) and N == 2048  # (a HITADV_FPS_DIAG=9 build) [B, npoint, 8 waves] keys of the first launch
+        if logging:
+            log = torch.zeros(2, B, npoint, 8, dtype=torch.int64, device=dev)  # [keys | (centre x, active lanes, winner) of lane 63]
+            lib.hitadv_debug_fps_log(ctypes.c_void_p(log.data_ptr()))
         idx = launch(0 if order == 'key64_first' else 1)
+        if logging:
+            lib.hitadv_debug_fps_log(None)
+        if os.environ.get("HITADV_FPS_HASH"):  # (a HITADV_FPS_DIAG=8 build) the winners the kernel saw against the table it stored
+            hs = torch.zeros(B, dtype=torch.int64, device=dev)
+            lib.hitadv_debug_fps_hashes(ops._p(hs), B, _stream())
+            want = torch.zeros(B, dtype=torch.int64, device=dev)
+            for j in range(npoint):
+                want = want * 1000003 + idx[:, j]
+            hm = _state.setdefault('stored_table_differs_from_what_the_kernel_saw', torch.zeros(2, dtype=torch.int64, device=dev))
+            hm[0] += (want != hs).sum()
+            hm[1] += B
         second, chk, again = launch(1), launch(0), launch(1)
-        lib.hitadv_debug_fps_form(0)  # the shipped form
+        lib.hitadv_debug_fps_form(1)  # the shipped form
         c = _state.setdefault('tables', torch.zeros(2, dtype=torch.int64, device=dev))
         more = _state.setdefault('more', torch.zeros(3, dtype=torch.int64, device=dev))
         chg = _state.setdefault('inputs_changed', torch.zeros(2, dtype=torch.int64, device=dev))
@@ -54,17 +72,31 @@ def install(order='lean_first', sync=None):
         cap['start'].copy_(torch.where(take, start[at], cap['start']))
         cap['first'].copy_(torch.where(take, idx[at], cap['first']))
         cap['key64'].copy_(torch.where(take, chk[at], cap['key64']))
+        if logging:
+            cl = cap.setdefault('log', torch.zeros(2, npoint, 8, dtype=torch.int64, device=dev))
+            cl.copy_(torch.where(take, log[:, at], cl))
         cap['have'].logical_or_(take)
         c[0] += bad.sum()
         c[1] += B
+        # is a wrong table the RIGHT table of the same stream's previous pass (the same buffer address, the cloud one Adam step older)?
+        hist = _state.setdefault(('hist', torch.cuda.current_stream().cuda_stream, N, npoint), dict(prev=torch.full((B, npoint), -1, dtype=torch.int64, device=dev)))
+        old = _state.setdefault('wrong_equals_previous_pass', torch.zeros(2, dtype=torch.int64, device=dev))
+        same_as_prev = (idx == hist['prev']).all(dim=1)
+        old[0] += (bad & same_as_prev).sum()
+        old[1] += bad.sum()
+        hist['prev'].copy_(chk)
+        pre = _state.setdefault('prefill_seen', torch.zeros(1, dtype=torch.int64, device=dev))
+        pre[0] += (idx == -7).sum()
         return idx
     ops.fps_from_start = fps_from_start
 
 
 def reset():
-    for v in _state.values():
+    for k, v in _state.items():
         if isinstance(v, torch.Tensor):
             v.zero_()
+        elif isinstance(k, tuple) and k[0] == 'hist':
+            v['prev'].fill_(-1)
 
 
 def counts():
@@ -74,4 +106,4 @@ def counts():
 
 
 def captures():
-    return {k: {n: t.cpu() for n, t in v.items()} for k, v in _state.items() if isinstance(k, tuple)}
+    return {k: {n: t.cpu() for n, t in v.items()} for k, v in _state.items() if isinstance(k, tuple) and k[0] != 'hist'}

@@ -40,4 +40,7 @@ for graph in (False,):
             _lib.load().hitadv_debug_fps_counters(buf)
         except AttributeError:
             pass
-        print('graph', graph, 'in flight', n, fps_check.counts(), 'kernel counters', list(buf)[:3], flush=True)
+        if n == 2:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            torch.save(fps_check.captures(), os.path.join(ROOT, 'gpurun_out', 'fps_mismatch.pt'))
+        print('graph', graph, 'in flight', n, fps_check.counts(), 'kernel counters', list(buf), flush=True)

@@ -131,7 +131,7 @@ def main():
             us = timed(lambda s=s0: fn(p(xs), p(start), B, n_, m_, p(fo), s), 20)
             row['key64' if form == 0 else 'lean'] = dict(us=round(us, 1), us_per_step=round(us / m_, 3))
         out[f'{nm}_N{n_}_m{m_}'] = row
-    lib.hitadv_debug_fps_form(0)  # the shipped form
+    lib.hitadv_debug_fps_form(1)  # the shipped form
     f32 = torch.empty(B, 51, dtype=torch.int32, device='cuda')
     us = timed(lambda s=s0: lib.hitadv_furthest_point_sampling(B, N, 51, p(x), None, p(f32), s), 20)
     out['fps_ext_m51'] = dict(us=round(us, 1), us_per_step=round(us / 50, 3))
