@@ -655,3 +655,42 @@ def test_other_victims_twenty_iterations_with_both_bookkeeping_branches_vs_cpu_o
     note('%s: result, largest |gpu - oracle| over the agreeing clouds' % name, float(err.max()))
     note('%s: result, 99th percentile' % name, float(np.quantile(err, 0.99)))
     assert float(np.quantile(err, 0.99)) <= 1e-3 and float(err.max()) <= 5e-2
+
+
+def test_fps_tables_with_two_attacks_in_flight_match_the_other_sampling_kernel():
+    """Round 5: two HiT-ADV attacks on PointNet++ in flight on two streams, every FPS table of every forward pass computed by both
+    sampling kernels (tools/fps_check.py: fps_lean first, again right behind it, the 64-bit-key kernel, fps_lean once more).  The
+    first fps_lean build -- distances on packed f32 instructions -- passed every bit-exact test alone on the GPU and returned a
+    different table for 1-30 % of the clouds here (a lane missing one update of its running distance); on plain instructions the
+    four tables of a call are the same bits, and the inputs do not change under the kernels."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fps_check
+    from hit_adv_amd import ops
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    keep = ops.fps_from_start
+    try:
+        fps_check.install()
+        fps_check.reset()
+        model = _tuned_victim('pointnet++').cuda()
+        batches = []
+        for i in range(2):
+            data, _ = synth_batch(16, 2048, first=300 * i)
+            data = data.cuda()
+            with torch.no_grad():
+                o = model(data[:, :, :3].transpose(1, 2).contiguous())
+            batches.append((data, (o[0] if isinstance(o, tuple) else o).argmax(1)))
+        torch.manual_seed(5)
+        att = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), binary_step=1, num_iter=25, verbose=False, use_graph=False,
+                      attack_lr=1e-2, central_num=192, total_central_num=256, init_weight=10., max_weight=80., cd_weight=1e-4, ker_weight=1.,
+                      hide_weight=1., curv_loss_knn=16, max_sigm=1.2, min_sigm=0.1, budget=0.55)
+        att.attack_many(batches)
+        torch.cuda.synchronize()
+        c = fps_check.counts()
+    finally:
+        ops.fps_from_start = keep
+    assert c['tables'][1] >= 2 * 16 * 25 * 2  # two FPS calls per forward pass, both attacks
+    assert c['tables'][0] == 0 and c['more'] == [0, 0, 0], c
+    assert c['inputs_changed'] == [0, 0], c
