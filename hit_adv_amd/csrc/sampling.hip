@@ -129,8 +129,9 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
 #ifndef HITADV_FPS_DIAG
 #define HITADV_FPS_DIAG 0
 #endif
-__device__ unsigned int g_fps_dbg[8];
-__device__ unsigned long long g_fps_hash[4096];  // HITADV_FPS_DIAG == 8: per block, a hash of the sequence of winners the kernel itself saw  // HITADV_FPS_DIAG == 4: [0] registers != memory at the end, [1] LDS copy != registers at the end, [2] points checked
+// tuning builds (-DHITADV_FPS_DIAG=n; docs/kernels/round5.md section 8): 4 = at the end, the coordinates in registers against memory and
+// the LDS copy against the registers; 5 = every wave's step counter behind every barrier; 9 = a log of every wave's key and centre
+__device__ unsigned int g_fps_dbg[8];  // [0] / [1] mismatches, [2] checked
 
 // the smallest float x with sqrt_rn(x) == s (s > 0 finite, the correctly rounded sqrt of some float)
 __device__ __forceinline__ float sqrt_preimage_floor(float s) {
@@ -145,13 +146,12 @@ __device__ __forceinline__ float sqrt_preimage_floor(float s) {
 // the waves, 3 no search for the holder, 4 no reduction across the lanes, 5 cycle stamps -- what each part of the step costs.
 // NW = waves per cloud.  A wave alone on its SIMD issues one instruction (of any kind) every 4-5 cycles at best and waits out
 // every dependency itself; two waves per SIMD (NW = 8) interleave, and each carries half of the points.
-template <int PT, bool PCT, int NW, typename IdxT, int PROBE = 0, bool SLOTS = false>
+template <int PT, bool PCT, int NW, typename IdxT, int PROBE = 0>
 __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xyz, const int64_t *__restrict__ start, int N, int m,
                                                     IdxT *__restrict__ idx, unsigned long long *dbg_log = nullptr) {
   constexpr int TH = 64 * NW;
   extern __shared__ float4 spts[];  // the cloud: (x, y, z, |p|^2)
   __shared__ unsigned long long s_key[3];  // step j's winner: the waves' keys meet in word j % 3 by ds_max_u64 (no merge to compute)
-  __shared__ unsigned long long s_slot[2][NW];  // SLOTS: one word per wave instead, merged by every thread
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   xyz += (size_t)b * N * 3;
@@ -194,60 +194,20 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
     }
   };
   if (PROBE == 5) t_prev = __builtin_readcyclecounter();
-#if HITADV_FPS_DIAG == 8
-  unsigned long long seen = 0ull;
-#endif
   for (int j = 0; j < m; ++j) {
-#if HITADV_FPS_DIAG == 8
-    seen = seen * 1000003ull + (unsigned long long)(unsigned int)far;
-#endif
-#if HITADV_FPS_DIAG == 1
-    __threadfence_block();
-    __syncthreads();
-#endif
-#if HITADV_FPS_DIAG >= 100  // a pure delay per step (64 x (DIAG - 100) cycles): does the failure depend on how long a step takes?
-    __builtin_amdgcn_s_sleep(HITADV_FPS_DIAG - 100);
-#endif
-#if HITADV_FPS_DIAG == 2
-    if (threadIdx.x == 0) idx[j] = (IdxT)far;
-#else
     if (wave == 0) idx[j] = (IdxT)far;  // a scalar branch; the wave's lanes store one value to one address
-#endif
     float4 c;
     if (PROBE == 1)
       c = make_float4(far * 1e-4f, far * 2e-4f, far * 3e-4f, far * 1e-5f);
-#if HITADV_FPS_DIAG == 3
-    else {
-      c.x = xyz[far * 3], c.y = xyz[far * 3 + 1], c.z = xyz[far * 3 + 2];
-      c.w = (c.x * c.x + c.y * c.y) + c.z * c.z;
-    }
-#else
     else {
       c = spts[far];
-#if HITADV_FPS_DIAG == 6
-      asm volatile("" ::"v"(c.w));  // keeps the whole 16-byte read (ds_read_b128, not ds_read_b96)
-#endif
-#if HITADV_FPS_DIAG == 9  // what lane 63 of every wave used as this step's winner and centre, and how many lanes were active
+#if HITADV_FPS_DIAG == 9  // what lane 63 of every wave used as this step's winner and centre
       if (dbg_log != nullptr && lane == 63) {
         unsigned long long *l2 = dbg_log + (size_t)gridDim.x * m * NW;
-        l2[((size_t)blockIdx.x * m + j) * NW + wave] = ((unsigned long long)__float_as_uint(c.x) << 32) | ((unsigned long long)__builtin_popcountll(__builtin_amdgcn_read_exec()) << 24) | (unsigned int)(far & 0xffffff);
-      }
-#endif
-#if HITADV_FPS_DIAG == 7  // the centre out of LDS against the same point out of memory, per lane and step
-      {
-        const float gx = xyz[far * 3], gy = xyz[far * 3 + 1], gz = xyz[far * 3 + 2];
-        if (!(gx == c.x && gy == c.y && gz == c.z)) {
-          const unsigned int n = atomicAdd(&g_fps_dbg[0], 1u);
-          if (n == 0) {
-            g_fps_dbg[3] = (unsigned int)far, g_fps_dbg[4] = (unsigned int)j, g_fps_dbg[5] = threadIdx.x, g_fps_dbg[6] = __float_as_uint(c.x),
-            g_fps_dbg[7] = __float_as_uint(gx);
-          }
-        }
-        if (lane == 0) atomicAdd(&g_fps_dbg[2], 1u);
+        l2[((size_t)blockIdx.x * m + j) * NW + wave] = ((unsigned long long)__float_as_uint(c.x) << 32) | (unsigned int)(far & 0xffffff);
       }
 #endif
     }
-#endif
     if (PROBE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     stamp(0);
     uint32_t lb = 0u;
@@ -294,16 +254,7 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
     if (dbg_log != nullptr && lane == 0) dbg_log[((size_t)blockIdx.x * m + j) * NW + wave] = key;
 #endif
     unsigned long long w;
-    if constexpr (SLOTS) {
-      if (lane == 0) s_slot[j & 1][wave] = key;
-      __syncthreads();
-      w = s_slot[j & 1][0];
-#pragma unroll
-      for (int t = 1; t < NW; ++t) {
-        const unsigned long long o = s_slot[j & 1][t];
-        w = o > w ? o : w;
-      }
-    } else {
+    {
       if (lane == 0) {
         unsigned long long before;  // the RETURNING form: its data coming back is proof that the LDS has performed the operation
         asm volatile("ds_max_rtn_u64 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(before) : "v"(key_at + 8u * (uint32_t)j3), "v"(key) : "memory");
@@ -330,9 +281,6 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
   }
   if (PROBE == 5 && threadIdx.x == 0 && m >= 5)
     for (int i = 0; i < 5; ++i) idx[i] = (IdxT)acc_t[i];
-#if HITADV_FPS_DIAG == 8
-  if (threadIdx.x == 0 && blockIdx.x < 4096) g_fps_hash[blockIdx.x] = seen;
-#endif
 #if HITADV_FPS_DIAG == 4
   __syncthreads();
 #pragma unroll
@@ -400,17 +348,12 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
   if (MODE != 1 && g_fps_form != 0 && use_lds && N > 256) {  // fps_lean: the cloud in LDS, 4 or 8 waves per cloud
 #define HITADV_FPS_LEAN(PT, NW)                                                                                   \
   if (N <= 64 * NW * PT) {                                                                                        \
-    if (slots_exchange)                                                                                           \
-      fps_lean<PT, MODE == 2, NW, IdxT, 0, true><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx);                   \
-    else                                                                                                          \
-      fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx, g_fps_log_ptr);             \
+    fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx, g_fps_log_ptr);               \
     return 0;                                                                                                     \
   }
     // waves per cloud (tools/tune/fps_step_probe.hip, us per step at 4 / 8 / 16 waves, before the posting lane's wait): N = 2048
     // 0.381 / 0.349 / 0.379, N = 1024 0.301 / 0.293; PCT's distance at N = 1024 0.379 / 0.419 (its sqrt and threshold are per wave)
-    static const bool slots_exchange = [] { const char *e = getenv("HITADV_FPS_EXCH"); return e && e[0] == 's'; }();  // A/B
-    static const bool four_waves_only = [] { const char *e = getenv("HITADV_FPS_WAVES"); return e && e[0] == '4'; }();  // A/B
-    if (MODE != 2 && N > 1024 && !four_waves_only) {
+    if (MODE != 2 && N > 1024) {
       HITADV_FPS_LEAN(4, 8)
       HITADV_FPS_LEAN(8, 8)
     } else {
@@ -440,11 +383,6 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
 }  // namespace hitadv
 
 using namespace hitadv;
-
-extern "C" int hitadv_debug_fps_hashes(unsigned long long *dev_out, int n, void *stream) {  // device-to-device, in stream order
-  return (int)hipMemcpyFromSymbolAsync(dev_out, HIP_SYMBOL(hitadv::g_fps_hash), sizeof(unsigned long long) * (n < 4096 ? n : 4096), 0,
-                                       hipMemcpyDeviceToDevice, (hipStream_t)stream);
-}
 
 extern "C" int hitadv_debug_fps_log(unsigned long long *dev_log) {
   g_fps_log_ptr = dev_log;

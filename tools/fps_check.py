@@ -42,15 +42,6 @@ def install(order='lean_first', sync=None):
         idx = launch(0 if order == 'key64_first' else 1)
         if logging:
             lib.hitadv_debug_fps_log(None)
-        if os.environ.get("HITADV_FPS_HASH"):  # (a HITADV_FPS_DIAG=8 build) the winners the kernel saw against the table it stored
-            hs = torch.zeros(B, dtype=torch.int64, device=dev)
-            lib.hitadv_debug_fps_hashes(ops._p(hs), B, _stream())
-            want = torch.zeros(B, dtype=torch.int64, device=dev)
-            for j in range(npoint):
-                want = want * 1000003 + idx[:, j]
-            hm = _state.setdefault('stored_table_differs_from_what_the_kernel_saw', torch.zeros(2, dtype=torch.int64, device=dev))
-            hm[0] += (want != hs).sum()
-            hm[1] += B
         second, chk, again = launch(1), launch(0), launch(1)
         lib.hitadv_debug_fps_form(1)  # the shipped form
         c = _state.setdefault('tables', torch.zeros(2, dtype=torch.int64, device=dev))
