@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
 //     squared has 50 bits; it is never itself a float, so no rounding tie exists).
 //   * the waves' (bits of the distance, ~index) keys meet in ONE LDS word by ds_max_u64: after the barrier the winner is one
 //     8-byte read, not NW slots and NW - 1 64-bit compare-selects (three words in rotation, so that clearing needs no barrier).
-//   * 8 waves per cloud for N > 1024 (two per SIMD interleave; each carries half of the points).
+//   * 8 waves per cloud for N > 512 (MODE 0; two per SIMD interleave, each carries half of the points).
 // Tried and dropped: the candidates' coordinates out of the holder lane's registers (v_readlane under a scalar branch tree on
 // u) posted beside the key, to save the LDS read of the winner's coordinates -- the branch tree and the five reads after the
 // barrier cost more than the trip (N = 1024: 0.56 us per step against 0.36).
@@ -353,7 +353,9 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
   }
     // waves per cloud (tools/tune/fps_step_probe.hip, us per step at 4 / 8 / 16 waves, before the posting lane's wait): N = 2048
     // 0.381 / 0.349 / 0.379, N = 1024 0.301 / 0.293; PCT's distance at N = 1024 0.379 / 0.419 (its sqrt and threshold are per wave)
-    if (MODE != 2 && N > 1024) {
+    static const int eight_from = [] { const char *e = getenv("HITADV_FPS_EIGHT_FROM"); return e ? atoi(e) : 512; }();  // tuning (plain instructions: N = 1024 0.333 on 4 waves, 0.314 on 8)
+    if (MODE != 2 && N > eight_from) {
+      HITADV_FPS_LEAN(2, 8)
       HITADV_FPS_LEAN(4, 8)
       HITADV_FPS_LEAN(8, 8)
     } else {
