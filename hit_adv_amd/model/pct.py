@@ -12,6 +12,8 @@ BatchNorm folded in eval mode, see _pointwise.py); the neighbourhood constructio
   the reference's).
 ``ops.victim_reference_arithmetic(False)`` selects direct-form distances for both.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -104,9 +106,25 @@ class SA_Layer(nn.Module):
         self.act = nn.ReLU()
         self.softmax = nn.Softmax(dim=-1)
 
+    # one autograd node per layer where the shapes allow (False, or HITADV_PCT_FUSED_SA=0: the op-by-op composition below)
+    FUSED_BACKWARD = os.environ.get("HITADV_PCT_FUSED_SA", "1") != "0"
+
+    def _fused_layer_ok(self, x):
+        from . import _pointwise as P
+        C = x.shape[2]
+        return (self.FUSED_BACKWARD and not P.WEIGHT_GRADS and not self.training and self.v_conv.bias is not None
+                and x.dtype == torch.float32 and ops.offset_attention_layer_supported(x.shape[1], C, self.q_conv.weight.shape[0]))
+
     def forward_pm(self, x):
         """The same layer on points-major x [B,N,C] (eval mode on the GPU): the 1x1 convolutions are GEMMs over B*N rows,
         the attention products take their transposes through the BLAS flags -- no permuted copies in either direction."""
+        if x.is_cuda and x.dim() == 3 and self._fused_layer_ok(x):
+            from . import _pointwise as P
+            Wq, _ = P._folded(self.q_conv, None)
+            Wv, bv = P._folded(self.v_conv, None)
+            Wt, bt = P._folded(self.trans_conv, self.after_norm)
+            # one autograd node with a hand-written backward pass (ops.OffsetAttentionLayer): the constants enter detached
+            return ops.offset_attention_layer(x, Wq.detach(), Wv.detach(), bv.detach(), Wt.detach(), bt.detach())
         q = linear_pm(self.q_conv, None, x)  # q_conv and k_conv share their weight (:116): one product serves both
         # q q^T: the tiled batched kernel (csrc/bmm.hip); softmax + column renormalisation: csrc/attention.hip
         attention = ops.offset_attention_norm(ops.bmm(q, q, False, True))

@@ -1128,6 +1128,60 @@ def offset_attention_norm(E):
     return A / (1e-9 + A.sum(dim=1, keepdim=True))
 
 
+class OffsetAttentionLayer(torch.autograd.Function):
+    """One offset-attention layer of PCT (model/pct_cls.py:111-139) on points-major x [B,N,C] with its constants folded:
+    ``q = x Wq^T`` (q and k share their weight), ``A = offset_attention_norm(q q^T)``, ``v = x Wv^T + bv``, ``x_r = A^T v``,
+    ``out = x + relu((x - x_r) Wt^T + bt)`` (trans_conv with its BatchNorm folded).  The forward pass is the composition
+    ``SA_Layer.forward_pm`` used to write out; the BACKWARD pass is written by hand: autograd's own spent ten element-wise launches
+    per layer on glue (the ReLU mask, ``-dt``, four accumulations of the gradient of ``x``, the sum of the two gradients of ``q``):
+    here the signs ride on ``addmm(alpha=-1)``, the residual's gradient is the first ``addmm``'s addend, and what is left is one mask,
+    one add for ``dq`` and one for ``dt``.  The weights are constants (gradient with respect to ``x`` only)."""
+
+    @staticmethod
+    def forward(ctx, x, Wq, Wv, bv, Wt, bt):
+        x = _dev(x, "x").contiguous()
+        B, N, C = x.shape
+        x2 = x.view(B * N, C)
+        q = x2 @ Wq.t()
+        q3 = q.view(B, N, -1)
+        E = _bmm_raw(q3, q3, False, True)
+        A = torch.empty_like(E)
+        c = torch.empty(B, N, device=x.device)
+        _lib.call("hitadv_offset_attention_fwd", _p(E), B, N, _p(A), _p(c), _stream())
+        v = torch.addmm(bv, x2, Wv.t())
+        x_r = _bmm_raw(A, v.view(B, N, C), True, False)
+        y = torch._addmm_activation(bt, (x - x_r).view(B * N, C), Wt.t(), use_gelu=False)
+        ctx.save_for_backward(q, A, c, v, y, Wq, Wv, Wt)
+        return x + y.view(B, N, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, A, c, v, y, Wq, Wv, Wt = ctx.saved_tensors
+        B, N, _ = A.shape
+        C = v.shape[1]
+        g2 = g.contiguous().view(B * N, C)
+        dt = torch.ops.aten.threshold_backward(g2, y, 0) @ Wt            # d (x - x_r): the gradient of x_r is -dt
+        dt3, q3 = dt.view(B, N, C), q.view(B, N, -1)
+        dv_neg = _bmm_raw(A, dt3, False, False)                            # -(d v)  = A dt
+        dA_neg = _bmm_raw(v.view(B, N, C), dt3, False, True)               # -(d A)  = v dt^T
+        dE_neg, h = torch.empty_like(A), torch.empty_like(c)               # the normalisation's backward is linear: -(d E)
+        _lib.call("hitadv_offset_attention_bwd", _p(dA_neg), _p(A), _p(c), B, N, _p(h), _p(dE_neg), _stream())
+        dq_neg = _bmm_raw(dE_neg, q3, False, False) + _bmm_raw(dE_neg, q3, True, False)   # -(dE + dE^T) q
+        dx = torch.addmm(g2, dv_neg.view(B * N, C), Wv, alpha=-1.0)        # g (the residual) + dv Wv
+        dx = torch.addmm(dx, dq_neg.view(B * N, -1), Wq, alpha=-1.0)       # + dq Wq
+        dx += dt
+        return dx.view(B, N, C), None, None, None, None, None
+
+
+def offset_attention_layer_supported(N, C, Cq):
+    lib = _lib.load()
+    return bool(N % 64 == 0 and C % 64 == 0 and Cq % 64 == 0 and lib.hitadv_offset_attention_supported(int(N)))
+
+
+def offset_attention_layer(x, Wq, Wv, bv, Wt, bt):
+    return OffsetAttentionLayer.apply(x, Wq, Wv, bv, Wt, bt)
+
+
 def gemm_f16x2_supported(N, K):
     """Whether ``gemm_f16x2`` / ``linear_lrelu_pool`` are built for N output columns over a K-deep contraction."""
     return bool(_lib.load().hitadv_gemm_f16x2_supported(int(N), int(K)))

@@ -4,6 +4,8 @@ libhitadv_hip.so), against the CPU oracle and the golden vectors captured from t
 Bar: bit-exact for every index output and for direct-form squared distances; for floating point
 results the tolerance is written next to each assertion.
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -1829,6 +1831,41 @@ def test_offset_attention_norm_matches_torch_composition(A, B, N):
     odd = torch.randn(2, 100, 100, device='cuda')
     S2 = torch.softmax(odd, dim=-1)
     assert torch.equal(A.offset_attention_norm(odd), S2 / (1e-9 + S2.sum(dim=1, keepdim=True)))
+
+
+@pytest.mark.parametrize("B,N", [(32, 256), (2, 64)])
+def test_pct_offset_attention_layer_as_one_autograd_node(B, N):
+    """Round 5: a whole PCT offset-attention layer (model/pct_cls.py:111-139) as ONE autograd node with a hand-written backward pass
+    (ops.OffsetAttentionLayer) against the op-by-op composition it replaces (the same forward kernels: equal bits;
+    gradient: the same products, accumulated in another order) and against float64 autograd of the reference's formula."""
+    from hit_adv_amd.model.pct import SA_Layer
+    torch.manual_seed(N)
+    layer = SA_Layer(256).eval().cuda()
+    with torch.no_grad():
+        layer.after_norm.running_mean.normal_(0., 0.1)
+        layer.after_norm.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(B, N, 256, device='cuda').requires_grad_()
+    w = torch.randn(B, N, 256, device='cuda')
+    assert layer._fused_layer_ok(x)
+    out = layer.forward_pm(x)
+    g, = torch.autograd.grad((out * w).sum(), x)
+    SA_Layer.FUSED_BACKWARD = False
+    try:
+        out0 = layer.forward_pm(x)
+        g0, = torch.autograd.grad((out0 * w).sum(), x)
+    finally:
+        SA_Layer.FUSED_BACKWARD = True
+    assert torch.equal(out, out0)
+    close(g, g0, rtol=0, atol=2e-6 * float(g0.abs().max()), what='offset-attention layer: dx, one node vs the op-by-op composition')
+    ld = copy.deepcopy(layer).double()
+    xd = x.detach().double().transpose(1, 2).contiguous().requires_grad_()  # the reference's layout [B,C,N]
+    od = ld(xd)
+    gd, = torch.autograd.grad((od * w.double().transpose(1, 2)).sum(), xd)
+    so, sg = float(od.detach().abs().max()), float(gd.abs().max())
+    close(out / so, (od.detach().transpose(1, 2).float()) / so, rtol=0, atol=2e-6, what='offset-attention layer vs float64 (over the output scale)')
+    close(g / sg, gd.transpose(1, 2).float() / sg, rtol=0, atol=5e-6, what='offset-attention layer: dx vs float64 autograd (over its scale)')
+    g2, = torch.autograd.grad((layer.forward_pm(x) * w).sum(), x)
+    assert torch.equal(g2, g)
 
 
 @pytest.mark.parametrize("B,Np", [(3, 1000), (2, 64), (5, 130), (64, 1024), (9, 2048)])
