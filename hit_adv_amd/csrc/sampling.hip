@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
 #ifndef HITADV_FPS_DIAG
 #define HITADV_FPS_DIAG 0
 #endif
-// tuning builds (-DHITADV_FPS_DIAG=n; docs/kernels/round5.md section 8): 4 = at the end, the coordinates in registers against memory and
+// tuning builds (-DHITADV_FPS_DIAG=n; docs/kernels/round5.md section 8): 2 = MODE 0's distances on packed f32 instructions, the build
+// that tools/fps_check_modes.py shows failing; 4 = at the end, the coordinates in registers against memory and
 // the LDS copy against the registers; 5 = every wave's step counter behind every barrier; 9 = a log of every wave's key and centre
 __device__ unsigned int g_fps_dbg[8];  // [0] / [1] mismatches, [2] checked
 
@@ -221,6 +222,21 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
       } else {
         d = fbits(sqdist3(px[u], py[u], pz[u], c.x, c.y, c.z));
       }
+#if HITADV_FPS_DIAG == 2  // the build that failed beside other streams' kernels: MODE 0's distances two points per packed instruction
+      if (!PCT && (u & 1) == 0 && u + 1 < PT) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        const f2v X = {px[u], px[u + 1]}, Y = {py[u], py[u + 1]}, Z = {pz[u], pz[u + 1]};
+        const f2v cx2 = {c.x, c.x}, cy2 = {c.y, c.y}, cz2 = {c.z, c.z};
+        const f2v dx = X - cx2, dy = Y - cy2, dz = Z - cz2;
+        const f2v dd = (dx * dx + dy * dy) + dz * dz;
+        d = fbits(dd[0]);
+        const uint32_t d1 = fbits(dd[1]);
+        run[u + 1] = d1 < run[u + 1] ? d1 : run[u + 1];
+        lb = run[u + 1] > lb ? run[u + 1] : lb;
+      } else if (!PCT && (u & 1) == 1) {
+        continue;  // done with its even neighbour
+      }
+#endif
       run[u] = d < run[u] ? d : run[u];
       lb = run[u] > lb ? run[u] : lb;
     }
