@@ -91,3 +91,40 @@ def test_logger_file_layout(tmp_path):
         if getattr(h, '_hitadv', False):
             logging.getLogger().removeHandler(h)
             h.close()
+
+
+def test_synthetic_victim_helpers_are_pure_functions_of_their_arguments():
+    """bench.py's victims and fixture g5d are described by (architecture, seed, gain, shake_bn's three numbers): the helpers must give
+    the same model for the same numbers, touch only what they say they touch, and the surface-like clouds must be what the name says."""
+    from hit_adv_amd.Dataset.synthetic import ToyVictim, shake_bn, sharpen, sphere_batch, synth_batch
+
+    def victim():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Conv1d(3, 8, 1), torch.nn.BatchNorm1d(8), torch.nn.ReLU(), torch.nn.Conv1d(8, 4, 1),
+                                   torch.nn.BatchNorm1d(4)).eval()
+    a, b, c = shake_bn(victim(), seed=2), shake_bn(victim(), seed=2), shake_bn(victim(), seed=3)
+    plain = victim()
+    for (na, pa), (_, pb), (_, pc), (_, pp) in zip(a.state_dict().items(), b.state_dict().items(), c.state_dict().items(), plain.state_dict().items()):
+        assert torch.equal(pa, pb)
+        if 'running_mean' in na or 'running_var' in na:
+            assert not torch.equal(pa, pp) and not torch.equal(pa, pc)
+            if 'running_var' in na:
+                assert float(pa.min()) >= 0.8 - 1e-6 and float(pa.max()) <= 1.2 + 1e-6
+        else:
+            assert torch.equal(pa, pp)  # weights, biases, affine parameters, counters untouched
+    s = sharpen(victim(), 1.5)
+    for (n, ps), (_, pp) in zip(s.state_dict().items(), plain.state_dict().items()):
+        if n in ('0.weight', '3.weight'):
+            assert torch.equal(ps, pp * 1.5)
+        else:
+            assert torch.equal(ps, pp)
+    toy = ToyVictim()
+    assert toy(torch.randn(2, 3, 50)).shape == (2, 40)
+    d1, l1 = sphere_batch(3, 256, first=40)
+    d2, _ = sphere_batch(3, 256, first=40)
+    assert d1.shape == (3, 256, 6) and l1.shape[0] == 3 and torch.equal(d1, d2)
+    r = d1[:, :, :3].norm(dim=2)
+    assert float(r.min()) > 0.7 and float(r.max()) <= 1.0 + 1e-6 and float(r.std()) < 0.05  # a shell (centred, scaled to radius 1), not a ball
+    g, _ = synth_batch(3, 256, first=40)
+    assert float(g[:, :, :3].norm(dim=2).std()) > 3 * float(r.std())  # the Gaussian clouds fill their volume
+    assert not torch.equal(sphere_batch(1, 256, first=41)[0], d1[:1])
