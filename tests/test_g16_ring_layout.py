@@ -1,0 +1,54 @@
+"""The LDS layout of gemm_f16x2_ring_k (hit_adv_amd/csrc/gemm16.hip), restated in Python: the swizzle is applied on the GLOBAL side
+(lane p of a 1 KB LDS-DMA wave-load fetches the chunk that belongs at LDS position p), so three things must agree -- where the DMA
+puts chunk c of row r, where the fragment read of lane (row % 16, k group) looks for it, and the claim that a ds_read_b128's four
+16-lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32: MI355X_MICROARCH.md, LDS) each touch sixteen different
+16-byte slots of the 256-byte bank row."""
+import itertools
+
+
+def gr_swz(r):
+    return ((r >> 1) & 1) | (((r >> 2) & 1) << 2)
+
+
+def g16_off(r, c):  # the B pieces' 64-byte rows (and the staged kernel's A rows)
+    return r * 64 + 16 * (c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3))
+
+
+GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+GROUPS += [[l + 32 for l in g] for g in GROUPS]
+
+
+def test_fp32_a_rows_land_where_the_fragment_reads_look():
+    where = {}
+    for wave, i, lane in itertools.product(range(8), range(4), range(64)):
+        L = 4 * wave + i                       # wave-load L fills LDS bytes [1024 L, 1024 L + 1024) in lane order
+        row = 8 * L + (lane >> 3)
+        chunk = (lane & 7) ^ gr_swz(row)       # the global chunk this lane fetches
+        where[(row, chunk)] = 1024 * L + 16 * lane
+    assert len(where) == 256 * 8 and len(set(where.values())) == 256 * 8
+    for wr, rt, lane in itertools.product(range(4), range(4), range(64)):
+        l16, g4 = lane & 15, lane >> 4
+        row = 64 * wr + 16 * rt + l16
+        for half in (0, 1):                    # k = 8 g4 .. 8 g4 + 7 = chunks 2 g4 and 2 g4 + 1 of the row's 32 floats
+            addr = 64 * wr * 128 + 16 * rt * 128 + l16 * 128 + 16 * ((2 * g4 + half) ^ gr_swz(l16))
+            assert addr == where[(row, 2 * g4 + half)]
+
+
+def test_fragment_reads_are_conflict_free_in_every_lane_group():
+    for half in (0, 1):
+        for grp in GROUPS:
+            slots = {(((l & 15) * 128 + 16 * ((2 * (l >> 4) + half) ^ gr_swz(l & 15))) % 256) // 16 for l in grp}
+            assert len(slots) == 16
+    for grp in GROUPS:                         # the B pieces (64-byte rows), read as (row l16, chunk g4)
+        slots = {(g16_off(l & 15, l >> 4) % 256) // 16 for l in grp}
+        assert len(slots) == 16
+
+
+def test_b_piece_rows_land_where_the_fragment_reads_look():
+    where = {}
+    for wave, lane in itertools.product(range(8), range(64)):
+        col = 16 * wave + (lane >> 2)
+        chunk = (lane & 3) ^ ((0x78 >> (2 * ((col >> 2) & 3))) & 3)
+        where[(col, chunk)] = 1024 * wave + 16 * lane
+    for col, c in itertools.product(range(128), range(4)):
+        assert where[(col, c)] == g16_off(col, c)
