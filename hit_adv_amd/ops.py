@@ -5,7 +5,6 @@ tape; every computation below happens in libhitadv_hip.so.  All functions requir
 (ROCm) tensors and raise otherwise -- there is no CPU path.
 """
 import ctypes
-import os
 import struct
 
 import torch

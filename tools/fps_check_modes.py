@@ -7,7 +7,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import torch
 import bench
-from hit_adv_amd import ops
 import fps_check
 fps_check.install(order=os.environ.get('HITADV_FPS_ORDER', 'lean_first'), sync=os.environ.get('HITADV_FPS_SYNC'))
 from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
