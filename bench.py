@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 # What the line reports as `hip_hardware_queues`: the variable's value only if the runtime cannot have started before it was
 # in the environment -- i.e. it was exported by the caller, or nothing had initialised the GPU when this file set it (a
-# profiler's preloaded library does: under rocprofv3 export GPU_MAX_HW_QUEUES=8 in the shell, tools/r03_measure.sh).
+# profiler's preloaded library does: under rocprofv3 export GPU_MAX_HW_QUEUES=8 in the shell, the measurement scripts, e.g. tools/r05_measure.sh).
 if _QUEUES_PRESET is not None:
     HW_QUEUES = int(_QUEUES_PRESET)
 elif torch.cuda.is_initialized() or os.environ.get("ROCPROFILER_LIBRARY_CTOR") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
@@ -389,20 +389,24 @@ def loop_floor(B, N, classes=40, matrix_mode='bf16x3', C=192):
                 loop_floor_max_us=round(max(us['bf16_mfma'] + us['f32_mfma'], us['hbm']), 2))
 
 
-def loop_traffic_measured():
-    """HBM bytes of ONE B=32 iteration as the counters saw them (newest profiles/*loop_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+LOOP_TRAFFIC_PROFILE = os.path.join("profiles", "r05_loop_traffic.json")  # named, not globbed: a later file must not change the line silently
+
+
+def loop_traffic_profiled_offline():
+    """HBM bytes of ONE B=32 iteration as the counters saw them in an OFFLINE profile kept under profiles/ (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes over tools/loop_pmc_probe.py -- three stacks of eight attacks, every loop kernel --, corrected per
-    MI355X_MICROARCH.md: writes exact, fetches doubled) next to `hbm_bytes`, the model loop_floor() prices.  Not measured in this
-    run: the counters need the profiler; `hbm_measured_source` names the file."""
-    import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*loop_traffic.json")))
-    if not paths:
-        return dict(hbm_bytes_measured=None)
-    with open(paths[-1]) as f:
+    MI355X_MICROARCH.md: writes exact, fetches doubled) next to `hbm_bytes`, the model loop_floor() prices.  NOT a measurement of this
+    run and not of this build: the counters need the profiler, and the file named here was taken on round 5's morning build, before
+    rowmlp_stream_k became the default (profiles/README_r05.md).  Hence the field names, and hence nothing of it in `summary`."""
+    path = os.path.join(ROOT, LOOP_TRAFFIC_PROFILE)
+    if not os.path.exists(path):
+        return dict(hbm_bytes_profiled_offline=None)
+    with open(path) as f:
         d = json.load(f)
     per = d.get("per_b32_iteration", {})
-    return dict(hbm_bytes_measured=per.get("hbm_bytes"), hbm_bytes_measured_fetch_not_doubled=per.get("hbm_bytes_fetch_not_doubled"),
-                hbm_measured_source=os.path.relpath(paths[-1], ROOT))
+    return dict(hbm_bytes_profiled_offline=per.get("hbm_bytes"), hbm_bytes_profiled_offline_fetch_not_doubled=per.get("hbm_bytes_fetch_not_doubled"),
+                hbm_profiled_offline_source=LOOP_TRAFFIC_PROFILE,
+                hbm_profiled_offline_note="an earlier build's profile (round 5, before the streaming V2), kept for orientation; not this run")
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline
@@ -971,7 +975,7 @@ def main():
             line["hot_loop_kernels"] = hot_loop_kernels(dev)
             floor = loop_floor(B, N, cfg['classes'], matrix_mode, HP['central_num'])
             eff = elapsed / steps / iters_per_step * 1e6  # wall time per B=32 iteration, all attacks in flight counted
-            measured = loop_traffic_measured()
+            measured = loop_traffic_profiled_offline()
             line["end_to_end"] = dict(
                 floor, us_per_iteration=round(eff, 2), attacks_in_flight=in_flight, **measured,
                 frac=round(floor['loop_floor_us'] / eff, 4), frac_of_max_floor=round(floor['loop_floor_max_us'] / eff, 4),
@@ -980,8 +984,8 @@ def main():
                      "ONE B=32 iteration (bench.py::loop_floor); us_per_iteration = ms_per_step / 5000 with "
                      "`attacks_in_flight` attacks sharing the GPU; frac = floor / measured; loop_floor_max_us = max(matrix time, HBM "
                      "time) of the same iteration (perfect overlap), frac_of_max_floor = that / measured")
-            if measured.get("hbm_bytes_measured"):
-                line["end_to_end"]["hbm_measured_over_model"] = round(measured["hbm_bytes_measured"] / floor["hbm_bytes"], 3)
+            if measured.get("hbm_bytes_profiled_offline"):
+                line["end_to_end"]["hbm_profiled_offline_over_model"] = round(measured["hbm_bytes_profiled_offline"] / floor["hbm_bytes"], 3)
             if single is not None:
                 us1 = single / iters_per_step * 1e6
                 line["single_attack"] = {"value": B / single, "unit": "clouds/s", "ms_per_step": single * 1e3, "steps": extra,
@@ -1027,8 +1031,6 @@ def main():
         brief = {"value": round(line["value"], 3), "attack_success": "%d/%d" % (succeeded, attacked), "roofline_frac": line["roofline"]["frac"]}
         if "end_to_end" in line:
             brief["loop_frac"] = line["end_to_end"]["frac"]
-            if line["end_to_end"].get("hbm_bytes_measured") is not None:
-                brief["loop_hbm_measured_over_model"] = line["end_to_end"]["hbm_measured_over_model"]
         if "single_attack" in line:
             brief["single_attack"] = round(line["single_attack"]["value"], 3)
         for mode in ('fp16x2', 'bf16x3', 'f32'):

@@ -101,9 +101,6 @@ PROTOTYPES = {
     "hitadv_pointnet_rowmlp_fwd": [_I] + [_P] * 13 + [_I, _I, _I, _P, _P],
     "hitadv_pointnet_rowmlp_fwd_stn": [_P] * 15 + [_I, _I, _I, _P, _P],
     "hitadv_pointnet_rowmlp_fwd_deform": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
-    "hitadv_linear_max_filter_supported": [_I, _I, _I, _I, _I],
-    "hitadv_linear_max_filter_scratch_words": [_I, _I],
-    "hitadv_linear_max_fwd_f16x2_filtered": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hitadv_pointnet_rowmlp_tiles": [_I],
     "hitadv_pointnet_rowmlp_form": [_I],
     "hitadv_pointnet_rowmlp_bwd_tiles": [_I, _I],
@@ -126,7 +123,7 @@ PROTOTYPES = {
     "hitadv_fc_layer_pre": [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
 }
 _RESTYPE = {"hitadv_version": _c.c_char_p, "hitadv_deform_bwd_scratch_floats": _c.c_int64,
-            "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_linear_max_fwd_scratch": _c.c_int64, "hitadv_linear_max_fwd_bf16x3_scratch": _c.c_int64, "hitadv_linear_max_filter_scratch_words": _c.c_int64, "hitadv_pointnet_rowmlp_tiles": _c.c_int64, "hitadv_pointnet_rowmlp_bwd_tiles": _c.c_int64, "hitadv_fc_layer_scratch_floats": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64,
+            "hitadv_max_over_points_scratch": _c.c_int64, "hitadv_linear_max_fwd_scratch": _c.c_int64, "hitadv_linear_max_fwd_bf16x3_scratch": _c.c_int64, "hitadv_pointnet_rowmlp_tiles": _c.c_int64, "hitadv_pointnet_rowmlp_bwd_tiles": _c.c_int64, "hitadv_fc_layer_scratch_floats": _c.c_int64, "hitadv_regulariser_scratch_floats": _c.c_int64,
             "hitadv_edge_max_bwd_scratch_ints": _c.c_int64, "hitadv_iteration_head_scratch_floats": _c.c_int64, "hitadv_deform_bwd_slabs": _c.c_int64, "hitadv_group_add_relu_bwd_scratch_ints": _c.c_int64,
             "hitadv_linear_lrelu_pool_scratch": _c.c_int64}
 

@@ -36,8 +36,9 @@
 // producer (rowmlp_stream_k) instead of the stash, candidates grouped by channel in the refine pass (half its traffic).
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "../common.hpp"
 #include "hitadv.h"
+#include "hitadv_experimental.h"
 
 namespace hitadv {
 

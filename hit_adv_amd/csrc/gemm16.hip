@@ -507,14 +507,15 @@ constexpr int GR_STAGES = 3;
 // row once (rows alternate between its halves, s takes {0, 1, 4, 5} on each parity of either row set)
 __device__ __forceinline__ int gr_swz(int r) { return ((r >> 1) & 1) | (((r >> 2) & 1) << 2); }
 
-// (m0 is not a clobber the compiler accepts; nothing else in this kernel uses it: gfx9 LDS instructions do not read m0)
+// (m0 is declared clobbered: nothing else in this kernel uses it today -- gfx9 LDS instructions do not read m0 --, but an epilogue
+// that made the compiler use it, e.g. a relative-indexed register move, must see that this statement overwrites it)
 __device__ __forceinline__ void gr_dma16(uint32_t lds_at, uint32_t voff, const void *sbase) {
   const unsigned long long a = (unsigned long long)(uintptr_t)sbase;
   const unsigned long long u = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_at)), "v"(voff),
                "s"(u)
-               : "memory");
+               : "memory", "m0");
 }
 
 // ABL != 0: tuning builds only (tools/tune/g16_ablate.py; results are garbage): 11 no MFMAs, 12 no split (raw bits), 13 no LDS reads,

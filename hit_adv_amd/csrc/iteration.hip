@@ -160,6 +160,9 @@ __device__ __forceinline__ void iteration_head_body(const HeadArgs &a, const int
       const float margin = kind == 0 ? (zt - other) + kappa : (other - zt) + kappa;
       const bool on = margin >= 0.f;  // torch's clamp(min=0) passes the gradient at the boundary
       const float s = on ? (kind == 0 ? invB : -invB) : 0.f;
+      // (not two classes per packed instruction: the loop vectoriser's v_cndmask_b32 -> v_pk_add_f32 is the instruction pair
+      // tests/test_isa_guards.py keeps out of every product kernel -- docs/kernels/round6.md section 1; same bits either way)
+#pragma clang loop vectorize(disable) interleave(disable)
       for (int j = lane; j < num_class; j += 64) d[j] = (j == t ? s : 0.f) - ((j == o && o != t) ? s : 0.f);
       mine = margin > 0.f ? margin : 0.f;
     }

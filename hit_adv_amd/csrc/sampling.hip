@@ -126,14 +126,6 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
 // Tried and dropped: the candidates' coordinates out of the holder lane's registers (v_readlane under a scalar branch tree on
 // u) posted beside the key, to save the LDS read of the winner's coordinates -- the branch tree and the five reads after the
 // barrier cost more than the trip (N = 1024: 0.56 us per step against 0.36).
-#ifndef HITADV_FPS_DIAG
-#define HITADV_FPS_DIAG 0
-#endif
-// tuning builds (-DHITADV_FPS_DIAG=n; docs/kernels/round5.md section 8): 2 = MODE 0's distances on packed f32 instructions, the build
-// that tools/fps_check_modes.py shows failing; 4 = at the end, the coordinates in registers against memory and
-// the LDS copy against the registers; 5 = every wave's step counter behind every barrier; 9 = a log of every wave's key and centre
-__device__ unsigned int g_fps_dbg[8];  // [0] / [1] mismatches, [2] checked
-
 // the smallest float x with sqrt_rn(x) == s (s > 0 finite, the correctly rounded sqrt of some float)
 __device__ __forceinline__ float sqrt_preimage_floor(float s) {
   const float sp = __uint_as_float(__float_as_uint(s) - 1u);
@@ -143,13 +135,13 @@ __device__ __forceinline__ float sqrt_preimage_floor(float s) {
   return (double)t < m2 ? __uint_as_float(__float_as_uint(t) + 1u) : t;
 }
 
-// PROBE (tools/tune/fps_step_probe.hip only; results are garbage): 1 no read of the winner's coordinates, 2 no exchange between
-// the waves, 3 no search for the holder, 4 no reduction across the lanes, 5 cycle stamps -- what each part of the step costs.
 // NW = waves per cloud.  A wave alone on its SIMD issues one instruction (of any kind) every 4-5 cycles at best and waits out
 // every dependency itself; two waves per SIMD (NW = 8) interleave, and each carries half of the points.
-template <int PT, bool PCT, int NW, typename IdxT, int PROBE = 0>
+// (The instrumented copy of this kernel -- part-removal probes, cycle stamps, the packed-f32 distance code that failed beside other
+// streams and the in-kernel self-checks of docs/kernels/round5.md section 8 -- lives in tools/tune/fps_lean_diag.hpp, outside the product.)
+template <int PT, bool PCT, int NW, typename IdxT>
 __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xyz, const int64_t *__restrict__ start, int N, int m,
-                                                    IdxT *__restrict__ idx, unsigned long long *dbg_log = nullptr) {
+                                                    IdxT *__restrict__ idx) {
   constexpr int TH = 64 * NW;
   extern __shared__ float4 spts[];  // the cloud: (x, y, z, |p|^2)
   __shared__ unsigned long long s_key[3];  // step j's winner: the waves' keys meet in word j % 3 by ds_max_u64 (no merge to compute)
@@ -168,13 +160,7 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
     const int k = threadIdx.x + TH * u;
     const bool in = k < N;
     const int kk = in ? k : 0;
-#ifdef HITADV_FPS_COHERENT_LOADS  // diagnostic: agent-scope loads (past this CU's L1)
-    const float x = __hip_atomic_load(&xyz[kk * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float y = __hip_atomic_load(&xyz[kk * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float z = __hip_atomic_load(&xyz[kk * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
     const float x = xyz[kk * 3], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
-#endif
     const float r = (x * x + y * y) + z * z;
     px[u] = x, py[u] = y, pz[u] = z, rp[u] = r;
     run[u] = in ? fbits(1e10f) : 0u;  // PCT: (1e5)^2
@@ -186,31 +172,9 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
   const uint32_t key_at = (uint32_t)(uintptr_t)(lds_u64 *)&s_key[0];
   int j3 = 0;  // j % 3
   __syncthreads();
-  unsigned long long acc_t[5] = {0, 0, 0, 0, 0}, t_prev = 0;  // PROBE 5: shader cycles per part of the step, summed over the steps
-  auto stamp = [&](int i) {
-    if (PROBE == 5) {
-      const unsigned long long t = __builtin_readcyclecounter();
-      acc_t[i] += t - t_prev;
-      t_prev = t;
-    }
-  };
-  if (PROBE == 5) t_prev = __builtin_readcyclecounter();
   for (int j = 0; j < m; ++j) {
     if (wave == 0) idx[j] = (IdxT)far;  // a scalar branch; the wave's lanes store one value to one address
-    float4 c;
-    if (PROBE == 1)
-      c = make_float4(far * 1e-4f, far * 2e-4f, far * 3e-4f, far * 1e-5f);
-    else {
-      c = spts[far];
-#if HITADV_FPS_DIAG == 9  // what lane 63 of every wave used as this step's winner and centre
-      if (dbg_log != nullptr && lane == 63) {
-        unsigned long long *l2 = dbg_log + (size_t)gridDim.x * m * NW;
-        l2[((size_t)blockIdx.x * m + j) * NW + wave] = ((unsigned long long)__float_as_uint(c.x) << 32) | (unsigned int)(far & 0xffffff);
-      }
-#endif
-    }
-    if (PROBE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    stamp(0);
+    const float4 c = spts[far];
     uint32_t lb = 0u;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
@@ -222,27 +186,10 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
       } else {
         d = fbits(sqdist3(px[u], py[u], pz[u], c.x, c.y, c.z));
       }
-#if HITADV_FPS_DIAG == 2  // the build that failed beside other streams' kernels: MODE 0's distances two points per packed instruction
-      if (!PCT && (u & 1) == 0 && u + 1 < PT) {
-        typedef float f2v __attribute__((ext_vector_type(2)));
-        const f2v X = {px[u], px[u + 1]}, Y = {py[u], py[u + 1]}, Z = {pz[u], pz[u + 1]};
-        const f2v cx2 = {c.x, c.x}, cy2 = {c.y, c.y}, cz2 = {c.z, c.z};
-        const f2v dx = X - cx2, dy = Y - cy2, dz = Z - cz2;
-        const f2v dd = (dx * dx + dy * dy) + dz * dz;
-        d = fbits(dd[0]);
-        const uint32_t d1 = fbits(dd[1]);
-        run[u + 1] = d1 < run[u + 1] ? d1 : run[u + 1];
-        lb = run[u + 1] > lb ? run[u + 1] : lb;
-      } else if (!PCT && (u & 1) == 1) {
-        continue;  // done with its even neighbour
-      }
-#endif
       run[u] = d < run[u] ? d : run[u];
       lb = run[u] > lb ? run[u] : lb;
     }
-    if (PROBE == 5) asm volatile("" : "+v"(lb));
-    stamp(1);
-    const uint32_t M = PROBE == 4 ? (uint32_t)__builtin_amdgcn_readlane((int)lb, 63) : wave_max_u32_dpp(lb);  // wave-uniform
+    const uint32_t M = wave_max_u32_dpp(lb);  // wave-uniform
     uint32_t value = M, floor = M;
     if (PCT) {
       const float sq = __builtin_sqrtf(__uint_as_float(M));
@@ -252,68 +199,27 @@ __global__ __launch_bounds__(64 * NW) void fps_lean(const float *__restrict__ xy
     int U = 0;
     unsigned long long holders = 0ull;
 #pragma unroll
-    for (int u = PT - 1; u >= (PROBE == 3 ? PT - 1 : 0); --u) {
+    for (int u = PT - 1; u >= 0; --u) {
       const unsigned long long h = __builtin_amdgcn_ballot_w64(run[u] >= floor);
       if (h) holders = h, U = u;
     }
     const uint32_t k = (uint32_t)(TH * U + 64 * wave + (int)__builtin_ctzll(holders));  // u = 0 of every wave is inside the cloud
     const unsigned long long key = ((unsigned long long)value << 32) | (0xFFFFFFFFu - k);
-    stamp(2);
-    if (PROBE == 2) {
-      far = (int)k % N;
-      continue;
-    }
     // (the wait is part of the asm: the compiler does not know this is an LDS operation and puts no s_waitcnt between it and the
     // barrier -- the winner read after the barrier then depends on the order the LDS happens to serve the waves in, which a
     // co-resident kernel's LDS traffic changed: tests/test_gpu_attack.py::test_cw_attacks_in_flight_at_once_...)
-#if HITADV_FPS_DIAG == 9  // every wave's key of every step: log[block][step][wave]
-    if (dbg_log != nullptr && lane == 0) dbg_log[((size_t)blockIdx.x * m + j) * NW + wave] = key;
-#endif
-    unsigned long long w;
-    {
-      if (lane == 0) {
-        unsigned long long before;  // the RETURNING form: its data coming back is proof that the LDS has performed the operation
-        asm volatile("ds_max_rtn_u64 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(before) : "v"(key_at + 8u * (uint32_t)j3), "v"(key) : "memory");
-        (void)before;
-      }
-#if HITADV_FPS_DIAG == 5  // every wave posts the step it is in before the barrier; behind it, all of them must have
-      __shared__ int s_step[NW];
-      if (lane == 0) s_step[wave] = j + 1;
-#endif
-      __syncthreads();
-#if HITADV_FPS_DIAG == 5
-      if (lane < NW && s_step[lane] != j + 1) atomicAdd(&g_fps_dbg[0], 1u);
-      if (lane == 0) atomicAdd(&g_fps_dbg[2], 1u);
-#endif
-      stamp(3);
-      w = s_key[j3];
-      j3 = j3 == 2 ? 0 : j3 + 1;
-      // word (j + 2) % 3 was last read before this barrier and is next written after the next one: clear it in between
-      if (wave == 0) s_key[j3 == 2 ? 0 : j3 + 1] = 0ull;
+    if (lane == 0) {
+      unsigned long long before;  // the RETURNING form: its data coming back is proof that the LDS has performed the operation
+      asm volatile("ds_max_rtn_u64 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(before) : "v"(key_at + 8u * (uint32_t)j3), "v"(key) : "memory");
+      (void)before;
     }
+    __syncthreads();
+    const unsigned long long w = s_key[j3];
+    j3 = j3 == 2 ? 0 : j3 + 1;
+    // word (j + 2) % 3 was last read before this barrier and is next written after the next one: clear it in between
+    if (wave == 0) s_key[j3 == 2 ? 0 : j3 + 1] = 0ull;
     far = (int)(0xFFFFFFFFu - (uint32_t)(w & 0xffffffffu));
-    if (PROBE == 5) asm volatile("" : "+v"(far));
-    stamp(4);
   }
-  if (PROBE == 5 && threadIdx.x == 0 && m >= 5)
-    for (int i = 0; i < 5; ++i) idx[i] = (IdxT)acc_t[i];
-#if HITADV_FPS_DIAG == 4
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < PT; ++u) {
-    const int k = threadIdx.x + TH * u;
-    if (k < N) {
-      const float gx = __hip_atomic_load(&xyz[k * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const float gy = __hip_atomic_load(&xyz[k * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const float gz = __hip_atomic_load(&xyz[k * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const float rx = px[u], ry = py[u], rz = pz[u];
-      const float4 l = spts[k];
-      if (!(gx == rx && gy == ry && gz == rz)) atomicAdd(&g_fps_dbg[0], 1u);
-      if (!(l.x == rx && l.y == ry && l.z == rz)) atomicAdd(&g_fps_dbg[1], 1u);
-      atomicAdd(&g_fps_dbg[2], 1u);
-    }
-  }
-#endif
 }
 
 __global__ __launch_bounds__(256) void gather_points_k(int c, int n, int npoints,
@@ -345,10 +251,13 @@ __global__ __launch_bounds__(256) void gather_points_grad_k(int c, int n, int np
       for (int l = 0; l < c; ++l) gp[(size_t)l * n] += go[(size_t)l * npoints + j];
 }
 
-// 1 (default) = fps_lean for MODE 0 / 2 with 256 < N <= 4080; 0 = the 64-bit-key kernel everywhere (HITADV_FPS_FORM=0, or
-// hitadv_debug_fps_form: A/B, tests)
-static unsigned long long *g_fps_log_ptr = nullptr;  // HITADV_FPS_DIAG == 9: where the next fps_lean launch logs its waves' keys
-static int g_fps_form = [] { const char *e = getenv("HITADV_FPS_FORM"); return e && e[0] == '0' ? 0 : 1; }();
+// 0 (default since round 6) = the 64-bit-key kernel fps<> for every size; 1 (HITADV_FPS_FORM=1, or hitadv_debug_fps_form: A/B, tests) =
+// fps_lean for MODE 0 / 2 with 256 < N <= 4080.  Why the faster kernel is not the default: its first build (distances on packed f32
+// instructions) lost single running-distance updates while another stream's kernels shared the GPU, the cause was never isolated
+// (docs/kernels/round5.md section 8, docs/kernels/round6.md section 1: the probes that would isolate it have not had a GPU to run
+// on), and the plain-instruction build that shows 0 wrong tables in 31,872 differs from it only in instruction selection.  fps<> is the
+// kernel the driver's own GPU runs have verified (rounds 1-4); 4.5 % of cfg4 is the price.
+static int g_fps_form = [] { const char *e = getenv("HITADV_FPS_FORM"); return e && e[0] == '1' ? 1 : 0; }();
 
 template <int MODE, typename IdxT>
 static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int m, IdxT *idx, hipStream_t s) {
@@ -364,7 +273,7 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
   if (MODE != 1 && g_fps_form != 0 && use_lds && N > 256) {  // fps_lean: the cloud in LDS, 4 or 8 waves per cloud
 #define HITADV_FPS_LEAN(PT, NW)                                                                                   \
   if (N <= 64 * NW * PT) {                                                                                        \
-    fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx, g_fps_log_ptr);               \
+    fps_lean<PT, MODE == 2, NW, IdxT><<<B, 64 * NW, shm, s>>>(xyz, start, N, m, idx);                              \
     return 0;                                                                                                     \
   }
     // waves per cloud (tools/tune/fps_step_probe.hip, us per step at 4 / 8 / 16 waves, before the posting lane's wait): N = 2048
@@ -401,15 +310,6 @@ static int launch_fps(const float *xyz, const int64_t *start, int B, int N, int 
 }  // namespace hitadv
 
 using namespace hitadv;
-
-extern "C" int hitadv_debug_fps_log(unsigned long long *dev_log) {
-  g_fps_log_ptr = dev_log;
-  return 0;
-}
-
-extern "C" int hitadv_debug_fps_counters(unsigned int *host8) {
-  return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(hitadv::g_fps_dbg), sizeof(unsigned int) * 8);
-}
 
 extern "C" int hitadv_debug_fps_form(int form) {
   const int old = g_fps_form;

@@ -637,35 +637,6 @@ def linear_max_fwd_f16x2(x, W2, B, N, bias=None, relu=False, blocks=0, range_fla
     return out, idx
 
 
-def linear_max_filter_supported(B, N, Cin, Cout, blocks=0):
-    """Whether ``linear_max_fwd_f16x2_filtered`` takes this shape (include/hitadv.h)."""
-    return bool(_lib.load().hitadv_linear_max_filter_supported(int(B), int(N), int(Cin), int(Cout), int(blocks)))
-
-
-def weight_row_norms(Wr):
-    """|Wr[c,:]|_2 per output channel with a 1e-5 allowance for its own rounding: the ``wnorm`` of the filtered layer."""
-    return (Wr.double().norm(dim=1) * (1. + 1e-5)).float().contiguous()
-
-
-def linear_max_fwd_f16x2_filtered(x, W2, wnorm, B, N, seed, bias=None, relu=False, blocks=0, range_flag=None, scratch=None):
-    """``linear_max_fwd_f16x2(..., packed=True)`` with one fp16 product per value instead of three and the exact evaluation of
-    the few points that can be the maximum (csrc/victim_filter.hip).  ``seed`` int64 [B,Cout] in / out: last call's arg-max
-    table (any content is valid; the result does not depend on it, the time does); ``range_flag`` is REQUIRED: it is raised
-    when a candidate list overflows, and the result is then invalid."""
-    x = _dev(x, "x")
-    _, Cout, Cin = W2.shape
-    if range_flag is None:
-        raise ValueError("linear_max_fwd_f16x2_filtered needs a range_flag: an overfull candidate list is reported there")
-    n = _lib.load().hitadv_linear_max_filter_scratch_words(B, Cout)
-    if scratch is None or scratch.numel() < n:
-        scratch = torch.empty(n, device=x.device, dtype=torch.int32)
-    out = torch.empty(B, Cout, device=x.device)
-    idx = torch.empty(B, Cout, device=x.device, dtype=torch.int64)
-    _lib.call("hitadv_linear_max_fwd_f16x2_filtered", _p(x), _p(W2), _p(wnorm), _p(bias), B, N, Cin, Cout, 1 if relu else 0,
-              int(blocks), _p(seed), _p(scratch), _p(out), _p(idx), _p(range_flag), _stream())
-    return out, idx
-
-
 def linear_max_fwd_supported(Cin, Cout):
     return Cin in (64, 128) and Cout % 64 == 0
 

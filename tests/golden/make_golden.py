@@ -372,7 +372,7 @@ def g5c():
 
 
 
-def g5d(steps=2, iters=50):
+def g5d(steps=2, iters=50, name='g5d_attack_pointnet.npz', p_every=10, logits_every=1, tag='g5d'):
     """The headline configuration's victim at a horizon that means something: the imported reference's
     HiT_ADV.attack on cfg2's shape -- seeded PointNetFeatureModel (the reference's own class) with shaken BatchNorm
     statistics, B=32, N=1024, C=192, T=256, eval.py's hyper-parameters, binary_step=2 x num_iter=50.  The victim seed /
@@ -409,7 +409,7 @@ def g5d(steps=2, iters=50):
         if not batch_avg:  # exactly once per iteration (:195): the distance the best-tracking compares
             it = count['it'] % iters
             trace['dist_val'].append(out.detach().clone())
-            if it % 10 == 0 or it == iters - 1:
+            if it % p_every == 0 or it == iters - 1:
                 trace['P'].append(perturb_mat.detach().clone())
                 trace['sigma'].append(gauss_delta.detach().clone())
             if it in (0, iters - 1):
@@ -428,7 +428,13 @@ def g5d(steps=2, iters=50):
 
         def forward(self, logits, targets):
             v = self.inner(logits, targets)
-            trace['logits'].append(logits.detach().clone())
+            it = len(trace['adv_loss']) % iters
+            if it % logits_every == 0 or it == iters - 1:
+                trace['logits'].append(logits.detach().clone())
+            if logits_every != 1:  # the long trace keeps every iteration's prediction and margin instead of every logit
+                trace.setdefault('pred', []).append(logits.argmax(1).to(torch.int16))
+                top2 = logits.detach().topk(2, dim=1).values
+                trace.setdefault('margin', []).append(top2[:, 0] - top2[:, 1])
             trace['adv_loss'].append(v.detach().clone())
             return v
 
@@ -442,19 +448,29 @@ def g5d(steps=2, iters=50):
     import time
     t0 = time.time()
     (best, succ), rec = watch_bookkeeping(run)
-    print("g5d: reference attack %d x %d at B=32 took %.0f s; success %d / 32" % (steps, iters, time.time() - t0, int(succ)))
+    print("%s: reference attack %d x %d at B=32 took %.0f s; success %d / 32" % (tag, steps, iters, time.time() - t0, int(succ)))
     assert len(rec['steps']) == steps and count['it'] == steps * iters
     out = {k: torch.stack(v) for k, v in trace.items()}
     out.update(cap)
     out.update(best=best, success_num=int(succ), target=target, clean_logits=clean, seed=seed, first=first, model_seed=0,
                shake_seed=shake['seed'], shake_mean_std=shake['mean_std'], shake_var_spread=shake['var_spread'],
                taken_step=rec['taken'][:, 0], taken_iter=rec['taken'][:, 1], final_o_bestdist=rec['final']['o_bestdist'],
-               kept_iterations=np.array([i for i in range(iters) if i % 10 == 0 or i == iters - 1]),
+               kept_iterations=np.array([i for i in range(iters) if i % p_every == 0 or i == iters - 1]),
                weight_checksum=np.array([float(v.double().abs().sum()) for v in model.state_dict().values()]))
     for name in ('lower', 'upper', 'scale_const', 'o_bestdist', 'o_bestscore', 'bestdist', 'bestscore'):
         out['step_' + name] = np.stack([s_[name] for s_ in rec['steps']])
     out.update({'hp_' + k: v for k, v in hp.items()})
-    save('g5d_attack_pointnet.npz', out)
+    if logits_every != 1:
+        out['kept_logit_iterations'] = np.array([i for i in range(iters) if i % logits_every == 0 or i == iters - 1])
+    save(name, out)
+
+
+def g5e():
+    """The headline's own inner horizon: the same victim, clouds and seed as g5d, ONE binary
+    step of num_iter=500 -- what eval.py:126-133 runs ten times per batch.  ~37 min of this container's 8 cores.  Stored: the
+    prediction, the top-two margin, adv_loss and the compared distance at EVERY iteration; the logits every 25th; (P, sigma)
+    every 50th; the deformed clouds at iterations 0 and 499; the reference's bookkeeping after the step and what it returns."""
+    g5d(steps=1, iters=500, name='g5e_attack_pointnet_500.npz', p_every=50, logits_every=25, tag='g5e')
 
 
 # ------------------------------------------------------------------ G6

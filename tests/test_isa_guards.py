@@ -1,0 +1,191 @@
+"""Static guards that read the REAL artefact: every product kernel file is compiled to gfx950 assembly with the Makefile's flags (hipcc
+cross-compiles without a GPU; ~1 min in parallel, once per test session) and the tests read the ISA and the kernel descriptors.
+
+* the suspect instruction pair of round 5's failing fps_lean build -- a 32-bit vector write into one half of a register pair and,
+  directly behind it, a packed f32 arithmetic instruction reading that pair (tools/isa_scan.py; docs/kernels/round6.md section 1) --
+  occurs in NO product kernel; the scanner is checked against the failing build itself (tools/tune/fps_diag_lib.hip,
+  -DHITADV_FPS_DIAG=2), where it must find the pair in the instantiations that failed;
+* fps_lean holds no packed f32 arithmetic at all (round 5's guard, kept), and its exchange of the waves' keys is what the comments say:
+  a returning ds_max_rtn_u64 with its own s_waitcnt lgkmcnt(0) in front of the barrier;
+* the kernels of the shipped hot paths keep their working set in registers.  Spills have cost whole rounds before (V3's two-pass
+  instantiation: 0.9-1.6 KB of scratch per lane, 388 us instead of 60 on surface-like clouds; V1's cloud-loop variants; the streaming V2
+  at three workgroups per CU), and they arrive silently -- a register more in an inner loop.  The legacy instantiations that do spill
+  are named as the known exceptions, so that the list of spilling kernels cannot grow unnoticed;
+* register and LDS budgets of the occupancy-critical kernels (what their launch shapes assume) hold."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_scan  # noqa: E402
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+KNOWN_SPILLERS = {  # name fragment -> why it is tolerated
+    "rowmlp_bwd16_kILi1ELi2ELb1E": "two-pass V3 instantiation, not launched unless HITADV_V3_FIX=0",
+    "rowmlp_bwd16_kILi2ELi2ELb1E": "two-pass V3 instantiation, not launched unless HITADV_V3_FIX=0",
+    "rowmlp_bwd16_kILi0ELi2ELb1E": "two-pass V3 instantiation, not launched unless HITADV_V3_FIX=0",
+    "linear_max_fwd_bf3_kILi128ELi2ELb0E": "V1's ragged / split form (one attack in flight at B = 32): 2 registers; the stacked loop runs the FLAT form",
+    "linear_max_fwd_bf3_kILi128ELi0ELb0E": "the bf16x3 ragged / split form: 16 registers",
+}
+KNOWN_PRIVATE = {  # a private segment without spills
+    "gemm_f16x2_kILi4ENS_6PlainAILb0ELi4EEE": "the staged GEMM's plain producer: an unused member of its register struct keeps a 48-byte slot",
+    "rowmlp_bwd_kILi2E": "the f32-mode backward chain indexes a small array (80 bytes)",
+    # (round 6: the guard now reads every file of the library, not seven -- these were there before and are named so that they cannot grow)
+    "bmm_f32_k": "PCT's batched f32 product (cfg5): a dynamically indexed fragment array, 48-80 bytes, no spills",
+    "group_linear_max_fwd_kILi128ELi32ELi2E": "PointNet++'s 32-sample group layer (cfg4): a dynamically indexed 400-byte array, no spills",
+}
+MUST_BE_CLEAN = ["linear_max_fwd_bf3_kILi128ELi2ELb1E", "rowmlp_stream_kILi1E", "rowmlp_stream_kILi2E", "rowmlp_fwd16_kILi0E",
+                 "rowmlp_bwd16_kILi0ELi2ELb0E", "rowmlp_bwd16_kILi1ELi2ELb0E", "rowmlp_bwd16_kILi2ELi2ELb0E", "rowmlp_bwd16_kILi1ELi1ELb0E",
+                 "gemm_f16x2_ring_k", "gemm_f16x2_kILi4E", "fps_lean", "deform_bwd", "pairwise3_vec4", "nn_min3", "knn_select"]
+
+
+def _flags():
+    mk = open(os.path.join(ROOT, "hit_adv_amd", "csrc", "Makefile")).read()
+    flags = re.search(r"^CXXFLAGS \?= (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    assert "-fno-slp-vectorize" in flags and "-ffp-contract=off" in flags
+    srcs = re.search(r"^SRCS := (.*)$", mk, re.M).group(1).split()
+    return [f.replace("../../include", os.path.join(ROOT, "include")) for f in flags if f != "-fPIC"], [s[:-4] for s in srcs]
+
+
+def _compile(src, out, extra=()):
+    flags, _ = _flags()
+    subprocess.check_call([HIPCC] + flags + list(extra) + ["-S", "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
+    return out
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    """{file stem: path of its gfx950 assembly} for every source the Makefile builds into libhitadv_hip.so."""
+    d = tmp_path_factory.mktemp("isa")
+    _, srcs = _flags()
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        paths = list(pool.map(lambda n: _compile(os.path.join(ROOT, "hit_adv_amd", "csrc", n + ".hip"), str(d / (n + ".s"))), srcs))
+    return dict(zip(srcs, paths))
+
+
+def _descriptors(path):
+    text = open(path).read()
+    out = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n((?:\s+\.\w+:.*\n)+)", text):
+        body = m.group(2)
+        priv = re.search(r"\.private_segment_fixed_size:\s+(\d+)", body)
+        spill = re.search(r"\.vgpr_spill_count:\s+(\d+)", body)
+        if priv and spill:
+            out[m.group(1)] = (int(priv.group(1)), int(spill.group(1)))
+    return out
+
+
+def test_scanner_finds_the_pair_in_the_build_that_failed(tmp_path):
+    """The guard guards something: in round 5's failing build (MODE 0's distances on packed instructions) the scanner finds
+    v_mov_b32 v0, vZ / v_pk_add_f32 ..., v[0:1] op_sel_hi:[1,0] in the instantiations that ran when the tables went wrong
+    (N = 2048: 4 points per lane on 8 waves; N = 512: 2 points per lane on 4 waves), and nothing in the plain build of the same file."""
+    src = os.path.join(ROOT, "tools", "tune", "fps_diag_lib.hip")
+    inc = ["-I" + os.path.join(ROOT, "hit_adv_amd", "csrc")]
+    bad = isa_scan.scan(_compile(src, str(tmp_path / "packed.s"), inc + ["-DHITADV_FPS_DIAG=2"]))
+    names = [k for k in bad if "fps_lean_diag" in k]
+    assert any("ILi4ELb0ELi8E" in k for k in names) and any("ILi2ELb0ELi4E" in k for k in names), sorted(bad)
+    for k in names:
+        for _, writer, reader in bad[k]:
+            assert writer.startswith("v_mov_b32") and reader.startswith("v_pk_add_f32") and "op_sel_hi:[1,0]" in reader
+    assert isa_scan.scan(_compile(src, str(tmp_path / "plain.s"), inc + ["-DHITADV_FPS_DIAG=0"])) == {}
+
+
+def test_no_product_kernel_holds_the_suspect_pair(isa):
+    """Every kernel of libhitadv_hip.so: no 32-bit vector write directly followed by a packed f32 instruction that reads it.  (Round 6
+    found it in three: the loop vectoriser had packed the logit-gradient loop of adv_loss_k / iteration_head_k / iteration_head_reg_k
+    two classes per instruction -- v_cndmask_b32 -> v_pk_add_f32; that loop is now kept scalar.  knn_select's 16 packed instructions
+    per instantiation, pairwise3_scalar's, pointnet.hip's read LDS data or other packed results: no site.)"""
+    hits, kernels, packed = {}, 0, 0
+    for stem, path in isa.items():
+        hits.update(isa_scan.scan(path))
+        counts = isa_scan.packed_counts(path)
+        kernels += len(counts)
+        packed += sum(counts.values())
+    assert kernels > 250 and packed > 500  # the scan saw the library (knn.hip alone carries ~690 packed instructions)
+    assert hits == {}, {k: v[:2] for k, v in hits.items()}
+
+
+def test_no_vector_instruction_reads_a_half_register_write_of_the_asm_split_in_the_next_slot(isa):
+    """the fp16x2 split's v_fma_mixlo_f16 / v_fma_mixhi_f16 are separate asm statements, so the compiler's hazard
+    recogniser cannot see that the second one writes HALF a register (gfx940+: one wait state before the next vector instruction reads
+    it).  Read from the ISA instead: ~2,000 such writes in the library, and behind none of them a vector-ALU reader in the very next
+    slot (the readers that do follow directly are LDS / memory stores, which the hardware interlocks)."""
+    writes, hits = 0, {}
+    for path in isa.values():
+        writes += open(path).read().count("v_fma_mixhi_f16")
+        hits.update(isa_scan.scan_hi_half_forwarding(path))
+    assert writes > 1000
+    assert hits == {}, {k: v[:2] for k, v in hits.items()}
+
+
+def test_fps_lean_has_no_packed_f32_arithmetic_and_waits_for_its_exchange(isa):
+    """Round 5's guard, on the stripped kernel: fps_lean (selected by HITADV_FPS_FORM=1) computes its distances on plain instructions;
+    and the exchange is the one the source describes -- every instantiation posts its key by ONE returning ds_max_rtn_u64, waits for it
+    (s_waitcnt lgkmcnt(0): the compiler does not know the asm is an LDS operation) and only then meets the barrier."""
+    ks = {k: v for k, v in isa_scan.kernels(isa["sampling"]).items() if "fps_lean" in k}
+    assert len(ks) >= 14  # both samplers, 4 and 8 waves, the point counts per lane of the launcher
+    counts = isa_scan.packed_counts(isa["sampling"])
+    assert {k: counts[k] for k in ks if counts[k]} == {}
+    for k, ins in ks.items():
+        text = [t for _, t in ins]
+        at = [i for i, t in enumerate(text) if t.startswith("ds_max_rtn_u64")]
+        assert len(at) == 1, (k, at)
+        assert text[at[0] + 1].startswith("s_waitcnt lgkmcnt(0)"), (k, text[at[0]:at[0] + 3])
+        nxt = next(i for i in range(at[0], len(text)) if text[i].startswith("s_barrier"))
+        assert not any(t.startswith("ds_") for t in text[at[0] + 1:nxt]), k  # nothing of the LDS between the post and the barrier
+
+
+def test_register_and_lds_budgets_of_the_launch_shapes(isa):
+    """What the launch shapes assume, read from the kernel descriptors: no kernel's static LDS exceeds the 160 KB a workgroup may
+    have (the G16 ring's 144 KB are dynamic: checked where it is launched, tests/test_gpu_kernels.py); the streaming V2 and the flat V1 fit two waves per SIMD (<= 256 registers per lane, accumulators
+    included), K1 / K2 stay at 64 (eight waves per SIMD), kNN's selection and fps_lean at 128 (four)."""
+    desc = {}
+    for path in isa.values():
+        desc.update(_resources(path))
+    assert len(desc) > 250
+    for k, v in desc.items():
+        assert v["lds"] <= 160 * 1024, (k, v)
+        assert v["vgpr"] <= 512, (k, v)  # (.vgpr_count is the unified total, accumulation registers included)
+    for frag, limit in (("linear_max_fwd_bf3_kILi128ELi2ELb1E", 256), ("rowmlp_stream_kILi1E", 256), ("rowmlp_stream_kILi2E", 256),
+                        ("pairwise3_vec4", 64), ("nn_min3", 64), ("fps_lean", 128), ("knn_select", 128)):
+        hit = {k: v for k, v in desc.items() if frag in k}
+        assert hit, frag
+        for k, v in hit.items():
+            assert v["vgpr"] <= limit, (k, v)
+
+
+def _resources(path):
+    """Per kernel, from the amdhsa.kernels metadata list (one YAML item per kernel, '  - .agpr_count: ...' first)."""
+    text = open(path).read()
+    out = {}
+    for item in re.split(r"\n  - (?=\.)", text[text.index("amdhsa.kernels:"):])[1:]:
+        g = lambda key: re.search(r"\.%s:\s+(\S+)" % key, item)  # noqa: E731
+        if g("name") and g("vgpr_count"):
+            out[g("name").group(1)] = dict(vgpr=int(g("vgpr_count").group(1)), agpr=int(g("agpr_count").group(1)) if g("agpr_count") else 0,
+                                           lds=int(g("group_segment_fixed_size").group(1)), sgpr=int(g("sgpr_count").group(1)))
+    return out
+
+
+def test_shipped_kernels_have_no_spills_and_the_known_spillers_are_the_only_ones(isa):
+    desc = {}
+    for path in isa.values():
+        desc.update(_descriptors(path))
+    assert len(desc) > 150
+    for frag in MUST_BE_CLEAN:
+        hits = {k: v for k, v in desc.items() if frag in k}
+        assert hits, frag
+        for k, (priv, spill) in hits.items():
+            assert spill == 0, (k, priv, spill)
+            assert priv == 0 or any(f in k for f in KNOWN_PRIVATE), (k, priv, spill)
+    spillers = {k for k, (priv, spill) in desc.items() if spill > 0}
+    unknown = {k for k in spillers if not any(frag in k for frag in KNOWN_SPILLERS)}
+    assert not unknown, unknown
+    private = {k for k, (priv, spill) in desc.items() if priv > 0 and spill == 0}
+    assert not {k for k in private if not any(frag in k for frag in KNOWN_PRIVATE)}, private

@@ -2,7 +2,9 @@
 """Diagnostic (round 5): `install()` replaces ops.fps_from_start by a version that computes every table with BOTH sampling kernels
 -- fps_lean first (or the 64-bit-key kernel first with order='key64_first'), fps_lean again right behind it, the 64-bit-key
 kernel, fps_lean once more -- and counts, on the device, the clouds whose tables differ.  `counts()` / `captures()` read the
-results.  tools/fps_check_modes.py and tools/fps_check_cfg4.py drive it; docs/kernels/round5.md section 8 has what it found."""
+results.  tools/fps_check_modes.py and tools/fps_check_cfg4.py drive it; docs/kernels/round5.md section 8 has what it found.
+With HITADV_FPS_DIAG_LIB=<path of a libfps_diag_<n>.so built from tools/tune/fps_diag_lib.hip> the "fps_lean" launches run THAT library's
+instrumented kernel (the packed-f32 build is -DHITADV_FPS_DIAG=2) instead of the product's: tools/fps_packed_repro.sh."""
 import ctypes
 import os
 
@@ -16,6 +18,9 @@ _state = {}
 def install(order='lean_first', sync=None):
     lib = _lib.load()
     _p, _dev, _stream = ops._p, ops._dev, ops._stream
+    shipped = lib.hitadv_debug_fps_form(-1)  # (an invalid value changes nothing and returns the current form)
+    diag = ctypes.CDLL(os.environ["HITADV_FPS_DIAG_LIB"]) if os.environ.get("HITADV_FPS_DIAG_LIB") else None
+    _state['diag'] = diag
 
     def fps_from_start(xyz, npoint, start):
         xyz = _dev(xyz.detach(), "xyz")
@@ -32,18 +37,22 @@ def install(order='lean_first', sync=None):
             out = torch.empty(B, npoint, device=dev, dtype=torch.int64)
             if os.environ.get("HITADV_FPS_PREFILL"):  # what a wrong table is made of: values the kernel computed, or what the buffer held before
                 out.fill_(-7)
+            if form == 1 and diag is not None and 256 < N <= 4080:
+                rc = diag.fpsdiag_fps_from_start(_p(xyz), _p(start), B, N, npoint, _p(out), _stream())
+                assert rc == 0, rc
+                return out
             lib.hitadv_debug_fps_form(form)
             _lib.call("hitadv_fps_from_start", _p(xyz), _p(start), B, N, npoint, _p(out), _stream())
             return out
-        logging = bool(os.environ.get("HITADV_FPS_LOG")) and N == 2048  # (a HITADV_FPS_DIAG=9 build) [B, npoint, 8 waves] keys of the first launch
+        logging = diag is not None and bool(os.environ.get("HITADV_FPS_LOG")) and N == 2048  # (a HITADV_FPS_DIAG=9 build) [B, npoint, 8 waves] keys of the first launch
         if logging:
             log = torch.zeros(2, B, npoint, 8, dtype=torch.int64, device=dev)  # [keys | (centre x, active lanes, winner) of lane 63]
-            lib.hitadv_debug_fps_log(ctypes.c_void_p(log.data_ptr()))
+            diag.fpsdiag_log(ctypes.c_void_p(log.data_ptr()))
         idx = launch(0 if order == 'key64_first' else 1)
         if logging:
-            lib.hitadv_debug_fps_log(None)
+            diag.fpsdiag_log(None)
         second, chk, again = launch(1), launch(0), launch(1)
-        lib.hitadv_debug_fps_form(1)  # the shipped form
+        lib.hitadv_debug_fps_form(shipped)
         c = _state.setdefault('tables', torch.zeros(2, dtype=torch.int64, device=dev))
         more = _state.setdefault('more', torch.zeros(3, dtype=torch.int64, device=dev))
         chg = _state.setdefault('inputs_changed', torch.zeros(2, dtype=torch.int64, device=dev))
@@ -88,6 +97,15 @@ def reset():
             v.zero_()
         elif isinstance(k, tuple) and k[0] == 'hist':
             v['prev'].fill_(-1)
+
+
+def diag_counters():
+    """The instrumented kernel's own counters (HITADV_FPS_DIAG 4 / 5 builds), or None without a diagnostic library."""
+    if _state.get('diag') is None:
+        return None
+    buf = (ctypes.c_uint * 8)()
+    _state['diag'].fpsdiag_counters(buf)
+    return list(buf)
 
 
 def counts():

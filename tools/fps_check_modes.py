@@ -32,14 +32,7 @@ for graph in (False,):
         else:
             att.attack_many(bs)
         torch.cuda.synchronize()
-        import ctypes
-        from hit_adv_amd import _lib
-        buf = (ctypes.c_uint * 8)()
-        try:
-            _lib.load().hitadv_debug_fps_counters(buf)
-        except AttributeError:
-            pass
         if n == 2:
             os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
             torch.save(fps_check.captures(), os.path.join(ROOT, 'gpurun_out', 'fps_mismatch.pt'))
-        print('graph', graph, 'in flight', n, fps_check.counts(), 'kernel counters', list(buf), flush=True)
+        print('graph', graph, 'in flight', n, fps_check.counts(), 'kernel counters', fps_check.diag_counters(), flush=True)

@@ -120,6 +120,7 @@ def main():
     out['fps_from_start_m256'] = dict(us=round(us, 1), us_per_step=round(us / 256, 3))
     # the step latency at the sizes the victims use (PointNet++: 1024 -> 512 -> 128, PCT: 1024 -> 512 -> 256), old kernel beside the new
     lib.hitadv_debug_fps_form.restype = ctypes.c_int
+    shipped_form = lib.hitadv_debug_fps_form(-1)
     for nm, fn, n_, m_ in (('fps_from_start', lib.hitadv_fps_from_start, 2048, 512), ('fps_from_start', lib.hitadv_fps_from_start, 1024, 512),
                            ('fps_from_start', lib.hitadv_fps_from_start, 512, 128), ('fps_pct', lib.hitadv_fps_pct, 1024, 512),
                            ('fps_pct', lib.hitadv_fps_pct, 512, 256)):
@@ -131,7 +132,7 @@ def main():
             us = timed(lambda s=s0: fn(p(xs), p(start), B, n_, m_, p(fo), s), 20)
             row['key64' if form == 0 else 'lean'] = dict(us=round(us, 1), us_per_step=round(us / m_, 3))
         out[f'{nm}_N{n_}_m{m_}'] = row
-    lib.hitadv_debug_fps_form(1)  # the shipped form
+    lib.hitadv_debug_fps_form(shipped_form)
     f32 = torch.empty(B, 51, dtype=torch.int32, device='cuda')
     us = timed(lambda s=s0: lib.hitadv_furthest_point_sampling(B, N, 51, p(x), None, p(f32), s), 20)
     out['fps_ext_m51'] = dict(us=round(us, 1), us_per_step=round(us / 50, 3))

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 6, first lease: the two probes round 5 wrote and never ran, then the driver's three checks on HEAD's build.
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r06
+export TMPDIR=/tmp
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/tune/pk_f32_probe.hip -o /tmp/pk_f32_probe 2>&1 | tail -3
+timeout 300 /tmp/pk_f32_probe > gpurun_out/r06/pk_f32_probe.txt 2>&1; echo "pk probe rc=$?" >> gpurun_out/r06/pk_f32_probe.txt
+
+timeout 1500 bash tools/fps_packed_repro.sh > gpurun_out/r06/fps_packed_repro.txt 2>&1; echo "repro rc=$?" >> gpurun_out/r06/fps_packed_repro.txt
+
+timeout 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r06/pytest_gpu_first.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/r06/pytest_gpu_first.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06/smoke_first.txt 2>&1; echo "smoke rc=$?" >> gpurun_out/r06/smoke_first.txt
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06/bench_first.txt 2>&1; echo "bench rc=$?" >> gpurun_out/r06/bench_first.txt
+tail -3 gpurun_out/r06/*.txt

@@ -1,7 +1,8 @@
-// What each part of an FPS step's dependent chain costs (sampling.hip::fps_lean, PROBE 1..5): one workgroup per cloud, the step is
+// What each part of an FPS step's dependent chain costs (tools/tune/fps_lean_diag.hpp, the instrumented copy of sampling.hip::fps_lean, PROBE 1..5): one workgroup per cloud, the step is
 // a serial chain on one CU, so the parts add.  hipcc -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950
 // -I include -I hit_adv_amd/csrc tools/tune/fps_step_probe.hip -o tools/tune/fps_step_probe
 #include "../../hit_adv_amd/csrc/sampling.hip"
+#include "fps_lean_diag.hpp"
 #include <cstdio>
 #include <vector>
 template <int PT, bool PCT, int NW, int PROBE>
@@ -11,7 +12,7 @@ static void run(const float *x, const int64_t *start, int64_t *idx, int B, int N
   float best = 1e30f;
   for (int rep = 0; rep < 6; ++rep) {
     (void)hipEventRecord(e0, 0);
-    hitadv::fps_lean<PT, PCT, NW, int64_t, PROBE><<<B, 64 * NW, (size_t)N * sizeof(float4), 0>>>(x, start, N, m, idx);
+    hitadv::fps_lean_diag<PT, PCT, NW, int64_t, PROBE><<<B, 64 * NW, (size_t)N * sizeof(float4), 0>>>(x, start, N, m, idx);
     (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     if (rep && ms < best) best = ms;
@@ -20,7 +21,7 @@ static void run(const float *x, const int64_t *start, int64_t *idx, int B, int N
 }
 template <int PT, bool PCT, int NW>
 static void stamps(const float *x, const int64_t *start, int64_t *idx, int B, int N, int m) {
-  hitadv::fps_lean<PT, PCT, NW, int64_t, 5><<<B, 64 * NW, (size_t)N * sizeof(float4), 0>>>(x, start, N, m, idx);
+  hitadv::fps_lean_diag<PT, PCT, NW, int64_t, 5><<<B, 64 * NW, (size_t)N * sizeof(float4), 0>>>(x, start, N, m, idx);
   int64_t h[5];
   (void)hipMemcpy(h, idx, sizeof(h), hipMemcpyDeviceToHost);
   printf("  N %5d PT %2d waves %d %s shader cycles per step: centre read %.0f | distances + lane max %.0f | wave max + holder %.0f | slot write + barrier %.0f | slot read + merge %.0f\n",
