@@ -183,7 +183,7 @@ __device__ __forceinline__ void split3x8(const float4 &lo4, const float4 &hi4, u
 // the residuals underflow and the result may be one ulp off __builtin_sqrtf, or flushed for a subnormal d: a distance < 2^-48 that
 // the deformation only uses as exp2(r * a2) (= 1 to the last bit for sigma >= 3e-4; min_sigm is 0.1) and as the factor of one term
 // < 2^-48 |dk| of the sigma gradient -- below the last bit of either sum.  The deformation's parity bar is a tolerance (1e-5
-// relative), not bit equality; tests/test_gpu_edges.py::test_deform_near_duplicate_points_at_the_origin_...
+// relative), not bit equality; tests/test_z_r06_edges.py::test_deform_near_duplicate_points_at_the_origin_...
 // holds it on such a cloud.  A wave-uniform fall-back would cost a compare, a ballot and a branch per value of a kernel bound by
 // its 38 vector instructions per value.
 __device__ __forceinline__ float sqrt_rn_ranged(float d) {

@@ -89,36 +89,6 @@ def test_deform_many_centres_and_odd_point_counts(A):
     close(sg.grad.cpu(), sig.grad, rtol=2e-4, atol=1e-5 * float(sig.grad.abs().max()))
 
 
-def test_deform_near_duplicate_points_at_the_origin_stay_within_the_tolerance(A):
-    """common.hpp::sqrt_rn_ranged is the correctly rounded sqrt for d = 0 or 2^-96 <= d < 2^96 (ADVICE r05): below that -- two distinct
-    points within 3.5e-15 of each other, which needs every coordinate of both below ~1e-14 -- the fix-up's residuals underflow and the
-    distance can be one ulp of a number < 2^-48 off (or flushed, for a subnormal d).  Such a distance enters the kernel weight as
-    exp2(r * a2) = 1 to the last bit and the sigma gradient as a term < 2^-48 |dk|: invisible to the fp32 sums.  The cloud here has
-    such pairs (points and centres at 1e-20 .. 1e-15 from the origin and from each other, a centre ON a point); forward and both
-    gradients must meet the usual tolerance of the deformation against the oracle."""
-    g = torch.Generator().manual_seed(31)
-    B, Np, C = 2, 200, 24
-    ori = torch.randn(B, 3, Np, generator=g) * 0.5
-    central = torch.randn(B, 3, C, generator=g) * 0.5
-    tiny = torch.tensor([1e-20, -2e-20, 3e-19, 1e-17, -4e-16, 2e-15, 1e-30, 0.0])
-    for b in range(B):
-        ori[b, :, :8] = torch.stack([tiny, tiny.roll(1), -tiny.roll(2)])
-        central[b, :, :6] = torch.stack([tiny.roll(3)[:6] * 1.5, tiny[:6] * 0.5, tiny.roll(1)[:6]])
-        central[b, :, 6] = ori[b, :, 3]  # distance exactly 0: a centre that IS a point (HiT_ADV.py:80: centres are dataset points)
-    P = ((torch.rand(B, C, 3, generator=g) - 0.5) * 0.2).requires_grad_()
-    sig = (0.1 + torch.rand(B, C, generator=g)).requires_grad_()
-    up = torch.randn(B, 3, Np, generator=g)
-    ref = O.deform_loop(ori, P, O.kernel_density(central, ori, sig))
-    (ref * up).sum().backward()
-    Pg, sg = P.detach().cuda().requires_grad_(), sig.detach().cuda().requires_grad_()
-    adv = A.deform(ori.cuda(), central.cuda(), Pg, sg)
-    close(adv.detach().cpu(), ref.detach(), rtol=1e-5, atol=2e-6)
-    (adv * up.cuda()).sum().backward()
-    assert torch.isfinite(Pg.grad).all() and torch.isfinite(sg.grad).all()
-    close(Pg.grad.cpu(), P.grad, rtol=2e-4, atol=1e-5 * float(P.grad.abs().max()))
-    close(sg.grad.cpu(), sig.grad, rtol=2e-4, atol=1e-5 * float(sig.grad.abs().max()))
-
-
 def test_fps_maximum_and_unsupported_sizes(A):
     from hit_adv_amd import _lib
     x = pts(1, 16384, 40)

@@ -1,9 +1,12 @@
 #!/bin/bash
-# round 6, first lease: the two probes round 5 wrote and never ran, then the driver's three checks on HEAD's build.
+# round 6, first lease (refused so far: GPU use for the repository was closed from outside the build -- docs/kernels/round6.md section 1): the probes round 5 wrote and never ran + this round's
+# second hypothesis, then the driver's three checks on HEAD's build.  Outputs: gpurun_out/r06/ (copy what is to be judged to profiles/r06_*).
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r06
 export TMPDIR=/tmp
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/tune/pk_f32_probe.hip -o /tmp/pk_f32_probe 2>&1 | tail -3
 timeout 300 /tmp/pk_f32_probe > gpurun_out/r06/pk_f32_probe.txt 2>&1; echo "pk probe rc=$?" >> gpurun_out/r06/pk_f32_probe.txt
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/tune/lds_return_probe.hip -o /tmp/lds_return_probe 2>&1 | tail -3
+timeout 300 /tmp/lds_return_probe > gpurun_out/r06/lds_return_probe.txt 2>&1; echo "lds probe rc=$?" >> gpurun_out/r06/lds_return_probe.txt
 
 timeout 1500 bash tools/fps_packed_repro.sh > gpurun_out/r06/fps_packed_repro.txt 2>&1; echo "repro rc=$?" >> gpurun_out/r06/fps_packed_repro.txt
 
