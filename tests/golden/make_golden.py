@@ -457,8 +457,8 @@ def g5d(steps=2, iters=50, name='g5d_attack_pointnet.npz', p_every=10, logits_ev
                taken_step=rec['taken'][:, 0], taken_iter=rec['taken'][:, 1], final_o_bestdist=rec['final']['o_bestdist'],
                kept_iterations=np.array([i for i in range(iters) if i % p_every == 0 or i == iters - 1]),
                weight_checksum=np.array([float(v.double().abs().sum()) for v in model.state_dict().values()]))
-    for name in ('lower', 'upper', 'scale_const', 'o_bestdist', 'o_bestscore', 'bestdist', 'bestscore'):
-        out['step_' + name] = np.stack([s_[name] for s_ in rec['steps']])
+    for field in ('lower', 'upper', 'scale_const', 'o_bestdist', 'o_bestscore', 'bestdist', 'bestscore'):
+        out['step_' + field] = np.stack([s_[field] for s_ in rec['steps']])
     out.update({'hp_' + k: v for k, v in hp.items()})
     if logits_every != 1:
         out['kept_logit_iterations'] = np.array([i for i in range(iters) if i % logits_every == 0 or i == iters - 1])

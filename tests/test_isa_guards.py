@@ -161,6 +161,19 @@ def test_register_and_lds_budgets_of_the_launch_shapes(isa):
             assert v["vgpr"] <= limit, (k, v)
 
 
+def test_instruction_mix_of_one_v1_tile(isa):
+    """The figure docs/kernels/round5.md section 2 and VERDICT r05 (weak #7) argue from, read from the artefact: one 64-point tile of the
+    flat fp16x2 V1 (`linear_max_fwd_bf3_k<128, 2, true>`, 52 % of cfg2's kernel time) is 96 MFMAs and ~148 vector instructions per wave
+    (tools/tune/mfma16_valu_overlap.hip: on gfx950 the two do not overlap, so the tile costs 96 x 16 + ~148 x 4 cycles).  A change that
+    adds vector work to the tile shows up here before it shows up on a GPU; a change that removes some moves the ceiling DOWN (the
+    target VERDICT names is 110)."""
+    mixes = isa_scan.tile_regions(isa["victim_bf3"], "linear_max_fwd_bf3_kILi128ELi2ELb1E", 96)
+    assert len(mixes) >= 2, mixes  # the two wave halves' schedules of a steady tile
+    for m in mixes:
+        assert m["valu"] <= 152, m
+        assert m.get("lds", 0) <= 48, m
+
+
 def _resources(path):
     """Per kernel, from the amdhsa.kernels metadata list (one YAML item per kernel, '  - .agpr_count: ...' first)."""
     text = open(path).read()

@@ -114,6 +114,48 @@ def scan_hi_half_forwarding(path):
     return hits
 
 
+def _category(t):
+    if t.startswith("v_mfma") or t.startswith("v_smfmac"):
+        return "mfma"
+    if t.startswith("v_"):
+        return "valu"
+    if t.startswith("s_"):
+        return "salu"
+    if t.startswith("ds_"):
+        return "lds"
+    if t.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        return "vmem"
+    return "other"
+
+
+def loop_regions(ins):
+    """[(first, last)] instruction index ranges of the natural loops of one kernel: a backward branch and its target label."""
+    labels = {t[:-1]: i for i, (_, t) in enumerate(ins) if t.endswith(":")}
+    out = []
+    for i, (_, t) in enumerate(ins):
+        m = re.match(r"s_c?branch\w*\s+(\.LBB\w+)", t)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            out.append((labels[m.group(1)], i))
+    return out
+
+
+def tile_regions(path, kernel_fragment, mfmas):
+    """Instruction mix of the smallest loop regions of a kernel that hold exactly `mfmas` matrix instructions -- one tile's worth:
+    [{category: count}], one per region (the kernels keep two copies of a tile, one per wave half's schedule)."""
+    out = []
+    for name, ins in kernels(path).items():
+        if kernel_fragment not in name:
+            continue
+        for a, b in loop_regions(ins):
+            mix = {}
+            for _, t in ins[a:b + 1]:
+                if not t.endswith(":"):
+                    mix[_category(t)] = mix.get(_category(t), 0) + 1
+            if mix.get("mfma") == mfmas:
+                out.append(mix)
+    return out
+
+
 def packed_counts(path):
     return {name: sum(1 for _, t in ins if PACKED.match(t)) for name, ins in kernels(path).items()}
 
