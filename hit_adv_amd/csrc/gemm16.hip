@@ -507,15 +507,17 @@ constexpr int GR_STAGES = 3;
 // row once (rows alternate between its halves, s takes {0, 1, 4, 5} on each parity of either row set)
 __device__ __forceinline__ int gr_swz(int r) { return ((r >> 1) & 1) | (((r >> 2) & 1) << 2); }
 
-// (m0 is declared clobbered: nothing else in this kernel uses it today -- gfx9 LDS instructions do not read m0 --, but an epilogue
-// that made the compiler use it, e.g. a relative-indexed register move, must see that this statement overwrites it)
+// (m0 cannot usefully be declared clobbered: clang lists it among the RESERVED registers -- the clobber is accepted with
+// "-Winline-asm: clobber list contains reserved registers" and has no effect (tried in round 6 for ADVICE r05: identical ISA, one warning per
+// instantiation).  Nothing else in this kernel uses m0: gfx9 LDS instructions do not read it, and the kernel has no relative-indexed
+// register move, LDS-direct load or s_sendmsg; tests/test_isa_guards.py checks that the ring kernel's only writes of m0 are these.)
 __device__ __forceinline__ void gr_dma16(uint32_t lds_at, uint32_t voff, const void *sbase) {
   const unsigned long long a = (unsigned long long)(uintptr_t)sbase;
   const unsigned long long u = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_at)), "v"(voff),
                "s"(u)
-               : "memory", "m0");
+               : "memory");
 }
 
 // ABL != 0: tuning builds only (tools/tune/g16_ablate.py; results are garbage): 11 no MFMAs, 12 no split (raw bits), 13 no LDS reads,

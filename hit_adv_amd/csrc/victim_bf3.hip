@@ -68,7 +68,12 @@ __device__ __forceinline__ void v1_sel2(int &ca, int &cb, unsigned long long ma,
 // of them): the clouds of a workgroup are ONE stream of tiles -- they are contiguous in X --, the running maximum is finished
 // and started again every N / 64 tiles, and the tile pipeline is neither drained nor refilled at a cloud boundary (3.3 us each
 // at N = 1024, tools/v1_bubble_probe.py).  The instantiation holds no ragged-tile or split-merge code at all.
-template <int CIN, int MODE, bool FLAT>
+// DEFER (round 6, NOT YET RUN ON A GPU; off unless HITADV_V1_DEFER=1 -- see the launcher): the search for the tile's first arg-max (30
+// compares + 32 selects per tile and wave, the largest single item of the tile's ~148 vector instructions) leaves the tile.  A lane keeps,
+// per channel, the 16 joined values of the LAST TILE THAT IMPROVED its running maximum (16 selects under the improvement mask) and that
+// tile's number; the search runs once per cloud, in finish(), over the kept values.  The same (value, point): the kept tile is the one
+// whose maximum the running maximum equals, and "first of its 16 values equal to it" is what the per-tile search computed.
+template <int CIN, int MODE, bool FLAT, bool DEFER = false>
 __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restrict__ X, const uint16_t *__restrict__ W3,
                                                             int B_, int N, int Cout, int rows_per_split, int S, int ncg, int cpb,
                                                             float *pval, int32_t *pidx, const float *__restrict__ bias,
@@ -214,6 +219,14 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   // 16 rt + 4 (lane / 16) + i, channel 16 ct + lane % 16.  A lane therefore scans TWO channels.
   float bv[2] = {-__builtin_inff(), -__builtin_inff()};
   int bi[2] = {-1, -1};
+  float sv[2][16];          // DEFER: the joined values of the last tile that improved bv (per channel)
+  int bt[2] = {-1, -1};     // DEFER: that tile's number (FLAT: within its cloud); -1 = none yet
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sv[ct][q] = 0.f;
+  }
   const int l16 = lane & 15, g4 = lane >> 4;
   const bool late = wave >= 4;  // wave-uniform
   // one tile: 8 units of (slice j, row-tile pair rp): 6 A fragments (2 row tiles x 3 pieces) feed 24 MFMAs; the next
@@ -307,6 +320,17 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
 #pragma unroll
       for (int q = 0; q < 16; q += 2) tv[ct] = __builtin_fmaxf(__builtin_fmaxf(tv[ct], v[ct][q]), v[ct][q + 1]);
     }
+    if constexpr (DEFER) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const bool g = tv[ct] > bv[ct];  // earlier tiles hold earlier points: they keep ties
+        bv[ct] = g ? tv[ct] : bv[ct];
+        bt[ct] = g ? (FLAT ? tile - tbase : tile) : bt[ct];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sv[ct][q] = g ? v[ct][q] : sv[ct][q];
+      }
+      return;
+    }
     // tc = v[q] == tv ? q : tc for q = 14 .. 0, written out: the compiler sends every compare through VCC and pays the
     // compare -> select hazard (2 wait states) thirty times per tile; here the compares run two steps ahead of the selects in
     // four SGPR pairs, so each result is five instructions old when it is read.
@@ -371,6 +395,16 @@ __global__ __launch_bounds__(512) void linear_max_fwd_bf3_k(const float *__restr
   // point); the four 16-lane groups of the wave hold the same channels, other points: two exchanges, the lower point keeps
   // a tie; then the result (S == 1) or this split's partial leaves, and the running maximum starts again
   auto finish = [&]() {
+    if constexpr (DEFER) {  // the search the tiles skipped: the first of the kept tile's 16 values equal to the running maximum
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        int tc = 15;
+#pragma unroll
+        for (int q = 14; q >= 0; --q) tc = sv[ct][q] == bv[ct] ? q : tc;
+        bi[ct] = bt[ct] < 0 ? -1 : bt[ct] * 16 + tc;
+        bt[ct] = -1;
+      }
+    }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       bi[ct] = bi[ct] < 0 ? n0 : n0 + (bi[ct] >> 4) * B3_TM + 16 * ((bi[ct] >> 2) & 3) + 4 * g4 + (bi[ct] & 3);
@@ -541,6 +575,16 @@ extern "C" int64_t hitadv_linear_max_fwd_bf16x3_scratch(int B, int N, int Cout, 
   return (int64_t)B * S * Cout;
 }
 
+// 0 (default) = the per-tile arg-max search; 1 (HITADV_V1_DEFER=1, or hitadv_debug_v1_defer: A/B, tests) = the search deferred to the end
+// of a cloud in the flat fp16x2 kernel on packed input (template parameter DEFER).  Same results, bit for bit, by construction -- and never
+// run on a GPU: written in round 6, which had none (docs/kernels/round6.md section 4).
+static int g_v1_defer = [] { const char *e = getenv("HITADV_V1_DEFER"); return e && e[0] == '1' ? 1 : 0; }();
+extern "C" int hitadv_debug_v1_defer(int on) {
+  const int old = g_v1_defer;
+  if (on == 0 || on == 1) g_v1_defer = on;
+  return old;
+}
+
 template <int MODE>
 static int launch_linear_max_pieces(const float *X, const uint16_t *W3, const float *bias, int B, int N, int Cin, int Cout,
                                     int relu, int blocks, float *part_val, int32_t *part_idx, float *out, int64_t *idx,
@@ -573,7 +617,17 @@ static int launch_linear_max_pieces(const float *X, const uint16_t *W3, const fl
                                                                    bias, relu, out, idx, tickets, range_flag);                 \
   } while (0)
   if (Cin == 128) {
-    if (flat) HITADV_V1_LAUNCH(128, true);
+    bool deferred = false;
+    if constexpr (MODE == 2) {  // (the stacked loop's kernel only -- the other modes are not instantiated; off by default: never run on a GPU yet)
+      if (flat && g_v1_defer) {
+        HITADV_RAISE_LDS((&linear_max_fwd_bf3_k<128, 2, true, true>), 2 * NP * B3_TM * (2 * 128 + 32));
+        linear_max_fwd_bf3_k<128, 2, true, true><<<grid, 512, shm, s>>>(X, W3, B, N, Cout, rows, S, ncg, cpb, part_val, part_idx, bias,
+                                                                        relu, out, idx, tickets, range_flag);
+        deferred = true;
+      }
+    }
+    if (deferred) {
+    } else if (flat) HITADV_V1_LAUNCH(128, true);
     else HITADV_V1_LAUNCH(128, false);
   } else {
     if (flat) HITADV_V1_LAUNCH(64, true);

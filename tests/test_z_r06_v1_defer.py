@@ -1,0 +1,94 @@
+"""V1 with the arg-max search deferred to the end of a cloud (csrc/victim_bf3.hip, template parameter DEFER; HITADV_V1_DEFER=1 or
+hitadv_debug_v1_defer(1); OFF by default) against the shipped per-tile search: THE SAME BITS -- maxima and arg-max tables of the layer,
+and a whole attack -- on Gaussian and surface-like activations, with exact ties inside a tile, across tiles and across clouds, a
+cloud that is all NaN, and every workgroup count that selects the flat kernel.  Static evidence (CPU): tests/test_isa_guards.py --
+249 registers, no spills, 111-114 vector instructions per tile and wave instead of 147-150.
+
+STATUS: written in round 6, which had no GPU access -- NOT RUN ON HARDWARE YET, which is exactly why the variant is off by default.  The
+file sorts last on purpose (`pytest -x`)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import synth_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import hit_adv_amd.ops as ops
+    return ops
+
+
+@pytest.fixture()
+def defer():
+    """Switch between the two kernels; always back to what was shipped."""
+    from hit_adv_amd import _lib
+    L = _lib.load()
+    shipped = L.hitadv_debug_v1_defer(-1)  # (an invalid value changes nothing and returns the current setting)
+    yield L.hitadv_debug_v1_defer
+    L.hitadv_debug_v1_defer(shipped)
+
+
+def _packed(h):
+    hi = h.half()
+    lo = ((h - hi.float()) * 2048.).half()
+    return ((hi.view(torch.int16).int() & 0xffff) | (lo.view(torch.int16).int() << 16)).contiguous().view(torch.float32)
+
+
+@pytest.mark.parametrize("B,Np,blocks", [(256, 1024, 128), (256, 1024, 256), (32, 1024, 16), (13, 1280, 8), (64, 128, 40), (8, 2048, 8)])
+@pytest.mark.parametrize("kind", ["gaussian", "sphere"])
+def test_deferred_search_gives_the_bits_of_the_per_tile_search(A, defer, B, Np, blocks, kind):
+    g = torch.Generator().manual_seed(B + Np + blocks)
+    x = torch.randn(B * Np, 128, generator=g).relu()
+    if kind == "sphere":  # rows of very different norms, many zero rows: long runs of equal (zero) maxima
+        x = x * (torch.rand(B * Np, 1, generator=g) > 0.7).float() * torch.rand(B * Np, 1, generator=g)
+    x = x.view(B, Np, 128)
+    x[0, 5] = x[0, 3]                       # an exact tie INSIDE a tile: the lower point must win
+    x[0, Np - 1] = x[0, 3]                  # ... and in the cloud's last tile
+    x[1 % B, 64] = x[1 % B, 63]             # across a tile boundary
+    x[2 % B] = x[2 % B, :1].expand(Np, 128)  # a cloud of IDENTICAL points: every tile ties with the first, point 0 wins every channel
+    x[3 % B] = float('nan')                 # nothing compares: the table must stay valid (index 0), the values NaN-free or not -- equal
+    x[4 % B, 7:] = 0.                        # maxima reached in the first tile only
+    xp = _packed(x.reshape(B * Np, 128)).cuda()
+    W = A.split_weights_f16x2((torch.randn(1024, 128, generator=g) * 0.1).cuda())
+    bias = torch.randn(1024, generator=g).cuda()
+    defer(0)
+    v0, i0 = A.linear_max_fwd_f16x2(xp, W, B, Np, bias=bias, relu=True, blocks=blocks, packed=True)
+    r0, j0 = A.linear_max_fwd_f16x2(xp, W, B, Np, blocks=blocks, packed=True)
+    defer(1)
+    v1, i1 = A.linear_max_fwd_f16x2(xp, W, B, Np, bias=bias, relu=True, blocks=blocks, packed=True)
+    r1, j1 = A.linear_max_fwd_f16x2(xp, W, B, Np, blocks=blocks, packed=True)
+    assert torch.equal(i0, i1) and torch.equal(j0, j1)
+    assert torch.equal(v0.view(torch.int32), v1.view(torch.int32)) and torch.equal(r0.view(torch.int32), r1.view(torch.int32))
+    assert int(i1[2 % B].max()) == 0 and int(i1.min()) >= 0 and int(i1.max()) < Np
+    assert int((i1[0] == 5).sum()) == 0 and int((i1[0] == Np - 1).sum()) == 0 and int((i1[1 % B] == 64).sum()) == 0
+
+
+def test_an_attack_with_the_deferred_search_is_the_attack_without_it(defer):
+    """Four stacked HiT-ADV attacks on the eval.py victim (the path the bench times: attack_many, captured graphs), 2 x 12 iterations:
+    returned clouds, success counts and bounds with HITADV_V1_DEFER on equal the ones with it off, bit for bit."""
+    from hit_adv_amd.ShapeAttack.HiT_ADV import HiT_ADV
+    from hit_adv_amd.model.pointnet import PointNetFeatureModel
+    from hit_adv_amd.util.adv_utils import UntargetedLogitsAdvLoss
+    torch.manual_seed(0)
+    model = PointNetFeatureModel(40, normal_channel=False).eval().cuda()
+    batches = []
+    for k in range(4):
+        d, _ = synth_batch(32, 1024, first=4000 + 32 * k)
+        with torch.no_grad():
+            lab = model(d[:, :, :3].transpose(1, 2).contiguous().cuda())[0].argmax(1).cpu()
+        batches.append((d, lab))
+    hp = dict(attack_lr=1e-2, central_num=192, total_central_num=256, init_weight=10., max_weight=80., cd_weight=1e-4, ker_weight=1.,
+              hide_weight=1., curv_loss_knn=16, max_sigm=1.2, min_sigm=0.1, budget=0.55, binary_step=2, num_iter=12)
+    runs = []
+    for on in (0, 1):
+        defer(on)
+        att = HiT_ADV(model, adv_func=UntargetedLogitsAdvLoss(kappa=30.), verbose=False, **hp)
+        torch.manual_seed(9)
+        res = att.attack_many(batches)
+        runs.append((res, att.last_lower_bound.clone()))
+    for (b0, s0), (b1, s1) in zip(runs[0][0], runs[1][0]):
+        assert np.array_equal(b0, b1) and int(s0) == int(s1)
+    assert torch.equal(runs[0][1], runs[1][1])

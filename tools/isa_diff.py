@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which kernels of two builds differ in their INSTRUCTIONS: `python tools/isa_diff.py dirA dirB` compares, file by file and kernel by
 kernel, the gfx950 assembly of two trees of `hipcc -S --cuda-device-only` outputs (labels normalised, comments and directives dropped).
-Round 6 used it to state what HEAD's library changes against the last library that ran on a GPU (docs/kernels/round6.md section 4)."""
+Round 6 used it to state what HEAD's library changes against the last library that ran on a GPU (docs/kernels/round6.md section 5)."""
 import glob
 import os
 import re
