@@ -48,7 +48,7 @@ def test_deferred_search_gives_the_bits_of_the_per_tile_search(A, defer, B, Np, 
     x[0, 5] = x[0, 3]                       # an exact tie INSIDE a tile: the lower point must win
     x[0, Np - 1] = x[0, 3]                  # ... and in the cloud's last tile
     x[1 % B, 64] = x[1 % B, 63]             # across a tile boundary
-    x[2 % B] = x[2 % B, :1].expand(Np, 128)  # a cloud of IDENTICAL points: every tile ties with the first, point 0 wins every channel
+    x[2 % B] = x[2 % B, :1].clone().expand(Np, 128)  # a cloud of IDENTICAL points: every tile ties with the first, point 0 wins every channel
     x[3 % B] = float('nan')                 # nothing compares: the table must stay valid (index 0), the values NaN-free or not -- equal
     x[4 % B, 7:] = 0.                        # maxima reached in the first tile only
     xp = _packed(x.reshape(B * Np, 128)).cuda()

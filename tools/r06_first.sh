@@ -13,4 +13,9 @@ timeout 1500 bash tools/fps_packed_repro.sh > gpurun_out/r06/fps_packed_repro.tx
 timeout 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r06/pytest_gpu_first.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/r06/pytest_gpu_first.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06/smoke_first.txt 2>&1; echo "smoke rc=$?" >> gpurun_out/r06/smoke_first.txt
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06/bench_first.txt 2>&1; echo "bench rc=$?" >> gpurun_out/r06/bench_first.txt
+# the A/B that decides about the deferred-search V1 (docs/kernels/round6.md section 4): its bitwise test first, then the headline either way, same box
+timeout 600 python -m pytest tests/test_z_r06_v1_defer.py -q > gpurun_out/r06/v1_defer_test.txt 2>&1; echo "defer test rc=$?" >> gpurun_out/r06/v1_defer_test.txt
+for d in 0 1 0 1; do
+  HITADV_V1_DEFER=$d timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-other-configs --no-single --no-f32 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('HITADV_V1_DEFER=$d', d['value'], d['ms_per_step'], d.get('attack_success'))" >> gpurun_out/r06/v1_defer_ab.txt 2>&1
+done
 tail -3 gpurun_out/r06/*.txt
