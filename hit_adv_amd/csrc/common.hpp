@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "arith.hpp"  // the distance forms, the three-piece split, PCT's tie threshold: plain C++, also compiled for the HOST by the CPU tests
+
 #define HITADV_WAVE 64
 
 #define HITADV_LAUNCH_CHECK()                       \
@@ -149,19 +151,6 @@ struct PieceWatch {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 u) { return __builtin_bit_cast(bf16x8, u); }
 
-// a = hi + mid + lo exactly, each the bf16 truncation of what is left (upper 16 bits of an fp32 = a bf16)
-__device__ __forceinline__ void split3(float a, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
-  hi = __float_as_uint(a) & 0xffff0000u;
-  const float r1 = a - __uint_as_float(hi);
-  mid = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mid);
-  lo = __float_as_uint(r2);  // at most 8 significant bits are left: its lower 16 bits are zero
-}
-
-__device__ __forceinline__ uint32_t pack_hi(uint32_t even, uint32_t odd) {  // two bf16 (upper halves) -> one dword
-  return (even >> 16) | (odd & 0xffff0000u);
-}
-
 // eight consecutive floats -> their three pieces, eight bf16 (one uint4) each
 __device__ __forceinline__ void split3x8(const float4 &lo4, const float4 &hi4, uint4 &p1, uint4 &p2, uint4 &p3) {
   const float a[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
@@ -197,57 +186,6 @@ __device__ __forceinline__ float sqrt_rn_ranged(float d) {
 // 2^x for x <= 0 with results below 2^-126 flushed to zero (v_exp_f32 alone: exp2f() scales such arguments to return
 // subnormals, four more instructions).  For sums that are not divided by: a term of 1e-38 is not seen by an fp32 sum.
 __device__ __forceinline__ float exp2_flush(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// Canonical squared distance: ((dx*dx + dy*dy) + dz*dz), one fp32 rounding per operation.
-// The translation unit is built with -ffp-contract=off so nothing here fuses into an FMA.
-__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
-  float dx = ax - bx, dy = ay - by, dz = az - bz;
-  return (dx * dx + dy * dy) + dz * dz;
-}
-
-// A squared distance as one of three fp32 expressions (include/hitadv.h, HITADV_FORM_*):
-//   0  direct       ((dx*dx + dy*dy) + dz*dz)                                 the project's canonical rule
-//   1  Gram         (|q|^2 + |p|^2) - 2 q.p, every dot product an FMA chain   _Distance.batch_pairwise_dist
-//                   fma(a2,b2, fma(a1,b1, a0*b0)) -- what the GEMM behind     (util/set_distance.py:15-32)
-//                   torch.bmm executes for a K = 3 inner dimension
-//   2  Gram (kNN)   (|p|^2 + (-2 q.p)) + |q|^2, q.p an FMA chain, |.|^2 a     KNNDist (util/dist_utils.py:148-150)
-//                   plain sum of squares ((a0*a0 + a1*a1) + a2*a2)
-//   3  square_distance  ((-2 q.p) + |q|^2) + |p|^2, q.p an FMA chain, |.|^2 a    the victims' square_distance(src = q, dst = p)
-//                   plain sum of squares                                      (model/pointnet2_utils.py:19-41,
-//                                                                              model/pct_utils.py:40-58)
-//   4  PCT get_dists  sqrt(d < 0 ? 1e-7 : d), d = (|q|^2 + |p|^2) - 2 q.p     util/other_utils.py:237-251 as PCT's sampler
-//                   with q.p = fma(q1, p1, q0 p0) + q2 p2: the product of a   calls it (:254-272); only pct_dist() below
-//                   ONE-row matrix does not take the GEMM kernel's chain
-// q = the row / query point, p = the column / reference point.  Forms 1 to 4 reproduce the reference's values bit for
-// bit (oracle/pointnet2_oracle.c::pair_value is checked against torch itself, tests/test_oracle_gram.py).
-__device__ __forceinline__ float dot3_fma(float ax, float ay, float az, float bx, float by, float bz) {
-  return fmaf(az, bz, fmaf(ay, by, ax * bx));
-}
-
-// form 4 (rq, rp = plain sums of squares); sqrtf is the correctly rounded one (hipcc's default for fp32 sqrt)
-__device__ __forceinline__ float pct_dist(float qx, float qy, float qz, float rq, float px, float py, float pz, float rp) {
-  const float zz = fmaf(qy, py, qx * px) + qz * pz;
-  const float d = fmaf(-2.0f, zz, rq + rp);  // 2*zz is exact: (rq + rp) - 2*zz rounded once
-  return __builtin_sqrtf(d < 0.f ? 1e-7f : d);
-}
-
-template <int FORM>
-__device__ __forceinline__ float sq_norm(float x, float y, float z) {
-  if (FORM == 1) return dot3_fma(x, y, z, x, y, z);
-  return (x * x + y * y) + z * z;
-}
-
-template <int FORM>
-__device__ __forceinline__ float pair_dist(float qx, float qy, float qz, float rq, float px, float py, float pz, float rp) {
-  if (FORM == 0) return sqdist3(qx, qy, qz, px, py, pz);
-  const float zz = dot3_fma(qx, qy, qz, px, py, pz);
-  if (FORM == 1) return fmaf(-2.0f, zz, rq + rp);  // 2*zz is exact, so this is (rq + rp) - 2*zz rounded once
-  if (FORM == 3) return fmaf(-2.0f, zz, rq) + rp;  // ((-2*zz) + rq) + rp
-  return fmaf(-2.0f, zz, rp) + rq;                 // (rp + (-2*zz)) + rq
-}
-
-// Order-preserving key for non-negative floats (and +inf): the raw bit pattern.
-__device__ __forceinline__ uint32_t fbits(float v) { return __float_as_uint(v); }
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);

@@ -126,14 +126,7 @@ __global__ __launch_bounds__(256) void fps(const float *__restrict__ xyz, const 
 // Tried and dropped: the candidates' coordinates out of the holder lane's registers (v_readlane under a scalar branch tree on
 // u) posted beside the key, to save the LDS read of the winner's coordinates -- the branch tree and the five reads after the
 // barrier cost more than the trip (N = 1024: 0.56 us per step against 0.36).
-// the smallest float x with sqrt_rn(x) == s (s > 0 finite, the correctly rounded sqrt of some float)
-__device__ __forceinline__ float sqrt_preimage_floor(float s) {
-  const float sp = __uint_as_float(__float_as_uint(s) - 1u);
-  const double mid = ((double)s + (double)sp) * 0.5;
-  const double m2 = mid * mid;
-  const float t = (float)m2;
-  return (double)t < m2 ? __uint_as_float(__float_as_uint(t) + 1u) : t;
-}
+// (sqrt_preimage_floor, the exact tie threshold of PCT's sampler: csrc/arith.hpp)
 
 // NW = waves per cloud.  A wave alone on its SIMD issues one instruction (of any kind) every 4-5 cycles at best and waits out
 // every dependency itself; two waves per SIMD (NW = 8) interleave, and each carries half of the points.

@@ -1,0 +1,122 @@
+"""The arithmetic of the bit-exact kernels, from the kernels' OWN SOURCE, on the CPU.
+
+hit_adv_amd/csrc/arith.hpp holds the four squared-distance forms, PCT's distance, the exact tie threshold of PCT's sampler and the
+three-piece bf16 split as plain C++; common.hpp includes it for gfx950, and tests/native/arith_host.cpp includes the same file for the
+host.  Here that host build (g++ -O2 -ffp-contract=off, the library's own contraction setting) is compared BIT FOR BIT with the C oracle
+(oracle/pointnet2_oracle.c::pair_value -- independent code, itself pinned against torch's own arithmetic in tests/test_oracle_gram.py and
+against the reference's fixtures) on Gaussian, surface-like, near-duplicate, tiny, huge and exactly tied inputs, and with exact integer /
+float64 arithmetic where there is no oracle.  The chain `reference = torch = oracle = kernel source` is thereby closed without a GPU;
+what the -m gpu tests add is that the hardware's add / mul / fma / sqrt round as IEEE says.  (Unlike docs/models/, nothing here is a
+re-description: edit arith.hpp and this test sees it.)"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GXX = shutil.which("g++")
+pytestmark = pytest.mark.skipif(GXX is None, reason="no g++")
+
+
+@pytest.fixture(scope="module")
+def H(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("arith") / "libarith_host.so")
+    flags = ["-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "hit_adv_amd", "csrc")]
+    if "fma" in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split():
+        flags.append("-mfma")  # fmaf() as one instruction; without it glibc's correctly rounded fmaf: the same bits, slower
+    subprocess.check_call([GXX] + flags + [os.path.join(ROOT, "tests", "native", "arith_host.cpp"), "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.arith_pairwise.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_long] + [ctypes.c_void_p] * 3
+    return lib
+
+
+def _clouds(seed):
+    g = torch.Generator().manual_seed(seed)
+    gauss = torch.randn(300, 3, generator=g)
+    gauss = (gauss - gauss.mean(0)) / gauss.norm(dim=1).max()
+    sphere = torch.randn(300, 3, generator=g)
+    sphere = sphere / sphere.norm(dim=1, keepdim=True) + 0.01 * torch.randn(300, 3, generator=g)
+    near = gauss.clone()
+    near[::2] = torch.nextafter(near[::2], torch.full_like(near[::2], 2.0))      # neighbours one ulp apart
+    lattice = torch.randint(-3, 4, (300, 3), generator=g).float() * 0.25        # exact ties, exact zeros
+    tiny = gauss * 1e-19                                                          # squares underflow into the subnormals
+    huge = gauss * 3e18                                                           # squares near the top of the range (no overflow)
+    mixed = torch.cat([gauss[:100], tiny[:100], lattice[:100]])
+    return dict(gauss=gauss, sphere=sphere, near=near, lattice=lattice, tiny=tiny, huge=huge, mixed=mixed)
+
+
+@pytest.mark.parametrize("form", [0, 1, 2, 3, 4])
+def test_kernel_source_distance_forms_equal_the_oracle_bit_for_bit(H, form):
+    """include/hitadv.h HITADV_FORM_DIRECT / GRAM / GRAM_KNN / SQUARE_DISTANCE and PCT's get_dists: util/set_distance.py:15-32,
+    util/dist_utils.py:148-150, model/pointnet2_utils.py:19-41, util/other_utils.py:237-251 as the oracle restates them."""
+    sets = _clouds(5 + form)
+    checked = 0
+    for xa, x in sets.items():
+        for ya, y in sets.items():
+            if xa > ya:
+                continue
+            x, y = x.contiguous(), y.contiguous()
+            P = torch.empty(x.shape[0], y.shape[0])
+            assert H.arith_pairwise(form, x.shape[0], y.shape[0], x.data_ptr(), y.data_ptr(), P.data_ptr()) == 0
+            want = N.pairwise(x[None], y[None], form)[0]
+            same = P.view(torch.int32) == want.view(torch.int32)
+            both_nan = P.isnan() & want.isnan()
+            assert bool((same | both_nan).all()), (form, xa, ya, int((~(same | both_nan)).sum()))
+            checked += P.numel()
+    assert checked > 2_000_000
+
+
+def test_direct_form_is_symmetric_and_the_gram_form_is_not_assumed_to_be(H):
+    """K2 evaluates (query, reference) pairs in both directions with ONE function: forms 0 and 1 must give d(x, y) == d(y, x) bit for bit
+    (csrc/pairwise.hip::nn_min3: "forms 0 and 1 are symmetric in (query, reference)")."""
+    s = _clouds(11)
+    for form in (0, 1):
+        for x in (s['gauss'], s['near'], s['mixed']):
+            y = s['sphere']
+            A, B = torch.empty(300, 300), torch.empty(300, 300)
+            H.arith_pairwise(form, 300, 300, x.data_ptr(), y.data_ptr(), A.data_ptr())
+            H.arith_pairwise(form, 300, 300, y.data_ptr(), x.data_ptr(), B.data_ptr())
+            assert torch.equal(A.view(torch.int32), B.t().contiguous().view(torch.int32)), form
+
+
+def test_three_piece_split_is_exact_and_bf16_representable(H):
+    """csrc/victim_bf3.hip / knn.hip: a = hi + mid + lo EXACTLY, each piece a bf16 number (its low 16 bits zero), for every finite float
+    whose third piece does not underflow -- the premise of "three bf16 pieces = fp32 accuracy" (six exact products per term)."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.cat([torch.randn(200_000, generator=g), torch.randn(100_000, generator=g) * 1e-12, torch.randn(100_000, generator=g) * 1e12,
+                   torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, 3.4e38, -3.4e38, 1.17549435e-38])]).contiguous()
+    n = a.numel()
+    hi, mid, lo = (torch.empty(n, dtype=torch.int32) for _ in range(3))
+    pk = torch.empty(n // 2, dtype=torch.int32)
+    H.arith_split3(ctypes.c_long(n), ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(hi.data_ptr()), ctypes.c_void_p(mid.data_ptr()),
+                   ctypes.c_void_p(lo.data_ptr()), ctypes.c_void_p(pk.data_ptr()))
+    for piece in (hi, mid, lo):
+        assert int((piece & 0xffff).abs().max()) == 0
+    total = hi.view(torch.float32).double() + mid.view(torch.float32).double() + lo.view(torch.float32).double()
+    assert torch.equal(total, a.double())
+    h = hi.view(torch.float32)
+    assert bool((h.abs() <= a.abs()).all()) and bool(((a - h).abs() <= a.abs() * 2.0 ** -7).all())  # truncation, 8 significant bits kept
+    want = ((hi[0:n - 1:2].long() & 0xffffffff) >> 16) | (hi[1:n:2].long() & 0xffff0000)
+    assert torch.equal(pk.long() & 0xffffffff, want)
+
+
+def test_pct_tie_threshold_is_the_smallest_float_whose_sqrt_rounds_to_s(H):
+    """csrc/arith.hpp::sqrt_preimage_floor (fps_lean's PCT sampler keeps the running distance SQUARED and takes one sqrt per wave and step;
+    util/other_utils.py:254-272 compares the ROUNDED square roots): for s = sqrt_rn(x) > 0 the threshold t satisfies sqrt_rn(t) == s and
+    sqrt_rn(pred(t)) < s.  numpy's float32 sqrt is correctly rounded."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.random(400_000, dtype=np.float32) * 4, (rng.random(100_000, dtype=np.float32) * 1e-6).astype(np.float32),
+                        np.float32([1e-7, 1.0, 4.0, 2.0, 1e10, 3.0])])
+    s = np.sqrt(x).astype(np.float32)
+    s = np.ascontiguousarray(s[s > 0])
+    out = np.empty_like(s)
+    H.arith_sqrt_preimage_floor(ctypes.c_long(s.size), ctypes.c_void_p(s.ctypes.data), ctypes.c_void_p(out.ctypes.data))
+    assert (np.sqrt(out).astype(np.float32) == s).all()
+    below = np.nextafter(out, np.float32(0), dtype=np.float32)
+    assert (np.sqrt(below).astype(np.float32) < s).all()
