@@ -1,5 +1,5 @@
 // The ARITHMETIC the bit-exact kernels are made of -- the four squared-distance forms, PCT's distance and its exact tie threshold, the
-// three-piece bf16 split -- as plain C++ with no GPU construct in it, so that the SAME SOURCE TEXT compiles for gfx950 (through
+// three-piece bf16 split, the two-piece fp16 split -- as plain C++ with no GPU construct in it, so that the SAME SOURCE TEXT compiles for gfx950 (through
 // common.hpp) and for the host: tests/test_arith_host.py builds tests/native/arith_host.cpp with g++ -ffp-contract=off and compares every
 // function here, bit for bit, with the C oracle (oracle/pointnet2_oracle.c::pair_value, itself pinned against torch in
 // tests/test_oracle_gram.py) and with exact float64 / integer arithmetic.  What the GPU adds to that chain is the hardware's IEEE add / mul /
@@ -91,5 +91,16 @@ HITADV_HD float sqrt_preimage_floor(float s) {
   const float t = (float)m2;
   return (double)t < m2 ? __uint_as_float(__float_as_uint(t) + 1u) : t;
 }
+
+#if defined(__HIPCC__) || defined(__HIP__) || defined(__clang__)  // (_Float16: hipcc, and clang++ on the host; g++ 11 has no such type)
+// An fp32 value as TWO fp16 pieces, a = hi + 2^-11 lo + r (csrc/victim_bf3.hip's header has the error analysis): hi = fp16(a) to nearest,
+// lo = fp16(2^11 (a - hi)).  Written as ONE fused multiply-add on the converted-back hi piece: 2048 v is exact, hi (-2048) + 2048 v =
+// 2048 (v - hi) is exact before its single rounding to fp16 -- the same bits as converting hi back, subtracting, scaling and converting.
+constexpr float F16X2_PIECE_SCALE = 2048.f;  // 2^11
+HITADV_HD void split_pair(float v, _Float16 &hi, _Float16 &lo) {
+  hi = (_Float16)v;
+  lo = (_Float16)__builtin_fmaf((float)hi, -F16X2_PIECE_SCALE, v * F16X2_PIECE_SCALE);
+}
+#endif
 
 }  // namespace hitadv

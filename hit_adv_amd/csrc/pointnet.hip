@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void rowmlp_fwd_k(RowMlpFwd a) {
 // from LDS tiles of fp16 pieces (row strides 144 / 272 bytes: conflict-free ds_read_b128 for lane -> (row r, half h)),
 // the B operand is split in registers once per block.
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-constexpr float PM_SC = 2048.f;   // 2^11
+constexpr float PM_SC = F16X2_PIECE_SCALE;   // 2^11 (csrc/arith.hpp)
 constexpr int PM_LH64 = 144;      // bytes per row of a 64-wide fp16 piece tile
 constexpr int PM_LH128 = 272;
 
@@ -269,10 +269,7 @@ constexpr int PM_LH128 = 272;
 // exact, hi (-2048) + 2048 v = 2048 (v - hi) is exact before its single rounding to fp16 -- the same bits as converting hi
 // back, subtracting, scaling and converting (five instructions per value; the splits were a quarter of the backward kernels'
 // vector instructions).
-__device__ __forceinline__ void split_pair(float v, _Float16 &hi, _Float16 &lo) {
-  hi = (_Float16)v;
-  lo = (_Float16)__builtin_fmaf((float)hi, -PM_SC, v * PM_SC);
-}
+// (split_pair itself: csrc/arith.hpp -- plain C++, also compiled for the host by tests/test_arith_host.py)
 // eight values: the hi pieces two per v_cvt_pk_f16_f32, the lo pieces written into the halves of their words by
 // v_fma_mixlo / mixhi reading the packed hi pieces in place (2.5 instructions per value; the compiler's own form converts every
 // hi piece twice, once alone for the residual and once packed)

@@ -48,7 +48,8 @@ constexpr int B3_TM = 64;
 //   a = a1 + 2^-11 a2 + ra,  a1 = fp16(a) (round to nearest: |a - a1| <= 2^-12 |a|, and a - a1 is exact in fp32),
 //   a2 = fp16(2^11 (a - a1)) (the residual scaled back into fp16's normal range), |ra| <= 2^-24 |a| for most a
 //   (each rounding is half an ulp of an 11-bit significand: 2^-12 of its operand in the mean, 2^-11 at a binade's lower edge, so the
-//   bound proper is 2^-22 |a|; measured over 2 M values: 2^-23.0.  docs/models/test_kernel_idioms_model.py),
+//   bound proper is 2^-22 |a| for 2^-14 <= |a| < 65520 -- below fp16's normal range the pieces' own subnormal spacing takes over: |ra| <= 2^-36
+//   absolute --; root mean square 2^-24.4, 99.9th percentile 2^-22.5: tests/test_arith_host.py, on the host build of csrc/arith.hpp::split_pair),
 // so  a.b = a1.b1 + 2^-11 (a1.b2 + a2.b1) + [a2.b2 2^-22 + ra.b + a.rb: each <= 2^-24 |a.b|, fp32's own unit roundoff]:
 // THREE fp16 MFMAs (every fp16 x fp16 product is exact in fp32) into two fp32 accumulator sets (one per power of two),
 // joined once per tile -- half the matrix time of the six-product bf16 form.  fp16 tops out at 65504: an operand beyond

@@ -120,3 +120,48 @@ def test_pct_tie_threshold_is_the_smallest_float_whose_sqrt_rounds_to_s(H):
     assert (np.sqrt(out).astype(np.float32) == s).all()
     below = np.nextafter(out, np.float32(0), dtype=np.float32)
     assert (np.sqrt(below).astype(np.float32) < s).all()
+
+
+CLANGXX = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.mark.skipif(not os.path.exists(CLANGXX), reason="no host clang++ with _Float16")
+def test_two_piece_fp16_split_is_what_the_kernels_headers_say(tmp_path):
+    """csrc/arith.hpp::split_pair -- the split behind every fp16x2 product of the PointNet engine (csrc/victim_bf3.hip's header):
+    a = hi + 2^-11 lo + r with hi = fp16(a), lo = fp16(2^11 (a - hi)).  From the real source, on the host: (1) the fused form is the
+    spelled-out form's bits (the claim next to the function; victim_bf3.hip's staging and split_weights_k spell it out), for every input
+    incl. fp16's subnormal range and beyond its top; (2) |r| <= 2^-22 |a| wherever |a| is inside fp16's NORMAL range (2^-14 <= |a| < 65520), about 2^-24.4 |a| in the
+    root mean square and <= 2^-22.5 |a| at the 99.9th percentile; (3) hi is an infinity exactly from |a| >= 65520 on -- the premise of the range
+    flag; (4) a product of two split values, a1 b1 + 2^-11 (a1 b2 + a2 b1), is within 3 x 2^-22 of a b."""
+    so = str(tmp_path / "libarith_f16.so")
+    subprocess.check_call([CLANGXX, "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
+                           "-I" + os.path.join(ROOT, "hit_adv_amd", "csrc"), os.path.join(ROOT, "tests", "native", "arith_f16_host.cpp"), "-o", so])
+    lib = ctypes.CDLL(so)
+    rng = np.random.default_rng(1)
+    a = np.concatenate([rng.standard_normal(1_000_000).astype(np.float32),
+                        (rng.standard_normal(300_000) * 100).astype(np.float32),
+                        (rng.standard_normal(300_000) * 1e-3).astype(np.float32),
+                        (rng.standard_normal(200_000) * 1e-6).astype(np.float32),      # hi in fp16's subnormal range
+                        (rng.random(200_000) * 7e4).astype(np.float32),                # up to and beyond fp16's top
+                        np.float32([0.0, -0.0, 65504.0, 65519.99, 65520.0, -65520.0, 1e30, 6.1035156e-05, 5.96e-08, 2.9e-08])])
+    a = np.ascontiguousarray(a)
+    n = a.size
+    hi, lo, lo2 = (np.empty(n, np.uint16) for _ in range(3))
+    lib.arith_split_pair(ctypes.c_long(n), *(ctypes.c_void_p(t.ctypes.data) for t in (a, hi, lo, lo2)))
+    h, l = hi.view(np.float16), lo.view(np.float16)
+    finite = np.isfinite(h)
+    assert (lo[finite] == lo2[finite]).all()                                   # (1) the same bits, fused or spelled out
+    assert (np.isinf(h) == (np.abs(a) >= 65520.0)).all()                       # (3)
+    normal = finite & (np.abs(a.astype(np.float64)) >= 2.0 ** -14) & np.isfinite(l)  # |a| inside fp16's NORMAL range: below it lo's own subnormal spacing bounds r
+    with np.errstate(invalid='ignore'):  # (inf - inf where hi overflowed: outside `normal`)
+        r = np.abs(a.astype(np.float64) - (h.astype(np.float64) + l.astype(np.float64) / 2048.0))
+    rel = r[normal] / np.abs(a[normal].astype(np.float64))
+    assert rel.max() <= 2.0 ** -22 and np.quantile(rel, 0.999) <= 2.0 ** -22.5   # (2)
+    assert 2.0 ** -25.5 <= np.sqrt((rel ** 2).mean()) <= 2.0 ** -23.5
+    k = 500_000                                                                 # (4) products of the first million (all normal here)
+    x, y = slice(0, k), slice(k, 2 * k)
+    ok = normal[x] & normal[y]
+    ab = a[x].astype(np.float64) * a[y].astype(np.float64)
+    h64, l64 = h.astype(np.float64), l.astype(np.float64)
+    approx = h64[x] * h64[y] + (h64[x] * l64[y] + l64[x] * h64[y]) / 2048.0
+    assert (np.abs(approx - ab)[ok] <= 3 * 2.0 ** -22 * np.abs(ab)[ok]).all()
