@@ -25,6 +25,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.hitadv_deform_bwd_scratch_floats(32, 1024, 192) == 32 * 16 * 4 * 192
 
 
+def test_v1_launch_geometry_of_the_bench_shapes():
+    """Host logic, no GPU: which form of the 128 -> 1024 layer + max a shape selects is a function of (B, N, Cout, blocks) that the
+    scratch query exposes (S = point splits per cloud; csrc/victim_bf3.hip::bf3_split).  The stacked loop of the bench (stacks of 6-8
+    attacks = 192-256 clouds on 128 workgroups, `HITADV_V1_BLOCKS_IN_FLIGHT`) must select S = 1 -- the FLAT kernel, the one the roofline
+    notes, the ISA guards and HITADV_V1_DEFER are about; one attack alone (32 clouds on 256 workgroups) takes two splits per cloud."""
+    from hit_adv_amd import _lib
+    f = _lib.load().hitadv_linear_max_fwd_bf16x3_scratch
+    splits = lambda B, N, blocks: f(B, N, 1024, blocks) // (B * 1024)  # noqa: E731
+    for B in (192, 224, 256):
+        assert splits(B, 1024, 128) == 1 and splits(B, 1024, 0) == 1
+    assert splits(32, 1024, 0) == 2 and splits(32, 1024, 128) == 1
+    assert splits(64, 2048, 0) == 1 and splits(13, 1280, 8) == 1
+    assert splits(1, 1024, 0) == 16 and splits(1, 64, 0) == 1          # never more splits than 64-point tiles
+    assert f(32, 1024, 1024, 7) == 0 and f(32, 1024, 1024, 300) == 0     # blocks outside 8..256: refused
+
+
 def test_invalid_arguments_return_error_codes_not_crashes():
     from hit_adv_amd import _lib
     lib = _lib.load()
