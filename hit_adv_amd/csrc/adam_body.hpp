@@ -57,18 +57,12 @@ __device__ __forceinline__ void adam_partials_body(const AdamArgs &a, const int 
 #pragma unroll
       for (int c = 0; c < 4; ++c) g[c] += s0 + s < nslab ? q[s][c] : 0.f;
   }
-  const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
-  const double bc1 = 1.0 - pow(beta1, (double)t);
-  const double bc2 = 1.0 - pow(beta2, (double)t);
-  const float bc2_sqrt = (float)sqrt(bc2);
   auto upd = [&](float *p, float *m, float *v, size_t i, int c, float gi, double lr, float lo, float hi) {
-    const float step_size = (float)(lr / bc1);
-    const float mi = m0[c] + (gi - m0[c]) * (float)(1.0 - beta1);
-    const float vi = v0[c] * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
+    const AdamCoef k = adam_coef(t, lr);  // csrc/arith.hpp: torch.optim.Adam's step, operation for operation
+    float mi = m0[c], vi = v0[c];
+    float q = adam_update(p0[c], gi, mi, vi, k);
     m[i] = mi;
     v[i] = vi;
-    const float denom = __builtin_sqrtf(vi) / bc2_sqrt + (float)eps;
-    float q = p0[c] - (step_size * mi) / denom;
     if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);
     p[i] = q;
   };

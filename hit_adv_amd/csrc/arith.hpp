@@ -92,6 +92,35 @@ HITADV_HD float sqrt_preimage_floor(float s) {
   return (double)t < m2 ? __uint_as_float(__float_as_uint(t) + 1u) : t;
 }
 
+// torch.optim.Adam's single-tensor step (torch/optim/adam.py::_single_tensor_adam, the CPU path the reference's optimiser takes:
+// ShapeAttack/HiT_ADV.py:139-145, CW/*.py), operation for operation in fp32 with the bias corrections in double as Python computes them:
+//   exp_avg.lerp_(grad, 1 - beta1)            m + (g - m) * (1 - beta1)
+//   exp_avg_sq.mul_(beta2).addcmul_(g, g, value = 1 - beta2)      v * beta2 + ((1 - beta2) * g) * g
+//   denom = exp_avg_sq.sqrt() / sqrt(bias_correction2) + eps;  param.addcdiv_(exp_avg, denom, value = -lr / bias_correction1)
+// betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad.  tests/test_arith_host.py steps this source beside torch.optim.Adam.
+struct AdamCoef {
+  float step_size, bc2_sqrt;
+};
+HITADV_HD AdamCoef adam_coef(int t, double lr) {  // t = the 1-based step number
+  const double beta1 = 0.9, beta2 = 0.999;
+  const double bc1 = 1.0 - pow(beta1, (double)t);
+  const double bc2 = 1.0 - pow(beta2, (double)t);
+  AdamCoef k;
+  k.step_size = (float)(lr / bc1);
+  k.bc2_sqrt = (float)sqrt(bc2);
+  return k;
+}
+// one coordinate: moments updated in place, the new parameter value returned (the caller projects and stores it)
+HITADV_HD float adam_update(float p, float gi, float &m, float &v, const AdamCoef &k) {
+  const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
+  const float mi = m + (gi - m) * (float)(1.0 - beta1);
+  const float vi = v * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
+  m = mi;
+  v = vi;
+  const float denom = __builtin_sqrtf(vi) / k.bc2_sqrt + (float)eps;
+  return p - (k.step_size * mi) / denom;
+}
+
 #if defined(__HIPCC__) || defined(__HIP__) || defined(__clang__)  // (_Float16: hipcc, and clang++ on the host; g++ 11 has no such type)
 // An fp32 value as TWO fp16 pieces, a = hi + 2^-11 lo + r (csrc/victim_bf3.hip's header has the error analysis): hi = fp16(a) to nearest,
 // lo = fp16(2^11 (a - hi)).  Written as ONE fused multiply-add on the converted-back hi piece: 2048 v is exact, hi (-2048) + 2048 v =

@@ -91,19 +91,12 @@ __global__ __launch_bounds__(256) void adam_k(float *__restrict__ p0, const floa
   float *m = second ? m1 : m0;
   float *v = second ? v1 : v0;
   const double lr = second ? (double)lr1 : (double)lr0;
-  const int t = *step + 1;
-  const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
-  const double bc1 = 1.0 - pow(beta1, (double)t);
-  const double bc2 = 1.0 - pow(beta2, (double)t);
-  const float step_size = (float)(lr / bc1);
-  const float bc2_sqrt = (float)sqrt(bc2);
-  const float gi = g[i];
-  const float mi = m[i] + (gi - m[i]) * (float)(1.0 - beta1);
-  const float vi = v[i] * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
+  const AdamCoef k = adam_coef(*step + 1, lr);  // csrc/arith.hpp: torch.optim.Adam's step, operation for operation
+  float mi = m[i], vi = v[i];
+  const float q = adam_update(p[i], g[i], mi, vi, k);
   m[i] = mi;
   v[i] = vi;
-  const float denom = __builtin_sqrtf(vi) / bc2_sqrt + (float)eps;
-  p[i] = p[i] - (step_size * mi) / denom;
+  p[i] = q;
 }
 
 __global__ void bump_k(int32_t *c) { *c += 1; }
@@ -130,19 +123,12 @@ __global__ __launch_bounds__(256) void adam2_k(float *__restrict__ p0, const flo
   float *v = second ? v1 : v0;
   const double lr = second ? (double)lr1 : (double)lr0;
   const float lo = second ? lo1 : lo0, hi = second ? hi1 : hi0;
-  const int t = *step;
-  const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
-  const double bc1 = 1.0 - pow(beta1, (double)t);
-  const double bc2 = 1.0 - pow(beta2, (double)t);
-  const float step_size = (float)(lr / bc1);
-  const float bc2_sqrt = (float)sqrt(bc2);
+  const AdamCoef k = adam_coef(*step, lr);
   const float gi = hh ? g[i] + hh[i] : g[i];
-  const float mi = m[i] + (gi - m[i]) * (float)(1.0 - beta1);
-  const float vi = v[i] * (float)beta2 + ((float)(1.0 - beta2) * gi) * gi;
+  float mi = m[i], vi = v[i];
+  float q = adam_update(p[i], gi, mi, vi, k);
   m[i] = mi;
   v[i] = vi;
-  const float denom = __builtin_sqrtf(vi) / bc2_sqrt + (float)eps;
-  float q = p[i] - (step_size * mi) / denom;
   if (lo <= hi) q = q < lo ? lo : (q > hi ? hi : q);
   p[i] = q;
 }

@@ -47,6 +47,12 @@ void arith_sqrt_preimage_floor(long n, const float *s, float *out) {
   for (long i = 0; i < n; ++i) out[i] = sqrt_preimage_floor(s[i]);
 }
 
+// one torch.optim.Adam step (t = 1-based step number) on n coordinates, in place, by the kernels' own adam_coef / adam_update
+void arith_adam_step(long n, int t, double lr, float *p, const float *g, float *m, float *v) {
+  const AdamCoef k = adam_coef(t, lr);
+  for (long i = 0; i < n; ++i) p[i] = adam_update(p[i], g[i], m[i], v[i], k);
+}
+
 void arith_fbits(long n, const float *v, uint32_t *out) {
   for (long i = 0; i < n; ++i) out[i] = fbits(v[i]);
 }

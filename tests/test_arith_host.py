@@ -122,6 +122,42 @@ def test_pct_tie_threshold_is_the_smallest_float_whose_sqrt_rounds_to_s(H):
     assert (np.sqrt(below).astype(np.float32) < s).all()
 
 
+
+def test_kernel_source_adam_follows_torch_optim_adam(H):
+    """csrc/arith.hpp::adam_coef / adam_update -- the one Adam step behind adam_k, adam2_k and the deformation's Adam tail -- stepped
+    beside torch.optim.Adam (the optimiser the reference builds at HiT_ADV.py:139-145 with lr = 5 x and 3 x attack_lr; CW/*.py: lr =
+    attack_lr) for 600 steps (> the headline's num_iter) on the same gradients.  NOT bit for bit, and it cannot be: torch's CPU kernels
+    fuse lerp's multiply-add (at::vec::fmadd; round 6 measured 2 of 4,096 parameters one ulp apart after the FIRST step and a quarter
+    of the first moments after the second), the kernels round each operation as written -- that one-ulp freedom per step is where the
+    measured "Adam drift" of tests/test_gpu_headline_parity.py starts.  What is held: for ordinary and for huge gradients the second
+    moment stays within 4 ulps of torch's and the first within 1e-6 of the gradient scale at every checked step and the parameters within 2e-6 after 600 steps (a wrong bias correction, eps
+    inside the square root or a missing 1 / bias_correction1 is off by orders of magnitude more); for exactly zero gradients everything
+    is exactly torch's (nothing moves)."""
+    H.arith_adam_step.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_double] + [ctypes.c_void_p] * 4
+    g = torch.Generator().manual_seed(17)
+    n = 3072
+    ulps = lambda a, b: (a.view(torch.int32).long() - b.view(torch.int32).long()).abs()  # noqa: E731  (same-sign neighbours)
+    for lr in (0.05, 0.03, 0.01):
+        p_t = torch.randn(n, generator=g).requires_grad_()
+        opt = torch.optim.Adam([p_t], lr=lr, weight_decay=0.)
+        p = p_t.detach().clone().contiguous()
+        m, v = torch.zeros(n), torch.zeros(n)
+        scale = torch.cat([torch.ones(n // 3), torch.zeros(n // 3), torch.full((n // 3,), 1e6)])
+        live = scale != 0
+        for t in range(1, 601):
+            grad = (torch.randn(n, generator=g) * scale).contiguous()
+            p_t.grad = grad.clone()
+            opt.step()
+            H.arith_adam_step(n, t, lr, p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr())
+            st = opt.state[p_t]
+            if t <= 20 or t % 50 == 0 or t == 600:
+                assert int(ulps(v, st['exp_avg_sq']).max()) <= 4, (lr, t)
+                dm = (m - st['exp_avg']).abs()  # one rounding of (g - m) * 0.1 more or less: an error at the GRADIENT's scale, not at |m|'s
+                assert bool((dm <= 1e-6 * scale).all()), (lr, t, float((dm / scale.clamp_min(1e-30)).max()))
+                assert torch.equal(p[~live], p_t.detach()[~live]) and torch.equal(m[~live], st['exp_avg'][~live])
+        assert float((p - p_t.detach())[live].abs().max()) <= 2e-6 * max(1.0, float(p_t.detach().abs().max())), lr
+
+
 CLANGXX = "/opt/rocm/lib/llvm/bin/clang++"
 
 
