@@ -127,8 +127,9 @@ def test_kernel_source_adam_follows_torch_optim_adam(H):
     """csrc/arith.hpp::adam_coef / adam_update -- the one Adam step behind adam_k, adam2_k and the deformation's Adam tail -- stepped
     beside torch.optim.Adam (the optimiser the reference builds at HiT_ADV.py:139-145 with lr = 5 x and 3 x attack_lr; CW/*.py: lr =
     attack_lr) for 600 steps (> the headline's num_iter) on the same gradients.  NOT bit for bit, and it cannot be: torch's CPU kernels
-    fuse lerp's multiply-add (at::vec::fmadd; round 6 measured 2 of 4,096 parameters one ulp apart after the FIRST step and a quarter
-    of the first moments after the second), the kernels round each operation as written -- that one-ulp freedom per step is where the
+    fuse the multiply-adds of lerp and addcmul (round 6 matched torch 2.10's moments bit for bit with m = fma(0.1, g - m, m) and v =
+    fma(0.001 g, g, 0.999 v); unfused, 2 of 4,096 parameters are one ulp apart after the FIRST step and a quarter of the first moments
+    after the second), the kernels round each operation as written -- that one-ulp freedom per step is where the
     measured "Adam drift" of tests/test_gpu_headline_parity.py starts.  What is held: for ordinary and for huge gradients the second
     moment stays within 4 ulps of torch's and the first within 1e-6 of the gradient scale at every checked step and the parameters within 2e-6 after 600 steps (a wrong bias correction, eps
     inside the square root or a missing 1 / bias_correction1 is off by orders of magnitude more); for exactly zero gradients everything
