@@ -7,6 +7,8 @@ export TMPDIR=/tmp
 timeout 300 /tmp/pk_f32_probe > gpurun_out/r06/pk_f32_probe.txt 2>&1; echo "pk probe rc=$?" >> gpurun_out/r06/pk_f32_probe.txt
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/tune/lds_return_probe.hip -o /tmp/lds_return_probe 2>&1 | tail -3
 timeout 300 /tmp/lds_return_probe > gpurun_out/r06/lds_return_probe.txt 2>&1; echo "lds probe rc=$?" >> gpurun_out/r06/lds_return_probe.txt
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/tune/fps_seq_probe.hip -o /tmp/fps_seq_probe 2>&1 | tail -3
+timeout 300 /tmp/fps_seq_probe > gpurun_out/r06/fps_seq_probe.txt 2>&1; echo "seq probe rc=$?" >> gpurun_out/r06/fps_seq_probe.txt
 
 timeout 1500 bash tools/fps_packed_repro.sh > gpurun_out/r06/fps_packed_repro.txt 2>&1; echo "repro rc=$?" >> gpurun_out/r06/fps_packed_repro.txt
 
