@@ -634,6 +634,16 @@ def reduce_over_ranks(elapsed_s, succeeded, attacked, dev, world, collectives):
     return elapsed.item(), counters[0].item(), counters[1].item()
 
 
+def kernel_knobs():
+    """Which of the library's either-way kernels this process runs (results never depend on them): so that an A/B line says which side it is."""
+    try:
+        from hit_adv_amd import _lib
+        lib = _lib.load()
+        return {"fps_form": int(lib.hitadv_debug_fps_form(-1)), "v1_deferred_search": int(lib.hitadv_debug_v1_defer(-1))}
+    except (OSError, AttributeError, RuntimeError):  # (the mock-CPU self-test of the launcher runs without the library)
+        return {}
+
+
 def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_step, in_flight, info, collectives,
              matrix_mode=None, host=None, backend="nccl (RCCL)"):
     """The fields every configuration's line carries (throughput is whole-job: clouds of all ranks / max-over-ranks time)."""
@@ -651,7 +661,7 @@ def headline(cfg, steps, warmup, world, elapsed, succeeded, attacked, iters_per_
                    **({"matrix_mode": matrix_mode} if matrix_mode else {}), **(host or {}),
                    "parallelism": "independent batch shards, 1 process per GPU",
                    "attacks_in_flight_per_gpu": in_flight,
-                   "hip_hardware_queues": HW_QUEUES, **info},
+                   "hip_hardware_queues": HW_QUEUES, "kernel_knobs": kernel_knobs(), **info},
         "cloud_iterations_per_s": clouds * iters_per_step / elapsed,
         "attack_success": {"succeeded": succeeded, "attacked": attacked},
         # what RCCL saw: the calls each rank made in this run (all zero in a single-process run)
