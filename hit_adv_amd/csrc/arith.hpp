@@ -7,7 +7,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__HIP__)
+#if defined(__HIPCC__) || defined(__HIP__) || defined(HITADV_EMULATED)  // (HITADV_EMULATED: the CPU wave emulator of tests/native/emu, which supplies the HIP vocabulary itself)
 #define HITADV_HD __device__ __forceinline__
 #else  // host build (tests only)
 #include <cmath>

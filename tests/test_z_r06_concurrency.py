@@ -12,6 +12,8 @@ result that is another launch's result counts as a mismatch.
 STATUS: written in round 6, which had no GPU access (gpurun refused every call: docs/kernels/round6.md section 1) -- this file has NOT
 RUN ON HARDWARE YET.  It sorts last on purpose: the driver runs `pytest -x`, and a fault in a test that has never seen the GPU must not
 hide the suite that has."""
+import os
+
 import pytest
 import torch
 
@@ -19,7 +21,10 @@ from oracle import c_oracle as N
 
 pytestmark = pytest.mark.gpu
 
-LAUNCHES = 1008  # per kernel; a multiple of 3 streams x 8 inputs
+# (the two knobs exist for the CPU wave emulator -- tests/native/emu_plugin.py --, where "beside other streams" means nothing and a launch
+# takes a second: it runs this file with 24 launches and no noise to check the TEST's own logic: shapes, dtypes, the oracle calls)
+LAUNCHES = int(os.environ.get("HITADV_CONCURRENCY_LAUNCHES", "1008"))  # per kernel; a multiple of 3 streams x 8 inputs
+NOISE = os.environ.get("HITADV_CONCURRENCY_NOISE", "1") != "0"
 INPUTS = 8
 
 
@@ -60,6 +65,8 @@ class Noise:
         torch.cuda.synchronize()
 
     def pump(self):
+        if not NOISE:
+            return
         with torch.cuda.stream(self.s_gemm):
             torch.mm(self.a, self.b, out=self.c)
         with torch.cuda.stream(self.s_lds):
