@@ -113,6 +113,27 @@ inline const uint64_t *wave_gather(uint64_t v, uint64_t *active) {
   if (active) *active = w.snapmask[g & 1];
   return w.snap[g & 1];
 }
+// the same rendezvous for a payload of up to 32 bytes per lane (the operands of a matrix instruction); returns the 64 lanes' payloads
+struct WaveBulk { unsigned char slots[64][32], snap[2][64][32]; };
+inline std::vector<WaveBulk> *bulk_store = nullptr;
+inline const unsigned char (*wave_gather_bytes(const void *p, size_t n))[32] {
+  static std::vector<WaveBulk> store;
+  Wave &w = blk->waves[cur->lin >> 6];
+  const size_t wi = (size_t)(cur->lin >> 6);
+  if (store.size() <= wi) store.resize(wi + 1);
+  const int lane = cur->lin & 63;
+  memcpy(store[wi].slots[lane], p, n);
+  const unsigned g = w.gen;
+  w.slots[lane] = 0;
+  w.arrived |= 1ull << lane;
+  if (w.arrived == w.alive) {
+    memcpy(store[wi].snap[g & 1], store[wi].slots, sizeof(store[wi].slots));
+    wave_release(w);
+  }
+  while (w.gen == g) yield();
+  return store[wi].snap[g & 1];
+}
+
 inline void barrier() {
   const unsigned g = blk->barrier_gen;
   if (++blk->at_barrier == blk->alive) {
@@ -318,12 +339,41 @@ static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_barrier() { emu::barrier(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-// matrix instructions are NOT emulated (their internal summation order is the hardware's): kernels that use them compile and abort if run
+// v_mfma_f32_16x16x32_{f16,bf16}: D[16 x 16] = A[16 x 32] B[32 x 16] + C.  Lane l holds A[l % 16][8 (l / 16) .. + 7], B[8 (l / 16) .. + 7][l % 16]
+// and C / D[4 (l / 16) + i][l % 16], i = 0 .. 3 (the layout csrc/victim_bf3.hip's comments state).  Every product of two 16-bit values is
+// exact in fp32; they are added to C in ascending k, one fp32 rounding each -- A model: the hardware's internal order is its own, so
+// results are fp32-accurate, not the hardware's bits.  Equality tests BETWEEN kernels that issue the same instructions are unaffected.
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+static inline float emu_half_to_float(uint16_t h) { _Float16 v; memcpy(&v, &h, 2); return (float)v; }
+static inline float emu_bf16_to_float(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+template <bool BF16, class V8>
+static inline emu_f32x4 emu_mfma_16x16x32(V8 a, V8 b, emu_f32x4 c) {
+  unsigned char pay[32];
+  memcpy(pay, &a, 16);
+  memcpy(pay + 16, &b, 16);
+  const unsigned char (*s)[32] = emu::wave_gather_bytes(pay, 32);
+  const int lane = emu::cur->lin & 63, n = lane & 15, m0 = 4 * (lane >> 4);
+  emu_f32x4 d = c;
+  for (int i = 0; i < 4; ++i) {
+    float acc = c[i];
+    for (int k = 0; k < 32; ++k) {
+      uint16_t av, bv;
+      memcpy(&av, s[(m0 + i) + 16 * (k >> 3)] + 2 * (k & 7), 2);
+      memcpy(&bv, s[n + 16 * (k >> 3)] + 16 + 2 * (k & 7), 2);
+      const float x = BF16 ? emu_bf16_to_float(av) : emu_half_to_float(av), y = BF16 ? emu_bf16_to_float(bv) : emu_half_to_float(bv);
+      acc = acc + x * y;
+    }
+    d[i] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_16x16x32<false>((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32<true>((a), (b), (c))
+// the other matrix instructions are NOT emulated: kernels that use them compile and abort if run
 template <class A, class B, class C> static inline C emu_no_mfma(A, B, C c, int, int, int) { fprintf(stderr, "simt_emu: MFMA kernels are not emulated\n"); abort(); return c; }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_no_mfma
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu_no_mfma
-#define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu_no_mfma
-#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_no_mfma
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_no_mfma
 #define __builtin_amdgcn_perm(a, b, sel) emu_perm((a), (b), (sel))
 static inline uint32_t emu_perm(uint32_t a, uint32_t b, uint32_t sel) {  // v_perm_b32: bytes 0-3 of b, 4-7 of a
   const uint64_t both = ((uint64_t)a << 32) | b;

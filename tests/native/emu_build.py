@@ -5,6 +5,7 @@ The file's text is the product's; three constructs plain C++ cannot parse are re
   2. `extern __shared__ T name[];`                 ->  `T *name = reinterpret_cast<T *>(emu::dyn_lds);`
   2b. operand-less `asm volatile("s_waitcnt ..." ::: "memory")` (the hand-off protocols' waits; also in the staged copies of the headers)  ->  nothing
   3. fps_lean's one LDS atomic written as inline asm (`ds_max_rtn_u64` + its wait)  ->  the same operation in C++
+  4. victim_bf3.hip's two scan helpers (compares into lane masks / selects on them, asm for their schedule)  ->  __ballot and a select
 and the result is compiled by ROCm's clang++ FOR x86-64 (-ffp-contract=off, like the library) against the emulator header in place of
 <hip/hip_runtime.h>.  The extern "C" entry points keep their names and signatures; "device" pointers are host pointers."""
 import os
@@ -115,6 +116,17 @@ def stage_headers(out_dir):
                 f.write(text)
 
 
+V1_CMP = re.compile(r'asm volatile\("v_cmp_eq_f32_e64 %0, %2, %3\\n\\tv_cmp_eq_f32_e64 %1, %4, %5" : "=s"\(ma\), "=s"\(mb\) : "v"\(a\), "v"\(ta\), "v"\(b\), "v"\(tb\)\);')
+V1_SEL = re.compile(r'asm volatile\("v_cndmask_b32_e64 %0, %0, %4, %2\\n\\tv_cndmask_b32_e64 %1, %1, %4, %3" : "\+v"\(ca\), "\+v"\(cb\) : "s"\(ma\), "s"\(mb\), "n"\(Q\)\);')
+
+
+def rewrite_v1_scan_asm(text):
+    """csrc/victim_bf3.hip: two compares into SGPR pairs (= lane masks) / two selects on them, written as asm for their schedule"""
+    text, a = V1_CMP.subn("ma = __ballot(a == ta); mb = __ballot(b == tb);", text)
+    text, b = V1_SEL.subn("{ const int l__ = emu::cur->lin & 63; ca = (ma >> l__) & 1 ? Q : ca; cb = (mb >> l__) & 1 ? Q : cb; }", text)
+    return text, a + b
+
+
 def build(stem, out_dir, extra_flags=()):
     """-> path of lib<stem>_emu.so built from hit_adv_amd/csrc/<stem>.hip"""
     stage_headers(out_dir)
@@ -126,6 +138,9 @@ def build(stem, out_dir, extra_flags=()):
     if stem == "sampling":
         text, n_asm = rewrite_fps_asm(text)
         assert n_asm == 1, "fps_lean's LDS atomic was not found: the rewrite rule needs updating"
+    if stem == "victim_bf3":
+        text, n_asm = rewrite_v1_scan_asm(text)
+        assert n_asm == 2, "V1's compare / select asm helpers were not found: the rewrite rule needs updating"
     assert n_launch > 0 and "<<<" not in text and "extern __shared__" not in text
     src = os.path.join(out_dir, stem + "_emu.cpp")
     with open(src, "w") as f:

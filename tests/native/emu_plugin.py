@@ -4,6 +4,7 @@
 
 What it does, all of it test-side (the product is untouched and still refuses CPU tensors on its own):
   * builds hit_adv_amd/csrc/{pairwise,knn,sampling,grouping,deform,regulariser,attack_state,iteration}.hip for the emulator
+    -- and victim_bf3.hip, whose 16x16x32 matrix instructions are emulated with a summation order of the emulator's own --
     (tests/native/emu_build.py) and puts a dispatcher over those libraries where hit_adv_amd._lib keeps the loaded libhitadv_hip.so;
   * lets `ops._dev` / `_ext._chk` accept CPU tensors and hands the kernels a null stream;
   * maps what the tests say about devices onto the CPU: `.cuda()`, `.to('cuda')`, `device='cuda'` (a TorchFunctionMode), a few
@@ -20,7 +21,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests", "native"))
-STEMS = ["pairwise", "knn", "sampling", "grouping", "deform", "regulariser", "attack_state", "iteration"]
+STEMS = ["pairwise", "knn", "sampling", "grouping", "deform", "regulariser", "attack_state", "iteration", "victim_bf3"]
+os.environ["HITADV_EMULATE"] = "1"  # (tests may pick emulator-sized shapes: a matrix instruction costs milliseconds here)
 
 
 def pytest_addoption(parser):

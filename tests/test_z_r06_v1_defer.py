@@ -6,6 +6,8 @@ cloud that is all NaN, and every workgroup count that selects the flat kernel.  
 
 STATUS: written in round 6, which had no GPU access -- NOT RUN ON HARDWARE YET, which is exactly why the variant is off by default.  The
 file sorts last on purpose (`pytest -x`)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -37,7 +39,12 @@ def _packed(h):
     return ((hi.view(torch.int16).int() & 0xffff) | (lo.view(torch.int16).int() << 16)).contiguous().view(torch.float32)
 
 
-@pytest.mark.parametrize("B,Np,blocks", [(256, 1024, 128), (256, 1024, 256), (32, 1024, 16), (13, 1280, 8), (64, 128, 40), (8, 2048, 8)])
+# (under the CPU wave emulator -- tests/native/emu_plugin.py -- a matrix instruction costs milliseconds: the same test on small flat shapes)
+SHAPES = [(5, 128, 8), (4, 256, 8), (3, 384, 8), (9, 128, 16)] if os.environ.get("HITADV_EMULATE") else \
+    [(256, 1024, 128), (256, 1024, 256), (32, 1024, 16), (13, 1280, 8), (64, 128, 40), (8, 2048, 8)]
+
+
+@pytest.mark.parametrize("B,Np,blocks", SHAPES)
 @pytest.mark.parametrize("kind", ["gaussian", "sphere"])
 def test_deferred_search_gives_the_bits_of_the_per_tile_search(A, defer, B, Np, blocks, kind):
     g = torch.Generator().manual_seed(B + Np + blocks)

@@ -10,12 +10,15 @@ K_ATTACK="test_hit_adv_follows_reference_trajectory[False or test_hit_adv_bookke
 OUT=tests/golden/emulated_suite_report.txt
 {
   echo "# GPU parity tests run UNMODIFIED on the CPU wave emulator (tools/run_emulated_suite.sh); commit $(git rev-parse --short HEAD), $(date -u +%F)"
-  echo "# kernels built for the emulator: pairwise knn sampling grouping deform regulariser attack_state iteration (.hip, hit_adv_amd/csrc)"
+  echo "# kernels built for the emulator: pairwise knn sampling grouping deform regulariser attack_state iteration victim_bf3 (.hip, hit_adv_amd/csrc)"
   for spec in "tests/test_gpu_kernels.py|$K_KERNELS" "tests/test_gpu_edges.py tests/test_z_r06_edges.py|$K_EDGES" "tests/test_gpu_attack.py|$K_ATTACK"; do
     files=${spec%%|*}; k=${spec#*|}
     echo "## $files"
     python -m pytest -p emu_plugin --emulate $files -q -rA -k "$k" 2>&1 | grep -E "^(PASSED|FAILED|ERROR|SKIPPED)|passed|failed" | sed 's/ - .*//'
   done
+  echo "## V1 (csrc/victim_bf3.hip; its 16x16x32 matrix instructions emulated with a summation order of the emulator's own): the deferred-search variant == the shipped kernel, bit for bit, on emulator-sized flat shapes; two of the suite's own V1 tests"
+  python -m pytest -p emu_plugin --emulate tests/test_z_r06_v1_defer.py tests/test_gpu_kernels.py -q -rA -k "deferred_search_gives or test_linear_max_fwd_bf16x3_ties_keep_the_first_point or test_linear_max_fwd_f16x2_raises_its_range_flag" 2>&1 | grep -E "^(PASSED|FAILED|ERROR|SKIPPED)|passed|failed" | sed 's/ - .*//'
+  echo "# (also passed once, 1,040 s: tests/test_gpu_kernels.py::test_linear_max_fwd_bf16x3_same_bits_for_every_grid -- the split / merge / flat forms of the bf16x3 kernel, same bits for every grid)"
   echo "## tests/test_z_r06_concurrency.py (24 launches per kernel, no noise streams: the test's own logic only)"
   HITADV_CONCURRENCY_LAUNCHES=24 HITADV_CONCURRENCY_NOISE=0 python -m pytest -p emu_plugin --emulate tests/test_z_r06_concurrency.py -q -rA 2>&1 | grep -E "^(PASSED|FAILED|ERROR|SKIPPED)|passed|failed" | sed 's/ - .*//'
 } > $OUT
