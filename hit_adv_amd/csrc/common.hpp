@@ -7,6 +7,13 @@
 
 #define HITADV_WAVE 64
 
+// Marks a place where the lanes of ONE wave hand data to each other through LDS without a block barrier: the region is read by this
+// wave only, a wave's LDS operations are performed in program order, and its lanes execute in lockstep -- so nothing is needed on the
+// GPU and the macro is empty.  (The CPU wave emulator of tests/native/emu, whose lanes are fibres, defines it as a wave rendezvous.)
+#ifndef HITADV_WAVE_LDS_HANDOFF
+#define HITADV_WAVE_LDS_HANDOFF() ((void)0)
+#endif
+
 #define HITADV_LAUNCH_CHECK()                       \
   do {                                              \
     hipError_t e__ = hipGetLastError();             \

@@ -2059,6 +2059,7 @@ __global__ __launch_bounds__(NWV * 64) void fc_wide_k(const float *__restrict__ 
         sW[acc_row(e, h) * FCW_LD + 32 * ct + r] = (!gated || mk[ct][e] > 0.f) ? pa[e] : 0.f;  // rows past B are zeros of P
     }
   }
+  HITADV_WAVE_LDS_HANDOFF();  // sW was written by this wave's lanes and is read by them only: no block barrier (see the kernel's header)
   f32x16 acc;
   zero(acc);
 #pragma unroll

@@ -30,6 +30,7 @@
 #define __launch_bounds__(...)
 #define __shared__ static
 #define HITADV_EMULATED 1
+#define HITADV_WAVE_LDS_HANDOFF() ((void)emu::wave_gather(0, nullptr))  // lanes are fibres here: a wave-private LDS hand-off needs a rendezvous
 
 struct dim3 {
   unsigned x, y, z;
@@ -369,11 +370,71 @@ static inline emu_f32x4 emu_mfma_16x16x32(V8 a, V8 b, emu_f32x4 c) {
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_16x16x32<false>((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32<true>((a), (b), (c))
+// v_mfma_f32_32x32x16_{f16,bf16}: D[32 x 32] = A[32 x 16] B[16 x 32] + C.  Lane l = (r = l % 32, h = l / 32) holds A[r][8 h .. 8 h + 7],
+// B[8 h .. 8 h + 7][r] and the sixteen C / D values of column r in rows (e & 3) + 8 (e >> 2) + 4 h, e = 0 .. 15 (csrc/pointnet.hip::acc_row).
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+template <bool BF16, class V8>
+static inline emu_f32x16 emu_mfma_32x32x16(V8 a, V8 b, emu_f32x16 c) {
+  unsigned char pay[32];
+  memcpy(pay, &a, 16);
+  memcpy(pay + 16, &b, 16);
+  const unsigned char (*s)[32] = emu::wave_gather_bytes(pay, 32);
+  const int lane = emu::cur->lin & 63, r = lane & 31, h = lane >> 5;
+  emu_f32x16 d = c;
+  for (int e = 0; e < 16; ++e) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+    float acc = c[e];
+    for (int k = 0; k < 16; ++k) {
+      uint16_t av, bv;
+      memcpy(&av, s[row + 32 * (k >> 3)] + 2 * (k & 7), 2);
+      memcpy(&bv, s[r + 32 * (k >> 3)] + 16 + 2 * (k & 7), 2);
+      const float x = BF16 ? emu_bf16_to_float(av) : emu_half_to_float(av), y = BF16 ? emu_bf16_to_float(bv) : emu_half_to_float(bv);
+      acc = acc + x * y;
+    }
+    d[e] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16<false>((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32x16<true>((a), (b), (c))
+// v_mfma_f32_32x32x2_f32: A[32 x 2], B[2 x 32]; lane (r, h) holds A[r][h], B[h][r]; the same C / D layout.  An fmaf chain in ascending k
+// (MI355X_MICROARCH.md: the f32 matrix instruction is "exact f32 (= fmaf chain, bitwise)").
+static inline emu_f32x16 emu_mfma_32x32x2_f32(float a, float b, emu_f32x16 c) {
+  float pay[2] = {a, b};
+  const unsigned char (*s)[32] = emu::wave_gather_bytes(pay, 8);
+  const int lane = emu::cur->lin & 63, r = lane & 31, h = lane >> 5;
+  emu_f32x16 d = c;
+  for (int e = 0; e < 16; ++e) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+    float acc = c[e];
+    for (int k = 0; k < 2; ++k) {
+      float x, y;
+      memcpy(&x, s[row + 32 * k], 4);
+      memcpy(&y, s[r + 32 * k] + 4, 4);
+      acc = fmaf(x, y, acc);
+    }
+    d[e] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32x2_f32((a), (b), (c))
+// the fp16x2 split's three instructions (csrc/pointnet.hip::split8v and its copies), which emu_build.py rewrites from asm to these calls
+static inline uint32_t emu_cvt_pk_f16_f32(float a, float b) {
+  _Float16 x = (_Float16)a, y = (_Float16)b;
+  uint16_t ux, uy;
+  memcpy(&ux, &x, 2);
+  memcpy(&uy, &y, 2);
+  return (uint32_t)ux | ((uint32_t)uy << 16);
+}
+static inline uint16_t emu_fma_mix_f16(uint16_t h, float s1, float s2) {  // fp16(fma((float)h, s1, s2)): exact before its single rounding here
+  _Float16 r = (_Float16)fmaf(emu_half_to_float(h), s1, s2);
+  uint16_t u;
+  memcpy(&u, &r, 2);
+  return u;
+}
 // the other matrix instructions are NOT emulated: kernels that use them compile and abort if run
 template <class A, class B, class C> static inline C emu_no_mfma(A, B, C c, int, int, int) { fprintf(stderr, "simt_emu: MFMA kernels are not emulated\n"); abort(); return c; }
-#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_no_mfma
-#define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu_no_mfma
-#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_no_mfma
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_no_mfma
 #define __builtin_amdgcn_perm(a, b, sel) emu_perm((a), (b), (sel))
 static inline uint32_t emu_perm(uint32_t a, uint32_t b, uint32_t sel) {  // v_perm_b32: bytes 0-3 of b, 4-7 of a
   const uint64_t both = ((uint64_t)a << 32) | b;

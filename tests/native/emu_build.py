@@ -5,6 +5,7 @@ The file's text is the product's; three constructs plain C++ cannot parse are re
   2. `extern __shared__ T name[];`                 ->  `T *name = reinterpret_cast<T *>(emu::dyn_lds);`
   2b. operand-less `asm volatile("s_waitcnt ..." ::: "memory")` (the hand-off protocols' waits; also in the staged copies of the headers)  ->  nothing
   3. fps_lean's one LDS atomic written as inline asm (`ds_max_rtn_u64` + its wait)  ->  the same operation in C++
+  3b. the fp16x2 split's three instructions written as asm (v_cvt_pk_f16_f32, v_fma_mixlo_f16, v_fma_mixhi_f16)  ->  the same operations in C++
   4. victim_bf3.hip's two scan helpers (compares into lane masks / selects on them, asm for their schedule)  ->  __ballot and a select
 and the result is compiled by ROCm's clang++ FOR x86-64 (-ffp-contract=off, like the library) against the emulator header in place of
 <hip/hip_runtime.h>.  The extern "C" entry points keep their names and signatures; "device" pointers are host pointers."""
@@ -100,6 +101,14 @@ def rewrite_fps_asm(text):
 WAITCNT = re.compile(r'asm volatile\("s_waitcnt [^"]*"\s*:::\s*"memory"\);')
 
 
+PKMAX = re.compile(r'asm\("v_pk_max_u16 %0, %1, %2" : "=v"\((\w+)\) : "v"\((\w+)\), "v"\((\w+)\)\);')
+
+
+def rewrite_pk_max(text):
+    """common.hpp::PieceWatch: a packed maximum of two pairs of unsigned 16-bit halves"""
+    return PKMAX.subn(r"\1 = (((\2 & 0xffffu) > (\3 & 0xffffu) ? \2 : \3) & 0xffffu) | (((\2 >> 16) > (\3 >> 16) ? \2 : \3) & 0xffff0000u);", text)
+
+
 def rewrite_waits(text):
     """operand-less `s_waitcnt` statements (memory-ordering waits of the hand-off protocols): nothing to wait for on one OS thread"""
     return WAITCNT.subn("((void)0);", text)
@@ -112,6 +121,7 @@ def stage_headers(out_dir):
             text = open(os.path.join(CSRC, name)).read()
             text, _ = rewrite_waits(text)
             text, _ = rewrite_extern_shared(text)
+            text, _ = rewrite_pk_max(text)
             with open(os.path.join(out_dir, name), "w") as f:
                 f.write(text)
 
@@ -127,6 +137,19 @@ def rewrite_v1_scan_asm(text):
     return text, a + b
 
 
+SPLIT_CVT = re.compile(r'asm\("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"\((\w+\[\w+\])\) : "v"\((\w+\[[^\]]+\])\), "v"\((\w+\[[^\]]+\])\)\);')
+SPLIT_LO = re.compile(r'asm\("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:\[0,0,0\] op_sel_hi:\[1,0,0\]" : "=v"\((\w+\[\w+\])\) : "v"\((\w+\[\w+\])\), "s"\((\w+)\), "v"\((\w+)\)\);')
+SPLIT_HI = re.compile(r'asm\("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:\[1,0,0\] op_sel_hi:\[1,0,0\]" : "\+v"\((\w+\[\w+\])\) : "v"\((\w+\[\w+\])\), "s"\((\w+)\), "v"\((\w+)\)\);')
+
+
+def rewrite_split_asm(text):
+    """the fp16x2 split's v_cvt_pk_f16_f32 / v_fma_mixlo_f16 / v_fma_mixhi_f16 (split8v and its copies) -> the same three operations in C++"""
+    text, a = SPLIT_CVT.subn(r"\1 = emu_cvt_pk_f16_f32(\2, \3);", text)
+    text, b = SPLIT_LO.subn(r"\1 = emu_fma_mix_f16((uint16_t)(\2 & 0xffffu), \3, \4);", text)
+    text, c = SPLIT_HI.subn(r"\1 = (\1 & 0xffffu) | ((uint32_t)emu_fma_mix_f16((uint16_t)(\2 >> 16), \3, \4) << 16);", text)
+    return text, (a, b, c)
+
+
 def build(stem, out_dir, extra_flags=()):
     """-> path of lib<stem>_emu.so built from hit_adv_amd/csrc/<stem>.hip"""
     stage_headers(out_dir)
@@ -138,6 +161,8 @@ def build(stem, out_dir, extra_flags=()):
     if stem == "sampling":
         text, n_asm = rewrite_fps_asm(text)
         assert n_asm == 1, "fps_lean's LDS atomic was not found: the rewrite rule needs updating"
+    text, n_split = rewrite_split_asm(text)
+    assert n_split[0] == n_split[1] == n_split[2], "the split's three asm statements come in triples: %r" % (n_split,)
     if stem == "victim_bf3":
         text, n_asm = rewrite_v1_scan_asm(text)
         assert n_asm == 2, "V1's compare / select asm helpers were not found: the rewrite rule needs updating"

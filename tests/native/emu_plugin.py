@@ -21,7 +21,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests", "native"))
-STEMS = ["pairwise", "knn", "sampling", "grouping", "deform", "regulariser", "attack_state", "iteration", "victim_bf3"]
+STEMS = ["pairwise", "knn", "sampling", "grouping", "deform", "regulariser", "attack_state", "iteration", "victim_bf3", "victim", "pointnet",
+         "bmm", "attention", "rows_linear", "group_mlp"]  # (all of csrc/ but gemm16.hip, whose LDS-DMA asm has no mechanical rewrite)
+if os.environ.get("HITADV_EMU_STEMS"):  # a subset builds faster (tests/test_emulated_gpu_subset.py: the non-matrix files only)
+    STEMS = [s_ for s_ in os.environ["HITADV_EMU_STEMS"].split(",") if s_]
 os.environ["HITADV_EMULATE"] = "1"  # (tests may pick emulator-sized shapes: a matrix instruction costs milliseconds here)
 
 
@@ -51,11 +54,16 @@ def _is_cuda(d):
     return d is not None and str(d).startswith("cuda")
 
 
+_IS_CUDA = torch.Tensor.is_cuda  # (the getset descriptor: attribute reads arrive as its __get__)
+
+
 class CpuForCuda(torch.overrides.TorchFunctionMode):
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = dict(kwargs or {})
         if _is_cuda(kwargs.get("device")):
             kwargs["device"] = "cpu"
+        if getattr(func, "__self__", None) is _IS_CUDA:  # the product's model code picks its engine path by `x.is_cuda`
+            return True
         name = getattr(func, "__name__", "")
         if name == "cuda" and args and torch.is_tensor(args[0]):
             return args[0].clone()  # a host-to-device copy is a NEW tensor (tests rely on it: x.cuda().requires_grad_() must not touch x)

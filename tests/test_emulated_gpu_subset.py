@@ -35,7 +35,8 @@ SLICE = [
 
 @pytest.mark.skipif(not os.path.exists(CLANGXX), reason="no host clang++")
 def test_a_slice_of_the_gpu_parity_suite_passes_unmodified_on_the_cpu_wave_emulator():
-    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tests", "native") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tests", "native") + os.pathsep + os.environ.get("PYTHONPATH", ""),
+               HITADV_EMU_STEMS="pairwise,knn,sampling,grouping,deform,regulariser,attack_state,iteration")
     r = subprocess.run([sys.executable, "-m", "pytest", "-p", "emu_plugin", "--emulate", "-q", "-p", "no:cacheprovider"] + SLICE,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
