@@ -342,7 +342,9 @@ static inline void __builtin_amdgcn_s_barrier() { emu::barrier(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 // v_mfma_f32_16x16x32_{f16,bf16}: D[16 x 16] = A[16 x 32] B[32 x 16] + C.  Lane l holds A[l % 16][8 (l / 16) .. + 7], B[8 (l / 16) .. + 7][l % 16]
 // and C / D[4 (l / 16) + i][l % 16], i = 0 .. 3 (the layout csrc/victim_bf3.hip's comments state).  Every product of two 16-bit values is
-// exact in fp32; they are added to C in ascending k, one fp32 rounding each -- A model: the hardware's internal order is its own, so
+// exact; the model here: the instruction's products and C are summed exactly (in double: 32 products of 22-bit significands) and rounded
+// ONCE to fp32 -- what a matrix unit with a wide internal accumulator does, and what keeps a K = 1024 chain as accurate as the hardware's
+// (a first model that rounded after every product lost to a blocked CPU GEMM by 30 %).  The hardware's own internal order is unknown, so
 // results are fp32-accurate, not the hardware's bits.  Equality tests BETWEEN kernels that issue the same instructions are unaffected.
 typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
 static inline float emu_half_to_float(uint16_t h) { _Float16 v; memcpy(&v, &h, 2); return (float)v; }
@@ -356,15 +358,15 @@ static inline emu_f32x4 emu_mfma_16x16x32(V8 a, V8 b, emu_f32x4 c) {
   const int lane = emu::cur->lin & 63, n = lane & 15, m0 = 4 * (lane >> 4);
   emu_f32x4 d = c;
   for (int i = 0; i < 4; ++i) {
-    float acc = c[i];
+    double acc = (double)c[i];  // the instruction's 32 exact products and C meet in one sum, rounded ONCE to fp32 (see the comment above)
     for (int k = 0; k < 32; ++k) {
       uint16_t av, bv;
       memcpy(&av, s[(m0 + i) + 16 * (k >> 3)] + 2 * (k & 7), 2);
       memcpy(&bv, s[n + 16 * (k >> 3)] + 16 + 2 * (k & 7), 2);
       const float x = BF16 ? emu_bf16_to_float(av) : emu_half_to_float(av), y = BF16 ? emu_bf16_to_float(bv) : emu_half_to_float(bv);
-      acc = acc + x * y;
+      acc += (double)x * (double)y;
     }
-    d[i] = acc;
+    d[i] = (float)acc;
   }
   return d;
 }
@@ -383,15 +385,15 @@ static inline emu_f32x16 emu_mfma_32x32x16(V8 a, V8 b, emu_f32x16 c) {
   emu_f32x16 d = c;
   for (int e = 0; e < 16; ++e) {
     const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-    float acc = c[e];
+    double acc = (double)c[e];
     for (int k = 0; k < 16; ++k) {
       uint16_t av, bv;
       memcpy(&av, s[row + 32 * (k >> 3)] + 2 * (k & 7), 2);
       memcpy(&bv, s[r + 32 * (k >> 3)] + 16 + 2 * (k & 7), 2);
       const float x = BF16 ? emu_bf16_to_float(av) : emu_half_to_float(av), y = BF16 ? emu_bf16_to_float(bv) : emu_half_to_float(bv);
-      acc = acc + x * y;
+      acc += (double)x * (double)y;
     }
-    d[e] = acc;
+    d[e] = (float)acc;
   }
   return d;
 }

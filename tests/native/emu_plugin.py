@@ -22,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests", "native"))
 STEMS = ["pairwise", "knn", "sampling", "grouping", "deform", "regulariser", "attack_state", "iteration", "victim_bf3", "victim", "pointnet",
-         "bmm", "attention", "rows_linear", "group_mlp"]  # (all of csrc/ but gemm16.hip, whose LDS-DMA asm has no mechanical rewrite)
+         "bmm", "attention", "rows_linear", "group_mlp", "gemm16"]  # (all of csrc/; gemm16's LDS-DMA ring kernel is switched off below)
 if os.environ.get("HITADV_EMU_STEMS"):  # a subset builds faster (tests/test_emulated_gpu_subset.py: the non-matrix files only)
     STEMS = [s_ for s_ in os.environ["HITADV_EMU_STEMS"].split(",") if s_]
 os.environ["HITADV_EMULATE"] = "1"  # (tests may pick emulator-sized shapes: a matrix instruction costs milliseconds here)
@@ -92,6 +92,8 @@ def pytest_configure(config):
     libs = [ctypes.CDLL(emu_build.build(s, out)) for s in STEMS]
     emu = EmuLib(libs, _lib.PROTOTYPES, _lib._RESTYPE)
     _lib._lib = emu
+    if "gemm16" in STEMS:
+        emu.hitadv_debug_g16_ring(0)  # the staged G16 kernel only: the ring kernel's LDS-DMA is not emulated
     _lib.load = lambda: emu
 
     def dev(t, name, dtype=torch.float32):
