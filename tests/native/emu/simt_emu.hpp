@@ -192,11 +192,28 @@ inline void launch(dim3 grid, dim3 block, size_t shm, std::function<void()> body
           t.ctx.uc_link = &sched_ctx;
           makecontext(&t.ctx, (void (*)())trampoline, 0);
         }
+        // the order in which the scheduler visits the fibres.  The hardware promises NO order between waves, so results must not depend
+        // on it: HITADV_EMU_SCHEDULE=desc runs the waves of a block last-to-first, =random:<seed> in a shuffled order that changes every
+        // round (lanes inside a wave stay ascending: a wave is in lockstep on the GPU).  A kernel that passes ascending and fails otherwise
+        // has a missing barrier between waves -- a race the GPU's timing may be hiding (tests/test_emulated_kernels.py runs all three).
+        static const char *sched_env = getenv("HITADV_EMU_SCHEDULE");
+        const int nw = (nthreads + 63) / 64;
+        std::vector<int> worder(nw);
+        for (int w = 0; w < nw; ++w) worder[w] = sched_env && sched_env[0] == 'd' ? nw - 1 - w : w;
+        unsigned rng = sched_env && sched_env[0] == 'r' ? (unsigned)atoi(sched_env + (strchr(sched_env, ':') ? strchr(sched_env, ':') - sched_env + 1 : 0)) * 2654435761u + 12345u + bx * 97u + by * 31u : 0u;
         int left = nthreads;
         while (left > 0) {
           const unsigned long before = progress;
           int ran = 0;
-          for (int i = 0; i < nthreads; ++i) {
+          if (rng) {
+            for (int w = nw - 1; w > 0; --w) {
+              rng = rng * 1664525u + 1013904223u;
+              std::swap(worder[w], worder[(rng >> 8) % (unsigned)(w + 1)]);
+            }
+          }
+          for (int oi = 0; oi < nthreads; ++oi) {
+            const int i = worder[oi >> 6] * 64 + (oi & 63);
+            if (i >= nthreads) continue;
             Thread &t = b.threads[i];
             if (t.done) continue;
             cur = &t;
