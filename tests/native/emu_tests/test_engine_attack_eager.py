@@ -7,6 +7,7 @@ MI355X), the same success count."""
 import contextlib
 import copy
 import io
+import os
 
 import numpy as np
 import pytest
@@ -15,7 +16,7 @@ import torch
 from helpers import synth_batch
 from oracle import hitadv_oracle as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("HITADV_EMULATE") != "1", reason="emulator-only: on a GPU the suite's own tests cover this")]
 
 
 def test_hit_adv_with_the_pointnet_engine_eager_follows_the_cpu_oracle():
